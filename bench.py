@@ -1,0 +1,229 @@
+#!/usr/bin/env python3
+"""bench.py -- the reference's headline benchmark on MI355X.
+
+Metric (BASELINE.json): images/sec, LeMeViT-Base 224^2 bf16 fwd+bwd.  One "step" reproduces
+benchmark.py's TrainBenchmarkRunner step (benchmark.py:572-596): zero_grad -> autocast(bf16){forward ->
+CrossEntropyLoss(randint targets) -> backward} -> AdamW.step, on ONE synthetic batch created once
+(benchmark.py:462-467), B = 128 per GPU, drop_path 0.1 (scripts/benchmark.sh:9), random-init weights.
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+One process per GPU; N > 1 shards images over ranks (weak scaling, 128 images per GPU) with gradients
+all-reduced by RCCL (torch DDP, bf16-compressed buckets).  Rank 0 prints ONE JSON line.
+
+`roofline` is measured live for the dominant kernel -- the bf16 MFMA GEMM of the Linear layers
+(gemm_kernel<bf16, NT>, forward launches) -- with HIP events on the launch stream inside the timed region:
+algorithmic FLOPs of those launches / their summed duration, against the 2.5 PFLOP/s dense bf16 MFMA peak.
+`cpu_baseline` times the CPU oracle (oracle/, a port of the reference) on a bounded sample of the same workload.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_BF16_TFLOPS = 2500.0          # dense bf16 MFMA, MI355X_MICROARCH.md
+CANONICAL_GFLOP_FWD = 22.12        # README/BASELINE: 11.06 GMAC forward per image (Base 224^2)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--model", default="lemevit_base")
+    ap.add_argument("--batch", type=int, default=128, help="images per GPU")
+    ap.add_argument("--img", type=int, default=224)
+    ap.add_argument("--mode", default="train", choices=["train", "infer"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-timing", action="store_true")
+    return ap.parse_args()
+
+
+class GemmTimer:
+    """Brackets every forward Linear launch (lemevit_amd.ops.linear_fwd) with HIP events on the launch stream."""
+
+    def __init__(self):
+        self.events, self.flops, self.enabled = [], [], False
+
+    def install(self):
+        from lemevit_amd import ops
+        orig = ops.linear_fwd
+        timer = self
+
+        def timed(probs, N, K, act=0):
+            if not timer.enabled:
+                return orig(probs, N, K, act)
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record()
+            orig(probs, N, K, act)
+            e.record()
+            timer.events.append((s, e))
+            timer.flops.append(2.0 * N * K * sum(p.rows for p in probs))
+
+        ops.linear_fwd = timed
+        import lemevit_amd.blocks as blocks
+        import lemevit_amd.model as model
+        blocks.ops.linear_fwd = timed
+        model.ops.linear_fwd = timed
+
+    def summary(self):
+        if not self.events:
+            return None
+        ms = sum(s.elapsed_time(e) for s, e in self.events)
+        fl = sum(self.flops)
+        return dict(launches=len(self.events), total_ms=ms, avg_us=1e3 * ms / len(self.events), tflops=fl / (ms * 1e-3) / 1e12,
+                    gflop_per_launch=fl / len(self.events) / 1e9)
+
+
+def cpu_baseline(model_name: str, img: int, mode: str):
+    """Oracle (port of the reference) on the host cores, bounded to ~10-30 s."""
+    from oracle import lemevit_oracle as O
+    cfg = O.VARIANTS[model_name]
+    torch.manual_seed(0)
+    spec = O.state_dict_spec(cfg, 1000)
+    sd = {}
+    for k, shp in spec.items():
+        if k.endswith("num_batches_tracked"):
+            sd[k] = torch.zeros((), dtype=torch.int64)
+        elif k.endswith("running_var"):
+            sd[k] = torch.ones(shp)
+        elif len(shp) >= 2:
+            sd[k] = torch.randn(shp) * 0.02
+        elif k.endswith(".weight"):
+            sd[k] = torch.ones(shp)
+        else:
+            sd[k] = torch.zeros(shp)
+    train = mode == "train"
+    if train:
+        for k, v in sd.items():
+            if v.dtype.is_floating_point and not k.endswith(("running_mean", "running_var")):
+                v.requires_grad_(True)
+    B = 4
+    x = torch.randn(B, 3, img, img)
+    tgt = torch.randint(0, 1000, (B,))
+
+    def step():
+        if train:
+            loss = torch.nn.functional.cross_entropy(O.lemevit_forward(sd, cfg, x, train=True), tgt)
+            loss.backward()
+            for v in sd.values():
+                v.grad = None
+        else:
+            with torch.no_grad():
+                O.lemevit_forward(sd, cfg, x)
+
+    step()                                        # warm-up
+    t0, n = time.perf_counter(), 0
+    while True:
+        step(); n += 1
+        if time.perf_counter() - t0 > 12.0 or n >= 8:
+            break
+    dt = time.perf_counter() - t0
+    return dict(value=round(B * n / dt, 3), unit="images/sec", cores=torch.get_num_threads(), kind="port",
+                sample=f"{n} {'fwd+bwd' if train else 'fwd'} steps of {model_name} {img}x{img} fp32 at batch {B} (oracle/lemevit_oracle.py, PyTorch CPU)")
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+
+    import lemevit_amd
+    from lemevit_amd.dist import wrap_ddp
+
+    torch.manual_seed(0)
+    train = args.mode == "train"
+    model = lemevit_amd.create_model(args.model, num_classes=1000, drop_path_rate=0.1 if train else 0.0).to(dev)
+    model.train(train)
+    x = torch.randn(args.batch, 3, args.img, args.img, device=dev)
+    loss_fn = torch.nn.CrossEntropyLoss().to(dev)
+    timer = GemmTimer()
+    if rank == 0 and not args.no_kernel_timing:
+        timer.install()
+    if train:
+        # benchmark.py:559-561 create_optimizer_v2(opt='adamw', lr=1e-4), scripts/benchmark.sh:8 eps 1e-8 wd 0.05
+        decay = [p for n, p in model.named_parameters() if p.ndim > 1]
+        no_decay = [p for n, p in model.named_parameters() if p.ndim <= 1]
+        opt = torch.optim.AdamW([dict(params=decay, weight_decay=0.05), dict(params=no_decay, weight_decay=0.0)], lr=1e-4, eps=1e-8, fused=True)
+        net = wrap_ddp(model, local) if world > 1 else model
+
+        def step():
+            opt.zero_grad(set_to_none=True)
+            with torch.autocast("cuda", torch.bfloat16):
+                out = net(x)
+                target = torch.empty((args.batch,), device=dev, dtype=torch.long).random_(1000)
+                loss_fn(out, target).backward()
+            opt.step()
+    else:
+        def step():
+            with torch.no_grad(), torch.autocast("cuda", torch.bfloat16):
+                model(x)
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    sync()
+    timer.enabled = True
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    sync()
+    dt = time.perf_counter() - t0
+    timer.enabled = False
+    tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax.item())
+
+    if rank == 0:
+        imgs = args.batch * world * args.steps
+        value = imgs / dt
+        mult = 3.0 if train else 1.0
+        g = timer.summary()
+        roof = None
+        if g is not None:
+            roof = dict(bound="mfma", achieved=round(g["tflops"], 2), peak=PEAK_BF16_TFLOPS, unit="TFLOP/s", frac=round(g["tflops"] / PEAK_BF16_TFLOPS, 4),
+                        traffic=None, kernel="gemm_kernel<bf16,NT> (Linear forward)", launches=g["launches"], avg_launch_us=round(g["avg_us"], 2),
+                        gflop_per_launch=round(g["gflop_per_launch"], 3))
+        line = {
+            "metric": "images/sec LeMeViT-Base 224^2 bf16 fwd+bwd" if train else "images/sec LeMeViT-Base 224^2 bf16 fwd",
+            "value": round(value, 2), "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(1e3 * dt / args.steps, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": f"{args.model} {args.img}x{args.img} bf16-autocast {'train step (fwd+bwd+AdamW)' if train else 'forward'}, "
+                                   f"batch {args.batch}/GPU, drop_path 0.1, random-init weights", "global_batch": args.batch * world,
+                       "parallelism": f"dp{world}"},
+            "model_tflops": round(value * CANONICAL_GFLOP_FWD * mult / 1e3, 2),
+            "model_frac_of_bf16_peak": round(value * CANONICAL_GFLOP_FWD * mult / 1e3 / (PEAK_BF16_TFLOPS * world), 4),
+            "roofline": roof,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(args.model, args.img, args.mode)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

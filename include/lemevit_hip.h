@@ -1,0 +1,149 @@
+/* lemevit_hip.h -- C ABI of liblemevit_hip.so, the MI355X (gfx950) kernels behind the LeMeViT
+ * backbone hot path.
+ *
+ * The reference (ViTAE-Transformer/LeMeViT) has no FFI: its hot path is PyTorch calls inside
+ * models/lemevit.py, dispatched through the attention-backend seam at models/lemevit.py:32-52.
+ * Each entry point below replaces the torch calls of the cited reference lines; the Python
+ * binding a maintainer would add is shown in INTEGRATION.md (ctypes, as lemevit_amd/_lib.py).
+ *
+ * Conventions
+ *   - plain pointers and sizes only; every pointer is DEVICE memory owned by the caller
+ *     (PyTorch's caching allocator) and must stay alive until `stream` reaches the kernel;
+ *   - tensors are contiguous row-major, token-major [B, L, C]; 16-byte aligned;
+ *   - dtype: LMV_F32 = 0, LMV_BF16 = 1 (activations and matrix weights); vectors (bias, LayerNorm
+ *     affine, statistics, DropPath scales) and gradient accumulators are always fp32;
+ *   - `stream` is a hipStream_t passed as void*; kernels are enqueued, never synchronised;
+ *   - return 0 on success, else LMV_ERR_* (message via lmv_last_error()); nothing throws;
+ *   - stateless and re-entrant; the device is whatever the caller made current.
+ */
+#ifndef LEMEVIT_HIP_H
+#define LEMEVIT_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LMV_ABI_VERSION 1
+
+enum { LMV_F32 = 0, LMV_BF16 = 1 };
+enum {
+  LMV_OK = 0,
+  LMV_ERR_SHAPE = -1,      /* bad shape / alignment */
+  LMV_ERR_DTYPE = -2,      /* unsupported dtype / arch */
+  LMV_ERR_WORKSPACE = -3,  /* workspace too small */
+  LMV_ERR_LAUNCH = -4      /* HIP launch error (hipGetLastError) */
+};
+
+int lmv_abi_version(void);
+const char* lmv_last_error(void);
+
+/* ------------------------------------------------------------------------------------------
+ * Linear layers (nn.Linear calls of models/lemevit.py:200,205,289,291,299,302,478-479,486 and
+ * the MLP :526-530).  One launch runs up to two independent "problems" that share N and K (the
+ * image-token matrix and the meta-token matrix of a block share LN/MLP -- and in S-blocks
+ * attention -- weights, :560-564,:632-635).
+ *
+ *   fwd : out[r, n] = res[r, n] + row_scale[r / rows_per_sample] * act(sum_k a[r,k] w[n,k] + bias[n])
+ *   dx  : out[r, k] = (sum_n a[r,n] w[n,k]) (* gelu'(aux[r,k]) if act == LMV_ACT_GELU_GRAD)
+ *   dw  : dw[n, k] += sum_r dy[r,n] x[r,k] ;  db[n] += sum_r dy[r,n]      (fp32, atomic)
+ * ------------------------------------------------------------------------------------------ */
+enum { LMV_ACT_NONE = 0, LMV_ACT_GELU = 1, LMV_ACT_GELU_GRAD = 2 };
+
+typedef struct {
+  const void* a;           /* fwd: x [rows, K]; dx: dy [rows, N]; dw: dy [rows, N]            */
+  const void* w;           /* fwd/dx: weight [N, K];               dw: x  [rows, K]            */
+  const float* bias;       /* fwd: [N] or NULL                                                  */
+  const void* res;         /* fwd: residual [rows, N] or NULL (dx: [rows, K] added to out)      */
+  const float* row_scale;  /* per-sample DropPath scale [rows / rows_per_sample] or NULL        */
+  const void* aux;         /* dx with GELU_GRAD: pre-activation u [rows, K]                     */
+  void* out;               /* fwd: [rows, N]; dx: [rows, K]; dw: fp32 dW [N, K] (accumulated)   */
+  void* out_pre;           /* fwd: optional copy of the pre-activation (training) or NULL       */
+  float* bias_grad;        /* dw: fp32 db [N] (accumulated) or NULL                             */
+  int64_t rows;
+  int32_t rows_per_sample; /* tokens per image for row_scale (ignored when row_scale == NULL)   */
+  int32_t _pad;
+} lmv_linear_problem;
+
+int lmv_linear_fwd(const lmv_linear_problem* p, int nproblems, int N, int K, int act, int dtype, void* stream);
+int lmv_linear_dx(const lmv_linear_problem* p, int nproblems, int N, int K, int act, int dtype, void* stream);
+int lmv_linear_dw(const lmv_linear_problem* p, int nproblems, int N, int K, int dtype, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * LayerNorm over the last dim (nn.LayerNorm, models/lemevit.py:513,525 eps 1e-6; :731-743,774
+ * eps 1e-5).  stats = [rows, 2] fp32 (mean, rstd), written by fwd when non-NULL.
+ *   bwd: dx = dres + LN'(dy)   (dres may be NULL);  dgamma/dbeta are ACCUMULATED (fp32 atomics).
+ * ------------------------------------------------------------------------------------------ */
+int lmv_layernorm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* stats,
+                      int64_t rows, int C, float eps, int dtype, void* stream);
+int lmv_layernorm_bwd(const void* dy, const void* x, const float* stats, const float* gamma, const void* dres,
+                      void* dx, float* dgamma, float* dbeta, int64_t rows, int C, int dtype, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Conditional position embedding: y = x + dwconv3x3(x) + bias, NHWC (models/lemevit.py:510,546).
+ * weight is the reference's [C, 1, 3, 3] fp32 tensor.
+ *   bwd_data  : dx = dy + dwconv3x3^T(dy)
+ *   bwd_weight: dw[C,1,3,3] += ..., db[C] += ...     (fp32 atomics)
+ * ------------------------------------------------------------------------------------------ */
+int lmv_dwconv3x3_residual_fwd(const void* x, const float* weight, const float* bias, void* y,
+                               int B, int H, int W, int C, int dtype, void* stream);
+int lmv_dwconv3x3_residual_bwd_data(const void* dy, const float* weight, void* dx,
+                                    int B, int H, int W, int C, int dtype, void* stream);
+int lmv_dwconv3x3_bwd_weight(const void* dy, const void* x, float* dweight, float* dbias,
+                             int B, int H, int W, int C, int dtype, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Attention cores, head dim 32 (all registered variants, models/lemevit.py:851,881,911).
+ * q/k/v/o are addressed as  ptr + b * batch_stride + l * row_stride + head * 32  (strides in
+ * ELEMENTS), so the packed projections of the reference (qkv [B,L,3C] :200-202, kv [B,N,2C]
+ * :479-482) are consumed in place -- no 'x B h N d' re-pack (:201,290,292,481).
+ *   o[b,l,h,:] = softmax_j(scale * q[b,l,h,:] . k[b,j,h,:]) v[b,j,h,:]       (:54-63)
+ *   lse[b,h,l] = log sum_j exp(scale * q.k)   (fp32, kept for the backward pass)
+ * Lq <= 16 (meta-token queries over image-token keys, :300,:484) takes the split-key path and
+ * needs `workspace` (lmv_attn_workspace_bytes).
+ * ------------------------------------------------------------------------------------------ */
+typedef struct {
+  const void* q; const void* k; const void* v;  /* inputs                                       */
+  void* o;                                      /* fwd: output; bwd: the saved forward output    */
+  float* lse;                                   /* [B, H, Lq] fp32                               */
+  const void* d_o;                              /* bwd: grad of o (strides of o)                 */
+  void* dq; void* dk; void* dv;                 /* bwd: grads (strides of q / k / v)             */
+  int64_t q_bs, q_rs, k_bs, k_rs, v_bs, v_rs, o_bs, o_rs;
+  int32_t B, H, Lq, Lk;
+  float scale;
+  int32_t _pad;
+} lmv_attn_desc;
+
+size_t lmv_attn_workspace_bytes(int B, int H, int Lq, int Lk, int backward);
+int lmv_attn_fwd(const lmv_attn_desc* d, void* workspace, size_t workspace_bytes, int dtype, void* stream);
+int lmv_attn_bwd(const lmv_attn_desc* d, void* workspace, size_t workspace_bytes, int dtype, void* stream);
+
+/* Named cores of the reference seam; thin wrappers that fill an lmv_attn_desc.
+ *   sa : StandardAttention      qkv [B,L,3C] -> o [B,L,C]                        (:199-205)
+ *   ca : CrossAttention         q [B,M,C], kv [B,N,2C] -> o [B,M,C]              (:477-486)
+ *   dca: DualCrossAttention     qkv1 [B,N,3C], qkv2 [B,M,3C] -> ox [B,N,C], oc [B,M,C]
+ *        with scale_x = log_N(M) C^-1/2, scale_c = C^-1/2                        (:235,255-256,288-302) */
+int lmv_sa_core_fwd(const void* qkv, void* o, float* lse, int B, int L, int C, void* ws, size_t ws_bytes, int dtype, void* stream);
+int lmv_ca_core_fwd(const void* q, const void* kv, void* o, float* lse, int B, int M, int N, int C,
+                    void* ws, size_t ws_bytes, int dtype, void* stream);
+int lmv_dca_core_fwd(const void* qkv1, const void* qkv2, void* ox, void* oc, float* lse_x, float* lse_c,
+                     int B, int N, int M, int C, void* ws, size_t ws_bytes, int dtype, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Small utilities used by the host side
+ * ------------------------------------------------------------------------------------------ */
+/* dst[i] = (dtype_dst) src[i]   (fp32 master weights -> bf16 compute copies and back) */
+int lmv_cast(const void* src, int src_dtype, void* dst, int dst_dtype, int64_t n, void* stream);
+/* y[r, :] = x[r, :] * scale[r / rows_per_sample]   (DropPath on a gradient) */
+int lmv_row_scale(const void* x, const float* scale, void* y, int64_t rows, int C, int rows_per_sample, int dtype, void* stream);
+/* Fused multi-tensor AdamW over a flat fp32 parameter / gradient / moment buffer
+ * (decoupled weight decay, bias correction as torch.optim.AdamW; benchmark.py:559-561,587). */
+int lmv_adamw_flat(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, const float* wd_mask,
+                   int64_t n, float lr, float beta1, float beta2, float eps, float weight_decay, int step, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LEMEVIT_HIP_H */

@@ -1,0 +1,85 @@
+"""ctypes binding of liblemevit_hip.so (the C ABI declared in include/lemevit_hip.h).
+
+There is deliberately NO fallback: if the shared library is missing or does not load, importing
+this module raises, and every op in ``lemevit_amd.ops`` is unusable.  Build it with
+``python -c 'import __graft_entry__ as g; g.build()'`` or ``make -C lemevit_amd/csrc``.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "liblemevit_hip.so")
+
+LMV_F32, LMV_BF16 = 0, 1
+ACT_NONE, ACT_GELU, ACT_GELU_GRAD = 0, 1, 2
+ABI_VERSION = 1
+
+
+class LinearProblem(C.Structure):
+    _fields_ = [("a", C.c_void_p), ("w", C.c_void_p), ("bias", C.c_void_p), ("res", C.c_void_p),
+                ("row_scale", C.c_void_p), ("aux", C.c_void_p), ("out", C.c_void_p), ("out_pre", C.c_void_p),
+                ("bias_grad", C.c_void_p), ("rows", C.c_int64), ("rows_per_sample", C.c_int32), ("_pad", C.c_int32)]
+
+
+class AttnDesc(C.Structure):
+    _fields_ = [("q", C.c_void_p), ("k", C.c_void_p), ("v", C.c_void_p), ("o", C.c_void_p), ("lse", C.c_void_p),
+                ("d_o", C.c_void_p), ("dq", C.c_void_p), ("dk", C.c_void_p), ("dv", C.c_void_p),
+                ("q_bs", C.c_int64), ("q_rs", C.c_int64), ("k_bs", C.c_int64), ("k_rs", C.c_int64),
+                ("v_bs", C.c_int64), ("v_rs", C.c_int64), ("o_bs", C.c_int64), ("o_rs", C.c_int64),
+                ("B", C.c_int32), ("H", C.c_int32), ("Lq", C.c_int32), ("Lk", C.c_int32),
+                ("scale", C.c_float), ("_pad", C.c_int32)]
+
+
+_P, _I, _L, _F, _Z = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_size_t
+
+# name -> (restype, argtypes); the complete export list of include/lemevit_hip.h
+SIGNATURES = {
+    "lmv_abi_version": (_I, []),
+    "lmv_last_error": (C.c_char_p, []),
+    "lmv_linear_fwd": (_I, [C.POINTER(LinearProblem), _I, _I, _I, _I, _I, _P]),
+    "lmv_linear_dx": (_I, [C.POINTER(LinearProblem), _I, _I, _I, _I, _I, _P]),
+    "lmv_linear_dw": (_I, [C.POINTER(LinearProblem), _I, _I, _I, _I, _P]),
+    "lmv_layernorm_fwd": (_I, [_P, _P, _P, _P, _P, _L, _I, _F, _I, _P]),
+    "lmv_layernorm_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _P]),
+    "lmv_dwconv3x3_residual_fwd": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
+    "lmv_dwconv3x3_residual_bwd_data": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P]),
+    "lmv_dwconv3x3_bwd_weight": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
+    "lmv_attn_workspace_bytes": (_Z, [_I, _I, _I, _I, _I]),
+    "lmv_attn_fwd": (_I, [C.POINTER(AttnDesc), _P, _Z, _I, _P]),
+    "lmv_attn_bwd": (_I, [C.POINTER(AttnDesc), _P, _Z, _I, _P]),
+    "lmv_sa_core_fwd": (_I, [_P, _P, _P, _I, _I, _I, _P, _Z, _I, _P]),
+    "lmv_ca_core_fwd": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P, _Z, _I, _P]),
+    "lmv_dca_core_fwd": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _Z, _I, _P]),
+    "lmv_cast": (_I, [_P, _I, _P, _I, _L, _P]),
+    "lmv_row_scale": (_I, [_P, _P, _P, _L, _I, _I, _I, _P]),
+    "lmv_adamw_flat": (_I, [_P, _P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _I, _P]),
+}
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"lemevit_amd: HIP kernel library not found at {LIB_PATH}. There is no CPU/PyTorch fallback; "
+            "build it with `make -C lemevit_amd/csrc` (hipcc, --offload-arch=gfx950).")
+    try:
+        lib = C.CDLL(LIB_PATH)
+    except OSError as e:  # pragma: no cover
+        raise RuntimeError(f"lemevit_amd: cannot load {LIB_PATH}: {e}") from e
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError here = ABI mismatch: fail loudly
+        fn.restype = res
+        fn.argtypes = args
+    v = lib.lmv_abi_version()
+    if v != ABI_VERSION:
+        raise RuntimeError(f"lemevit_amd: ABI version mismatch (library {v}, binding {ABI_VERSION}); rebuild csrc")
+    return lib
+
+
+lib = _load()
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        raise RuntimeError(f"{what} failed (code {rc}): {lib.lmv_last_error().decode(errors='replace')}")

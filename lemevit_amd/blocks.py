@@ -1,0 +1,211 @@
+"""Forward / backward schedules of the three LeMeBlock flavours over the HIP kernels.
+
+Everything here is token-major: x is [B, N, C] (N = H*W image tokens), c is [B, M, C] (meta tokens).
+The reference bounces NCHW <-> NLC twice per block (models/lemevit.py:548,579) and re-packs qkv
+(:201,290,292,481); here there is no layout change inside a stage and the attention kernels read the
+packed projections in place.
+
+  "S" block (:615-650)  x,c share norm1/attn/norm2/mlp weights  -> every Linear is ONE dual-problem launch
+  "D" block (:542-582)  x,c share norm1/norm2/mlp; qkv1/qkv2 and proj_x/proj_c differ (dual launch, two weights)
+  "C" block (:584-613)  only c is updated; x is returned untouched (:610)
+
+``block_forward`` returns the saved tensors the hand-written ``block_backward`` needs; autograd sees one
+node per block (lemevit_amd/model.py::_BlockFn).
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import torch
+
+from . import ops
+from .ops import ACT_GELU, ACT_GELU_GRAD, Prob
+
+Tensor = torch.Tensor
+BLOCK_LN_EPS = 1e-6   # models/lemevit.py:513,525
+
+# parameter order per block type (names relative to the block; the reference's state_dict keys)
+PARAM_NAMES = {
+    "S": ["pos_embed.weight", "pos_embed.bias", "norm1.weight", "norm1.bias", "attn.qkv.weight", "attn.qkv.bias",
+          "attn.proj.weight", "attn.proj.bias", "norm2.weight", "norm2.bias", "mlp.0.weight", "mlp.0.bias", "mlp.3.weight", "mlp.3.bias"],
+    "D": ["pos_embed.weight", "pos_embed.bias", "norm1.weight", "norm1.bias", "attn.qkv1.weight", "attn.qkv1.bias",
+          "attn.qkv2.weight", "attn.qkv2.bias", "attn.proj_x.weight", "attn.proj_x.bias", "attn.proj_c.weight", "attn.proj_c.bias",
+          "norm2.weight", "norm2.bias", "mlp.0.weight", "mlp.0.bias", "mlp.3.weight", "mlp.3.bias"],
+    "C": ["pos_embed.weight", "pos_embed.bias", "norm1.weight", "norm1.bias", "attn.q.weight", "attn.q.bias", "attn.kv.weight", "attn.kv.bias",
+          "attn.proj.weight", "attn.proj.bias", "norm2.weight", "norm2.bias", "mlp.0.weight", "mlp.0.bias", "mlp.3.weight", "mlp.3.bias"],
+}
+
+
+def _empty(rows_like: Tensor, cols: int) -> Tensor:
+    return torch.empty(rows_like.shape[:-1] + (cols,), device=rows_like.device, dtype=rows_like.dtype)
+
+
+def _rps(t: Tensor) -> int:
+    return t.shape[1]
+
+
+# ------------------------------------------------------------------------------------------------
+# MLP half of a block:  t <- t + ds * fc2(GELU(fc1(LN2(t))))   for every stream t in `ts`
+# ------------------------------------------------------------------------------------------------
+def _mlp_fwd(P: Dict[str, Tensor], ts: Sequence[Tensor], ds: Sequence[Optional[Tensor]], save: bool):
+    C = ts[0].shape[-1]
+    Hd = P["mlp.0.weight"].shape[0]
+    xn, st = zip(*[ops.layernorm_fwd(t, P["norm2.weight"], P["norm2.bias"], BLOCK_LN_EPS, want_stats=save) for t in ts])
+    h = [_empty(t, Hd) for t in ts]
+    u = [_empty(t, Hd) if save else None for t in ts]
+    ops.linear_fwd([Prob(a, P["mlp.0.weight"], o, bias=P["mlp.0.bias"], out_pre=pre) for a, o, pre in zip(xn, h, u)], Hd, C, ACT_GELU)
+    out = [torch.empty_like(t) for t in ts]
+    ops.linear_fwd([Prob(a, P["mlp.3.weight"], o, bias=P["mlp.3.bias"], res=t, row_scale=s, rps=_rps(t)) for a, o, t, s in zip(h, out, ts, ds)], C, Hd)
+    saved = (list(ts), list(st), list(xn), u, h) if save else None
+    return out, saved
+
+
+def _mlp_bwd(P, G, saved, douts: Sequence[Tensor], ds: Sequence[Optional[Tensor]]) -> List[Tensor]:
+    ts, st, xn, u, h = saved
+    C = ts[0].shape[-1]
+    Hd = P["mlp.0.weight"].shape[0]
+    g = [d if s is None else ops.row_scale(d, s, _rps(d)) for d, s in zip(douts, ds)]
+    ops.linear_dw([Prob(gi, hi, G["mlp.3.weight"], bias_grad=G["mlp.3.bias"]) for gi, hi in zip(g, h)], C, Hd)
+    du = [torch.empty_like(ui) for ui in u]
+    ops.linear_dx([Prob(gi, P["mlp.3.weight"], o, aux=ui) for gi, o, ui in zip(g, du, u)], C, Hd, ACT_GELU_GRAD)
+    ops.linear_dw([Prob(dui, xi, G["mlp.0.weight"], bias_grad=G["mlp.0.bias"]) for dui, xi in zip(du, xn)], Hd, C)
+    dxn = [torch.empty_like(t) for t in ts]
+    ops.linear_dx([Prob(dui, P["mlp.0.weight"], o) for dui, o in zip(du, dxn)], Hd, C)
+    return [ops.layernorm_bwd(dn, t, s, P["norm2.weight"], G["norm2.weight"], G["norm2.bias"], dres=d) for dn, t, s, d in zip(dxn, ts, st, douts)]
+
+
+# ------------------------------------------------------------------------------------------------
+# attention halves
+# ------------------------------------------------------------------------------------------------
+def _attn_S_fwd(P, ts, ds, save):
+    """t <- t + ds * proj(SA(qkv(LN1(t)))) for x and c with the SAME weights (models/lemevit.py:632,634)."""
+    C = ts[0].shape[-1]
+    xn, st = zip(*[ops.layernorm_fwd(t, P["norm1.weight"], P["norm1.bias"], BLOCK_LN_EPS, want_stats=save) for t in ts])
+    qkv = [_empty(t, 3 * C) for t in ts]
+    ops.linear_fwd([Prob(a, P["attn.qkv.weight"], o, bias=P["attn.qkv.bias"]) for a, o in zip(xn, qkv)], 3 * C, C)
+    ao, lse = zip(*[ops.attn_fwd((q, 0), (q, C), (q, 2 * C), C, ops.SDPA_SCALE, want_lse=save) for q in qkv])
+    out = [torch.empty_like(t) for t in ts]
+    ops.linear_fwd([Prob(a, P["attn.proj.weight"], o, bias=P["attn.proj.bias"], res=t, row_scale=s, rps=_rps(t)) for a, o, t, s in zip(ao, out, ts, ds)], C, C)
+    return out, ((list(ts), list(st), list(xn), qkv, list(ao), list(lse)) if save else None)
+
+
+def _attn_S_bwd(P, G, saved, douts, ds):
+    ts, st, xn, qkv, ao, lse = saved
+    C = ts[0].shape[-1]
+    g = [d if s is None else ops.row_scale(d, s, _rps(d)) for d, s in zip(douts, ds)]
+    ops.linear_dw([Prob(gi, ai, G["attn.proj.weight"], bias_grad=G["attn.proj.bias"]) for gi, ai in zip(g, ao)], C, C)
+    dao = [torch.empty_like(t) for t in ts]
+    ops.linear_dx([Prob(gi, P["attn.proj.weight"], o) for gi, o in zip(g, dao)], C, C)
+    dqkv = [torch.empty_like(q) for q in qkv]
+    for q, a, l, da, dq in zip(qkv, ao, lse, dao, dqkv):
+        ops.attn_bwd((q, 0), (q, C), (q, 2 * C), a, l, da, (dq, 0), (dq, C), (dq, 2 * C), C, ops.SDPA_SCALE)
+    ops.linear_dw([Prob(dq, xi, G["attn.qkv.weight"], bias_grad=G["attn.qkv.bias"]) for dq, xi in zip(dqkv, xn)], 3 * C, C)
+    dxn = [torch.empty_like(t) for t in ts]
+    ops.linear_dx([Prob(dq, P["attn.qkv.weight"], o) for dq, o in zip(dqkv, dxn)], 3 * C, C)
+    return [ops.layernorm_bwd(dn, t, s, P["norm1.weight"], G["norm1.weight"], G["norm1.bias"], dres=d) for dn, t, s, d in zip(dxn, ts, st, douts)]
+
+
+def _attn_D_fwd(P, ts, ds, save):
+    """Dual cross attention (models/lemevit.py:252-256,288-302): ts = [x, c]."""
+    x, c = ts
+    C, N, M = x.shape[-1], x.shape[1], c.shape[1]
+    sx, sc = ops.dca_scales(N, M, C)
+    xn, st = zip(*[ops.layernorm_fwd(t, P["norm1.weight"], P["norm1.bias"], BLOCK_LN_EPS, want_stats=save) for t in ts])
+    q1, q2 = _empty(x, 3 * C), _empty(c, 3 * C)
+    ops.linear_fwd([Prob(xn[0], P["attn.qkv1.weight"], q1, bias=P["attn.qkv1.bias"]),
+                    Prob(xn[1], P["attn.qkv2.weight"], q2, bias=P["attn.qkv2.bias"])], 3 * C, C)
+    aox, lsex = ops.attn_fwd((q1, 0), (q2, C), (q2, 2 * C), C, sx, want_lse=save)     # image -> meta   (:297)
+    aoc, lsec = ops.attn_fwd((q2, 0), (q1, C), (q1, 2 * C), C, sc, want_lse=save)     # meta  -> image  (:300)
+    ox, oc = torch.empty_like(x), torch.empty_like(c)
+    ops.linear_fwd([Prob(aox, P["attn.proj_x.weight"], ox, bias=P["attn.proj_x.bias"], res=x, row_scale=ds[0], rps=N),
+                    Prob(aoc, P["attn.proj_c.weight"], oc, bias=P["attn.proj_c.bias"], res=c, row_scale=ds[1], rps=M)], C, C)
+    return [ox, oc], ((list(ts), list(st), list(xn), q1, q2, aox, aoc, lsex, lsec) if save else None)
+
+
+def _attn_D_bwd(P, G, saved, douts, ds):
+    ts, st, xn, q1, q2, aox, aoc, lsex, lsec = saved
+    x, c = ts
+    C, N, M = x.shape[-1], x.shape[1], c.shape[1]
+    sx, sc = ops.dca_scales(N, M, C)
+    g = [d if s is None else ops.row_scale(d, s, _rps(d)) for d, s in zip(douts, ds)]
+    ops.linear_dw([Prob(g[0], aox, G["attn.proj_x.weight"], bias_grad=G["attn.proj_x.bias"]),
+                   Prob(g[1], aoc, G["attn.proj_c.weight"], bias_grad=G["attn.proj_c.bias"])], C, C)
+    daox, daoc = torch.empty_like(x), torch.empty_like(c)
+    ops.linear_dx([Prob(g[0], P["attn.proj_x.weight"], daox), Prob(g[1], P["attn.proj_c.weight"], daoc)], C, C)
+    dq1, dq2 = torch.empty_like(q1), torch.empty_like(q2)
+    ops.attn_bwd((q1, 0), (q2, C), (q2, 2 * C), aox, lsex, daox, (dq1, 0), (dq2, C), (dq2, 2 * C), C, sx)
+    ops.attn_bwd((q2, 0), (q1, C), (q1, 2 * C), aoc, lsec, daoc, (dq2, 0), (dq1, C), (dq1, 2 * C), C, sc)
+    ops.linear_dw([Prob(dq1, xn[0], G["attn.qkv1.weight"], bias_grad=G["attn.qkv1.bias"]),
+                   Prob(dq2, xn[1], G["attn.qkv2.weight"], bias_grad=G["attn.qkv2.bias"])], 3 * C, C)
+    dxn = [torch.empty_like(x), torch.empty_like(c)]
+    ops.linear_dx([Prob(dq1, P["attn.qkv1.weight"], dxn[0]), Prob(dq2, P["attn.qkv2.weight"], dxn[1])], 3 * C, C)
+    return [ops.layernorm_bwd(dn, t, s, P["norm1.weight"], G["norm1.weight"], G["norm1.bias"], dres=d) for dn, t, s, d in zip(dxn, ts, st, douts)]
+
+
+def _attn_C_fwd(P, xp, c, ds, save):
+    """c <- c + ds * proj(CA(q(LN1(c)), kv(LN1(xp))))  (models/lemevit.py:477-486,600)."""
+    C, N, M = c.shape[-1], xp.shape[1], c.shape[1]
+    xn, stx = ops.layernorm_fwd(xp, P["norm1.weight"], P["norm1.bias"], BLOCK_LN_EPS, want_stats=save)
+    cn, stc = ops.layernorm_fwd(c, P["norm1.weight"], P["norm1.bias"], BLOCK_LN_EPS, want_stats=save)
+    kv, q = _empty(xp, 2 * C), _empty(c, C)
+    ops.linear_fwd([Prob(xn, P["attn.kv.weight"], kv, bias=P["attn.kv.bias"])], 2 * C, C)
+    ops.linear_fwd([Prob(cn, P["attn.q.weight"], q, bias=P["attn.q.bias"])], C, C)
+    ao, lse = ops.attn_fwd((q, 0), (kv, 0), (kv, C), C, ops.SDPA_SCALE, want_lse=save)
+    oc = torch.empty_like(c)
+    ops.linear_fwd([Prob(ao, P["attn.proj.weight"], oc, bias=P["attn.proj.bias"], res=c, row_scale=ds, rps=M)], C, C)
+    return oc, ((xp, c, stx, stc, xn, cn, kv, q, ao, lse) if save else None)
+
+
+def _attn_C_bwd(P, G, saved, dout, ds):
+    xp, c, stx, stc, xn, cn, kv, q, ao, lse = saved
+    C, M = c.shape[-1], c.shape[1]
+    g = dout if ds is None else ops.row_scale(dout, ds, M)
+    ops.linear_dw([Prob(g, ao, G["attn.proj.weight"], bias_grad=G["attn.proj.bias"])], C, C)
+    dao = torch.empty_like(c)
+    ops.linear_dx([Prob(g, P["attn.proj.weight"], dao)], C, C)
+    dq, dkv = torch.empty_like(q), torch.empty_like(kv)
+    ops.attn_bwd((q, 0), (kv, 0), (kv, C), ao, lse, dao, (dq, 0), (dkv, 0), (dkv, C), C, ops.SDPA_SCALE)
+    ops.linear_dw([Prob(dq, cn, G["attn.q.weight"], bias_grad=G["attn.q.bias"])], C, C)
+    ops.linear_dw([Prob(dkv, xn, G["attn.kv.weight"], bias_grad=G["attn.kv.bias"])], 2 * C, C)
+    dcn, dxn = torch.empty_like(c), torch.empty_like(xp)
+    ops.linear_dx([Prob(dq, P["attn.q.weight"], dcn)], C, C)
+    ops.linear_dx([Prob(dkv, P["attn.kv.weight"], dxn)], 2 * C, C)
+    dc = ops.layernorm_bwd(dcn, c, stc, P["norm1.weight"], G["norm1.weight"], G["norm1.bias"], dres=dout)
+    dxp = ops.layernorm_bwd(dxn, xp, stx, P["norm1.weight"], G["norm1.weight"], G["norm1.bias"], dres=None)
+    return dxp, dc
+
+
+# ------------------------------------------------------------------------------------------------
+# whole blocks
+# ------------------------------------------------------------------------------------------------
+def block_forward(kind: str, x: Tensor, c: Tensor, H: int, W: int, P: Dict[str, Tensor],
+                  masks: Sequence[Optional[Tensor]], save: bool):
+    """LeMeBlock.forward (models/lemevit.py:652-660) on token-major x [B,HW,C], c [B,M,C].
+    masks: per-sample DropPath scales in the reference's draw order (D/S: x-attn, x-mlp, c-attn, c-mlp; C: c-attn, c-mlp)."""
+    xp = ops.dwconv_residual_fwd(x, P["pos_embed.weight"], P["pos_embed.bias"], H, W)          # :546
+    if kind == "C":
+        c1, sa = _attn_C_fwd(P, xp, c, masks[0], save)
+        (c2,), sm = _mlp_fwd(P, [c1], [masks[1]], save)
+        return x, c2, ((x, sa, sm) if save else None)                                            # returns the ORIGINAL x (:610)
+    fwd = _attn_S_fwd if kind == "S" else _attn_D_fwd
+    (x2, c1), sa = fwd(P, [xp, c], [masks[0], masks[2]], save)
+    (x3, c2), sm = _mlp_fwd(P, [x2, c1], [masks[1], masks[3]], save)
+    return x3, c2, ((x, sa, sm) if save else None)
+
+
+def block_backward(kind: str, saved, dx: Tensor, dc: Tensor, H: int, W: int, P: Dict[str, Tensor], G: Dict[str, Tensor],
+                   masks: Sequence[Optional[Tensor]]) -> Tuple[Tensor, Tensor]:
+    """Gradients wrt the block inputs; parameter gradients are accumulated (fp32) into G."""
+    x0, sa, sm = saved
+    if kind == "C":
+        (dc1,) = _mlp_bwd(P, G, sm, [dc], [masks[1]])
+        dxp, dc0 = _attn_C_bwd(P, G, sa, dc1, masks[0])
+        ops.dwconv_bwd_weight(dxp, x0, G["pos_embed.weight"], G["pos_embed.bias"], H, W)
+        dx0 = ops.dwconv_residual_bwd_data(dxp, P["pos_embed.weight"], H, W)
+        return (dx0 if dx is None else dx0 + dx), dc0   # the untouched x's pass-through gradient is added by autograd
+    dx2, dc1 = _mlp_bwd(P, G, sm, [dx, dc], [masks[1], masks[3]])
+    bwd = _attn_S_bwd if kind == "S" else _attn_D_bwd
+    dxp, dc0 = bwd(P, G, sa, [dx2, dc1], [masks[0], masks[2]])
+    ops.dwconv_bwd_weight(dxp, x0, G["pos_embed.weight"], G["pos_embed.bias"], H, W)
+    dx0 = ops.dwconv_residual_bwd_data(dxp, P["pos_embed.weight"], H, W)
+    return dx0, dc0

@@ -1,0 +1,98 @@
+// common.h -- shared device helpers for the gfx950 (CDNA4, wave64) kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include "../../include/lemevit_hip.h"
+
+typedef unsigned short bf16_t;  // storage type: raw bfloat16 bits
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4_t;
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+
+#define LMV_WAVE 64
+
+// ---- error plumbing (host) -----------------------------------------------------------------
+void lmv_set_error(const char* fmt, ...);
+#define LMV_FAIL(code, ...)          \
+  do {                               \
+    lmv_set_error(__VA_ARGS__);      \
+    return (code);                   \
+  } while (0)
+#define LMV_CHECK_LAUNCH(name)                                                \
+  do {                                                                        \
+    hipError_t e__ = hipGetLastError();                                       \
+    if (e__ != hipSuccess) LMV_FAIL(LMV_ERR_LAUNCH, "%s: %s", name, hipGetErrorString(e__)); \
+  } while (0)
+
+static inline bool lmv_aligned16(const void* p) { return (((uintptr_t)p) & 15u) == 0; }
+
+// ---- bf16 <-> f32 ---------------------------------------------------------------------------
+__device__ __forceinline__ float bf2f(bf16_t v) { return __uint_as_float(((unsigned)v) << 16); }
+__device__ __forceinline__ bf16_t f2bf(float f) {
+  unsigned u = __float_as_uint(f);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40u);  // quiet NaN
+  u += 0x7fffu + ((u >> 16) & 1u);                                            // round to nearest even
+  return (bf16_t)(u >> 16);
+}
+__device__ __forceinline__ unsigned pack_bf2(float lo, float hi) { return (unsigned)f2bf(lo) | ((unsigned)f2bf(hi) << 16); }
+
+template <typename T> struct DT;
+template <> struct DT<float> {
+  static constexpr int EPC = 4;  // elements per 16-byte chunk
+  static __device__ __forceinline__ float ld(const float* p) { return *p; }
+  static __device__ __forceinline__ void st(float* p, float v) { *p = v; }
+};
+template <> struct DT<bf16_t> {
+  static constexpr int EPC = 8;
+  static __device__ __forceinline__ float ld(const bf16_t* p) { return bf2f(*p); }
+  static __device__ __forceinline__ void st(bf16_t* p, float v) { *p = f2bf(v); }
+};
+
+// 16-byte chunk <-> floats
+template <typename T> __device__ __forceinline__ void chunk_to_f(const uint4& c, float* f);
+template <> __device__ __forceinline__ void chunk_to_f<float>(const uint4& c, float* f) {
+  f[0] = __uint_as_float(c.x); f[1] = __uint_as_float(c.y); f[2] = __uint_as_float(c.z); f[3] = __uint_as_float(c.w);
+}
+template <> __device__ __forceinline__ void chunk_to_f<bf16_t>(const uint4& c, float* f) {
+  f[0] = __uint_as_float(c.x << 16); f[1] = __uint_as_float(c.x & 0xffff0000u);
+  f[2] = __uint_as_float(c.y << 16); f[3] = __uint_as_float(c.y & 0xffff0000u);
+  f[4] = __uint_as_float(c.z << 16); f[5] = __uint_as_float(c.z & 0xffff0000u);
+  f[6] = __uint_as_float(c.w << 16); f[7] = __uint_as_float(c.w & 0xffff0000u);
+}
+template <typename T> __device__ __forceinline__ uint4 f_to_chunk(const float* f);
+template <> __device__ __forceinline__ uint4 f_to_chunk<float>(const float* f) {
+  return make_uint4(__float_as_uint(f[0]), __float_as_uint(f[1]), __float_as_uint(f[2]), __float_as_uint(f[3]));
+}
+template <> __device__ __forceinline__ uint4 f_to_chunk<bf16_t>(const float* f) {
+  return make_uint4(pack_bf2(f[0], f[1]), pack_bf2(f[2], f[3]), pack_bf2(f[4], f[5]), pack_bf2(f[6], f[7]));
+}
+
+// load / store n (= 4) consecutive elements as floats (8 B for bf16, 16 B for f32)
+__device__ __forceinline__ void ld4(const float* p, float* f) {
+  float4 v = *reinterpret_cast<const float4*>(p); f[0] = v.x; f[1] = v.y; f[2] = v.z; f[3] = v.w;
+}
+__device__ __forceinline__ void ld4(const bf16_t* p, float* f) {
+  uint2 v = *reinterpret_cast<const uint2*>(p);
+  f[0] = __uint_as_float(v.x << 16); f[1] = __uint_as_float(v.x & 0xffff0000u);
+  f[2] = __uint_as_float(v.y << 16); f[3] = __uint_as_float(v.y & 0xffff0000u);
+}
+__device__ __forceinline__ void st4(float* p, const float* f) { *reinterpret_cast<float4*>(p) = make_float4(f[0], f[1], f[2], f[3]); }
+__device__ __forceinline__ void st4(bf16_t* p, const float* f) { *reinterpret_cast<uint2*>(p) = make_uint2(pack_bf2(f[0], f[1]), pack_bf2(f[2], f[3])); }
+
+// exact-erf GELU and its derivative (nn.GELU default, models/lemevit.py:528)
+__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+__device__ __forceinline__ float gelu_grad_f(float x) {
+  return 0.5f * (1.0f + erff(x * 0.70710678118654752f)) + x * 0.39894228040143268f * __expf(-0.5f * x * x);
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}

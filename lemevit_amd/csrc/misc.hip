@@ -1,0 +1,116 @@
+// misc.hip -- error plumbing and the small memory-bound utilities (cast, DropPath row scale,
+// fused flat AdamW).  All are grid-stride, 16-byte-per-lane kernels bounded by HBM bandwidth.
+#include <stdarg.h>
+#include "common.h"
+
+static thread_local char g_err[512] = "";
+
+void lmv_set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+extern "C" const char* lmv_last_error(void) { return g_err; }
+extern "C" int lmv_abi_version(void) { return LMV_ABI_VERSION; }
+
+namespace {
+
+constexpr int TPB = 256;
+inline int grid_for(int64_t work_items) {
+  int64_t b = (work_items + TPB - 1) / TPB;
+  if (b > 2048) b = 2048;
+  if (b < 1) b = 1;
+  return (int)b;
+}
+
+template <typename S, typename D>
+__global__ __launch_bounds__(TPB) void cast_kernel(const S* __restrict__ src, D* __restrict__ dst, int64_t n) {
+  const int64_t n4 = n >> 2;
+  for (int64_t i = blockIdx.x * (int64_t)TPB + threadIdx.x; i < n4; i += (int64_t)gridDim.x * TPB) {
+    float f[4];
+    ld4(src + i * 4, f);
+    st4(dst + i * 4, f);
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+    const int64_t i = (n4 << 2) + threadIdx.x;
+    DT<D>::st(dst + i, DT<S>::ld(src + i));
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(TPB) void row_scale_kernel(const T* __restrict__ x, const float* __restrict__ scale, T* __restrict__ y,
+                                                       int64_t rows, int C, int rps) {
+  const int c4 = C >> 2;
+  const int64_t total = rows * c4;
+  for (int64_t i = blockIdx.x * (int64_t)TPB + threadIdx.x; i < total; i += (int64_t)gridDim.x * TPB) {
+    const int64_t r = i / c4;
+    const float s = scale[r / rps];
+    float f[4];
+    ld4(x + i * 4, f);
+    f[0] *= s; f[1] *= s; f[2] *= s; f[3] *= s;
+    st4(y + i * 4, f);
+  }
+}
+
+__global__ __launch_bounds__(TPB) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                   float* __restrict__ v, const float* __restrict__ wd_mask, int64_t n, float lr,
+                                                   float b1, float b2, float eps, float wd, float bc1, float bc2_sqrt) {
+  const int64_t n4 = n >> 2;
+  for (int64_t i = blockIdx.x * (int64_t)TPB + threadIdx.x; i < n4; i += (int64_t)gridDim.x * TPB) {
+    float4 P = reinterpret_cast<float4*>(p)[i], G = reinterpret_cast<const float4*>(g)[i];
+    float4 M = reinterpret_cast<float4*>(m)[i], V = reinterpret_cast<float4*>(v)[i];
+    float4 W = wd_mask ? reinterpret_cast<const float4*>(wd_mask)[i] : make_float4(1.f, 1.f, 1.f, 1.f);
+    float* pp = &P.x; const float* gg = &G.x; float* mm = &M.x; float* vv = &V.x; const float* ww = &W.x;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      pp[q] *= 1.f - lr * wd * ww[q];                       // decoupled weight decay
+      mm[q] = b1 * mm[q] + (1.f - b1) * gg[q];
+      vv[q] = b2 * vv[q] + (1.f - b2) * gg[q] * gg[q];
+      const float denom = sqrtf(vv[q]) / bc2_sqrt + eps;
+      pp[q] -= (lr / bc1) * mm[q] / denom;
+    }
+    reinterpret_cast<float4*>(p)[i] = P; reinterpret_cast<float4*>(m)[i] = M; reinterpret_cast<float4*>(v)[i] = V;
+  }
+}
+
+}  // namespace
+
+extern "C" int lmv_cast(const void* src, int sd, void* dst, int dd, int64_t n, void* stream) {
+  if (n <= 0) return LMV_OK;
+  if (!lmv_aligned16(src) || !lmv_aligned16(dst)) LMV_FAIL(LMV_ERR_SHAPE, "cast: pointers must be 16-byte aligned");
+  hipStream_t st = (hipStream_t)stream;
+  const int grid = grid_for(n / 4);
+  if (sd == LMV_F32 && dd == LMV_BF16) hipLaunchKernelGGL((cast_kernel<float, bf16_t>), dim3(grid), dim3(TPB), 0, st, (const float*)src, (bf16_t*)dst, n);
+  else if (sd == LMV_BF16 && dd == LMV_F32) hipLaunchKernelGGL((cast_kernel<bf16_t, float>), dim3(grid), dim3(TPB), 0, st, (const bf16_t*)src, (float*)dst, n);
+  else if (sd == LMV_F32 && dd == LMV_F32) hipLaunchKernelGGL((cast_kernel<float, float>), dim3(grid), dim3(TPB), 0, st, (const float*)src, (float*)dst, n);
+  else if (sd == LMV_BF16 && dd == LMV_BF16) hipLaunchKernelGGL((cast_kernel<bf16_t, bf16_t>), dim3(grid), dim3(TPB), 0, st, (const bf16_t*)src, (bf16_t*)dst, n);
+  else LMV_FAIL(LMV_ERR_DTYPE, "cast: unsupported dtypes %d -> %d", sd, dd);
+  LMV_CHECK_LAUNCH("cast");
+  return LMV_OK;
+}
+
+extern "C" int lmv_row_scale(const void* x, const float* scale, void* y, int64_t rows, int C, int rps, int dtype, void* stream) {
+  if (rows <= 0) return LMV_OK;
+  if (C <= 0 || (C % 8) || rps <= 0) LMV_FAIL(LMV_ERR_SHAPE, "row_scale: C=%d must be a multiple of 8, rows_per_sample=%d > 0", C, rps);
+  hipStream_t st = (hipStream_t)stream;
+  const int grid = grid_for(rows * (C / 4));
+  if (dtype == LMV_BF16) hipLaunchKernelGGL((row_scale_kernel<bf16_t>), dim3(grid), dim3(TPB), 0, st, (const bf16_t*)x, scale, (bf16_t*)y, rows, C, rps);
+  else if (dtype == LMV_F32) hipLaunchKernelGGL((row_scale_kernel<float>), dim3(grid), dim3(TPB), 0, st, (const float*)x, scale, (float*)y, rows, C, rps);
+  else LMV_FAIL(LMV_ERR_DTYPE, "row_scale: unsupported dtype %d", dtype);
+  LMV_CHECK_LAUNCH("row_scale");
+  return LMV_OK;
+}
+
+extern "C" int lmv_adamw_flat(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, const float* wd_mask, int64_t n,
+                              float lr, float beta1, float beta2, float eps, float weight_decay, int step, void* stream) {
+  if (n <= 0) return LMV_OK;
+  if (n % 4) LMV_FAIL(LMV_ERR_SHAPE, "adamw_flat: n=%lld must be a multiple of 4 (pad the flat buffer)", (long long)n);
+  if (step < 1) LMV_FAIL(LMV_ERR_SHAPE, "adamw_flat: step must be >= 1");
+  const float bc1 = 1.f - powf(beta1, (float)step);
+  const float bc2_sqrt = sqrtf(1.f - powf(beta2, (float)step));
+  hipLaunchKernelGGL(adamw_kernel, dim3(grid_for(n / 4)), dim3(TPB), 0, (hipStream_t)stream, param, grad, exp_avg, exp_avg_sq, wd_mask, n,
+                     lr, beta1, beta2, eps, weight_decay, bc1, bc2_sqrt);
+  LMV_CHECK_LAUNCH("adamw_flat");
+  return LMV_OK;
+}

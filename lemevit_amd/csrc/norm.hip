@@ -1,0 +1,221 @@
+// norm.hip -- LayerNorm forward / backward over token rows (memory-bound; graded on HBM GB/s).
+//
+// A row of C elements is C/8 (bf16) or C/4 (fp32) 16-byte chunks.  LPR = 2^k lanes cooperate on a
+// row (k chosen on the host so that chunks/LPR <= NIT with the fewest idle lanes), so a 64-lane
+// wavefront processes 64/LPR rows at once and every lane issues 16-byte loads; the row lives in
+// registers between the statistics pass and the normalise pass (one HBM read, one HBM write).
+// Two-pass (mean, then centred variance) in fp32 to match torch's numerics.
+#include "common.h"
+
+namespace {
+
+constexpr int TPB = 256;
+constexpr int MAXIT = 8;   // 7, 8 only instantiated for fp32 (4-element chunks)
+constexpr int BWD_MAXC = 2048;
+
+template <int LPRMAX = 64>
+__device__ __forceinline__ float group_sum(float v, int lpr) {
+#pragma unroll
+  for (int o = LPRMAX / 2; o > 0; o >>= 1)
+    if (o < lpr) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+template <typename T, int NIT>
+__global__ __launch_bounds__(TPB) void ln_fwd_kernel(const T* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                    T* __restrict__ y, float* __restrict__ stats, int64_t rows, int C, int lpr_log2, float eps) {
+  constexpr int EPC = DT<T>::EPC;
+  const int lpr = 1 << lpr_log2, nch = C / EPC;
+  const int lir = threadIdx.x & (lpr - 1), rib = threadIdx.x >> lpr_log2, rpb = TPB >> lpr_log2;
+  const float invC = 1.f / (float)C;
+  for (int64_t row = (int64_t)blockIdx.x * rpb + rib; row < rows; row += (int64_t)gridDim.x * rpb) {
+    const T* xr = x + row * C;
+    float v[NIT][EPC];
+    float s = 0.f;
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int ch = lir + it * lpr;
+      if (ch < nch) {
+        const uint4 c4 = *reinterpret_cast<const uint4*>(xr + ch * EPC);
+        chunk_to_f<T>(c4, v[it]);
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) s += v[it][e];
+      }
+    }
+    const float mean = group_sum(s, lpr) * invC;
+    float q = 0.f;
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      if (lir + it * lpr < nch) {
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) { const float d = v[it][e] - mean; q += d * d; }
+      }
+    }
+    const float rstd = 1.f / sqrtf(group_sum(q, lpr) * invC + eps);
+    T* yr = y + row * C;
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int ch = lir + it * lpr;
+      if (ch < nch) {
+        float o[EPC];
+#pragma unroll
+        for (int e = 0; e < EPC; e += 4) {
+          const float4 g4 = *reinterpret_cast<const float4*>(gamma + ch * EPC + e);
+          const float4 b4 = *reinterpret_cast<const float4*>(beta + ch * EPC + e);
+          o[e + 0] = (v[it][e + 0] - mean) * rstd * g4.x + b4.x;
+          o[e + 1] = (v[it][e + 1] - mean) * rstd * g4.y + b4.y;
+          o[e + 2] = (v[it][e + 2] - mean) * rstd * g4.z + b4.z;
+          o[e + 3] = (v[it][e + 3] - mean) * rstd * g4.w + b4.w;
+        }
+        *reinterpret_cast<uint4*>(yr + ch * EPC) = f_to_chunk<T>(o);
+      }
+    }
+    if (stats && lir == 0) { stats[row * 2] = mean; stats[row * 2 + 1] = rstd; }
+  }
+}
+
+template <typename T, int NIT>
+__global__ __launch_bounds__(TPB) void ln_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x, const float* __restrict__ stats,
+                                                    const float* __restrict__ gamma, const T* __restrict__ dres, T* __restrict__ dx,
+                                                    float* __restrict__ dgamma, float* __restrict__ dbeta, int64_t rows, int C, int lpr_log2) {
+  constexpr int EPC = DT<T>::EPC;
+  __shared__ float s_dg[BWD_MAXC], s_db[BWD_MAXC];
+  const int lpr = 1 << lpr_log2, nch = C / EPC;
+  const int lir = threadIdx.x & (lpr - 1), rib = threadIdx.x >> lpr_log2, rpb = TPB >> lpr_log2;
+  const float invC = 1.f / (float)C;
+  for (int c = threadIdx.x; c < C; c += TPB) { s_dg[c] = 0.f; s_db[c] = 0.f; }
+  float adg[NIT][EPC], adb[NIT][EPC], gm[NIT][EPC];
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    const int ch = lir + it * lpr;
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) { adg[it][e] = 0.f; adb[it][e] = 0.f; gm[it][e] = (ch < nch) ? gamma[ch * EPC + e] : 0.f; }
+  }
+  for (int64_t row = (int64_t)blockIdx.x * rpb + rib; row < rows; row += (int64_t)gridDim.x * rpb) {
+    const float mean = stats[row * 2], rstd = stats[row * 2 + 1];
+    float xh[NIT][EPC], g[NIT][EPC];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int ch = lir + it * lpr;
+      if (ch < nch) {
+        float xv[EPC], dv[EPC];
+        chunk_to_f<T>(*reinterpret_cast<const uint4*>(x + row * C + ch * EPC), xv);
+        chunk_to_f<T>(*reinterpret_cast<const uint4*>(dy + row * C + ch * EPC), dv);
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) {
+          xh[it][e] = (xv[e] - mean) * rstd;
+          g[it][e] = dv[e] * gm[it][e];
+          s1 += g[it][e]; s2 += g[it][e] * xh[it][e];
+          adg[it][e] += dv[e] * xh[it][e]; adb[it][e] += dv[e];
+        }
+      }
+    }
+    s1 = group_sum(s1, lpr) * invC; s2 = group_sum(s2, lpr) * invC;
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int ch = lir + it * lpr;
+      if (ch < nch) {
+        float o[EPC];
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) o[e] = rstd * (g[it][e] - s1 - xh[it][e] * s2);
+        if (dres) {
+          float r[EPC];
+          chunk_to_f<T>(*reinterpret_cast<const uint4*>(dres + row * C + ch * EPC), r);
+#pragma unroll
+          for (int e = 0; e < EPC; ++e) o[e] += r[e];
+        }
+        *reinterpret_cast<uint4*>(dx + row * C + ch * EPC) = f_to_chunk<T>(o);
+      }
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    const int ch = lir + it * lpr;
+    if (ch < nch) {
+#pragma unroll
+      for (int e = 0; e < EPC; ++e) { atomicAdd(&s_dg[ch * EPC + e], adg[it][e]); atomicAdd(&s_db[ch * EPC + e], adb[it][e]); }
+    }
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < C; c += TPB) { atomicAdd(dgamma + c, s_dg[c]); atomicAdd(dbeta + c, s_db[c]); }
+}
+
+// lanes per row (log2) and iterations for a row of `nch` 16-byte chunks
+inline bool pick_geometry(int nch, int max_it, int* lpr_log2, int* nit) {
+  int best = -1, best_score = 1 << 30, best_it = 0;
+  for (int l = 2; l <= 6; ++l) {
+    const int lpr = 1 << l, it = (nch + lpr - 1) / lpr;
+    if (it > max_it) continue;
+    const int waste = it * lpr - nch;                       // idle lane-iterations per row
+    const int score = waste * 100 + (it > 3 ? it - 3 : 3 - it);  // then ~3 loads in flight per lane
+    if (score < best_score) { best = l; best_score = score; best_it = it; }
+  }
+  if (best < 0) return false;
+  *lpr_log2 = best; *nit = best_it;
+  return true;
+}
+
+template <typename T>
+int launch_fwd(const void* x, const float* gamma, const float* beta, void* y, float* stats, int64_t rows, int C, float eps, hipStream_t st) {
+  int l2, nit;
+  if (!pick_geometry(C / DT<T>::EPC, sizeof(T) == 4 ? 8 : 6, &l2, &nit)) LMV_FAIL(LMV_ERR_SHAPE, "layernorm: C=%d too wide", C);
+  const int rpb = TPB >> l2;
+  int64_t blocks = (rows + rpb - 1) / rpb; if (blocks > 4096) blocks = 4096;
+  dim3 grid((int)blocks), block(TPB);
+#define LN_FWD_CASE(N) case N: hipLaunchKernelGGL((ln_fwd_kernel<T, N>), grid, block, 0, st, (const T*)x, gamma, beta, (T*)y, stats, rows, C, l2, eps); break;
+  switch (nit) {
+    LN_FWD_CASE(1) LN_FWD_CASE(2) LN_FWD_CASE(3) LN_FWD_CASE(4) LN_FWD_CASE(5) LN_FWD_CASE(6)
+    default:
+      if constexpr (sizeof(T) == 4) { switch (nit) { LN_FWD_CASE(7) LN_FWD_CASE(8) } }
+      else LMV_FAIL(LMV_ERR_SHAPE, "layernorm: C=%d too wide", C);
+  }
+#undef LN_FWD_CASE
+  LMV_CHECK_LAUNCH("layernorm_fwd");
+  return LMV_OK;
+}
+
+template <typename T>
+int launch_bwd(const void* dy, const void* x, const float* stats, const float* gamma, const void* dres, void* dx, float* dgamma, float* dbeta,
+               int64_t rows, int C, hipStream_t st) {
+  int l2, nit;
+  if (C > BWD_MAXC || !pick_geometry(C / DT<T>::EPC, sizeof(T) == 4 ? 8 : 6, &l2, &nit)) LMV_FAIL(LMV_ERR_SHAPE, "layernorm_bwd: C=%d too wide", C);
+  const int rpb = TPB >> l2;
+  int64_t blocks = (rows + rpb - 1) / rpb; if (blocks > 512) blocks = 512;
+  dim3 grid((int)blocks), block(TPB);
+#define LN_BWD_CASE(N) case N: hipLaunchKernelGGL((ln_bwd_kernel<T, N>), grid, block, 0, st, (const T*)dy, (const T*)x, stats, gamma, (const T*)dres, (T*)dx, dgamma, dbeta, rows, C, l2); break;
+  switch (nit) {
+    LN_BWD_CASE(1) LN_BWD_CASE(2) LN_BWD_CASE(3) LN_BWD_CASE(4) LN_BWD_CASE(5) LN_BWD_CASE(6)
+    default:
+      if constexpr (sizeof(T) == 4) { switch (nit) { LN_BWD_CASE(7) LN_BWD_CASE(8) } }
+      else LMV_FAIL(LMV_ERR_SHAPE, "layernorm_bwd: C=%d too wide", C);
+  }
+#undef LN_BWD_CASE
+  LMV_CHECK_LAUNCH("layernorm_bwd");
+  return LMV_OK;
+}
+
+}  // namespace
+
+extern "C" int lmv_layernorm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* stats, int64_t rows, int C, float eps,
+                                 int dtype, void* stream) {
+  if (rows <= 0) return LMV_OK;
+  if (C <= 0 || (C % 8)) LMV_FAIL(LMV_ERR_SHAPE, "layernorm: C=%d must be a positive multiple of 8", C);
+  if (!x || !gamma || !beta || !y || !lmv_aligned16(x) || !lmv_aligned16(y) || !lmv_aligned16(gamma) || !lmv_aligned16(beta))
+    LMV_FAIL(LMV_ERR_SHAPE, "layernorm: null or misaligned operand");
+  if (dtype == LMV_BF16) return launch_fwd<bf16_t>(x, gamma, beta, y, stats, rows, C, eps, (hipStream_t)stream);
+  if (dtype == LMV_F32) return launch_fwd<float>(x, gamma, beta, y, stats, rows, C, eps, (hipStream_t)stream);
+  LMV_FAIL(LMV_ERR_DTYPE, "layernorm: unsupported dtype %d", dtype);
+}
+
+extern "C" int lmv_layernorm_bwd(const void* dy, const void* x, const float* stats, const float* gamma, const void* dres, void* dx,
+                                 float* dgamma, float* dbeta, int64_t rows, int C, int dtype, void* stream) {
+  if (rows <= 0) return LMV_OK;
+  if (C <= 0 || (C % 8)) LMV_FAIL(LMV_ERR_SHAPE, "layernorm_bwd: C=%d must be a positive multiple of 8", C);
+  if (!dy || !x || !stats || !gamma || !dx || !dgamma || !dbeta || !lmv_aligned16(dy) || !lmv_aligned16(x) || !lmv_aligned16(dx) || !lmv_aligned16(dres))
+    LMV_FAIL(LMV_ERR_SHAPE, "layernorm_bwd: null or misaligned operand");
+  if (dtype == LMV_BF16) return launch_bwd<bf16_t>(dy, x, stats, gamma, dres, dx, dgamma, dbeta, rows, C, (hipStream_t)stream);
+  if (dtype == LMV_F32) return launch_bwd<float>(dy, x, stats, gamma, dres, dx, dgamma, dbeta, rows, C, (hipStream_t)stream);
+  LMV_FAIL(LMV_ERR_DTYPE, "layernorm_bwd: unsupported dtype %d", dtype);
+}

@@ -1,0 +1,397 @@
+"""Host-side mirror of the reference's model interface (models/lemevit.py) over the HIP kernels.
+
+Same class names, constructor arguments, ``forward`` signatures and -- crucially -- the same
+``state_dict()`` keys and shapes as the reference, so reference checkpoints load
+unchanged and ``benchmark.py`` / ``main.py`` style callers (``create_model('lemevit_base')``,
+``model(x)``, DDP, optimizers, autocast) work as before.  What differs is underneath:
+
+* activations stay token-major [B, N, C] through a whole stage (no NCHW<->NLC bounce per block);
+* every LeMeBlock is ONE autograd node whose forward and backward are schedules of hand-written
+  gfx950 kernels (lemevit_amd/blocks.py);
+* the batch-invariant meta-token prefix (``meta_tokens.repeat`` + ``meta_token_downsample[0]``,
+  models/lemevit.py:812,833) is computed once and broadcast.
+
+Boundary glue still served by PyTorch-ROCm library ops this round: the stem
+and stride-2 down-sample conv+BatchNorm, the 16-token meta MLPs, and the BN/LN/mean-pool/head tail.
+
+Compute dtype: fp32 input without autocast -> exact-fp32 kernels; bf16 input (``model.to(bfloat16)``)
+or ``torch.autocast('cuda', torch.bfloat16)`` -> bf16 MFMA kernels with fp32 accumulation, fp32
+statistics, fp32 master weights and gradients (the bf16 matrix copies are cached per parameter version).
+"""
+from __future__ import annotations
+
+import weakref
+from collections import OrderedDict
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import ops
+from .blocks import PARAM_NAMES, block_backward, block_forward
+from .ops import Prob
+
+Tensor = torch.Tensor
+
+
+def _cfg(url: str = "", **kwargs) -> dict:
+    """timm.models.vision_transformer._cfg equivalent (models/lemevit.py:22,866)."""
+    return dict(url=url, num_classes=1000, input_size=(3, 224, 224), pool_size=None, crop_pct=0.9, interpolation="bicubic",
+                fixed_input_size=True, mean=(0.485, 0.456, 0.406), std=(0.229, 0.224, 0.225),
+                first_conv="patch_embed.proj", classifier="head", **kwargs)
+
+
+# ------------------------------------------------------------------------------------------------
+# compute-dtype copies of parameters
+# ------------------------------------------------------------------------------------------------
+_copy_cache: Dict[int, tuple] = {}
+
+
+def _is_matrix(name: str) -> bool:
+    return name.endswith(".weight") and (name.startswith("attn.") or name.startswith("mlp."))
+
+
+def compute_copy(p: Tensor, want: torch.dtype) -> Tensor:
+    """Detached tensor with p's values in dtype `want`; casts are cached per parameter version."""
+    if p.dtype == want:
+        return p.detach()
+    key = id(p)
+    ent = _copy_cache.get(key)
+    if ent is not None and ent[0]() is p and ent[1] == p._version and ent[2].dtype == want and ent[2].device == p.device:
+        return ent[2]
+    t = ops.cast(p.detach().contiguous(), want)
+    _copy_cache[key] = (weakref.ref(p), p._version, t)
+    return t
+
+
+def _resolve_dtype(x: Tensor) -> torch.dtype:
+    if not x.is_cuda:
+        raise RuntimeError("lemevit_amd: the model runs on an MI355X only -- move the model and inputs to 'cuda' "
+                           "(the CPU restatement under oracle/ is test infrastructure, not a fallback)")
+    if torch.is_autocast_enabled():
+        dt = torch.get_autocast_gpu_dtype()
+        if dt != torch.bfloat16:
+            raise NotImplementedError("lemevit_amd: autocast dtype must be torch.bfloat16 (fp16 kernels are not built)")
+        return dt
+    if x.dtype in (torch.float32, torch.bfloat16):
+        return x.dtype
+    raise NotImplementedError(f"lemevit_amd: unsupported input dtype {x.dtype}")
+
+
+# ------------------------------------------------------------------------------------------------
+# one autograd node per block
+# ------------------------------------------------------------------------------------------------
+class _BlockFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, c, kind, H, W, masks, names, *params):
+        cd = x.dtype
+        P = {n: compute_copy(p, cd if _is_matrix(n) else torch.float32) for n, p in zip(names, params)}
+        xo, co, saved = block_forward(kind, x, c, H, W, P, masks, save=True)
+        ctx.kind, ctx.H, ctx.W, ctx.masks, ctx.names = kind, H, W, masks, names
+        ctx.saved, ctx.P = saved, P
+        ctx.pmeta = [(p.shape, p.dtype) for p in params]
+        ctx.cshape = c.shape
+        if kind == "C":
+            return co                      # x passes through unchanged outside the node (models/lemevit.py:610)
+        return xo, co
+
+    @staticmethod
+    def backward(ctx, *grads):
+        kind, names, P = ctx.kind, ctx.names, ctx.P
+        if kind == "C":
+            dx, dc = None, grads[0]
+        else:
+            dx, dc = grads
+        x0 = ctx.saved[0]
+        if dc is None:
+            dc = torch.zeros(ctx.cshape, device=x0.device, dtype=x0.dtype)
+        if dx is None and kind != "C":
+            dx = torch.zeros_like(x0)
+        sizes = [int(torch.Size(s).numel()) for s, _ in ctx.pmeta]
+        pad = [(n + 3) // 4 * 4 for n in sizes]                 # keep every slice 16-byte aligned
+        flat = torch.zeros(sum(pad), device=x0.device, dtype=torch.float32)
+        G, off = {}, 0
+        for n, (shape, _), sz, pd in zip(names, ctx.pmeta, sizes, pad):
+            G[n] = flat[off:off + sz].view(shape)
+            off += pd
+        dx0, dc0 = block_backward(kind, ctx.saved, None if dx is None else dx.contiguous(), dc.contiguous(), ctx.H, ctx.W, P, G, ctx.masks)
+        ctx.saved = None
+        pg = [G[n] if dt == torch.float32 else G[n].to(dt) for n, (_, dt) in zip(names, ctx.pmeta)]
+        return (dx0, dc0, None, None, None, None, None, *pg)
+
+
+def run_block(kind: str, x: Tensor, c: Tensor, H: int, W: int, params: "OrderedDict[str, Tensor]",
+              masks: Sequence[Optional[Tensor]]) -> Tuple[Tensor, Tensor]:
+    """LeMeBlock on token-major tensors; picks the autograd node or the no-grad fast path."""
+    names = PARAM_NAMES[kind]
+    plist = [params[n] for n in names]
+    need_grad = torch.is_grad_enabled() and (x.requires_grad or c.requires_grad or any(p.requires_grad for p in plist))
+    if need_grad:
+        out = _BlockFn.apply(x, c, kind, H, W, tuple(masks), names, *plist)
+        return (x, out) if kind == "C" else out
+    cd = x.dtype
+    P = {n: compute_copy(p, cd if _is_matrix(n) else torch.float32) for n, p in zip(names, plist)}
+    xo, co, _ = block_forward(kind, x, c, H, W, P, masks, save=False)
+    return xo, co
+
+
+# ------------------------------------------------------------------------------------------------
+# attention modules (parameter containers with the reference's names + inference forward)
+# ------------------------------------------------------------------------------------------------
+def _lin_probs(pairs, dtype):
+    return [Prob(a, compute_copy(m.weight, dtype), o, bias=compute_copy(m.bias, torch.float32)) for a, m, o in pairs]
+
+
+class StandardAttention(nn.Module):
+    """models/lemevit.py:156-217.  forward(x [B,L,C]) -> [B,L,C] (inference path; training runs inside the block node)."""
+
+    def __init__(self, dim, num_heads, scale=None, bias=False, attn_drop=0.0, proj_drop=0.0, **kwargs):
+        super().__init__()
+        assert dim % num_heads == 0, f"dim {dim} not divisible by num_heads {num_heads}"
+        assert dim // num_heads == ops.HEAD_DIM, "lemevit_amd kernels are built for head_dim 32 (all registered variants)"
+        self.num_heads = num_heads
+        self.qkv = nn.Linear(dim, 3 * dim)
+        self.proj = nn.Linear(dim, dim)
+
+    @torch.no_grad()
+    def forward(self, x):
+        x = x.contiguous()
+        C = x.shape[-1]
+        qkv = torch.empty(x.shape[:-1] + (3 * C,), device=x.device, dtype=x.dtype)
+        ops.linear_fwd(_lin_probs([(x, self.qkv, qkv)], x.dtype), 3 * C, C)
+        ao, _ = ops.attn_fwd((qkv, 0), (qkv, C), (qkv, 2 * C), C, ops.SDPA_SCALE)
+        out = torch.empty_like(x)
+        ops.linear_fwd(_lin_probs([(ao, self.proj, out)], x.dtype), C, C)
+        return out
+
+
+class DualCrossAttention(nn.Module):
+    """models/lemevit.py:220-324.  forward(x [B,N,C], c [B,M,C]) -> (x', c')."""
+
+    def __init__(self, dim, num_heads, scale=None, bias=False, attn_drop=0.0, proj_drop=0.0, **kwargs):
+        super().__init__()
+        assert dim % num_heads == 0 and dim // num_heads == ops.HEAD_DIM
+        self.num_heads = num_heads
+        self.scale = scale or dim ** (-0.5)
+        self.qkv1 = nn.Linear(dim, 3 * dim)
+        self.qkv2 = nn.Linear(dim, 3 * dim)
+        self.proj_x = nn.Linear(dim, dim)
+        self.proj_c = nn.Linear(dim, dim)
+
+    @torch.no_grad()
+    def forward(self, x, c):
+        x, c = x.contiguous(), c.contiguous()
+        C, N, M = x.shape[-1], x.shape[1], c.shape[1]
+        sx, sc = ops.dca_scales(N, M, C)
+        q1 = torch.empty(x.shape[:-1] + (3 * C,), device=x.device, dtype=x.dtype)
+        q2 = torch.empty(c.shape[:-1] + (3 * C,), device=x.device, dtype=x.dtype)
+        ops.linear_fwd(_lin_probs([(x, self.qkv1, q1), (c, self.qkv2, q2)], x.dtype), 3 * C, C)
+        aox, _ = ops.attn_fwd((q1, 0), (q2, C), (q2, 2 * C), C, sx)
+        aoc, _ = ops.attn_fwd((q2, 0), (q1, C), (q1, 2 * C), C, sc)
+        ox, oc = torch.empty_like(x), torch.empty_like(c)
+        ops.linear_fwd(_lin_probs([(aox, self.proj_x, ox), (aoc, self.proj_c, oc)], x.dtype), C, C)
+        return ox, oc
+
+
+class CrossAttention(nn.Module):
+    """models/lemevit.py:425-497.  forward(x [B,N,C], c [B,M,C]) -> c'."""
+
+    def __init__(self, dim, num_heads, scale=None, bias=False, attn_drop=0.0, proj_drop=0.0, **kwargs):
+        super().__init__()
+        assert dim % num_heads == 0 and dim // num_heads == ops.HEAD_DIM
+        self.num_heads = num_heads
+        self.q = nn.Linear(dim, dim)
+        self.kv = nn.Linear(dim, 2 * dim)
+        self.proj = nn.Linear(dim, dim)
+
+    @torch.no_grad()
+    def forward(self, x, c):
+        x, c = x.contiguous(), c.contiguous()
+        C = x.shape[-1]
+        kv = torch.empty(x.shape[:-1] + (2 * C,), device=x.device, dtype=x.dtype)
+        q = torch.empty_like(c)
+        ops.linear_fwd(_lin_probs([(x, self.kv, kv)], x.dtype), 2 * C, C)
+        ops.linear_fwd(_lin_probs([(c, self.q, q)], x.dtype), C, C)
+        ao, _ = ops.attn_fwd((q, 0), (kv, 0), (kv, C), C, ops.SDPA_SCALE)
+        out = torch.empty_like(c)
+        ops.linear_fwd(_lin_probs([(ao, self.proj, out)], x.dtype), C, C)
+        return out
+
+
+class LeMeBlock(nn.Module):
+    """models/lemevit.py:500-660 (pre_norm=True, no layer scale, cpe_ks=3, mlp_dwconv=False: the shipped variants)."""
+
+    def __init__(self, dim, attn_drop, proj_drop, drop_path=0.0, attn_type=None, layer_scale_init_value=-1, num_heads=8, qk_dim=None,
+                 mlp_ratio=4, mlp_dwconv=False, cpe_ks=3, pre_norm=True):
+        super().__init__()
+        if layer_scale_init_value > 0 or not pre_norm or mlp_dwconv or cpe_ks != 3:
+            raise NotImplementedError("lemevit_amd builds the live path of the shipped variants: pre_norm, no layer scale, cpe_ks=3, no mlp_dwconv")
+        self.pos_embed = nn.Conv2d(dim, dim, kernel_size=cpe_ks, padding=1, groups=dim)
+        self.norm1 = nn.LayerNorm(dim, eps=1e-6)
+        self.attn_type = attn_type or "S"
+        if self.attn_type == "D":
+            self.attn = DualCrossAttention(dim=dim, num_heads=num_heads)
+        elif self.attn_type == "S":
+            self.attn = StandardAttention(dim=dim, num_heads=num_heads)
+        elif self.attn_type == "C":
+            self.attn = CrossAttention(dim=dim, num_heads=num_heads)
+        else:
+            raise NotImplementedError(f"attention type {attn_type!r} (the 'D2' variant is a SURVEY section 8 f4 'next' row)")
+        self.norm2 = nn.LayerNorm(dim, eps=1e-6)
+        self.mlp = nn.Sequential(nn.Linear(dim, int(mlp_ratio * dim)), nn.Identity(), nn.GELU(), nn.Linear(int(mlp_ratio * dim), dim))
+        self.drop_prob = float(drop_path)
+        self._pcache = None
+
+    def _params(self) -> "OrderedDict[str, Tensor]":
+        if self._pcache is None:
+            table = dict(self.named_parameters())
+            self._pcache = OrderedDict((n, table[n]) for n in PARAM_NAMES[self.attn_type])
+        return self._pcache
+
+    def _apply(self, fn, *a, **k):     # .to()/.cuda() may replace Parameters
+        self._pcache = None
+        return super()._apply(fn, *a, **k)
+
+    def _masks(self, B: int, device) -> List[Optional[Tensor]]:
+        n = 2 if self.attn_type == "C" else 4
+        if not self.training or self.drop_prob <= 0.0:
+            return [None] * 4
+        keep = 1.0 - self.drop_prob            # timm DropPath: per-sample Bernoulli(keep) / keep, drawn independently per call
+        m = [torch.empty(B, device=device, dtype=torch.float32).bernoulli_(keep).div_(keep) for _ in range(n)]
+        return m + [None] * (4 - n)
+
+    def forward_tokens(self, x: Tensor, c: Tensor, H: int, W: int, masks=None) -> Tuple[Tensor, Tensor]:
+        """x [B, H*W, C] token-major, c [B, M, C]."""
+        if masks is None:
+            masks = self._masks(x.shape[0], x.device)
+        return run_block(self.attn_type, x, c, H, W, self._params(), masks)
+
+    def forward(self, x: Tensor, c: Tensor) -> Tuple[Tensor, Tensor]:
+        """Reference signature: x NCHW in / out (models/lemevit.py:652)."""
+        B, C, H, W = x.shape
+        xt = x.permute(0, 2, 3, 1).reshape(B, H * W, C).contiguous()
+        xt, c = self.forward_tokens(xt, c.contiguous(), H, W)
+        return xt.reshape(B, H, W, C).permute(0, 3, 1, 2), c
+
+
+# ------------------------------------------------------------------------------------------------
+# the model
+# ------------------------------------------------------------------------------------------------
+class LeMeViT(nn.Module):
+    """models/lemevit.py:663-836 -- same constructor, attributes, methods and state_dict layout."""
+
+    def __init__(self, depth=[2, 3, 4, 8, 3], in_chans=3, num_classes=1000, embed_dim=[64, 64, 128, 320, 512], head_dim=64,
+                 mlp_ratios=[4, 4, 4, 4, 4], qkv_bias=True, qk_scale=None, drop_rate=0.0, attn_drop=0.0, drop_path_rate=0.0,
+                 attn_type=["C", "D", "D", "S", "S"], queries_len=128, qk_dims=None, cpe_ks=3, pre_norm=True, mlp_dwconv=False,
+                 representation_size=None, layer_scale_init_value=-1, use_checkpoint_stages=[]):
+        super().__init__()
+        if representation_size:
+            raise NotImplementedError("representation_size is unused by every registered variant")
+        if head_dim != ops.HEAD_DIM:
+            raise NotImplementedError("lemevit_amd kernels are built for head_dim 32 (all registered variants)")
+        if queries_len > 16:
+            raise NotImplementedError("lemevit_amd kernels are built for <= 16 meta tokens (all registered variants use 16)")
+        self.num_classes = num_classes
+        self.num_features = self.embed_dim = embed_dim
+        qk_dims = qk_dims or embed_dim
+        self.num_stages = len(attn_type)
+        self.attn_type = list(attn_type)
+        self.depth = list(depth)
+
+        self.downsample_layers = nn.ModuleList()
+        self.downsample_layers.append(nn.Sequential(
+            nn.Conv2d(in_chans, embed_dim[0] // 2, kernel_size=(3, 3), stride=(2, 2), padding=(1, 1)), nn.BatchNorm2d(embed_dim[0] // 2), nn.GELU(),
+            nn.Conv2d(embed_dim[0] // 2, embed_dim[0], kernel_size=(3, 3), stride=(2, 2), padding=(1, 1)), nn.BatchNorm2d(embed_dim[0])))
+        for i in range(self.num_stages - 1):
+            if attn_type[i] == "C":
+                self.downsample_layers.append(nn.Identity())
+            else:
+                self.downsample_layers.append(nn.Sequential(
+                    nn.Conv2d(embed_dim[i], embed_dim[i + 1], kernel_size=(3, 3), stride=(2, 2), padding=(1, 1)), nn.BatchNorm2d(embed_dim[i + 1])))
+
+        self.queries_len = queries_len
+        self.meta_tokens = nn.Parameter(torch.randn(self.queries_len, embed_dim[0]), requires_grad=True)
+        self.meta_token_downsample = nn.ModuleList()
+        for i in range(self.num_stages):
+            cin = embed_dim[0] if i == 0 else embed_dim[i - 1]
+            self.meta_token_downsample.append(nn.Sequential(
+                nn.Linear(cin, cin * 4), nn.LayerNorm(cin * 4), nn.GELU(), nn.Linear(cin * 4, embed_dim[i]), nn.LayerNorm(embed_dim[i])))
+
+        self.stages = nn.ModuleList()
+        nheads = [dim // head_dim for dim in qk_dims]
+        dp_rates = [x.item() for x in torch.linspace(0, drop_path_rate, sum(depth))]
+        cur = 0
+        for i in range(self.num_stages):
+            self.stages.append(nn.ModuleList([
+                LeMeBlock(dim=embed_dim[i], attn_drop=attn_drop, proj_drop=drop_rate, drop_path=dp_rates[cur + j], attn_type=attn_type[i],
+                          layer_scale_init_value=layer_scale_init_value, num_heads=nheads[i], qk_dim=qk_dims[i], mlp_ratio=mlp_ratios[i],
+                          mlp_dwconv=mlp_dwconv, cpe_ks=cpe_ks, pre_norm=pre_norm) for j in range(depth[i])]))
+            cur += depth[i]
+
+        self.norm = nn.BatchNorm2d(embed_dim[-1])
+        self.norm_c = nn.LayerNorm(embed_dim[-1])
+        self.pre_logits = nn.Identity()
+        self.head = nn.Linear(embed_dim[-1], num_classes) if num_classes > 0 else nn.Identity()
+        self.apply(self._init_weights)
+        self.default_cfg = _cfg()
+
+    def _init_weights(self, m):                      # models/lemevit.py:789-796
+        if isinstance(m, nn.Linear):
+            nn.init.trunc_normal_(m.weight, mean=0.0, std=0.02, a=-2.0, b=2.0)
+            if m.bias is not None:
+                nn.init.constant_(m.bias, 0)
+        elif isinstance(m, nn.LayerNorm):
+            nn.init.constant_(m.bias, 0)
+            nn.init.constant_(m.weight, 1.0)
+
+    @torch.jit.ignore
+    def no_weight_decay(self):
+        return {"pos_embed", "cls_token"}
+
+    def get_classifier(self):
+        return self.head
+
+    def reset_classifier(self, num_classes, global_pool=""):
+        self.num_classes = num_classes
+        self.head = nn.Linear(self.embed_dim[-1], num_classes) if num_classes > 0 else nn.Identity()
+
+    # ---- boundary glue (PyTorch-ROCm library ops) --------------------------
+    @staticmethod
+    def _to_tokens(x: Tensor, dtype) -> Tuple[Tensor, int, int]:
+        B, C, H, W = x.shape
+        return x.permute(0, 2, 3, 1).reshape(B, H * W, C).to(dtype).contiguous(), H, W
+
+    @staticmethod
+    def _to_nchw(xt: Tensor, H: int, W: int) -> Tensor:
+        B, N, C = xt.shape
+        return xt.view(B, H, W, C).permute(0, 3, 1, 2)          # channels_last-strided view, no copy
+
+    def forward_features(self, x: Tensor, c: Optional[Tensor] = None) -> Tensor:
+        """models/lemevit.py:809-829.  c = None hoists the batch-invariant meta-token prefix."""
+        cd = _resolve_dtype(x)
+        B = x.shape[0]
+        x = x.contiguous(memory_format=torch.channels_last)
+        hoist = c is None
+        if hoist:
+            c = self.meta_tokens.unsqueeze(0)
+        xt, H, W = None, 0, 0
+        for i in range(self.num_stages):
+            if i == 0 or not isinstance(self.downsample_layers[i], nn.Identity):
+                x = self.downsample_layers[i](x if xt is None else self._to_nchw(xt, H, W))
+                xt, H, W = self._to_tokens(x, cd)
+            c = self.meta_token_downsample[i](c)
+            if hoist:
+                c = c.expand(B, -1, -1)
+                hoist = False
+            c = c.to(cd).contiguous()
+            for blk in self.stages[i]:
+                xt, c = blk.forward_tokens(xt, c, H, W)
+        xn = self.norm(self._to_nchw(xt, H, W))
+        xn = self.pre_logits(xn)
+        cn = self.pre_logits(self.norm_c(c))
+        return xn.flatten(2).mean(-1) + cn.mean(dim=1)
+
+    def forward(self, x: Tensor) -> Tensor:
+        x = self.forward_features(x, None)
+        return self.head(x)

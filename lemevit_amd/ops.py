@@ -1,0 +1,219 @@
+"""Thin torch-tensor wrappers over the C ABI (include/lemevit_hip.h).
+
+PyTorch is plumbing here: it owns device memory and the stream; every op below enqueues hand-written
+HIP kernels on ``torch.cuda.current_stream()`` and nothing else.  Tensors must live on a GPU: there is
+no CPU path (the CPU restatement lives under ``oracle/`` and is test infrastructure only).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from typing import List, Optional, Sequence, Tuple
+
+import torch
+
+from . import _lib
+from ._lib import ACT_GELU, ACT_GELU_GRAD, ACT_NONE, AttnDesc, LinearProblem, check, lib
+
+Tensor = torch.Tensor
+HEAD_DIM = 32
+
+
+def dtype_code(t: Tensor) -> int:
+    if t.dtype == torch.float32:
+        return _lib.LMV_F32
+    if t.dtype == torch.bfloat16:
+        return _lib.LMV_BF16
+    raise TypeError(f"lemevit_amd: unsupported dtype {t.dtype} (float32 and bfloat16 only)")
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _ptr(t: Optional[Tensor]) -> Optional[int]:
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise RuntimeError("lemevit_amd: tensors must be on the GPU (no CPU fallback exists)")
+    if not t.is_contiguous():
+        raise RuntimeError("lemevit_amd: tensors must be contiguous")
+    return t.data_ptr()
+
+
+def _f32(t: Optional[Tensor]) -> Optional[int]:
+    if t is not None and t.dtype != torch.float32:
+        raise TypeError("lemevit_amd: vector operands (bias, LN affine, scales, gradient accumulators) must be float32")
+    return _ptr(t)
+
+
+# -------------------------------------------------------------------------------------------
+# Linear
+# -------------------------------------------------------------------------------------------
+class Prob:
+    """One problem of a (dual) linear launch; see lmv_linear_problem."""
+    __slots__ = ("a", "w", "bias", "res", "row_scale", "aux", "out", "out_pre", "bias_grad", "rows", "rps")
+
+    def __init__(self, a, w, out, bias=None, res=None, row_scale=None, aux=None, out_pre=None, bias_grad=None, rps=0):
+        self.a, self.w, self.out, self.bias, self.res = a, w, out, bias, res
+        self.row_scale, self.aux, self.out_pre, self.bias_grad, self.rps = row_scale, aux, out_pre, bias_grad, rps
+        self.rows = a.numel() // a.shape[-1]
+
+
+def _pack(probs: Sequence[Prob]):
+    arr = (LinearProblem * len(probs))()
+    for s, p in zip(arr, probs):
+        s.a, s.w, s.out = _ptr(p.a), _ptr(p.w), _ptr(p.out)
+        s.bias, s.row_scale, s.bias_grad = _f32(p.bias), _f32(p.row_scale), _f32(p.bias_grad)
+        s.res, s.aux, s.out_pre = _ptr(p.res), _ptr(p.aux), _ptr(p.out_pre)
+        s.rows, s.rows_per_sample = p.rows, p.rps
+    return arr
+
+
+def linear_fwd(probs: Sequence[Prob], N: int, K: int, act: int = ACT_NONE) -> None:
+    """out = res + row_scale * act(a @ w^T + bias) for up to two problems sharing (N, K)."""
+    check(lib.lmv_linear_fwd(_pack(probs), len(probs), N, K, act, dtype_code(probs[0].a), _stream()), "lmv_linear_fwd")
+
+
+def linear_dx(probs: Sequence[Prob], N: int, K: int, act: int = ACT_NONE) -> None:
+    """out[r,k] = (a[r,:] @ w) (* gelu'(aux)) (+ res); a = dY [rows,N], w = W [N,K]."""
+    check(lib.lmv_linear_dx(_pack(probs), len(probs), N, K, act, dtype_code(probs[0].a), _stream()), "lmv_linear_dx")
+
+
+def linear_dw(probs: Sequence[Prob], N: int, K: int) -> None:
+    """out (fp32 [N,K]) += a^T @ w ; bias_grad (fp32 [N]) += colsum(a); a = dY [rows,N], w = X [rows,K]."""
+    check(lib.lmv_linear_dw(_pack(probs), len(probs), N, K, dtype_code(probs[0].a), _stream()), "lmv_linear_dw")
+
+
+# -------------------------------------------------------------------------------------------
+# LayerNorm
+# -------------------------------------------------------------------------------------------
+def layernorm_fwd(x: Tensor, gamma: Tensor, beta: Tensor, eps: float, want_stats: bool = False) -> Tuple[Tensor, Optional[Tensor]]:
+    C_ = x.shape[-1]
+    rows = x.numel() // C_
+    y = torch.empty_like(x)
+    stats = torch.empty((rows, 2), device=x.device, dtype=torch.float32) if want_stats else None
+    check(lib.lmv_layernorm_fwd(_ptr(x), _f32(gamma), _f32(beta), _ptr(y), _ptr(stats), rows, C_, eps, dtype_code(x), _stream()),
+          "lmv_layernorm_fwd")
+    return y, stats
+
+
+def layernorm_bwd(dy: Tensor, x: Tensor, stats: Tensor, gamma: Tensor, dgamma: Tensor, dbeta: Tensor, dres: Optional[Tensor] = None) -> Tensor:
+    """dx = dres + LN'(dy); dgamma / dbeta (fp32) are accumulated in place."""
+    C_ = x.shape[-1]
+    rows = x.numel() // C_
+    dx = torch.empty_like(x)
+    check(lib.lmv_layernorm_bwd(_ptr(dy), _ptr(x), _f32(stats), _f32(gamma), _ptr(dres), _ptr(dx), _f32(dgamma), _f32(dbeta),
+                                rows, C_, dtype_code(x), _stream()), "lmv_layernorm_bwd")
+    return dx
+
+
+# -------------------------------------------------------------------------------------------
+# depth-wise 3x3 position embedding (token-major x: [B, H*W, C])
+# -------------------------------------------------------------------------------------------
+def dwconv_residual_fwd(x: Tensor, weight: Tensor, bias: Tensor, H: int, W: int) -> Tensor:
+    B, N, C_ = x.shape
+    assert N == H * W
+    y = torch.empty_like(x)
+    check(lib.lmv_dwconv3x3_residual_fwd(_ptr(x), _f32(weight), _f32(bias), _ptr(y), B, H, W, C_, dtype_code(x), _stream()),
+          "lmv_dwconv3x3_residual_fwd")
+    return y
+
+
+def dwconv_residual_bwd_data(dy: Tensor, weight: Tensor, H: int, W: int) -> Tensor:
+    B, N, C_ = dy.shape
+    dx = torch.empty_like(dy)
+    check(lib.lmv_dwconv3x3_residual_bwd_data(_ptr(dy), _f32(weight), _ptr(dx), B, H, W, C_, dtype_code(dy), _stream()),
+          "lmv_dwconv3x3_residual_bwd_data")
+    return dx
+
+
+def dwconv_bwd_weight(dy: Tensor, x: Tensor, dweight: Tensor, dbias: Tensor, H: int, W: int) -> None:
+    B, N, C_ = dy.shape
+    check(lib.lmv_dwconv3x3_bwd_weight(_ptr(dy), _ptr(x), _f32(dweight), _f32(dbias), B, H, W, C_, dtype_code(dy), _stream()),
+          "lmv_dwconv3x3_bwd_weight")
+
+
+# -------------------------------------------------------------------------------------------
+# attention cores; q/k/v are (tensor, column offset) views into packed projections [B, L, X*C]
+# -------------------------------------------------------------------------------------------
+_ws_cache = {}
+
+
+def _workspace(nbytes: int, device) -> Tensor:
+    key = (device, torch.cuda.current_stream().cuda_stream)
+    ws = _ws_cache.get(key)
+    if ws is None or ws.numel() < nbytes:
+        ws = torch.empty(max(nbytes, 1 << 20), device=device, dtype=torch.uint8)
+        _ws_cache[key] = ws
+    return ws
+
+
+def _desc(q: Tuple[Tensor, int], k: Tuple[Tensor, int], v: Tuple[Tensor, int], o: Tensor, lse: Optional[Tensor], C_: int, scale: float) -> AttnDesc:
+    qt, qo = q; kt, ko = k; vt, vo = v
+    es = qt.element_size()
+    d = AttnDesc()
+    d.q, d.k, d.v = _ptr(qt) + qo * es, _ptr(kt) + ko * es, _ptr(vt) + vo * es
+    d.o, d.lse = _ptr(o), _f32(lse)
+    B, Lq, Lk = qt.shape[0], qt.shape[1], kt.shape[1]
+    d.q_bs, d.q_rs = Lq * qt.shape[2], qt.shape[2]
+    d.k_bs, d.k_rs = Lk * kt.shape[2], kt.shape[2]
+    d.v_bs, d.v_rs = Lk * vt.shape[2], vt.shape[2]
+    d.o_bs, d.o_rs = Lq * o.shape[2], o.shape[2]
+    d.B, d.H, d.Lq, d.Lk, d.scale = B, C_ // HEAD_DIM, Lq, Lk, scale
+    return d
+
+
+def attn_fwd(q, k, v, C_: int, scale: float, want_lse: bool = False) -> Tuple[Tensor, Optional[Tensor]]:
+    """o[b,l,h,:] = softmax(scale q.k^T) v with q/k/v = (packed tensor [B,L,XC], column offset)."""
+    qt = q[0]
+    B, Lq, Lk = qt.shape[0], qt.shape[1], k[0].shape[1]
+    o = torch.empty((B, Lq, C_), device=qt.device, dtype=qt.dtype)
+    lse = torch.empty((B, C_ // HEAD_DIM, Lq), device=qt.device, dtype=torch.float32) if want_lse else None
+    d = _desc(q, k, v, o, lse, C_, scale)
+    nb = lib.lmv_attn_workspace_bytes(d.B, d.H, Lq, Lk, 0)
+    ws = _workspace(nb, qt.device)
+    check(lib.lmv_attn_fwd(C.byref(d), ws.data_ptr(), ws.numel(), dtype_code(qt), _stream()), "lmv_attn_fwd")
+    return o, lse
+
+
+def attn_bwd(q, k, v, o: Tensor, lse: Tensor, d_o: Tensor, dq, dk, dv, C_: int, scale: float) -> None:
+    """Writes dq/dk/dv = (packed grad tensor, column offset) with the layout of q/k/v."""
+    d = _desc(q, k, v, o, lse, C_, scale)
+    es = q[0].element_size()
+    d.d_o = _ptr(d_o)
+    d.dq, d.dk, d.dv = _ptr(dq[0]) + dq[1] * es, _ptr(dk[0]) + dk[1] * es, _ptr(dv[0]) + dv[1] * es
+    nb = lib.lmv_attn_workspace_bytes(d.B, d.H, d.Lq, d.Lk, 1)
+    ws = _workspace(nb, o.device)
+    check(lib.lmv_attn_bwd(C.byref(d), ws.data_ptr(), ws.numel(), dtype_code(o), _stream()), "lmv_attn_bwd")
+
+
+def dca_scales(N: int, M: int, C_: int) -> Tuple[float, float]:
+    """models/lemevit.py:235,255-256."""
+    base = C_ ** (-0.5)
+    return math.log(M, N) * base, math.log(N, N) * base
+
+
+SDPA_SCALE = HEAD_DIM ** (-0.5)
+
+
+# -------------------------------------------------------------------------------------------
+# utilities
+# -------------------------------------------------------------------------------------------
+def cast(src: Tensor, dtype: torch.dtype) -> Tensor:
+    dst = torch.empty(src.shape, device=src.device, dtype=dtype)
+    check(lib.lmv_cast(_ptr(src), dtype_code(src), _ptr(dst), dtype_code(dst), src.numel(), _stream()), "lmv_cast")
+    return dst
+
+
+def row_scale(x: Tensor, scale: Tensor, rows_per_sample: int) -> Tensor:
+    y = torch.empty_like(x)
+    C_ = x.shape[-1]
+    check(lib.lmv_row_scale(_ptr(x), _f32(scale), _ptr(y), x.numel() // C_, C_, rows_per_sample, dtype_code(x), _stream()), "lmv_row_scale")
+    return y
+
+
+def adamw_flat(param: Tensor, grad: Tensor, exp_avg: Tensor, exp_avg_sq: Tensor, wd_mask: Optional[Tensor], lr: float, beta1: float,
+               beta2: float, eps: float, weight_decay: float, step: int) -> None:
+    check(lib.lmv_adamw_flat(_f32(param), _f32(grad), _f32(exp_avg), _f32(exp_avg_sq), _f32(wd_mask), param.numel(), lr, beta1, beta2, eps,
+                             weight_decay, step, _stream()), "lmv_adamw_flat")

@@ -1,0 +1,264 @@
+"""Per-kernel parity on a real MI355X: every C-ABI op vs a float64 CPU restatement of the same math
+(oracle primitives) on identical (bf16-rounded, in bf16 mode) inputs.
+
+Tolerances (BASELINE.json north_star): fp32 1e-5, bf16 1e-3, both relative to the output's max-abs;
+in bf16 mode one bf16 output rounding (2^-8 * |ref|, elementwise) is allowed on top, because the
+kernel's *output* is itself stored in bf16."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from detfill import det_tensor
+from oracle import lemevit_oracle as O
+
+DTYPES = [torch.float32, torch.bfloat16]
+
+
+def dev():
+    return torch.device("cuda:0")
+
+
+def ops():
+    from lemevit_amd import ops as _ops
+    return _ops
+
+
+def rnd(shape, name, dtype, scale=1.0):
+    """deterministic tensor, rounded to `dtype`; returns (gpu tensor in dtype, float64 cpu copy of the rounded values)"""
+    t = det_tensor(shape, name, 7, scale).to(dtype)
+    return t.to(dev()), t.to(torch.float64)
+
+
+def assert_close(out, ref, dtype, what, tol32=1e-5, tol16=1e-3):
+    out = out.detach().to("cpu", torch.float64)
+    ref = ref.to(torch.float64)
+    assert out.shape == ref.shape, (what, out.shape, ref.shape)
+    assert torch.isfinite(out).all(), what + ": non-finite output"
+    mx = max(float(ref.abs().max()), 1e-30)
+    err = (out - ref).abs()
+    if dtype == torch.float32:
+        assert float(err.max()) <= tol32 * mx, f"{what}: max-abs err {float(err.max()):.3e} vs {tol32 * mx:.3e}"
+    else:
+        bound = tol16 * mx + ref.abs() * 2.0 ** -8
+        bad = err > bound
+        assert not bool(bad.any()), f"{what}: {int(bad.sum())} elements off, worst {float((err - bound).max()):.3e} over (max-abs {mx:.3e})"
+
+
+def gelu64(x):
+    return 0.5 * x * (1 + torch.erf(x / math.sqrt(2)))
+
+
+def gelu_grad64(x):
+    return 0.5 * (1 + torch.erf(x / math.sqrt(2))) + x * torch.exp(-0.5 * x * x) / math.sqrt(2 * math.pi)
+
+
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("rows,N,K", [(300, 96, 64), (4096, 288, 96), (1000, 1152, 384), (129, 384, 1536), (16, 64, 256), (2051, 1000, 512)])
+def test_linear_fwd(dtype, rows, N, K):
+    o = ops()
+    a, a64 = rnd((rows, K), "a", dtype)
+    w, w64 = rnd((N, K), "w", dtype, 1 / math.sqrt(K))
+    bias = det_tensor((N,), "b", 7, 0.5).to(dev()); res, res64 = rnd((rows, N), "res", dtype)
+    rps = 7
+    nsamp = (rows + rps - 1) // rps
+    rs = (det_tensor((nsamp,), "rs", 7).abs() + 0.5).to(dev())
+    # plain
+    out = torch.empty((rows, N), device=dev(), dtype=dtype)
+    o.linear_fwd([o.Prob(a, w, out)], N, K)
+    assert_close(out, a64 @ w64.t(), dtype, "plain")
+    # bias + gelu + pre-activation copy + DropPath scale + residual
+    pre = torch.empty_like(out)
+    o.linear_fwd([o.Prob(a, w, out, bias=bias, res=res, row_scale=rs, out_pre=pre, rps=rps)], N, K, o.ACT_GELU)
+    u = a64 @ w64.t() + bias.cpu().double()
+    scale_rows = rs.cpu().double()[torch.arange(rows) // rps][:, None]
+    assert_close(pre, u, dtype, "pre")
+    assert_close(out, res64 + scale_rows * gelu64(u), dtype, "epilogue")
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_linear_dual(dtype):
+    o = ops()
+    N, K = 192, 96
+    ax, ax64 = rnd((1500, K), "ax", dtype); ac, ac64 = rnd((48, K), "ac", dtype)
+    w1, w164 = rnd((N, K), "w1", dtype, 0.1); w2, w264 = rnd((N, K), "w2", dtype, 0.1)
+    b1 = det_tensor((N,), "b1", 7).to(dev()); b2 = det_tensor((N,), "b2", 7).to(dev())
+    ox = torch.empty((1500, N), device=dev(), dtype=dtype); oc = torch.empty((48, N), device=dev(), dtype=dtype)
+    o.linear_fwd([o.Prob(ax, w1, ox, bias=b1), o.Prob(ac, w2, oc, bias=b2)], N, K)
+    assert_close(ox, ax64 @ w164.t() + b1.cpu().double(), dtype, "x")
+    assert_close(oc, ac64 @ w264.t() + b2.cpu().double(), dtype, "c")
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("rows,N,K", [(300, 96, 64), (4100, 288, 96), (777, 1536, 384), (130, 384, 1536), (513, 1000, 512)])
+def test_linear_dx(dtype, rows, N, K):
+    o = ops()
+    dy, dy64 = rnd((rows, N), "dy", dtype)
+    w, w64 = rnd((N, K), "w", dtype, 1 / math.sqrt(N))
+    u, u64 = rnd((rows, K), "u", dtype, 2.0); res, res64 = rnd((rows, K), "res", dtype)
+    out = torch.empty((rows, K), device=dev(), dtype=dtype)
+    o.linear_dx([o.Prob(dy, w, out)], N, K)
+    assert_close(out, dy64 @ w64, dtype, "dx")
+    o.linear_dx([o.Prob(dy, w, out, aux=u, res=res)], N, K, o.ACT_GELU_GRAD)
+    assert_close(out, res64 + (dy64 @ w64) * gelu_grad64(u64), dtype, "dx*gelu'+res")
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("rows,N,K", [(300, 96, 64), (40000, 288, 96), (5000, 1152, 384), (2049, 384, 1536), (128, 1000, 512)])
+def test_linear_dw(dtype, rows, N, K):
+    o = ops()
+    dy, dy64 = rnd((rows, N), "dy", dtype)
+    x, x64 = rnd((rows, K), "x", dtype)
+    dyc, dyc64 = rnd((33, N), "dyc", dtype); xc, xc64 = rnd((33, K), "xc", dtype)
+    dw = torch.zeros((N, K), device=dev()); db = torch.zeros((N,), device=dev())
+    # two problems accumulating into the SAME weight gradient (shared weights of x- and c-path)
+    o.linear_dw([o.Prob(dy, x, dw, bias_grad=db), o.Prob(dyc, xc, dw, bias_grad=db)], N, K)
+    ref_w = dy64.t() @ x64 + dyc64.t() @ xc64
+    ref_b = dy64.sum(0) + dyc64.sum(0)
+    # fp32 atomics: order-dependent rounding, scale tolerance with sqrt(rows)
+    assert_close(dw, ref_w, torch.float32, "dw", tol32=3e-6 * math.sqrt(rows) if dtype == torch.float32 else 2e-5)
+    assert_close(db, ref_b, torch.float32, "db", tol32=3e-6 * math.sqrt(rows) if dtype == torch.float32 else 2e-5)
+
+
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("rows,C", [(1000, 64), (3137, 96), (800, 192), (212, 320), (333, 384), (65, 512), (48, 1280), (16, 2048), (5, 128)])
+def test_layernorm(dtype, rows, C):
+    o = ops()
+    x, x64 = rnd((rows, C), "x", dtype, 2.0)
+    x64 = x64 + 0.0
+    g = (det_tensor((C,), "g", 7, 0.3) + 1).to(dev()); b = det_tensor((C,), "be", 7, 0.2).to(dev())
+    y, stats = o.layernorm_fwd(x, g, b, 1e-6, want_stats=True)
+    g64, b64 = g.cpu().double(), b.cpu().double()
+    assert_close(y, O.layer_norm(x64, g64, b64, 1e-6), dtype, "ln fwd")
+    mu = x64.mean(-1); rstd = 1 / torch.sqrt(x64.var(-1, unbiased=False) + 1e-6)
+    assert_close(stats[:, 0], mu, torch.float32, "mean", 2e-5); assert_close(stats[:, 1], rstd, torch.float32, "rstd", 2e-5)
+    # backward
+    dy, dy64 = rnd((rows, C), "dy", dtype); dres, dres64 = rnd((rows, C), "dres", dtype)
+    xr = x64.clone().requires_grad_(True); gr = g64.clone().requires_grad_(True); br = b64.clone().requires_grad_(True)
+    (O.layer_norm(xr, gr, br, 1e-6) * dy64).sum().backward()
+    dg = torch.zeros(C, device=dev()); dbt = torch.zeros(C, device=dev())
+    dx = o.layernorm_bwd(dy, x, stats, g, dg, dbt, dres=dres)
+    assert_close(dx, xr.grad + dres64, dtype, "ln dx", tol32=2e-5, tol16=2e-3)
+    assert_close(dg, gr.grad, torch.float32, "dgamma", 2e-5); assert_close(dbt, br.grad, torch.float32, "dbeta", 2e-5)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("B,H,W,C", [(2, 56, 56, 96), (3, 7, 7, 512), (1, 35, 35, 64), (2, 14, 14, 384), (1, 5, 3, 32)])
+def test_dwconv(dtype, B, H, W, C):
+    o = ops()
+    x, x64 = rnd((B, H * W, C), "x", dtype)
+    wt = det_tensor((C, 1, 3, 3), "w", 7, 0.4).to(dev()); bs = det_tensor((C,), "b", 7, 0.2).to(dev())
+    sd = {"p.pos_embed.weight": wt.cpu().double().requires_grad_(True), "p.pos_embed.bias": bs.cpu().double().requires_grad_(True)}
+    xr = x64.clone().requires_grad_(True)
+    ref = O.pos_embed_residual(sd, "p.", xr, H, W)
+    y = o.dwconv_residual_fwd(x, wt, bs, H, W)
+    assert_close(y, ref.detach(), dtype, "dwconv fwd")
+    dy, dy64 = rnd((B, H * W, C), "dy", dtype)
+    (ref * dy64).sum().backward()
+    dx = o.dwconv_residual_bwd_data(dy, wt, H, W)
+    assert_close(dx, xr.grad, dtype, "dwconv dx")
+    dw = torch.zeros_like(wt); db = torch.zeros_like(bs)
+    o.dwconv_bwd_weight(dy, x, dw, db, H, W)
+    assert_close(dw, sd["p.pos_embed.weight"].grad, torch.float32, "dwconv dw", 3e-5); assert_close(db, sd["p.pos_embed.bias"].grad, torch.float32, "dwconv db", 3e-5)
+
+
+# ------------------------------------------------------------------------------------------------
+def _attn_ref(q, k, v, h, scale):
+    """q [B,Lq,C], k/v [B,Lk,C] float64 -> o [B,Lq,C], via the oracle's sdpa."""
+    (qh,) = O.split_heads(q, 1, h); (kh,) = O.split_heads(k, 1, h); (vh,) = O.split_heads(v, 1, h)
+    return O.merge_heads(O.sdpa(qh, kh, vh, scale))
+
+
+ATTN_CASES = [  # name, B, Lq, Lk, C, self (packed qkv) ?
+    ("sa196", 2, 196, 196, 384, True), ("sa49", 3, 49, 49, 512, True), ("sa16", 2, 16, 16, 64, True), ("sa577", 1, 577, 577, 64, True),
+    ("fewq", 2, 16, 3136, 96, False), ("fewq_odd", 1, 16, 1225, 64, False), ("fewq_short", 2, 16, 70, 64, False),
+    ("fewk", 2, 3136, 16, 96, False), ("fewk_odd", 1, 1225, 16, 64, False), ("gen", 2, 100, 37, 64, False),
+]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("case", ATTN_CASES, ids=[c[0] for c in ATTN_CASES])
+def test_attention(dtype, case):
+    o = ops()
+    name, B, Lq, Lk, C, packed = case
+    h = C // 32
+    scale = 0.2 if not packed else 32 ** -0.5
+    if packed:
+        qkv, qkv64 = rnd((B, Lq, 3 * C), name + "qkv", dtype, 1.5)
+        q = (qkv, 0); k = (qkv, C); v = (qkv, 2 * C)
+        q64, k64, v64 = qkv64[..., :C], qkv64[..., C:2 * C], qkv64[..., 2 * C:]
+    else:   # q from a packed [B,Lq,3C] (its first third), k/v from a packed [B,Lk,2C]
+        qp, qp64 = rnd((B, Lq, 3 * C), name + "q", dtype, 1.5); kv, kv64 = rnd((B, Lk, 2 * C), name + "kv", dtype, 1.5)
+        q = (qp, 0); k = (kv, 0); v = (kv, C)
+        q64, k64, v64 = qp64[..., :C], kv64[..., :C], kv64[..., C:]
+    q64 = q64.clone().requires_grad_(True); k64 = k64.clone().requires_grad_(True); v64 = v64.clone().requires_grad_(True)
+    ref = _attn_ref(q64, k64, v64, h, scale)
+    out, lse = o.attn_fwd(q, k, v, C, scale, want_lse=True)
+    assert_close(out, ref.detach(), dtype, name + " fwd")
+    (qh,) = O.split_heads(q64.detach(), 1, h); (kh,) = O.split_heads(k64.detach(), 1, h)
+    assert_close(lse, torch.logsumexp(qh @ kh.transpose(-1, -2) * scale, -1), torch.float32, name + " lse", 2e-5)
+    # backward
+    do, do64 = rnd((B, Lq, C), name + "do", dtype)
+    (ref * do64).sum().backward()
+    if packed:
+        dqkv = torch.full_like(qkv, float("nan"))
+        o.attn_bwd(q, k, v, out, lse, do, (dqkv, 0), (dqkv, C), (dqkv, 2 * C), C, scale)
+        got = dqkv; want = torch.cat([q64.grad, k64.grad, v64.grad], -1)
+        assert_close(got, want, dtype, name + " dqkv", tol32=2e-5, tol16=3e-3)
+    else:
+        dqp = torch.zeros_like(qp); dkv = torch.full_like(kv, float("nan"))
+        o.attn_bwd(q, k, v, out, lse, do, (dqp, 0), (dkv, 0), (dkv, C), C, scale)
+        assert_close(dqp[..., :C], q64.grad, dtype, name + " dq", tol32=2e-5, tol16=3e-3)
+        assert_close(dkv, torch.cat([k64.grad, v64.grad], -1), dtype, name + " dkv", tol32=2e-5, tol16=3e-3)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_named_cores(dtype):
+    """lmv_sa_core_fwd / lmv_ca_core_fwd / lmv_dca_core_fwd == the oracle's attention flavours (sans projections)."""
+    from lemevit_amd._lib import lib, check
+    o = ops()
+    B, N, M, C = 2, 784, 16, 96
+    h = C // 32
+    qkv1, qkv164 = rnd((B, N, 3 * C), "qkv1", dtype, 1.5); qkv2, qkv264 = rnd((B, M, 3 * C), "qkv2", dtype, 1.5)
+    ox = torch.empty((B, N, C), device=dev(), dtype=dtype); oc = torch.empty((B, M, C), device=dev(), dtype=dtype)
+    ws = torch.empty(lib.lmv_attn_workspace_bytes(B, h, M, N, 0) + 1024, device=dev(), dtype=torch.uint8)
+    st = torch.cuda.current_stream().cuda_stream
+    code = o.dtype_code(qkv1)
+    check(lib.lmv_dca_core_fwd(qkv1.data_ptr(), qkv2.data_ptr(), ox.data_ptr(), oc.data_ptr(), None, None, B, N, M, C, ws.data_ptr(), ws.numel(), code, st), "dca")
+    sx, sc = O.dca_scales(N, M, C)
+    assert_close(ox, _attn_ref(qkv164[..., :C], qkv264[..., C:2 * C], qkv264[..., 2 * C:], h, sx), dtype, "dca x")
+    assert_close(oc, _attn_ref(qkv264[..., :C], qkv164[..., C:2 * C], qkv164[..., 2 * C:], h, sc), dtype, "dca c")
+    check(lib.lmv_sa_core_fwd(qkv1.data_ptr(), ox.data_ptr(), None, B, N, C, ws.data_ptr(), ws.numel(), code, st), "sa")
+    assert_close(ox, _attn_ref(qkv164[..., :C], qkv164[..., C:2 * C], qkv164[..., 2 * C:], h, None), dtype, "sa")
+    qc, qc64 = rnd((B, M, C), "qc", dtype, 1.5); kv, kv64 = rnd((B, N, 2 * C), "kv", dtype, 1.5)
+    check(lib.lmv_ca_core_fwd(qc.data_ptr(), kv.data_ptr(), oc.data_ptr(), None, B, M, N, C, ws.data_ptr(), ws.numel(), code, st), "ca")
+    assert_close(oc, _attn_ref(qc64, kv64[..., :C], kv64[..., C:], h, None), dtype, "ca")
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_utils(dtype):
+    o = ops()
+    x, x64 = rnd((1001, 96), "x", dtype)
+    s = (det_tensor((143,), "s", 7).abs()).to(dev())
+    y = o.row_scale(x, s, 7)
+    assert_close(y, x64 * s.cpu().double()[torch.arange(1001) // 7][:, None], dtype, "row_scale")
+    other = torch.bfloat16 if dtype == torch.float32 else torch.float32
+    z = o.cast(x.reshape(-1)[:96003], other)
+    assert torch.equal(z.cpu(), x.reshape(-1)[:96003].cpu().to(other))
+
+
+def test_adamw_flat():
+    o = ops()
+    n = 4096 * 3
+    p = det_tensor((n,), "p", 7).to(dev()); g = det_tensor((n,), "g", 7, 0.1).to(dev())
+    pr = torch.nn.Parameter(p.clone()); opt = torch.optim.AdamW([pr], lr=1e-2, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.05)
+    m = torch.zeros_like(p); v = torch.zeros_like(p)
+    for step in range(1, 4):
+        pr.grad = g.clone(); opt.step()
+        o.adamw_flat(p, g, m, v, None, 1e-2, 0.9, 0.999, 1e-8, 0.05, step)
+    assert_close(p, pr.detach().cpu(), torch.float32, "adamw", 1e-5)

@@ -70,7 +70,7 @@ def _resolve_dtype(x: Tensor) -> torch.dtype:
         raise RuntimeError("lemevit_amd: the model runs on an MI355X only -- move the model and inputs to 'cuda' "
                            "(the CPU restatement under oracle/ is test infrastructure, not a fallback)")
     if torch.is_autocast_enabled():
-        dt = torch.get_autocast_gpu_dtype()
+        dt = torch.get_autocast_dtype("cuda")
         if dt != torch.bfloat16:
             raise NotImplementedError("lemevit_amd: autocast dtype must be torch.bfloat16 (fp16 kernels are not built)")
         return dt

@@ -48,7 +48,8 @@ const char* lmv_last_error(void);
  *
  *   fwd : out[r, n] = res[r, n] + row_scale[r / rows_per_sample] * act(sum_k a[r,k] w[n,k] + bias[n])
  *   dx  : out[r, k] = (sum_n a[r,n] w[n,k]) (* gelu'(aux[r,k]) if act == LMV_ACT_GELU_GRAD)
- *   dw  : dw[n, k] += sum_r dy[r,n] x[r,k] ;  db[n] += sum_r dy[r,n]      (fp32, atomic)
+ *   dw  : dw[n, k] += sum_r dy[r,n] x[r,k] ;  db[n] += sum_r dy[r,n]      (fp32; split-K partial slabs in
+ *         `workspace` + a reduce kernel: deterministic, no atomics)
  * ------------------------------------------------------------------------------------------ */
 enum { LMV_ACT_NONE = 0, LMV_ACT_GELU = 1, LMV_ACT_GELU_GRAD = 2 };
 
@@ -69,30 +70,35 @@ typedef struct {
 
 int lmv_linear_fwd(const lmv_linear_problem* p, int nproblems, int N, int K, int act, int dtype, void* stream);
 int lmv_linear_dx(const lmv_linear_problem* p, int nproblems, int N, int K, int act, int dtype, void* stream);
-int lmv_linear_dw(const lmv_linear_problem* p, int nproblems, int N, int K, int dtype, void* stream);
+size_t lmv_linear_dw_workspace_bytes(const lmv_linear_problem* p, int nproblems, int N, int K, int dtype);
+int lmv_linear_dw(const lmv_linear_problem* p, int nproblems, int N, int K, void* workspace, size_t workspace_bytes, int dtype, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * LayerNorm over the last dim (nn.LayerNorm, models/lemevit.py:513,525 eps 1e-6; :731-743,774
  * eps 1e-5).  stats = [rows, 2] fp32 (mean, rstd), written by fwd when non-NULL.
- *   bwd: dx = dres + LN'(dy)   (dres may be NULL);  dgamma/dbeta are ACCUMULATED (fp32 atomics).
+ *   bwd: dx = dres + LN'(dy)   (dres may be NULL);  dgamma/dbeta are ACCUMULATED (fp32; per-workgroup partials
+ *        in `workspace` + a reduce kernel).
  * ------------------------------------------------------------------------------------------ */
 int lmv_layernorm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* stats,
                       int64_t rows, int C, float eps, int dtype, void* stream);
+size_t lmv_layernorm_bwd_workspace_bytes(int64_t rows, int C, int dtype);
 int lmv_layernorm_bwd(const void* dy, const void* x, const float* stats, const float* gamma, const void* dres,
-                      void* dx, float* dgamma, float* dbeta, int64_t rows, int C, int dtype, void* stream);
+                      void* dx, float* dgamma, float* dbeta, int64_t rows, int C,
+                      void* workspace, size_t workspace_bytes, int dtype, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Conditional position embedding: y = x + dwconv3x3(x) + bias, NHWC (models/lemevit.py:510,546).
  * weight is the reference's [C, 1, 3, 3] fp32 tensor.
  *   bwd_data  : dx = dy + dwconv3x3^T(dy)
- *   bwd_weight: dw[C,1,3,3] += ..., db[C] += ...     (fp32 atomics)
+ *   bwd_weight: dw[C,1,3,3] += ..., db[C] += ...     (fp32; per-workgroup partials in `workspace` + reduce)
  * ------------------------------------------------------------------------------------------ */
 int lmv_dwconv3x3_residual_fwd(const void* x, const float* weight, const float* bias, void* y,
                                int B, int H, int W, int C, int dtype, void* stream);
 int lmv_dwconv3x3_residual_bwd_data(const void* dy, const float* weight, void* dx,
                                     int B, int H, int W, int C, int dtype, void* stream);
+size_t lmv_dwconv3x3_bwd_weight_workspace_bytes(int B, int H, int W, int C, int dtype);
 int lmv_dwconv3x3_bwd_weight(const void* dy, const void* x, float* dweight, float* dbias,
-                             int B, int H, int W, int C, int dtype, void* stream);
+                             int B, int H, int W, int C, void* workspace, size_t workspace_bytes, int dtype, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Attention cores, head dim 32 (all registered variants, models/lemevit.py:851,881,911).

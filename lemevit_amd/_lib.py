@@ -40,12 +40,15 @@ SIGNATURES = {
     "lmv_last_error": (C.c_char_p, []),
     "lmv_linear_fwd": (_I, [C.POINTER(LinearProblem), _I, _I, _I, _I, _I, _P]),
     "lmv_linear_dx": (_I, [C.POINTER(LinearProblem), _I, _I, _I, _I, _I, _P]),
-    "lmv_linear_dw": (_I, [C.POINTER(LinearProblem), _I, _I, _I, _I, _P]),
+    "lmv_linear_dw_workspace_bytes": (_Z, [C.POINTER(LinearProblem), _I, _I, _I, _I]),
+    "lmv_linear_dw": (_I, [C.POINTER(LinearProblem), _I, _I, _I, _P, _Z, _I, _P]),
     "lmv_layernorm_fwd": (_I, [_P, _P, _P, _P, _P, _L, _I, _F, _I, _P]),
-    "lmv_layernorm_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _P]),
+    "lmv_layernorm_bwd_workspace_bytes": (_Z, [_L, _I, _I]),
+    "lmv_layernorm_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _P, _Z, _I, _P]),
     "lmv_dwconv3x3_residual_fwd": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "lmv_dwconv3x3_residual_bwd_data": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P]),
-    "lmv_dwconv3x3_bwd_weight": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
+    "lmv_dwconv3x3_bwd_weight_workspace_bytes": (_Z, [_I, _I, _I, _I, _I]),
+    "lmv_dwconv3x3_bwd_weight": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P, _Z, _I, _P]),
     "lmv_attn_workspace_bytes": (_Z, [_I, _I, _I, _I, _I]),
     "lmv_attn_fwd": (_I, [C.POINTER(AttnDesc), _P, _Z, _I, _P]),
     "lmv_attn_bwd": (_I, [C.POINTER(AttnDesc), _P, _Z, _I, _P]),

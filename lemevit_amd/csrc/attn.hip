@@ -11,6 +11,7 @@
 // registers, LDS-staged small GEMMs for the 16-row reductions).  The bf16 MFMA variants replace
 // the hot ones later ("attention roadmap").
 #include "common.h"
+#include "attn_internal.h"
 
 namespace {
 
@@ -20,13 +21,7 @@ constexpr int KC = 64;    // rows per LDS chunk
 constexpr int FQ = 16;    // max queries of the few-query path
 constexpr int FKB = 256;  // keys per workgroup in the few-query forward
 
-struct Args {
-  const void* q; const void* k; const void* v; void* o; float* lse; const void* d_o;
-  void* dq; void* dk; void* dv;
-  int64_t q_bs, q_rs, k_bs, k_rs, v_bs, v_rs, o_bs, o_rs;
-  int B, H, Lq, Lk;
-  float scale;
-};
+typedef AttnArgs Args;
 
 template <typename T>
 __device__ __forceinline__ void load_row(const T* p, float* f) {   // 32 contiguous elements -> floats
@@ -387,6 +382,7 @@ Args to_args(const lmv_attn_desc* d) {
 template <typename T>
 int fwd_impl(const lmv_attn_desc* d, void* ws, size_t ws_bytes, hipStream_t st) {
   const Args a = to_args(d);
+  if (sizeof(T) == 2 && lmv_attn_mfma_supported(a)) return lmv_attn_mfma_fwd(a, st);
   if (few_q(d->Lq, d->Lk)) {
     const int nsplit = (d->Lk + FKB - 1) / FKB;
     const size_t need = (size_t)d->B * d->H * nsplit * FQ * (D + 2) * sizeof(float);
@@ -412,6 +408,7 @@ int bwd_impl(const lmv_attn_desc* d, void* ws, size_t ws_bytes, hipStream_t st) 
   float* acc1 = acc0 + acc_elems;
   const int64_t nd = (int64_t)d->B * d->H * d->Lq;
   hipLaunchKernelGGL((bwd_delta_kernel<T>), dim3((unsigned)((nd + 255) / 256)), dim3(256), 0, st, a, delta);
+  if (sizeof(T) == 2 && lmv_attn_mfma_supported(a)) return lmv_attn_mfma_bwd(a, delta, acc0, st);
   const dim3 gk((d->Lk + QB - 1) / QB, d->H, d->B), gq((d->Lq + QB - 1) / QB, d->H, d->B);
   if (few_q(d->Lq, d->Lk)) {
     if (hipMemsetAsync(acc0, 0, acc_elems * sizeof(float), st) != hipSuccess) LMV_FAIL(LMV_ERR_LAUNCH, "attn_bwd: memset failed");
@@ -441,7 +438,12 @@ extern "C" size_t lmv_attn_workspace_bytes(int B, int H, int Lq, int Lk, int bac
     const int nsplit = (Lk + FKB - 1) / FKB;
     return align256((size_t)B * H * nsplit * FQ * (D + 2) * sizeof(float));
   }
-  return align256((size_t)B * H * Lq * sizeof(float)) + align256(2 * (size_t)B * H * FQ * D * sizeof(float));
+  // delta + fp32 accumulators of the split reductions (sized for the larger of the generic and the MFMA path)
+  AttnArgs a{};
+  a.B = B; a.H = H; a.Lq = Lq; a.Lk = Lk;
+  size_t acc = 2 * (size_t)B * H * FQ * D * sizeof(float);
+  if (lmv_attn_mfma_supported(a) && lmv_attn_mfma_bwd_acc_bytes(a) > acc) acc = lmv_attn_mfma_bwd_acc_bytes(a);
+  return align256((size_t)B * H * Lq * sizeof(float)) + align256(acc);
 }
 
 extern "C" int lmv_attn_fwd(const lmv_attn_desc* d, void* ws, size_t ws_bytes, int dtype, void* stream) {

@@ -1,0 +1,16 @@
+// attn_internal.h -- shared between attn.hip (dispatch, fp32 / generic kernels) and attn_mfma.hip (bf16 MFMA kernels)
+#pragma once
+#include "common.h"
+
+struct AttnArgs {
+  const void* q; const void* k; const void* v; void* o; float* lse; const void* d_o;
+  void* dq; void* dk; void* dv;
+  int64_t q_bs, q_rs, k_bs, k_rs, v_bs, v_rs, o_bs, o_rs;
+  int B, H, Lq, Lk;
+  float scale;
+};
+
+bool lmv_attn_mfma_supported(const AttnArgs& a);          // bf16, Lk <= 224
+size_t lmv_attn_mfma_bwd_acc_bytes(const AttnArgs& a);    // fp32 scratch for split query ranges
+int lmv_attn_mfma_fwd(const AttnArgs& a, hipStream_t st);
+int lmv_attn_mfma_bwd(const AttnArgs& a, const float* delta, float* acc, hipStream_t st);

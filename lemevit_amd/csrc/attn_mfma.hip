@@ -1,0 +1,372 @@
+// attn_mfma.hip -- bf16 MFMA attention cores (head dim 32) for key counts up to 224:
+// the late-stage self-attention (L = 196 / 49 / 16) and the image->meta direction of Dual Cross-Attention
+// (N queries x 16 keys).  v_mfma_f32_16x16x32_bf16 fits d = 32 exactly: one instruction per 16x16 score tile.
+//
+// Register-level dataflow (no LDS round trip for the probabilities):
+//   S^T tile  D[key][q] = mfma(A = K fragment, B = Q fragment)       lane holds 4 consecutive keys of query (lane & 15)
+//   softmax over the whole row in registers: 4 * NKT values per lane + two xor-shuffles across the 4 lane groups
+//   O^T tile  D[d][q]   = sum over 32-key blocks of mfma(A = V^T fragment, B = P fragment)
+// The P fragment of a 32-key block is exactly the two S^T accumulators of that block converted to bf16 -- the MFMA
+// contraction does not care WHICH keys sit in which k-slot as long as both operands agree -- and the matching V^T
+// fragment is what two ds_read_b64_tr_b16 transpose reads deliver (4 keys x 16 d per 16-lane group).
+// The backward kernels use the same trick in both orientations (D[key][q] for dQ, D[q][key] for dK / dV) and
+// recompute P = exp(scale * s - LSE).
+//
+// LDS images are [rows][32] bf16 (64-byte rows); the 16-byte chunk c of row r is stored at c ^ (((r >> 2) & 1) << 1),
+// which is conflict-free for BOTH the 16-byte fragment reads and the transpose reads (derivation in DESIGN.md).
+#include "common.h"
+#include "attn_internal.h"
+
+namespace {
+
+constexpr int D = 32;
+typedef __attribute__((address_space(3))) bf16x4_t* lds4_t;
+
+__device__ __forceinline__ int swz(int r, int c16) { return r * 64 + ((c16 ^ (((r >> 2) & 1) << 1)) << 4); }
+
+// rows [r0, r0 + nrows) of a strided [L][32] bf16 matrix -> LDS image (rows >= L zero-filled)
+template <int NTHREADS>
+__device__ __forceinline__ void stage_rows(unsigned char* s, const bf16_t* base, int64_t rs, int r0, int nrows, int L, int tid) {
+  for (int c = tid; c < nrows * 4; c += NTHREADS) {
+    const int r = c >> 2, cc = c & 3;
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (r0 + r < L) v = *reinterpret_cast<const uint4*>(base + (int64_t)(r0 + r) * rs + cc * 8);
+    *reinterpret_cast<uint4*>(s + swz(r, cc)) = v;
+  }
+}
+
+// normal fragment: 16 rows starting at row0, lane -> row (lane & 15), 8 d-values at (lane >> 4) * 8
+__device__ __forceinline__ bf16x8_t frag_n(const unsigned char* s, int row0, int lane) {
+  return *reinterpret_cast<const bf16x8_t*>(s + swz(row0 + (lane & 15), lane >> 4));
+}
+// transposed fragment for the 32-row block {rowA + 0..15, rowB + 0..15} and the 16 columns d0..d0+15:
+// lane -> column d0 + (lane & 15); k-slot j of lane group g -> row (j < 4 ? rowA : rowB) + g * 4 + (j & 3)
+__device__ __forceinline__ bf16x8_t frag_t(const unsigned char* s, int rowA, int rowB, int d0, int lane) {
+  const int g = lane >> 4, i = lane & 15, rr = i >> 2, q = i & 3;
+  const int ra = rowA + g * 4 + rr, rb = rowB + g * 4 + rr, c16 = (d0 >> 3) + (q >> 1), off = (q & 1) * 8;
+  bf16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds4_t)(s + swz(ra, c16) + off));
+  bf16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds4_t)(s + swz(rb, c16) + off));
+  return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+
+__device__ __forceinline__ bf16x8_t pack8(const f32x4_t& a, const f32x4_t& b) {
+  bf16x8_t r;
+  r[0] = (__bf16)a[0]; r[1] = (__bf16)a[1]; r[2] = (__bf16)a[2]; r[3] = (__bf16)a[3];
+  r[4] = (__bf16)b[0]; r[5] = (__bf16)b[1]; r[6] = (__bf16)b[2]; r[7] = (__bf16)b[3];
+  return r;
+}
+__device__ __forceinline__ bf16x8_t load_frag_global(const bf16_t* base, int64_t rs, int row, int L, int lane) {
+  uint4 v = make_uint4(0, 0, 0, 0);
+  if (row < L) v = *reinterpret_cast<const uint4*>(base + (int64_t)row * rs + (lane >> 4) * 8);
+  return __builtin_bit_cast(bf16x8_t, v);
+}
+__device__ __forceinline__ float group_max4(float v) { v = fmaxf(v, __shfl_xor(v, 16, 64)); return fmaxf(v, __shfl_xor(v, 32, 64)); }
+__device__ __forceinline__ float group_sum4(float v) { v += __shfl_xor(v, 16, 64); return v + __shfl_xor(v, 32, 64); }
+__device__ __forceinline__ void store4(bf16_t* p, const f32x4_t& v) { *reinterpret_cast<uint2*>(p) = make_uint2(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])); }
+
+#define MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0)
+
+// =============================================================================================
+// forward: NKT = number of 16-key tiles (even), keys padded with zero rows / masked scores
+// =============================================================================================
+template <int NKT>
+__global__ __launch_bounds__(256) void mfma_fwd_kernel(const AttnArgs a, int qt_per_block) {
+  __shared__ __attribute__((aligned(16))) unsigned char sK[NKT * 16 * 64], sV[NKT * 16 * 64];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = blockIdx.y, b = blockIdx.z;
+  const bf16_t* qb = reinterpret_cast<const bf16_t*>(a.q) + b * a.q_bs + h * D;
+  const bf16_t* kb = reinterpret_cast<const bf16_t*>(a.k) + b * a.k_bs + h * D;
+  const bf16_t* vb = reinterpret_cast<const bf16_t*>(a.v) + b * a.v_bs + h * D;
+  bf16_t* ob = reinterpret_cast<bf16_t*>(a.o) + b * a.o_bs + h * D;
+  stage_rows<256>(sK, kb, a.k_rs, 0, NKT * 16, a.Lk, tid);
+  stage_rows<256>(sV, vb, a.v_rs, 0, NKT * 16, a.Lk, tid);
+  __syncthreads();
+  const int nqt = (a.Lq + 15) >> 4;
+  const int qt_end = min(nqt, (int)(blockIdx.x + 1) * qt_per_block);
+  const int g = lane >> 4;
+  for (int qt = blockIdx.x * qt_per_block + wave; qt < qt_end; qt += 4) {
+    const int q = qt * 16 + (lane & 15);
+    const bf16x8_t qf = load_frag_global(qb, a.q_rs, q, a.Lq, lane);
+    f32x4_t s[NKT];
+    float m = -1e30f;
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt) {
+      s[kt] = MFMA(frag_n(sK, kt * 16, lane), qf, (f32x4_t{0.f, 0.f, 0.f, 0.f}));
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        s[kt][r] = (kt * 16 + g * 4 + r < a.Lk) ? s[kt][r] * a.scale : -1e30f;
+        m = fmaxf(m, s[kt][r]);
+      }
+    }
+    m = group_max4(m);
+    float l = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { const float p = __expf(s[kt][r] - m); s[kt][r] = p; l += p; }
+    l = group_sum4(l);
+    f32x4_t o0 = {0.f, 0.f, 0.f, 0.f}, o1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kb2 = 0; kb2 < NKT / 2; ++kb2) {
+      // P is fed to the matrix core as hi + lo bf16 parts (16 mantissa bits): the forward output then carries only
+      // its own bf16 rounding, which keeps the kernel inside the 1e-3 parity budget at 2 extra MFMAs per block
+      const bf16x8_t ph = pack8(s[2 * kb2], s[2 * kb2 + 1]);
+      f32x4_t r0, r1;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { r0[r] = s[2 * kb2][r] - (float)ph[r]; r1[r] = s[2 * kb2 + 1][r] - (float)ph[4 + r]; }
+      const bf16x8_t pl = pack8(r0, r1);
+      const bf16x8_t vt0 = frag_t(sV, kb2 * 32, kb2 * 32 + 16, 0, lane), vt1 = frag_t(sV, kb2 * 32, kb2 * 32 + 16, 16, lane);
+      o0 = MFMA(vt0, ph, o0); o0 = MFMA(vt0, pl, o0);
+      o1 = MFMA(vt1, ph, o1); o1 = MFMA(vt1, pl, o1);
+    }
+    if (q < a.Lq) {
+      const float inv = 1.f / l;
+      o0 *= inv; o1 *= inv;
+      store4(ob + (int64_t)q * a.o_rs + g * 4, o0);
+      store4(ob + (int64_t)q * a.o_rs + 16 + g * 4, o1);
+      if (a.lse && g == 0) a.lse[((int64_t)b * a.H + h) * a.Lq + q] = m + __logf(l);
+    }
+  }
+}
+
+// =============================================================================================
+// backward, dQ: one 16-query tile per wave iteration, loop over 32-key blocks
+// =============================================================================================
+template <int NKT>
+__global__ __launch_bounds__(256) void mfma_bwd_dq_kernel(const AttnArgs a, const float* __restrict__ delta, int qt_per_block) {
+  __shared__ __attribute__((aligned(16))) unsigned char sK[NKT * 16 * 64], sV[NKT * 16 * 64];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = blockIdx.y, b = blockIdx.z;
+  const bf16_t* qb = reinterpret_cast<const bf16_t*>(a.q) + b * a.q_bs + h * D;
+  const bf16_t* gb = reinterpret_cast<const bf16_t*>(a.d_o) + b * a.o_bs + h * D;
+  bf16_t* dqb = reinterpret_cast<bf16_t*>(a.dq) + b * a.q_bs + h * D;
+  stage_rows<256>(sK, reinterpret_cast<const bf16_t*>(a.k) + b * a.k_bs + h * D, a.k_rs, 0, NKT * 16, a.Lk, tid);
+  stage_rows<256>(sV, reinterpret_cast<const bf16_t*>(a.v) + b * a.v_bs + h * D, a.v_rs, 0, NKT * 16, a.Lk, tid);
+  __syncthreads();
+  const int nqt = (a.Lq + 15) >> 4;
+  const int qt_end = min(nqt, (int)(blockIdx.x + 1) * qt_per_block);
+  const int g = lane >> 4;
+  const int64_t bh = ((int64_t)b * a.H + h) * a.Lq;
+  for (int qt = blockIdx.x * qt_per_block + wave; qt < qt_end; qt += 4) {
+    const int q = qt * 16 + (lane & 15);
+    const bool vq = q < a.Lq;
+    const bf16x8_t qf = load_frag_global(qb, a.q_rs, q, a.Lq, lane);
+    const bf16x8_t gf = load_frag_global(gb, a.o_rs, q, a.Lq, lane);
+    const float lse = vq ? a.lse[bh + q] : 0.f, dl = vq ? delta[bh + q] : 0.f;
+    f32x4_t dq0 = {0.f, 0.f, 0.f, 0.f}, dq1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kb2 = 0; kb2 < NKT / 2; ++kb2) {
+      f32x4_t ds[2];
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const int kt = 2 * kb2 + t;
+        const f32x4_t s = MFMA(frag_n(sK, kt * 16, lane), qf, (f32x4_t{0.f, 0.f, 0.f, 0.f}));
+        const f32x4_t dp = MFMA(frag_n(sV, kt * 16, lane), gf, (f32x4_t{0.f, 0.f, 0.f, 0.f}));
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const bool ok = vq && (kt * 16 + g * 4 + r < a.Lk);
+          const float p = ok ? __expf(s[r] * a.scale - lse) : 0.f;
+          ds[t][r] = p * (dp[r] - dl) * a.scale;
+        }
+      }
+      const bf16x8_t dsf = pack8(ds[0], ds[1]);
+      dq0 = MFMA(frag_t(sK, kb2 * 32, kb2 * 32 + 16, 0, lane), dsf, dq0);
+      dq1 = MFMA(frag_t(sK, kb2 * 32, kb2 * 32 + 16, 16, lane), dsf, dq1);
+    }
+    if (vq) {
+      store4(dqb + (int64_t)q * a.q_rs + g * 4, dq0);
+      store4(dqb + (int64_t)q * a.q_rs + 16 + g * 4, dq1);
+    }
+  }
+}
+
+// =============================================================================================
+// backward, dK / dV: one workgroup per (b, h, query range); wave w owns key tiles kt = w % KW, + KW, ... and the
+// 32-query blocks qb = w / KW, + QW, ...  (KW * QW = 4).  Partial tiles of the QW query groups are summed in LDS.
+// ATOMIC: several query ranges per (b, h) -> fp32 atomics into acc_k / acc_v [B][H][NKT*16][32] (scattered later).
+// =============================================================================================
+constexpr int QR_MAX = 448;   // queries staged per workgroup (Q and dO images: 2 * 448 * 64 B = 56 KB)
+
+template <int NKT, int KW, bool ATOMIC>
+__global__ __launch_bounds__(256) void mfma_bwd_dkv_kernel(const AttnArgs a, const float* __restrict__ delta, float* __restrict__ acc_k,
+                                                          float* __restrict__ acc_v, int q_per_block) {
+  constexpr int QW = 4 / KW;
+  constexpr int TPW = (NKT + KW - 1) / KW;     // key tiles per wave
+  __shared__ __attribute__((aligned(16))) unsigned char sQG[2 * QR_MAX * 64];     // Q image | dO image (reused by the final reduce)
+  __shared__ __attribute__((aligned(16))) float sL[QR_MAX], sDl[QR_MAX];
+  unsigned char* sQ = sQG;
+  unsigned char* sG = sQG + QR_MAX * 64;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = blockIdx.y, b = blockIdx.z;
+  const int kw = wave % KW, qw = wave / KW, g = lane >> 4;
+  const int q0 = blockIdx.x * q_per_block, q1 = min(a.Lq, q0 + q_per_block);
+  const int nrows = ((q1 - q0 + 31) >> 5) << 5;
+  const int64_t bh = ((int64_t)b * a.H + h) * a.Lq;
+  stage_rows<256>(sQ, reinterpret_cast<const bf16_t*>(a.q) + b * a.q_bs + h * D, a.q_rs, q0, nrows, q1, tid);
+  stage_rows<256>(sG, reinterpret_cast<const bf16_t*>(a.d_o) + b * a.o_bs + h * D, a.o_rs, q0, nrows, q1, tid);
+  for (int i = tid; i < nrows; i += 256) {
+    const bool ok = q0 + i < q1;
+    sL[i] = ok ? a.lse[bh + q0 + i] : 1e30f;      // exp(s - 1e30) = 0 masks the padded queries
+    sDl[i] = ok ? delta[bh + q0 + i] : 0.f;
+  }
+  const bf16_t* kb = reinterpret_cast<const bf16_t*>(a.k) + b * a.k_bs + h * D;
+  const bf16_t* vb = reinterpret_cast<const bf16_t*>(a.v) + b * a.v_bs + h * D;
+  bf16x8_t kf[TPW], vf[TPW];
+  f32x4_t dk[TPW][2], dv[TPW][2];
+#pragma unroll
+  for (int i = 0; i < TPW; ++i) {
+    const int kt = kw + i * KW;
+    kf[i] = load_frag_global(kb, a.k_rs, kt * 16 + (lane & 15), (kt < NKT) ? a.Lk : 0, lane);
+    vf[i] = load_frag_global(vb, a.v_rs, kt * 16 + (lane & 15), (kt < NKT) ? a.Lk : 0, lane);
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt) { dk[i][dt] = f32x4_t{0.f, 0.f, 0.f, 0.f}; dv[i][dt] = f32x4_t{0.f, 0.f, 0.f, 0.f}; }
+  }
+  __syncthreads();
+  const bool vkey = true;
+  for (int qb = qw; qb * 32 < nrows; qb += QW) {
+    const int r0 = qb * 32;
+    const bf16x8_t qn0 = frag_n(sQ, r0, lane), qn1 = frag_n(sQ, r0 + 16, lane);
+    const bf16x8_t gn0 = frag_n(sG, r0, lane), gn1 = frag_n(sG, r0 + 16, lane);
+    const bf16x8_t qt0 = frag_t(sQ, r0, r0 + 16, 0, lane), qt1 = frag_t(sQ, r0, r0 + 16, 16, lane);
+    const bf16x8_t gt0 = frag_t(sG, r0, r0 + 16, 0, lane), gt1 = frag_t(sG, r0, r0 + 16, 16, lane);
+    const float4 l0 = *reinterpret_cast<const float4*>(sL + r0 + g * 4), l1 = *reinterpret_cast<const float4*>(sL + r0 + 16 + g * 4);
+    const float4 d0 = *reinterpret_cast<const float4*>(sDl + r0 + g * 4), d1 = *reinterpret_cast<const float4*>(sDl + r0 + 16 + g * 4);
+    const float lse[8] = {l0.x, l0.y, l0.z, l0.w, l1.x, l1.y, l1.z, l1.w};
+    const float dl[8] = {d0.x, d0.y, d0.z, d0.w, d1.x, d1.y, d1.z, d1.w};
+#pragma unroll
+    for (int i = 0; i < TPW; ++i) {
+      const int kt = kw + i * KW;
+      if (kt >= NKT) continue;
+      const bool kvalid = vkey && (kt * 16 + (lane & 15) < a.Lk);
+      // D[q][key]: lane holds queries r0 + t*16 + g*4 + r of key (lane & 15)
+      const f32x4_t s0 = MFMA(qn0, kf[i], (f32x4_t{0.f, 0.f, 0.f, 0.f})), s1 = MFMA(qn1, kf[i], (f32x4_t{0.f, 0.f, 0.f, 0.f}));
+      const f32x4_t p0 = MFMA(gn0, vf[i], (f32x4_t{0.f, 0.f, 0.f, 0.f})), p1 = MFMA(gn1, vf[i], (f32x4_t{0.f, 0.f, 0.f, 0.f}));
+      f32x4_t pr[2], ds[2];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float e0 = kvalid ? __expf(s0[r] * a.scale - lse[r]) : 0.f, e1 = kvalid ? __expf(s1[r] * a.scale - lse[4 + r]) : 0.f;
+        pr[0][r] = e0; pr[1][r] = e1;
+        ds[0][r] = e0 * (p0[r] - dl[r]) * a.scale; ds[1][r] = e1 * (p1[r] - dl[4 + r]) * a.scale;
+      }
+      const bf16x8_t pf = pack8(pr[0], pr[1]), dsf = pack8(ds[0], ds[1]);
+      // D[d][key]: lane holds d = dt*16 + g*4 + r of key (lane & 15)
+      dv[i][0] = MFMA(gt0, pf, dv[i][0]); dv[i][1] = MFMA(gt1, pf, dv[i][1]);
+      dk[i][0] = MFMA(qt0, dsf, dk[i][0]); dk[i][1] = MFMA(qt1, dsf, dk[i][1]);
+    }
+  }
+  // ---- combine the QW query groups through LDS (reuses the Q image), then write / accumulate ----------
+  if (QW > 1) {
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(sQG);         // [wave][TPW][4 frags][64 lanes][4] <= 32 KB
+#pragma unroll
+    for (int i = 0; i < TPW; ++i)
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt) {
+        *reinterpret_cast<f32x4_t*>(red + ((((qw * KW + kw) * TPW + i) * 4 + dt) * 64 + lane) * 4) = dk[i][dt];
+        *reinterpret_cast<f32x4_t*>(red + ((((qw * KW + kw) * TPW + i) * 4 + 2 + dt) * 64 + lane) * 4) = dv[i][dt];
+      }
+    __syncthreads();
+    if (qw != 0) return;
+#pragma unroll
+    for (int i = 0; i < TPW; ++i)
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int o = 1; o < QW; ++o) {
+          dk[i][dt] += *reinterpret_cast<const f32x4_t*>(red + ((((o * KW + kw) * TPW + i) * 4 + dt) * 64 + lane) * 4);
+          dv[i][dt] += *reinterpret_cast<const f32x4_t*>(red + ((((o * KW + kw) * TPW + i) * 4 + 2 + dt) * 64 + lane) * 4);
+        }
+  }
+#pragma unroll
+  for (int i = 0; i < TPW; ++i) {
+    const int kt = kw + i * KW, key = kt * 16 + (lane & 15);
+    if (kt >= NKT || key >= a.Lk) continue;
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt) {
+      const int d = dt * 16 + g * 4;
+      if (ATOMIC) {
+        const int64_t o = ((((int64_t)b * a.H + h) * (NKT * 16)) + key) * D + d;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { atomicAdd(acc_k + o + r, dk[i][dt][r]); atomicAdd(acc_v + o + r, dv[i][dt][r]); }
+      } else {
+        store4(reinterpret_cast<bf16_t*>(a.dk) + b * a.k_bs + (int64_t)key * a.k_rs + h * D + d, dk[i][dt]);
+        store4(reinterpret_cast<bf16_t*>(a.dv) + b * a.v_bs + (int64_t)key * a.v_rs + h * D + d, dv[i][dt]);
+      }
+    }
+  }
+}
+
+// fp32 [B][H][LP][32] accumulator -> strided bf16 rows (first L rows)
+__global__ __launch_bounds__(256) void scatter_bf16_kernel(const float* __restrict__ acc, bf16_t* __restrict__ dst, int64_t bs, int64_t rs, int B, int H,
+                                                          int L, int LP) {
+  const unsigned idx = blockIdx.x * 256 + threadIdx.x, total = (unsigned)B * H * L * D;
+  if (idx >= total) return;
+  const unsigned d = idx % D, l = (idx / D) % L, h = (idx / (D * L)) % H, b = idx / (D * L * H);
+  dst[b * bs + (int64_t)l * rs + h * D + d] = f2bf(acc[((((int64_t)b * H + h) * LP) + l) * D + d]);
+}
+
+inline int nkt_for(int Lk) { return Lk <= 32 ? 2 : (Lk <= 64 ? 4 : (Lk <= 128 ? 8 : 14)); }
+
+// query tiles per workgroup: whole (b, h) in one workgroup when small, else ~32 tiles, but keep the grid >= ~1024
+inline int qt_per_block_for(const AttnArgs& a) {
+  const int nqt = (a.Lq + 15) / 16;
+  int per = nqt < 32 ? nqt : 32;
+  while (per > 4 && (int64_t)a.B * a.H * ((nqt + per - 1) / per) < 1024) per = (per + 1) / 2;
+  return per < 4 ? (nqt < 4 ? nqt : 4) : per;
+}
+
+}  // namespace
+
+bool lmv_attn_mfma_supported(const AttnArgs& a) { return a.Lk <= 224; }
+
+size_t lmv_attn_mfma_bwd_acc_bytes(const AttnArgs& a) {
+  return 2 * (size_t)a.B * a.H * nkt_for(a.Lk) * 16 * D * sizeof(float);
+}
+
+int lmv_attn_mfma_fwd(const AttnArgs& a, hipStream_t st) {
+  const int per = qt_per_block_for(a), nqt = (a.Lq + 15) / 16;
+  dim3 grid((nqt + per - 1) / per, a.H, a.B), block(256);
+  switch (nkt_for(a.Lk)) {
+    case 2: hipLaunchKernelGGL((mfma_fwd_kernel<2>), grid, block, 0, st, a, per); break;
+    case 4: hipLaunchKernelGGL((mfma_fwd_kernel<4>), grid, block, 0, st, a, per); break;
+    case 8: hipLaunchKernelGGL((mfma_fwd_kernel<8>), grid, block, 0, st, a, per); break;
+    default: hipLaunchKernelGGL((mfma_fwd_kernel<14>), grid, block, 0, st, a, per); break;
+  }
+  LMV_CHECK_LAUNCH("attn_mfma_fwd");
+  return LMV_OK;
+}
+
+// acc: lmv_attn_mfma_bwd_acc_bytes() of fp32 scratch (only touched when the query range is split)
+int lmv_attn_mfma_bwd(const AttnArgs& a, const float* delta, float* acc, hipStream_t st) {
+  const int per = qt_per_block_for(a), nqt = (a.Lq + 15) / 16, nkt = nkt_for(a.Lk);
+  {
+    dim3 grid((nqt + per - 1) / per, a.H, a.B), block(256);
+    switch (nkt) {
+      case 2: hipLaunchKernelGGL((mfma_bwd_dq_kernel<2>), grid, block, 0, st, a, delta, per); break;
+      case 4: hipLaunchKernelGGL((mfma_bwd_dq_kernel<4>), grid, block, 0, st, a, delta, per); break;
+      case 8: hipLaunchKernelGGL((mfma_bwd_dq_kernel<8>), grid, block, 0, st, a, delta, per); break;
+      default: hipLaunchKernelGGL((mfma_bwd_dq_kernel<14>), grid, block, 0, st, a, delta, per); break;
+    }
+  }
+  // dK / dV: split the query range so that the grid fills the chip (and fits the LDS images)
+  int nsplit = (a.Lq + QR_MAX - 1) / QR_MAX;
+  while ((int64_t)a.B * a.H * nsplit < 1024 && a.Lq / (nsplit + 1) >= 128) ++nsplit;
+  int qpb = (((a.Lq + nsplit - 1) / nsplit) + 31) / 32 * 32;
+  if (qpb > QR_MAX) qpb = QR_MAX;
+  nsplit = (a.Lq + qpb - 1) / qpb;
+  dim3 grid(nsplit, a.H, a.B), block(256);
+  const size_t acc_elems = (size_t)a.B * a.H * nkt * 16 * D;
+  float* acc_k = acc; float* acc_v = acc + acc_elems;
+  if (nsplit > 1) {
+    if (hipMemsetAsync(acc, 0, 2 * acc_elems * sizeof(float), st) != hipSuccess) LMV_FAIL(LMV_ERR_LAUNCH, "attn_mfma_bwd: memset failed");
+#define DKV(N, K) hipLaunchKernelGGL((mfma_bwd_dkv_kernel<N, K, true>), grid, block, 0, st, a, delta, acc_k, acc_v, qpb)
+    switch (nkt) { case 2: DKV(2, 1); break; case 4: DKV(4, 2); break; case 8: DKV(8, 4); break; default: DKV(14, 4); break; }
+#undef DKV
+    const unsigned n = (unsigned)a.B * a.H * a.Lk * D;
+    hipLaunchKernelGGL(scatter_bf16_kernel, dim3((n + 255) / 256), dim3(256), 0, st, (const float*)acc_k, (bf16_t*)a.dk, a.k_bs, a.k_rs, a.B, a.H, a.Lk, nkt * 16);
+    hipLaunchKernelGGL(scatter_bf16_kernel, dim3((n + 255) / 256), dim3(256), 0, st, (const float*)acc_v, (bf16_t*)a.dv, a.v_bs, a.v_rs, a.B, a.H, a.Lk, nkt * 16);
+  } else {
+#define DKV(N, K) hipLaunchKernelGGL((mfma_bwd_dkv_kernel<N, K, false>), grid, block, 0, st, a, delta, acc_k, acc_v, qpb)
+    switch (nkt) { case 2: DKV(2, 1); break; case 4: DKV(4, 2); break; case 8: DKV(8, 4); break; default: DKV(14, 4); break; }
+#undef DKV
+  }
+  LMV_CHECK_LAUNCH("attn_mfma_bwd");
+  return LMV_OK;
+}

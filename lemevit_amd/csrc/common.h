@@ -25,6 +25,10 @@ void lmv_set_error(const char* fmt, ...);
     if (e__ != hipSuccess) LMV_FAIL(LMV_ERR_LAUNCH, "%s: %s", name, hipGetErrorString(e__)); \
   } while (0)
 
+// out[map(i)] += sum_r partial[r][i], i < width  (misc.hip).  mode 0: i < na -> out_a[i], else out_b[i - na];
+// mode 1 (dwconv, partial index i = tap * C + c with na = C): tap < 9 -> out_a[c * 9 + tap], tap == 9 -> out_b[c].
+int lmv_launch_partial_reduce(const float* partial, int nrows, int width, float* out_a, int na, float* out_b, int mode, hipStream_t st);
+
 static inline bool lmv_aligned16(const void* p) { return (((uintptr_t)p) & 15u) == 0; }
 
 // ---- bf16 <-> f32 ---------------------------------------------------------------------------

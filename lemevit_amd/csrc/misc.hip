@@ -41,15 +41,15 @@ __global__ __launch_bounds__(TPB) void cast_kernel(const S* __restrict__ src, D*
 template <typename T>
 __global__ __launch_bounds__(TPB) void row_scale_kernel(const T* __restrict__ x, const float* __restrict__ scale, T* __restrict__ y,
                                                        int64_t rows, int C, int rps) {
-  const int c4 = C >> 2;
-  const int64_t total = rows * c4;
-  for (int64_t i = blockIdx.x * (int64_t)TPB + threadIdx.x; i < total; i += (int64_t)gridDim.x * TPB) {
-    const int64_t r = i / c4;
-    const float s = scale[r / rps];
+  const unsigned c4 = (unsigned)C >> 2;
+  const unsigned total = (unsigned)rows * c4;              // < 2^31 (checked on the host): 32-bit index math only
+  for (unsigned i = blockIdx.x * TPB + threadIdx.x; i < total; i += gridDim.x * TPB) {
+    const unsigned r = i / c4;
+    const float s = scale[r / (unsigned)rps];
     float f[4];
-    ld4(x + i * 4, f);
+    ld4(x + (size_t)i * 4, f);
     f[0] *= s; f[1] *= s; f[2] *= s; f[3] *= s;
-    st4(y + i * 4, f);
+    st4(y + (size_t)i * 4, f);
   }
 }
 
@@ -74,7 +74,52 @@ __global__ __launch_bounds__(TPB) void adamw_kernel(float* __restrict__ p, const
   }
 }
 
+// 8 float4 columns (128 B of each partial row) x 32 row-groups per workgroup; every thread sums rows rg, rg+32, ...
+// with four independent 16-byte loads in flight, then the 32 row-groups are combined through LDS.
+__global__ __launch_bounds__(256) void partial_reduce_kernel(const float* __restrict__ partial, int nrows, int width, float* __restrict__ out_a, int na,
+                                                            float* __restrict__ out_b, int mode) {
+  __shared__ float4 red[32][8];
+  const int cx = threadIdx.x & 7, rg = threadIdx.x >> 3, i = (blockIdx.x * 8 + cx) * 4;
+  float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (i < width) {
+    const float* p = partial + i;
+    int r = rg;
+    for (; r + 96 < nrows; r += 128) {
+      const float4 v0 = *reinterpret_cast<const float4*>(p + (int64_t)r * width);
+      const float4 v1 = *reinterpret_cast<const float4*>(p + (int64_t)(r + 32) * width);
+      const float4 v2 = *reinterpret_cast<const float4*>(p + (int64_t)(r + 64) * width);
+      const float4 v3 = *reinterpret_cast<const float4*>(p + (int64_t)(r + 96) * width);
+      a.x += (v0.x + v1.x) + (v2.x + v3.x); a.y += (v0.y + v1.y) + (v2.y + v3.y);
+      a.z += (v0.z + v1.z) + (v2.z + v3.z); a.w += (v0.w + v1.w) + (v2.w + v3.w);
+    }
+    for (; r < nrows; r += 32) {
+      const float4 v = *reinterpret_cast<const float4*>(p + (int64_t)r * width);
+      a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+    }
+  }
+  red[rg][cx] = a;
+  __syncthreads();
+  if (rg == 0 && i < width) {
+#pragma unroll 8
+    for (int k = 1; k < 32; ++k) { const float4 v = red[k][cx]; a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w; }
+    const float s[4] = {a.x, a.y, a.z, a.w};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int j = i + e;
+      if (mode == 0) { if (j < na) out_a[j] += s[e]; else out_b[j - na] += s[e]; }
+      else { const int t = j / na, ch = j - t * na; if (t < 9) out_a[ch * 9 + t] += s[e]; else out_b[ch] += s[e]; }
+    }
+  }
+}
+
 }  // namespace
+
+int lmv_launch_partial_reduce(const float* partial, int nrows, int width, float* out_a, int na, float* out_b, int mode, hipStream_t st) {
+  if (width % 4) LMV_FAIL(LMV_ERR_SHAPE, "partial_reduce: width %d must be a multiple of 4", width);
+  hipLaunchKernelGGL(partial_reduce_kernel, dim3((width / 4 + 7) / 8), dim3(256), 0, st, partial, nrows, width, out_a, na, out_b, mode);
+  LMV_CHECK_LAUNCH("partial_reduce");
+  return LMV_OK;
+}
 
 extern "C" int lmv_cast(const void* src, int sd, void* dst, int dd, int64_t n, void* stream) {
   if (n <= 0) return LMV_OK;
@@ -93,6 +138,7 @@ extern "C" int lmv_cast(const void* src, int sd, void* dst, int dd, int64_t n, v
 extern "C" int lmv_row_scale(const void* x, const float* scale, void* y, int64_t rows, int C, int rps, int dtype, void* stream) {
   if (rows <= 0) return LMV_OK;
   if (C <= 0 || (C % 8) || rps <= 0) LMV_FAIL(LMV_ERR_SHAPE, "row_scale: C=%d must be a multiple of 8, rows_per_sample=%d > 0", C, rps);
+  if (rows * (C / 4) >= (int64_t)1 << 31) LMV_FAIL(LMV_ERR_SHAPE, "row_scale: tensor too large (%lld x %d)", (long long)rows, C);
   hipStream_t st = (hipStream_t)stream;
   const int grid = grid_for(rows * (C / 4));
   if (dtype == LMV_BF16) hipLaunchKernelGGL((row_scale_kernel<bf16_t>), dim3(grid), dim3(TPB), 0, st, (const bf16_t*)x, scale, (bf16_t*)y, rows, C, rps);

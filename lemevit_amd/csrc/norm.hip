@@ -77,7 +77,7 @@ __global__ __launch_bounds__(TPB) void ln_fwd_kernel(const T* __restrict__ x, co
 template <typename T, int NIT>
 __global__ __launch_bounds__(TPB) void ln_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x, const float* __restrict__ stats,
                                                     const float* __restrict__ gamma, const T* __restrict__ dres, T* __restrict__ dx,
-                                                    float* __restrict__ dgamma, float* __restrict__ dbeta, int64_t rows, int C, int lpr_log2) {
+                                                    float* __restrict__ partial, int64_t rows, int C, int lpr_log2) {
   constexpr int EPC = DT<T>::EPC;
   __shared__ float s_dg[BWD_MAXC], s_db[BWD_MAXC];
   const int lpr = 1 << lpr_log2, nch = C / EPC;
@@ -139,7 +139,9 @@ __global__ __launch_bounds__(TPB) void ln_bwd_kernel(const T* __restrict__ dy, c
     }
   }
   __syncthreads();
-  for (int c = threadIdx.x; c < C; c += TPB) { atomicAdd(dgamma + c, s_dg[c]); atomicAdd(dbeta + c, s_db[c]); }
+  // this workgroup's partial (dgamma | dbeta) row; summed over workgroups by partial_reduce_kernel
+  float* prow = partial + (int64_t)blockIdx.x * 2 * C;
+  for (int c = threadIdx.x; c < C; c += TPB) { prow[c] = s_dg[c]; prow[C + c] = s_db[c]; }
 }
 
 // lanes per row (log2) and iterations for a row of `nch` 16-byte chunks
@@ -176,15 +178,23 @@ int launch_fwd(const void* x, const float* gamma, const float* beta, void* y, fl
   return LMV_OK;
 }
 
+inline int bwd_blocks(int64_t rows, int l2) {
+  const int rpb = TPB >> l2;
+  int64_t blocks = (rows + rpb - 1) / rpb;
+  return (int)(blocks > 512 ? 512 : blocks);
+}
+
 template <typename T>
 int launch_bwd(const void* dy, const void* x, const float* stats, const float* gamma, const void* dres, void* dx, float* dgamma, float* dbeta,
-               int64_t rows, int C, hipStream_t st) {
+               int64_t rows, int C, void* ws, size_t ws_bytes, hipStream_t st) {
   int l2, nit;
   if (C > BWD_MAXC || !pick_geometry(C / DT<T>::EPC, sizeof(T) == 4 ? 8 : 6, &l2, &nit)) LMV_FAIL(LMV_ERR_SHAPE, "layernorm_bwd: C=%d too wide", C);
-  const int rpb = TPB >> l2;
-  int64_t blocks = (rows + rpb - 1) / rpb; if (blocks > 512) blocks = 512;
-  dim3 grid((int)blocks), block(TPB);
-#define LN_BWD_CASE(N) case N: hipLaunchKernelGGL((ln_bwd_kernel<T, N>), grid, block, 0, st, (const T*)dy, (const T*)x, stats, gamma, (const T*)dres, (T*)dx, dgamma, dbeta, rows, C, l2); break;
+  const int blocks = bwd_blocks(rows, l2);
+  const size_t need = (size_t)blocks * 2 * C * sizeof(float);
+  if (!ws || ws_bytes < need) LMV_FAIL(LMV_ERR_WORKSPACE, "layernorm_bwd: workspace %zu < %zu bytes", ws_bytes, need);
+  float* partial = reinterpret_cast<float*>(ws);
+  dim3 grid(blocks), block(TPB);
+#define LN_BWD_CASE(N) case N: hipLaunchKernelGGL((ln_bwd_kernel<T, N>), grid, block, 0, st, (const T*)dy, (const T*)x, stats, gamma, (const T*)dres, (T*)dx, partial, rows, C, l2); break;
   switch (nit) {
     LN_BWD_CASE(1) LN_BWD_CASE(2) LN_BWD_CASE(3) LN_BWD_CASE(4) LN_BWD_CASE(5) LN_BWD_CASE(6)
     default:
@@ -193,7 +203,7 @@ int launch_bwd(const void* dy, const void* x, const float* stats, const float* g
   }
 #undef LN_BWD_CASE
   LMV_CHECK_LAUNCH("layernorm_bwd");
-  return LMV_OK;
+  return lmv_launch_partial_reduce(partial, blocks, 2 * C, dgamma, C, dbeta, 0, st);
 }
 
 }  // namespace
@@ -209,13 +219,18 @@ extern "C" int lmv_layernorm_fwd(const void* x, const float* gamma, const float*
   LMV_FAIL(LMV_ERR_DTYPE, "layernorm: unsupported dtype %d", dtype);
 }
 
+extern "C" size_t lmv_layernorm_bwd_workspace_bytes(int64_t rows, int C, int dtype) {
+  if (rows <= 0 || C <= 0) return 0;
+  return (size_t)512 * 2 * C * sizeof(float);     // upper bound: at most 512 workgroups
+}
+
 extern "C" int lmv_layernorm_bwd(const void* dy, const void* x, const float* stats, const float* gamma, const void* dres, void* dx,
-                                 float* dgamma, float* dbeta, int64_t rows, int C, int dtype, void* stream) {
+                                 float* dgamma, float* dbeta, int64_t rows, int C, void* workspace, size_t workspace_bytes, int dtype, void* stream) {
   if (rows <= 0) return LMV_OK;
   if (C <= 0 || (C % 8)) LMV_FAIL(LMV_ERR_SHAPE, "layernorm_bwd: C=%d must be a positive multiple of 8", C);
   if (!dy || !x || !stats || !gamma || !dx || !dgamma || !dbeta || !lmv_aligned16(dy) || !lmv_aligned16(x) || !lmv_aligned16(dx) || !lmv_aligned16(dres))
     LMV_FAIL(LMV_ERR_SHAPE, "layernorm_bwd: null or misaligned operand");
-  if (dtype == LMV_BF16) return launch_bwd<bf16_t>(dy, x, stats, gamma, dres, dx, dgamma, dbeta, rows, C, (hipStream_t)stream);
-  if (dtype == LMV_F32) return launch_bwd<float>(dy, x, stats, gamma, dres, dx, dgamma, dbeta, rows, C, (hipStream_t)stream);
+  if (dtype == LMV_BF16) return launch_bwd<bf16_t>(dy, x, stats, gamma, dres, dx, dgamma, dbeta, rows, C, workspace, workspace_bytes, (hipStream_t)stream);
+  if (dtype == LMV_F32) return launch_bwd<float>(dy, x, stats, gamma, dres, dx, dgamma, dbeta, rows, C, workspace, workspace_bytes, (hipStream_t)stream);
   LMV_FAIL(LMV_ERR_DTYPE, "layernorm_bwd: unsupported dtype %d", dtype);
 }

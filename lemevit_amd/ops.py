@@ -41,6 +41,20 @@ def _ptr(t: Optional[Tensor]) -> Optional[int]:
     return t.data_ptr()
 
 
+_ws_cache = {}
+
+
+def _workspace(nbytes: int, device) -> Tensor:
+    """Scratch for the split reductions, one per (device, stream); stream-ordered reuse is safe because every consumer
+    of the scratch is enqueued on the same stream before the next producer."""
+    key = (device, torch.cuda.current_stream().cuda_stream)
+    ws = _ws_cache.get(key)
+    if ws is None or ws.numel() < nbytes:
+        ws = torch.empty(max(int(nbytes * 1.25), 1 << 22), device=device, dtype=torch.uint8)
+        _ws_cache[key] = ws
+    return ws
+
+
 def _f32(t: Optional[Tensor]) -> Optional[int]:
     if t is not None and t.dtype != torch.float32:
         raise TypeError("lemevit_amd: vector operands (bias, LN affine, scales, gradient accumulators) must be float32")
@@ -82,7 +96,9 @@ def linear_dx(probs: Sequence[Prob], N: int, K: int, act: int = ACT_NONE) -> Non
 
 def linear_dw(probs: Sequence[Prob], N: int, K: int) -> None:
     """out (fp32 [N,K]) += a^T @ w ; bias_grad (fp32 [N]) += colsum(a); a = dY [rows,N], w = X [rows,K]."""
-    check(lib.lmv_linear_dw(_pack(probs), len(probs), N, K, dtype_code(probs[0].a), _stream()), "lmv_linear_dw")
+    arr, code = _pack(probs), dtype_code(probs[0].a)
+    ws = _workspace(lib.lmv_linear_dw_workspace_bytes(arr, len(probs), N, K, code), probs[0].a.device)
+    check(lib.lmv_linear_dw(arr, len(probs), N, K, ws.data_ptr(), ws.numel(), code, _stream()), "lmv_linear_dw")
 
 
 # -------------------------------------------------------------------------------------------
@@ -103,8 +119,9 @@ def layernorm_bwd(dy: Tensor, x: Tensor, stats: Tensor, gamma: Tensor, dgamma: T
     C_ = x.shape[-1]
     rows = x.numel() // C_
     dx = torch.empty_like(x)
+    ws = _workspace(lib.lmv_layernorm_bwd_workspace_bytes(rows, C_, dtype_code(x)), x.device)
     check(lib.lmv_layernorm_bwd(_ptr(dy), _ptr(x), _f32(stats), _f32(gamma), _ptr(dres), _ptr(dx), _f32(dgamma), _f32(dbeta),
-                                rows, C_, dtype_code(x), _stream()), "lmv_layernorm_bwd")
+                                rows, C_, ws.data_ptr(), ws.numel(), dtype_code(x), _stream()), "lmv_layernorm_bwd")
     return dx
 
 
@@ -130,25 +147,14 @@ def dwconv_residual_bwd_data(dy: Tensor, weight: Tensor, H: int, W: int) -> Tens
 
 def dwconv_bwd_weight(dy: Tensor, x: Tensor, dweight: Tensor, dbias: Tensor, H: int, W: int) -> None:
     B, N, C_ = dy.shape
-    check(lib.lmv_dwconv3x3_bwd_weight(_ptr(dy), _ptr(x), _f32(dweight), _f32(dbias), B, H, W, C_, dtype_code(dy), _stream()),
+    ws = _workspace(lib.lmv_dwconv3x3_bwd_weight_workspace_bytes(B, H, W, C_, dtype_code(dy)), dy.device)
+    check(lib.lmv_dwconv3x3_bwd_weight(_ptr(dy), _ptr(x), _f32(dweight), _f32(dbias), B, H, W, C_, ws.data_ptr(), ws.numel(), dtype_code(dy), _stream()),
           "lmv_dwconv3x3_bwd_weight")
 
 
 # -------------------------------------------------------------------------------------------
 # attention cores; q/k/v are (tensor, column offset) views into packed projections [B, L, X*C]
 # -------------------------------------------------------------------------------------------
-_ws_cache = {}
-
-
-def _workspace(nbytes: int, device) -> Tensor:
-    key = (device, torch.cuda.current_stream().cuda_stream)
-    ws = _ws_cache.get(key)
-    if ws is None or ws.numel() < nbytes:
-        ws = torch.empty(max(nbytes, 1 << 20), device=device, dtype=torch.uint8)
-        _ws_cache[key] = ws
-    return ws
-
-
 def _desc(q: Tuple[Tensor, int], k: Tuple[Tensor, int], v: Tuple[Tensor, int], o: Tensor, lse: Optional[Tensor], C_: int, scale: float) -> AttnDesc:
     qt, qo = q; kt, ko = k; vt, vo = v
     es = qt.element_size()

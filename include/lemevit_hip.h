@@ -75,15 +75,26 @@ int lmv_linear_dw(const lmv_linear_problem* p, int nproblems, int N, int K, void
 
 /* ------------------------------------------------------------------------------------------
  * LayerNorm over the last dim (nn.LayerNorm, models/lemevit.py:513,525 eps 1e-6; :731-743,774
- * eps 1e-5).  stats = [rows, 2] fp32 (mean, rstd), written by fwd when non-NULL.
+ * eps 1e-5).  One launch normalises up to TWO row segments with the same (gamma, beta): the image-token
+ * and the meta-token matrix of a block share norm1 / norm2 (:560-564,:632-635).
+ *   fwd: y = LN(x); stats = [rows, 2] fp32 (mean, rstd), written when non-NULL.
  *   bwd: dx = dres + LN'(dy)   (dres may be NULL);  dgamma/dbeta are ACCUMULATED (fp32; per-workgroup partials
- *        in `workspace` + a reduce kernel).
+ *        in `workspace` + a reduce kernel, no atomics).
  * ------------------------------------------------------------------------------------------ */
-int lmv_layernorm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* stats,
-                      int64_t rows, int C, float eps, int dtype, void* stream);
-size_t lmv_layernorm_bwd_workspace_bytes(int64_t rows, int C, int dtype);
-int lmv_layernorm_bwd(const void* dy, const void* x, const float* stats, const float* gamma, const void* dres,
-                      void* dx, float* dgamma, float* dbeta, int64_t rows, int C,
+typedef struct {
+  const void* x;      /* [rows, C] input of the forward pass                               */
+  void* y;            /* fwd: output [rows, C]                                              */
+  float* stats;       /* [rows, 2] (mean, rstd): written by fwd (may be NULL), read by bwd  */
+  const void* dy;     /* bwd: gradient of y                                                 */
+  const void* dres;   /* bwd: optional residual-path gradient added to dx (or NULL)         */
+  void* dx;           /* bwd: output [rows, C]                                              */
+  int64_t rows;
+} lmv_ln_segment;
+
+int lmv_layernorm_fwd(const lmv_ln_segment* seg, int nseg, const float* gamma, const float* beta, int C, float eps,
+                      int dtype, void* stream);
+size_t lmv_layernorm_bwd_workspace_bytes(int64_t total_rows, int C, int dtype);
+int lmv_layernorm_bwd(const lmv_ln_segment* seg, int nseg, const float* gamma, float* dgamma, float* dbeta, int C,
                       void* workspace, size_t workspace_bytes, int dtype, void* stream);
 
 /* ------------------------------------------------------------------------------------------

@@ -23,6 +23,11 @@ class LinearProblem(C.Structure):
                 ("bias_grad", C.c_void_p), ("rows", C.c_int64), ("rows_per_sample", C.c_int32), ("_pad", C.c_int32)]
 
 
+class LnSegment(C.Structure):
+    _fields_ = [("x", C.c_void_p), ("y", C.c_void_p), ("stats", C.c_void_p), ("dy", C.c_void_p), ("dres", C.c_void_p),
+                ("dx", C.c_void_p), ("rows", C.c_int64)]
+
+
 class AttnDesc(C.Structure):
     _fields_ = [("q", C.c_void_p), ("k", C.c_void_p), ("v", C.c_void_p), ("o", C.c_void_p), ("lse", C.c_void_p),
                 ("d_o", C.c_void_p), ("dq", C.c_void_p), ("dk", C.c_void_p), ("dv", C.c_void_p),
@@ -42,9 +47,9 @@ SIGNATURES = {
     "lmv_linear_dx": (_I, [C.POINTER(LinearProblem), _I, _I, _I, _I, _I, _P]),
     "lmv_linear_dw_workspace_bytes": (_Z, [C.POINTER(LinearProblem), _I, _I, _I, _I]),
     "lmv_linear_dw": (_I, [C.POINTER(LinearProblem), _I, _I, _I, _P, _Z, _I, _P]),
-    "lmv_layernorm_fwd": (_I, [_P, _P, _P, _P, _P, _L, _I, _F, _I, _P]),
+    "lmv_layernorm_fwd": (_I, [C.POINTER(LnSegment), _I, _P, _P, _I, _F, _I, _P]),
     "lmv_layernorm_bwd_workspace_bytes": (_Z, [_L, _I, _I]),
-    "lmv_layernorm_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _P, _Z, _I, _P]),
+    "lmv_layernorm_bwd": (_I, [C.POINTER(LnSegment), _I, _P, _P, _P, _I, _P, _Z, _I, _P]),
     "lmv_dwconv3x3_residual_fwd": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "lmv_dwconv3x3_residual_bwd_data": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "lmv_dwconv3x3_bwd_weight_workspace_bytes": (_Z, [_I, _I, _I, _I, _I]),

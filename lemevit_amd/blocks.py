@@ -50,7 +50,7 @@ def _rps(t: Tensor) -> int:
 def _mlp_fwd(P: Dict[str, Tensor], ts: Sequence[Tensor], ds: Sequence[Optional[Tensor]], save: bool):
     C = ts[0].shape[-1]
     Hd = P["mlp.0.weight"].shape[0]
-    xn, st = zip(*[ops.layernorm_fwd(t, P["norm2.weight"], P["norm2.bias"], BLOCK_LN_EPS, want_stats=save) for t in ts])
+    xn, st = ops.layernorm_fwd_multi(ts, P["norm2.weight"], P["norm2.bias"], BLOCK_LN_EPS, want_stats=save)
     h = [_empty(t, Hd) for t in ts]
     u = [_empty(t, Hd) if save else None for t in ts]
     ops.linear_fwd([Prob(a, P["mlp.0.weight"], o, bias=P["mlp.0.bias"], out_pre=pre) for a, o, pre in zip(xn, h, u)], Hd, C, ACT_GELU)
@@ -71,7 +71,7 @@ def _mlp_bwd(P, G, saved, douts: Sequence[Tensor], ds: Sequence[Optional[Tensor]
     ops.linear_dw([Prob(dui, xi, G["mlp.0.weight"], bias_grad=G["mlp.0.bias"]) for dui, xi in zip(du, xn)], Hd, C)
     dxn = [torch.empty_like(t) for t in ts]
     ops.linear_dx([Prob(dui, P["mlp.0.weight"], o) for dui, o in zip(du, dxn)], Hd, C)
-    return [ops.layernorm_bwd(dn, t, s, P["norm2.weight"], G["norm2.weight"], G["norm2.bias"], dres=d) for dn, t, s, d in zip(dxn, ts, st, douts)]
+    return ops.layernorm_bwd_multi(dxn, ts, st, P["norm2.weight"], G["norm2.weight"], G["norm2.bias"], douts)
 
 
 # ------------------------------------------------------------------------------------------------
@@ -80,7 +80,7 @@ def _mlp_bwd(P, G, saved, douts: Sequence[Tensor], ds: Sequence[Optional[Tensor]
 def _attn_S_fwd(P, ts, ds, save):
     """t <- t + ds * proj(SA(qkv(LN1(t)))) for x and c with the SAME weights (models/lemevit.py:632,634)."""
     C = ts[0].shape[-1]
-    xn, st = zip(*[ops.layernorm_fwd(t, P["norm1.weight"], P["norm1.bias"], BLOCK_LN_EPS, want_stats=save) for t in ts])
+    xn, st = ops.layernorm_fwd_multi(ts, P["norm1.weight"], P["norm1.bias"], BLOCK_LN_EPS, want_stats=save)
     qkv = [_empty(t, 3 * C) for t in ts]
     ops.linear_fwd([Prob(a, P["attn.qkv.weight"], o, bias=P["attn.qkv.bias"]) for a, o in zip(xn, qkv)], 3 * C, C)
     ao, lse = zip(*[ops.attn_fwd((q, 0), (q, C), (q, 2 * C), C, ops.SDPA_SCALE, want_lse=save) for q in qkv])
@@ -102,7 +102,7 @@ def _attn_S_bwd(P, G, saved, douts, ds):
     ops.linear_dw([Prob(dq, xi, G["attn.qkv.weight"], bias_grad=G["attn.qkv.bias"]) for dq, xi in zip(dqkv, xn)], 3 * C, C)
     dxn = [torch.empty_like(t) for t in ts]
     ops.linear_dx([Prob(dq, P["attn.qkv.weight"], o) for dq, o in zip(dqkv, dxn)], 3 * C, C)
-    return [ops.layernorm_bwd(dn, t, s, P["norm1.weight"], G["norm1.weight"], G["norm1.bias"], dres=d) for dn, t, s, d in zip(dxn, ts, st, douts)]
+    return ops.layernorm_bwd_multi(dxn, ts, st, P["norm1.weight"], G["norm1.weight"], G["norm1.bias"], douts)
 
 
 def _attn_D_fwd(P, ts, ds, save):
@@ -110,7 +110,7 @@ def _attn_D_fwd(P, ts, ds, save):
     x, c = ts
     C, N, M = x.shape[-1], x.shape[1], c.shape[1]
     sx, sc = ops.dca_scales(N, M, C)
-    xn, st = zip(*[ops.layernorm_fwd(t, P["norm1.weight"], P["norm1.bias"], BLOCK_LN_EPS, want_stats=save) for t in ts])
+    xn, st = ops.layernorm_fwd_multi(ts, P["norm1.weight"], P["norm1.bias"], BLOCK_LN_EPS, want_stats=save)
     q1, q2 = _empty(x, 3 * C), _empty(c, 3 * C)
     ops.linear_fwd([Prob(xn[0], P["attn.qkv1.weight"], q1, bias=P["attn.qkv1.bias"]),
                     Prob(xn[1], P["attn.qkv2.weight"], q2, bias=P["attn.qkv2.bias"])], 3 * C, C)
@@ -139,14 +139,13 @@ def _attn_D_bwd(P, G, saved, douts, ds):
                    Prob(dq2, xn[1], G["attn.qkv2.weight"], bias_grad=G["attn.qkv2.bias"])], 3 * C, C)
     dxn = [torch.empty_like(x), torch.empty_like(c)]
     ops.linear_dx([Prob(dq1, P["attn.qkv1.weight"], dxn[0]), Prob(dq2, P["attn.qkv2.weight"], dxn[1])], 3 * C, C)
-    return [ops.layernorm_bwd(dn, t, s, P["norm1.weight"], G["norm1.weight"], G["norm1.bias"], dres=d) for dn, t, s, d in zip(dxn, ts, st, douts)]
+    return ops.layernorm_bwd_multi(dxn, ts, st, P["norm1.weight"], G["norm1.weight"], G["norm1.bias"], douts)
 
 
 def _attn_C_fwd(P, xp, c, ds, save):
     """c <- c + ds * proj(CA(q(LN1(c)), kv(LN1(xp))))  (models/lemevit.py:477-486,600)."""
     C, N, M = c.shape[-1], xp.shape[1], c.shape[1]
-    xn, stx = ops.layernorm_fwd(xp, P["norm1.weight"], P["norm1.bias"], BLOCK_LN_EPS, want_stats=save)
-    cn, stc = ops.layernorm_fwd(c, P["norm1.weight"], P["norm1.bias"], BLOCK_LN_EPS, want_stats=save)
+    (xn, cn), (stx, stc) = ops.layernorm_fwd_multi([xp, c], P["norm1.weight"], P["norm1.bias"], BLOCK_LN_EPS, want_stats=save)
     kv, q = _empty(xp, 2 * C), _empty(c, C)
     ops.linear_fwd([Prob(xn, P["attn.kv.weight"], kv, bias=P["attn.kv.bias"])], 2 * C, C)
     ops.linear_fwd([Prob(cn, P["attn.q.weight"], q, bias=P["attn.q.bias"])], C, C)
@@ -170,8 +169,7 @@ def _attn_C_bwd(P, G, saved, dout, ds):
     dcn, dxn = torch.empty_like(c), torch.empty_like(xp)
     ops.linear_dx([Prob(dq, P["attn.q.weight"], dcn)], C, C)
     ops.linear_dx([Prob(dkv, P["attn.kv.weight"], dxn)], 2 * C, C)
-    dc = ops.layernorm_bwd(dcn, c, stc, P["norm1.weight"], G["norm1.weight"], G["norm1.bias"], dres=dout)
-    dxp = ops.layernorm_bwd(dxn, xp, stx, P["norm1.weight"], G["norm1.weight"], G["norm1.bias"], dres=None)
+    dc, dxp = ops.layernorm_bwd_multi([dcn, dxn], [c, xp], [stc, stx], P["norm1.weight"], G["norm1.weight"], G["norm1.bias"], [dout, None])
     return dxp, dc
 
 

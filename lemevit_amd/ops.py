@@ -13,7 +13,7 @@ from typing import List, Optional, Sequence, Tuple
 import torch
 
 from . import _lib
-from ._lib import ACT_GELU, ACT_GELU_GRAD, ACT_NONE, AttnDesc, LinearProblem, check, lib
+from ._lib import ACT_GELU, ACT_GELU_GRAD, ACT_NONE, AttnDesc, LinearProblem, LnSegment, check, lib
 
 Tensor = torch.Tensor
 HEAD_DIM = 32
@@ -104,25 +104,47 @@ def linear_dw(probs: Sequence[Prob], N: int, K: int) -> None:
 # -------------------------------------------------------------------------------------------
 # LayerNorm
 # -------------------------------------------------------------------------------------------
+def layernorm_fwd_multi(xs: Sequence[Tensor], gamma: Tensor, beta: Tensor, eps: float, want_stats: bool = False):
+    """LayerNorm of up to two tensors sharing (gamma, beta) in ONE launch; returns (ys, stats)."""
+    C_ = xs[0].shape[-1]
+    seg = (LnSegment * len(xs))()
+    ys, sts = [], []
+    for s, x in zip(seg, xs):
+        rows = x.numel() // C_
+        y = torch.empty_like(x)
+        st = torch.empty((rows, 2), device=x.device, dtype=torch.float32) if want_stats else None
+        s.x, s.y, s.stats, s.rows = _ptr(x), _ptr(y), _ptr(st), rows
+        ys.append(y); sts.append(st)
+    check(lib.lmv_layernorm_fwd(seg, len(xs), _f32(gamma), _f32(beta), C_, eps, dtype_code(xs[0]), _stream()), "lmv_layernorm_fwd")
+    return ys, sts
+
+
+def layernorm_bwd_multi(dys: Sequence[Tensor], xs: Sequence[Tensor], stats: Sequence[Tensor], gamma: Tensor, dgamma: Tensor, dbeta: Tensor,
+                        dres: Sequence[Optional[Tensor]]) -> List[Tensor]:
+    """dx_i = dres_i + LN'(dy_i) for up to two tensors in ONE launch; dgamma / dbeta (fp32) are accumulated in place."""
+    C_ = xs[0].shape[-1]
+    seg = (LnSegment * len(xs))()
+    dxs, total = [], 0
+    for s, dy, x, st, dr in zip(seg, dys, xs, stats, dres):
+        dx = torch.empty_like(x)
+        s.x, s.dy, s.stats, s.dres, s.dx, s.rows = _ptr(x), _ptr(dy), _f32(st), _ptr(dr), _ptr(dx), x.numel() // C_
+        total += s.rows
+        dxs.append(dx)
+    code = dtype_code(xs[0])
+    ws = _workspace(lib.lmv_layernorm_bwd_workspace_bytes(total, C_, code), xs[0].device)
+    check(lib.lmv_layernorm_bwd(seg, len(xs), _f32(gamma), _f32(dgamma), _f32(dbeta), C_, ws.data_ptr(), ws.numel(), code, _stream()),
+          "lmv_layernorm_bwd")
+    return dxs
+
+
 def layernorm_fwd(x: Tensor, gamma: Tensor, beta: Tensor, eps: float, want_stats: bool = False) -> Tuple[Tensor, Optional[Tensor]]:
-    C_ = x.shape[-1]
-    rows = x.numel() // C_
-    y = torch.empty_like(x)
-    stats = torch.empty((rows, 2), device=x.device, dtype=torch.float32) if want_stats else None
-    check(lib.lmv_layernorm_fwd(_ptr(x), _f32(gamma), _f32(beta), _ptr(y), _ptr(stats), rows, C_, eps, dtype_code(x), _stream()),
-          "lmv_layernorm_fwd")
-    return y, stats
+    ys, sts = layernorm_fwd_multi([x], gamma, beta, eps, want_stats)
+    return ys[0], sts[0]
 
 
 def layernorm_bwd(dy: Tensor, x: Tensor, stats: Tensor, gamma: Tensor, dgamma: Tensor, dbeta: Tensor, dres: Optional[Tensor] = None) -> Tensor:
     """dx = dres + LN'(dy); dgamma / dbeta (fp32) are accumulated in place."""
-    C_ = x.shape[-1]
-    rows = x.numel() // C_
-    dx = torch.empty_like(x)
-    ws = _workspace(lib.lmv_layernorm_bwd_workspace_bytes(rows, C_, dtype_code(x)), x.device)
-    check(lib.lmv_layernorm_bwd(_ptr(dy), _ptr(x), _f32(stats), _f32(gamma), _ptr(dres), _ptr(dx), _f32(dgamma), _f32(dbeta),
-                                rows, C_, ws.data_ptr(), ws.numel(), dtype_code(x), _stream()), "lmv_layernorm_bwd")
-    return dx
+    return layernorm_bwd_multi([dy], [x], [stats], gamma, dgamma, dbeta, [dres])[0]
 
 
 # -------------------------------------------------------------------------------------------

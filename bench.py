@@ -47,6 +47,7 @@ def parse():
     ap.add_argument("--mode", default="train", choices=["train", "infer"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--graph", type=int, default=1, help="capture the step into a hipGraph (lemevit_amd.graph.GraphedStep); 0 = eager launches")
     return ap.parse_args()
 
 
@@ -161,7 +162,8 @@ def main():
         # benchmark.py:559-561 create_optimizer_v2(opt='adamw', lr=1e-4), scripts/benchmark.sh:8 eps 1e-8 wd 0.05
         decay = [p for n, p in model.named_parameters() if p.ndim > 1]
         no_decay = [p for n, p in model.named_parameters() if p.ndim <= 1]
-        opt = torch.optim.AdamW([dict(params=decay, weight_decay=0.05), dict(params=no_decay, weight_decay=0.0)], lr=1e-4, eps=1e-8, fused=True)
+        opt = torch.optim.AdamW([dict(params=decay, weight_decay=0.05), dict(params=no_decay, weight_decay=0.0)], lr=1e-4, eps=1e-8, fused=True,
+                                capturable=bool(args.graph))
         net = wrap_ddp(model, local) if world > 1 else model
 
         def step():
@@ -181,16 +183,30 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    eager_step, graph_note = step, "eager"
+    if args.graph and world == 1:
+        from lemevit_amd.graph import try_graphed
+        step, why = try_graphed(eager_step, warmup=3)
+        graph_note = "hipGraph replay" if why is None else f"eager (graph capture failed: {why})"
     for _ in range(args.warmup):
         step()
     sync()
-    timer.enabled = True
+    timer.enabled = step is eager_step                 # HIP events cannot be timed inside a captured graph
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     sync()
     dt = time.perf_counter() - t0
     timer.enabled = False
+    kernel_timing_note = "HIP events around every launch inside the timed region"
+    if step is not eager_step and rank == 0 and not args.no_kernel_timing:
+        # same kernels, same shapes: bracket the launches of 3 eager steps right after the timed (graph-replay) region
+        timer.enabled = True
+        for _ in range(3):
+            eager_step()
+        torch.cuda.synchronize()
+        timer.enabled = False
+        kernel_timing_note = "HIP events around every launch of 3 eager steps run right after the timed hipGraph-replay region"
     tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -204,7 +220,7 @@ def main():
         roof = None
         if g is not None:
             roof = dict(bound="mfma", achieved=round(g["tflops"], 2), peak=PEAK_BF16_TFLOPS, unit="TFLOP/s", frac=round(g["tflops"] / PEAK_BF16_TFLOPS, 4),
-                        traffic=None, kernel="gemm_kernel<bf16,NT> (Linear forward)", launches=g["launches"], avg_launch_us=round(g["avg_us"], 2),
+                        traffic=None, kernel="gemm_kernel<bf16,NT> (Linear forward)", measured=kernel_timing_note, launches=g["launches"], avg_launch_us=round(g["avg_us"], 2),
                         gflop_per_launch=round(g["gflop_per_launch"], 3))
         line = {
             "metric": "images/sec LeMeViT-Base 224^2 bf16 fwd+bwd" if train else "images/sec LeMeViT-Base 224^2 bf16 fwd",
@@ -213,7 +229,7 @@ def main():
             "dtype": "bf16", "data": "synthetic",
             "config": {"workload": f"{args.model} {args.img}x{args.img} bf16-autocast {'train step (fwd+bwd+AdamW)' if train else 'forward'}, "
                                    f"batch {args.batch}/GPU, drop_path 0.1, random-init weights", "global_batch": args.batch * world,
-                       "parallelism": f"dp{world}"},
+                       "parallelism": f"dp{world}", "launch": graph_note},
             "model_tflops": round(value * CANONICAL_GFLOP_FWD * mult / 1e3, 2),
             "model_frac_of_bf16_peak": round(value * CANONICAL_GFLOP_FWD * mult / 1e3 / (PEAK_BF16_TFLOPS * world), 4),
             "roofline": roof,

@@ -248,12 +248,57 @@ __device__ __forceinline__ void store_tile(unsigned char* smem, const f32x4_t (&
   }
 }
 
-template <typename T, bool ATR, bool BTR, bool SPLITK, int BK>
+// ---- global -> LDS directly (bf16): global_load_lds_dwordx4 writes  wave-uniform base + lane * 16, i.e. each
+// wave-instruction fills one LINEAR 1 KiB segment of the tile image.  The XOR swizzle therefore goes on the per-lane
+// SOURCE address: the lane that lands on physical chunk p of row r fetches logical chunk p ^ swz(r).  No staging
+// VGPRs and no ds_write pass (ds_write_b128 costs ~13 LDS cycles per wave-instruction and made the register-staged
+// loop LDS-bound).  Lanes whose tile row / column lies outside the matrix are masked off: their LDS bytes stay stale,
+// which only ever feeds accumulators of outputs that are not stored (the reduction dimension is never masked here:
+// the host uses this path only when Kred is a multiple of BK).
+typedef __attribute__((address_space(3))) void* lds_vp;
+typedef const __attribute__((address_space(1))) void* glb_vp;
+
+template <bool TR, int BK>
+__device__ __forceinline__ void stage_dma(unsigned char* tile, const bf16_t* __restrict__ base, int64_t ld, int dim, int tile0, int k0,
+                                          int lane, int wave) {
+  constexpr int NSEG = BM * BK * 2 / 1024;          // 1 KiB segments per tile image
+#pragma unroll
+  for (int i = 0; i < NSEG / 4; ++i) {
+    const int sg = wave + i * 4;
+    const bf16_t* src;
+    bool ok;
+    // out-of-range rows / columns are CLAMPED, not masked: every wave issues exactly the same number of LDS-DMA
+    // instructions per tile (the ring pipeline below counts them with s_waitcnt vmcnt(N)), and the duplicated data
+    // only reaches accumulators of outputs that are never stored.
+    if (!TR) {
+      constexpr int ROWB = BK * 2, CPR = ROWB / 16, RPS = 1024 / ROWB;
+      const int r = sg * RPS + lane / CPR, p = lane % CPR, kc = p ^ swz_n<ROWB>(r);
+      src = base + (int64_t)min(tile0 + r, dim - 1) * ld + k0 + kc * 8;
+    } else {
+      const int r = sg * 4 + (lane >> 4), p16 = lane & 15, c16 = ((((p16 >> 1) ^ swz_t(r))) << 1) | (p16 & 1);
+      src = base + (int64_t)(k0 + r) * ld + min(tile0 + c16 * 8, dim - 8);
+    }
+    (void)ok;
+    __builtin_amdgcn_global_load_lds((glb_vp)src, (lds_vp)(tile + sg * 1024), 16, 0, 0);
+  }
+}
+
+// wait until at most `pending` whole tiles (DPT LDS-DMA instructions each) of this wave are still in flight
+template <int DPT>
+__device__ __forceinline__ void wait_tiles(int pending) {
+  if (pending <= 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  else if (pending == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DPT) : "memory");
+  else if (pending == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * DPT) : "memory");
+  else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * DPT) : "memory");
+}
+
+template <typename T, bool ATR, bool BTR, bool SPLITK, int BK, bool DMA, int NBUF>
 __global__ __launch_bounds__(NTHR) void gemm_kernel(const GemmArgs g) {
   constexpr int NCH = (BM * BK * (int)sizeof(T)) / 16 / NTHR;
   constexpr int TILE_BYTES = BM * BK * (int)sizeof(T);
-  __shared__ __attribute__((aligned(16))) unsigned char smem[4 * TILE_BYTES];   // [buffer][A | B]; reused by the epilogue
-  static_assert(4 * TILE_BYTES >= 64 * BN * 4, "epilogue staging needs 32 KB");
+  static_assert(DMA || NBUF == 2, "the register-staged loop is double-buffered");
+  __shared__ __attribute__((aligned(16))) unsigned char smem[NBUF * 2 * TILE_BYTES];   // [buffer][A | B]; reused by the epilogue
+  static_assert(NBUF * 2 * TILE_BYTES >= 64 * BN * 4, "epilogue staging needs 32 KB");
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
@@ -286,31 +331,65 @@ __global__ __launch_bounds__(NTHR) void gemm_kernel(const GemmArgs g) {
     for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
   }
 
-  uint4 ra[NCH], rb[NCH];
-  stage_load<T, ATR, BK, NCH>(ra, A, g.lda, M, Kred, m0, kt_beg * BK, tid);
-  stage_load<T, BTR, BK, NCH>(rb, Bw, g.ldb, N, Kred, n0, kt_beg * BK, tid);
   const bool do_bsum = SPLITK && (P.bias_grad != nullptr) && tn == 0 && wn == 0;      // wave-uniform
-  stage_store<T, ATR, BK, NCH>(smem, ra, tid);
-  stage_store<T, BTR, BK, NCH>(smem + TILE_BYTES, rb, tid);
-  __syncthreads();
-
   int cur = 0;
-  for (int kt = kt_beg; kt < kt_end; ++kt) {
-    const bool has_next = kt + 1 < kt_end;
-    if (has_next) {                                   // global loads of the next k-tile fly under this tile's MFMAs
-      stage_load<T, ATR, BK, NCH>(ra, A, g.lda, M, Kred, m0, (kt + 1) * BK, tid);
-      stage_load<T, BTR, BK, NCH>(rb, Bw, g.ldb, N, Kred, n0, (kt + 1) * BK, tid);
+  if constexpr (DMA) {
+    static_assert(sizeof(T) == 2, "the direct-to-LDS path is bf16 only");
+    const bf16_t* A16 = reinterpret_cast<const bf16_t*>(A);
+    const bf16_t* B16 = reinterpret_cast<const bf16_t*>(Bw);
+    // Ring of NBUF tile buffers with up to NBUF-1 k-tiles in flight.  HBM latency (~2 us under load) is far longer
+    // than one tile's MFMAs, so a single prefetched tile leaves the matrix cores idle; LDS-DMA requests are kept in
+    // flight ACROSS barriers by counting them (s_waitcnt vmcnt(N), raw s_barrier -- a __syncthreads() would drain
+    // them).  Per k-tile: wait for tile kt (own DMAs) -> barrier (everyone's DMAs for kt landed, everyone finished
+    // reading the buffer of tile kt-1) -> refill that buffer with tile kt+NBUF-1 -> MFMAs on tile kt.
+    constexpr int DPT = 2 * (BM * BK * 2 / 1024) / 4;   // LDS-DMA instructions per wave per k-tile (A + B)
+    const int nk = kt_end - kt_beg;
+#pragma unroll
+    for (int s = 0; s < NBUF - 1; ++s) {
+      if (s < nk) {
+        stage_dma<ATR, BK>(smem + s * 2 * TILE_BYTES, A16, g.lda, M, m0, (kt_beg + s) * BK, lane, wave);
+        stage_dma<BTR, BK>(smem + s * 2 * TILE_BYTES + TILE_BYTES, B16, g.ldb, N, n0, (kt_beg + s) * BK, lane, wave);
+      }
     }
-    const unsigned char* sA = smem + cur * 2 * TILE_BYTES;
-    const unsigned char* sB = sA + TILE_BYTES;
-    tile_mma<T, ATR, BTR, BK, SPLITK>(sA, sB, acc, accb, do_bsum, wm, wn, lane);
-    if (has_next) {
-      unsigned char* dA = smem + (cur ^ 1) * 2 * TILE_BYTES;
-      stage_store<T, ATR, BK, NCH>(dA, ra, tid);
-      stage_store<T, BTR, BK, NCH>(dA + TILE_BYTES, rb, tid);
+    for (int i = 0; i < nk; ++i) {
+      const int issued_after = min(NBUF - 2, nk - 1 - i);          // tiles issued after tile i and still allowed in flight
+      wait_tiles<DPT>(issued_after);
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      if (i + NBUF - 1 < nk) {
+        unsigned char* dA = smem + ((i + NBUF - 1) % NBUF) * 2 * TILE_BYTES;
+        stage_dma<ATR, BK>(dA, A16, g.lda, M, m0, (kt_beg + i + NBUF - 1) * BK, lane, wave);
+        stage_dma<BTR, BK>(dA + TILE_BYTES, B16, g.ldb, N, n0, (kt_beg + i + NBUF - 1) * BK, lane, wave);
+      }
+      const unsigned char* sA = smem + (i % NBUF) * 2 * TILE_BYTES;
+      tile_mma<T, ATR, BTR, BK, SPLITK>(sA, sA + TILE_BYTES, acc, accb, do_bsum, wm, wn, lane);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");           // this wave's LDS reads of tile i are complete
     }
     __syncthreads();
-    cur ^= 1;
+  } else {
+    uint4 ra[NCH], rb[NCH];
+    stage_load<T, ATR, BK, NCH>(ra, A, g.lda, M, Kred, m0, kt_beg * BK, tid);
+    stage_load<T, BTR, BK, NCH>(rb, Bw, g.ldb, N, Kred, n0, kt_beg * BK, tid);
+    stage_store<T, ATR, BK, NCH>(smem, ra, tid);
+    stage_store<T, BTR, BK, NCH>(smem + TILE_BYTES, rb, tid);
+    __syncthreads();
+    for (int kt = kt_beg; kt < kt_end; ++kt) {
+      const bool has_next = kt + 1 < kt_end;
+      if (has_next) {                                   // global loads of the next k-tile fly under this tile's MFMAs
+        stage_load<T, ATR, BK, NCH>(ra, A, g.lda, M, Kred, m0, (kt + 1) * BK, tid);
+        stage_load<T, BTR, BK, NCH>(rb, Bw, g.ldb, N, Kred, n0, (kt + 1) * BK, tid);
+      }
+      const unsigned char* sA = smem + cur * 2 * TILE_BYTES;
+      const unsigned char* sB = sA + TILE_BYTES;
+      tile_mma<T, ATR, BTR, BK, SPLITK>(sA, sB, acc, accb, do_bsum, wm, wn, lane);
+      if (has_next) {
+        unsigned char* dA = smem + (cur ^ 1) * 2 * TILE_BYTES;
+        stage_store<T, ATR, BK, NCH>(dA, ra, tid);
+        stage_store<T, BTR, BK, NCH>(dA + TILE_BYTES, rb, tid);
+      }
+      __syncthreads();
+      cur ^= 1;
+    }
   }
 
   if constexpr (SPLITK) {
@@ -355,7 +434,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
 
 enum Mode { MODE_FWD = 0, MODE_DX = 1, MODE_DW = 2 };
 
-struct Plan { GemmArgs g; int total, splits, bk, nsplit[2]; size_t ws_bytes; };
+struct Plan { GemmArgs g; int total, splits, bk, nbuf, nsplit[2]; size_t ws_bytes; };
 
 int make_plan(const lmv_linear_problem* p, int nproblems, int N, int K, int act, int dtype, Mode mode, Plan* pl) {
   if (nproblems < 1 || nproblems > 2) LMV_FAIL(LMV_ERR_SHAPE, "linear: nproblems must be 1 or 2 (got %d)", nproblems);
@@ -394,7 +473,15 @@ int make_plan(const lmv_linear_problem* p, int nproblems, int N, int K, int act,
   int min_kred = 1 << 30;
   bool all64 = true;
   for (int i = 0; i < nproblems; ++i) { if (g.p[i].Kred < min_kred) min_kred = g.p[i].Kred; if (g.p[i].Kred % 64) all64 = false; }
-  const int bk = (bf && (mode == MODE_DW || all64 || min_kred >= 512)) ? 64 : 32;
+  // LMV_GEMM_RING=0: 64-deep tiles, double-buffered (2 x 32 KB); default: 32-deep tiles in a 4-slot LDS-DMA ring (4 x 16 KB,
+  // up to 3 k-tiles in flight per workgroup)
+  static const bool ring = [] { const char* e = getenv("LMV_GEMM_RING"); return !e || atoi(e) != 0; }();
+  static const bool no_dma_env = getenv("LMV_GEMM_NO_DMA") != nullptr;
+  bool all32 = true;
+  for (int i = 0; i < nproblems; ++i) if (g.p[i].Kred % 32) all32 = false;
+  const bool use_ring = bf && ring && !no_dma_env && all32;
+  const int bk = use_ring ? 32 : ((bf && (mode == MODE_DW || all64 || min_kred >= 512)) ? 64 : 32);
+  pl->nbuf = use_ring ? 4 : 2;
   int max_kt = 1;
   for (int i = 0; i < nproblems; ++i) { const int kt = (g.p[i].Kred + bk - 1) / bk; if (kt > max_kt) max_kt = kt; }
   int splits = 1;
@@ -435,14 +522,26 @@ int launch(const lmv_linear_problem* p, int nproblems, int N, int K, int act, in
   const int bk = pl.bk;
   dim3 grid(pl.total, pl.splits), block(NTHR);
   hipStream_t st = (hipStream_t)stream;
-#define LAUNCH(T, A, B, SK, KK) hipLaunchKernelGGL((gemm_kernel<T, A, B, SK, KK>), grid, block, 0, st, g)
+  // direct-to-LDS staging needs an unmasked reduction dimension (and is bf16 only); LMV_GEMM_NO_DMA=1 forces the
+  // register-staged kernels (A/B testing)
+  static const bool no_dma = getenv("LMV_GEMM_NO_DMA") != nullptr;
+  bool dma = bf && !no_dma;
+  for (int i = 0; i < nproblems; ++i) if (g.p[i].Kred % bk) dma = false;
+#define LAUNCH(T, A, B, SK, KK, DM, NB) hipLaunchKernelGGL((gemm_kernel<T, A, B, SK, KK, DM, NB>), grid, block, 0, st, g)
+#define LAUNCH_BF(A, B, SK)                                                                                           \
+  do {                                                                                                                \
+    if (dma && pl.nbuf == 4) LAUNCH(bf16_t, A, B, SK, 32, true, 4);                                                    \
+    else if (bk == 64) { if (dma) LAUNCH(bf16_t, A, B, SK, 64, true, 2); else LAUNCH(bf16_t, A, B, SK, 64, false, 2); } \
+    else               { if (dma) LAUNCH(bf16_t, A, B, SK, 32, true, 2); else LAUNCH(bf16_t, A, B, SK, 32, false, 2); } \
+  } while (0)
   if (mode == MODE_FWD) {
-    if (!bf) LAUNCH(float, false, false, false, 32); else if (bk == 64) LAUNCH(bf16_t, false, false, false, 64); else LAUNCH(bf16_t, false, false, false, 32);
+    if (!bf) LAUNCH(float, false, false, false, 32, false, 2); else LAUNCH_BF(false, false, false);
   } else if (mode == MODE_DX) {
-    if (!bf) LAUNCH(float, false, true, false, 32); else if (bk == 64) LAUNCH(bf16_t, false, true, false, 64); else LAUNCH(bf16_t, false, true, false, 32);
+    if (!bf) LAUNCH(float, false, true, false, 32, false, 2); else LAUNCH_BF(false, true, false);
   } else {
-    if (!bf) LAUNCH(float, true, true, true, 32); else LAUNCH(bf16_t, true, true, true, 64);
+    if (!bf) LAUNCH(float, true, true, true, 32, false, 2); else LAUNCH_BF(true, true, true);
   }
+#undef LAUNCH_BF
 #undef LAUNCH
   LMV_CHECK_LAUNCH("linear");
   if (mode == MODE_DW) {

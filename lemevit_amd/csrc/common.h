@@ -87,7 +87,22 @@ __device__ __forceinline__ void st4(bf16_t* p, const float* f) { *reinterpret_ca
 // exact-erf GELU and its derivative (nn.GELU default, models/lemevit.py:528)
 __device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
 __device__ __forceinline__ float gelu_grad_f(float x) {
-  return 0.5f * (1.0f + erff(x * 0.70710678118654752f)) + x * 0.39894228040143268f * __expf(-0.5f * x * x);
+  return 0.5f * (1.0f + erff(x * 0.70710678118654752f)) + x * 0.39894228040143268f * expf(-0.5f * x * x);
+}
+// bf16 epilogues: branch-free erf (Abramowitz-Stegun 7.1.26, |err| <= 1.5e-7 -- far below bf16 resolution) sharing its
+// exponential with the Gaussian term of GELU'.  ~12 VALU ops instead of libm erff's ~40 with branches.
+__device__ __forceinline__ void erf_as(float x, float* erfv, float* gauss) {   // erf(x / sqrt 2), exp(-x^2 / 2)
+  const float z = fabsf(x) * 0.70710678118654752f;
+  const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * z);
+  const float ex = __expf(-z * z);
+  const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
+  *erfv = copysignf(1.0f - poly * ex, x);
+  *gauss = ex;
+}
+__device__ __forceinline__ float gelu_fast_f(float x) { float e, g; erf_as(x, &e, &g); return 0.5f * x * (1.0f + e); }
+__device__ __forceinline__ float gelu_grad_fast_f(float x) {
+  float e, g; erf_as(x, &e, &g);
+  return 0.5f * (1.0f + e) + x * 0.39894228040143268f * g;
 }
 
 __device__ __forceinline__ float wave_sum(float v) {

@@ -9,26 +9,41 @@
 //                                              ~170 ns each across XCDs)
 // so the backward pass needs neither transposed weight copies nor transposed activations.
 //
-// Tile: 128 x 128 x BK per 256-thread workgroup (BK = 64 bf16 / 32 fp32 and K-tails), 4 waves as
-// 2 x 2, each wave 64 x 64 = 4 x 4 MFMA tiles (v_mfma_f32_16x16x32_bf16, or v_mfma_f32_16x16x4_f32 in
-// the exact-fp32 mode).  Operands are register-staged (global -> VGPR -> LDS) into a DOUBLE-BUFFERED
-// LDS image: the next k-tile's 16-B global loads are issued before the current tile's MFMAs and
-// written to the other buffer after them, so there is ONE barrier per k-step.  LDS images are
-// XOR-swizzled so that both the 16-B fragment reads and the transpose reads are bank-conflict free
-// (derivation in DESIGN.md).  Workgroup ids are remapped so that the n-tiles of one m-tile (which
-// re-read the same activation rows) run on the same XCD and hit its L2.
-// The MFMA operands are passed swapped (W as "A") so every lane ends up with 4 CONSECUTIVE output
-// columns of one row.  The epilogue stages the fp32 tile through (swizzled) LDS, 64 rows at a time, and
-// leaves as whole 256-byte row segments: 16-byte coalesced stores, 16-byte coalesced residual / GELU'
-// operand loads, with bias, exact-erf GELU, DropPath scale and residual add fused.
-// In dW mode the bias gradient (column sums of dY) rides the matrix pipe: one extra MFMA per fragment
-// against an all-ones operand.
+// Workgroup tile (template Cfg): 128x128 (4 waves), 256x128 or 256x256 (8 waves); every wave owns 64x64 or 128x64
+// outputs = WM x 4 MFMA tiles (v_mfma_f32_16x16x32_bf16; exact-fp32 mode: v_mfma_f32_16x16x4_f32).  With K = 96..512
+// these GEMMs are bound by L2 -> CU operand traffic (measured 7.3 TB/s, PMC: MFMA busy 21 %, zero LDS bank
+// conflicts at 128x128 = 64 FLOP per operand byte), so the host picks the LARGEST tile the problem fills the chip
+// with: 256x128 is 85 FLOP/B, 256x256 is 128 FLOP/B.
+//
+// Operand tiles live in LDS as 128-row (or, transposed, 128-column) PANELS, double-buffered over k-tiles of 64
+// (bf16) / 32.  bf16 panels are filled by LDS-DMA (global_load_lds_dwordx4: wave-uniform LDS base + lane * 16, so
+// the XOR swizzle is applied to the per-lane SOURCE address); fp32 and ragged-K problems use a register-staged
+// path (global -> VGPR -> ds_write) on the 128x128 tile.  The swizzles make the 16-byte fragment reads and the
+// transpose reads bank-conflict free (derivation in DESIGN.md; SQ_LDS_BANK_CONFLICT = 0 measured).
+// Workgroup ids are remapped so that the n-tiles of one m-tile run on the same XCD and share its L2.
+//
+// The MFMA operands are passed swapped (W as "A") so every lane ends up with 4 CONSECUTIVE output columns of one
+// row.  The epilogue stages the fp32 tile through swizzled LDS, 64 rows at a time, and leaves as whole row
+// segments: 16-byte coalesced stores, 16-byte coalesced residual / GELU' operand loads, with bias, GELU,
+// DropPath scale and residual add fused.  In dW mode the bias gradient (column sums of dY) rides the matrix pipe:
+// one extra MFMA per fragment against an all-ones operand.
 #include <stdlib.h>
 #include "common.h"
 
 namespace {
 
-constexpr int BM = 128, BN = 128, NTHR = 256;
+constexpr int PANEL = 128;   // rows (normal) or columns (transposed) of one LDS operand panel
+
+template <int NWM_, int NWN_, int WM_>
+struct Cfg {
+  static constexpr int NWM = NWM_, NWN = NWN_, WM = WM_;      // waves along M / N, 16-row MFMA tiles per wave along M
+  static constexpr int NW = NWM * NWN, NTHR = NW * 64;
+  static constexpr int BM = NWM * WM * 16, BN = NWN * 64;
+  static constexpr int PA = BM / PANEL, PB = BN / PANEL;      // operand panels per k-tile
+};
+using C128 = Cfg<2, 2, 4>;        // 128 x 128, 4 waves of 64 x 64
+using C256x128 = Cfg<4, 2, 4>;    // 256 x 128, 8 waves of 64 x 64
+using C256 = Cfg<2, 4, 8>;        // 256 x 256, 8 waves of 128 x 64
 
 struct Problem {
   const void* a; const void* b; const float* bias; const void* res; const float* row_scale; const void* aux;
@@ -37,7 +52,7 @@ struct Problem {
   int Kred;        // reduction length
   int rps;         // rows per sample (DropPath scale index)
   int tiles_m;
-  int tile_begin;  // first blockIdx.x of this problem
+  int tile_begin;  // first logical tile of this problem
   int pad_;
 };
 struct GemmArgs {
@@ -48,19 +63,19 @@ struct GemmArgs {
   int slab_base[2];       // first slab of each problem
 };
 
-// chunk swizzle of a reduction-contiguous tile whose rows are ROWB bytes (64 or 128)
+// chunk swizzle of a reduction-contiguous panel whose rows are ROWB bytes (64 or 128)
 template <int ROWB> __device__ __forceinline__ int swz_n(int row) { return ROWB == 64 ? ((-(row >> 2)) & 3) : ((row >> 1) & 7); }
 __device__ __forceinline__ int swz_t(int r) { return (r & 3) | ((r >> 1) & 4); }
 
-// ---- global -> registers ---------------------------------------------------------------------
-// Normal operand: tile [128 rows][BK] (reduction-contiguous).  TR operand: tile [BK rows][128 cols].
+// ---- register-staged path (128x128 tile, 256 threads): global -> VGPR -> swizzled LDS -------------------------
+// Normal operand: panel [128 rows][BK] (reduction-contiguous).  TR operand: panel [BK rows][128 cols].
 template <typename T, bool TR, int BK, int NCH>
 __device__ __forceinline__ void stage_load(uint4 (&regs)[NCH], const T* __restrict__ base, int64_t ld, int dim, int Kred,
                                            int tile0, int k0, int tid) {
   constexpr int EPC = DT<T>::EPC;
 #pragma unroll
   for (int i = 0; i < NCH; ++i) {
-    const int c = tid + i * NTHR;
+    const int c = tid + i * 256;
     int64_t off; bool ok;
     if (!TR) {
       constexpr int CPR = BK / EPC;
@@ -68,7 +83,7 @@ __device__ __forceinline__ void stage_load(uint4 (&regs)[NCH], const T* __restri
       ok = (row < dim) && (k < Kred);
       off = (int64_t)row * ld + k;
     } else {
-      constexpr int CPR = BM / EPC;
+      constexpr int CPR = PANEL / EPC;
       const int r = k0 + c / CPR, col = tile0 + (c % CPR) * EPC;
       ok = (r < Kred) && (col < dim);
       off = (int64_t)r * ld + col;
@@ -77,21 +92,20 @@ __device__ __forceinline__ void stage_load(uint4 (&regs)[NCH], const T* __restri
   }
 }
 
-// ---- registers -> LDS (swizzled) -------------------------------------------------------------
 template <typename T, bool TR, int BK, int NCH>
 __device__ __forceinline__ void stage_store(unsigned char* s, const uint4 (&regs)[NCH], int tid) {
   constexpr int EPC = DT<T>::EPC;
   constexpr int ROWB = BK * (int)sizeof(T);
 #pragma unroll
   for (int i = 0; i < NCH; ++i) {
-    const int c = tid + i * NTHR;
+    const int c = tid + i * 256;
     int off;
     if (!TR) {
       constexpr int CPR = BK / EPC;
       const int row = c / CPR, kc = c % CPR;
       off = row * ROWB + ((kc ^ swz_n<ROWB>(row)) << 4);
     } else {
-      constexpr int CPR = BM / EPC;
+      constexpr int CPR = PANEL / EPC;
       const int r = c / CPR, cc = c % CPR;
       if (sizeof(T) == 2) off = r * 256 + ((((cc >> 1) ^ swz_t(r))) << 5) + ((cc & 1) << 4);
       else off = r * 512 + (cc << 4);
@@ -100,8 +114,36 @@ __device__ __forceinline__ void stage_store(unsigned char* s, const uint4 (&regs
   }
 }
 
-// ---- LDS -> MFMA fragments -------------------------------------------------------------------
-// bf16: the 32-deep MFMA k-step `hh` of a BK-deep tile
+// ---- LDS-DMA path (bf16): one panel, NW waves ----------------------------------------------------------------
+// Each wave-instruction fills one LINEAR 1 KiB segment of the panel image; the lane that lands on physical chunk p
+// of row r fetches logical chunk p ^ swz(r).  Rows / columns outside the matrix are CLAMPED (never masked), so the
+// duplicated data only reaches accumulators of outputs that are not stored; the reduction dimension is never
+// ragged on this path (host guarantees Kred % BK == 0).
+typedef __attribute__((address_space(3))) void* lds_vp;
+typedef const __attribute__((address_space(1))) void* glb_vp;
+
+template <bool TR, int BK, int NW>
+__device__ __forceinline__ void panel_dma(unsigned char* panel, const bf16_t* __restrict__ base, int64_t ld, int dim, int tile0, int k0,
+                                          int lane, int wave) {
+  constexpr int NSEG = PANEL * BK * 2 / 1024;
+  static_assert(NSEG % NW == 0, "segments must divide over the waves");
+#pragma unroll
+  for (int i = 0; i < NSEG / NW; ++i) {
+    const int sg = wave + i * NW;
+    const bf16_t* src;
+    if (!TR) {
+      constexpr int ROWB = BK * 2, CPR = ROWB / 16, RPS = 1024 / ROWB;
+      const int r = sg * RPS + lane / CPR, p = lane % CPR, kc = p ^ swz_n<ROWB>(r);
+      src = base + (int64_t)min(tile0 + r, dim - 1) * ld + k0 + kc * 8;
+    } else {
+      const int r = sg * 4 + (lane >> 4), p16 = lane & 15, c16 = ((((p16 >> 1) ^ swz_t(r))) << 1) | (p16 & 1);
+      src = base + (int64_t)(k0 + r) * ld + min(tile0 + c16 * 8, dim - 8);
+    }
+    __builtin_amdgcn_global_load_lds((glb_vp)src, (lds_vp)(panel + sg * 1024), 16, 0, 0);
+  }
+}
+
+// ---- LDS -> MFMA fragments (row / column `base` inside ONE panel) ------------------------------------------------
 template <bool TR, int BK>
 __device__ __forceinline__ bf16x8_t frag_bf16(const unsigned char* s, int base, int lane, int hh) {
   if (!TR) {
@@ -131,19 +173,20 @@ __device__ __forceinline__ void frag_f32(const unsigned char* s, int base, int l
   }
 }
 
-template <typename T, bool ATR, bool BTR, int BK, bool BSUM>
-__device__ __forceinline__ void tile_mma(const unsigned char* sA, const unsigned char* sB, f32x4_t (&acc)[4][4], f32x4_t (&accb)[4],
-                                         bool do_bsum, int wm, int wn, int lane) {
+// one k-tile: sA / sB = the wave's A / B panel, oa / ob = its first row / column inside that panel
+template <typename T, bool ATR, bool BTR, int BK, bool BSUM, int WM>
+__device__ __forceinline__ void tile_mma(const unsigned char* sA, int oa, const unsigned char* sB, int ob, f32x4_t (&acc)[WM][4],
+                                         f32x4_t (&accb)[WM], bool do_bsum, int lane) {
   if constexpr (sizeof(T) == 2) {
 #pragma unroll
     for (int hh = 0; hh < BK / 32; ++hh) {
-      bf16x8_t af[4], bf[4];
+      bf16x8_t af[WM], bf[4];
 #pragma unroll
-      for (int t = 0; t < 4; ++t) af[t] = frag_bf16<ATR, BK>(sA, wm * 64 + t * 16, lane, hh);
+      for (int t = 0; t < 4; ++t) bf[t] = frag_bf16<BTR, BK>(sB, ob + t * 16, lane, hh);
 #pragma unroll
-      for (int t = 0; t < 4; ++t) bf[t] = frag_bf16<BTR, BK>(sB, wn * 64 + t * 16, lane, hh);
+      for (int t = 0; t < WM; ++t) af[t] = frag_bf16<ATR, BK>(sA, oa + t * 16, lane, hh);
 #pragma unroll
-      for (int ti = 0; ti < 4; ++ti)
+      for (int ti = 0; ti < WM; ++ti)
 #pragma unroll
         for (int tj = 0; tj < 4; ++tj) acc[ti][tj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[tj], af[ti], acc[ti][tj], 0, 0, 0);
       if constexpr (BSUM) {
@@ -152,7 +195,7 @@ __device__ __forceinline__ void tile_mma(const unsigned char* sA, const unsigned
           const u16x8_t o16 = {0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80};
           const bf16x8_t ones = __builtin_bit_cast(bf16x8_t, o16);
 #pragma unroll
-          for (int ti = 0; ti < 4; ++ti) accb[ti] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, af[ti], accb[ti], 0, 0, 0);
+          for (int ti = 0; ti < WM; ++ti) accb[ti] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, af[ti], accb[ti], 0, 0, 0);
         }
       }
     }
@@ -160,21 +203,21 @@ __device__ __forceinline__ void tile_mma(const unsigned char* sA, const unsigned
     static_assert(sizeof(T) == 2 || BK == 32, "fp32 tiles are 32 deep");
 #pragma unroll
     for (int hh = 0; hh < 2; ++hh) {
-      float af[4][4], bf[4][4];
+      float af[WM][4], bf[4][4];
 #pragma unroll
-      for (int t = 0; t < 4; ++t) frag_f32<ATR>(sA, wm * 64 + t * 16, lane, hh, af[t]);
+      for (int t = 0; t < WM; ++t) frag_f32<ATR>(sA, oa + t * 16, lane, hh, af[t]);
 #pragma unroll
-      for (int t = 0; t < 4; ++t) frag_f32<BTR>(sB, wn * 64 + t * 16, lane, hh, bf[t]);
+      for (int t = 0; t < 4; ++t) frag_f32<BTR>(sB, ob + t * 16, lane, hh, bf[t]);
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
 #pragma unroll
-        for (int ti = 0; ti < 4; ++ti)
+        for (int ti = 0; ti < WM; ++ti)
 #pragma unroll
           for (int tj = 0; tj < 4; ++tj) acc[ti][tj] = __builtin_amdgcn_mfma_f32_16x16x4f32(bf[tj][q], af[ti][q], acc[ti][tj], 0, 0, 0);
         if constexpr (BSUM) {
           if (do_bsum) {
 #pragma unroll
-            for (int ti = 0; ti < 4; ++ti) accb[ti] = __builtin_amdgcn_mfma_f32_16x16x4f32(1.0f, af[ti][q], accb[ti], 0, 0, 0);
+            for (int ti = 0; ti < WM; ++ti) accb[ti] = __builtin_amdgcn_mfma_f32_16x16x4f32(1.0f, af[ti][q], accb[ti], 0, 0, 0);
           }
         }
       }
@@ -182,45 +225,57 @@ __device__ __forceinline__ void tile_mma(const unsigned char* sA, const unsigned
   }
 }
 
+template <typename T> __device__ __forceinline__ float act_gelu(float x);
+template <> __device__ __forceinline__ float act_gelu<float>(float x) { return gelu_f(x); }
+template <> __device__ __forceinline__ float act_gelu<bf16_t>(float x) { return gelu_fast_f(x); }
+template <typename T> __device__ __forceinline__ float act_gelu_grad(float x);
+template <> __device__ __forceinline__ float act_gelu_grad<float>(float x) { return gelu_grad_f(x); }
+template <> __device__ __forceinline__ float act_gelu_grad<bf16_t>(float x) { return gelu_grad_fast_f(x); }
+
 // ---- coalesced epilogue: fp32 tile -> swizzled LDS (64 rows per pass) -> 16-byte row-major stores --------------
 // PRE = true : out_pre = acc + bias                      (pre-activation copy kept for the backward pass)
 // PRE = false: out = res + row_scale * act(acc + bias)   (act = GELU here; GELU' (x aux) applied in phase B)
-template <typename T, bool PRE>
-__device__ __forceinline__ void store_tile(unsigned char* smem, const f32x4_t (&acc)[4][4], const Problem& P, int act, int N, int64_t ldc,
-                                           int m0, int n0, int wm, int wn, int lane, int tid) {
+// Every wave transposes ITS OWN 64-column strip through a private LDS region (no workgroup barrier, all waves busy):
+// RPP rows per pass, a row of 64 fp32 = 16 float4 chunks, chunk c of row r stored at c ^ (r & 7).
+template <typename T, bool PRE, typename CF, int REGION_BYTES>
+__device__ __forceinline__ void store_tile(unsigned char* smem, const f32x4_t (&acc)[CF::WM][4], const Problem& P, int act, int N, int64_t ldc,
+                                           int m0, int n0, int wm, int wn, int lane, int wave) {
   constexpr int EPC = DT<T>::EPC;
-  constexpr int CPR = BN / EPC;                 // output chunks per tile row
-  float* sT = reinterpret_cast<float*>(smem);   // [64][128] fp32, float4 chunk c of row r stored at c ^ (r & 7)
+  constexpr int CPR = 64 / EPC;                 // output chunks per 64-column row
+  constexpr int RPP = REGION_BYTES >= 16384 ? 64 : 32;
+  static_assert(REGION_BYTES >= RPP * 256 && (CF::WM * 16) % RPP == 0, "per-wave epilogue region too small");
+  float* sT = reinterpret_cast<float*>(smem + wave * REGION_BYTES);
   T* outp = reinterpret_cast<T*>(PRE ? P.out_pre : P.out);
-#pragma unroll 1
-  for (int p = 0; p < 2; ++p) {
-    __syncthreads();
-    if (wm == p) {
+  const int nw0 = n0 + wn * 64;                 // first column of this wave's strip
 #pragma unroll
-      for (int tj = 0; tj < 4; ++tj) {
-        const int n = n0 + wn * 64 + tj * 16 + (lane >> 4) * 4;
-        float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (P.bias && n < N) b4 = *reinterpret_cast<const float4*>(P.bias + n);
+  for (int p = 0; p < CF::WM * 16 / RPP; ++p) {
+    __builtin_amdgcn_wave_barrier();
 #pragma unroll
-        for (int ti = 0; ti < 4; ++ti) {
-          float4 v = make_float4(acc[ti][tj][0] + b4.x, acc[ti][tj][1] + b4.y, acc[ti][tj][2] + b4.z, acc[ti][tj][3] + b4.w);
-          if (!PRE && act == LMV_ACT_GELU) { v.x = gelu_f(v.x); v.y = gelu_f(v.y); v.z = gelu_f(v.z); v.w = gelu_f(v.w); }
-          const int r = ti * 16 + (lane & 15), c4 = wn * 16 + tj * 4 + (lane >> 4);
-          *reinterpret_cast<float4*>(sT + r * BN + ((c4 ^ (r & 7)) << 2)) = v;
-        }
+    for (int tj = 0; tj < 4; ++tj) {
+      const int n = nw0 + tj * 16 + (lane >> 4) * 4;
+      float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (P.bias && n < N) b4 = *reinterpret_cast<const float4*>(P.bias + n);
+#pragma unroll
+      for (int i = 0; i < RPP / 16; ++i) {
+        const f32x4_t a = acc[p * (RPP / 16) + i][tj];
+        float4 v = make_float4(a[0] + b4.x, a[1] + b4.y, a[2] + b4.z, a[3] + b4.w);
+        if (!PRE && act == LMV_ACT_GELU) { v.x = act_gelu<T>(v.x); v.y = act_gelu<T>(v.y); v.z = act_gelu<T>(v.z); v.w = act_gelu<T>(v.w); }
+        const int r = i * 16 + (lane & 15), c4 = tj * 4 + (lane >> 4);
+        *reinterpret_cast<float4*>(sT + r * 64 + ((c4 ^ (r & 7)) << 2)) = v;
       }
     }
-    __syncthreads();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // this wave's LDS writes are visible to all of its lanes
+    __builtin_amdgcn_wave_barrier();
 #pragma unroll
-    for (int i = 0; i < 64 * CPR / NTHR; ++i) {
-      const int c = tid + i * NTHR, r = c / CPR, oc = c % CPR;
-      const int m = m0 + p * 64 + r, n = n0 + oc * EPC;
+    for (int i = 0; i < RPP * CPR / 64; ++i) {
+      const int c = lane + i * 64, r = c / CPR, oc = c % CPR;
+      const int m = m0 + wm * (CF::WM * 16) + p * RPP + r, n = nw0 + oc * EPC;
       if (m >= P.M || n >= N) continue;
       float v[EPC];
 #pragma unroll
       for (int e = 0; e < EPC; e += 4) {
         const int c4 = (oc * EPC + e) >> 2;
-        const float4 t = *reinterpret_cast<const float4*>(sT + r * BN + ((c4 ^ (r & 7)) << 2));
+        const float4 t = *reinterpret_cast<const float4*>(sT + r * 64 + ((c4 ^ (r & 7)) << 2));
         v[e] = t.x; v[e + 1] = t.y; v[e + 2] = t.z; v[e + 3] = t.w;
       }
       const int64_t o = (int64_t)m * ldc + n;
@@ -229,7 +284,7 @@ __device__ __forceinline__ void store_tile(unsigned char* smem, const f32x4_t (&
           float u[EPC];
           chunk_to_f<T>(*reinterpret_cast<const uint4*>(reinterpret_cast<const T*>(P.aux) + o), u);
 #pragma unroll
-          for (int e = 0; e < EPC; ++e) v[e] *= gelu_grad_f(u[e]);
+          for (int e = 0; e < EPC; ++e) v[e] *= act_gelu_grad<T>(u[e]);
         }
         if (P.row_scale) {
           const float rs = P.row_scale[m / P.rps];
@@ -248,60 +303,16 @@ __device__ __forceinline__ void store_tile(unsigned char* smem, const f32x4_t (&
   }
 }
 
-// ---- global -> LDS directly (bf16): global_load_lds_dwordx4 writes  wave-uniform base + lane * 16, i.e. each
-// wave-instruction fills one LINEAR 1 KiB segment of the tile image.  The XOR swizzle therefore goes on the per-lane
-// SOURCE address: the lane that lands on physical chunk p of row r fetches logical chunk p ^ swz(r).  No staging
-// VGPRs and no ds_write pass (ds_write_b128 costs ~13 LDS cycles per wave-instruction and made the register-staged
-// loop LDS-bound).  Lanes whose tile row / column lies outside the matrix are masked off: their LDS bytes stay stale,
-// which only ever feeds accumulators of outputs that are not stored (the reduction dimension is never masked here:
-// the host uses this path only when Kred is a multiple of BK).
-typedef __attribute__((address_space(3))) void* lds_vp;
-typedef const __attribute__((address_space(1))) void* glb_vp;
-
-template <bool TR, int BK>
-__device__ __forceinline__ void stage_dma(unsigned char* tile, const bf16_t* __restrict__ base, int64_t ld, int dim, int tile0, int k0,
-                                          int lane, int wave) {
-  constexpr int NSEG = BM * BK * 2 / 1024;          // 1 KiB segments per tile image
-#pragma unroll
-  for (int i = 0; i < NSEG / 4; ++i) {
-    const int sg = wave + i * 4;
-    const bf16_t* src;
-    bool ok;
-    // out-of-range rows / columns are CLAMPED, not masked: every wave issues exactly the same number of LDS-DMA
-    // instructions per tile (the ring pipeline below counts them with s_waitcnt vmcnt(N)), and the duplicated data
-    // only reaches accumulators of outputs that are never stored.
-    if (!TR) {
-      constexpr int ROWB = BK * 2, CPR = ROWB / 16, RPS = 1024 / ROWB;
-      const int r = sg * RPS + lane / CPR, p = lane % CPR, kc = p ^ swz_n<ROWB>(r);
-      src = base + (int64_t)min(tile0 + r, dim - 1) * ld + k0 + kc * 8;
-    } else {
-      const int r = sg * 4 + (lane >> 4), p16 = lane & 15, c16 = ((((p16 >> 1) ^ swz_t(r))) << 1) | (p16 & 1);
-      src = base + (int64_t)(k0 + r) * ld + min(tile0 + c16 * 8, dim - 8);
-    }
-    (void)ok;
-    __builtin_amdgcn_global_load_lds((glb_vp)src, (lds_vp)(tile + sg * 1024), 16, 0, 0);
-  }
-}
-
-// wait until at most `pending` whole tiles (DPT LDS-DMA instructions each) of this wave are still in flight
-template <int DPT>
-__device__ __forceinline__ void wait_tiles(int pending) {
-  if (pending <= 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  else if (pending == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DPT) : "memory");
-  else if (pending == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * DPT) : "memory");
-  else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * DPT) : "memory");
-}
-
-template <typename T, bool ATR, bool BTR, bool SPLITK, int BK, bool DMA, int NBUF>
-__global__ __launch_bounds__(NTHR) void gemm_kernel(const GemmArgs g) {
-  constexpr int NCH = (BM * BK * (int)sizeof(T)) / 16 / NTHR;
-  constexpr int TILE_BYTES = BM * BK * (int)sizeof(T);
-  static_assert(DMA || NBUF == 2, "the register-staged loop is double-buffered");
-  __shared__ __attribute__((aligned(16))) unsigned char smem[NBUF * 2 * TILE_BYTES];   // [buffer][A | B]; reused by the epilogue
-  static_assert(NBUF * 2 * TILE_BYTES >= 64 * BN * 4, "epilogue staging needs 32 KB");
+template <typename T, bool ATR, bool BTR, bool SPLITK, int BK, bool DMA, typename CF>
+__global__ __launch_bounds__(CF::NTHR) void gemm_kernel(const GemmArgs g) {
+  constexpr int PANEL_BYTES = PANEL * BK * (int)sizeof(T);
+  constexpr int BUF_BYTES = (CF::PA + CF::PB) * PANEL_BYTES;
+  constexpr int WM = CF::WM;
+  static_assert(DMA || (CF::PA == 1 && CF::PB == 1 && CF::NTHR == 256), "the register-staged loop is written for the 128x128 tile");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];     // [2 buffers][A panels | B panels]; reused by the epilogue
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
+  const int wm = wave / CF::NWN, wn = wave % CF::NWN;
   // XCD-aware order: hardware places block b on XCD b % 8; give each XCD a contiguous run of logical tiles so
   // the n-tiles of one m-tile share an L2 (speed only -- any placement is correct).
   int bid;
@@ -313,7 +324,7 @@ __global__ __launch_bounds__(NTHR) void gemm_kernel(const GemmArgs g) {
   const Problem& P = g.p[pi];
   bid -= P.tile_begin;
   const int tm = bid / g.tiles_n, tn = bid % g.tiles_n;
-  const int m0 = tm * BM, n0 = tn * BN;
+  const int m0 = tm * CF::BM, n0 = tn * CF::BN;
   const int M = P.M, N = g.N, Kred = P.Kred;
   const int kt_total = (Kred + BK - 1) / BK;
   const int kt_beg = blockIdx.y * g.kt_per_split;
@@ -323,55 +334,47 @@ __global__ __launch_bounds__(NTHR) void gemm_kernel(const GemmArgs g) {
   const T* __restrict__ A = reinterpret_cast<const T*>(P.a);
   const T* __restrict__ Bw = reinterpret_cast<const T*>(P.b);
 
-  f32x4_t acc[4][4], accb[4];
+  f32x4_t acc[WM][4], accb[WM];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
+  for (int i = 0; i < WM; ++i) {
     accb[i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
   }
-
+  // this wave's operand panels and offsets inside them
+  const int ra0 = wm * WM * 16, cb0 = wn * 64;
+  const int pa = ra0 / PANEL, oa = ra0 % PANEL, pb = cb0 / PANEL, ob = cb0 % PANEL;
   const bool do_bsum = SPLITK && (P.bias_grad != nullptr) && tn == 0 && wn == 0;      // wave-uniform
+
   int cur = 0;
   if constexpr (DMA) {
     static_assert(sizeof(T) == 2, "the direct-to-LDS path is bf16 only");
     const bf16_t* A16 = reinterpret_cast<const bf16_t*>(A);
     const bf16_t* B16 = reinterpret_cast<const bf16_t*>(Bw);
-    // Ring of NBUF tile buffers with up to NBUF-1 k-tiles in flight.  HBM latency (~2 us under load) is far longer
-    // than one tile's MFMAs, so a single prefetched tile leaves the matrix cores idle; LDS-DMA requests are kept in
-    // flight ACROSS barriers by counting them (s_waitcnt vmcnt(N), raw s_barrier -- a __syncthreads() would drain
-    // them).  Per k-tile: wait for tile kt (own DMAs) -> barrier (everyone's DMAs for kt landed, everyone finished
-    // reading the buffer of tile kt-1) -> refill that buffer with tile kt+NBUF-1 -> MFMAs on tile kt.
-    constexpr int DPT = 2 * (BM * BK * 2 / 1024) / 4;   // LDS-DMA instructions per wave per k-tile (A + B)
-    const int nk = kt_end - kt_beg;
+    auto issue = [&](unsigned char* buf, int kt) {
 #pragma unroll
-    for (int s = 0; s < NBUF - 1; ++s) {
-      if (s < nk) {
-        stage_dma<ATR, BK>(smem + s * 2 * TILE_BYTES, A16, g.lda, M, m0, (kt_beg + s) * BK, lane, wave);
-        stage_dma<BTR, BK>(smem + s * 2 * TILE_BYTES + TILE_BYTES, B16, g.ldb, N, n0, (kt_beg + s) * BK, lane, wave);
-      }
+      for (int q = 0; q < CF::PA; ++q) panel_dma<ATR, BK, CF::NW>(buf + q * PANEL_BYTES, A16, g.lda, M, m0 + q * PANEL, kt * BK, lane, wave);
+#pragma unroll
+      for (int q = 0; q < CF::PB; ++q) panel_dma<BTR, BK, CF::NW>(buf + (CF::PA + q) * PANEL_BYTES, B16, g.ldb, N, n0 + q * PANEL, kt * BK, lane, wave);
+    };
+    issue(smem, kt_beg);
+    __syncthreads();                                  // (the compiler drains vmcnt before the barrier: the LDS-DMA landed)
+    const bool dbg_no_mma = g.act & 0x100, dbg_no_dma = g.act & 0x200;      // DEBUG ablation switches
+    for (int kt = kt_beg; kt < kt_end; ++kt) {
+      if (kt + 1 < kt_end && !dbg_no_dma) issue(smem + (cur ^ 1) * BUF_BYTES, kt + 1);   // streams under this tile's MFMAs
+      const unsigned char* buf = smem + cur * BUF_BYTES;
+      if (!dbg_no_mma) tile_mma<T, ATR, BTR, BK, SPLITK, WM>(buf + pa * PANEL_BYTES, oa, buf + (CF::PA + pb) * PANEL_BYTES, ob, acc, accb, do_bsum, lane);
+      __syncthreads();
+      cur ^= 1;
     }
-    for (int i = 0; i < nk; ++i) {
-      const int issued_after = min(NBUF - 2, nk - 1 - i);          // tiles issued after tile i and still allowed in flight
-      wait_tiles<DPT>(issued_after);
-      __builtin_amdgcn_s_barrier();
-      asm volatile("" ::: "memory");
-      if (i + NBUF - 1 < nk) {
-        unsigned char* dA = smem + ((i + NBUF - 1) % NBUF) * 2 * TILE_BYTES;
-        stage_dma<ATR, BK>(dA, A16, g.lda, M, m0, (kt_beg + i + NBUF - 1) * BK, lane, wave);
-        stage_dma<BTR, BK>(dA + TILE_BYTES, B16, g.ldb, N, n0, (kt_beg + i + NBUF - 1) * BK, lane, wave);
-      }
-      const unsigned char* sA = smem + (i % NBUF) * 2 * TILE_BYTES;
-      tile_mma<T, ATR, BTR, BK, SPLITK>(sA, sA + TILE_BYTES, acc, accb, do_bsum, wm, wn, lane);
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");           // this wave's LDS reads of tile i are complete
-    }
-    __syncthreads();
+    if (g.act & 0x400) return;                                              // DEBUG: skip the epilogue
   } else {
+    constexpr int NCH = PANEL_BYTES / 16 / 256;
     uint4 ra[NCH], rb[NCH];
     stage_load<T, ATR, BK, NCH>(ra, A, g.lda, M, Kred, m0, kt_beg * BK, tid);
     stage_load<T, BTR, BK, NCH>(rb, Bw, g.ldb, N, Kred, n0, kt_beg * BK, tid);
     stage_store<T, ATR, BK, NCH>(smem, ra, tid);
-    stage_store<T, BTR, BK, NCH>(smem + TILE_BYTES, rb, tid);
+    stage_store<T, BTR, BK, NCH>(smem + PANEL_BYTES, rb, tid);
     __syncthreads();
     for (int kt = kt_beg; kt < kt_end; ++kt) {
       const bool has_next = kt + 1 < kt_end;
@@ -379,13 +382,12 @@ __global__ __launch_bounds__(NTHR) void gemm_kernel(const GemmArgs g) {
         stage_load<T, ATR, BK, NCH>(ra, A, g.lda, M, Kred, m0, (kt + 1) * BK, tid);
         stage_load<T, BTR, BK, NCH>(rb, Bw, g.ldb, N, Kred, n0, (kt + 1) * BK, tid);
       }
-      const unsigned char* sA = smem + cur * 2 * TILE_BYTES;
-      const unsigned char* sB = sA + TILE_BYTES;
-      tile_mma<T, ATR, BTR, BK, SPLITK>(sA, sB, acc, accb, do_bsum, wm, wn, lane);
+      const unsigned char* buf = smem + cur * BUF_BYTES;
+      tile_mma<T, ATR, BTR, BK, SPLITK, WM>(buf, oa, buf + PANEL_BYTES, ob, acc, accb, do_bsum, lane);
       if (has_next) {
-        unsigned char* dA = smem + (cur ^ 1) * 2 * TILE_BYTES;
+        unsigned char* dA = smem + (cur ^ 1) * BUF_BYTES;
         stage_store<T, ATR, BK, NCH>(dA, ra, tid);
-        stage_store<T, BTR, BK, NCH>(dA + TILE_BYTES, rb, tid);
+        stage_store<T, BTR, BK, NCH>(dA + PANEL_BYTES, rb, tid);
       }
       __syncthreads();
       cur ^= 1;
@@ -396,20 +398,21 @@ __global__ __launch_bounds__(NTHR) void gemm_kernel(const GemmArgs g) {
     // partial tile -> this split's slab (plain stores; summed by splitk_reduce_kernel)
     float* slab = g.ws + (int64_t)(g.slab_base[pi] + blockIdx.y) * g.slab_stride;
 #pragma unroll
-    for (int ti = 0; ti < 4; ++ti) {
-      const int m = m0 + wm * 64 + ti * 16 + (lane & 15);
+    for (int ti = 0; ti < WM; ++ti) {
+      const int m = m0 + ra0 + ti * 16 + (lane & 15);
       if (m >= M) continue;
 #pragma unroll
       for (int tj = 0; tj < 4; ++tj) {
-        const int n = n0 + wn * 64 + tj * 16 + (lane >> 4) * 4;
+        const int n = n0 + cb0 + tj * 16 + (lane >> 4) * 4;
         if (n >= N) continue;
         *reinterpret_cast<float4*>(slab + (int64_t)m * g.ldc + n) = make_float4(acc[ti][tj][0], acc[ti][tj][1], acc[ti][tj][2], acc[ti][tj][3]);
       }
       if (do_bsum && lane < 16) slab[(int64_t)M * g.ldc + m] = accb[ti][0];
     }
   } else {
-    if (P.out_pre) store_tile<T, true>(smem, acc, P, g.act, N, g.ldc, m0, n0, wm, wn, lane, tid);
-    store_tile<T, false>(smem, acc, P, g.act, N, g.ldc, m0, n0, wm, wn, lane, tid);
+    constexpr int REGION = 2 * BUF_BYTES / CF::NW;      // the operand buffers, carved into one private region per wave
+    if (P.out_pre) store_tile<T, true, CF, REGION>(smem, acc, P, g.act & 0xff, N, g.ldc, m0, n0, wm, wn, lane, wave);
+    store_tile<T, false, CF, REGION>(smem, acc, P, g.act & 0xff, N, g.ldc, m0, n0, wm, wn, lane, wave);
   }
 }
 
@@ -433,8 +436,9 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
 }
 
 enum Mode { MODE_FWD = 0, MODE_DX = 1, MODE_DW = 2 };
+enum Tile { TILE_128 = 0, TILE_256x128 = 1, TILE_256 = 2 };
 
-struct Plan { GemmArgs g; int total, splits, bk, nbuf, nsplit[2]; size_t ws_bytes; };
+struct Plan { GemmArgs g; int total, splits, bk, tile, dma, nsplit[2]; size_t ws_bytes; };
 
 int make_plan(const lmv_linear_problem* p, int nproblems, int N, int K, int act, int dtype, Mode mode, Plan* pl) {
   if (nproblems < 1 || nproblems > 2) LMV_FAIL(LMV_ERR_SHAPE, "linear: nproblems must be 1 or 2 (got %d)", nproblems);
@@ -443,14 +447,16 @@ int make_plan(const lmv_linear_problem* p, int nproblems, int N, int K, int act,
   GemmArgs& g = pl->g;
   g = GemmArgs{};
   g.nprob = nproblems; g.act = act;
+  { const char* e = getenv("LMV_GEMM_DEBUG"); if (e) g.act |= atoi(e); }
   int out_cols;
   switch (mode) {
     case MODE_FWD: g.N = N; g.lda = K; g.ldb = K; g.ldc = N; out_cols = N; break;
     case MODE_DX:  g.N = K; g.lda = N; g.ldb = K; g.ldc = K; out_cols = K; break;
     default:       g.N = K; g.lda = N; g.ldb = K; g.ldc = K; out_cols = K; break;
   }
-  g.tiles_n = (out_cols + BN - 1) / BN;
-  int total = 0;
+  int64_t max_m = 0;
+  int min_kred = 1 << 30;
+  bool all64 = true, all32 = true;
   for (int i = 0; i < nproblems; ++i) {
     const lmv_linear_problem& q = p[i];
     if (q.rows <= 0 || q.rows > 0x7fffffffLL / 4) LMV_FAIL(LMV_ERR_SHAPE, "linear: bad rows %lld", (long long)q.rows);
@@ -464,24 +470,45 @@ int make_plan(const lmv_linear_problem* p, int nproblems, int N, int K, int act,
     P.out = q.out; P.out_pre = q.out_pre; P.bias_grad = q.bias_grad; P.rps = q.rows_per_sample > 0 ? q.rows_per_sample : 1;
     if (mode == MODE_DW) { P.M = N; P.Kred = (int)q.rows; }
     else { P.M = (int)q.rows; P.Kred = (mode == MODE_FWD) ? K : N; }
-    P.tiles_m = (P.M + BM - 1) / BM;
-    P.tile_begin = total;
-    total += P.tiles_m * g.tiles_n;
+    if (P.M > max_m) max_m = P.M;
+    if (P.Kred < min_kred) min_kred = P.Kred;
+    if (P.Kred % 64) all64 = false;
+    if (P.Kred % 32) all32 = false;
   }
   const bool bf = dtype == LMV_BF16;
   // bf16: 64-deep k-tiles unless the reduction is a short non-multiple of 64 (C = 96 layers); fp32: 32-deep
-  int min_kred = 1 << 30;
-  bool all64 = true;
-  for (int i = 0; i < nproblems; ++i) { if (g.p[i].Kred < min_kred) min_kred = g.p[i].Kred; if (g.p[i].Kred % 64) all64 = false; }
-  // LMV_GEMM_RING=0: 64-deep tiles, double-buffered (2 x 32 KB); default: 32-deep tiles in a 4-slot LDS-DMA ring (4 x 16 KB,
-  // up to 3 k-tiles in flight per workgroup)
-  static const bool ring = [] { const char* e = getenv("LMV_GEMM_RING"); return !e || atoi(e) != 0; }();
-  static const bool no_dma_env = getenv("LMV_GEMM_NO_DMA") != nullptr;
-  bool all32 = true;
-  for (int i = 0; i < nproblems; ++i) if (g.p[i].Kred % 32) all32 = false;
-  const bool use_ring = bf && ring && !no_dma_env && all32;
-  const int bk = use_ring ? 32 : ((bf && (mode == MODE_DW || all64 || min_kred >= 512)) ? 64 : 32);
-  pl->nbuf = use_ring ? 4 : 2;
+  static const int force_bk = [] { const char* e = getenv("LMV_GEMM_BK"); return e ? atoi(e) : 0; }();   // A/B testing
+  int bk = (bf && (mode == MODE_DW || all64 || min_kred >= 512)) ? 64 : 32;
+  if (force_bk == 32 && all32) bk = 32;
+  static const bool no_dma = getenv("LMV_GEMM_NO_DMA") != nullptr;     // A/B testing
+  const bool dma = bf && !no_dma && (bk == 64 ? all64 : all32);
+  // Tile choice.  Measured on the LeMeViT shapes (K = 96..2048, tools/gemm_ablate.py): the k-loop alone runs at
+  // ~1 PFLOP/s, but with K this short HALF of a workgroup's life is its epilogue (writing the tile), and the only thing
+  // that hides it is another co-resident workgroup: 128x128 (64 KB LDS, 2 workgroups per CU) beats 256x128 and
+  // 256x256 (1 workgroup per CU) on every shape of the model, so it is the default; LMV_GEMM_TILE=-1 selects the
+  // larger tiles automatically (they win for long-K problems), 1 / 2 force them.
+  static const int force_tile = [] { const char* e = getenv("LMV_GEMM_TILE"); return e ? atoi(e) : 0; }();
+  int tile = TILE_128;
+  if (dma && bk == 64) {
+    if (force_tile < 0) {
+      auto tiles_of = [&](int bm, int bn) { int64_t t = 0; for (int i = 0; i < nproblems; ++i) t += (int64_t)((g.p[i].M + bm - 1) / bm) * ((out_cols + bn - 1) / bn); return t; };
+      const int64_t need = (mode == MODE_DW) ? 48 : 200;      // dW multiplies its grid by the k-splits
+      const bool fits256 = out_cols % 256 == 0 || out_cols >= 1024;      // <= 12 % padded columns
+      if (max_m >= 256 && fits256 && tiles_of(256, 256) >= need) tile = TILE_256;
+      else if (max_m >= 256 && tiles_of(256, 128) >= need) tile = TILE_256x128;
+    } else if (force_tile <= TILE_256) {
+      tile = force_tile;
+    }
+  }
+  const int bm = tile == TILE_128 ? 128 : 256, bn = tile == TILE_256 ? 256 : 128;
+  g.tiles_n = (out_cols + bn - 1) / bn;
+  int total = 0;
+  for (int i = 0; i < nproblems; ++i) {
+    Problem& P = g.p[i];
+    P.tiles_m = (P.M + bm - 1) / bm;
+    P.tile_begin = total;
+    total += P.tiles_m * g.tiles_n;
+  }
   int max_kt = 1;
   for (int i = 0; i < nproblems; ++i) { const int kt = (g.p[i].Kred + bk - 1) / bk; if (kt > max_kt) max_kt = kt; }
   int splits = 1;
@@ -489,8 +516,10 @@ int make_plan(const lmv_linear_problem* p, int nproblems, int N, int K, int act,
   pl->ws_bytes = 0;
   pl->nsplit[0] = pl->nsplit[1] = 1;
   if (mode == MODE_DW) {
+    // split the token reduction so the launch fills the chip (each split ends in a plain store of its partial tile)
     static const int target = [] { const char* e = getenv("LMV_DW_TARGET_BLOCKS"); return e ? atoi(e) : 768; }();
-    splits = (target + total - 1) / total;
+    const int tgt = tile == TILE_128 ? target : target / 2;      // 8-wave workgroups: one per CU
+    splits = (tgt + total - 1) / total;
     const int max_splits = (max_kt + 7) / 8;   // at least 8 k-tiles per split
     if (splits > max_splits) splits = max_splits;
     if (splits < 1) splits = 1;
@@ -506,8 +535,36 @@ int make_plan(const lmv_linear_problem* p, int nproblems, int N, int K, int act,
     g.slab_stride = (int64_t)N * K + N;
     pl->ws_bytes = (size_t)slabs * g.slab_stride * sizeof(float);
   }
-  pl->total = total; pl->splits = splits; pl->bk = bk;
+  pl->total = total; pl->splits = splits; pl->bk = bk; pl->tile = tile; pl->dma = dma;
   return LMV_OK;
+}
+
+template <typename T, bool ATR, bool BTR, bool SPLITK, int BK, bool DMA, typename CF>
+int launch_one(const GemmArgs& g, dim3 grid, hipStream_t st) {
+  constexpr int lds = 2 * (CF::PA + CF::PB) * PANEL * BK * (int)sizeof(T);
+  auto kern = gemm_kernel<T, ATR, BTR, SPLITK, BK, DMA, CF>;
+  static bool attr_set = false;                 // > 64 KiB of dynamic LDS needs an explicit opt-in, once per kernel
+  if (!attr_set) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
+      LMV_FAIL(LMV_ERR_LAUNCH, "linear: cannot reserve %d bytes of LDS", lds);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(kern, grid, dim3(CF::NTHR), lds, st, g);
+  return LMV_OK;
+}
+
+template <bool ATR, bool BTR, bool SPLITK>
+int launch_mode(const Plan& pl, dim3 grid, bool bf, hipStream_t st) {
+  const GemmArgs& g = pl.g;
+  if (!bf) return launch_one<float, ATR, BTR, SPLITK, 32, false, C128>(g, grid, st);
+  if (!pl.dma) return pl.bk == 64 ? launch_one<bf16_t, ATR, BTR, SPLITK, 64, false, C128>(g, grid, st)
+                                  : launch_one<bf16_t, ATR, BTR, SPLITK, 32, false, C128>(g, grid, st);
+  if (pl.bk == 32) return launch_one<bf16_t, ATR, BTR, SPLITK, 32, true, C128>(g, grid, st);
+  switch (pl.tile) {
+    case TILE_256:     return launch_one<bf16_t, ATR, BTR, SPLITK, 64, true, C256>(g, grid, st);
+    case TILE_256x128: return launch_one<bf16_t, ATR, BTR, SPLITK, 64, true, C256x128>(g, grid, st);
+    default:           return launch_one<bf16_t, ATR, BTR, SPLITK, 64, true, C128>(g, grid, st);
+  }
 }
 
 int launch(const lmv_linear_problem* p, int nproblems, int N, int K, int act, int dtype, void* stream, Mode mode, void* ws, size_t ws_bytes) {
@@ -519,30 +576,13 @@ int launch(const lmv_linear_problem* p, int nproblems, int N, int K, int act, in
     g.ws = reinterpret_cast<float*>(ws);
   }
   const bool bf = dtype == LMV_BF16;
-  const int bk = pl.bk;
-  dim3 grid(pl.total, pl.splits), block(NTHR);
+  dim3 grid(pl.total, pl.splits);
   hipStream_t st = (hipStream_t)stream;
-  // direct-to-LDS staging needs an unmasked reduction dimension (and is bf16 only); LMV_GEMM_NO_DMA=1 forces the
-  // register-staged kernels (A/B testing)
-  static const bool no_dma = getenv("LMV_GEMM_NO_DMA") != nullptr;
-  bool dma = bf && !no_dma;
-  for (int i = 0; i < nproblems; ++i) if (g.p[i].Kred % bk) dma = false;
-#define LAUNCH(T, A, B, SK, KK, DM, NB) hipLaunchKernelGGL((gemm_kernel<T, A, B, SK, KK, DM, NB>), grid, block, 0, st, g)
-#define LAUNCH_BF(A, B, SK)                                                                                           \
-  do {                                                                                                                \
-    if (dma && pl.nbuf == 4) LAUNCH(bf16_t, A, B, SK, 32, true, 4);                                                    \
-    else if (bk == 64) { if (dma) LAUNCH(bf16_t, A, B, SK, 64, true, 2); else LAUNCH(bf16_t, A, B, SK, 64, false, 2); } \
-    else               { if (dma) LAUNCH(bf16_t, A, B, SK, 32, true, 2); else LAUNCH(bf16_t, A, B, SK, 32, false, 2); } \
-  } while (0)
-  if (mode == MODE_FWD) {
-    if (!bf) LAUNCH(float, false, false, false, 32, false, 2); else LAUNCH_BF(false, false, false);
-  } else if (mode == MODE_DX) {
-    if (!bf) LAUNCH(float, false, true, false, 32, false, 2); else LAUNCH_BF(false, true, false);
-  } else {
-    if (!bf) LAUNCH(float, true, true, true, 32, false, 2); else LAUNCH_BF(true, true, true);
-  }
-#undef LAUNCH_BF
-#undef LAUNCH
+  int rc;
+  if (mode == MODE_FWD) rc = launch_mode<false, false, false>(pl, grid, bf, st);
+  else if (mode == MODE_DX) rc = launch_mode<false, true, false>(pl, grid, bf, st);
+  else rc = launch_mode<true, true, true>(pl, grid, bf, st);
+  if (rc) return rc;
   LMV_CHECK_LAUNCH("linear");
   if (mode == MODE_DW) {
     const int64_t nw = (int64_t)N * K;

@@ -34,6 +34,8 @@ sys.path.insert(0, ROOT)
 
 PEAK_BF16_TFLOPS = 2500.0          # dense bf16 MFMA, MI355X_MICROARCH.md
 CANONICAL_GFLOP_FWD = 22.12        # README/BASELINE: 11.06 GMAC forward per image (Base 224^2)
+CANONICAL_GMAC = {("lemevit_base", 224): 11.060, ("lemevit_small", 224): 3.736, ("lemevit_tiny", 224): 1.779,
+                  ("lemevit_base", 384): 30.986, ("lemevit_tiny", 384): 5.004}     # BASELINE.md section 1 (canonical = README-style)
 
 
 def parse():
@@ -213,9 +215,12 @@ def main():
     dt = float(tmax.item())
 
     if rank == 0:
+        pretty = {"lemevit_tiny": "LeMeViT-Tiny", "lemevit_small": "LeMeViT-Small", "lemevit_base": "LeMeViT-Base"}.get(args.model, args.model)
         imgs = args.batch * world * args.steps
         value = imgs / dt
         mult = 3.0 if train else 1.0
+        gmac = CANONICAL_GMAC.get((args.model, args.img))
+        gflop = None if gmac is None else 2.0 * gmac
         g = timer.summary()
         roof = None
         if g is not None:
@@ -223,15 +228,15 @@ def main():
                         traffic=None, kernel="gemm_kernel<bf16,NT> (Linear forward)", measured=kernel_timing_note, launches=g["launches"], avg_launch_us=round(g["avg_us"], 2),
                         gflop_per_launch=round(g["gflop_per_launch"], 3))
         line = {
-            "metric": "images/sec LeMeViT-Base 224^2 bf16 fwd+bwd" if train else "images/sec LeMeViT-Base 224^2 bf16 fwd",
+            "metric": f"images/sec {pretty} {args.img}^2 bf16 " + ("fwd+bwd" if train else "fwd"),
             "value": round(value, 2), "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * dt / args.steps, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "bf16", "data": "synthetic",
             "config": {"workload": f"{args.model} {args.img}x{args.img} bf16-autocast {'train step (fwd+bwd+AdamW)' if train else 'forward'}, "
                                    f"batch {args.batch}/GPU, drop_path 0.1, random-init weights", "global_batch": args.batch * world,
                        "parallelism": f"dp{world}", "launch": graph_note},
-            "model_tflops": round(value * CANONICAL_GFLOP_FWD * mult / 1e3, 2),
-            "model_frac_of_bf16_peak": round(value * CANONICAL_GFLOP_FWD * mult / 1e3 / (PEAK_BF16_TFLOPS * world), 4),
+            "model_tflops": None if gflop is None else round(value * gflop * mult / 1e3, 2),
+            "model_frac_of_bf16_peak": None if gflop is None else round(value * gflop * mult / 1e3 / (PEAK_BF16_TFLOPS * world), 4),
             "roofline": roof,
         }
         if world == 1 and not args.no_cpu_baseline:

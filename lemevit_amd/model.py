@@ -367,6 +367,29 @@ class LeMeViT(nn.Module):
         B, N, C = xt.shape
         return xt.view(B, H, W, C).permute(0, 3, 1, 2)          # channels_last-strided view, no copy
 
+    def _draw_drop_path(self, B: int, device) -> Dict[int, List[Optional[Tensor]]]:
+        """All DropPath masks of one forward pass from ONE uniform draw (instead of ~120 tiny bernoulli_/div_ launches):
+        per block and per DropPath call an independent per-sample Bernoulli(keep) / keep vector, as timm's DropPath
+        (models/lemevit.py:531,561-564; block 0 has rate 0 -> identity)."""
+        if not self.training:
+            return {}
+        plan = [(blk, 2 if blk.attn_type == "C" else 4) for st in self.stages for blk in st if blk.drop_prob > 0.0 and type(blk)._masks is LeMeBlock._masks
+                and "_masks" not in blk.__dict__]
+        if not plan:
+            return {}
+        nmask = sum(n for _, n in plan)
+        keep = getattr(self, "_dp_keep", None)      # cached on the device: no per-step host-to-device copy
+        if keep is None or keep.shape[0] != nmask or keep.device != torch.device(device):
+            keep = torch.tensor([1.0 - blk.drop_prob for blk, n in plan for _ in range(n)], dtype=torch.float32, device=device)
+            self._dp_keep = keep
+        u = torch.rand((keep.shape[0], B), device=device, dtype=torch.float32)
+        scale = (u < keep[:, None]).to(torch.float32) / keep[:, None]
+        out, r = {}, 0
+        for blk, n in plan:
+            out[id(blk)] = [scale[r + q] for q in range(n)] + [None] * (4 - n)
+            r += n
+        return out
+
     def forward_features(self, x: Tensor, c: Optional[Tensor] = None) -> Tensor:
         """models/lemevit.py:809-829.  c = None hoists the batch-invariant meta-token prefix."""
         cd = _resolve_dtype(x)
@@ -376,6 +399,7 @@ class LeMeViT(nn.Module):
         if hoist:
             c = self.meta_tokens.unsqueeze(0)
         xt, H, W = None, 0, 0
+        all_masks = self._draw_drop_path(B, x.device)
         for i in range(self.num_stages):
             if i == 0 or not isinstance(self.downsample_layers[i], nn.Identity):
                 x = self.downsample_layers[i](x if xt is None else self._to_nchw(xt, H, W))
@@ -386,7 +410,7 @@ class LeMeViT(nn.Module):
                 hoist = False
             c = c.to(cd).contiguous()
             for blk in self.stages[i]:
-                xt, c = blk.forward_tokens(xt, c, H, W)
+                xt, c = blk.forward_tokens(xt, c, H, W, masks=all_masks.get(id(blk)) if all_masks else None)
         xn = self.norm(self._to_nchw(xt, H, W))
         xn = self.pre_logits(xn)
         cn = self.pre_logits(self.norm_c(c))

@@ -31,6 +31,9 @@ PARAM_NAMES = {
     "D": ["pos_embed.weight", "pos_embed.bias", "norm1.weight", "norm1.bias", "attn.qkv1.weight", "attn.qkv1.bias",
           "attn.qkv2.weight", "attn.qkv2.bias", "attn.proj_x.weight", "attn.proj_x.bias", "attn.proj_c.weight", "attn.proj_c.bias",
           "norm2.weight", "norm2.bias", "mlp.0.weight", "mlp.0.bias", "mlp.3.weight", "mlp.3.bias"],
+    "D2": ["pos_embed.weight", "pos_embed.bias", "norm1.weight", "norm1.bias", "attn.qv1.weight", "attn.qv1.bias",
+           "attn.kv2.weight", "attn.kv2.bias", "attn.proj_x.weight", "attn.proj_x.bias", "attn.proj_c.weight", "attn.proj_c.bias",
+           "norm2.weight", "norm2.bias", "mlp.0.weight", "mlp.0.bias", "mlp.3.weight", "mlp.3.bias"],
     "C": ["pos_embed.weight", "pos_embed.bias", "norm1.weight", "norm1.bias", "attn.q.weight", "attn.q.bias", "attn.kv.weight", "attn.kv.bias",
           "attn.proj.weight", "attn.proj.bias", "norm2.weight", "norm2.bias", "mlp.0.weight", "mlp.0.bias", "mlp.3.weight", "mlp.3.bias"],
 }
@@ -142,6 +145,49 @@ def _attn_D_bwd(P, G, saved, douts, ds):
     return ops.layernorm_bwd_multi(dxn, ts, st, P["norm1.weight"], G["norm1.weight"], G["norm1.bias"], douts)
 
 
+def _attn_D2_fwd(P, ts, ds, save):
+    """DualCrossAttention_v2 ("D2", models/lemevit.py:357-361,393-407): q, v1 from the image tokens, k, v2 from the meta tokens;
+    the SAME q / k serve both directions (x' = sdpa(q, k, v2), c' = sdpa(k, q, v1))."""
+    x, c = ts
+    C, N, M = x.shape[-1], x.shape[1], c.shape[1]
+    sx, sc = ops.dca_scales(N, M, C)
+    xn, st = ops.layernorm_fwd_multi(ts, P["norm1.weight"], P["norm1.bias"], BLOCK_LN_EPS, want_stats=save)
+    qv1, kv2 = _empty(x, 2 * C), _empty(c, 2 * C)
+    ops.linear_fwd([Prob(xn[0], P["attn.qv1.weight"], qv1, bias=P["attn.qv1.bias"]),
+                    Prob(xn[1], P["attn.kv2.weight"], kv2, bias=P["attn.kv2.bias"])], 2 * C, C)
+    aox, lsex = ops.attn_fwd((qv1, 0), (kv2, 0), (kv2, C), C, sx, want_lse=save)     # :402
+    aoc, lsec = ops.attn_fwd((kv2, 0), (qv1, 0), (qv1, C), C, sc, want_lse=save)     # :405
+    ox, oc = torch.empty_like(x), torch.empty_like(c)
+    ops.linear_fwd([Prob(aox, P["attn.proj_x.weight"], ox, bias=P["attn.proj_x.bias"], res=x, row_scale=ds[0], rps=N),
+                    Prob(aoc, P["attn.proj_c.weight"], oc, bias=P["attn.proj_c.bias"], res=c, row_scale=ds[1], rps=M)], C, C)
+    return [ox, oc], ((list(ts), list(st), list(xn), qv1, kv2, aox, aoc, lsex, lsec) if save else None)
+
+
+def _attn_D2_bwd(P, G, saved, douts, ds):
+    ts, st, xn, qv1, kv2, aox, aoc, lsex, lsec = saved
+    x, c = ts
+    C, N, M = x.shape[-1], x.shape[1], c.shape[1]
+    sx, sc = ops.dca_scales(N, M, C)
+    g = [d if s is None else ops.row_scale(d, s, _rps(d)) for d, s in zip(douts, ds)]
+    ops.linear_dw([Prob(g[0], aox, G["attn.proj_x.weight"], bias_grad=G["attn.proj_x.bias"]),
+                   Prob(g[1], aoc, G["attn.proj_c.weight"], bias_grad=G["attn.proj_c.bias"])], C, C)
+    daox, daoc = torch.empty_like(x), torch.empty_like(c)
+    ops.linear_dx([Prob(g[0], P["attn.proj_x.weight"], daox), Prob(g[1], P["attn.proj_c.weight"], daoc)], C, C)
+    dqv1, dkv2 = torch.empty_like(qv1), torch.empty_like(kv2)
+    ops.attn_bwd((qv1, 0), (kv2, 0), (kv2, C), aox, lsex, daox, (dqv1, 0), (dkv2, 0), (dkv2, C), C, sx)
+    # second direction: k is the query, q the key -> their gradients ADD to the ones above (small torch adds, "D2" only)
+    # (gradient tensors carry the strides of the operand they belong to: scratch copies of the packed layouts)
+    t_kv2, t_qv1 = torch.empty_like(kv2), torch.empty_like(qv1)
+    ops.attn_bwd((kv2, 0), (qv1, 0), (qv1, C), aoc, lsec, daoc, (t_kv2, 0), (t_qv1, 0), (dqv1, C), C, sc)
+    dqv1[..., :C] += t_qv1[..., :C]
+    dkv2[..., :C] += t_kv2[..., :C]
+    ops.linear_dw([Prob(dqv1, xn[0], G["attn.qv1.weight"], bias_grad=G["attn.qv1.bias"]),
+                   Prob(dkv2, xn[1], G["attn.kv2.weight"], bias_grad=G["attn.kv2.bias"])], 2 * C, C)
+    dxn = [torch.empty_like(x), torch.empty_like(c)]
+    ops.linear_dx([Prob(dqv1, P["attn.qv1.weight"], dxn[0]), Prob(dkv2, P["attn.kv2.weight"], dxn[1])], 2 * C, C)
+    return ops.layernorm_bwd_multi(dxn, ts, st, P["norm1.weight"], G["norm1.weight"], G["norm1.bias"], douts)
+
+
 def _attn_C_fwd(P, xp, c, ds, save):
     """c <- c + ds * proj(CA(q(LN1(c)), kv(LN1(xp))))  (models/lemevit.py:477-486,600)."""
     C, N, M = c.shape[-1], xp.shape[1], c.shape[1]
@@ -185,7 +231,7 @@ def block_forward(kind: str, x: Tensor, c: Tensor, H: int, W: int, P: Dict[str, 
         c1, sa = _attn_C_fwd(P, xp, c, masks[0], save)
         (c2,), sm = _mlp_fwd(P, [c1], [masks[1]], save)
         return x, c2, ((x, sa, sm) if save else None)                                            # returns the ORIGINAL x (:610)
-    fwd = _attn_S_fwd if kind == "S" else _attn_D_fwd
+    fwd = {"S": _attn_S_fwd, "D": _attn_D_fwd, "D2": _attn_D2_fwd}[kind]
     (x2, c1), sa = fwd(P, [xp, c], [masks[0], masks[2]], save)
     (x3, c2), sm = _mlp_fwd(P, [x2, c1], [masks[1], masks[3]], save)
     return x3, c2, ((x, sa, sm) if save else None)
@@ -202,7 +248,7 @@ def block_backward(kind: str, saved, dx: Tensor, dc: Tensor, H: int, W: int, P: 
         dx0 = ops.dwconv_residual_bwd_data(dxp, P["pos_embed.weight"], H, W)
         return (dx0 if dx is None else dx0 + dx), dc0   # the untouched x's pass-through gradient is added by autograd
     dx2, dc1 = _mlp_bwd(P, G, sm, [dx, dc], [masks[1], masks[3]])
-    bwd = _attn_S_bwd if kind == "S" else _attn_D_bwd
+    bwd = {"S": _attn_S_bwd, "D": _attn_D_bwd, "D2": _attn_D2_bwd}[kind]
     dxp, dc0 = bwd(P, G, sa, [dx2, dc1], [masks[0], masks[2]])
     ops.dwconv_bwd_weight(dxp, x0, G["pos_embed.weight"], G["pos_embed.bias"], H, W)
     dx0 = ops.dwconv_residual_bwd_data(dxp, P["pos_embed.weight"], H, W)

@@ -194,6 +194,34 @@ class DualCrossAttention(nn.Module):
         return ox, oc
 
 
+class DualCrossAttention_v2(nn.Module):
+    """models/lemevit.py:326-423 ("D2", lemevit_tiny_v2): q, v1 = qv1(x); k, v2 = kv2(c); x' = sdpa(q,k,v2), c' = sdpa(k,q,v1)."""
+
+    def __init__(self, dim, num_heads, scale=None, bias=False, attn_drop=0.0, proj_drop=0.0, **kwargs):
+        super().__init__()
+        assert dim % num_heads == 0 and dim // num_heads == ops.HEAD_DIM
+        self.num_heads = num_heads
+        self.scale = scale or dim ** (-0.5)
+        self.qv1 = nn.Linear(dim, 2 * dim)
+        self.kv2 = nn.Linear(dim, 2 * dim)
+        self.proj_x = nn.Linear(dim, dim)
+        self.proj_c = nn.Linear(dim, dim)
+
+    @torch.no_grad()
+    def forward(self, x, c):
+        x, c = x.contiguous(), c.contiguous()
+        C, N, M = x.shape[-1], x.shape[1], c.shape[1]
+        sx, sc = ops.dca_scales(N, M, C)
+        qv1 = torch.empty(x.shape[:-1] + (2 * C,), device=x.device, dtype=x.dtype)
+        kv2 = torch.empty(c.shape[:-1] + (2 * C,), device=x.device, dtype=x.dtype)
+        ops.linear_fwd(_lin_probs([(x, self.qv1, qv1), (c, self.kv2, kv2)], x.dtype), 2 * C, C)
+        aox, _ = ops.attn_fwd((qv1, 0), (kv2, 0), (kv2, C), C, sx)
+        aoc, _ = ops.attn_fwd((kv2, 0), (qv1, 0), (qv1, C), C, sc)
+        ox, oc = torch.empty_like(x), torch.empty_like(c)
+        ops.linear_fwd(_lin_probs([(aox, self.proj_x, ox), (aoc, self.proj_c, oc)], x.dtype), C, C)
+        return ox, oc
+
+
 class CrossAttention(nn.Module):
     """models/lemevit.py:425-497.  forward(x [B,N,C], c [B,M,C]) -> c'."""
 
@@ -232,12 +260,14 @@ class LeMeBlock(nn.Module):
         self.attn_type = attn_type or "S"
         if self.attn_type == "D":
             self.attn = DualCrossAttention(dim=dim, num_heads=num_heads)
+        elif self.attn_type == "D2":
+            self.attn = DualCrossAttention_v2(dim=dim, num_heads=num_heads)
         elif self.attn_type == "S":
             self.attn = StandardAttention(dim=dim, num_heads=num_heads)
         elif self.attn_type == "C":
             self.attn = CrossAttention(dim=dim, num_heads=num_heads)
         else:
-            raise NotImplementedError(f"attention type {attn_type!r} (the 'D2' variant is a SURVEY section 8 f4 'next' row)")
+            raise NotImplementedError(f"attention type {attn_type!r}")
         self.norm2 = nn.LayerNorm(dim, eps=1e-6)
         self.mlp = nn.Sequential(nn.Linear(dim, int(mlp_ratio * dim)), nn.Identity(), nn.GELU(), nn.Linear(int(mlp_ratio * dim), dim))
         self.drop_prob = float(drop_path)

@@ -107,6 +107,13 @@ def lemevit_small_v2(pretrained=False, pretrained_cfg=None, pretrained_cfg_overl
 
 
 @register_model
+def lemevit_tiny_v2(pretrained=False, pretrained_cfg=None, pretrained_cfg_overlay=None, **kwargs):
+    """models/lemevit.py:965-992 (shared-q/k "D2" dual cross attention)."""
+    return _variant(pretrained, kwargs, depth=[2, 2, 2, 4, 2], embed_dim=[96, 96, 192, 320, 384], mlp_ratios=[4, 4, 4, 4, 4],
+                    attn_type=["C", "D2", "D2", "S", "S"])
+
+
+@register_model
 def vit_tiny(pretrained=False, pretrained_cfg=None, pretrained_cfg_overlay=None, **kwargs):
     """models/lemevit.py:996-1023 (all-"S" baseline)."""
     return _variant(pretrained, kwargs, depth=[2, 2, 4, 2], embed_dim=[96, 192, 320, 384], mlp_ratios=[4, 4, 4, 4],

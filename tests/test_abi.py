@@ -43,7 +43,7 @@ def test_error_reporting_without_gpu():
 def test_registry_and_state_dict_layout():
     import lemevit_amd as L
     from oracle import lemevit_oracle as O
-    assert {"lemevit_tiny", "lemevit_small", "lemevit_base", "lemevit_small_v2", "vit_tiny"} <= set(L.list_models())
+    assert {"lemevit_tiny", "lemevit_small", "lemevit_base", "lemevit_small_v2", "lemevit_tiny_v2", "vit_tiny"} <= set(L.list_models())
     # timm-style call as benchmark.py:409-419 makes it (None-valued kwargs are dropped)
     m = L.create_model("lemevit_tiny", pretrained=False, num_classes=51, in_chans=3, global_pool=None, scriptable=False,
                        drop_rate=0.0, drop_path_rate=0.1, drop_block_rate=None)

@@ -42,12 +42,14 @@ MODES = [(torch.float32, 1e-5), (torch.bfloat16, 2e-2)]
 
 
 @pytest.mark.parametrize("dtype,tol", MODES)
-@pytest.mark.parametrize("name", ["dca_96", "dca_192", "dca_odd"])
+@pytest.mark.parametrize("name", ["dca_96", "dca_192", "dca_odd", "dca2_96"])
 def test_dca_module(golden, name, dtype, tol):
     meta, g = golden(name)
     C, h, N, B = meta["C"], meta["h"], meta["N"], meta["B"]
-    m = load(L().DualCrossAttention(dim=C, num_heads=h), "attn.", meta["seed"]).eval()
-    x = det_tensor((B, N, C), name + ".x", 1).to(DEV, dtype); c = det_tensor((B, 16, C), name + ".c", 1).to(DEV, dtype)
+    cls = L().DualCrossAttention_v2 if meta["kind"] == "dca2" else L().DualCrossAttention
+    m = load(cls(dim=C, num_heads=h), "attn.", meta["seed"]).eval()
+    pre = "dca2" if meta["kind"] == "dca2" else name
+    x = det_tensor((B, N, C), pre + ".x", 1).to(DEV, dtype); c = det_tensor((B, 16, C), pre + ".c", 1).to(DEV, dtype)
     xo, co = m(x, c)
     close(sample(xo.float()), g["x_out"], tol, name + ".x"); close(co, g["c_out"], tol, name + ".c")
 
@@ -108,7 +110,7 @@ def test_block_backward_fp32(golden, name):
 def test_block_backward_bf16_vs_oracle():
     """bf16 kernels: gradients of a D and an S block vs the fp64 oracle on the same bf16-rounded inputs
     and weights; 3e-2 of each gradient's max-abs (bf16 activations inside the block)."""
-    for t, C, h, Hs in [("D", 96, 3, 14), ("S", 192, 6, 7), ("C", 64, 2, 14)]:
+    for t, C, h, Hs in [("D", 96, 3, 14), ("S", 192, 6, 7), ("C", 64, 2, 14), ("D2", 96, 3, 14)]:
         B = 3
         m = load(_block(t, C, h), "blk.", 5).eval()
         sd = {"blk." + k: v.detach().to(torch.bfloat16).double().cpu().requires_grad_(True) if ("attn." in k or "mlp." in k) and k.endswith("weight")
@@ -140,7 +142,8 @@ def _model(variant, num_classes, seed, **kw):
     return m.to(DEV)
 
 
-@pytest.mark.parametrize("name", ["model_tiny_224", "model_base_224", "model_small_224", "model_tiny_384", "model_small_v2_224", "model_vit_tiny_224"])
+@pytest.mark.parametrize("name", ["model_tiny_224", "model_base_224", "model_small_224", "model_tiny_384", "model_small_v2_224", "model_tiny_v2_224",
+                                  "model_vit_tiny_224"])
 def test_model_forward_fp32(golden, name):
     """BASELINE config 1 + fp32 parity: logits within 1e-5 (rel. max-abs) of the reference's CPU forward."""
     meta, g = golden(name)

@@ -383,6 +383,15 @@ template <typename T>
 int fwd_impl(const lmv_attn_desc* d, void* ws, size_t ws_bytes, hipStream_t st) {
   const Args a = to_args(d);
   if (sizeof(T) == 2 && lmv_attn_mfma_supported(a)) return lmv_attn_mfma_fwd(a, st);
+  if (sizeof(T) == 2 && lmv_attn_mfma_fewq_supported(a)) {
+    const int nsplit = lmv_attn_mfma_fewq_nsplit(a);
+    const size_t need = (size_t)d->B * d->H * nsplit * FQ * (D + 2) * sizeof(float);
+    if (!ws || ws_bytes < need) LMV_FAIL(LMV_ERR_WORKSPACE, "attn_fwd: workspace %zu < %zu bytes", ws_bytes, need);
+    if (int rc = lmv_attn_mfma_fewq_fwd(a, (float*)ws, st)) return rc;
+    hipLaunchKernelGGL((fwd_fewq_combine_kernel<T>), dim3(d->H, d->B), dim3(FQ * D), 0, st, a, (const float*)ws, nsplit);
+    LMV_CHECK_LAUNCH("attn_fwd combine");
+    return LMV_OK;
+  }
   if (few_q(d->Lq, d->Lk)) {
     const int nsplit = (d->Lk + FKB - 1) / FKB;
     const size_t need = (size_t)d->B * d->H * nsplit * FQ * (D + 2) * sizeof(float);
@@ -409,6 +418,7 @@ int bwd_impl(const lmv_attn_desc* d, void* ws, size_t ws_bytes, hipStream_t st) 
   const int64_t nd = (int64_t)d->B * d->H * d->Lq;
   hipLaunchKernelGGL((bwd_delta_kernel<T>), dim3((unsigned)((nd + 255) / 256)), dim3(256), 0, st, a, delta);
   if (sizeof(T) == 2 && lmv_attn_mfma_supported(a)) return lmv_attn_mfma_bwd(a, delta, acc0, st);
+  if (sizeof(T) == 2 && lmv_attn_mfma_fewq_supported(a)) return lmv_attn_mfma_fewq_bwd(a, delta, acc0, st);
   const dim3 gk((d->Lk + QB - 1) / QB, d->H, d->B), gq((d->Lq + QB - 1) / QB, d->H, d->B);
   if (few_q(d->Lq, d->Lk)) {
     if (hipMemsetAsync(acc0, 0, acc_elems * sizeof(float), st) != hipSuccess) LMV_FAIL(LMV_ERR_LAUNCH, "attn_bwd: memset failed");
@@ -435,7 +445,7 @@ extern "C" size_t lmv_attn_workspace_bytes(int B, int H, int Lq, int Lk, int bac
   if (B <= 0 || H <= 0 || Lq <= 0 || Lk <= 0) return 0;
   if (!backward) {
     if (!few_q(Lq, Lk)) return 256;
-    const int nsplit = (Lk + FKB - 1) / FKB;
+    const int nsplit = (Lk + 127) / 128;        // the bf16 MFMA path splits the keys into ranges of 128 (generic path: 256)
     return align256((size_t)B * H * nsplit * FQ * (D + 2) * sizeof(float));
   }
   // delta + fp32 accumulators of the split reductions (sized for the larger of the generic and the MFMA path)

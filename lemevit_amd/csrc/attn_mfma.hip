@@ -302,6 +302,167 @@ __global__ __launch_bounds__(256) void scatter_bf16_kernel(const float* __restri
   dst[b * bs + (int64_t)l * rs + h * D + d] = f2bf(acc[((((int64_t)b * H + h) * LP) + l) * D + d]);
 }
 
+// =============================================================================================
+// <= 16 queries over MANY keys (meta tokens attend to N image tokens: DCA c-direction, stage-0 CA).
+// B * h alone under-fills 256 CUs, so the KEYS are split: one wavefront per range of RK = 128 keys (4 ranges per
+// workgroup); forward writes per-range (max, sum, unnormalised O) partials that fwd_fewq_combine_kernel merges;
+// backward is ONE kernel: every wave produces dK / dV of its own keys (D[q][key] orientation) and its share of dQ
+// (D[key][q] orientation), the four waves' dQ are summed in LDS and added to an fp32 accumulator.
+// =============================================================================================
+constexpr int RKT = 8, RK = RKT * 16;      // forward: key tiles / keys per wave
+constexpr int RKT_B = 4, RKB = RKT_B * 16; // backward (more LDS per key: Q / dO images, reduction scratch)
+
+__global__ __launch_bounds__(256) void mfma_fwd_split_kernel(const AttnArgs a, float* __restrict__ part, int nsplit) {
+  __shared__ __attribute__((aligned(16))) unsigned char sK[4 * RK * 64], sV[4 * RK * 64];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = blockIdx.y, b = blockIdx.z, g = lane >> 4;
+  const int split = blockIdx.x * 4 + wave, k0 = split * RK;
+  const bf16_t* kb = reinterpret_cast<const bf16_t*>(a.k) + b * a.k_bs + h * D;
+  const bf16_t* vb = reinterpret_cast<const bf16_t*>(a.v) + b * a.v_bs + h * D;
+  unsigned char* wK = sK + wave * RK * 64;
+  unsigned char* wV = sV + wave * RK * 64;
+  stage_rows<64>(wK, kb, a.k_rs, k0, RK, a.Lk, lane);          // per-wave images: only wave-level ordering needed
+  stage_rows<64>(wV, vb, a.v_rs, k0, RK, a.Lk, lane);
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_wave_barrier();
+  if (split >= nsplit) return;
+  const int q = lane & 15;
+  float* pp = part + ((((int64_t)b * a.H + h) * nsplit + split) * 16 + q) * (D + 2);
+  if (k0 >= a.Lk) {                                              // empty range: neutral partial
+    if (g == 0) { pp[0] = -1e30f; pp[1] = 0.f; }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { pp[2 + g * 4 + r] = 0.f; pp[18 + g * 4 + r] = 0.f; }
+    return;
+  }
+  const bf16x8_t qf = load_frag_global(reinterpret_cast<const bf16_t*>(a.q) + b * a.q_bs + h * D, a.q_rs, q, a.Lq, lane);
+  f32x4_t s[RKT];
+  float m = -1e30f;
+#pragma unroll
+  for (int kt = 0; kt < RKT; ++kt) {
+    s[kt] = MFMA(frag_n(wK, kt * 16, lane), qf, (f32x4_t{0.f, 0.f, 0.f, 0.f}));
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      s[kt][r] = (k0 + kt * 16 + g * 4 + r < a.Lk) ? s[kt][r] * a.scale : -1e30f;
+      m = fmaxf(m, s[kt][r]);
+    }
+  }
+  m = group_max4(m);
+  float l = 0.f;
+#pragma unroll
+  for (int kt = 0; kt < RKT; ++kt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { const float p = __expf(s[kt][r] - m); s[kt][r] = p; l += p; }
+  l = group_sum4(l);
+  f32x4_t o0 = {0.f, 0.f, 0.f, 0.f}, o1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int kb2 = 0; kb2 < RKT / 2; ++kb2) {
+    const bf16x8_t ph = pack8(s[2 * kb2], s[2 * kb2 + 1]);
+    f32x4_t r0, r1;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { r0[r] = s[2 * kb2][r] - (float)ph[r]; r1[r] = s[2 * kb2 + 1][r] - (float)ph[4 + r]; }
+    const bf16x8_t pl = pack8(r0, r1);
+    const bf16x8_t vt0 = frag_t(wV, kb2 * 32, kb2 * 32 + 16, 0, lane), vt1 = frag_t(wV, kb2 * 32, kb2 * 32 + 16, 16, lane);
+    o0 = MFMA(vt0, ph, o0); o0 = MFMA(vt0, pl, o0);
+    o1 = MFMA(vt1, ph, o1); o1 = MFMA(vt1, pl, o1);
+  }
+  if (g == 0) { pp[0] = m; pp[1] = l; }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) { pp[2 + g * 4 + r] = o0[r]; pp[18 + g * 4 + r] = o1[r]; }
+}
+
+// backward of the same shape, RKB = 64 keys per wave: grid (ceil(ceil(Lk / 64) / 4), H, B)
+__global__ __launch_bounds__(256) void mfma_bwd_fewq_kernel(const AttnArgs a, const float* __restrict__ delta, float* __restrict__ acc_q) {
+  __shared__ __attribute__((aligned(16))) unsigned char sK[4 * RKB * 64], sV[4 * RKB * 64];
+  __shared__ __attribute__((aligned(16))) unsigned char sQ[32 * 64], sG[32 * 64];
+  __shared__ __attribute__((aligned(16))) float sL[32], sDl[32], sRed[4][2][64][4];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = blockIdx.y, b = blockIdx.z, g = lane >> 4;
+  const int k0 = (blockIdx.x * 4 + wave) * RKB;
+  const int64_t bh = ((int64_t)b * a.H + h) * a.Lq;
+  const bf16_t* kb = reinterpret_cast<const bf16_t*>(a.k) + b * a.k_bs + h * D;
+  const bf16_t* vb = reinterpret_cast<const bf16_t*>(a.v) + b * a.v_bs + h * D;
+  unsigned char* wK = sK + wave * RKB * 64;
+  unsigned char* wV = sV + wave * RKB * 64;
+  stage_rows<64>(wK, kb, a.k_rs, k0, RKB, a.Lk, lane);
+  stage_rows<64>(wV, vb, a.v_rs, k0, RKB, a.Lk, lane);
+  stage_rows<256>(sQ, reinterpret_cast<const bf16_t*>(a.q) + b * a.q_bs + h * D, a.q_rs, 0, 32, a.Lq, tid);
+  stage_rows<256>(sG, reinterpret_cast<const bf16_t*>(a.d_o) + b * a.o_bs + h * D, a.o_rs, 0, 32, a.Lq, tid);
+  if (tid < 32) {
+    const bool ok = tid < a.Lq;
+    sL[tid] = ok ? a.lse[bh + tid] : 1e30f;     // exp(s - 1e30) = 0 masks the padded queries
+    sDl[tid] = ok ? delta[bh + tid] : 0.f;
+  }
+  __syncthreads();
+  // ---- orientation D[q][key]: dK, dV of this wave's keys (query rows 0..31, rows >= Lq are zero / masked) --------
+  const bf16x8_t qn0 = frag_n(sQ, 0, lane), qn1 = frag_n(sQ, 16, lane), gn0 = frag_n(sG, 0, lane), gn1 = frag_n(sG, 16, lane);
+  const bf16x8_t qt0 = frag_t(sQ, 0, 16, 0, lane), qt1 = frag_t(sQ, 0, 16, 16, lane);
+  const bf16x8_t gt0 = frag_t(sG, 0, 16, 0, lane), gt1 = frag_t(sG, 0, 16, 16, lane);
+  const float4 l0 = *reinterpret_cast<const float4*>(sL + g * 4), l1 = *reinterpret_cast<const float4*>(sL + 16 + g * 4);
+  const float4 d0 = *reinterpret_cast<const float4*>(sDl + g * 4), d1 = *reinterpret_cast<const float4*>(sDl + 16 + g * 4);
+  const float lse[8] = {l0.x, l0.y, l0.z, l0.w, l1.x, l1.y, l1.z, l1.w};
+  const float dl[8] = {d0.x, d0.y, d0.z, d0.w, d1.x, d1.y, d1.z, d1.w};
+#pragma unroll
+  for (int kt = 0; kt < RKT_B; ++kt) {
+    const int key = k0 + kt * 16 + (lane & 15);
+    if (k0 + kt * 16 >= a.Lk) break;                              // wave-uniform
+    const bool kvalid = key < a.Lk;
+    const bf16x8_t kf = frag_n(wK, kt * 16, lane), vf = frag_n(wV, kt * 16, lane);
+    const f32x4_t s0 = MFMA(qn0, kf, (f32x4_t{0.f, 0.f, 0.f, 0.f})), s1 = MFMA(qn1, kf, (f32x4_t{0.f, 0.f, 0.f, 0.f}));
+    const f32x4_t p0 = MFMA(gn0, vf, (f32x4_t{0.f, 0.f, 0.f, 0.f})), p1 = MFMA(gn1, vf, (f32x4_t{0.f, 0.f, 0.f, 0.f}));
+    f32x4_t pr[2], ds[2];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float e0 = kvalid ? __expf(s0[r] * a.scale - lse[r]) : 0.f, e1 = kvalid ? __expf(s1[r] * a.scale - lse[4 + r]) : 0.f;
+      pr[0][r] = e0; pr[1][r] = e1;
+      ds[0][r] = e0 * (p0[r] - dl[r]) * a.scale; ds[1][r] = e1 * (p1[r] - dl[4 + r]) * a.scale;
+    }
+    const bf16x8_t pf = pack8(pr[0], pr[1]), dsf = pack8(ds[0], ds[1]);
+    const f32x4_t z = {0.f, 0.f, 0.f, 0.f};
+    const f32x4_t dv0 = MFMA(gt0, pf, z), dv1 = MFMA(gt1, pf, z), dk0 = MFMA(qt0, dsf, z), dk1 = MFMA(qt1, dsf, z);
+    if (kvalid) {
+      bf16_t* dkp = reinterpret_cast<bf16_t*>(a.dk) + b * a.k_bs + (int64_t)key * a.k_rs + h * D + g * 4;
+      bf16_t* dvp = reinterpret_cast<bf16_t*>(a.dv) + b * a.v_bs + (int64_t)key * a.v_rs + h * D + g * 4;
+      store4(dkp, dk0); store4(dkp + 16, dk1); store4(dvp, dv0); store4(dvp + 16, dv1);
+    }
+  }
+  // ---- orientation D[key][q]: this wave's share of dQ (query tile 0: rows 0..15) --------------------------------
+  const int q = lane & 15;
+  const bool vq = q < a.Lq;
+  const float lq = sL[q], dq_ = sDl[q];
+  f32x4_t dq0 = {0.f, 0.f, 0.f, 0.f}, dq1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int kb2 = 0; kb2 < RKT_B / 2; ++kb2) {
+    if (k0 + kb2 * 32 >= a.Lk) break;
+    f32x4_t ds[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const int kt = 2 * kb2 + t;
+      const f32x4_t s = MFMA(frag_n(wK, kt * 16, lane), qn0, (f32x4_t{0.f, 0.f, 0.f, 0.f}));
+      const f32x4_t dp = MFMA(frag_n(wV, kt * 16, lane), gn0, (f32x4_t{0.f, 0.f, 0.f, 0.f}));
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const bool ok = vq && (k0 + kt * 16 + g * 4 + r < a.Lk);
+        const float p = ok ? __expf(s[r] * a.scale - lq) : 0.f;
+        ds[t][r] = p * (dp[r] - dq_) * a.scale;
+      }
+    }
+    const bf16x8_t dsf = pack8(ds[0], ds[1]);
+    dq0 = MFMA(frag_t(wK, kb2 * 32, kb2 * 32 + 16, 0, lane), dsf, dq0);
+    dq1 = MFMA(frag_t(wK, kb2 * 32, kb2 * 32 + 16, 16, lane), dsf, dq1);
+  }
+  *reinterpret_cast<f32x4_t*>(&sRed[wave][0][lane][0]) = dq0;
+  *reinterpret_cast<f32x4_t*>(&sRed[wave][1][lane][0]) = dq1;
+  __syncthreads();
+  if (wave == 0 && vq) {
+#pragma unroll
+    for (int w = 1; w < 4; ++w) {
+      dq0 += *reinterpret_cast<const f32x4_t*>(&sRed[w][0][lane][0]);
+      dq1 += *reinterpret_cast<const f32x4_t*>(&sRed[w][1][lane][0]);
+    }
+    float* dst = acc_q + (((int64_t)b * a.H + h) * 16 + q) * D + g * 4;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { atomicAdd(dst + r, dq0[r]); atomicAdd(dst + 16 + r, dq1[r]); }
+  }
+}
+
 inline int nkt_for(int Lk) { return Lk <= 32 ? 2 : (Lk <= 64 ? 4 : (Lk <= 128 ? 8 : 14)); }
 
 // query tiles per workgroup: whole (b, h) in one workgroup when small, else ~32 tiles, but keep the grid >= ~1024
@@ -315,6 +476,28 @@ inline int qt_per_block_for(const AttnArgs& a) {
 }  // namespace
 
 bool lmv_attn_mfma_supported(const AttnArgs& a) { return a.Lk <= 224; }
+bool lmv_attn_mfma_fewq_supported(const AttnArgs& a) { return a.Lq <= 16 && a.Lk > 224; }
+int lmv_attn_mfma_fewq_nsplit(const AttnArgs& a) { return (a.Lk + RK - 1) / RK; }
+
+// forward partials [B][H][nsplit][16][34] (max, sum, unnormalised O); the caller runs fwd_fewq_combine_kernel on them
+int lmv_attn_mfma_fewq_fwd(const AttnArgs& a, float* part, hipStream_t st) {
+  const int nsplit = lmv_attn_mfma_fewq_nsplit(a);
+  hipLaunchKernelGGL(mfma_fwd_split_kernel, dim3((nsplit + 3) / 4, a.H, a.B), dim3(256), 0, st, a, part, nsplit);
+  LMV_CHECK_LAUNCH("attn_mfma_fewq_fwd");
+  return LMV_OK;
+}
+
+// acc: >= B*H*16*32 floats of scratch for dQ
+int lmv_attn_mfma_fewq_bwd(const AttnArgs& a, const float* delta, float* acc, hipStream_t st) {
+  const size_t n = (size_t)a.B * a.H * 16 * D;
+  if (hipMemsetAsync(acc, 0, n * sizeof(float), st) != hipSuccess) LMV_FAIL(LMV_ERR_LAUNCH, "attn_mfma_fewq_bwd: memset failed");
+  const int nr = (a.Lk + RKB - 1) / RKB;
+  hipLaunchKernelGGL(mfma_bwd_fewq_kernel, dim3((nr + 3) / 4, a.H, a.B), dim3(256), 0, st, a, delta, acc);
+  const unsigned tot = (unsigned)a.B * a.H * a.Lq * D;
+  hipLaunchKernelGGL(scatter_bf16_kernel, dim3((tot + 255) / 256), dim3(256), 0, st, (const float*)acc, (bf16_t*)a.dq, a.q_bs, a.q_rs, a.B, a.H, a.Lq, 16);
+  LMV_CHECK_LAUNCH("attn_mfma_fewq_bwd");
+  return LMV_OK;
+}
 
 size_t lmv_attn_mfma_bwd_acc_bytes(const AttnArgs& a) {
   return 2 * (size_t)a.B * a.H * nkt_for(a.Lk) * 16 * D * sizeof(float);

@@ -36,7 +36,7 @@ def test_error_reporting_without_gpu():
     assert lib.lmv_linear_fwd(p, 1, 60, 64, 0, 1, None) == -1 and b"multiples of 8" in lib.lmv_last_error()
     assert lib.lmv_linear_fwd(p, 1, 64, 64, 0, 7, None) == -2
     assert lib.lmv_layernorm_fwd(None, 1, None, None, 12, 1e-6, 0, None) == -1
-    assert lib.lmv_attn_workspace_bytes(128, 3, 16, 3136, 0) == 128 * 3 * 13 * 16 * 34 * 4
+    assert lib.lmv_attn_workspace_bytes(128, 3, 16, 3136, 0) == 128 * 3 * 25 * 16 * 34 * 4      # 25 key ranges of 128
     assert lib.lmv_sa_core_fwd(None, None, None, 1, 4, 48, None, 0, 0, None) == -1 and b"head dim" in lib.lmv_last_error()
 
 

@@ -303,8 +303,8 @@ __device__ __forceinline__ void store_tile(unsigned char* smem, const f32x4_t (&
   }
 }
 
-template <typename T, bool ATR, bool BTR, bool SPLITK, int BK, bool DMA, typename CF>
-__global__ __launch_bounds__(CF::NTHR) void gemm_kernel(const GemmArgs g) {
+template <typename T, bool ATR, bool BTR, bool SPLITK, int BK, bool DMA, typename CF, int MINW = 1>
+__global__ __launch_bounds__(CF::NTHR, MINW) void gemm_kernel(const GemmArgs g) {
   constexpr int PANEL_BYTES = PANEL * BK * (int)sizeof(T);
   constexpr int BUF_BYTES = (CF::PA + CF::PB) * PANEL_BYTES;
   constexpr int WM = CF::WM;
@@ -479,7 +479,19 @@ int make_plan(const lmv_linear_problem* p, int nproblems, int N, int K, int act,
   // bf16: 64-deep k-tiles unless the reduction is a short non-multiple of 64 (C = 96 layers); fp32: 32-deep
   static const int force_bk = [] { const char* e = getenv("LMV_GEMM_BK"); return e ? atoi(e) : 0; }();   // A/B testing
   int bk = (bf && (mode == MODE_DW || all64 || min_kred >= 512)) ? 64 : 32;
+  // Occupancy beats k-tile depth whenever the launch has enough tiles to put 4 workgroups on every CU: half of a
+  // workgroup's life is launch + first-load latency + epilogue + store drain, which only OTHER resident workgroups
+  // hide.  The 32-deep variant needs 32 KB of LDS and <= 128 registers (4 per CU) against 64 KB / 160 (2 per CU).
+  if (bf && all32 && mode != MODE_DW) {
+    int64_t tiles128 = 0;
+    for (int i = 0; i < nproblems; ++i) tiles128 += (int64_t)((g.p[i].M + 127) / 128) * ((out_cols + 127) / 128);
+    static const int min_tiles = [] { const char* e = getenv("LMV_GEMM_BK32_TILES"); return e ? atoi(e) : 512; }();
+    if (tiles128 >= min_tiles) bk = 32;
+  }
+  static const int dw_bk = [] { const char* e = getenv("LMV_DW_BK"); return e ? atoi(e) : 64; }();   // A/B testing
+  if (bf && all32 && mode == MODE_DW && dw_bk == 32) bk = 32;
   if (force_bk == 32 && all32) bk = 32;
+  if (force_bk == 64 && all64) bk = 64;
   static const bool no_dma = getenv("LMV_GEMM_NO_DMA") != nullptr;     // A/B testing
   const bool dma = bf && !no_dma && (bk == 64 ? all64 : all32);
   // Tile choice.  Measured on the LeMeViT shapes (K = 96..2048, tools/gemm_ablate.py): the k-loop alone runs at
@@ -539,10 +551,10 @@ int make_plan(const lmv_linear_problem* p, int nproblems, int N, int K, int act,
   return LMV_OK;
 }
 
-template <typename T, bool ATR, bool BTR, bool SPLITK, int BK, bool DMA, typename CF>
+template <typename T, bool ATR, bool BTR, bool SPLITK, int BK, bool DMA, typename CF, int MINW = 1>
 int launch_one(const GemmArgs& g, dim3 grid, hipStream_t st) {
   constexpr int lds = 2 * (CF::PA + CF::PB) * PANEL * BK * (int)sizeof(T);
-  auto kern = gemm_kernel<T, ATR, BTR, SPLITK, BK, DMA, CF>;
+  auto kern = gemm_kernel<T, ATR, BTR, SPLITK, BK, DMA, CF, MINW>;
   static bool attr_set = false;                 // > 64 KiB of dynamic LDS needs an explicit opt-in, once per kernel
   if (!attr_set) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
@@ -559,7 +571,8 @@ int launch_mode(const Plan& pl, dim3 grid, bool bf, hipStream_t st) {
   if (!bf) return launch_one<float, ATR, BTR, SPLITK, 32, false, C128>(g, grid, st);
   if (!pl.dma) return pl.bk == 64 ? launch_one<bf16_t, ATR, BTR, SPLITK, 64, false, C128>(g, grid, st)
                                   : launch_one<bf16_t, ATR, BTR, SPLITK, 32, false, C128>(g, grid, st);
-  if (pl.bk == 32) return launch_one<bf16_t, ATR, BTR, SPLITK, 32, true, C128>(g, grid, st);
+  // 32-deep k-tiles: 32 KB of LDS and (capped by MINW) <= 128 / 168 registers: 4 (fwd, dX) or 3 (dW) workgroups per CU
+  if (pl.bk == 32) return launch_one<bf16_t, ATR, BTR, SPLITK, 32, true, C128, SPLITK ? 3 : 4>(g, grid, st);
   switch (pl.tile) {
     case TILE_256:     return launch_one<bf16_t, ATR, BTR, SPLITK, 64, true, C256>(g, grid, st);
     case TILE_256x128: return launch_one<bf16_t, ATR, BTR, SPLITK, 64, true, C256x128>(g, grid, st);

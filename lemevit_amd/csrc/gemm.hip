@@ -58,6 +58,7 @@ struct Problem {
 struct GemmArgs {
   Problem p[2];
   int nprob, N, lda, ldb, ldc, act, tiles_n, kt_per_split;
+  int ntiles, nsplits, concat;   // dW: tiles of dW, k-splits, and whether problem 1's rows extend problem 0's reduction
   float* ws;              // split-K (dW) mode: partial slabs [slab][N*K + N] fp32
   int64_t slab_stride;    // floats per slab
   int slab_base[2];       // first slab of each problem
@@ -315,24 +316,41 @@ __global__ __launch_bounds__(CF::NTHR, MINW) void gemm_kernel(const GemmArgs g) 
   const int wm = wave / CF::NWN, wn = wave % CF::NWN;
   // XCD-aware order: hardware places block b on XCD b % 8; give each XCD a contiguous run of logical tiles so
   // the n-tiles of one m-tile share an L2 (speed only -- any placement is correct).
-  int bid;
-  {
+  // dW: the workgroups of one k-split (all tiles of dW read the SAME token rows) sit 8 ids apart -- same XCD, launched
+  // together -- so the rows are fetched from HBM once and shared through that XCD's L2.
+  int bid, split = 0;
+  if constexpr (SPLITK) {
+    const int x = blockIdx.x & 7, y = blockIdx.x >> 3;
+    if (g.nsplits >= 8) {                // a multiple of 8: XCD x owns splits x, x + 8, ...
+      bid = y % g.ntiles;
+      split = (y / g.ntiles) * 8 + x;
+    } else {                             // 1, 2 or 4: the XCDs that share a split divide its tiles
+      split = x % g.nsplits;
+      bid = y * (8 / g.nsplits) + x / g.nsplits;
+    }
+    if (split >= g.nsplits || bid >= g.ntiles) return;
+  } else {
     const int T_ = gridDim.x, xcd = blockIdx.x & 7, idx = blockIdx.x >> 3, q = T_ >> 3, r = T_ & 7;
     bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
   }
-  const int pi = (g.nprob > 1 && bid >= g.p[1].tile_begin) ? 1 : 0;
+  const int pi = (g.nprob > 1 && !g.concat && bid >= g.p[1].tile_begin) ? 1 : 0;
   const Problem& P = g.p[pi];
   bid -= P.tile_begin;
   const int tm = bid / g.tiles_n, tn = bid % g.tiles_n;
   const int m0 = tm * CF::BM, n0 = tn * CF::BN;
-  const int M = P.M, N = g.N, Kred = P.Kred;
-  const int kt_total = (Kred + BK - 1) / BK;
-  const int kt_beg = blockIdx.y * g.kt_per_split;
+  const int M = P.M, N = g.N;
+  // dW of two problems that share dW (x and c rows through the same weights): ONE reduction over the rows of both
+  const int kt0 = (P.Kred + BK - 1) / BK;
+  const int kt_total = kt0 + ((SPLITK && g.concat) ? (g.p[1].Kred + BK - 1) / BK : 0);
+  const int kt_beg = split * g.kt_per_split;
   const int kt_end = min(kt_total, kt_beg + g.kt_per_split);
   if (kt_beg >= kt_end) return;
-
-  const T* __restrict__ A = reinterpret_cast<const T*>(P.a);
-  const T* __restrict__ Bw = reinterpret_cast<const T*>(P.b);
+  // operands of k-tile kt
+  auto src_of = [&](int kt, const T** a, const T** b, int* kred, int* k0) {
+    const Problem& Q = (SPLITK && kt >= kt0) ? g.p[1] : P;
+    *a = reinterpret_cast<const T*>(Q.a); *b = reinterpret_cast<const T*>(Q.b);
+    *kred = Q.Kred; *k0 = ((SPLITK && kt >= kt0) ? kt - kt0 : kt) * BK;
+  };
 
   f32x4_t acc[WM][4], accb[WM];
 #pragma unroll
@@ -349,39 +367,39 @@ __global__ __launch_bounds__(CF::NTHR, MINW) void gemm_kernel(const GemmArgs g) 
   int cur = 0;
   if constexpr (DMA) {
     static_assert(sizeof(T) == 2, "the direct-to-LDS path is bf16 only");
-    const bf16_t* A16 = reinterpret_cast<const bf16_t*>(A);
-    const bf16_t* B16 = reinterpret_cast<const bf16_t*>(Bw);
     auto issue = [&](unsigned char* buf, int kt) {
+      const bf16_t *A16, *B16; int kred, k0;
+      src_of(kt, &A16, &B16, &kred, &k0);
 #pragma unroll
-      for (int q = 0; q < CF::PA; ++q) panel_dma<ATR, BK, CF::NW>(buf + q * PANEL_BYTES, A16, g.lda, M, m0 + q * PANEL, kt * BK, lane, wave);
+      for (int q = 0; q < CF::PA; ++q) panel_dma<ATR, BK, CF::NW>(buf + q * PANEL_BYTES, A16, g.lda, M, m0 + q * PANEL, k0, lane, wave);
 #pragma unroll
-      for (int q = 0; q < CF::PB; ++q) panel_dma<BTR, BK, CF::NW>(buf + (CF::PA + q) * PANEL_BYTES, B16, g.ldb, N, n0 + q * PANEL, kt * BK, lane, wave);
+      for (int q = 0; q < CF::PB; ++q) panel_dma<BTR, BK, CF::NW>(buf + (CF::PA + q) * PANEL_BYTES, B16, g.ldb, N, n0 + q * PANEL, k0, lane, wave);
     };
     issue(smem, kt_beg);
     __syncthreads();                                  // (the compiler drains vmcnt before the barrier: the LDS-DMA landed)
-    const bool dbg_no_mma = g.act & 0x100, dbg_no_dma = g.act & 0x200;      // DEBUG ablation switches
     for (int kt = kt_beg; kt < kt_end; ++kt) {
-      if (kt + 1 < kt_end && !dbg_no_dma) issue(smem + (cur ^ 1) * BUF_BYTES, kt + 1);   // streams under this tile's MFMAs
+      if (kt + 1 < kt_end) issue(smem + (cur ^ 1) * BUF_BYTES, kt + 1);   // streams under this tile's MFMAs
       const unsigned char* buf = smem + cur * BUF_BYTES;
-      if (!dbg_no_mma) tile_mma<T, ATR, BTR, BK, SPLITK, WM>(buf + pa * PANEL_BYTES, oa, buf + (CF::PA + pb) * PANEL_BYTES, ob, acc, accb, do_bsum, lane);
+      tile_mma<T, ATR, BTR, BK, SPLITK, WM>(buf + pa * PANEL_BYTES, oa, buf + (CF::PA + pb) * PANEL_BYTES, ob, acc, accb, do_bsum, lane);
       __syncthreads();
       cur ^= 1;
     }
-    if (g.act & 0x400) return;                                              // DEBUG: skip the epilogue
   } else {
     constexpr int NCH = PANEL_BYTES / 16 / 256;
     uint4 ra[NCH], rb[NCH];
-    stage_load<T, ATR, BK, NCH>(ra, A, g.lda, M, Kred, m0, kt_beg * BK, tid);
-    stage_load<T, BTR, BK, NCH>(rb, Bw, g.ldb, N, Kred, n0, kt_beg * BK, tid);
+    auto fetch = [&](int kt) {
+      const T *A, *Bw; int kred, k0;
+      src_of(kt, &A, &Bw, &kred, &k0);
+      stage_load<T, ATR, BK, NCH>(ra, A, g.lda, M, kred, m0, k0, tid);
+      stage_load<T, BTR, BK, NCH>(rb, Bw, g.ldb, N, kred, n0, k0, tid);
+    };
+    fetch(kt_beg);
     stage_store<T, ATR, BK, NCH>(smem, ra, tid);
     stage_store<T, BTR, BK, NCH>(smem + PANEL_BYTES, rb, tid);
     __syncthreads();
     for (int kt = kt_beg; kt < kt_end; ++kt) {
       const bool has_next = kt + 1 < kt_end;
-      if (has_next) {                                   // global loads of the next k-tile fly under this tile's MFMAs
-        stage_load<T, ATR, BK, NCH>(ra, A, g.lda, M, Kred, m0, (kt + 1) * BK, tid);
-        stage_load<T, BTR, BK, NCH>(rb, Bw, g.ldb, N, Kred, n0, (kt + 1) * BK, tid);
-      }
+      if (has_next) fetch(kt + 1);                      // global loads of the next k-tile fly under this tile's MFMAs
       const unsigned char* buf = smem + cur * BUF_BYTES;
       tile_mma<T, ATR, BTR, BK, SPLITK, WM>(buf, oa, buf + PANEL_BYTES, ob, acc, accb, do_bsum, lane);
       if (has_next) {
@@ -396,7 +414,7 @@ __global__ __launch_bounds__(CF::NTHR, MINW) void gemm_kernel(const GemmArgs g) 
 
   if constexpr (SPLITK) {
     // partial tile -> this split's slab (plain stores; summed by splitk_reduce_kernel)
-    float* slab = g.ws + (int64_t)(g.slab_base[pi] + blockIdx.y) * g.slab_stride;
+    float* slab = g.ws + (int64_t)(g.slab_base[pi] + split) * g.slab_stride;
 #pragma unroll
     for (int ti = 0; ti < WM; ++ti) {
       const int m = m0 + ra0 + ti * 16 + (lane & 15);
@@ -417,22 +435,37 @@ __global__ __launch_bounds__(CF::NTHR, MINW) void gemm_kernel(const GemmArgs g) 
 }
 
 // out[i] += sum_s ws[s][i]  (i < nw: dW; nw <= i < nw + nb: db)
+// A block covers 256 / SL float4 elements x SL slab lanes: lane l sums slabs l, l + SL, ... in order, lane 0 then adds
+// the SL lane sums in order (fixed summation tree: run-to-run reproducible).  SL > 1 keeps small dW matrices with
+// hundreds of slabs from being a latency-bound serial walk.
+template <int SL>
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ ws, int nslabs, int64_t stride, float* __restrict__ out_w,
                                                            int64_t nw, float* __restrict__ out_b, int nb) {
+  constexpr int EL = 256 / SL;
+  __shared__ float4 red[SL > 1 ? 256 : 1];
   const int64_t n4 = (nw + (out_b ? nb : 0)) >> 2;
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
-    float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+  const int e = threadIdx.x % EL, sl = threadIdx.x / EL;
+  const int64_t i = (int64_t)blockIdx.x * EL + e;
+  float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (i < n4) {
     const float* p = ws + i * 4;
-#pragma unroll 4
-    for (int s = 0; s < nslabs; ++s) {
+#pragma unroll 8
+    for (int s = sl; s < nslabs; s += SL) {
       const float4 v = *reinterpret_cast<const float4*>(p + (int64_t)s * stride);
       a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
     }
-    float* o = (i * 4 < nw) ? out_w + i * 4 : out_b + (i * 4 - nw);
-    float4 c = *reinterpret_cast<float4*>(o);
-    c.x += a.x; c.y += a.y; c.z += a.z; c.w += a.w;
-    *reinterpret_cast<float4*>(o) = c;
   }
+  if (SL > 1) {
+    red[threadIdx.x] = a;
+    __syncthreads();
+    if (sl != 0) return;
+    for (int l = 1; l < SL; ++l) { const float4 v = red[l * EL + e]; a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w; }
+  }
+  if (i >= n4) return;
+  float* o = (i * 4 < nw) ? out_w + i * 4 : out_b + (i * 4 - nw);
+  float4 c = *reinterpret_cast<float4*>(o);
+  c.x += a.x; c.y += a.y; c.z += a.z; c.w += a.w;
+  *reinterpret_cast<float4*>(o) = c;
 }
 
 enum Mode { MODE_FWD = 0, MODE_DX = 1, MODE_DW = 2 };
@@ -447,7 +480,6 @@ int make_plan(const lmv_linear_problem* p, int nproblems, int N, int K, int act,
   GemmArgs& g = pl->g;
   g = GemmArgs{};
   g.nprob = nproblems; g.act = act;
-  { const char* e = getenv("LMV_GEMM_DEBUG"); if (e) g.act |= atoi(e); }
   int out_cols;
   switch (mode) {
     case MODE_FWD: g.N = N; g.lda = K; g.ldb = K; g.ldc = N; out_cols = N; break;
@@ -488,7 +520,8 @@ int make_plan(const lmv_linear_problem* p, int nproblems, int N, int K, int act,
     static const int min_tiles = [] { const char* e = getenv("LMV_GEMM_BK32_TILES"); return e ? atoi(e) : 512; }();
     if (tiles128 >= min_tiles) bk = 32;
   }
-  static const int dw_bk = [] { const char* e = getenv("LMV_DW_BK"); return e ? atoi(e) : 64; }();   // A/B testing
+  // dW: 32-deep as well (3 workgroups per CU; tools/dw_sweep.py: best or within 5 % of best on every layer shape)
+  const int dw_bk = [] { const char* e = getenv("LMV_DW_BK"); return e ? atoi(e) : 32; }();   // A/B testing (re-read per call)
   if (bf && all32 && mode == MODE_DW && dw_bk == 32) bk = 32;
   if (force_bk == 32 && all32) bk = 32;
   if (force_bk == 64 && all64) bk = 64;
@@ -514,32 +547,47 @@ int make_plan(const lmv_linear_problem* p, int nproblems, int N, int K, int act,
   }
   const int bm = tile == TILE_128 ? 128 : 256, bn = tile == TILE_256 ? 256 : 128;
   g.tiles_n = (out_cols + bn - 1) / bn;
+  // dW of two problems that accumulate into the same dW / db (x and c rows through shared weights): one reduction
+  g.concat = mode == MODE_DW && nproblems == 2 && p[0].out == p[1].out && p[0].bias_grad == p[1].bias_grad;
   int total = 0;
   for (int i = 0; i < nproblems; ++i) {
     Problem& P = g.p[i];
     P.tiles_m = (P.M + bm - 1) / bm;
-    P.tile_begin = total;
-    total += P.tiles_m * g.tiles_n;
+    P.tile_begin = (g.concat && i == 1) ? 0 : total;
+    if (!(g.concat && i == 1)) total += P.tiles_m * g.tiles_n;
   }
-  int max_kt = 1;
-  for (int i = 0; i < nproblems; ++i) { const int kt = (g.p[i].Kred + bk - 1) / bk; if (kt > max_kt) max_kt = kt; }
+  int max_kt = 1, sum_kt = 0;
+  for (int i = 0; i < nproblems; ++i) { const int kt = (g.p[i].Kred + bk - 1) / bk; if (kt > max_kt) max_kt = kt; sum_kt += kt; }
+  if (g.concat) max_kt = sum_kt;
   int splits = 1;
   g.kt_per_split = max_kt;
+  g.ntiles = total; g.nsplits = 1;
   pl->ws_bytes = 0;
   pl->nsplit[0] = pl->nsplit[1] = 1;
   if (mode == MODE_DW) {
-    // split the token reduction so the launch fills the chip (each split ends in a plain store of its partial tile)
-    static const int target = [] { const char* e = getenv("LMV_DW_TARGET_BLOCKS"); return e ? atoi(e) : 768; }();
-    const int tgt = tile == TILE_128 ? target : target / 2;      // 8-wave workgroups: one per CU
-    splits = (tgt + total - 1) / total;
+    // Split the token reduction so that ONE generation of workgroups fills the chip: slots = CUs x resident workgroups
+    // (3 at 32-deep k-tiles, 2 at 64-deep); each split ends in a plain store of its partial tile.
+    const int target = [] { const char* e = getenv("LMV_DW_TARGET_BLOCKS"); return e ? atoi(e) : 0; }();
+    int per_xcd = target > 0 ? target / 8 : 32 * (bk == 32 && dma ? 3 : 2);
+    if (tile != TILE_128) per_xcd /= 2;      // 8-wave workgroups
+    // The workgroups of one split run on one XCD (they share the token rows through its L2), so the split count is a
+    // multiple of 8 -- every XCD gets the same number -- or, when one split's tiles already overfill an XCD, 4 / 2 / 1
+    // with the tiles of a split divided over the XCDs that share it.
     const int max_splits = (max_kt + 7) / 8;   // at least 8 k-tiles per split
-    if (splits > max_splits) splits = max_splits;
-    if (splits < 1) splits = 1;
+    if (per_xcd >= total && max_splits >= 8) {
+      splits = 8 * (per_xcd / total);
+      if (splits > max_splits) splits = max_splits / 8 * 8;
+    } else {
+      splits = 4;
+      while (splits > 1 && ((int64_t)total * splits > 8 * (int64_t)per_xcd || splits > max_splits)) splits /= 2;
+    }
     g.kt_per_split = (max_kt + splits - 1) / splits;
-    splits = (max_kt + g.kt_per_split - 1) / g.kt_per_split;
+    g.nsplits = splits;
+    splits = (max_kt + g.kt_per_split - 1) / g.kt_per_split;      // non-empty splits (= slabs)
     int slabs = 0;
     for (int i = 0; i < nproblems; ++i) {
-      const int kt = (g.p[i].Kred + bk - 1) / bk;
+      if (g.concat && i == 1) { pl->nsplit[1] = 0; g.slab_base[1] = 0; break; }
+      const int kt = g.concat ? max_kt : (g.p[i].Kred + bk - 1) / bk;
       pl->nsplit[i] = (kt + g.kt_per_split - 1) / g.kt_per_split;
       g.slab_base[i] = slabs;
       slabs += pl->nsplit[i];
@@ -589,7 +637,8 @@ int launch(const lmv_linear_problem* p, int nproblems, int N, int K, int act, in
     g.ws = reinterpret_cast<float*>(ws);
   }
   const bool bf = dtype == LMV_BF16;
-  dim3 grid(pl.total, pl.splits);
+  dim3 grid(pl.total);
+  if (mode == MODE_DW) grid.x = g.nsplits >= 8 ? pl.total * g.nsplits : 8 * ((pl.total + 8 / g.nsplits - 1) / (8 / g.nsplits));
   hipStream_t st = (hipStream_t)stream;
   int rc;
   if (mode == MODE_FWD) rc = launch_mode<false, false, false>(pl, grid, bf, st);
@@ -605,9 +654,15 @@ int launch(const lmv_linear_problem* p, int nproblems, int N, int K, int act, in
       const int nslabs = shared ? pl.nsplit[0] + pl.nsplit[1] : pl.nsplit[i];
       if (shared && p[0].bias_grad != p[1].bias_grad) LMV_FAIL(LMV_ERR_SHAPE, "linear_dw: problems sharing dW must share db");
       const float* base = g.ws + (int64_t)g.slab_base[i] * g.slab_stride;
-      int blocks = (int)((nw / 4 + 255) / 256); if (blocks > 1024) blocks = 1024;
-      hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, st, base, nslabs, g.slab_stride, reinterpret_cast<float*>(p[i].out), nw,
-                         p[i].bias_grad, N);
+      const int64_t n4 = (nw + (p[i].bias_grad ? N : 0)) / 4;
+      float* outw = reinterpret_cast<float*>(p[i].out);
+      // slab lanes: enough blocks to fill the chip, and at most ~32 serial slab reads per thread
+      int sl = 1;
+      while (sl < 16 && (n4 * sl < 256 * 256 || nslabs > 32 * sl) && nslabs >= 4 * sl) sl *= 4;
+      const int blocks = (int)((n4 * sl + 255) / 256);
+      if (sl == 1) hipLaunchKernelGGL(splitk_reduce_kernel<1>, dim3(blocks), dim3(256), 0, st, base, nslabs, g.slab_stride, outw, nw, p[i].bias_grad, N);
+      else if (sl == 4) hipLaunchKernelGGL(splitk_reduce_kernel<4>, dim3(blocks), dim3(256), 0, st, base, nslabs, g.slab_stride, outw, nw, p[i].bias_grad, N);
+      else hipLaunchKernelGGL(splitk_reduce_kernel<16>, dim3(blocks), dim3(256), 0, st, base, nslabs, g.slab_stride, outw, nw, p[i].bias_grad, N);
     }
     LMV_CHECK_LAUNCH("linear_dw reduce");
   }

@@ -33,13 +33,15 @@ static inline bool lmv_aligned16(const void* p) { return (((uintptr_t)p) & 15u) 
 
 // ---- bf16 <-> f32 ---------------------------------------------------------------------------
 __device__ __forceinline__ float bf2f(bf16_t v) { return __uint_as_float(((unsigned)v) << 16); }
-__device__ __forceinline__ bf16_t f2bf(float f) {
-  unsigned u = __float_as_uint(f);
-  if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40u);  // quiet NaN
-  u += 0x7fffu + ((u >> 16) & 1u);                                            // round to nearest even
-  return (bf16_t)(u >> 16);
+// f32 -> bf16, round to nearest even, NaN stays NaN: ONE v_cvt_pk_bf16_f32 per pair on gfx950 (the integer recipe with
+// its NaN branch costs ~8 VALU ops and an exec-mask branch per element)
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+__device__ __forceinline__ unsigned pack_bf2(float lo, float hi) {
+  const f32x2_t f = {lo, hi};
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(f, bf16x2_t));
 }
-__device__ __forceinline__ unsigned pack_bf2(float lo, float hi) { return (unsigned)f2bf(lo) | ((unsigned)f2bf(hi) << 16); }
+__device__ __forceinline__ bf16_t f2bf(float f) { return (bf16_t)(pack_bf2(f, 0.f) & 0xffffu); }
 
 template <typename T> struct DT;
 template <> struct DT<float> {

@@ -8,8 +8,10 @@
 //
 // One launch covers up to TWO row segments that share (gamma, beta): the image-token matrix and the
 // meta-token matrix of a block are normalised by the same LayerNorm (models/lemevit.py:560-564).
-// Backward: dgamma / dbeta are reduced registers -> wavefront shuffles -> LDS -> one partial row per
-// workgroup; a second tiny kernel sums the partial rows (no global atomics: they serialise across XCDs).
+// Backward: dgamma / dbeta are reduced registers -> LDS transpose (fixed-order sums, no atomics or shuffles: the
+// shuffle + LDS-atomic version cost 10-20 us per launch) -> one partial row per workgroup; a second tiny kernel
+// sums the partial rows (no global atomics: they serialise across XCDs).
+#include <stdlib.h>
 #include "common.h"
 
 namespace {
@@ -37,48 +39,52 @@ __global__ __launch_bounds__(TPB) void ln_fwd_kernel(const Segs<T> sg, const flo
   const int lpr = 1 << lpr_log2, nch = C / EPC;
   const int lir = threadIdx.x & (lpr - 1), rib = threadIdx.x >> lpr_log2, rpb = TPB >> lpr_log2;
   const float invC = 1.f / (float)C;
+  // Chunk indices past the row are CLAMPED so every load is unconditional (a bounds branch around each load costs one
+  // L2 round trip per load); `vm` zeroes what the clamped lanes would add to the sums, and only the stores are guarded.
+  float gm[NIT][EPC], bt[NIT][EPC], vm[NIT];
+  int chs[NIT];
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    const int ch = lir + it * lpr;
+    chs[it] = min(ch, nch - 1);
+    vm[it] = (ch < nch) ? 1.f : 0.f;
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) { gm[it][e] = gamma[chs[it] * EPC + e]; bt[it][e] = beta[chs[it] * EPC + e]; }
+  }
   for (int64_t row = (int64_t)blockIdx.x * rpb + rib; row < sg.total; row += (int64_t)gridDim.x * rpb) {
     const int s = row >= sg.rows0;
     const int64_t lr = row - (s ? sg.rows0 : 0);
     const T* xr = (s ? sg.x[1] : sg.x[0]) + lr * C;
+    uint4 raw[NIT];
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) raw[it] = *reinterpret_cast<const uint4*>(xr + chs[it] * EPC);
     float v[NIT][EPC];
     float sum = 0.f;
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
-      const int ch = lir + it * lpr;
-      if (ch < nch) {
-        chunk_to_f<T>(*reinterpret_cast<const uint4*>(xr + ch * EPC), v[it]);
+      chunk_to_f<T>(raw[it], v[it]);
+      float t = 0.f;
 #pragma unroll
-        for (int e = 0; e < EPC; ++e) sum += v[it][e];
-      }
+      for (int e = 0; e < EPC; ++e) t += v[it][e];
+      sum += t * vm[it];
     }
     const float mean = group_sum(sum, lpr) * invC;
     float q = 0.f;
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
-      if (lir + it * lpr < nch) {
+      float t = 0.f;
 #pragma unroll
-        for (int e = 0; e < EPC; ++e) { const float d = v[it][e] - mean; q += d * d; }
-      }
+      for (int e = 0; e < EPC; ++e) { const float d = v[it][e] - mean; t += d * d; }
+      q += t * vm[it];
     }
     const float rstd = 1.f / sqrtf(group_sum(q, lpr) * invC + eps);
     T* yr = (s ? sg.y[1] : sg.y[0]) + lr * C;
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
-      const int ch = lir + it * lpr;
-      if (ch < nch) {
-        float o[EPC];
+      float o[EPC];
 #pragma unroll
-        for (int e = 0; e < EPC; e += 4) {
-          const float4 g4 = *reinterpret_cast<const float4*>(gamma + ch * EPC + e);
-          const float4 b4 = *reinterpret_cast<const float4*>(beta + ch * EPC + e);
-          o[e + 0] = (v[it][e + 0] - mean) * rstd * g4.x + b4.x;
-          o[e + 1] = (v[it][e + 1] - mean) * rstd * g4.y + b4.y;
-          o[e + 2] = (v[it][e + 2] - mean) * rstd * g4.z + b4.z;
-          o[e + 3] = (v[it][e + 3] - mean) * rstd * g4.w + b4.w;
-        }
-        *reinterpret_cast<uint4*>(yr + ch * EPC) = f_to_chunk<T>(o);
-      }
+      for (int e = 0; e < EPC; ++e) o[e] = (v[it][e] - mean) * rstd * gm[it][e] + bt[it][e];
+      if (lir + it * lpr < nch) *reinterpret_cast<uint4*>(yr + chs[it] * EPC) = f_to_chunk<T>(o);
     }
     float* st = s ? sg.stats[1] : sg.stats[0];
     if (st && lir == 0) { st[lr * 2] = mean; st[lr * 2 + 1] = rstd; }
@@ -88,17 +94,19 @@ __global__ __launch_bounds__(TPB) void ln_fwd_kernel(const Segs<T> sg, const flo
 template <typename T, int NIT>
 __global__ __launch_bounds__(TPB) void ln_bwd_kernel(const Segs<T> sg, const float* __restrict__ gamma, float* __restrict__ partial, int C, int lpr_log2) {
   constexpr int EPC = DT<T>::EPC;
-  __shared__ float s_dg[BWD_MAXC], s_db[BWD_MAXC];
+  __shared__ __attribute__((aligned(16))) float red[TPB * 2 * EPC];
   const int lpr = 1 << lpr_log2, nch = C / EPC;
   const int lir = threadIdx.x & (lpr - 1), rib = threadIdx.x >> lpr_log2, rpb = TPB >> lpr_log2;
   const float invC = 1.f / (float)C;
-  for (int c = threadIdx.x; c < C; c += TPB) { s_dg[c] = 0.f; s_db[c] = 0.f; }
-  float adg[NIT][EPC], adb[NIT][EPC], gm[NIT][EPC];
+  float adg[NIT][EPC], adb[NIT][EPC], gm[NIT][EPC], vm[NIT];
+  int chs[NIT];
 #pragma unroll
   for (int it = 0; it < NIT; ++it) {
     const int ch = lir + it * lpr;
+    chs[it] = min(ch, nch - 1);                    // clamped: all loads are unconditional (see ln_fwd_kernel)
+    vm[it] = (ch < nch) ? 1.f : 0.f;
 #pragma unroll
-    for (int e = 0; e < EPC; ++e) { adg[it][e] = 0.f; adb[it][e] = 0.f; gm[it][e] = (ch < nch) ? gamma[ch * EPC + e] : 0.f; }
+    for (int e = 0; e < EPC; ++e) { adg[it][e] = 0.f; adb[it][e] = 0.f; gm[it][e] = gamma[chs[it] * EPC + e]; }
   }
   for (int64_t row = (int64_t)blockIdx.x * rpb + rib; row < sg.total; row += (int64_t)gridDim.x * rpb) {
     const int s = row >= sg.rows0;
@@ -109,59 +117,69 @@ __global__ __launch_bounds__(TPB) void ln_bwd_kernel(const Segs<T> sg, const flo
     const T* drp = s ? sg.dres[1] : sg.dres[0];
     T* dxr = (s ? sg.dx[1] : sg.dx[0]) + lr * C;
     const float mean = st[lr * 2], rstd = st[lr * 2 + 1];
+    uint4 rx[NIT], rdy[NIT], rres[NIT];
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      rx[it] = *reinterpret_cast<const uint4*>(xr + chs[it] * EPC);
+      rdy[it] = *reinterpret_cast<const uint4*>(dyr + chs[it] * EPC);
+    }
+    if (drp) {
+#pragma unroll
+      for (int it = 0; it < NIT; ++it) rres[it] = *reinterpret_cast<const uint4*>(drp + lr * C + chs[it] * EPC);
+    }
     float xh[NIT][EPC], g[NIT][EPC];
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
-      const int ch = lir + it * lpr;
-      if (ch < nch) {
-        float xv[EPC], dv[EPC];
-        chunk_to_f<T>(*reinterpret_cast<const uint4*>(xr + ch * EPC), xv);
-        chunk_to_f<T>(*reinterpret_cast<const uint4*>(dyr + ch * EPC), dv);
+      float xv[EPC], dv[EPC];
+      chunk_to_f<T>(rx[it], xv);
+      chunk_to_f<T>(rdy[it], dv);
 #pragma unroll
-        for (int e = 0; e < EPC; ++e) {
-          xh[it][e] = (xv[e] - mean) * rstd;
-          g[it][e] = dv[e] * gm[it][e];
-          s1 += g[it][e]; s2 += g[it][e] * xh[it][e];
-          adg[it][e] += dv[e] * xh[it][e]; adb[it][e] += dv[e];
-        }
+      for (int e = 0; e < EPC; ++e) {
+        dv[e] *= vm[it];
+        xh[it][e] = (xv[e] - mean) * rstd;
+        g[it][e] = dv[e] * gm[it][e];
+        s1 += g[it][e]; s2 += g[it][e] * xh[it][e];
+        adg[it][e] += dv[e] * xh[it][e]; adb[it][e] += dv[e];
       }
     }
     s1 = group_sum(s1, lpr) * invC; s2 = group_sum(s2, lpr) * invC;
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
-      const int ch = lir + it * lpr;
-      if (ch < nch) {
-        float o[EPC];
+      float o[EPC];
 #pragma unroll
-        for (int e = 0; e < EPC; ++e) o[e] = rstd * (g[it][e] - s1 - xh[it][e] * s2);
-        if (drp) {
-          float r[EPC];
-          chunk_to_f<T>(*reinterpret_cast<const uint4*>(drp + lr * C + ch * EPC), r);
+      for (int e = 0; e < EPC; ++e) o[e] = rstd * (g[it][e] - s1 - xh[it][e] * s2);
+      if (drp) {
+        float r[EPC];
+        chunk_to_f<T>(rres[it], r);
 #pragma unroll
-          for (int e = 0; e < EPC; ++e) o[e] += r[e];
-        }
-        *reinterpret_cast<uint4*>(dxr + ch * EPC) = f_to_chunk<T>(o);
+        for (int e = 0; e < EPC; ++e) o[e] += r[e];
       }
+      if (lir + it * lpr < nch) *reinterpret_cast<uint4*>(dxr + chs[it] * EPC) = f_to_chunk<T>(o);
     }
   }
-  __syncthreads();
-  // column sums: first across the row groups of this wavefront (lanes with equal `lir`), then one LDS add per wave
+  // Column sums over the row groups of this workgroup, one chunk slot (`it`) at a time: every thread drops its
+  // 2 x EPC sums into LDS as [row group][lane in row][dg | db]; output j of the slot is then the sum of `rpb` floats
+  // a fixed stride apart (consecutive threads -> consecutive banks).  No atomics, no shuffles, fixed order.
+  float* prow = partial + (int64_t)blockIdx.x * 2 * C;
+  const int nout = lpr * 2 * EPC;
 #pragma unroll
   for (int it = 0; it < NIT; ++it) {
-    const int ch = lir + it * lpr;
+    __syncthreads();
+    float* w = red + threadIdx.x * (2 * EPC);
 #pragma unroll
-    for (int e = 0; e < EPC; ++e) {
-      float a = adg[it][e], b = adb[it][e];
-#pragma unroll
-      for (int o = 32; o > 0; o >>= 1)
-        if (o >= lpr) { a += __shfl_xor(a, o, 64); b += __shfl_xor(b, o, 64); }
-      if ((threadIdx.x & 63) < lpr && ch < nch) { atomicAdd(&s_dg[ch * EPC + e], a); atomicAdd(&s_db[ch * EPC + e], b); }
+    for (int e = 0; e < EPC; e += 4) {
+      *reinterpret_cast<float4*>(w + e) = make_float4(adg[it][e], adg[it][e + 1], adg[it][e + 2], adg[it][e + 3]);
+      *reinterpret_cast<float4*>(w + EPC + e) = make_float4(adb[it][e], adb[it][e + 1], adb[it][e + 2], adb[it][e + 3]);
+    }
+    __syncthreads();
+    for (int j = threadIdx.x; j < nout; j += TPB) {
+      float s = 0.f;
+      for (int r = 0; r < rpb; ++r) s += red[r * nout + j];
+      const int l = j / (2 * EPC), k = j - l * (2 * EPC), ch = l + it * lpr;
+      if (ch < nch) prow[(k < EPC ? 0 : C - EPC) + ch * EPC + k] = s;
     }
   }
-  __syncthreads();
-  float* prow = partial + (int64_t)blockIdx.x * 2 * C;
-  for (int c = threadIdx.x; c < C; c += TPB) { prow[c] = s_dg[c]; prow[C + c] = s_db[c]; }
 }
 
 // lanes per row (log2) and iterations for a row of `nch` 16-byte chunks
@@ -181,8 +199,10 @@ inline bool pick_geometry(int nch, int max_it, int* lpr_log2, int* nit) {
 
 inline int bwd_blocks(int64_t rows, int l2) {
   const int rpb = TPB >> l2;
-  int64_t blocks = (rows + 2 * rpb - 1) / (2 * rpb);           // >= 2 rows per row group
-  return (int)(blocks > 512 ? 512 : (blocks < 1 ? 1 : blocks));
+  static const int cap = [] { const char* e = getenv("LMV_LN_BWD_BLOCKS"); const int v = e ? atoi(e) : 0; return v > 0 && v <= 2048 ? v : 512; }();
+  static const int minrows = [] { const char* e = getenv("LMV_LN_BWD_MINROWS"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 2; }();
+  int64_t blocks = (rows + minrows * rpb - 1) / (minrows * rpb);           // >= 2 rows per row group
+  return (int)(blocks > cap ? cap : (blocks < 1 ? 1 : blocks));
 }
 
 template <typename T>
@@ -260,7 +280,7 @@ extern "C" int lmv_layernorm_fwd(const lmv_ln_segment* seg, int nseg, const floa
 
 extern "C" size_t lmv_layernorm_bwd_workspace_bytes(int64_t total_rows, int C, int dtype) {
   if (total_rows <= 0 || C <= 0) return 0;
-  return (size_t)512 * 2 * C * sizeof(float);     // upper bound: at most 512 workgroups
+  return (size_t)2048 * 2 * C * sizeof(float);     // upper bound: at most 2048 workgroups
 }
 
 extern "C" int lmv_layernorm_bwd(const lmv_ln_segment* seg, int nseg, const float* gamma, float* dgamma, float* dbeta, int C,

@@ -1,5 +1,5 @@
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out/cp
-rocprofv3 --kernel-trace -d gpurun_out/cp -o t -- python tools/conv_probe.py > gpurun_out/cp/log.txt 2>&1
+rocprofv3 --kernel-trace -d gpurun_out/cp -o t -- python $1 > gpurun_out/cp/log.txt 2>&1
 DB=$(find gpurun_out/cp -name "*.db" | head -1)
 python - <<PY
 import sqlite3,re

@@ -416,9 +416,10 @@ int bwd_impl(const lmv_attn_desc* d, void* ws, size_t ws_bytes, hipStream_t st) 
   float* acc0 = (float*)((char*)ws + delta_bytes);
   float* acc1 = acc0 + acc_elems;
   const int64_t nd = (int64_t)d->B * d->H * d->Lq;
-  hipLaunchKernelGGL((bwd_delta_kernel<T>), dim3((unsigned)((nd + 255) / 256)), dim3(256), 0, st, a, delta);
+  // the bf16 MFMA paths compute delta = rowsum(dO * O) inside their own kernels
   if (sizeof(T) == 2 && lmv_attn_mfma_supported(a)) return lmv_attn_mfma_bwd(a, delta, acc0, st);
-  if (sizeof(T) == 2 && lmv_attn_mfma_fewq_supported(a)) return lmv_attn_mfma_fewq_bwd(a, delta, acc0, st);
+  if (sizeof(T) == 2 && lmv_attn_mfma_fewq_supported(a)) return lmv_attn_mfma_fewq_bwd(a, acc0, st);
+  hipLaunchKernelGGL((bwd_delta_kernel<T>), dim3((unsigned)((nd + 255) / 256)), dim3(256), 0, st, a, delta);
   const dim3 gk((d->Lk + QB - 1) / QB, d->H, d->B), gq((d->Lq + QB - 1) / QB, d->H, d->B);
   if (few_q(d->Lq, d->Lk)) {
     if (hipMemsetAsync(acc0, 0, acc_elems * sizeof(float), st) != hipSuccess) LMV_FAIL(LMV_ERR_LAUNCH, "attn_bwd: memset failed");

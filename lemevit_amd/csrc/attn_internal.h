@@ -13,9 +13,9 @@ struct AttnArgs {
 bool lmv_attn_mfma_supported(const AttnArgs& a);          // bf16, Lk <= 224
 size_t lmv_attn_mfma_bwd_acc_bytes(const AttnArgs& a);    // fp32 scratch for split query ranges
 int lmv_attn_mfma_fwd(const AttnArgs& a, hipStream_t st);
-int lmv_attn_mfma_bwd(const AttnArgs& a, const float* delta, float* acc, hipStream_t st);
+int lmv_attn_mfma_bwd(const AttnArgs& a, float* delta, float* acc, hipStream_t st);   // delta: B*H*Lq floats of scratch (written by the dQ kernel)
 // <= 16 queries over > 224 keys (bf16): split-key MFMA kernels
 bool lmv_attn_mfma_fewq_supported(const AttnArgs& a);
 int lmv_attn_mfma_fewq_nsplit(const AttnArgs& a);
 int lmv_attn_mfma_fewq_fwd(const AttnArgs& a, float* part, hipStream_t st);
-int lmv_attn_mfma_fewq_bwd(const AttnArgs& a, const float* delta, float* acc, hipStream_t st);
+int lmv_attn_mfma_fewq_bwd(const AttnArgs& a, float* acc, hipStream_t st);

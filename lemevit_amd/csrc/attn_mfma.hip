@@ -132,11 +132,12 @@ __global__ __launch_bounds__(256) void mfma_fwd_kernel(const AttnArgs a, int qt_
 // backward, dQ: one 16-query tile per wave iteration, loop over 32-key blocks
 // =============================================================================================
 template <int NKT>
-__global__ __launch_bounds__(256) void mfma_bwd_dq_kernel(const AttnArgs a, const float* __restrict__ delta, int qt_per_block) {
+__global__ __launch_bounds__(256) void mfma_bwd_dq_kernel(const AttnArgs a, float* __restrict__ delta, int qt_per_block) {
   __shared__ __attribute__((aligned(16))) unsigned char sK[NKT * 16 * 64], sV[NKT * 16 * 64];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = blockIdx.y, b = blockIdx.z;
   const bf16_t* qb = reinterpret_cast<const bf16_t*>(a.q) + b * a.q_bs + h * D;
   const bf16_t* gb = reinterpret_cast<const bf16_t*>(a.d_o) + b * a.o_bs + h * D;
+  const bf16_t* ob = reinterpret_cast<const bf16_t*>(a.o) + b * a.o_bs + h * D;
   bf16_t* dqb = reinterpret_cast<bf16_t*>(a.dq) + b * a.q_bs + h * D;
   stage_rows<256>(sK, reinterpret_cast<const bf16_t*>(a.k) + b * a.k_bs + h * D, a.k_rs, 0, NKT * 16, a.Lk, tid);
   stage_rows<256>(sV, reinterpret_cast<const bf16_t*>(a.v) + b * a.v_bs + h * D, a.v_rs, 0, NKT * 16, a.Lk, tid);
@@ -150,7 +151,14 @@ __global__ __launch_bounds__(256) void mfma_bwd_dq_kernel(const AttnArgs a, cons
     const bool vq = q < a.Lq;
     const bf16x8_t qf = load_frag_global(qb, a.q_rs, q, a.Lq, lane);
     const bf16x8_t gf = load_frag_global(gb, a.o_rs, q, a.Lq, lane);
-    const float lse = vq ? a.lse[bh + q] : 0.f, dl = vq ? delta[bh + q] : 0.f;
+    const bf16x8_t of = load_frag_global(ob, a.o_rs, q, a.Lq, lane);
+    const float lse = vq ? a.lse[bh + q] : 0.f;
+    // delta = rowsum(dO * O): the lane's 8 d-values, then the 4 lane groups of the query; kept for the dK / dV kernel
+    float dl = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) dl += (float)gf[j] * (float)of[j];
+    dl = group_sum4(dl);
+    if (vq && g == 0) delta[bh + q] = dl;
     f32x4_t dq0 = {0.f, 0.f, 0.f, 0.f}, dq1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int kb2 = 0; kb2 < NKT / 2; ++kb2) {
@@ -370,7 +378,7 @@ __global__ __launch_bounds__(256) void mfma_fwd_split_kernel(const AttnArgs a, f
 }
 
 // backward of the same shape, RKB = 64 keys per wave: grid (ceil(ceil(Lk / 64) / 4), H, B)
-__global__ __launch_bounds__(256) void mfma_bwd_fewq_kernel(const AttnArgs a, const float* __restrict__ delta, float* __restrict__ acc_q) {
+__global__ __launch_bounds__(256) void mfma_bwd_fewq_kernel(const AttnArgs a, float* __restrict__ acc_q) {
   __shared__ __attribute__((aligned(16))) unsigned char sK[4 * RKB * 64], sV[4 * RKB * 64];
   __shared__ __attribute__((aligned(16))) unsigned char sQ[32 * 64], sG[32 * 64];
   __shared__ __attribute__((aligned(16))) float sL[32], sDl[32], sRed[4][2][64][4];
@@ -388,7 +396,20 @@ __global__ __launch_bounds__(256) void mfma_bwd_fewq_kernel(const AttnArgs a, co
   if (tid < 32) {
     const bool ok = tid < a.Lq;
     sL[tid] = ok ? a.lse[bh + tid] : 1e30f;     // exp(s - 1e30) = 0 masks the padded queries
-    sDl[tid] = ok ? delta[bh + tid] : 0.f;
+    float dl = 0.f;                             // delta = rowsum(dO * O) of query `tid`
+    if (ok) {
+      const bf16_t* gp = reinterpret_cast<const bf16_t*>(a.d_o) + b * a.o_bs + (int64_t)tid * a.o_rs + h * D;
+      const bf16_t* op = reinterpret_cast<const bf16_t*>(a.o) + b * a.o_bs + (int64_t)tid * a.o_rs + h * D;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        float gv[8], ov[8];
+        chunk_to_f<bf16_t>(*reinterpret_cast<const uint4*>(gp + c * 8), gv);
+        chunk_to_f<bf16_t>(*reinterpret_cast<const uint4*>(op + c * 8), ov);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) dl += gv[j] * ov[j];
+      }
+    }
+    sDl[tid] = dl;
   }
   __syncthreads();
   // ---- orientation D[q][key]: dK, dV of this wave's keys (query rows 0..31, rows >= Lq are zero / masked) --------
@@ -488,11 +509,11 @@ int lmv_attn_mfma_fewq_fwd(const AttnArgs& a, float* part, hipStream_t st) {
 }
 
 // acc: >= B*H*16*32 floats of scratch for dQ
-int lmv_attn_mfma_fewq_bwd(const AttnArgs& a, const float* delta, float* acc, hipStream_t st) {
+int lmv_attn_mfma_fewq_bwd(const AttnArgs& a, float* acc, hipStream_t st) {
   const size_t n = (size_t)a.B * a.H * 16 * D;
   if (hipMemsetAsync(acc, 0, n * sizeof(float), st) != hipSuccess) LMV_FAIL(LMV_ERR_LAUNCH, "attn_mfma_fewq_bwd: memset failed");
   const int nr = (a.Lk + RKB - 1) / RKB;
-  hipLaunchKernelGGL(mfma_bwd_fewq_kernel, dim3((nr + 3) / 4, a.H, a.B), dim3(256), 0, st, a, delta, acc);
+  hipLaunchKernelGGL(mfma_bwd_fewq_kernel, dim3((nr + 3) / 4, a.H, a.B), dim3(256), 0, st, a, acc);
   const unsigned tot = (unsigned)a.B * a.H * a.Lq * D;
   hipLaunchKernelGGL(scatter_bf16_kernel, dim3((tot + 255) / 256), dim3(256), 0, st, (const float*)acc, (bf16_t*)a.dq, a.q_bs, a.q_rs, a.B, a.H, a.Lq, 16);
   LMV_CHECK_LAUNCH("attn_mfma_fewq_bwd");
@@ -517,7 +538,7 @@ int lmv_attn_mfma_fwd(const AttnArgs& a, hipStream_t st) {
 }
 
 // acc: lmv_attn_mfma_bwd_acc_bytes() of fp32 scratch (only touched when the query range is split)
-int lmv_attn_mfma_bwd(const AttnArgs& a, const float* delta, float* acc, hipStream_t st) {
+int lmv_attn_mfma_bwd(const AttnArgs& a, float* delta, float* acc, hipStream_t st) {
   const int per = qt_per_block_for(a), nqt = (a.Lq + 15) / 16, nkt = nkt_for(a.Lk);
   {
     dim3 grid((nqt + per - 1) / per, a.H, a.B), block(256);

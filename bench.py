@@ -57,7 +57,7 @@ class GemmTimer:
     """Brackets every forward Linear launch (lemevit_amd.ops.linear_fwd) with HIP events on the launch stream."""
 
     def __init__(self):
-        self.events, self.flops, self.enabled = [], [], False
+        self.events, self.flops, self.bytes, self.enabled = [], [], [], False
 
     def install(self):
         from lemevit_amd import ops
@@ -73,6 +73,8 @@ class GemmTimer:
             e.record()
             timer.events.append((s, e))
             timer.flops.append(2.0 * N * K * sum(p.rows for p in probs))
+            # algorithmic HBM bytes of the launch: A in, C out (+ pre-activation copy, + residual in), W and bias once (bf16 = 2 B)
+            timer.bytes.append(sum(2.0 * p.rows * (K + N * (1 + (p.out_pre is not None) + (p.res is not None))) for p in probs) + 2.0 * N * K + 4.0 * N)
 
         ops.linear_fwd = timed
         import lemevit_amd.blocks as blocks
@@ -86,7 +88,7 @@ class GemmTimer:
         ms = sum(s.elapsed_time(e) for s, e in self.events)
         fl = sum(self.flops)
         return dict(launches=len(self.events), total_ms=ms, avg_us=1e3 * ms / len(self.events), tflops=fl / (ms * 1e-3) / 1e12,
-                    gflop_per_launch=fl / len(self.events) / 1e9)
+                    gflop_per_launch=fl / len(self.events) / 1e9, mbytes_per_launch=sum(self.bytes) / len(self.events) / 1e6)
 
 
 def cpu_baseline(model_name: str, img: int, mode: str):
@@ -224,8 +226,17 @@ def main():
         g = timer.summary()
         roof = None
         if g is not None:
+            # HBM bytes per launch of the same kernel from the PMC passes committed under profiles/ (tools/pmc_traffic.sh: FETCH_SIZE x 2
+            # per the gfx950 correction + WRITE_SIZE, separate passes); only quoted for the workload it was collected on
+            traffic, traffic_src = None, None
+            pmc = os.path.join(ROOT, "profiles", "r01_gemm_fwd_pmc_traffic.json")
+            if train and args.model == "lemevit_base" and args.img == 224 and args.batch == 128 and os.path.exists(pmc):
+                with open(pmc) as f:
+                    traffic = round(json.load(f)["traffic_bytes_per_launch"] / 1e6, 2)
+                traffic_src = "profiles/r01_gemm_fwd_pmc_traffic.json (MB per launch, rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command)"
             roof = dict(bound="mfma", achieved=round(g["tflops"], 2), peak=PEAK_BF16_TFLOPS, unit="TFLOP/s", frac=round(g["tflops"] / PEAK_BF16_TFLOPS, 4),
-                        traffic=None, kernel="gemm_kernel<bf16,NT> (Linear forward)", measured=kernel_timing_note, launches=g["launches"], avg_launch_us=round(g["avg_us"], 2),
+                        traffic=traffic, traffic_unit="MB/launch", traffic_source=traffic_src, algorithmic_mbytes_per_launch=round(g["mbytes_per_launch"], 2),
+                        kernel="gemm_kernel<bf16,NT> (Linear forward)", measured=kernel_timing_note, launches=g["launches"], avg_launch_us=round(g["avg_us"], 2),
                         gflop_per_launch=round(g["gflop_per_launch"], 3))
         line = {
             "metric": f"images/sec {pretty} {args.img}^2 bf16 " + ("fwd+bwd" if train else "fwd"),

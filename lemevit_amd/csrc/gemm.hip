@@ -11,12 +11,13 @@
 //
 // Workgroup tile (template Cfg): 128x128 (4 waves), 256x128 or 256x256 (8 waves); every wave owns 64x64 or 128x64
 // outputs = WM x 4 MFMA tiles (v_mfma_f32_16x16x32_bf16; exact-fp32 mode: v_mfma_f32_16x16x4_f32).  With K = 96..512
-// these GEMMs are bound by L2 -> CU operand traffic (measured 7.3 TB/s, PMC: MFMA busy 21 %, zero LDS bank
-// conflicts at 128x128 = 64 FLOP per operand byte), so the host picks the LARGEST tile the problem fills the chip
-// with: 256x128 is 85 FLOP/B, 256x256 is 128 FLOP/B.
+// a workgroup spends as long in launch + first-load latency + epilogue + store drain as in its k-loop, and only OTHER
+// resident workgroups hide that, so occupancy decides: 128x128 tiles over 32-deep k-tiles (32 KB of LDS) under a
+// 128-register cap put 4 workgroups on a CU (3 for dW); the larger tiles and 64-deep k-tiles (2 per CU) lose on every
+// large layer shape of the model (make_plan; measurements in DESIGN.md 4.1).
 //
-// Operand tiles live in LDS as 128-row (or, transposed, 128-column) PANELS, double-buffered over k-tiles of 64
-// (bf16) / 32.  bf16 panels are filled by LDS-DMA (global_load_lds_dwordx4: wave-uniform LDS base + lane * 16, so
+// Operand tiles live in LDS as 128-row (or, transposed, 128-column) PANELS, double-buffered over k-tiles of 32 / 64
+// (bf16) or 32 (fp32).  bf16 panels are filled by LDS-DMA (global_load_lds_dwordx4: wave-uniform LDS base + lane * 16, so
 // the XOR swizzle is applied to the per-lane SOURCE address); fp32 and ragged-K problems use a register-staged
 // path (global -> VGPR -> ds_write) on the 128x128 tile.  The swizzles make the 16-byte fragment reads and the
 // transpose reads bank-conflict free (derivation in DESIGN.md; SQ_LDS_BANK_CONFLICT = 0 measured).
@@ -243,7 +244,7 @@ __device__ __forceinline__ void store_tile(unsigned char* smem, const f32x4_t (&
                                            int m0, int n0, int wm, int wn, int lane, int wave) {
   constexpr int EPC = DT<T>::EPC;
   constexpr int CPR = 64 / EPC;                 // output chunks per 64-column row
-  constexpr int RPP = REGION_BYTES >= 16384 ? 64 : 32;
+  constexpr int RPP = REGION_BYTES >= 16384 ? 64 : (REGION_BYTES >= 8192 ? 32 : 16);
   static_assert(REGION_BYTES >= RPP * 256 && (CF::WM * 16) % RPP == 0, "per-wave epilogue region too small");
   float* sT = reinterpret_cast<float*>(smem + wave * REGION_BYTES);
   T* outp = reinterpret_cast<T*>(PRE ? P.out_pre : P.out);
@@ -527,14 +528,13 @@ int make_plan(const lmv_linear_problem* p, int nproblems, int N, int K, int act,
   if (force_bk == 64 && all64) bk = 64;
   static const bool no_dma = getenv("LMV_GEMM_NO_DMA") != nullptr;     // A/B testing
   const bool dma = bf && !no_dma && (bk == 64 ? all64 : all32);
-  // Tile choice.  Measured on the LeMeViT shapes (K = 96..2048, tools/gemm_ablate.py): the k-loop alone runs at
-  // ~1 PFLOP/s, but with K this short HALF of a workgroup's life is its epilogue (writing the tile), and the only thing
-  // that hides it is another co-resident workgroup: 128x128 (64 KB LDS, 2 workgroups per CU) beats 256x128 and
-  // 256x256 (1 workgroup per CU) on every shape of the model, so it is the default; LMV_GEMM_TILE=-1 selects the
-  // larger tiles automatically (they win for long-K problems), 1 / 2 force them.
+  // Tile choice.  Measured on the LeMeViT shapes (K = 96..2048, tools/bench_kernels.py): 128x128 beats 256x128 and
+  // 256x256 on every shape of the model -- at 64-deep k-tiles because the large tiles leave one workgroup per CU, and at
+  // 32-deep k-tiles / 4 waves per SIMD (256x128 only) by a few per cent -- so it is the default; LMV_GEMM_TILE=-1 selects
+  // the larger tiles automatically for 64-deep problems (they win for long K), 1 / 2 force them.
   static const int force_tile = [] { const char* e = getenv("LMV_GEMM_TILE"); return e ? atoi(e) : 0; }();
   int tile = TILE_128;
-  if (dma && bk == 64) {
+  if (dma && (bk == 64 || (force_tile == TILE_256x128 && mode != MODE_DW))) {
     if (force_tile < 0) {
       auto tiles_of = [&](int bm, int bn) { int64_t t = 0; for (int i = 0; i < nproblems; ++i) t += (int64_t)((g.p[i].M + bm - 1) / bm) * ((out_cols + bn - 1) / bn); return t; };
       const int64_t need = (mode == MODE_DW) ? 48 : 200;      // dW multiplies its grid by the k-splits
@@ -620,7 +620,12 @@ int launch_mode(const Plan& pl, dim3 grid, bool bf, hipStream_t st) {
   if (!pl.dma) return pl.bk == 64 ? launch_one<bf16_t, ATR, BTR, SPLITK, 64, false, C128>(g, grid, st)
                                   : launch_one<bf16_t, ATR, BTR, SPLITK, 32, false, C128>(g, grid, st);
   // 32-deep k-tiles: 32 KB of LDS and (capped by MINW) <= 128 / 168 registers: 4 (fwd, dX) or 3 (dW) workgroups per CU
-  if (pl.bk == 32) return launch_one<bf16_t, ATR, BTR, SPLITK, 32, true, C128, SPLITK ? 3 : 4>(g, grid, st);
+  if (pl.bk == 32) {
+    if constexpr (!SPLITK) {
+      if (pl.tile == TILE_256x128) return launch_one<bf16_t, ATR, BTR, SPLITK, 32, true, C256x128, 4>(g, grid, st);
+    }
+    return launch_one<bf16_t, ATR, BTR, SPLITK, 32, true, C128, SPLITK ? 3 : 4>(g, grid, st);
+  }
   switch (pl.tile) {
     case TILE_256:     return launch_one<bf16_t, ATR, BTR, SPLITK, 64, true, C256>(g, grid, st);
     case TILE_256x128: return launch_one<bf16_t, ATR, BTR, SPLITK, 64, true, C256x128>(g, grid, st);

@@ -383,6 +383,7 @@ template <typename T>
 int fwd_impl(const lmv_attn_desc* d, void* ws, size_t ws_bytes, hipStream_t st) {
   const Args a = to_args(d);
   if (sizeof(T) == 2 && lmv_attn_mfma_supported(a)) return lmv_attn_mfma_fwd(a, st);
+  if (sizeof(T) == 2 && lmv_attn_mfma_long_supported(a)) return lmv_attn_mfma_long_fwd(a, st);
   if (sizeof(T) == 2 && lmv_attn_mfma_fewq_supported(a)) {
     const int nsplit = lmv_attn_mfma_fewq_nsplit(a);
     const size_t need = (size_t)d->B * d->H * nsplit * FQ * (D + 2) * sizeof(float);
@@ -418,6 +419,7 @@ int bwd_impl(const lmv_attn_desc* d, void* ws, size_t ws_bytes, hipStream_t st) 
   const int64_t nd = (int64_t)d->B * d->H * d->Lq;
   // the bf16 MFMA paths compute delta = rowsum(dO * O) inside their own kernels
   if (sizeof(T) == 2 && lmv_attn_mfma_supported(a)) return lmv_attn_mfma_bwd(a, delta, acc0, st);
+  if (sizeof(T) == 2 && lmv_attn_mfma_long_supported(a)) return lmv_attn_mfma_long_bwd(a, delta, st);
   if (sizeof(T) == 2 && lmv_attn_mfma_fewq_supported(a)) return lmv_attn_mfma_fewq_bwd(a, acc0, st);
   hipLaunchKernelGGL((bwd_delta_kernel<T>), dim3((unsigned)((nd + 255) / 256)), dim3(256), 0, st, a, delta);
   const dim3 gk((d->Lk + QB - 1) / QB, d->H, d->B), gq((d->Lq + QB - 1) / QB, d->H, d->B);

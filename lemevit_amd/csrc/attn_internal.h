@@ -19,3 +19,7 @@ bool lmv_attn_mfma_fewq_supported(const AttnArgs& a);
 int lmv_attn_mfma_fewq_nsplit(const AttnArgs& a);
 int lmv_attn_mfma_fewq_fwd(const AttnArgs& a, float* part, hipStream_t st);
 int lmv_attn_mfma_fewq_bwd(const AttnArgs& a, float* acc, hipStream_t st);
+// many queries over 225..640 keys (bf16): whole-row kernels with K / V of a (b, h) in dynamic LDS
+bool lmv_attn_mfma_long_supported(const AttnArgs& a);
+int lmv_attn_mfma_long_fwd(const AttnArgs& a, hipStream_t st);
+int lmv_attn_mfma_long_bwd(const AttnArgs& a, float* delta, hipStream_t st);

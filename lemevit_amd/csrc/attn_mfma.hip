@@ -484,6 +484,210 @@ __global__ __launch_bounds__(256) void mfma_bwd_fewq_kernel(const AttnArgs a, fl
   }
 }
 
+// =============================================================================================
+// Many queries x 225..640 keys (self-attention at 384^2: 576 + 16 tokens).  K and V of one (b, h) still fit in LDS
+// (<= 80 KB), so these are the whole-row kernels with run-time tile counts and dynamic LDS:
+//   forward: TWO passes over the key tiles (row maximum first, then exp / sum / PV with S recomputed) -- the score row
+//            no longer fits in registers, and a second S MFMA per tile is cheaper than an online-softmax rescale that
+//            needs two cross-lane-group shuffles per block;
+//   dQ:      the block loop of mfma_bwd_dq_kernel with a run-time bound;
+//   dK / dV: one workgroup per range of 14 key tiles, looping over query chunks staged in LDS (no atomics).
+// =============================================================================================
+constexpr int LONG_MAX_NKT = 40;
+
+__global__ __launch_bounds__(256) void mfma_fwd_long_kernel(const AttnArgs a, int qt_per_block, int nkt) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_long[];
+  unsigned char* sK = smem_long;
+  unsigned char* sV = smem_long + nkt * 1024;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = blockIdx.y, b = blockIdx.z;
+  const bf16_t* qb = reinterpret_cast<const bf16_t*>(a.q) + b * a.q_bs + h * D;
+  bf16_t* ob = reinterpret_cast<bf16_t*>(a.o) + b * a.o_bs + h * D;
+  stage_rows<256>(sK, reinterpret_cast<const bf16_t*>(a.k) + b * a.k_bs + h * D, a.k_rs, 0, nkt * 16, a.Lk, tid);
+  stage_rows<256>(sV, reinterpret_cast<const bf16_t*>(a.v) + b * a.v_bs + h * D, a.v_rs, 0, nkt * 16, a.Lk, tid);
+  __syncthreads();
+  const int nqt = (a.Lq + 15) >> 4;
+  const int qt_end = min(nqt, (int)(blockIdx.x + 1) * qt_per_block);
+  const int g = lane >> 4;
+  for (int qt = blockIdx.x * qt_per_block + wave; qt < qt_end; qt += 4) {
+    const int q = qt * 16 + (lane & 15);
+    const bf16x8_t qf = load_frag_global(qb, a.q_rs, q, a.Lq, lane);
+    float m = -1e30f;
+#pragma unroll 2
+    for (int kt = 0; kt < nkt; ++kt) {
+      const f32x4_t s = MFMA(frag_n(sK, kt * 16, lane), qf, (f32x4_t{0.f, 0.f, 0.f, 0.f}));
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        if (kt * 16 + g * 4 + r < a.Lk) m = fmaxf(m, s[r] * a.scale);
+    }
+    m = group_max4(m);
+    float l = 0.f;
+    f32x4_t o0 = {0.f, 0.f, 0.f, 0.f}, o1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 2
+    for (int kb2 = 0; kb2 < nkt / 2; ++kb2) {
+      f32x4_t p[2];
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const int kt = 2 * kb2 + t;
+        const f32x4_t s = MFMA(frag_n(sK, kt * 16, lane), qf, (f32x4_t{0.f, 0.f, 0.f, 0.f}));
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          p[t][r] = (kt * 16 + g * 4 + r < a.Lk) ? __expf(s[r] * a.scale - m) : 0.f;
+          l += p[t][r];
+        }
+      }
+      const bf16x8_t ph = pack8(p[0], p[1]);                      // hi + lo parts of P: see mfma_fwd_kernel
+      f32x4_t r0, r1;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { r0[r] = p[0][r] - (float)ph[r]; r1[r] = p[1][r] - (float)ph[4 + r]; }
+      const bf16x8_t pl = pack8(r0, r1);
+      const bf16x8_t vt0 = frag_t(sV, kb2 * 32, kb2 * 32 + 16, 0, lane), vt1 = frag_t(sV, kb2 * 32, kb2 * 32 + 16, 16, lane);
+      o0 = MFMA(vt0, ph, o0); o0 = MFMA(vt0, pl, o0);
+      o1 = MFMA(vt1, ph, o1); o1 = MFMA(vt1, pl, o1);
+    }
+    l = group_sum4(l);
+    if (q < a.Lq) {
+      const float inv = 1.f / l;
+      o0 *= inv; o1 *= inv;
+      store4(ob + (int64_t)q * a.o_rs + g * 4, o0);
+      store4(ob + (int64_t)q * a.o_rs + 16 + g * 4, o1);
+      if (a.lse && g == 0) a.lse[((int64_t)b * a.H + h) * a.Lq + q] = m + __logf(l);
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void mfma_bwd_dq_long_kernel(const AttnArgs a, float* __restrict__ delta, int qt_per_block, int nkt) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_long[];
+  unsigned char* sK = smem_long;
+  unsigned char* sV = smem_long + nkt * 1024;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = blockIdx.y, b = blockIdx.z;
+  const bf16_t* qb = reinterpret_cast<const bf16_t*>(a.q) + b * a.q_bs + h * D;
+  const bf16_t* gb = reinterpret_cast<const bf16_t*>(a.d_o) + b * a.o_bs + h * D;
+  const bf16_t* ob = reinterpret_cast<const bf16_t*>(a.o) + b * a.o_bs + h * D;
+  bf16_t* dqb = reinterpret_cast<bf16_t*>(a.dq) + b * a.q_bs + h * D;
+  stage_rows<256>(sK, reinterpret_cast<const bf16_t*>(a.k) + b * a.k_bs + h * D, a.k_rs, 0, nkt * 16, a.Lk, tid);
+  stage_rows<256>(sV, reinterpret_cast<const bf16_t*>(a.v) + b * a.v_bs + h * D, a.v_rs, 0, nkt * 16, a.Lk, tid);
+  __syncthreads();
+  const int nqt = (a.Lq + 15) >> 4;
+  const int qt_end = min(nqt, (int)(blockIdx.x + 1) * qt_per_block);
+  const int g = lane >> 4;
+  const int64_t bh = ((int64_t)b * a.H + h) * a.Lq;
+  for (int qt = blockIdx.x * qt_per_block + wave; qt < qt_end; qt += 4) {
+    const int q = qt * 16 + (lane & 15);
+    const bool vq = q < a.Lq;
+    const bf16x8_t qf = load_frag_global(qb, a.q_rs, q, a.Lq, lane);
+    const bf16x8_t gf = load_frag_global(gb, a.o_rs, q, a.Lq, lane);
+    const bf16x8_t of = load_frag_global(ob, a.o_rs, q, a.Lq, lane);
+    const float lse = vq ? a.lse[bh + q] : 0.f;
+    float dl = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) dl += (float)gf[j] * (float)of[j];
+    dl = group_sum4(dl);
+    if (vq && g == 0) delta[bh + q] = dl;
+    f32x4_t dq0 = {0.f, 0.f, 0.f, 0.f}, dq1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 2
+    for (int kb2 = 0; kb2 < nkt / 2; ++kb2) {
+      f32x4_t ds[2];
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const int kt = 2 * kb2 + t;
+        const f32x4_t s = MFMA(frag_n(sK, kt * 16, lane), qf, (f32x4_t{0.f, 0.f, 0.f, 0.f}));
+        const f32x4_t dp = MFMA(frag_n(sV, kt * 16, lane), gf, (f32x4_t{0.f, 0.f, 0.f, 0.f}));
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const bool ok = vq && (kt * 16 + g * 4 + r < a.Lk);
+          const float p = ok ? __expf(s[r] * a.scale - lse) : 0.f;
+          ds[t][r] = p * (dp[r] - dl) * a.scale;
+        }
+      }
+      const bf16x8_t dsf = pack8(ds[0], ds[1]);
+      dq0 = MFMA(frag_t(sK, kb2 * 32, kb2 * 32 + 16, 0, lane), dsf, dq0);
+      dq1 = MFMA(frag_t(sK, kb2 * 32, kb2 * 32 + 16, 16, lane), dsf, dq1);
+    }
+    if (vq) {
+      store4(dqb + (int64_t)q * a.q_rs + g * 4, dq0);
+      store4(dqb + (int64_t)q * a.q_rs + 16 + g * 4, dq1);
+    }
+  }
+}
+
+// dK / dV of the 14 key tiles starting at tile blockIdx.x * 14: wave w owns tiles w, w + 4, w + 8, w + 12 of the range
+// and walks ALL queries, staged chunk by chunk (Q and dO images, LSE, delta) -- no cross-wave or cross-workgroup sums.
+__global__ __launch_bounds__(256) void mfma_bwd_dkv_long_kernel(const AttnArgs a, const float* __restrict__ delta, int q_chunk) {
+  constexpr int NKT = 14, KW = 4, TPW = 4;
+  __shared__ __attribute__((aligned(16))) unsigned char sQG[2 * QR_MAX * 64];
+  __shared__ __attribute__((aligned(16))) float sL[QR_MAX], sDl[QR_MAX];
+  unsigned char* sQ = sQG;
+  unsigned char* sG = sQG + QR_MAX * 64;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = blockIdx.y, b = blockIdx.z, g = lane >> 4;
+  const int kt0 = blockIdx.x * NKT;
+  const int64_t bh = ((int64_t)b * a.H + h) * a.Lq;
+  const bf16_t* kb = reinterpret_cast<const bf16_t*>(a.k) + b * a.k_bs + h * D;
+  const bf16_t* vb = reinterpret_cast<const bf16_t*>(a.v) + b * a.v_bs + h * D;
+  bf16x8_t kf[TPW], vf[TPW];
+  f32x4_t dk[TPW][2], dv[TPW][2];
+#pragma unroll
+  for (int i = 0; i < TPW; ++i) {
+    const int lt = wave + i * KW;                                  // tile inside the range
+    const int key = (kt0 + lt) * 16 + (lane & 15);
+    kf[i] = load_frag_global(kb, a.k_rs, key, (lt < NKT) ? a.Lk : 0, lane);
+    vf[i] = load_frag_global(vb, a.v_rs, key, (lt < NKT) ? a.Lk : 0, lane);
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt) { dk[i][dt] = f32x4_t{0.f, 0.f, 0.f, 0.f}; dv[i][dt] = f32x4_t{0.f, 0.f, 0.f, 0.f}; }
+  }
+  for (int q0 = 0; q0 < a.Lq; q0 += q_chunk) {
+    const int q1 = min(a.Lq, q0 + q_chunk);
+    const int nrows = ((q1 - q0 + 31) >> 5) << 5;
+    __syncthreads();                                               // the previous chunk's images are consumed
+    stage_rows<256>(sQ, reinterpret_cast<const bf16_t*>(a.q) + b * a.q_bs + h * D, a.q_rs, q0, nrows, q1, tid);
+    stage_rows<256>(sG, reinterpret_cast<const bf16_t*>(a.d_o) + b * a.o_bs + h * D, a.o_rs, q0, nrows, q1, tid);
+    for (int i = tid; i < nrows; i += 256) {
+      const bool ok = q0 + i < q1;
+      sL[i] = ok ? a.lse[bh + q0 + i] : 1e30f;                     // exp(s - 1e30) = 0 masks the padded queries
+      sDl[i] = ok ? delta[bh + q0 + i] : 0.f;
+    }
+    __syncthreads();
+    for (int r0 = 0; r0 < nrows; r0 += 32) {
+      const bf16x8_t qn0 = frag_n(sQ, r0, lane), qn1 = frag_n(sQ, r0 + 16, lane);
+      const bf16x8_t gn0 = frag_n(sG, r0, lane), gn1 = frag_n(sG, r0 + 16, lane);
+      const bf16x8_t qt0 = frag_t(sQ, r0, r0 + 16, 0, lane), qt1 = frag_t(sQ, r0, r0 + 16, 16, lane);
+      const bf16x8_t gt0 = frag_t(sG, r0, r0 + 16, 0, lane), gt1 = frag_t(sG, r0, r0 + 16, 16, lane);
+      const float4 l0 = *reinterpret_cast<const float4*>(sL + r0 + g * 4), l1 = *reinterpret_cast<const float4*>(sL + r0 + 16 + g * 4);
+      const float4 d0 = *reinterpret_cast<const float4*>(sDl + r0 + g * 4), d1 = *reinterpret_cast<const float4*>(sDl + r0 + 16 + g * 4);
+      const float lse[8] = {l0.x, l0.y, l0.z, l0.w, l1.x, l1.y, l1.z, l1.w};
+      const float dl[8] = {d0.x, d0.y, d0.z, d0.w, d1.x, d1.y, d1.z, d1.w};
+#pragma unroll
+      for (int i = 0; i < TPW; ++i) {
+        const int lt = wave + i * KW;
+        if (lt >= NKT || (kt0 + lt) * 16 >= a.Lk) continue;       // wave-uniform
+        const bool kvalid = (kt0 + lt) * 16 + (lane & 15) < a.Lk;
+        const f32x4_t s0 = MFMA(qn0, kf[i], (f32x4_t{0.f, 0.f, 0.f, 0.f})), s1 = MFMA(qn1, kf[i], (f32x4_t{0.f, 0.f, 0.f, 0.f}));
+        const f32x4_t p0 = MFMA(gn0, vf[i], (f32x4_t{0.f, 0.f, 0.f, 0.f})), p1 = MFMA(gn1, vf[i], (f32x4_t{0.f, 0.f, 0.f, 0.f}));
+        f32x4_t pr[2], ds[2];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float e0 = kvalid ? __expf(s0[r] * a.scale - lse[r]) : 0.f, e1 = kvalid ? __expf(s1[r] * a.scale - lse[4 + r]) : 0.f;
+          pr[0][r] = e0; pr[1][r] = e1;
+          ds[0][r] = e0 * (p0[r] - dl[r]) * a.scale; ds[1][r] = e1 * (p1[r] - dl[4 + r]) * a.scale;
+        }
+        const bf16x8_t pf = pack8(pr[0], pr[1]), dsf = pack8(ds[0], ds[1]);
+        dv[i][0] = MFMA(gt0, pf, dv[i][0]); dv[i][1] = MFMA(gt1, pf, dv[i][1]);
+        dk[i][0] = MFMA(qt0, dsf, dk[i][0]); dk[i][1] = MFMA(qt1, dsf, dk[i][1]);
+      }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < TPW; ++i) {
+    const int lt = wave + i * KW, key = (kt0 + lt) * 16 + (lane & 15);
+    if (lt >= NKT || key >= a.Lk) continue;
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt) {
+      const int d = dt * 16 + g * 4;
+      store4(reinterpret_cast<bf16_t*>(a.dk) + b * a.k_bs + (int64_t)key * a.k_rs + h * D + d, dk[i][dt]);
+      store4(reinterpret_cast<bf16_t*>(a.dv) + b * a.v_bs + (int64_t)key * a.v_rs + h * D + d, dv[i][dt]);
+    }
+  }
+}
+
 inline int nkt_for(int Lk) { return Lk <= 32 ? 2 : (Lk <= 64 ? 4 : (Lk <= 128 ? 8 : 14)); }
 
 // query tiles per workgroup: whole (b, h) in one workgroup when small, else ~32 tiles, but keep the grid >= ~1024
@@ -495,6 +699,47 @@ inline int qt_per_block_for(const AttnArgs& a) {
 }
 
 }  // namespace
+
+bool lmv_attn_mfma_long_supported(const AttnArgs& a) { return a.Lk > 224 && a.Lk <= LONG_MAX_NKT * 16 && a.Lq > 16; }
+
+static int long_geometry(const AttnArgs& a, int* nkt, int* per, int* lds) {
+  *nkt = ((a.Lk + 31) / 32) * 2;                                   // even number of 16-key tiles
+  *lds = 2 * *nkt * 1024;
+  const int nqt = (a.Lq + 15) / 16, per0 = qt_per_block_for(a), nblk = (nqt + per0 - 1) / per0;
+  *per = (nqt + nblk - 1) / nblk;                                  // balanced query-tile ranges
+  static bool attr_set = false;                                    // > 64 KiB of dynamic LDS needs an explicit opt-in
+  if (!attr_set) {
+    const int max_lds = 2 * LONG_MAX_NKT * 1024;
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(mfma_fwd_long_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, max_lds) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void*>(mfma_bwd_dq_long_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, max_lds) != hipSuccess)
+      LMV_FAIL(LMV_ERR_LAUNCH, "attn_mfma_long: cannot reserve %d bytes of LDS", max_lds);
+    attr_set = true;
+  }
+  return LMV_OK;
+}
+
+int lmv_attn_mfma_long_fwd(const AttnArgs& a, hipStream_t st) {
+  int nkt, per, lds;
+  if (int rc = long_geometry(a, &nkt, &per, &lds)) return rc;
+  const int nqt = (a.Lq + 15) / 16;
+  hipLaunchKernelGGL(mfma_fwd_long_kernel, dim3((nqt + per - 1) / per, a.H, a.B), dim3(256), lds, st, a, per, nkt);
+  LMV_CHECK_LAUNCH("attn_mfma_long_fwd");
+  return LMV_OK;
+}
+
+// delta: B*H*Lq floats of scratch (written by the dQ kernel, read by the dK / dV kernel)
+int lmv_attn_mfma_long_bwd(const AttnArgs& a, float* delta, hipStream_t st) {
+  int nkt, per, lds;
+  if (int rc = long_geometry(a, &nkt, &per, &lds)) return rc;
+  const int nqt = (a.Lq + 15) / 16;
+  hipLaunchKernelGGL(mfma_bwd_dq_long_kernel, dim3((nqt + per - 1) / per, a.H, a.B), dim3(256), lds, st, a, delta, per, nkt);
+  const int nchunks = (a.Lq + QR_MAX - 1) / QR_MAX;
+  const int q_chunk = (((a.Lq + nchunks - 1) / nchunks) + 31) / 32 * 32;     // balanced chunks, multiples of 32, <= QR_MAX
+  const int nranges = ((a.Lk + 15) / 16 + 13) / 14;
+  hipLaunchKernelGGL(mfma_bwd_dkv_long_kernel, dim3(nranges, a.H, a.B), dim3(256), 0, st, a, (const float*)delta, q_chunk);
+  LMV_CHECK_LAUNCH("attn_mfma_long_bwd");
+  return LMV_OK;
+}
 
 bool lmv_attn_mfma_supported(const AttnArgs& a) { return a.Lk <= 224; }
 bool lmv_attn_mfma_fewq_supported(const AttnArgs& a) { return a.Lq <= 16 && a.Lk > 224; }

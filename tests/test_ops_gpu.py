@@ -178,6 +178,9 @@ ATTN_CASES = [  # name, B, Lq, Lk, C, self (packed qkv) ?
     ("sa196", 2, 196, 196, 384, True), ("sa49", 3, 49, 49, 512, True), ("sa16", 2, 16, 16, 64, True), ("sa577", 1, 577, 577, 64, True),
     ("fewq", 2, 16, 3136, 96, False), ("fewq_odd", 1, 16, 1225, 64, False), ("fewq_short", 2, 16, 70, 64, False),
     ("fewk", 2, 3136, 16, 96, False), ("fewk_odd", 1, 1225, 16, 64, False), ("gen", 2, 100, 37, 64, False),
+    # many queries x 225..640 keys: the whole-row MFMA kernels with K / V in dynamic LDS (SA at 384^2 is 576 + 16 tokens)
+    ("sa592", 2, 592, 592, 384, True), ("long_640", 1, 300, 640, 64, False), ("long_225", 1, 33, 225, 64, False),
+    ("gen_long", 1, 40, 700, 64, False),     # beyond 640 keys: generic kernels
 ]
 
 

@@ -154,6 +154,13 @@ int lmv_dca_core_fwd(const void* qkv1, const void* qkv2, void* ox, void* oc, flo
 /* dst[i] = (dtype_dst) src[i]   (fp32 master weights -> bf16 compute copies and back) */
 int lmv_cast(const void* src, int src_dtype, void* dst, int dst_dtype, int64_t n, void* stream);
 /* y[r, :] = x[r, :] * scale[r / rows_per_sample]   (DropPath on a gradient) */
+/* Stem, first convolution (models/lemevit.py:713, Conv2d(3, C/2, kernel 3, stride 2, padding 1)) lowered to a GEMM:
+ * patches[(b, ho, wo)][ci * 9 + ky * 3 + kx] = x[b][ci][2 ho - 1 + ky][2 wo - 1 + kx] (zero outside the image), columns
+ * 27..31 zero -> a [B * ceil(H/2) * ceil(W/2), 32] matrix in `dtype`.  x is read through its element strides
+ * (sb, sc, sh, sw), so NCHW and channels-last batches of fp32 or bf16 images are accepted as they are.
+ * lmv_linear_fwd(patches, W[Cout, 32]) is then the convolution (NHWC output), lmv_linear_dw its weight gradient. */
+int lmv_im2col3x3s2_c3(const void* x, int x_dtype, void* patches, int dtype, int B, int H, int W, int64_t sb, int64_t sc, int64_t sh,
+                       int64_t sw, void* stream);
 int lmv_row_scale(const void* x, const float* scale, void* y, int64_t rows, int C, int rows_per_sample, int dtype, void* stream);
 /* Fused multi-tensor AdamW over a flat fp32 parameter / gradient / moment buffer
  * (decoupled weight decay, bias correction as torch.optim.AdamW; benchmark.py:559-561,587). */

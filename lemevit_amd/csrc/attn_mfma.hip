@@ -512,7 +512,6 @@ __global__ __launch_bounds__(256) void mfma_fwd_long_kernel(const AttnArgs a, in
     const int q = qt * 16 + (lane & 15);
     const bf16x8_t qf = load_frag_global(qb, a.q_rs, q, a.Lq, lane);
     float m = -1e30f;
-#pragma unroll 2
     for (int kt = 0; kt < nkt; ++kt) {
       const f32x4_t s = MFMA(frag_n(sK, kt * 16, lane), qf, (f32x4_t{0.f, 0.f, 0.f, 0.f}));
 #pragma unroll
@@ -522,7 +521,6 @@ __global__ __launch_bounds__(256) void mfma_fwd_long_kernel(const AttnArgs a, in
     m = group_max4(m);
     float l = 0.f;
     f32x4_t o0 = {0.f, 0.f, 0.f, 0.f}, o1 = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll 2
     for (int kb2 = 0; kb2 < nkt / 2; ++kb2) {
       f32x4_t p[2];
 #pragma unroll
@@ -584,7 +582,6 @@ __global__ __launch_bounds__(256) void mfma_bwd_dq_long_kernel(const AttnArgs a,
     dl = group_sum4(dl);
     if (vq && g == 0) delta[bh + q] = dl;
     f32x4_t dq0 = {0.f, 0.f, 0.f, 0.f}, dq1 = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll 2
     for (int kb2 = 0; kb2 < nkt / 2; ++kb2) {
       f32x4_t ds[2];
 #pragma unroll

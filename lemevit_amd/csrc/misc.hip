@@ -135,6 +135,56 @@ extern "C" int lmv_cast(const void* src, int sd, void* dst, int dd, int64_t n, v
   return LMV_OK;
 }
 
+// ---- stem, first convolution (models/lemevit.py:713: Conv2d(3, C/2, 3, stride 2, padding 1)) as a GEMM ------------
+// patches[(b, ho, wo)][j] = x[b][ci][2 ho - 1 + ky][2 wo - 1 + kx],  j = ci * 9 + ky * 3 + kx  (the weight's own
+// [Cout][3][3][3] order), j = 27..31 zero: a [B Ho Wo, 32] matrix that lmv_linear_fwd multiplies by the [Cout, 32]
+// weight (forward) and lmv_linear_dw contracts with dY (weight gradient) -- the input needs no gradient.  The source is
+// read through its strides (NCHW or channels-last, fp32 or bf16: the image batch as the data loader hands it over).
+template <typename S, typename T>
+__global__ __launch_bounds__(TPB) void im2col_c3_kernel(const S* __restrict__ x, T* __restrict__ out, int B, int H, int W, int Ho, int Wo,
+                                                       int64_t sb, int64_t sc, int64_t sh, int64_t sw) {
+  const unsigned p = blockIdx.x * TPB + threadIdx.x, total = (unsigned)B * Ho * Wo;
+  if (p >= total) return;
+  const unsigned wo = p % Wo, t = p / Wo, ho = t % Ho, b = t / Ho;
+  float v[32];
+#pragma unroll
+  for (int ci = 0; ci < 3; ++ci)
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx) {
+        const int h = 2 * (int)ho - 1 + ky, w = 2 * (int)wo - 1 + kx;
+        const int hc = min(max(h, 0), H - 1), wc = min(max(w, 0), W - 1);      // clamped load, zeroed below
+        const float val = DT<S>::ld(x + b * sb + ci * sc + hc * sh + wc * sw);
+        v[ci * 9 + ky * 3 + kx] = (h == hc && w == wc) ? val : 0.f;
+      }
+#pragma unroll
+  for (int j = 27; j < 32; ++j) v[j] = 0.f;
+  T* o = out + (size_t)p * 32;
+#pragma unroll
+  for (int c = 0; c < 32; c += DT<T>::EPC) *reinterpret_cast<uint4*>(o + c) = f_to_chunk<T>(v + c);
+}
+
+extern "C" int lmv_im2col3x3s2_c3(const void* x, int x_dtype, void* patches, int dtype, int B, int H, int W, int64_t sb, int64_t sc, int64_t sh,
+                                  int64_t sw, void* stream) {
+  if (B <= 0 || H <= 0 || W <= 0) LMV_FAIL(LMV_ERR_SHAPE, "im2col: bad shape B=%d H=%d W=%d", B, H, W);
+  if (!x || !patches || !lmv_aligned16(patches)) LMV_FAIL(LMV_ERR_SHAPE, "im2col: null or misaligned operand");
+  const int Ho = (H + 1) / 2, Wo = (W + 1) / 2;
+  const int64_t total = (int64_t)B * Ho * Wo;
+  if (total >= (int64_t)1 << 31) LMV_FAIL(LMV_ERR_SHAPE, "im2col: too many output pixels");
+  hipStream_t st = (hipStream_t)stream;
+  const dim3 grid((unsigned)((total + TPB - 1) / TPB)), block(TPB);
+#define IM2COL(S, T) hipLaunchKernelGGL((im2col_c3_kernel<S, T>), grid, block, 0, st, (const S*)x, (T*)patches, B, H, W, Ho, Wo, sb, sc, sh, sw)
+  if (x_dtype == LMV_F32 && dtype == LMV_BF16) IM2COL(float, bf16_t);
+  else if (x_dtype == LMV_F32 && dtype == LMV_F32) IM2COL(float, float);
+  else if (x_dtype == LMV_BF16 && dtype == LMV_BF16) IM2COL(bf16_t, bf16_t);
+  else if (x_dtype == LMV_BF16 && dtype == LMV_F32) IM2COL(bf16_t, float);
+  else LMV_FAIL(LMV_ERR_DTYPE, "im2col: unsupported dtypes %d -> %d", x_dtype, dtype);
+#undef IM2COL
+  LMV_CHECK_LAUNCH("im2col3x3s2_c3");
+  return LMV_OK;
+}
+
 extern "C" int lmv_row_scale(const void* x, const float* scale, void* y, int64_t rows, int C, int rps, int dtype, void* stream) {
   if (rows <= 0) return LMV_OK;
   if (C <= 0 || (C % 8) || rps <= 0) LMV_FAIL(LMV_ERR_SHAPE, "row_scale: C=%d must be a multiple of 8, rows_per_sample=%d > 0", C, rps);

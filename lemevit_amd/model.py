@@ -65,6 +65,85 @@ def compute_copy(p: Tensor, want: torch.dtype) -> Tensor:
     return t
 
 
+_fold_cache: dict = {}
+_conv1_cache: dict = {}
+
+
+def _conv1_matrix(weight: Tensor, dtype: torch.dtype) -> Tensor:
+    """[Cout, 3, 3, 3] stem weight -> the [Cout, 32] GEMM operand of ops.im2col3x3s2_c3 (columns 27..31 zero), cached per version."""
+    key = (id(weight), dtype)
+    ent = _conv1_cache.get(key)
+    if ent is not None and ent[0]() is weight and ent[1] == weight._version:
+        return ent[2]
+    with torch.no_grad():
+        m = torch.zeros(weight.shape[0], 32, device=weight.device, dtype=dtype)
+        m[:, :27] = weight.detach().reshape(weight.shape[0], 27)
+    _conv1_cache[key] = (weakref.ref(weight), weight._version, m)
+    return m
+
+
+class _StemConv1Fn(torch.autograd.Function):
+    """First convolution of the stem (models/lemevit.py:713: 3 -> C/2 channels, 3x3, stride 2, padding 1) as im2col + the
+    block GEMM kernels: y[NHWC] = patches @ W^T + b, dW = dY^T @ patches.  The image batch needs no gradient.  (MIOpen's
+    implicit-GEMM kernel for this 27-deep reduction takes 455 us at B = 128; this is ~5x faster, weight gradient included.)"""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, cd):
+        B, _, H, W = x.shape
+        Ho, Wo, Co = (H + 1) // 2, (W + 1) // 2, weight.shape[0]
+        patches = ops.im2col3x3s2_c3(x, cd)
+        y = torch.empty(B * Ho * Wo, Co, device=x.device, dtype=cd)
+        b32 = None if bias is None else compute_copy(bias, torch.float32)
+        ops.linear_fwd([Prob(patches, _conv1_matrix(weight, cd), y, bias=b32)], Co, 32)
+        ctx.save_for_backward(patches)
+        ctx.meta = (weight.shape, weight.dtype, None if bias is None else bias.dtype)
+        return y.view(B, Ho, Wo, Co).permute(0, 3, 1, 2)            # NCHW-shaped, channels-last-strided: no copy
+
+    @staticmethod
+    def backward(ctx, dy):
+        (patches,) = ctx.saved_tensors
+        wshape, wdt, bdt = ctx.meta
+        Co = wshape[0]
+        g = dy.permute(0, 2, 3, 1).contiguous().view(-1, Co)
+        if g.dtype != patches.dtype:
+            g = g.to(patches.dtype)
+        dwm = torch.zeros(Co, 32, device=g.device, dtype=torch.float32)
+        db = torch.zeros(Co, device=g.device, dtype=torch.float32)
+        ops.linear_dw([Prob(g, patches, dwm, bias_grad=db)], Co, 32)
+        dw = dwm[:, :27].reshape(wshape).to(wdt)
+        return None, dw, (None if bdt is None else db.to(bdt)), None
+
+
+def _is_stem_conv1(m: nn.Module, x: Tensor) -> bool:
+    return (isinstance(m, nn.Conv2d) and m.in_channels == 3 and m.kernel_size == (3, 3) and m.stride == (2, 2) and m.padding == (1, 1)
+            and m.dilation == (1, 1) and m.groups == 1 and m.out_channels % 8 == 0 and m.padding_mode == "zeros" and not x.requires_grad
+            and x.dtype in (torch.float32, torch.bfloat16))
+
+
+def _folded_conv_bn(conv: nn.Conv2d, bn: nn.BatchNorm2d, dtype: torch.dtype):
+    """(weight, bias, fp32 bias) of conv followed by eval-mode BatchNorm, cached until any of the six source tensors changes."""
+    src = [conv.weight, conv.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var]
+    ver = tuple(-1 if t is None else t._version for t in src) + tuple(0 if t is None else t.data_ptr() for t in src)
+    key = (id(conv), id(bn), dtype)
+    ent = _fold_cache.get(key)
+    if ent is not None and ent[0] == ver:
+        return ent[1], ent[2], ent[3]
+    with torch.no_grad():
+        s = (bn.running_var.float() + bn.eps).rsqrt()
+        if bn.weight is not None:
+            s = s * bn.weight.float()
+        w = conv.weight.float() * s[:, None, None, None]
+        b0 = conv.bias.float() if conv.bias is not None else torch.zeros_like(s)
+        b = (b0 - bn.running_mean.float()) * s
+        if bn.bias is not None:
+            b = b + bn.bias.float()
+        w = w.to(dtype).contiguous(memory_format=torch.channels_last)
+        b32 = b.contiguous()
+        b = b.to(dtype)
+    _fold_cache[key] = (ver, w, b, b32)
+    return w, b, b32
+
+
 def _resolve_dtype(x: Tensor) -> torch.dtype:
     if not x.is_cuda:
         raise RuntimeError("lemevit_amd: the model runs on an MI355X only -- move the model and inputs to 'cuda' "
@@ -397,6 +476,30 @@ class LeMeViT(nn.Module):
         B, N, C = xt.shape
         return xt.view(B, H, W, C).permute(0, 3, 1, 2)          # channels_last-strided view, no copy
 
+    def _run_downsample(self, seq: nn.Module, x: Tensor) -> Tensor:
+        """Conv-BN(-GELU-Conv-BN) of the stem / a stage transition (models/lemevit.py:713-728).  In inference (eval mode,
+        no grad) every BatchNorm is folded into the weights of the convolution before it: y = conv(x; w*s, (b-mu)*s+beta),
+        s = gamma / sqrt(var + eps) -- the same affine map, one kernel and one pass over the feature map less per layer."""
+        if not isinstance(seq, nn.Sequential):
+            return seq(x)
+        cd = x.dtype if not torch.is_autocast_enabled() else torch.get_autocast_dtype("cuda")
+        fold = not (self.training or torch.is_grad_enabled())
+        mods, i = list(seq), 0
+        while i < len(mods):
+            m = mods[i]
+            bn = mods[i + 1] if i + 1 < len(mods) and isinstance(mods[i + 1], nn.BatchNorm2d) and mods[i + 1].track_running_stats else None
+            if fold and isinstance(m, nn.Conv2d) and bn is not None:
+                w, b, b32 = _folded_conv_bn(m, bn, cd)
+                x = _StemConv1Fn.apply(x, w, b32, cd) if _is_stem_conv1(m, x) else F.conv2d(x.to(w.dtype), w, b, m.stride, m.padding, m.dilation, m.groups)
+                i += 2
+            elif _is_stem_conv1(m, x) and cd in (torch.float32, torch.bfloat16):
+                x = _StemConv1Fn.apply(x, m.weight, m.bias, cd)
+                i += 1
+            else:
+                x = m(x)
+                i += 1
+        return x
+
     def _draw_drop_path(self, B: int, device) -> Dict[int, List[Optional[Tensor]]]:
         """All DropPath masks of one forward pass from ONE uniform draw (instead of ~120 tiny bernoulli_/div_ launches):
         per block and per DropPath call an independent per-sample Bernoulli(keep) / keep vector, as timm's DropPath
@@ -424,7 +527,6 @@ class LeMeViT(nn.Module):
         """models/lemevit.py:809-829.  c = None hoists the batch-invariant meta-token prefix."""
         cd = _resolve_dtype(x)
         B = x.shape[0]
-        x = x.contiguous(memory_format=torch.channels_last)
         hoist = c is None
         if hoist:
             c = self.meta_tokens.unsqueeze(0)
@@ -432,7 +534,7 @@ class LeMeViT(nn.Module):
         all_masks = self._draw_drop_path(B, x.device)
         for i in range(self.num_stages):
             if i == 0 or not isinstance(self.downsample_layers[i], nn.Identity):
-                x = self.downsample_layers[i](x if xt is None else self._to_nchw(xt, H, W))
+                x = self._run_downsample(self.downsample_layers[i], x if xt is None else self._to_nchw(xt, H, W))
                 xt, H, W = self._to_tokens(x, cd)
             c = self.meta_token_downsample[i](c)
             if hoist:

@@ -234,6 +234,17 @@ def cast(src: Tensor, dtype: torch.dtype) -> Tensor:
     return dst
 
 
+def im2col3x3s2_c3(x: Tensor, dtype: torch.dtype) -> Tensor:
+    """[B, 3, H, W] images (any strides, fp32 or bf16) -> [B * ceil(H/2) * ceil(W/2), 32] patch matrix of the stem's first conv."""
+    B, C, H, W = x.shape
+    if C != 3:
+        raise ValueError("im2col3x3s2_c3: 3 input channels expected")
+    out = torch.empty(B * ((H + 1) // 2) * ((W + 1) // 2), 32, device=x.device, dtype=dtype)
+    sb, sc, sh, sw = x.stride()
+    check(lib.lmv_im2col3x3s2_c3(_ptr(x), dtype_code(x), _ptr(out), dtype_code(out), B, H, W, sb, sc, sh, sw, _stream()), "lmv_im2col3x3s2_c3")
+    return out
+
+
 def row_scale(x: Tensor, scale: Tensor, rows_per_sample: int) -> Tensor:
     y = torch.empty_like(x)
     C_ = x.shape[-1]

@@ -156,6 +156,27 @@ def test_model_forward_fp32(golden, name):
     print(f"{name}: fp32 logits rel err {e:.2e}")
 
 
+def test_eval_conv_bn_folding_fp32(golden):
+    """Under no_grad the stem / stage-transition BatchNorms are folded into their convolutions (model.py::_run_downsample);
+    with grad enabled the eval forward runs conv and BatchNorm separately.  Both must meet the golden logits, and the
+    folded weights must follow an in-place update of the BatchNorm statistics."""
+    name = "model_tiny_224"
+    meta, g = golden(name)
+    m = _model(meta["variant"], meta["num_classes"], meta["seed"]).eval()
+    img = det_tensor((meta["B"], 3, meta["res"], meta["res"]), name + ".img", 4).to(DEV)
+    with torch.no_grad():
+        folded = m(img)
+    unfolded = m(img)                      # grad enabled: nn.Sequential path
+    close(folded, g["logits"], 1e-5, "folded")
+    close(unfolded, g["logits"], 1e-5, "unfolded")
+    with torch.no_grad():
+        m.downsample_layers[0][1].running_mean.add_(0.25)
+        moved = m(img)
+    ref = m(img)
+    assert float((moved - folded).abs().max()) > 1e-4, "folded weights were not refreshed after the statistics changed"
+    close(moved, ref.detach().cpu().numpy(), 1e-5, "refreshed fold")
+
+
 @pytest.mark.parametrize("name", ["model_tiny_224", "model_base_224"])
 @pytest.mark.parametrize("mode", ["autocast", "pure"])
 def test_model_forward_bf16(golden, name, mode):

@@ -241,7 +241,9 @@ def im2col3x3s2_c3(x: Tensor, dtype: torch.dtype) -> Tensor:
         raise ValueError("im2col3x3s2_c3: 3 input channels expected")
     out = torch.empty(B * ((H + 1) // 2) * ((W + 1) // 2), 32, device=x.device, dtype=dtype)
     sb, sc, sh, sw = x.stride()
-    check(lib.lmv_im2col3x3s2_c3(_ptr(x), dtype_code(x), _ptr(out), dtype_code(out), B, H, W, sb, sc, sh, sw, _stream()), "lmv_im2col3x3s2_c3")
+    if not x.is_cuda:
+        raise RuntimeError("lemevit_amd: tensors must be on the GPU (no CPU fallback exists)")
+    check(lib.lmv_im2col3x3s2_c3(x.data_ptr(), dtype_code(x), _ptr(out), dtype_code(out), B, H, W, sb, sc, sh, sw, _stream()), "lmv_im2col3x3s2_c3")
     return out
 
 

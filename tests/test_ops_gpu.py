@@ -265,3 +265,29 @@ def test_adamw_flat():
         pr.grad = g.clone(); opt.step()
         o.adamw_flat(p, g, m, v, None, 1e-2, 0.9, 0.999, 1e-8, 0.05, step)
     assert_close(p, pr.detach().cpu(), torch.float32, "adamw", 1e-5)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("shape", [(2, 3, 224, 224), (1, 3, 97, 131), (3, 3, 8, 5)])
+def test_im2col_stem(dtype, shape):
+    """Patch matrix of the stem's first convolution (3x3, stride 2, padding 1; models/lemevit.py:713): bit-exact copy of the
+    pixels in the weight's own (ci, ky, kx) order, zero padding, columns 27..31 zero; NCHW and channels-last sources; and the
+    convolution it stands for: patches @ W^T + b == F.conv2d."""
+    o = ops()
+    B, _, H, W = shape
+    x = det_tensor(shape, "img", 5).to(dev())
+    ref = torch.nn.functional.unfold(x.double(), 3, padding=1, stride=2).transpose(1, 2).reshape(-1, 27)       # [B*Ho*Wo, 27]
+    for src in (x, x.contiguous(memory_format=torch.channels_last), x.to(torch.bfloat16)):
+        p = o.im2col3x3s2_c3(src, dtype)
+        want = ref if src.dtype == torch.float32 else torch.nn.functional.unfold(src.double(), 3, padding=1, stride=2).transpose(1, 2).reshape(-1, 27)
+        assert p.shape == (B * ((H + 1) // 2) * ((W + 1) // 2), 32) and p.dtype == dtype
+        assert torch.equal(p[:, :27].double().cpu(), want.to(dtype).double().cpu()), "patch values"
+        assert not bool(p[:, 27:].any()), "padding columns must be zero"
+    Co = 48
+    w = det_tensor((Co, 3, 3, 3), "w", 5, 0.3).to(dev()); b = det_tensor((Co,), "b", 5, 0.1).to(dev())
+    wm = torch.zeros(Co, 32, device=dev(), dtype=dtype); wm[:, :27] = w.reshape(Co, 27).to(dtype)
+    p = o.im2col3x3s2_c3(x, dtype)
+    y = torch.empty(p.shape[0], Co, device=dev(), dtype=dtype)
+    o.linear_fwd([o.Prob(p, wm, y, bias=b)], Co, 32)
+    conv = torch.nn.functional.conv2d(x.to(dtype).double().cpu(), w.to(dtype).double().cpu(), b.double().cpu(), stride=2, padding=1)
+    assert_close(y, conv.permute(0, 2, 3, 1).reshape(-1, Co), dtype, "stem conv1 as GEMM")

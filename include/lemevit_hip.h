@@ -162,6 +162,12 @@ int lmv_cast(const void* src, int src_dtype, void* dst, int dst_dtype, int64_t n
 int lmv_im2col3x3s2_c3(const void* x, int x_dtype, void* patches, int dtype, int B, int H, int W, int64_t sb, int64_t sc, int64_t sh,
                        int64_t sw, void* stream);
 int lmv_row_scale(const void* x, const float* scale, void* y, int64_t rows, int C, int rows_per_sample, int dtype, void* stream);
+/* The same for up to two row segments in ONE launch (the x and c gradients of a block, each with its own DropPath vector). */
+typedef struct lmv_row_scale_segment {
+  const void* x; const float* scale; void* y;
+  int64_t rows; int rows_per_sample;
+} lmv_row_scale_segment;
+int lmv_row_scale_multi(const lmv_row_scale_segment* seg, int nseg, int C, int dtype, void* stream);
 /* Fused multi-tensor AdamW over a flat fp32 parameter / gradient / moment buffer
  * (decoupled weight decay, bias correction as torch.optim.AdamW; benchmark.py:559-561,587). */
 int lmv_adamw_flat(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, const float* wd_mask,

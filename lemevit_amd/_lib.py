@@ -28,6 +28,10 @@ class LnSegment(C.Structure):
                 ("dx", C.c_void_p), ("rows", C.c_int64)]
 
 
+class RowScaleSegment(C.Structure):
+    _fields_ = [("x", C.c_void_p), ("scale", C.c_void_p), ("y", C.c_void_p), ("rows", C.c_int64), ("rows_per_sample", C.c_int)]
+
+
 class AttnDesc(C.Structure):
     _fields_ = [("q", C.c_void_p), ("k", C.c_void_p), ("v", C.c_void_p), ("o", C.c_void_p), ("lse", C.c_void_p),
                 ("d_o", C.c_void_p), ("dq", C.c_void_p), ("dk", C.c_void_p), ("dv", C.c_void_p),
@@ -62,6 +66,7 @@ SIGNATURES = {
     "lmv_dca_core_fwd": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _Z, _I, _P]),
     "lmv_cast": (_I, [_P, _I, _P, _I, _L, _P]),
     "lmv_im2col3x3s2_c3": (_I, [_P, _I, _P, _I, _I, _I, _I, _L, _L, _L, _L, _P]),
+    "lmv_row_scale_multi": (_I, [_P, _I, _I, _I, _P]),
     "lmv_row_scale": (_I, [_P, _P, _P, _L, _I, _I, _I, _P]),
     "lmv_adamw_flat": (_I, [_P, _P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _I, _P]),
 }

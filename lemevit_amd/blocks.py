@@ -99,7 +99,7 @@ def _mlp_bwd(P, G, saved, douts: Sequence[Tensor], ds: Sequence[Optional[Tensor]
     ts, st, xn, u, h = saved
     C = ts[0].shape[-1]
     Hd = P["mlp.0.weight"].shape[0]
-    g = [d if s is None else ops.row_scale(d, s, _rps(d)) for d, s in zip(douts, ds)]
+    g = ops.row_scale_multi(douts, ds)
     _dw([Prob(gi, hi, G["mlp.3.weight"], bias_grad=G["mlp.3.bias"]) for gi, hi in zip(g, h)], C, Hd)
     du = [torch.empty_like(ui) for ui in u]
     ops.linear_dx([Prob(gi, P["mlp.3.weight"], o, aux=ui) for gi, o, ui in zip(g, du, u)], C, Hd, ACT_GELU_GRAD)
@@ -127,7 +127,7 @@ def _attn_S_fwd(P, ts, ds, save):
 def _attn_S_bwd(P, G, saved, douts, ds):
     ts, st, xn, qkv, ao, lse = saved
     C = ts[0].shape[-1]
-    g = [d if s is None else ops.row_scale(d, s, _rps(d)) for d, s in zip(douts, ds)]
+    g = ops.row_scale_multi(douts, ds)
     _dw([Prob(gi, ai, G["attn.proj.weight"], bias_grad=G["attn.proj.bias"]) for gi, ai in zip(g, ao)], C, C)
     dao = [torch.empty_like(t) for t in ts]
     ops.linear_dx([Prob(gi, P["attn.proj.weight"], o) for gi, o in zip(g, dao)], C, C)
@@ -162,7 +162,7 @@ def _attn_D_bwd(P, G, saved, douts, ds):
     x, c = ts
     C, N, M = x.shape[-1], x.shape[1], c.shape[1]
     sx, sc = ops.dca_scales(N, M, C)
-    g = [d if s is None else ops.row_scale(d, s, _rps(d)) for d, s in zip(douts, ds)]
+    g = ops.row_scale_multi(douts, ds)
     _dw([Prob(g[0], aox, G["attn.proj_x.weight"], bias_grad=G["attn.proj_x.bias"]),
                    Prob(g[1], aoc, G["attn.proj_c.weight"], bias_grad=G["attn.proj_c.bias"])], C, C)
     daox, daoc = torch.empty_like(x), torch.empty_like(c)
@@ -200,7 +200,7 @@ def _attn_D2_bwd(P, G, saved, douts, ds):
     x, c = ts
     C, N, M = x.shape[-1], x.shape[1], c.shape[1]
     sx, sc = ops.dca_scales(N, M, C)
-    g = [d if s is None else ops.row_scale(d, s, _rps(d)) for d, s in zip(douts, ds)]
+    g = ops.row_scale_multi(douts, ds)
     _dw([Prob(g[0], aox, G["attn.proj_x.weight"], bias_grad=G["attn.proj_x.bias"]),
                    Prob(g[1], aoc, G["attn.proj_c.weight"], bias_grad=G["attn.proj_c.bias"])], C, C)
     daox, daoc = torch.empty_like(x), torch.empty_like(c)

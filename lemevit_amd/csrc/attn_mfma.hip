@@ -189,7 +189,8 @@ __global__ __launch_bounds__(256) void mfma_bwd_dq_kernel(const AttnArgs a, floa
 // =============================================================================================
 // backward, dK / dV: one workgroup per (b, h, query range); wave w owns key tiles kt = w % KW, + KW, ... and the
 // 32-query blocks qb = w / KW, + QW, ...  (KW * QW = 4).  Partial tiles of the QW query groups are summed in LDS.
-// ATOMIC: several query ranges per (b, h) -> fp32 atomics into acc_k / acc_v [B][H][NKT*16][32] (scattered later).
+// ATOMIC (name kept): several query ranges per (b, h) -> one fp32 partial slab per range, acc_k / acc_v [range][B][H][NKT*16][32],
+// summed and scattered by scatter_sum_kernel (the first version used fp32 atomics: 5.5 M of them per launch at stage 1).
 // =============================================================================================
 constexpr int QR_MAX = 448;   // queries staged per workgroup (Q and dO images: 2 * 448 * 64 B = 56 KB)
 
@@ -289,10 +290,10 @@ __global__ __launch_bounds__(256) void mfma_bwd_dkv_kernel(const AttnArgs a, con
 #pragma unroll
     for (int dt = 0; dt < 2; ++dt) {
       const int d = dt * 16 + g * 4;
-      if (ATOMIC) {
-        const int64_t o = ((((int64_t)b * a.H + h) * (NKT * 16)) + key) * D + d;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) { atomicAdd(acc_k + o + r, dk[i][dt][r]); atomicAdd(acc_v + o + r, dv[i][dt][r]); }
+      if (ATOMIC) {      // several query ranges per (b, h): this range's partial goes to ITS slab (plain stores; summed by scatter_sum_kernel)
+        const int64_t o = ((((int64_t)blockIdx.x * a.B + b) * a.H + h) * (NKT * 16) + key) * D + d;
+        *reinterpret_cast<f32x4_t*>(acc_k + o) = dk[i][dt];
+        *reinterpret_cast<f32x4_t*>(acc_v + o) = dv[i][dt];
       } else {
         store4(reinterpret_cast<bf16_t*>(a.dk) + b * a.k_bs + (int64_t)key * a.k_rs + h * D + d, dk[i][dt]);
         store4(reinterpret_cast<bf16_t*>(a.dv) + b * a.v_bs + (int64_t)key * a.v_rs + h * D + d, dv[i][dt]);
@@ -308,6 +309,23 @@ __global__ __launch_bounds__(256) void scatter_bf16_kernel(const float* __restri
   if (idx >= total) return;
   const unsigned d = idx % D, l = (idx / D) % L, h = (idx / (D * L)) % H, b = idx / (D * L * H);
   dst[b * bs + (int64_t)l * rs + h * D + d] = f2bf(acc[((((int64_t)b * H + h) * LP) + l) * D + d]);
+}
+
+// dst[b][l][h][:] = sum over `nslab` slabs of acc[slab][b][h][l][:]  (two tensors per launch: dK and dV)
+__global__ __launch_bounds__(256) void scatter_sum_kernel(const float* __restrict__ acc0, const float* __restrict__ acc1, bf16_t* __restrict__ dst0,
+                                                         bf16_t* __restrict__ dst1, int64_t bs0, int64_t rs0, int64_t bs1, int64_t rs1, int B, int H, int L,
+                                                         int LP, int nslab) {
+  const unsigned idx = blockIdx.x * 256 + threadIdx.x, per = (unsigned)B * H * L * (D / 4);
+  if (idx >= 2 * per) return;
+  const bool second = idx >= per;
+  const unsigned i = second ? idx - per : idx;
+  const unsigned d4 = i % (D / 4), l = (i / (D / 4)) % L, h = (i / ((D / 4) * L)) % H, b = i / ((D / 4) * L * H);
+  const float* src = (second ? acc1 : acc0) + ((((int64_t)b * H + h) * LP) + l) * D + d4 * 4;
+  const int64_t slab = (int64_t)B * H * LP * D;
+  f32x4_t s = {0.f, 0.f, 0.f, 0.f};
+  for (int k = 0; k < nslab; ++k) s += *reinterpret_cast<const f32x4_t*>(src + k * slab);
+  bf16_t* dst = second ? dst1 + b * bs1 + (int64_t)l * rs1 + h * D + d4 * 4 : dst0 + b * bs0 + (int64_t)l * rs0 + h * D + d4 * 4;
+  store4(dst, s);
 }
 
 // =============================================================================================
@@ -762,8 +780,20 @@ int lmv_attn_mfma_fewq_bwd(const AttnArgs& a, float* acc, hipStream_t st) {
   return LMV_OK;
 }
 
+// dK / dV: split the query range so that the grid fills the chip (and fits the LDS images)
+static void dkv_split(const AttnArgs& a, int* nsplit, int* qpb) {
+  int ns = (a.Lq + QR_MAX - 1) / QR_MAX;
+  while ((int64_t)a.B * a.H * ns < 1024 && a.Lq / (ns + 1) >= 128) ++ns;
+  int q = (((a.Lq + ns - 1) / ns) + 31) / 32 * 32;
+  if (q > QR_MAX) q = QR_MAX;
+  *qpb = q;
+  *nsplit = (a.Lq + q - 1) / q;
+}
+
 size_t lmv_attn_mfma_bwd_acc_bytes(const AttnArgs& a) {
-  return 2 * (size_t)a.B * a.H * nkt_for(a.Lk) * 16 * D * sizeof(float);
+  int nsplit, qpb;
+  dkv_split(a, &nsplit, &qpb);
+  return 2 * (size_t)nsplit * a.B * a.H * nkt_for(a.Lk) * 16 * D * sizeof(float);
 }
 
 int lmv_attn_mfma_fwd(const AttnArgs& a, hipStream_t st) {
@@ -791,23 +821,18 @@ int lmv_attn_mfma_bwd(const AttnArgs& a, float* delta, float* acc, hipStream_t s
       default: hipLaunchKernelGGL((mfma_bwd_dq_kernel<14>), grid, block, 0, st, a, delta, per); break;
     }
   }
-  // dK / dV: split the query range so that the grid fills the chip (and fits the LDS images)
-  int nsplit = (a.Lq + QR_MAX - 1) / QR_MAX;
-  while ((int64_t)a.B * a.H * nsplit < 1024 && a.Lq / (nsplit + 1) >= 128) ++nsplit;
-  int qpb = (((a.Lq + nsplit - 1) / nsplit) + 31) / 32 * 32;
-  if (qpb > QR_MAX) qpb = QR_MAX;
-  nsplit = (a.Lq + qpb - 1) / qpb;
+  int nsplit, qpb;
+  dkv_split(a, &nsplit, &qpb);
   dim3 grid(nsplit, a.H, a.B), block(256);
-  const size_t acc_elems = (size_t)a.B * a.H * nkt * 16 * D;
+  const size_t acc_elems = (size_t)nsplit * a.B * a.H * nkt * 16 * D;
   float* acc_k = acc; float* acc_v = acc + acc_elems;
   if (nsplit > 1) {
-    if (hipMemsetAsync(acc, 0, 2 * acc_elems * sizeof(float), st) != hipSuccess) LMV_FAIL(LMV_ERR_LAUNCH, "attn_mfma_bwd: memset failed");
 #define DKV(N, K) hipLaunchKernelGGL((mfma_bwd_dkv_kernel<N, K, true>), grid, block, 0, st, a, delta, acc_k, acc_v, qpb)
     switch (nkt) { case 2: DKV(2, 1); break; case 4: DKV(4, 2); break; case 8: DKV(8, 4); break; default: DKV(14, 4); break; }
 #undef DKV
-    const unsigned n = (unsigned)a.B * a.H * a.Lk * D;
-    hipLaunchKernelGGL(scatter_bf16_kernel, dim3((n + 255) / 256), dim3(256), 0, st, (const float*)acc_k, (bf16_t*)a.dk, a.k_bs, a.k_rs, a.B, a.H, a.Lk, nkt * 16);
-    hipLaunchKernelGGL(scatter_bf16_kernel, dim3((n + 255) / 256), dim3(256), 0, st, (const float*)acc_v, (bf16_t*)a.dv, a.v_bs, a.v_rs, a.B, a.H, a.Lk, nkt * 16);
+    const unsigned n = 2u * (unsigned)a.B * a.H * a.Lk * (D / 4);
+    hipLaunchKernelGGL(scatter_sum_kernel, dim3((n + 255) / 256), dim3(256), 0, st, (const float*)acc_k, (const float*)acc_v, (bf16_t*)a.dk, (bf16_t*)a.dv,
+                       a.k_bs, a.k_rs, a.v_bs, a.v_rs, a.B, a.H, a.Lk, nkt * 16, nsplit);
   } else {
 #define DKV(N, K) hipLaunchKernelGGL((mfma_bwd_dkv_kernel<N, K, false>), grid, block, 0, st, a, delta, acc_k, acc_v, qpb)
     switch (nkt) { case 2: DKV(2, 1); break; case 4: DKV(4, 2); break; case 8: DKV(8, 4); break; default: DKV(14, 4); break; }

@@ -38,18 +38,24 @@ __global__ __launch_bounds__(TPB) void cast_kernel(const S* __restrict__ src, D*
   }
 }
 
+// y[r, :] = x[r, :] * scale[r / rps] for up to TWO row segments per launch (the image-token and the meta-token gradient of a
+// block are scaled by their own DropPath vectors at the same point of the backward pass); 16-byte chunks, 32-bit index math.
+struct RowScaleSeg { const void* x; const float* scale; void* y; unsigned chunks, cpr, rps; };      // chunks = rows * cpr, cpr = C / EPC
+struct RowScaleArgs { RowScaleSeg s[2]; unsigned total; };
+
 template <typename T>
-__global__ __launch_bounds__(TPB) void row_scale_kernel(const T* __restrict__ x, const float* __restrict__ scale, T* __restrict__ y,
-                                                       int64_t rows, int C, int rps) {
-  const unsigned c4 = (unsigned)C >> 2;
-  const unsigned total = (unsigned)rows * c4;              // < 2^31 (checked on the host): 32-bit index math only
-  for (unsigned i = blockIdx.x * TPB + threadIdx.x; i < total; i += gridDim.x * TPB) {
-    const unsigned r = i / c4;
-    const float s = scale[r / (unsigned)rps];
-    float f[4];
-    ld4(x + (size_t)i * 4, f);
-    f[0] *= s; f[1] *= s; f[2] *= s; f[3] *= s;
-    st4(y + (size_t)i * 4, f);
+__global__ __launch_bounds__(TPB) void row_scale_kernel(const RowScaleArgs a) {
+  constexpr int EPC = DT<T>::EPC;
+  for (unsigned i = blockIdx.x * TPB + threadIdx.x; i < a.total; i += gridDim.x * TPB) {
+    const bool second = i >= a.s[0].chunks;
+    const RowScaleSeg& g = a.s[second ? 1 : 0];
+    const unsigned j = second ? i - a.s[0].chunks : i;
+    const float sc = g.scale[(j / g.cpr) / g.rps];
+    float f[EPC];
+    chunk_to_f<T>(reinterpret_cast<const uint4*>(g.x)[j], f);
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) f[e] *= sc;
+    reinterpret_cast<uint4*>(g.y)[j] = f_to_chunk<T>(f);
   }
 }
 
@@ -185,17 +191,39 @@ extern "C" int lmv_im2col3x3s2_c3(const void* x, int x_dtype, void* patches, int
   return LMV_OK;
 }
 
-extern "C" int lmv_row_scale(const void* x, const float* scale, void* y, int64_t rows, int C, int rps, int dtype, void* stream) {
-  if (rows <= 0) return LMV_OK;
-  if (C <= 0 || (C % 8) || rps <= 0) LMV_FAIL(LMV_ERR_SHAPE, "row_scale: C=%d must be a multiple of 8, rows_per_sample=%d > 0", C, rps);
-  if (rows * (C / 4) >= (int64_t)1 << 31) LMV_FAIL(LMV_ERR_SHAPE, "row_scale: tensor too large (%lld x %d)", (long long)rows, C);
+extern "C" int lmv_row_scale_multi(const lmv_row_scale_segment* seg, int nseg, int C, int dtype, void* stream) {
+  if (!seg || nseg < 1 || nseg > 2) LMV_FAIL(LMV_ERR_SHAPE, "row_scale: 1 or 2 segments");
+  if (C <= 0 || (C % 8)) LMV_FAIL(LMV_ERR_SHAPE, "row_scale: C=%d must be a multiple of 8", C);
+  if (dtype != LMV_BF16 && dtype != LMV_F32) LMV_FAIL(LMV_ERR_DTYPE, "row_scale: unsupported dtype %d", dtype);
+  const unsigned cpr = (unsigned)(C / (dtype == LMV_BF16 ? 8 : 4));
+  RowScaleArgs a{};
+  int64_t total = 0;
+  int k = 0;
+  for (int i = 0; i < nseg; ++i) {
+    if (seg[i].rows <= 0) continue;
+    if (seg[i].rows_per_sample <= 0) LMV_FAIL(LMV_ERR_SHAPE, "row_scale: rows_per_sample must be > 0");
+    if (!seg[i].x || !seg[i].y || !seg[i].scale || !lmv_aligned16(seg[i].x) || !lmv_aligned16(seg[i].y)) LMV_FAIL(LMV_ERR_SHAPE, "row_scale: null or misaligned operand");
+    const int64_t chunks = seg[i].rows * cpr;
+    total += chunks;
+    if (total >= (int64_t)1 << 31) LMV_FAIL(LMV_ERR_SHAPE, "row_scale: tensor too large");
+    a.s[k].x = seg[i].x; a.s[k].scale = seg[i].scale; a.s[k].y = seg[i].y;
+    a.s[k].chunks = (unsigned)chunks; a.s[k].cpr = cpr; a.s[k].rps = (unsigned)seg[i].rows_per_sample;
+    ++k;
+  }
+  if (k == 0) return LMV_OK;
+  if (k == 1) { a.s[1] = a.s[0]; a.s[1].chunks = 0; }
+  a.total = (unsigned)total;
   hipStream_t st = (hipStream_t)stream;
-  const int grid = grid_for(rows * (C / 4));
-  if (dtype == LMV_BF16) hipLaunchKernelGGL((row_scale_kernel<bf16_t>), dim3(grid), dim3(TPB), 0, st, (const bf16_t*)x, scale, (bf16_t*)y, rows, C, rps);
-  else if (dtype == LMV_F32) hipLaunchKernelGGL((row_scale_kernel<float>), dim3(grid), dim3(TPB), 0, st, (const float*)x, scale, (float*)y, rows, C, rps);
-  else LMV_FAIL(LMV_ERR_DTYPE, "row_scale: unsupported dtype %d", dtype);
+  const int grid = grid_for(total);
+  if (dtype == LMV_BF16) hipLaunchKernelGGL((row_scale_kernel<bf16_t>), dim3(grid), dim3(TPB), 0, st, a);
+  else hipLaunchKernelGGL((row_scale_kernel<float>), dim3(grid), dim3(TPB), 0, st, a);
   LMV_CHECK_LAUNCH("row_scale");
   return LMV_OK;
+}
+
+extern "C" int lmv_row_scale(const void* x, const float* scale, void* y, int64_t rows, int C, int rps, int dtype, void* stream) {
+  lmv_row_scale_segment s{x, scale, y, rows, rps};
+  return lmv_row_scale_multi(&s, 1, C, dtype, stream);
 }
 
 extern "C" int lmv_adamw_flat(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, const float* wd_mask, int64_t n,

@@ -254,6 +254,26 @@ def row_scale(x: Tensor, scale: Tensor, rows_per_sample: int) -> Tensor:
     return y
 
 
+def row_scale_multi(xs: Sequence[Tensor], scales: Sequence[Optional[Tensor]]) -> List[Tensor]:
+    """DropPath scaling of up to two [B, L, C] tensors (same C) in ONE launch; a None scale passes its tensor through."""
+    todo = [(x, s) for x, s in zip(xs, scales) if s is not None]
+    if not todo:
+        return list(xs)
+    if len(todo) > 2 or len({x.shape[-1] for x, _ in todo}) != 1 or len({x.dtype for x, _ in todo}) != 1:
+        return [x if s is None else row_scale(x, s, x.shape[1]) for x, s in zip(xs, scales)]
+    from ._lib import RowScaleSegment
+    arr = (RowScaleSegment * len(todo))()
+    outs = []
+    for seg, (x, s) in zip(arr, todo):
+        y = torch.empty_like(x)
+        seg.x, seg.scale, seg.y = _ptr(x), _f32(s), _ptr(y)
+        seg.rows, seg.rows_per_sample = x.numel() // x.shape[-1], x.shape[1]
+        outs.append(y)
+    check(lib.lmv_row_scale_multi(arr, len(todo), todo[0][0].shape[-1], dtype_code(todo[0][0]), _stream()), "lmv_row_scale_multi")
+    it = iter(outs)
+    return [x if s is None else next(it) for x, s in zip(xs, scales)]
+
+
 def adamw_flat(param: Tensor, grad: Tensor, exp_avg: Tensor, exp_avg_sq: Tensor, wd_mask: Optional[Tensor], lr: float, beta1: float,
                beta2: float, eps: float, weight_decay: float, step: int) -> None:
     check(lib.lmv_adamw_flat(_f32(param), _f32(grad), _f32(exp_avg), _f32(exp_avg_sq), _f32(wd_mask), param.numel(), lr, beta1, beta2, eps,

@@ -52,16 +52,34 @@ def _is_matrix(name: str) -> bool:
     return name.endswith(".weight") and (name.startswith("attn.") or name.startswith("mlp."))
 
 
+_train_pass = 0          # bumped by every training-mode forward pass: casts made for an earlier pass are not reused
+
+
+def new_training_pass() -> None:
+    global _train_pass
+    _train_pass += 1
+
+
 def compute_copy(p: Tensor, want: torch.dtype) -> Tensor:
-    """Detached tensor with p's values in dtype `want`; casts are cached per parameter version."""
+    """Detached tensor with p's values in dtype `want`.
+
+    Inference: casts are cached per parameter version (load_state_dict / copy_ bump it).  Training: the cache is only
+    valid within ONE forward pass -- fused optimizers (torch.optim.AdamW(fused=True), torch._fused_adamw_) update the
+    parameters in place WITHOUT bumping ``_version``, so a version-keyed cache would keep feeding stale bf16 weights to
+    the kernels.  An optimizer that maintains the bf16 copy itself (lemevit_amd.optim.FlatAdamW) attaches it as
+    ``p._lmv_shadow`` and no cast is launched at all."""
     if p.dtype == want:
         return p.detach()
+    shadow = getattr(p, "_lmv_shadow", None)
+    if shadow is not None and shadow.dtype == want and shadow.device == p.device:
+        return shadow
     key = id(p)
     ent = _copy_cache.get(key)
-    if ent is not None and ent[0]() is p and ent[1] == p._version and ent[2].dtype == want and ent[2].device == p.device:
+    stamp = (p._version, _train_pass, torch.is_grad_enabled() and p.requires_grad)      # a later training pass invalidates inference casts too
+    if ent is not None and ent[0]() is p and ent[1] == stamp and ent[2].dtype == want and ent[2].device == p.device:
         return ent[2]
     t = ops.cast(p.detach().contiguous(), want)
-    _copy_cache[key] = (weakref.ref(p), p._version, t)
+    _copy_cache[key] = (weakref.ref(p), stamp, t)
     return t
 
 
@@ -73,12 +91,13 @@ def _conv1_matrix(weight: Tensor, dtype: torch.dtype) -> Tensor:
     """[Cout, 3, 3, 3] stem weight -> the [Cout, 32] GEMM operand of ops.im2col3x3s2_c3 (columns 27..31 zero), cached per version."""
     key = (id(weight), dtype)
     ent = _conv1_cache.get(key)
-    if ent is not None and ent[0]() is weight and ent[1] == weight._version:
+    stamp = (weight._version, _train_pass, torch.is_grad_enabled() and weight.requires_grad)      # see compute_copy
+    if ent is not None and ent[0]() is weight and ent[1] == stamp:
         return ent[2]
     with torch.no_grad():
         m = torch.zeros(weight.shape[0], 32, device=weight.device, dtype=dtype)
         m[:, :27] = weight.detach().reshape(weight.shape[0], 27)
-    _conv1_cache[key] = (weakref.ref(weight), weight._version, m)
+    _conv1_cache[key] = (weakref.ref(weight), stamp, m)
     return m
 
 
@@ -235,6 +254,8 @@ class StandardAttention(nn.Module):
 
     @torch.no_grad()
     def forward(self, x):
+        if torch.is_grad_enabled():
+            new_training_pass()        # parameters may have been updated in place since the last call (see compute_copy)
         x = x.contiguous()
         C = x.shape[-1]
         qkv = torch.empty(x.shape[:-1] + (3 * C,), device=x.device, dtype=x.dtype)
@@ -260,6 +281,8 @@ class DualCrossAttention(nn.Module):
 
     @torch.no_grad()
     def forward(self, x, c):
+        if torch.is_grad_enabled():
+            new_training_pass()        # parameters may have been updated in place since the last call (see compute_copy)
         x, c = x.contiguous(), c.contiguous()
         C, N, M = x.shape[-1], x.shape[1], c.shape[1]
         sx, sc = ops.dca_scales(N, M, C)
@@ -288,6 +311,8 @@ class DualCrossAttention_v2(nn.Module):
 
     @torch.no_grad()
     def forward(self, x, c):
+        if torch.is_grad_enabled():
+            new_training_pass()        # parameters may have been updated in place since the last call (see compute_copy)
         x, c = x.contiguous(), c.contiguous()
         C, N, M = x.shape[-1], x.shape[1], c.shape[1]
         sx, sc = ops.dca_scales(N, M, C)
@@ -314,6 +339,8 @@ class CrossAttention(nn.Module):
 
     @torch.no_grad()
     def forward(self, x, c):
+        if torch.is_grad_enabled():
+            new_training_pass()        # parameters may have been updated in place since the last call (see compute_copy)
         x, c = x.contiguous(), c.contiguous()
         C = x.shape[-1]
         kv = torch.empty(x.shape[:-1] + (2 * C,), device=x.device, dtype=x.dtype)
@@ -377,6 +404,8 @@ class LeMeBlock(nn.Module):
         return run_block(self.attn_type, x, c, H, W, self._params(), masks)
 
     def forward(self, x: Tensor, c: Tensor) -> Tuple[Tensor, Tensor]:
+        if torch.is_grad_enabled():
+            new_training_pass()        # parameters may have been updated in place since the last call (see compute_copy)
         """Reference signature: x NCHW in / out (models/lemevit.py:652)."""
         B, C, H, W = x.shape
         xt = x.permute(0, 2, 3, 1).reshape(B, H * W, C).contiguous()
@@ -527,6 +556,8 @@ class LeMeViT(nn.Module):
         """models/lemevit.py:809-829.  c = None hoists the batch-invariant meta-token prefix."""
         cd = _resolve_dtype(x)
         B = x.shape[0]
+        if torch.is_grad_enabled():
+            new_training_pass()
         hoist = c is None
         if hoist:
             c = self.meta_tokens.unsqueeze(0)

@@ -268,3 +268,28 @@ def test_full_size_properties_bf16():
     assert torch.isfinite(loss)
     for k, p in m.named_parameters():
         assert p.grad is not None and torch.isfinite(p.grad).all(), k
+
+
+def test_bf16_weight_copies_follow_fused_optimizer():
+    """torch.optim.AdamW(fused=True) updates parameters in place WITHOUT bumping Tensor._version; the bf16 operand copies the
+    kernels read must still be refreshed every training pass (and for the evaluation that follows)."""
+    torch.manual_seed(0)
+    m = L().create_model("lemevit_tiny", num_classes=10).to(DEV).train()
+    opt = torch.optim.AdamW(m.parameters(), lr=5e-2, fused=True)
+    x = torch.randn(4, 3, 64, 64, device=DEV)
+    w = m.stages[2][0].mlp[0].weight
+    from lemevit_amd.model import compute_copy
+    outs = []
+    for _ in range(3):
+        opt.zero_grad(set_to_none=True)
+        with torch.autocast("cuda", torch.bfloat16):
+            out = m(x)
+            out.float().square().mean().backward()
+        assert torch.equal(compute_copy(w, torch.bfloat16), w.detach().to(torch.bfloat16)), "stale bf16 copy inside a training pass"
+        opt.step()
+        outs.append(out.detach().float().clone())
+    assert float((outs[1] - outs[0]).abs().max()) > 0 and float((outs[2] - outs[1]).abs().max()) > 0, "the forward ignores optimizer updates"
+    m.eval()
+    with torch.no_grad(), torch.autocast("cuda", torch.bfloat16):
+        m(x)
+        assert torch.equal(compute_copy(w, torch.bfloat16), w.detach().to(torch.bfloat16)), "stale bf16 copy in evaluation after training"

@@ -48,6 +48,7 @@ def parse():
     ap.add_argument("--img", type=int, default=224)
     ap.add_argument("--mode", default="train", choices=["train", "infer"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--torch-adamw", action="store_true", help="use torch.optim.AdamW(fused=True) instead of lemevit_amd.FlatAdamW at N=1")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--graph", type=int, default=1, help="capture the step into a hipGraph (lemevit_amd.graph.GraphedStep); 0 = eager launches")
     return ap.parse_args()
@@ -166,8 +167,13 @@ def main():
         # benchmark.py:559-561 create_optimizer_v2(opt='adamw', lr=1e-4), scripts/benchmark.sh:8 eps 1e-8 wd 0.05
         decay = [p for n, p in model.named_parameters() if p.ndim > 1]
         no_decay = [p for n, p in model.named_parameters() if p.ndim <= 1]
-        opt = torch.optim.AdamW([dict(params=decay, weight_decay=0.05), dict(params=no_decay, weight_decay=0.0)], lr=1e-4, eps=1e-8, fused=True,
-                                capturable=bool(args.graph))
+        if world == 1 and not args.torch_adamw:
+            # the framework's optimizer: block parameters flat, gradients written in place, one fused AdamW launch that also
+            # refreshes the bf16 operand copies (same update rule; tests/test_model_gpu.py::test_flat_adamw_matches_torch_adamw)
+            opt = lemevit_amd.FlatAdamW(model, lr=1e-4, eps=1e-8, weight_decay=0.05)
+        else:
+            opt = torch.optim.AdamW([dict(params=decay, weight_decay=0.05), dict(params=no_decay, weight_decay=0.0)], lr=1e-4, eps=1e-8, fused=True,
+                                    capturable=bool(args.graph))
         net = wrap_ddp(model, local) if world > 1 else model
 
         def step():

@@ -169,9 +169,14 @@ typedef struct lmv_row_scale_segment {
 } lmv_row_scale_segment;
 int lmv_row_scale_multi(const lmv_row_scale_segment* seg, int nseg, int C, int dtype, void* stream);
 /* Fused multi-tensor AdamW over a flat fp32 parameter / gradient / moment buffer
- * (decoupled weight decay, bias correction as torch.optim.AdamW; benchmark.py:559-561,587). */
-int lmv_adamw_flat(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, const float* wd_mask,
-                   int64_t n, float lr, float beta1, float beta2, float eps, float weight_decay, int step, void* stream);
+ * (decoupled weight decay, bias correction as torch.optim.AdamW; benchmark.py:559-561,587).
+ * wd_mask (nullable): per-element 0/1 factor on weight_decay.  shadow_bf16 (nullable): bf16 copy of the updated parameters,
+ * written in the same pass (the operand copy the block kernels read; no separate cast launches).  step_dev (nullable):
+ * device int holding the 1-based step count -- read by the kernel instead of `step`, so a captured hipGraph replays with
+ * the right bias correction. */
+int lmv_adamw_flat(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, const float* wd_mask, void* shadow_bf16,
+                   int64_t n, float lr, float beta1, float beta2, float eps, float weight_decay, int step, const int* step_dev,
+                   void* stream);
 
 #ifdef __cplusplus
 }

@@ -60,8 +60,14 @@ __global__ __launch_bounds__(TPB) void row_scale_kernel(const RowScaleArgs a) {
 }
 
 __global__ __launch_bounds__(TPB) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
-                                                   float* __restrict__ v, const float* __restrict__ wd_mask, int64_t n, float lr,
-                                                   float b1, float b2, float eps, float wd, float bc1, float bc2_sqrt) {
+                                                   float* __restrict__ v, const float* __restrict__ wd_mask, bf16_t* __restrict__ shadow,
+                                                   const int* __restrict__ step_dev, int64_t n, float lr, float b1, float b2, float eps, float wd,
+                                                   float bc1, float bc2_sqrt) {
+  if (step_dev) {                                   // step count lives on the device (captured graphs replay the launch unchanged)
+    const float t = (float)*step_dev;
+    bc1 = 1.f - powf(b1, t);
+    bc2_sqrt = sqrtf(1.f - powf(b2, t));
+  }
   const int64_t n4 = n >> 2;
   for (int64_t i = blockIdx.x * (int64_t)TPB + threadIdx.x; i < n4; i += (int64_t)gridDim.x * TPB) {
     float4 P = reinterpret_cast<float4*>(p)[i], G = reinterpret_cast<const float4*>(g)[i];
@@ -77,6 +83,7 @@ __global__ __launch_bounds__(TPB) void adamw_kernel(float* __restrict__ p, const
       pp[q] -= (lr / bc1) * mm[q] / denom;
     }
     reinterpret_cast<float4*>(p)[i] = P; reinterpret_cast<float4*>(m)[i] = M; reinterpret_cast<float4*>(v)[i] = V;
+    if (shadow) reinterpret_cast<uint2*>(shadow)[i] = make_uint2(pack_bf2(P.x, P.y), pack_bf2(P.z, P.w));      // bf16 operand copy, refreshed in the same pass
   }
 }
 
@@ -226,15 +233,20 @@ extern "C" int lmv_row_scale(const void* x, const float* scale, void* y, int64_t
   return lmv_row_scale_multi(&s, 1, C, dtype, stream);
 }
 
-extern "C" int lmv_adamw_flat(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, const float* wd_mask, int64_t n,
-                              float lr, float beta1, float beta2, float eps, float weight_decay, int step, void* stream) {
+extern "C" int lmv_adamw_flat(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, const float* wd_mask, void* shadow_bf16,
+                              int64_t n, float lr, float beta1, float beta2, float eps, float weight_decay, int step, const int* step_dev,
+                              void* stream) {
   if (n <= 0) return LMV_OK;
   if (n % 4) LMV_FAIL(LMV_ERR_SHAPE, "adamw_flat: n=%lld must be a multiple of 4 (pad the flat buffer)", (long long)n);
-  if (step < 1) LMV_FAIL(LMV_ERR_SHAPE, "adamw_flat: step must be >= 1");
-  const float bc1 = 1.f - powf(beta1, (float)step);
-  const float bc2_sqrt = sqrtf(1.f - powf(beta2, (float)step));
-  hipLaunchKernelGGL(adamw_kernel, dim3(grid_for(n / 4)), dim3(TPB), 0, (hipStream_t)stream, param, grad, exp_avg, exp_avg_sq, wd_mask, n,
-                     lr, beta1, beta2, eps, weight_decay, bc1, bc2_sqrt);
+  if (!step_dev && step < 1) LMV_FAIL(LMV_ERR_SHAPE, "adamw_flat: step must be >= 1");
+  if (!param || !grad || !exp_avg || !exp_avg_sq || !lmv_aligned16(param) || !lmv_aligned16(grad) || !lmv_aligned16(exp_avg) || !lmv_aligned16(exp_avg_sq) ||
+      !lmv_aligned16(wd_mask) || ((uintptr_t)shadow_bf16 & 7u))
+    LMV_FAIL(LMV_ERR_SHAPE, "adamw_flat: null or misaligned buffer");
+  const float t = step_dev ? 1.f : (float)step;
+  const float bc1 = 1.f - powf(beta1, t);
+  const float bc2_sqrt = sqrtf(1.f - powf(beta2, t));
+  hipLaunchKernelGGL(adamw_kernel, dim3(grid_for(n / 4)), dim3(TPB), 0, (hipStream_t)stream, param, grad, exp_avg, exp_avg_sq, wd_mask,
+                     reinterpret_cast<bf16_t*>(shadow_bf16), step_dev, n, lr, beta1, beta2, eps, weight_decay, bc1, bc2_sqrt);
   LMV_CHECK_LAUNCH("adamw_flat");
   return LMV_OK;
 }

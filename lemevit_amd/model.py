@@ -189,6 +189,7 @@ class _BlockFn(torch.autograd.Function):
         ctx.kind, ctx.H, ctx.W, ctx.masks, ctx.names = kind, H, W, masks, names
         ctx.saved, ctx.P = saved, P
         ctx.pmeta = [(p.shape, p.dtype) for p in params]
+        ctx.params = params
         ctx.cshape = c.shape
         if kind == "C":
             return co                      # x passes through unchanged outside the node (models/lemevit.py:610)
@@ -206,15 +207,24 @@ class _BlockFn(torch.autograd.Function):
             dc = torch.zeros(ctx.cshape, device=x0.device, dtype=x0.dtype)
         if dx is None and kind != "C":
             dx = torch.zeros_like(x0)
-        sizes = [int(torch.Size(s).numel()) for s, _ in ctx.pmeta]
-        pad = [(n + 3) // 4 * 4 for n in sizes]                 # keep every slice 16-byte aligned
-        flat = torch.zeros(sum(pad), device=x0.device, dtype=torch.float32)
-        G, off = {}, 0
-        for n, (shape, _), sz, pd in zip(names, ctx.pmeta, sizes, pad):
-            G[n] = flat[off:off + sz].view(shape)
-            off += pd
+        # lemevit_amd.optim.FlatAdamW keeps every block parameter's .grad as a slice of one flat fp32 buffer: the kernels then
+        # accumulate straight into it and autograd is handed None (no per-parameter accumulation launches)
+        inplace = all(getattr(p, "_lmv_flat_grad", False) and p.grad is not None and p.grad.dtype == torch.float32 and p.grad.is_contiguous()
+                      for p in ctx.params)
+        if inplace:
+            G = {n: p.grad for n, p in zip(names, ctx.params)}
+        else:
+            sizes = [int(torch.Size(s).numel()) for s, _ in ctx.pmeta]
+            pad = [(n + 3) // 4 * 4 for n in sizes]                 # keep every slice 16-byte aligned
+            flat = torch.zeros(sum(pad), device=x0.device, dtype=torch.float32)
+            G, off = {}, 0
+            for n, (shape, _), sz, pd in zip(names, ctx.pmeta, sizes, pad):
+                G[n] = flat[off:off + sz].view(shape)
+                off += pd
         dx0, dc0 = block_backward(kind, ctx.saved, None if dx is None else dx.contiguous(), dc.contiguous(), ctx.H, ctx.W, P, G, ctx.masks)
-        ctx.saved = None
+        ctx.saved = ctx.params = None
+        if inplace:
+            return (dx0, dc0, None, None, None, None, None, *([None] * len(names)))
         pg = [G[n] if dt == torch.float32 else G[n].to(dt) for n, (_, dt) in zip(names, ctx.pmeta)]
         return (dx0, dc0, None, None, None, None, None, *pg)
 

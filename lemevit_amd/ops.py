@@ -275,6 +275,10 @@ def row_scale_multi(xs: Sequence[Tensor], scales: Sequence[Optional[Tensor]]) ->
 
 
 def adamw_flat(param: Tensor, grad: Tensor, exp_avg: Tensor, exp_avg_sq: Tensor, wd_mask: Optional[Tensor], lr: float, beta1: float,
-               beta2: float, eps: float, weight_decay: float, step: int) -> None:
-    check(lib.lmv_adamw_flat(_f32(param), _f32(grad), _f32(exp_avg), _f32(exp_avg_sq), _f32(wd_mask), param.numel(), lr, beta1, beta2, eps,
-                             weight_decay, step, _stream()), "lmv_adamw_flat")
+               beta2: float, eps: float, weight_decay: float, step: int, shadow: Optional[Tensor] = None, step_dev: Optional[Tensor] = None) -> None:
+    if shadow is not None and (shadow.dtype != torch.bfloat16 or shadow.numel() != param.numel()):
+        raise TypeError("adamw_flat: shadow must be a bfloat16 tensor of the parameter buffer's length")
+    if step_dev is not None and step_dev.dtype != torch.int32:
+        raise TypeError("adamw_flat: step_dev must be an int32 device scalar")
+    check(lib.lmv_adamw_flat(_f32(param), _f32(grad), _f32(exp_avg), _f32(exp_avg_sq), _f32(wd_mask), _ptr(shadow), param.numel(), lr, beta1, beta2, eps,
+                             weight_decay, step, _ptr(step_dev), _stream()), "lmv_adamw_flat")

@@ -1,0 +1,116 @@
+"""Flat multi-tensor AdamW for the LeMeBlock parameters (benchmark.py:559-561,587).
+
+``torch.optim.AdamW(fused=True)`` walks the ~450 block parameters of LeMeViT-Base in 16 multi-tensor launches, and every
+training pass then re-casts the 146 weight matrices to bf16 for the kernels (fused optimizers update in place without
+bumping ``Tensor._version``, so those casts cannot be cached: see model.compute_copy).  Here the block parameters live in
+ONE flat fp32 buffer, their gradients in ONE flat fp32 buffer that the block backward writes straight into
+(``_BlockFn`` accumulates into ``p.grad`` and hands autograd ``None``), and one launch of ``lmv_adamw_flat`` updates
+everything and refreshes the bf16 operand copies in the same pass.  The handful of non-block parameters (stem, stage
+transitions, meta-token MLPs, norms, head) stay on ``torch.optim.AdamW(fused=True)``.
+
+Not for DistributedDataParallel: DDP's reducer waits for autograd's AccumulateGrad hooks, which never fire for
+gradients written in place -- wrap the model in DDP with a regular optimizer instead (bench.py does that for N > 1).
+"""
+from __future__ import annotations
+
+from typing import Callable, Dict, Iterable, List, Optional, Tuple
+
+import torch
+import torch.nn as nn
+
+from . import ops
+
+Tensor = torch.Tensor
+_ALIGN = 8          # elements: 32-byte fp32 / 16-byte bf16 alignment of every parameter's slice
+
+
+def _default_no_decay(name: str, p: Tensor) -> bool:
+    return p.ndim <= 1          # biases, LayerNorm / BatchNorm affine, as benchmark.py's create_optimizer_v2 (filter_bias_and_bn)
+
+
+class FlatAdamW:
+    """AdamW over ``model``: block parameters flat + fused into one launch, everything else ``torch.optim.AdamW(fused=True)``.
+
+    Interface: ``step()``, ``zero_grad()``, ``param_groups`` (one dict per group with ``lr`` -- schedulers may edit it),
+    ``state_dict()`` / ``load_state_dict()``, ``refresh()`` (re-derive the bf16 copies after the parameters were
+    changed by something else; done automatically after ``model.load_state_dict``)."""
+
+    def __init__(self, model: nn.Module, lr: float = 1e-3, betas: Tuple[float, float] = (0.9, 0.999), eps: float = 1e-8,
+                 weight_decay: float = 1e-2, no_decay: Callable[[str, Tensor], bool] = _default_no_decay, capturable: bool = True):
+        from .model import LeMeBlock, _is_matrix
+        self.betas, self.eps, self.weight_decay = betas, eps, weight_decay
+        flat_named: List[Tuple[str, nn.Parameter, bool]] = []        # (name, param, wants bf16 copy)
+        seen = set()
+        for mname, mod in model.named_modules():
+            if isinstance(mod, LeMeBlock):
+                for pname, p in mod.named_parameters():
+                    if p.requires_grad and id(p) not in seen and p.dtype == torch.float32 and p.is_cuda:
+                        seen.add(id(p))
+                        flat_named.append((f"{mname}.{pname}", p, _is_matrix(pname)))
+        if not flat_named:
+            raise ValueError("FlatAdamW: the model has no fp32 LeMeBlock parameters on the GPU")
+        dev = flat_named[0][1].device
+        offs, total = [], 0
+        for _, p, _m in flat_named:
+            offs.append(total)
+            total += (p.numel() + _ALIGN - 1) // _ALIGN * _ALIGN
+        self._flat_p = torch.zeros(total, device=dev)
+        self._flat_g = torch.zeros(total, device=dev)
+        self._exp_avg = torch.zeros(total, device=dev)
+        self._exp_avg_sq = torch.zeros(total, device=dev)
+        self._wd_mask = torch.zeros(total, device=dev)
+        self._shadow = torch.zeros(total, device=dev, dtype=torch.bfloat16)
+        self._step_dev = torch.zeros((), device=dev, dtype=torch.int32)
+        self._slices: List[Tuple[str, nn.Parameter, int, int]] = []
+        with torch.no_grad():
+            for (name, p, matrix), off in zip(flat_named, offs):
+                n = p.numel()
+                self._flat_p[off:off + n].copy_(p.detach().reshape(-1))
+                p.data = self._flat_p[off:off + n].view(p.shape)
+                p.grad = self._flat_g[off:off + n].view(p.shape)
+                p._lmv_flat_grad = True                               # _BlockFn.backward accumulates into p.grad in place
+                if not no_decay(name, p):
+                    self._wd_mask[off:off + n] = 1.0
+                if matrix:
+                    p._lmv_shadow = self._shadow[off:off + n].view(p.shape)
+                self._slices.append((name, p, off, n))
+        self.refresh()
+        rest_decay = [p for n, p in model.named_parameters() if p.requires_grad and id(p) not in seen and not no_decay(n, p)]
+        rest_plain = [p for n, p in model.named_parameters() if p.requires_grad and id(p) not in seen and no_decay(n, p)]
+        groups = [g for g in (dict(params=rest_decay, weight_decay=weight_decay), dict(params=rest_plain, weight_decay=0.0)) if g["params"]]
+        self._rest = torch.optim.AdamW(groups, lr=lr, betas=betas, eps=eps, fused=True, capturable=capturable) if groups else None
+        self.param_groups = [dict(lr=lr, name="lemevit_blocks_flat")] + (self._rest.param_groups if self._rest else [])
+        self._hook = model.register_load_state_dict_post_hook(lambda *_: self.refresh())
+
+    # ---- the optimizer interface ---------------------------------------------------------------------------------
+    def zero_grad(self, set_to_none: bool = True) -> None:
+        self._flat_g.zero_()                                           # the flat gradients stay allocated: the kernels accumulate into them
+        if self._rest is not None:
+            self._rest.zero_grad(set_to_none=set_to_none)
+
+    @torch.no_grad()
+    def step(self) -> None:
+        if self._rest is not None:
+            self._rest.step()
+        self._step_dev += 1
+        ops.adamw_flat(self._flat_p, self._flat_g, self._exp_avg, self._exp_avg_sq, self._wd_mask, float(self.param_groups[0]["lr"]),
+                       self.betas[0], self.betas[1], self.eps, self.weight_decay, 0, shadow=self._shadow, step_dev=self._step_dev)
+
+    @torch.no_grad()
+    def refresh(self) -> None:
+        """bf16 operand copies <- current fp32 parameters."""
+        self._shadow.copy_(self._flat_p)
+
+    def state_dict(self) -> Dict[str, object]:
+        return dict(step=int(self._step_dev.item()), exp_avg=self._exp_avg.clone(), exp_avg_sq=self._exp_avg_sq.clone(),
+                    names=[(n, off, k) for n, _, off, k in self._slices], lr=self.param_groups[0]["lr"],
+                    rest=None if self._rest is None else self._rest.state_dict())
+
+    def load_state_dict(self, sd: Dict[str, object]) -> None:
+        if [(n, off, k) for n, _, off, k in self._slices] != list(sd["names"]):
+            raise ValueError("FlatAdamW.load_state_dict: parameter layout differs")
+        self._step_dev.fill_(int(sd["step"]))
+        self._exp_avg.copy_(sd["exp_avg"]); self._exp_avg_sq.copy_(sd["exp_avg_sq"])
+        self.param_groups[0]["lr"] = sd["lr"]
+        if self._rest is not None and sd.get("rest") is not None:
+            self._rest.load_state_dict(sd["rest"])

@@ -293,3 +293,37 @@ def test_bf16_weight_copies_follow_fused_optimizer():
     with torch.no_grad(), torch.autocast("cuda", torch.bfloat16):
         m(x)
         assert torch.equal(compute_copy(w, torch.bfloat16), w.detach().to(torch.bfloat16)), "stale bf16 copy in evaluation after training"
+
+
+def test_flat_adamw_matches_torch_adamw():
+    """lemevit_amd.FlatAdamW (flat block parameters, gradients written in place by the block backward, one fused launch that
+    also refreshes the bf16 operand copies) against torch.optim.AdamW on a twin model: same losses and parameters after 3
+    bf16-autocast steps, and the bf16 copies equal the rounded parameters."""
+    torch.manual_seed(0)
+    Lm = L()
+    m1 = Lm.create_model("lemevit_tiny", num_classes=10).to(DEV).train()
+    m2 = Lm.create_model("lemevit_tiny", num_classes=10).to(DEV).train()
+    m2.load_state_dict(m1.state_dict())
+    decay = [p for n, p in m1.named_parameters() if p.ndim > 1]; plain = [p for n, p in m1.named_parameters() if p.ndim <= 1]
+    o1 = torch.optim.AdamW([dict(params=decay, weight_decay=0.05), dict(params=plain, weight_decay=0.0)], lr=1e-3, eps=1e-8)
+    o2 = Lm.FlatAdamW(m2, lr=1e-3, eps=1e-8, weight_decay=0.05)
+    x = torch.randn(4, 3, 64, 64, device=DEV); y = torch.randint(0, 10, (4,), device=DEV)
+    lf = torch.nn.CrossEntropyLoss()
+    for step in range(3):
+        losses = []
+        for m, o in ((m1, o1), (m2, o2)):
+            o.zero_grad(set_to_none=True)
+            with torch.autocast("cuda", torch.bfloat16):
+                loss = lf(m(x), y)
+            loss.backward()
+            o.step()
+            losses.append(float(loss.detach()))
+        assert abs(losses[0] - losses[1]) <= 2e-3 * max(1.0, abs(losses[0])), (step, losses)
+    for (n, p1), (_, p2) in zip(m1.named_parameters(), m2.named_parameters()):
+        d = float((p1 - p2).abs().max()); s = float(p1.abs().max()) + 1e-12
+        assert d <= 5e-3 * s + 3e-3, f"{n}: {d:.3e} vs scale {s:.3e}"      # 3 Adam steps of lr 1e-3 move a weight by <= 3e-3
+    w = m2.stages[2][0].mlp[0].weight
+    assert torch.equal(w._lmv_shadow, w.detach().to(torch.bfloat16))
+    sd = m1.state_dict()
+    m2.load_state_dict(sd)                                   # post-hook refreshes the bf16 copies
+    assert torch.equal(w._lmv_shadow, w.detach().to(torch.bfloat16))

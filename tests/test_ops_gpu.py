@@ -261,10 +261,24 @@ def test_adamw_flat():
     p = det_tensor((n,), "p", 7).to(dev()); g = det_tensor((n,), "g", 7, 0.1).to(dev())
     pr = torch.nn.Parameter(p.clone()); opt = torch.optim.AdamW([pr], lr=1e-2, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.05)
     m = torch.zeros_like(p); v = torch.zeros_like(p)
+    shadow = torch.zeros(n, device=dev(), dtype=torch.bfloat16)
     for step in range(1, 4):
         pr.grad = g.clone(); opt.step()
-        o.adamw_flat(p, g, m, v, None, 1e-2, 0.9, 0.999, 1e-8, 0.05, step)
+        o.adamw_flat(p, g, m, v, None, 1e-2, 0.9, 0.999, 1e-8, 0.05, step, shadow=shadow)
     assert_close(p, pr.detach().cpu(), torch.float32, "adamw", 1e-5)
+    assert torch.equal(shadow, p.to(torch.bfloat16)), "bf16 shadow must be the rounded updated parameters"
+    # step count on the device (captured graphs) + per-element weight-decay mask
+    p2 = det_tensor((n,), "p", 7).to(dev()); m2 = torch.zeros_like(p2); v2 = torch.zeros_like(p2)
+    mask = (torch.arange(n, device=dev()) % 3 == 0).float()
+    pa = torch.nn.Parameter(p2[mask.bool()].clone()); pb = torch.nn.Parameter(p2[~mask.bool()].clone())
+    opt2 = torch.optim.AdamW([dict(params=[pa], weight_decay=0.05), dict(params=[pb], weight_decay=0.0)], lr=1e-2, eps=1e-8)
+    sd = torch.zeros((), device=dev(), dtype=torch.int32)
+    for _ in range(3):
+        pa.grad = g[mask.bool()].clone(); pb.grad = g[~mask.bool()].clone(); opt2.step()
+        sd += 1
+        o.adamw_flat(p2, g, m2, v2, mask, 1e-2, 0.9, 0.999, 1e-8, 0.05, 0, step_dev=sd)
+    assert_close(p2[mask.bool()], pa.detach().cpu(), torch.float32, "adamw masked decay", 1e-5)
+    assert_close(p2[~mask.bool()], pb.detach().cpu(), torch.float32, "adamw no decay", 1e-5)
 
 
 @pytest.mark.parametrize("dtype", DTYPES)

@@ -48,9 +48,14 @@ def parse():
     ap.add_argument("--img", type=int, default=224)
     ap.add_argument("--mode", default="train", choices=["train", "infer"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--ddp", action="store_true", help="N > 1: torch DistributedDataParallel + torch AdamW instead of FlatAdamW + FlatGradSync")
+    ap.add_argument("--force-sync", action="store_true", help="run the FlatGradSync collectives even at world size 1 (1-rank process group)")
+    ap.add_argument("--force-ddp", action="store_true", help="wrap in DDP (and use the DDP code path) even at world size 1: measures the wrapper's overhead")
     ap.add_argument("--torch-adamw", action="store_true", help="use torch.optim.AdamW(fused=True) instead of lemevit_amd.FlatAdamW at N=1")
     ap.add_argument("--no-kernel-timing", action="store_true")
-    ap.add_argument("--graph", type=int, default=1, help="capture the step into a hipGraph (lemevit_amd.graph.GraphedStep); 0 = eager launches")
+    ap.add_argument("--graph", type=int, default=0, help="1 = capture the step into a hipGraph (lemevit_amd.graph.GraphedStep) and replay it; default 0 = "
+                    "eager launches, which are faster here: the weight-gradient GEMMs overlap the dX chain on a side stream, and the "
+                    "runtime serialises the branches of a captured graph (38.0 vs 39.6 ms per step)")
     return ap.parse_args()
 
 
@@ -145,9 +150,6 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
 
@@ -163,18 +165,33 @@ def main():
     timer = GemmTimer()
     if rank == 0 and not args.no_kernel_timing:
         timer.install()
+    # The process group is created AFTER the model: with RCCL initialised first, every step of this workload is ~3 ms slower
+    # even when no collective runs (measured with a 1-rank group, tools/cpu_launch_time.py --pg-first); all ranks seed
+    # identically and FlatGradSync / DDP broadcast rank 0's parameters anyway.
+    if world > 1 or args.force_ddp or args.force_sync:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
     if train:
         # benchmark.py:559-561 create_optimizer_v2(opt='adamw', lr=1e-4), scripts/benchmark.sh:8 eps 1e-8 wd 0.05
         decay = [p for n, p in model.named_parameters() if p.ndim > 1]
         no_decay = [p for n, p in model.named_parameters() if p.ndim <= 1]
-        if world == 1 and not args.torch_adamw:
+        use_ddp = (world > 1 and args.ddp) or args.force_ddp
+        gsync = None
+        if not use_ddp and not args.torch_adamw:
             # the framework's optimizer: block parameters flat, gradients written in place, one fused AdamW launch that also
             # refreshes the bf16 operand copies (same update rule; tests/test_model_gpu.py::test_flat_adamw_matches_torch_adamw)
             opt = lemevit_amd.FlatAdamW(model, lr=1e-4, eps=1e-8, weight_decay=0.05)
+            if world > 1 or args.force_sync:
+                # data parallelism without a DDP wrapper: the flat block-gradient buffer is all-reduced in 4 large chunks, each as soon
+                # as the backward pass has written it (lemevit_amd/dist.py::FlatGradSync)
+                from lemevit_amd.dist import attach_flat_grad_sync
+                gsync = attach_flat_grad_sync(model, opt, force=args.force_sync)
         else:
             opt = torch.optim.AdamW([dict(params=decay, weight_decay=0.05), dict(params=no_decay, weight_decay=0.0)], lr=1e-4, eps=1e-8, fused=True,
                                     capturable=bool(args.graph))
-        net = wrap_ddp(model, local) if world > 1 else model
+        net = wrap_ddp(model, local) if use_ddp else model
 
         def step():
             opt.zero_grad(set_to_none=True)
@@ -182,6 +199,8 @@ def main():
                 out = net(x)
                 target = torch.empty((args.batch,), device=dev, dtype=torch.long).random_(1000)
                 loss_fn(out, target).backward()
+            if gsync is not None:
+                gsync.finish()
             opt.step()
     else:
         def step():
@@ -193,30 +212,30 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    eager_step, graph_note = step, "eager"
-    if args.graph and world == 1:
+    eager_step, graph_note = step, "eager, weight-gradient GEMMs on a side stream"
+    if args.graph and world == 1 and not args.force_ddp and not args.force_sync:
         from lemevit_amd.graph import try_graphed
         step, why = try_graphed(eager_step, warmup=3)
         graph_note = "hipGraph replay" if why is None else f"eager (graph capture failed: {why})"
     for _ in range(args.warmup):
         step()
     sync()
-    timer.enabled = step is eager_step                 # HIP events cannot be timed inside a captured graph
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     sync()
     dt = time.perf_counter() - t0
-    timer.enabled = False
-    kernel_timing_note = "HIP events around every launch inside the timed region"
-    if step is not eager_step and rank == 0 and not args.no_kernel_timing:
-        # same kernels, same shapes: bracket the launches of 3 eager steps right after the timed (graph-replay) region
-        timer.enabled = True
+    kernel_timing_note = None
+    if not args.no_kernel_timing:
+        # Same kernels, same shapes: every forward-GEMM launch of 3 eager steps run right AFTER the timed region is bracketed by HIP
+        # events on rank 0 (events cannot be timed inside a captured graph, and in eager mode they cost ~1 ms per step, which
+        # must not leak into `value`).  All ranks run the 3 steps: they contain the gradient collectives.
+        timer.enabled = rank == 0
         for _ in range(3):
             eager_step()
-        torch.cuda.synchronize()
+        sync()
         timer.enabled = False
-        kernel_timing_note = "HIP events around every launch of 3 eager steps run right after the timed hipGraph-replay region"
+        kernel_timing_note = "HIP events around every launch of 3 eager steps run right after the timed region"
     tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -259,7 +278,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args.model, args.img, args.mode)
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 

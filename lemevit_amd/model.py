@@ -222,7 +222,10 @@ class _BlockFn(torch.autograd.Function):
                 G[n] = flat[off:off + sz].view(shape)
                 off += pd
         dx0, dc0 = block_backward(kind, ctx.saved, None if dx is None else dx.contiguous(), dc.contiguous(), ctx.H, ctx.W, P, G, ctx.masks)
+        cb = getattr(ctx.params[0], "_lmv_grad_cb", None) if inplace else None
         ctx.saved = ctx.params = None
+        if cb is not None:
+            cb()                     # lemevit_amd.dist.FlatGradSync: this block closes a chunk of the flat gradient buffer -> start its all-reduce
         if inplace:
             return (dx0, dc0, None, None, None, None, None, *([None] * len(names)))
         pg = [G[n] if dt == torch.float32 else G[n].to(dt) for n, (_, dt) in zip(names, ctx.pmeta)]

@@ -56,6 +56,39 @@ def test_ddp_gradients_match_single_process(tmp_path, bf16):
     assert abs(float(got["loss"]) - float(loss)) < 1e-6
 
 
+def _sync_worker(rank, world, port, out):
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    from lemevit_amd import dist as D
+    D.init_distributed("gloo")
+    torch.manual_seed(100 + rank)
+    flat = torch.randn(1000)                                       # this rank's flat block gradients
+    rest = [torch.nn.Parameter(torch.zeros(7, 3)), torch.nn.Parameter(torch.zeros(5)), torch.nn.Parameter(torch.zeros(2, 2))]
+    for p in rest[:2]:
+        p.grad = torch.randn_like(p)                               # the third parameter has no gradient this step
+    mine = dict(flat=flat.clone(), rest=[None if p.grad is None else p.grad.clone() for p in rest])
+    sync = D.FlatGradSync(flat, [(0, 300), (300, 640), (640, 1000)], rest)
+    sync.chunk_ready(2)                                            # the backward pass finishes the LAST chunk first
+    sync.chunk_ready(1)
+    sync.finish()                                                  # sends chunk 0 and the remaining parameters, waits, averages
+    torch.save(dict(mine=mine, flat=flat, rest=[None if p.grad is None else p.grad for p in rest]), out + f".{rank}")
+    torch.distributed.destroy_process_group()
+
+
+def test_flat_grad_sync_two_ranks(tmp_path):
+    """FlatGradSync (the DDP-free exchange used with FlatAdamW): after finish() every rank holds the MEAN of the ranks' flat
+    gradients and of the remaining parameters' gradients, whatever order the chunks were released in."""
+    out = str(tmp_path / "s.pt")
+    mp.spawn(_sync_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    r0, r1 = torch.load(out + ".0"), torch.load(out + ".1")
+    want = (r0["mine"]["flat"] + r1["mine"]["flat"]) / 2
+    assert torch.allclose(r0["flat"], want, atol=1e-6) and torch.allclose(r1["flat"], want, atol=1e-6)
+    for i in range(2):
+        w = (r0["mine"]["rest"][i] + r1["mine"]["rest"][i]) / 2
+        assert torch.allclose(r0["rest"][i], w, atol=1e-6) and torch.allclose(r1["rest"][i], w, atol=1e-6)
+    assert r0["rest"][2] is None and r1["rest"][2] is None
+
+
 def test_shard_batch():
     from lemevit_amd.dist import shard_batch
     assert [list(shard_batch(8, r, 4)) for r in range(4)] == [[0, 1], [2, 3], [4, 5], [6, 7]]

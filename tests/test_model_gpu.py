@@ -321,9 +321,54 @@ def test_flat_adamw_matches_torch_adamw():
         assert abs(losses[0] - losses[1]) <= 2e-3 * max(1.0, abs(losses[0])), (step, losses)
     for (n, p1), (_, p2) in zip(m1.named_parameters(), m2.named_parameters()):
         d = float((p1 - p2).abs().max()); s = float(p1.abs().max()) + 1e-12
-        assert d <= 5e-3 * s + 3e-3, f"{n}: {d:.3e} vs scale {s:.3e}"      # 3 Adam steps of lr 1e-3 move a weight by <= 3e-3
+        # 3 Adam steps of lr 1e-3 move a weight by <= 3e-3; where the true gradient is ~0 (conv bias in front of BatchNorm) the
+        # SIGN of the update is rounding noise, so two correct implementations may differ by twice that
+        assert d <= 5e-3 * s + 6.5e-3, f"{n}: {d:.3e} vs scale {s:.3e}"
     w = m2.stages[2][0].mlp[0].weight
     assert torch.equal(w._lmv_shadow, w.detach().to(torch.bfloat16))
     sd = m1.state_dict()
     m2.load_state_dict(sd)                                   # post-hook refreshes the bf16 copies
     assert torch.equal(w._lmv_shadow, w.detach().to(torch.bfloat16))
+
+
+def test_flat_grad_sync_single_rank_nccl():
+    """FlatGradSync over RCCL with a 1-rank process group: the chunked asynchronous all-reduces hooked into the block backward,
+    the flattened exchange of the remaining gradients and the buffer broadcast must leave a training step unchanged."""
+    import os
+    import torch.distributed as dist
+    from lemevit_amd.dist import attach_flat_grad_sync
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29541")
+    created = not dist.is_initialized()
+    if created:
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device(DEV))
+    try:
+        torch.manual_seed(0)
+        Lm = L()
+        m1 = Lm.create_model("lemevit_tiny", num_classes=10).to(DEV).train()
+        m2 = Lm.create_model("lemevit_tiny", num_classes=10).to(DEV).train()
+        m2.load_state_dict(m1.state_dict())
+        o1 = Lm.FlatAdamW(m1, lr=1e-3, weight_decay=0.05); o2 = Lm.FlatAdamW(m2, lr=1e-3, weight_decay=0.05)
+        sync = attach_flat_grad_sync(m2, o2, nchunks=3, force=True)
+        assert sync.active and len(sync.bounds) == 3 and sync.bounds[0][0] == 0 and sync.bounds[-1][1] == o2._flat_g.numel()
+        x = torch.randn(4, 3, 64, 64, device=DEV); y = torch.randint(0, 10, (4,), device=DEV)
+        for _ in range(1):                              # one step: MIOpen's convolution weight gradients are not run-to-run reproducible,
+            for m, o, s in ((m1, o1, None), (m2, o2, sync)):      # (neither are its data gradients), so only the LAST stage's parameters after the first step can be compared bit for bit
+                torch.manual_seed(7)                       # same DropPath draws for both twins
+                o.zero_grad()
+                if s is not None:
+                    s.broadcast_buffers(m)
+                with torch.autocast("cuda", torch.bfloat16):
+                    loss = torch.nn.functional.cross_entropy(m(x), y)
+                loss.backward()
+                if s is not None:
+                    assert len(s._work) >= 1, "no chunk was released during the backward pass"
+                    s.finish()
+                o.step()
+        for (n, p1), (_, p2) in zip(m1.named_parameters(), m2.named_parameters()):
+            if n.startswith("stages.4."):                  # the last stage: no MIOpen convolution between it and the loss
+                assert torch.equal(p1, p2), n
+            else:
+                assert float((p1 - p2).abs().max()) <= 2.5e-3, n     # at most the two lr-sized Adam moves of a ~zero-gradient entry
+    finally:
+        if created:
+            dist.destroy_process_group()

@@ -27,7 +27,14 @@ def dtype_code(t: Tensor) -> int:
     raise TypeError(f"lemevit_amd: unsupported dtype {t.dtype} (float32 and bfloat16 only)")
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
 def _stream() -> int:
+    """Raw handle of the current HIP stream of the current device.  (torch.cuda.current_stream().cuda_stream builds a Python
+    Stream object per call: ~8 us, i.e. ~6 ms of host time per train step at ~700 launches.)"""
+    if _raw_stream is not None:
+        return _raw_stream(torch.cuda.current_device())
     return torch.cuda.current_stream().cuda_stream
 
 
@@ -47,7 +54,7 @@ _ws_cache = {}
 def _workspace(nbytes: int, device) -> Tensor:
     """Scratch for the split reductions, one per (device, stream); stream-ordered reuse is safe because every consumer
     of the scratch is enqueued on the same stream before the next producer."""
-    key = (device, torch.cuda.current_stream().cuda_stream)
+    key = (device, _stream())
     ws = _ws_cache.get(key)
     if ws is None or ws.numel() < nbytes:
         ws = torch.empty(max(int(nbytes * 1.25), 1 << 22), device=device, dtype=torch.uint8)

@@ -151,6 +151,7 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     torch.cuda.set_device(local)
+    torch.backends.cudnn.benchmark = True      # as the reference's harness (benchmark.py:76): MIOpen searches its solvers for the stem / stage-transition convolutions
     dev = torch.device("cuda", local)
 
     import lemevit_amd

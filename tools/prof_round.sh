@@ -9,8 +9,12 @@ rocprofv3 --kernel-trace --stats -d $O/kt -o trace -- python bench.py --no-cpu-b
 DB=$(find $O/kt -name "*.db" | head -1)
 python tools/rocpd_stats.py $DB > $O/train_kernel_stats_full.csv
 python tools/rocpd_stats.py $DB 400 > $O/train_kernel_stats_steady.csv
-python tools/step_breakdown.py $DB $O/bench_under_rocprof.log 3 > $O/train_step_breakdown.csv
 rm -rf $O/kt
+# per-step breakdown with the weight-gradient GEMMs in line (side-stream overlap inflates per-kernel durations)
+LMV_SIDE_STREAM=0 rocprofv3 --kernel-trace -d $O/kt2 -o trace -- python bench.py --steps 6 --warmup 3 --no-cpu-baseline > $O/bench_inline_under_rocprof.log 2>&1
+DB2=$(find $O/kt2 -name "*.db" | head -1)
+python tools/step_breakdown.py $DB2 $O/bench_inline_under_rocprof.log 3 > $O/train_step_breakdown.csv
+rm -rf $O/kt2
 python tools/bench_kernels.py gemm attn > $O/kernel_microbench.txt 2>&1
 bash tools/probe_prof.sh tools/ln_probe.py > $O/ln_kernel_durations.txt 2>&1
 bash tools/probe_prof.sh tools/conv_probe.py > $O/conv_kernel_durations.txt 2>&1

@@ -45,7 +45,7 @@ PARAM_NAMES = {
 # idle, is filled by the other stream's workgroups.  The fork / join are stream waits (capturable into a hipGraph);
 # operands of in-flight side launches are kept referenced until the join so the caching allocator cannot recycle them.
 _SIDE = os.environ.get("LMV_SIDE_STREAM", "1") != "0"
-_side_streams: Dict[torch.device, "torch.cuda.Stream"] = {}
+_side_streams: Dict[int, tuple] = {}          # device index -> (side stream, its raw handle, fork event, join event)
 _inflight: List[object] = []
 
 
@@ -55,19 +55,23 @@ def _dw(probs, N: int, K: int) -> None:
     if not _SIDE or torch.cuda.is_current_stream_capturing():
         ops.linear_dw(probs, N, K)
         return
-    main = torch.cuda.current_stream()
-    side = _side_streams.get(main.device)
-    if side is None:
-        side = _side_streams[main.device] = torch.cuda.Stream(device=main.device)
-    side.wait_stream(main)
-    with torch.cuda.stream(side):
-        ops.linear_dw(probs, N, K)
-    _inflight.append((side, probs))
+    dev = probs[0].a.device
+    ent = _side_streams.get(dev.index)
+    if ent is None:
+        side = torch.cuda.Stream(device=dev)
+        ent = _side_streams[dev.index] = (side, side.cuda_stream, torch.cuda.Event(), torch.cuda.Event())
+    side, raw, fork, _ = ent
+    fork.record()                                   # on the current (main) stream: the operands are ready
+    side.wait_event(fork)
+    ops.linear_dw(probs, N, K, stream=raw)          # launched on the side stream by handle: no current-stream switch
+    _inflight.append(probs)
 
 
 def _join() -> None:
     if _inflight:
-        torch.cuda.current_stream().wait_stream(_inflight[-1][0])
+        side, _, _, join = _side_streams[_inflight[-1][0].a.device.index]
+        join.record(side)
+        torch.cuda.current_stream(side.device).wait_event(join)
         _inflight.clear()
 
 

@@ -51,10 +51,10 @@ def _ptr(t: Optional[Tensor]) -> Optional[int]:
 _ws_cache = {}
 
 
-def _workspace(nbytes: int, device) -> Tensor:
+def _workspace(nbytes: int, device, stream: Optional[int] = None) -> Tensor:
     """Scratch for the split reductions, one per (device, stream); stream-ordered reuse is safe because every consumer
     of the scratch is enqueued on the same stream before the next producer."""
-    key = (device, _stream())
+    key = (device, _stream() if stream is None else stream)
     ws = _ws_cache.get(key)
     if ws is None or ws.numel() < nbytes:
         ws = torch.empty(max(int(nbytes * 1.25), 1 << 22), device=device, dtype=torch.uint8)
@@ -101,11 +101,13 @@ def linear_dx(probs: Sequence[Prob], N: int, K: int, act: int = ACT_NONE) -> Non
     check(lib.lmv_linear_dx(_pack(probs), len(probs), N, K, act, dtype_code(probs[0].a), _stream()), "lmv_linear_dx")
 
 
-def linear_dw(probs: Sequence[Prob], N: int, K: int) -> None:
-    """out (fp32 [N,K]) += a^T @ w ; bias_grad (fp32 [N]) += colsum(a); a = dY [rows,N], w = X [rows,K]."""
+def linear_dw(probs: Sequence[Prob], N: int, K: int, stream: Optional[int] = None) -> None:
+    """out (fp32 [N,K]) += a^T @ w ; bias_grad (fp32 [N]) += colsum(a); a = dY [rows,N], w = X [rows,K].
+    stream: raw HIP stream handle to launch on (default: the current stream); the scratch is per stream."""
     arr, code = _pack(probs), dtype_code(probs[0].a)
-    ws = _workspace(lib.lmv_linear_dw_workspace_bytes(arr, len(probs), N, K, code), probs[0].a.device)
-    check(lib.lmv_linear_dw(arr, len(probs), N, K, ws.data_ptr(), ws.numel(), code, _stream()), "lmv_linear_dw")
+    st = _stream() if stream is None else stream
+    ws = _workspace(lib.lmv_linear_dw_workspace_bytes(arr, len(probs), N, K, code), probs[0].a.device, st)
+    check(lib.lmv_linear_dw(arr, len(probs), N, K, ws.data_ptr(), ws.numel(), code, st), "lmv_linear_dw")
 
 
 # -------------------------------------------------------------------------------------------

@@ -235,11 +235,11 @@ template <> __device__ __forceinline__ float act_gelu_grad<float>(float x) { ret
 template <> __device__ __forceinline__ float act_gelu_grad<bf16_t>(float x) { return gelu_grad_fast_f(x); }
 
 // ---- coalesced epilogue: fp32 tile -> swizzled LDS (64 rows per pass) -> 16-byte row-major stores --------------
-// PRE = true : out_pre = acc + bias                      (pre-activation copy kept for the backward pass)
-// PRE = false: out = res + row_scale * act(acc + bias)   (act = GELU here; GELU' (x aux) applied in phase B)
+// out_pre = acc + bias (optional pre-activation copy for the backward pass) and out = res + row_scale * act(acc + bias)
+// (act = GELU, or x GELU'(aux) for dX) leave in ONE pass: the transposed fp32 tile is read back once and stored twice.
 // Every wave transposes ITS OWN 64-column strip through a private LDS region (no workgroup barrier, all waves busy):
 // RPP rows per pass, a row of 64 fp32 = 16 float4 chunks, chunk c of row r stored at c ^ (r & 7).
-template <typename T, bool PRE, typename CF, int REGION_BYTES>
+template <typename T, typename CF, int REGION_BYTES>
 __device__ __forceinline__ void store_tile(unsigned char* smem, const f32x4_t (&acc)[CF::WM][4], const Problem& P, int act, int N, int64_t ldc,
                                            int m0, int n0, int wm, int wn, int lane, int wave) {
   constexpr int EPC = DT<T>::EPC;
@@ -247,7 +247,8 @@ __device__ __forceinline__ void store_tile(unsigned char* smem, const f32x4_t (&
   constexpr int RPP = REGION_BYTES >= 16384 ? 64 : (REGION_BYTES >= 8192 ? 32 : 16);
   static_assert(REGION_BYTES >= RPP * 256 && (CF::WM * 16) % RPP == 0, "per-wave epilogue region too small");
   float* sT = reinterpret_cast<float*>(smem + wave * REGION_BYTES);
-  T* outp = reinterpret_cast<T*>(PRE ? P.out_pre : P.out);
+  T* outp = reinterpret_cast<T*>(P.out);
+  T* prep = reinterpret_cast<T*>(P.out_pre);
   const int nw0 = n0 + wn * 64;                 // first column of this wave's strip
 #pragma unroll
   for (int p = 0; p < CF::WM * 16 / RPP; ++p) {
@@ -260,8 +261,7 @@ __device__ __forceinline__ void store_tile(unsigned char* smem, const f32x4_t (&
 #pragma unroll
       for (int i = 0; i < RPP / 16; ++i) {
         const f32x4_t a = acc[p * (RPP / 16) + i][tj];
-        float4 v = make_float4(a[0] + b4.x, a[1] + b4.y, a[2] + b4.z, a[3] + b4.w);
-        if (!PRE && act == LMV_ACT_GELU) { v.x = act_gelu<T>(v.x); v.y = act_gelu<T>(v.y); v.z = act_gelu<T>(v.z); v.w = act_gelu<T>(v.w); }
+        const float4 v = make_float4(a[0] + b4.x, a[1] + b4.y, a[2] + b4.z, a[3] + b4.w);
         const int r = i * 16 + (lane & 15), c4 = tj * 4 + (lane >> 4);
         *reinterpret_cast<float4*>(sT + r * 64 + ((c4 ^ (r & 7)) << 2)) = v;
       }
@@ -281,24 +281,26 @@ __device__ __forceinline__ void store_tile(unsigned char* smem, const f32x4_t (&
         v[e] = t.x; v[e + 1] = t.y; v[e + 2] = t.z; v[e + 3] = t.w;
       }
       const int64_t o = (int64_t)m * ldc + n;
-      if (!PRE) {
-        if (act == LMV_ACT_GELU_GRAD) {
-          float u[EPC];
-          chunk_to_f<T>(*reinterpret_cast<const uint4*>(reinterpret_cast<const T*>(P.aux) + o), u);
+      if (prep) *reinterpret_cast<uint4*>(prep + o) = f_to_chunk<T>(v);      // pre-activation copy kept for the backward pass (same pass)
+      if (act == LMV_ACT_GELU) {
 #pragma unroll
-          for (int e = 0; e < EPC; ++e) v[e] *= act_gelu_grad<T>(u[e]);
-        }
-        if (P.row_scale) {
-          const float rs = P.row_scale[m / P.rps];
+        for (int e = 0; e < EPC; ++e) v[e] = act_gelu<T>(v[e]);
+      } else if (act == LMV_ACT_GELU_GRAD) {
+        float u[EPC];
+        chunk_to_f<T>(*reinterpret_cast<const uint4*>(reinterpret_cast<const T*>(P.aux) + o), u);
 #pragma unroll
-          for (int e = 0; e < EPC; ++e) v[e] *= rs;
-        }
-        if (P.res) {
-          float r8[EPC];
-          chunk_to_f<T>(*reinterpret_cast<const uint4*>(reinterpret_cast<const T*>(P.res) + o), r8);
+        for (int e = 0; e < EPC; ++e) v[e] *= act_gelu_grad<T>(u[e]);
+      }
+      if (P.row_scale) {
+        const float rs = P.row_scale[m / P.rps];
 #pragma unroll
-          for (int e = 0; e < EPC; ++e) v[e] += r8[e];
-        }
+        for (int e = 0; e < EPC; ++e) v[e] *= rs;
+      }
+      if (P.res) {
+        float r8[EPC];
+        chunk_to_f<T>(*reinterpret_cast<const uint4*>(reinterpret_cast<const T*>(P.res) + o), r8);
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) v[e] += r8[e];
       }
       *reinterpret_cast<uint4*>(outp + o) = f_to_chunk<T>(v);
     }
@@ -430,8 +432,7 @@ __global__ __launch_bounds__(CF::NTHR, MINW) void gemm_kernel(const GemmArgs g) 
     }
   } else {
     constexpr int REGION = 2 * BUF_BYTES / CF::NW;      // the operand buffers, carved into one private region per wave
-    if (P.out_pre) store_tile<T, true, CF, REGION>(smem, acc, P, g.act & 0xff, N, g.ldc, m0, n0, wm, wn, lane, wave);
-    store_tile<T, false, CF, REGION>(smem, acc, P, g.act & 0xff, N, g.ldc, m0, n0, wm, wn, lane, wave);
+    store_tile<T, CF, REGION>(smem, acc, P, g.act & 0xff, N, g.ldc, m0, n0, wm, wn, lane, wave);
   }
 }
 

@@ -89,6 +89,11 @@ typedef struct {
   const void* dres;   /* bwd: optional residual-path gradient added to dx (or NULL)         */
   void* dx;           /* bwd: output [rows, C]                                              */
   int64_t rows;
+  /* bwd, optional (all three or none): a second output dx_scaled[r, :] = dx[r, :] * dx_scale[r / rows_per_sample] -- the
+   * DropPath-scaled gradient the NEXT backward stage consumes (saves a separate lmv_row_scale pass over dx) */
+  const float* dx_scale;
+  void* dx_scaled;
+  int64_t rows_per_sample;
 } lmv_ln_segment;
 
 int lmv_layernorm_fwd(const lmv_ln_segment* seg, int nseg, const float* gamma, const float* beta, int C, float eps,

@@ -25,7 +25,7 @@ class LinearProblem(C.Structure):
 
 class LnSegment(C.Structure):
     _fields_ = [("x", C.c_void_p), ("y", C.c_void_p), ("stats", C.c_void_p), ("dy", C.c_void_p), ("dres", C.c_void_p),
-                ("dx", C.c_void_p), ("rows", C.c_int64)]
+                ("dx", C.c_void_p), ("rows", C.c_int64), ("dx_scale", C.c_void_p), ("dx_scaled", C.c_void_p), ("rows_per_sample", C.c_int64)]
 
 
 class RowScaleSegment(C.Structure):

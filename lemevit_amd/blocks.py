@@ -99,7 +99,9 @@ def _mlp_fwd(P: Dict[str, Tensor], ts: Sequence[Tensor], ds: Sequence[Optional[T
     return out, saved
 
 
-def _mlp_bwd(P, G, saved, douts: Sequence[Tensor], ds: Sequence[Optional[Tensor]]) -> List[Tensor]:
+def _mlp_bwd(P, G, saved, douts: Sequence[Tensor], ds: Sequence[Optional[Tensor]], next_ds: Optional[Sequence[Optional[Tensor]]] = None):
+    """next_ds: DropPath vectors of the attention half that is differentiated next; the closing LayerNorm-backward launch then
+    also writes the gradient pre-scaled by them (returned as the second list) -- no separate row-scale pass."""
     ts, st, xn, u, h = saved
     C = ts[0].shape[-1]
     Hd = P["mlp.0.weight"].shape[0]
@@ -110,7 +112,7 @@ def _mlp_bwd(P, G, saved, douts: Sequence[Tensor], ds: Sequence[Optional[Tensor]
     _dw([Prob(dui, xi, G["mlp.0.weight"], bias_grad=G["mlp.0.bias"]) for dui, xi in zip(du, xn)], Hd, C)
     dxn = [torch.empty_like(t) for t in ts]
     ops.linear_dx([Prob(dui, P["mlp.0.weight"], o) for dui, o in zip(du, dxn)], Hd, C)
-    return ops.layernorm_bwd_multi(dxn, ts, st, P["norm2.weight"], G["norm2.weight"], G["norm2.bias"], douts)
+    return ops.layernorm_bwd_multi(dxn, ts, st, P["norm2.weight"], G["norm2.weight"], G["norm2.bias"], douts, next_scales=next_ds)
 
 
 # ------------------------------------------------------------------------------------------------
@@ -128,10 +130,10 @@ def _attn_S_fwd(P, ts, ds, save):
     return out, ((list(ts), list(st), list(xn), qkv, list(ao), list(lse)) if save else None)
 
 
-def _attn_S_bwd(P, G, saved, douts, ds):
+def _attn_S_bwd(P, G, saved, douts, ds, g=None):
     ts, st, xn, qkv, ao, lse = saved
     C = ts[0].shape[-1]
-    g = ops.row_scale_multi(douts, ds)
+    g = ops.row_scale_multi(douts, ds) if g is None else g
     _dw([Prob(gi, ai, G["attn.proj.weight"], bias_grad=G["attn.proj.bias"]) for gi, ai in zip(g, ao)], C, C)
     dao = [torch.empty_like(t) for t in ts]
     ops.linear_dx([Prob(gi, P["attn.proj.weight"], o) for gi, o in zip(g, dao)], C, C)
@@ -161,12 +163,12 @@ def _attn_D_fwd(P, ts, ds, save):
     return [ox, oc], ((list(ts), list(st), list(xn), q1, q2, aox, aoc, lsex, lsec) if save else None)
 
 
-def _attn_D_bwd(P, G, saved, douts, ds):
+def _attn_D_bwd(P, G, saved, douts, ds, g=None):
     ts, st, xn, q1, q2, aox, aoc, lsex, lsec = saved
     x, c = ts
     C, N, M = x.shape[-1], x.shape[1], c.shape[1]
     sx, sc = ops.dca_scales(N, M, C)
-    g = ops.row_scale_multi(douts, ds)
+    g = ops.row_scale_multi(douts, ds) if g is None else g
     _dw([Prob(g[0], aox, G["attn.proj_x.weight"], bias_grad=G["attn.proj_x.bias"]),
                    Prob(g[1], aoc, G["attn.proj_c.weight"], bias_grad=G["attn.proj_c.bias"])], C, C)
     daox, daoc = torch.empty_like(x), torch.empty_like(c)
@@ -199,12 +201,12 @@ def _attn_D2_fwd(P, ts, ds, save):
     return [ox, oc], ((list(ts), list(st), list(xn), qv1, kv2, aox, aoc, lsex, lsec) if save else None)
 
 
-def _attn_D2_bwd(P, G, saved, douts, ds):
+def _attn_D2_bwd(P, G, saved, douts, ds, g=None):
     ts, st, xn, qv1, kv2, aox, aoc, lsex, lsec = saved
     x, c = ts
     C, N, M = x.shape[-1], x.shape[1], c.shape[1]
     sx, sc = ops.dca_scales(N, M, C)
-    g = ops.row_scale_multi(douts, ds)
+    g = ops.row_scale_multi(douts, ds) if g is None else g
     _dw([Prob(g[0], aox, G["attn.proj_x.weight"], bias_grad=G["attn.proj_x.bias"]),
                    Prob(g[1], aoc, G["attn.proj_c.weight"], bias_grad=G["attn.proj_c.bias"])], C, C)
     daox, daoc = torch.empty_like(x), torch.empty_like(c)
@@ -284,9 +286,9 @@ def block_backward(kind: str, saved, dx: Tensor, dc: Tensor, H: int, W: int, P: 
         dx0 = ops.dwconv_residual_bwd_data(dxp, P["pos_embed.weight"], H, W)
         _join()
         return (dx0 if dx is None else dx0 + dx), dc0   # the untouched x's pass-through gradient is added by autograd
-    dx2, dc1 = _mlp_bwd(P, G, sm, [dx, dc], [masks[1], masks[3]])
+    (dx2, dc1), g_attn = _mlp_bwd(P, G, sm, [dx, dc], [masks[1], masks[3]], next_ds=[masks[0], masks[2]])
     bwd = {"S": _attn_S_bwd, "D": _attn_D_bwd, "D2": _attn_D2_bwd}[kind]
-    dxp, dc0 = bwd(P, G, sa, [dx2, dc1], [masks[0], masks[2]])
+    dxp, dc0 = bwd(P, G, sa, [dx2, dc1], [masks[0], masks[2]], g=g_attn)
     ops.dwconv_bwd_weight(dxp, x0, G["pos_embed.weight"], G["pos_embed.bias"], H, W)
     dx0 = ops.dwconv_residual_bwd_data(dxp, P["pos_embed.weight"], H, W)
     _join()

@@ -22,6 +22,7 @@ constexpr int BWD_MAXC = 2048;
 template <typename T>
 struct Segs {
   const T* x[2]; T* y[2]; float* stats[2]; const T* dy[2]; const T* dres[2]; T* dx[2];
+  const float* sc[2]; T* dxs[2]; int64_t rps[2];      // bwd: optional DropPath-scaled second copy of dx
   int64_t rows0, total;
 };
 
@@ -116,6 +117,9 @@ __global__ __launch_bounds__(TPB) void ln_bwd_kernel(const Segs<T> sg, const flo
     const T* dyr = (s ? sg.dy[1] : sg.dy[0]) + lr * C;
     const T* drp = s ? sg.dres[1] : sg.dres[0];
     T* dxr = (s ? sg.dx[1] : sg.dx[0]) + lr * C;
+    const float* dsc = s ? sg.sc[1] : sg.sc[0];
+    T* dsp = s ? sg.dxs[1] : sg.dxs[0];
+    const float dsc_v = dsc ? dsc[lr / (s ? sg.rps[1] : sg.rps[0])] : 1.f;
     const float mean = st[lr * 2], rstd = st[lr * 2 + 1];
     uint4 rx[NIT], rdy[NIT], rres[NIT];
 #pragma unroll
@@ -155,7 +159,14 @@ __global__ __launch_bounds__(TPB) void ln_bwd_kernel(const Segs<T> sg, const flo
 #pragma unroll
         for (int e = 0; e < EPC; ++e) o[e] += r[e];
       }
-      if (lir + it * lpr < nch) *reinterpret_cast<uint4*>(dxr + chs[it] * EPC) = f_to_chunk<T>(o);
+      if (lir + it * lpr < nch) {
+        *reinterpret_cast<uint4*>(dxr + chs[it] * EPC) = f_to_chunk<T>(o);
+        if (dsc) {
+#pragma unroll
+          for (int e = 0; e < EPC; ++e) o[e] *= dsc_v;
+          *reinterpret_cast<uint4*>(dsp + lr * C + chs[it] * EPC) = f_to_chunk<T>(o);
+        }
+      }
     }
   }
   // Column sums over the row groups of this workgroup, one chunk slot (`it`) at a time: every thread drops its
@@ -217,6 +228,11 @@ int fill(Segs<T>* sg, const lmv_ln_segment* seg, int nseg, bool bwd, const char*
     if (bwd && (!s.dy || !s.dx || !s.stats || !lmv_aligned16(s.dy) || !lmv_aligned16(s.dx) || !lmv_aligned16(s.dres)))
       LMV_FAIL(LMV_ERR_SHAPE, "%s: null or misaligned gradient operand", who);
     sg->x[i] = (const T*)s.x; sg->y[i] = (T*)s.y; sg->stats[i] = s.stats; sg->dy[i] = (const T*)s.dy; sg->dres[i] = (const T*)s.dres; sg->dx[i] = (T*)s.dx;
+    if (bwd && (s.dx_scale || s.dx_scaled)) {
+      if (!s.dx_scale || !s.dx_scaled || s.rows_per_sample <= 0 || !lmv_aligned16(s.dx_scaled))
+        LMV_FAIL(LMV_ERR_SHAPE, "%s: dx_scale, dx_scaled and rows_per_sample come together", who);
+      sg->sc[i] = s.dx_scale; sg->dxs[i] = (T*)s.dx_scaled; sg->rps[i] = s.rows_per_sample;
+    }
   }
   sg->rows0 = seg[0].rows;
   sg->total = seg[0].rows + (nseg == 2 ? seg[1].rows : 0);

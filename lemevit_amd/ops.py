@@ -129,21 +129,30 @@ def layernorm_fwd_multi(xs: Sequence[Tensor], gamma: Tensor, beta: Tensor, eps: 
 
 
 def layernorm_bwd_multi(dys: Sequence[Tensor], xs: Sequence[Tensor], stats: Sequence[Tensor], gamma: Tensor, dgamma: Tensor, dbeta: Tensor,
-                        dres: Sequence[Optional[Tensor]]) -> List[Tensor]:
-    """dx_i = dres_i + LN'(dy_i) for up to two tensors in ONE launch; dgamma / dbeta (fp32) are accumulated in place."""
+                        dres: Sequence[Optional[Tensor]], next_scales: Optional[Sequence[Optional[Tensor]]] = None):
+    """dx_i = dres_i + LN'(dy_i) for up to two tensors in ONE launch; dgamma / dbeta (fp32) are accumulated in place.
+    next_scales: per-sample DropPath vectors of the NEXT backward stage; when given, returns (dxs, scaled) where scaled[i] is
+    dx_i * next_scales[i][sample] written by the same launch (or dx_i itself where the scale is None)."""
     C_ = xs[0].shape[-1]
     seg = (LnSegment * len(xs))()
-    dxs, total = [], 0
-    for s, dy, x, st, dr in zip(seg, dys, xs, stats, dres):
+    dxs, scaled, total = [], [], 0
+    for i, (s, dy, x, st, dr) in enumerate(zip(seg, dys, xs, stats, dres)):
         dx = torch.empty_like(x)
         s.x, s.dy, s.stats, s.dres, s.dx, s.rows = _ptr(x), _ptr(dy), _f32(st), _ptr(dr), _ptr(dx), x.numel() // C_
+        sc = None if next_scales is None else next_scales[i]
+        if sc is not None:
+            d2 = torch.empty_like(x)
+            s.dx_scale, s.dx_scaled, s.rows_per_sample = _f32(sc), _ptr(d2), x.shape[1]
+            scaled.append(d2)
+        else:
+            scaled.append(dx)
         total += s.rows
         dxs.append(dx)
     code = dtype_code(xs[0])
     ws = _workspace(lib.lmv_layernorm_bwd_workspace_bytes(total, C_, code), xs[0].device)
     check(lib.lmv_layernorm_bwd(seg, len(xs), _f32(gamma), _f32(dgamma), _f32(dbeta), C_, ws.data_ptr(), ws.numel(), code, _stream()),
           "lmv_layernorm_bwd")
-    return dxs
+    return dxs if next_scales is None else (dxs, scaled)
 
 
 def layernorm_fwd(x: Tensor, gamma: Tensor, beta: Tensor, eps: float, want_stats: bool = False) -> Tuple[Tensor, Optional[Tensor]]:

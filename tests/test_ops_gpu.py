@@ -145,6 +145,13 @@ def test_layernorm(dtype, rows, C):
     dx = o.layernorm_bwd(dy, x, stats, g, dg, dbt, dres=dres)
     assert_close(dx, xr.grad + dres64, dtype, "ln dx", tol32=2e-5, tol16=2e-3)
     assert_close(dg, gr.grad, torch.float32, "dgamma", 2e-5); assert_close(dbt, br.grad, torch.float32, "dbeta", 2e-5)
+    # optional second output of the same launch: dx pre-scaled by the NEXT stage's per-sample DropPath vector
+    if rows % 5 == 0:
+        x3 = x.view(rows // 5, 5, C); sc = (det_tensor((rows // 5,), "sc", 7).abs() + 0.25).to(dev())
+        (dx2,), (dxs,) = o.layernorm_bwd_multi([dy.view_as(x3)], [x3], [stats], g, torch.zeros_like(dg), torch.zeros_like(dbt), [dres.view_as(x3)],
+                                               next_scales=[sc])
+        assert torch.equal(dx2.view_as(dx), dx)
+        assert_close(dxs.view_as(dx), (xr.grad + dres64) * sc.cpu().double().repeat_interleave(5)[:, None], dtype, "ln dx scaled", tol32=2e-5, tol16=2e-3)
 
 
 @pytest.mark.parametrize("dtype", DTYPES)

@@ -147,6 +147,11 @@ def cpu_baseline(model_name: str, img: int, mode: str):
 
 def main():
     args = parse()
+    # stdout carries exactly ONE line, the JSON record: RCCL prints a version banner through C stdio on stdout (flushed at
+    # exit, i.e. AFTER anything printed here), MIOpen / hipBLASLt may log there too.  Everything else goes to stderr.
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -278,7 +283,7 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args.model, args.img, args.mode)
-        print(json.dumps(line), flush=True)
+        os.write(json_fd, (json.dumps(line) + "\n").encode())
     if dist.is_initialized():
         dist.destroy_process_group()
 

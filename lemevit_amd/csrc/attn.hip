@@ -361,6 +361,7 @@ int check_desc(const lmv_attn_desc* d, int dtype, bool bwd) {
   if (dtype != LMV_F32 && dtype != LMV_BF16) LMV_FAIL(LMV_ERR_DTYPE, "attn: unsupported dtype %d", dtype);
   if (d->B <= 0 || d->H <= 0 || d->Lq <= 0 || d->Lk <= 0) LMV_FAIL(LMV_ERR_SHAPE, "attn: bad sizes B=%d H=%d Lq=%d Lk=%d", d->B, d->H, d->Lq, d->Lk);
   if (d->H > 65535 || d->B > 65535) LMV_FAIL(LMV_ERR_SHAPE, "attn: B and H must be <= 65535");
+  if (!(d->scale > 0.f)) LMV_FAIL(LMV_ERR_SHAPE, "attn: scale must be positive (the softmax maximum is taken on the raw scores)");
   const int64_t st[8] = {d->q_bs, d->q_rs, d->k_bs, d->k_rs, d->v_bs, d->v_rs, d->o_bs, d->o_rs};
   for (int i = 0; i < 8; ++i)
     if (st[i] % 8) LMV_FAIL(LMV_ERR_SHAPE, "attn: strides must be multiples of 8 elements");

@@ -14,6 +14,7 @@
 //
 // LDS images are [rows][32] bf16 (64-byte rows); the 16-byte chunk c of row r is stored at c ^ (((r >> 2) & 1) << 1),
 // which is conflict-free for BOTH the 16-byte fragment reads and the transpose reads (derivation in DESIGN.md).
+#include <stdlib.h>
 #include "common.h"
 #include "attn_internal.h"
 
@@ -83,26 +84,33 @@ __global__ __launch_bounds__(256) void mfma_fwd_kernel(const AttnArgs a, int qt_
   const int nqt = (a.Lq + 15) >> 4;
   const int qt_end = min(nqt, (int)(blockIdx.x + 1) * qt_per_block);
   const int g = lane >> 4;
+  const float sc2 = a.scale * 1.4426950408889634f;
   for (int qt = blockIdx.x * qt_per_block + wave; qt < qt_end; qt += 4) {
     const int q = qt * 16 + (lane & 15);
     const bf16x8_t qf = load_frag_global(qb, a.q_rs, q, a.Lq, lane);
+    // softmax on the RAW scores (scale > 0 commutes with the maximum): p = 2^(s * c - m * c), c = scale * log2(e) -- one FMA
+    // and one v_exp_f32 per score; only the tiles that reach past Lk are masked (the kernel is VALU-bound: 4 * NKT scores
+    // per lane against NKT + 4 * NKT / 2 MFMAs)
     f32x4_t s[NKT];
-    float m = -1e30f;
+    float m = -3e38f;
 #pragma unroll
     for (int kt = 0; kt < NKT; ++kt) {
       s[kt] = MFMA(frag_n(sK, kt * 16, lane), qf, (f32x4_t{0.f, 0.f, 0.f, 0.f}));
+      if (kt * 16 + 16 > a.Lk) {                            // wave-uniform: boundary / padding tile
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        s[kt][r] = (kt * 16 + g * 4 + r < a.Lk) ? s[kt][r] * a.scale : -1e30f;
-        m = fmaxf(m, s[kt][r]);
+        for (int r = 0; r < 4; ++r)
+          if (kt * 16 + g * 4 + r >= a.Lk) s[kt][r] = -3e38f;
       }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) m = fmaxf(m, s[kt][r]);
     }
     m = group_max4(m);
+    const float mc = m * sc2;
     float l = 0.f;
 #pragma unroll
     for (int kt = 0; kt < NKT; ++kt)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) { const float p = __expf(s[kt][r] - m); s[kt][r] = p; l += p; }
+      for (int r = 0; r < 4; ++r) { const float p = __builtin_amdgcn_exp2f(fmaf(s[kt][r], sc2, -mc)); s[kt][r] = p; l += p; }
     l = group_sum4(l);
     f32x4_t o0 = {0.f, 0.f, 0.f, 0.f}, o1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -123,7 +131,7 @@ __global__ __launch_bounds__(256) void mfma_fwd_kernel(const AttnArgs a, int qt_
       o0 *= inv; o1 *= inv;
       store4(ob + (int64_t)q * a.o_rs + g * 4, o0);
       store4(ob + (int64_t)q * a.o_rs + 16 + g * 4, o1);
-      if (a.lse && g == 0) a.lse[((int64_t)b * a.H + h) * a.Lq + q] = m + __logf(l);
+      if (a.lse && g == 0) a.lse[((int64_t)b * a.H + h) * a.Lq + q] = m * a.scale + __logf(l);
     }
   }
 }
@@ -529,14 +537,20 @@ __global__ __launch_bounds__(256) void mfma_fwd_long_kernel(const AttnArgs a, in
   for (int qt = blockIdx.x * qt_per_block + wave; qt < qt_end; qt += 4) {
     const int q = qt * 16 + (lane & 15);
     const bf16x8_t qf = load_frag_global(qb, a.q_rs, q, a.Lq, lane);
-    float m = -1e30f;
+    float m = -3e38f;                                      // maximum of the RAW scores (scale > 0), see mfma_fwd_kernel
     for (int kt = 0; kt < nkt; ++kt) {
       const f32x4_t s = MFMA(frag_n(sK, kt * 16, lane), qf, (f32x4_t{0.f, 0.f, 0.f, 0.f}));
+      if (kt * 16 + 16 > a.Lk) {
 #pragma unroll
-      for (int r = 0; r < 4; ++r)
-        if (kt * 16 + g * 4 + r < a.Lk) m = fmaxf(m, s[r] * a.scale);
+        for (int r = 0; r < 4; ++r)
+          if (kt * 16 + g * 4 + r < a.Lk) m = fmaxf(m, s[r]);
+      } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) m = fmaxf(m, s[r]);
+      }
     }
     m = group_max4(m);
+    const float sc2 = a.scale * 1.4426950408889634f, mc = m * sc2;
     float l = 0.f;
     f32x4_t o0 = {0.f, 0.f, 0.f, 0.f}, o1 = {0.f, 0.f, 0.f, 0.f};
     for (int kb2 = 0; kb2 < nkt / 2; ++kb2) {
@@ -547,7 +561,8 @@ __global__ __launch_bounds__(256) void mfma_fwd_long_kernel(const AttnArgs a, in
         const f32x4_t s = MFMA(frag_n(sK, kt * 16, lane), qf, (f32x4_t{0.f, 0.f, 0.f, 0.f}));
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          p[t][r] = (kt * 16 + g * 4 + r < a.Lk) ? __expf(s[r] * a.scale - m) : 0.f;
+          p[t][r] = __builtin_amdgcn_exp2f(fmaf(s[r], sc2, -mc));
+          if (kt * 16 + 16 > a.Lk && kt * 16 + g * 4 + r >= a.Lk) p[t][r] = 0.f;
           l += p[t][r];
         }
       }
@@ -566,7 +581,7 @@ __global__ __launch_bounds__(256) void mfma_fwd_long_kernel(const AttnArgs a, in
       o0 *= inv; o1 *= inv;
       store4(ob + (int64_t)q * a.o_rs + g * 4, o0);
       store4(ob + (int64_t)q * a.o_rs + 16 + g * 4, o1);
-      if (a.lse && g == 0) a.lse[((int64_t)b * a.H + h) * a.Lq + q] = m + __logf(l);
+      if (a.lse && g == 0) a.lse[((int64_t)b * a.H + h) * a.Lq + q] = m * a.scale + __logf(l);
     }
   }
 }
@@ -812,7 +827,12 @@ int lmv_attn_mfma_fwd(const AttnArgs& a, hipStream_t st) {
 // acc: lmv_attn_mfma_bwd_acc_bytes() of fp32 scratch (only touched when the query range is split)
 int lmv_attn_mfma_bwd(const AttnArgs& a, float* delta, float* acc, hipStream_t st) {
   const int per = qt_per_block_for(a), nqt = (a.Lq + 15) / 16, nkt = nkt_for(a.Lk);
-  {
+  if (nkt == 14 && a.Lq > 16) {
+    // 129..224 keys: the run-time-bound dQ loop (86 registers, 5 waves per SIMD) beats the fully unrolled one (169 registers, 2)
+    int nk, pr, lds;
+    if (int rc = long_geometry(a, &nk, &pr, &lds)) return rc;
+    hipLaunchKernelGGL(mfma_bwd_dq_long_kernel, dim3((nqt + pr - 1) / pr, a.H, a.B), dim3(256), lds, st, a, delta, pr, nk);
+  } else {
     dim3 grid((nqt + per - 1) / per, a.H, a.B), block(256);
     switch (nkt) {
       case 2: hipLaunchKernelGGL((mfma_bwd_dq_kernel<2>), grid, block, 0, st, a, delta, per); break;

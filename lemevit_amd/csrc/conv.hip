@@ -232,6 +232,8 @@ inline Geo make_geo(int B, int H, int W, int C, int dtype, int R) {
   const char* e = getenv("LMV_DWCONV_V");
   if (e && atoi(e) > 0) {
     g.V = atoi(e);
+  } else if (R == RW) {
+    g.V = H < 14 ? H : 14;      // weight gradient: long strips (more accumulation per thread, fewer partial rows) win on every stage
   } else {
     const int64_t per_range = (int64_t)B * g.nstrips * nch, want = 2048 * 64;
     int64_t nr = (want + per_range - 1) / per_range;

@@ -201,7 +201,7 @@ inline bool pick_geometry(int nch, int max_it, int* lpr_log2, int* nit) {
     if (it > max_it) continue;
     const int waste = it * lpr - nch;                            // idle lane-iterations per row
     const int score = waste * 100 + (it > 3 ? it - 3 : 3 - it);  // then ~3 loads in flight per lane
-    if (score < best_score) { best = l; best_score = score; best_it = it; }
+    if (score <= best_score) { best = l; best_score = score; best_it = it; }      // ties: more lanes per row (fewer registers per lane)
   }
   if (best < 0) return false;
   *lpr_log2 = best; *nit = best_it;

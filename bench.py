@@ -53,7 +53,7 @@ def parse():
     ap.add_argument("--force-ddp", action="store_true", help="wrap in DDP (and use the DDP code path) even at world size 1: measures the wrapper's overhead")
     ap.add_argument("--torch-adamw", action="store_true", help="use torch.optim.AdamW(fused=True) instead of lemevit_amd.FlatAdamW at N=1")
     ap.add_argument("--no-kernel-timing", action="store_true")
-    ap.add_argument("--graph", type=int, default=0, help="1 = capture the step into a hipGraph (lemevit_amd.graph.GraphedStep) and replay it; default 0 = "
+    ap.add_argument("--graph", type=int, default=-1, help="(-1 = auto: eager for train, graph replay for infer)  1 = capture the step into a hipGraph (lemevit_amd.graph.GraphedStep) and replay it; default 0 = "
                     "eager launches, which are faster here: the weight-gradient GEMMs overlap the dX chain on a side stream, and the "
                     "runtime serialises the branches of a captured graph (38.0 vs 39.6 ms per step)")
     return ap.parse_args()
@@ -147,6 +147,8 @@ def cpu_baseline(model_name: str, img: int, mode: str):
 
 def main():
     args = parse()
+    if args.graph < 0:
+        args.graph = 0 if args.mode == "train" else 1
     # stdout carries exactly ONE line, the JSON record: RCCL prints a version banner through C stdio on stdout (flushed at
     # exit, i.e. AFTER anything printed here), MIOpen / hipBLASLt may log there too.  Everything else goes to stderr.
     sys.stdout.flush()

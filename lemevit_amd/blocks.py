@@ -49,13 +49,12 @@ _side_streams: Dict[int, tuple] = {}          # device index -> (side stream, it
 _inflight: List[object] = []
 
 
-def _dw(probs, N: int, K: int) -> None:
+def _fork(dev) -> Optional[int]:
+    """Raw handle of the side stream, made to wait for everything enqueued on the current stream so far; None = launch in line."""
     # (measured: -3 % step time in eager mode; inside a hipGraph capture the branch is serialised by the runtime and the
-    #  extra dependencies cost 1 %, so captured steps launch dW in line)
+    #  extra dependencies cost 1 %, so captured steps launch the weight gradients in line)
     if not _SIDE or torch.cuda.is_current_stream_capturing():
-        ops.linear_dw(probs, N, K)
-        return
-    dev = probs[0].a.device
+        return None
     ent = _side_streams.get(dev.index)
     if ent is None:
         side = torch.cuda.Stream(device=dev)
@@ -63,13 +62,26 @@ def _dw(probs, N: int, K: int) -> None:
     side, raw, fork, _ = ent
     fork.record()                                   # on the current (main) stream: the operands are ready
     side.wait_event(fork)
+    return raw
+
+
+def _dw(probs, N: int, K: int) -> None:
+    raw = _fork(probs[0].a.device)
     ops.linear_dw(probs, N, K, stream=raw)          # launched on the side stream by handle: no current-stream switch
-    _inflight.append(probs)
+    if raw is not None:
+        _inflight.append((probs[0].a.device.index, probs))
+
+
+def _dwconv_w(dy: Tensor, x: Tensor, dweight: Tensor, dbias: Tensor, H: int, W: int) -> None:
+    raw = _fork(dy.device)
+    ops.dwconv_bwd_weight(dy, x, dweight, dbias, H, W, stream=raw)
+    if raw is not None:
+        _inflight.append((dy.device.index, (dy, x)))
 
 
 def _join() -> None:
     if _inflight:
-        side, _, _, join = _side_streams[_inflight[-1][0].a.device.index]
+        side, _, _, join = _side_streams[_inflight[-1][0]]
         join.record(side)
         torch.cuda.current_stream(side.device).wait_event(join)
         _inflight.clear()
@@ -282,14 +294,14 @@ def block_backward(kind: str, saved, dx: Tensor, dc: Tensor, H: int, W: int, P: 
     if kind == "C":
         (dc1,) = _mlp_bwd(P, G, sm, [dc], [masks[1]])
         dxp, dc0 = _attn_C_bwd(P, G, sa, dc1, masks[0])
-        ops.dwconv_bwd_weight(dxp, x0, G["pos_embed.weight"], G["pos_embed.bias"], H, W)
+        _dwconv_w(dxp, x0, G["pos_embed.weight"], G["pos_embed.bias"], H, W)
         dx0 = ops.dwconv_residual_bwd_data(dxp, P["pos_embed.weight"], H, W)
         _join()
         return (dx0 if dx is None else dx0 + dx), dc0   # the untouched x's pass-through gradient is added by autograd
     (dx2, dc1), g_attn = _mlp_bwd(P, G, sm, [dx, dc], [masks[1], masks[3]], next_ds=[masks[0], masks[2]])
     bwd = {"S": _attn_S_bwd, "D": _attn_D_bwd, "D2": _attn_D2_bwd}[kind]
     dxp, dc0 = bwd(P, G, sa, [dx2, dc1], [masks[0], masks[2]], g=g_attn)
-    ops.dwconv_bwd_weight(dxp, x0, G["pos_embed.weight"], G["pos_embed.bias"], H, W)
+    _dwconv_w(dxp, x0, G["pos_embed.weight"], G["pos_embed.bias"], H, W)
     dx0 = ops.dwconv_residual_bwd_data(dxp, P["pos_embed.weight"], H, W)
     _join()
     return dx0, dc0

@@ -185,10 +185,12 @@ def dwconv_residual_bwd_data(dy: Tensor, weight: Tensor, H: int, W: int) -> Tens
     return dx
 
 
-def dwconv_bwd_weight(dy: Tensor, x: Tensor, dweight: Tensor, dbias: Tensor, H: int, W: int) -> None:
+def dwconv_bwd_weight(dy: Tensor, x: Tensor, dweight: Tensor, dbias: Tensor, H: int, W: int, stream: Optional[int] = None) -> None:
+    """stream: raw HIP stream handle to launch on (default: the current stream); the scratch is per stream."""
     B, N, C_ = dy.shape
-    ws = _workspace(lib.lmv_dwconv3x3_bwd_weight_workspace_bytes(B, H, W, C_, dtype_code(dy)), dy.device)
-    check(lib.lmv_dwconv3x3_bwd_weight(_ptr(dy), _ptr(x), _f32(dweight), _f32(dbias), B, H, W, C_, ws.data_ptr(), ws.numel(), dtype_code(dy), _stream()),
+    st = _stream() if stream is None else stream
+    ws = _workspace(lib.lmv_dwconv3x3_bwd_weight_workspace_bytes(B, H, W, C_, dtype_code(dy)), dy.device, st)
+    check(lib.lmv_dwconv3x3_bwd_weight(_ptr(dy), _ptr(x), _f32(dweight), _f32(dbias), B, H, W, C_, ws.data_ptr(), ws.numel(), dtype_code(dy), st),
           "lmv_dwconv3x3_bwd_weight")
 
 

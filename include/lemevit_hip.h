@@ -98,6 +98,12 @@ typedef struct {
 
 int lmv_layernorm_fwd(const lmv_ln_segment* seg, int nseg, const float* gamma, const float* beta, int C, float eps,
                       int dtype, void* stream);
+/* y = GELU(LayerNorm(x)) in one pass and its backward (dy is multiplied by GELU'(LayerNorm(x)), recomputed from x, gamma, beta):
+ * the Linear -> LayerNorm -> GELU -> Linear -> LayerNorm meta-token MLP of every stage (models/lemevit.py:731-743). */
+int lmv_layernorm_gelu_fwd(const lmv_ln_segment* seg, int nseg, const float* gamma, const float* beta, int C, float eps,
+                           int dtype, void* stream);
+int lmv_layernorm_gelu_bwd(const lmv_ln_segment* seg, int nseg, const float* gamma, const float* beta, float* dgamma, float* dbeta, int C,
+                           void* workspace, size_t workspace_bytes, int dtype, void* stream);
 size_t lmv_layernorm_bwd_workspace_bytes(int64_t total_rows, int C, int dtype);
 int lmv_layernorm_bwd(const lmv_ln_segment* seg, int nseg, const float* gamma, float* dgamma, float* dbeta, int C,
                       void* workspace, size_t workspace_bytes, int dtype, void* stream);

@@ -52,6 +52,8 @@ SIGNATURES = {
     "lmv_linear_dw_workspace_bytes": (_Z, [C.POINTER(LinearProblem), _I, _I, _I, _I]),
     "lmv_linear_dw": (_I, [C.POINTER(LinearProblem), _I, _I, _I, _P, _Z, _I, _P]),
     "lmv_layernorm_fwd": (_I, [C.POINTER(LnSegment), _I, _P, _P, _I, _F, _I, _P]),
+    "lmv_layernorm_gelu_fwd": (_I, [C.POINTER(LnSegment), _I, _P, _P, _I, _F, _I, _P]),
+    "lmv_layernorm_gelu_bwd": (_I, [C.POINTER(LnSegment), _I, _P, _P, _P, _P, _I, _P, _Z, _I, _P]),
     "lmv_layernorm_bwd_workspace_bytes": (_Z, [_L, _I, _I]),
     "lmv_layernorm_bwd": (_I, [C.POINTER(LnSegment), _I, _P, _P, _P, _I, _P, _Z, _I, _P]),
     "lmv_dwconv3x3_residual_fwd": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),

@@ -35,7 +35,7 @@ __device__ __forceinline__ float group_sum(float v, int lpr) {
 
 template <typename T, int NIT>
 __global__ __launch_bounds__(TPB) void ln_fwd_kernel(const Segs<T> sg, const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                    int C, int lpr_log2, float eps) {
+                                                    int C, int lpr_log2, float eps, int act) {
   constexpr int EPC = DT<T>::EPC;
   const int lpr = 1 << lpr_log2, nch = C / EPC;
   const int lir = threadIdx.x & (lpr - 1), rib = threadIdx.x >> lpr_log2, rpb = TPB >> lpr_log2;
@@ -85,6 +85,10 @@ __global__ __launch_bounds__(TPB) void ln_fwd_kernel(const Segs<T> sg, const flo
       float o[EPC];
 #pragma unroll
       for (int e = 0; e < EPC; ++e) o[e] = (v[it][e] - mean) * rstd * gm[it][e] + bt[it][e];
+      if (act) {                                           // y = GELU(LN(x)): the meta-token MLPs (models/lemevit.py:731-743)
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) o[e] = sizeof(T) == 4 ? gelu_f(o[e]) : gelu_fast_f(o[e]);
+      }
       if (lir + it * lpr < nch) *reinterpret_cast<uint4*>(yr + chs[it] * EPC) = f_to_chunk<T>(o);
     }
     float* st = s ? sg.stats[1] : sg.stats[0];
@@ -92,14 +96,16 @@ __global__ __launch_bounds__(TPB) void ln_fwd_kernel(const Segs<T> sg, const flo
   }
 }
 
-template <typename T, int NIT>
-__global__ __launch_bounds__(TPB) void ln_bwd_kernel(const Segs<T> sg, const float* __restrict__ gamma, float* __restrict__ partial, int C, int lpr_log2) {
+// ACT: the forward was y = GELU(LN(x)); dy is first multiplied by GELU'(LN(x)), recomputed from x, gamma and beta
+template <typename T, int NIT, bool ACT>
+__global__ __launch_bounds__(TPB) void ln_bwd_kernel(const Segs<T> sg, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                    float* __restrict__ partial, int C, int lpr_log2) {
   constexpr int EPC = DT<T>::EPC;
   __shared__ __attribute__((aligned(16))) float red[TPB * 2 * EPC];
   const int lpr = 1 << lpr_log2, nch = C / EPC;
   const int lir = threadIdx.x & (lpr - 1), rib = threadIdx.x >> lpr_log2, rpb = TPB >> lpr_log2;
   const float invC = 1.f / (float)C;
-  float adg[NIT][EPC], adb[NIT][EPC], gm[NIT][EPC], vm[NIT];
+  float adg[NIT][EPC], adb[NIT][EPC], gm[NIT][EPC], bt[ACT ? NIT : 1][EPC], vm[NIT];
   int chs[NIT];
 #pragma unroll
   for (int it = 0; it < NIT; ++it) {
@@ -107,7 +113,10 @@ __global__ __launch_bounds__(TPB) void ln_bwd_kernel(const Segs<T> sg, const flo
     chs[it] = min(ch, nch - 1);                    // clamped: all loads are unconditional (see ln_fwd_kernel)
     vm[it] = (ch < nch) ? 1.f : 0.f;
 #pragma unroll
-    for (int e = 0; e < EPC; ++e) { adg[it][e] = 0.f; adb[it][e] = 0.f; gm[it][e] = gamma[chs[it] * EPC + e]; }
+    for (int e = 0; e < EPC; ++e) {
+      adg[it][e] = 0.f; adb[it][e] = 0.f; gm[it][e] = gamma[chs[it] * EPC + e];
+      if (ACT) bt[it][e] = beta[chs[it] * EPC + e];
+    }
   }
   for (int64_t row = (int64_t)blockIdx.x * rpb + rib; row < sg.total; row += (int64_t)gridDim.x * rpb) {
     const int s = row >= sg.rows0;
@@ -142,6 +151,10 @@ __global__ __launch_bounds__(TPB) void ln_bwd_kernel(const Segs<T> sg, const flo
       for (int e = 0; e < EPC; ++e) {
         dv[e] *= vm[it];
         xh[it][e] = (xv[e] - mean) * rstd;
+        if (ACT) {
+          const float pre = xh[it][e] * gm[it][e] + bt[it][e];
+          dv[e] *= sizeof(T) == 4 ? gelu_grad_f(pre) : gelu_grad_fast_f(pre);
+        }
         g[it][e] = dv[e] * gm[it][e];
         s1 += g[it][e]; s2 += g[it][e] * xh[it][e];
         adg[it][e] += dv[e] * xh[it][e]; adb[it][e] += dv[e];
@@ -240,7 +253,7 @@ int fill(Segs<T>* sg, const lmv_ln_segment* seg, int nseg, bool bwd, const char*
 }
 
 template <typename T>
-int launch_fwd(const lmv_ln_segment* seg, int nseg, const float* gamma, const float* beta, int C, float eps, hipStream_t st) {
+int launch_fwd(const lmv_ln_segment* seg, int nseg, const float* gamma, const float* beta, int C, float eps, int act, hipStream_t st) {
   Segs<T> sg;
   if (int rc = fill(&sg, seg, nseg, false, "layernorm")) return rc;
   int l2, nit;
@@ -248,7 +261,7 @@ int launch_fwd(const lmv_ln_segment* seg, int nseg, const float* gamma, const fl
   const int rpb = TPB >> l2;
   int64_t blocks = (sg.total + rpb - 1) / rpb; if (blocks > 4096) blocks = 4096;
   dim3 grid((int)blocks), block(TPB);
-#define LN_FWD_CASE(N) case N: hipLaunchKernelGGL((ln_fwd_kernel<T, N>), grid, block, 0, st, sg, gamma, beta, C, l2, eps); break;
+#define LN_FWD_CASE(N) case N: hipLaunchKernelGGL((ln_fwd_kernel<T, N>), grid, block, 0, st, sg, gamma, beta, C, l2, eps, act); break;
   switch (nit) {
     LN_FWD_CASE(1) LN_FWD_CASE(2) LN_FWD_CASE(3) LN_FWD_CASE(4) LN_FWD_CASE(5) LN_FWD_CASE(6)
     default:
@@ -260,8 +273,9 @@ int launch_fwd(const lmv_ln_segment* seg, int nseg, const float* gamma, const fl
   return LMV_OK;
 }
 
-template <typename T>
-int launch_bwd(const lmv_ln_segment* seg, int nseg, const float* gamma, float* dgamma, float* dbeta, int C, void* ws, size_t ws_bytes, hipStream_t st) {
+template <typename T, bool ACT>
+int launch_bwd(const lmv_ln_segment* seg, int nseg, const float* gamma, const float* beta, float* dgamma, float* dbeta, int C, void* ws, size_t ws_bytes,
+               hipStream_t st) {
   Segs<T> sg;
   if (int rc = fill(&sg, seg, nseg, true, "layernorm_bwd")) return rc;
   int l2, nit;
@@ -271,7 +285,7 @@ int launch_bwd(const lmv_ln_segment* seg, int nseg, const float* gamma, float* d
   if (!ws || ws_bytes < need) LMV_FAIL(LMV_ERR_WORKSPACE, "layernorm_bwd: workspace %zu < %zu bytes", ws_bytes, need);
   float* partial = reinterpret_cast<float*>(ws);
   dim3 grid(blocks), block(TPB);
-#define LN_BWD_CASE(N) case N: hipLaunchKernelGGL((ln_bwd_kernel<T, N>), grid, block, 0, st, sg, gamma, partial, C, l2); break;
+#define LN_BWD_CASE(N) case N: hipLaunchKernelGGL((ln_bwd_kernel<T, N, ACT>), grid, block, 0, st, sg, gamma, beta, partial, C, l2); break;
   switch (nit) {
     LN_BWD_CASE(1) LN_BWD_CASE(2) LN_BWD_CASE(3) LN_BWD_CASE(4) LN_BWD_CASE(5) LN_BWD_CASE(6)
     default:
@@ -289,9 +303,19 @@ extern "C" int lmv_layernorm_fwd(const lmv_ln_segment* seg, int nseg, const floa
   if (!seg) LMV_FAIL(LMV_ERR_SHAPE, "layernorm: null segments");
   if (C <= 0 || (C % 8)) LMV_FAIL(LMV_ERR_SHAPE, "layernorm: C=%d must be a positive multiple of 8", C);
   if (!gamma || !beta || !lmv_aligned16(gamma) || !lmv_aligned16(beta)) LMV_FAIL(LMV_ERR_SHAPE, "layernorm: null or misaligned affine");
-  if (dtype == LMV_BF16) return launch_fwd<bf16_t>(seg, nseg, gamma, beta, C, eps, (hipStream_t)stream);
-  if (dtype == LMV_F32) return launch_fwd<float>(seg, nseg, gamma, beta, C, eps, (hipStream_t)stream);
+  if (dtype == LMV_BF16) return launch_fwd<bf16_t>(seg, nseg, gamma, beta, C, eps, 0, (hipStream_t)stream);
+  if (dtype == LMV_F32) return launch_fwd<float>(seg, nseg, gamma, beta, C, eps, 0, (hipStream_t)stream);
   LMV_FAIL(LMV_ERR_DTYPE, "layernorm: unsupported dtype %d", dtype);
+}
+
+extern "C" int lmv_layernorm_gelu_fwd(const lmv_ln_segment* seg, int nseg, const float* gamma, const float* beta, int C, float eps, int dtype,
+                                      void* stream) {
+  if (!seg) LMV_FAIL(LMV_ERR_SHAPE, "layernorm_gelu: null segments");
+  if (C <= 0 || (C % 8)) LMV_FAIL(LMV_ERR_SHAPE, "layernorm_gelu: C=%d must be a positive multiple of 8", C);
+  if (!gamma || !beta || !lmv_aligned16(gamma) || !lmv_aligned16(beta)) LMV_FAIL(LMV_ERR_SHAPE, "layernorm_gelu: null or misaligned affine");
+  if (dtype == LMV_BF16) return launch_fwd<bf16_t>(seg, nseg, gamma, beta, C, eps, 1, (hipStream_t)stream);
+  if (dtype == LMV_F32) return launch_fwd<float>(seg, nseg, gamma, beta, C, eps, 1, (hipStream_t)stream);
+  LMV_FAIL(LMV_ERR_DTYPE, "layernorm_gelu: unsupported dtype %d", dtype);
 }
 
 extern "C" size_t lmv_layernorm_bwd_workspace_bytes(int64_t total_rows, int C, int dtype) {
@@ -304,7 +328,17 @@ extern "C" int lmv_layernorm_bwd(const lmv_ln_segment* seg, int nseg, const floa
   if (!seg) LMV_FAIL(LMV_ERR_SHAPE, "layernorm_bwd: null segments");
   if (C <= 0 || (C % 8)) LMV_FAIL(LMV_ERR_SHAPE, "layernorm_bwd: C=%d must be a positive multiple of 8", C);
   if (!gamma || !dgamma || !dbeta) LMV_FAIL(LMV_ERR_SHAPE, "layernorm_bwd: null affine / gradient buffer");
-  if (dtype == LMV_BF16) return launch_bwd<bf16_t>(seg, nseg, gamma, dgamma, dbeta, C, workspace, workspace_bytes, (hipStream_t)stream);
-  if (dtype == LMV_F32) return launch_bwd<float>(seg, nseg, gamma, dgamma, dbeta, C, workspace, workspace_bytes, (hipStream_t)stream);
+  if (dtype == LMV_BF16) return launch_bwd<bf16_t, false>(seg, nseg, gamma, nullptr, dgamma, dbeta, C, workspace, workspace_bytes, (hipStream_t)stream);
+  if (dtype == LMV_F32) return launch_bwd<float, false>(seg, nseg, gamma, nullptr, dgamma, dbeta, C, workspace, workspace_bytes, (hipStream_t)stream);
   LMV_FAIL(LMV_ERR_DTYPE, "layernorm_bwd: unsupported dtype %d", dtype);
+}
+
+extern "C" int lmv_layernorm_gelu_bwd(const lmv_ln_segment* seg, int nseg, const float* gamma, const float* beta, float* dgamma, float* dbeta, int C,
+                                      void* workspace, size_t workspace_bytes, int dtype, void* stream) {
+  if (!seg) LMV_FAIL(LMV_ERR_SHAPE, "layernorm_gelu_bwd: null segments");
+  if (C <= 0 || (C % 8)) LMV_FAIL(LMV_ERR_SHAPE, "layernorm_gelu_bwd: C=%d must be a positive multiple of 8", C);
+  if (!gamma || !beta || !dgamma || !dbeta) LMV_FAIL(LMV_ERR_SHAPE, "layernorm_gelu_bwd: null affine / gradient buffer");
+  if (dtype == LMV_BF16) return launch_bwd<bf16_t, true>(seg, nseg, gamma, beta, dgamma, dbeta, C, workspace, workspace_bytes, (hipStream_t)stream);
+  if (dtype == LMV_F32) return launch_bwd<float, true>(seg, nseg, gamma, beta, dgamma, dbeta, C, workspace, workspace_bytes, (hipStream_t)stream);
+  LMV_FAIL(LMV_ERR_DTYPE, "layernorm_gelu_bwd: unsupported dtype %d", dtype);
 }

@@ -133,6 +133,69 @@ class _StemConv1Fn(torch.autograd.Function):
         return None, dw, (None if bdt is None else db.to(bdt)), None
 
 
+class _MetaMLPFn(torch.autograd.Function):
+    """The per-stage meta-token MLP, Linear -> LayerNorm -> GELU -> Linear -> LayerNorm on [*, 16, C] (models/lemevit.py:731-743),
+    as four launches of the block kernels (GEMM with bias epilogue, LayerNorm with fused GELU) and a hand-written backward --
+    instead of ~25 library kernels and autocast casts per stage."""
+
+    @staticmethod
+    def forward(ctx, c, w1, b1, g1, be1, w2, b2, g2, be2, eps1, eps2, cd):
+        cin, hid, cout = w1.shape[1], w1.shape[0], w2.shape[0]
+        x = c.detach().to(cd).contiguous().view(-1, cin)
+        R = x.shape[0]
+        W1, W2 = compute_copy(w1, cd), compute_copy(w2, cd)
+        f32 = lambda p: compute_copy(p, torch.float32)
+        h1 = torch.empty(R, hid, device=x.device, dtype=cd)
+        ops.linear_fwd([Prob(x, W1, h1, bias=f32(b1))], hid, cin)
+        (a1,), (st1,) = ops.layernorm_fwd_multi([h1], f32(g1), f32(be1), eps1, want_stats=True, gelu=True)
+        h2 = torch.empty(R, cout, device=x.device, dtype=cd)
+        ops.linear_fwd([Prob(a1, W2, h2, bias=f32(b2))], cout, hid)
+        (y,), (st2,) = ops.layernorm_fwd_multi([h2], f32(g2), f32(be2), eps2, want_stats=True)
+        ctx.saved = (x, h1, st1, a1, h2, st2, W1, W2, f32(g1), f32(be1), f32(g2))
+        ctx.meta = (c.shape, c.dtype, [(p.shape, p.dtype) for p in (w1, b1, g1, be1, w2, b2, g2, be2)])
+        return y.view(c.shape[:-1] + (cout,))
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, h1, st1, a1, h2, st2, W1, W2, g1, be1, g2 = ctx.saved
+        cshape, cdtype, pmeta = ctx.meta
+        cin, hid, cout = W1.shape[1], W1.shape[0], W2.shape[0]
+        dy = dy.contiguous().view(-1, cout)
+        if dy.dtype != x.dtype:
+            dy = dy.to(x.dtype)
+        sizes = [int(torch.Size(sh).numel()) for sh, _ in pmeta]
+        pad = [(n + 3) // 4 * 4 for n in sizes]
+        flat = torch.zeros(sum(pad), device=x.device, dtype=torch.float32)
+        G, off = [], 0
+        for (sh, _), n, pd in zip(pmeta, sizes, pad):
+            G.append(flat[off:off + n].view(sh)); off += pd
+        dW1, db1, dg1, dbe1, dW2, db2, dg2, dbe2 = G
+        (dh2,) = ops.layernorm_bwd_multi([dy], [h2], [st2], g2, dg2, dbe2, [None])
+        ops.linear_dw([Prob(dh2, a1, dW2, bias_grad=db2)], cout, hid)
+        da1 = torch.empty_like(a1)
+        ops.linear_dx([Prob(dh2, W2, da1)], cout, hid)
+        (dh1,) = ops.layernorm_bwd_multi([da1], [h1], [st1], g1, dg1, dbe1, [None], gelu_beta=be1)
+        ops.linear_dw([Prob(dh1, x, dW1, bias_grad=db1)], hid, cin)
+        dc = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(x)
+            ops.linear_dx([Prob(dh1, W1, dx)], hid, cin)
+            dc = dx.view(cshape).to(cdtype)
+        ctx.saved = None
+        return (dc, *[g if dt == torch.float32 else g.to(dt) for g, (_, dt) in zip(G, pmeta)], None, None, None)
+
+
+def _is_meta_mlp(seq: nn.Module, c: Tensor, cd: torch.dtype) -> bool:
+    if not (isinstance(seq, nn.Sequential) and len(seq) == 5 and c.is_cuda and cd in (torch.float32, torch.bfloat16)):
+        return False
+    l1, n1, act, l2, n2 = seq
+    return (isinstance(l1, nn.Linear) and isinstance(n1, nn.LayerNorm) and isinstance(act, nn.GELU) and getattr(act, "approximate", "none") == "none"
+            and isinstance(l2, nn.Linear) and isinstance(n2, nn.LayerNorm) and l1.bias is not None and l2.bias is not None
+            and n1.elementwise_affine and n2.elementwise_affine and n1.bias is not None and n2.bias is not None
+            and l1.in_features % 8 == 0 and l1.out_features % 8 == 0 and l2.out_features % 8 == 0 and l1.out_features <= 2048
+            and l1.weight.dtype == torch.float32 and c.dtype in (torch.float32, torch.bfloat16))
+
+
 def _is_stem_conv1(m: nn.Module, x: Tensor) -> bool:
     return (isinstance(m, nn.Conv2d) and m.in_channels == 3 and m.kernel_size == (3, 3) and m.stride == (2, 2) and m.padding == (1, 1)
             and m.dilation == (1, 1) and m.groups == 1 and m.out_channels % 8 == 0 and m.padding_mode == "zeros" and not x.requires_grad
@@ -580,7 +643,12 @@ class LeMeViT(nn.Module):
             if i == 0 or not isinstance(self.downsample_layers[i], nn.Identity):
                 x = self._run_downsample(self.downsample_layers[i], x if xt is None else self._to_nchw(xt, H, W))
                 xt, H, W = self._to_tokens(x, cd)
-            c = self.meta_token_downsample[i](c)
+            mlp = self.meta_token_downsample[i]
+            if _is_meta_mlp(mlp, c, cd):
+                l1, n1, _, l2, n2 = mlp
+                c = _MetaMLPFn.apply(c, l1.weight, l1.bias, n1.weight, n1.bias, l2.weight, l2.bias, n2.weight, n2.bias, n1.eps, n2.eps, cd)
+            else:
+                c = mlp(c)
             if hoist:
                 c = c.expand(B, -1, -1)
                 hoist = False

@@ -113,8 +113,8 @@ def linear_dw(probs: Sequence[Prob], N: int, K: int, stream: Optional[int] = Non
 # -------------------------------------------------------------------------------------------
 # LayerNorm
 # -------------------------------------------------------------------------------------------
-def layernorm_fwd_multi(xs: Sequence[Tensor], gamma: Tensor, beta: Tensor, eps: float, want_stats: bool = False):
-    """LayerNorm of up to two tensors sharing (gamma, beta) in ONE launch; returns (ys, stats)."""
+def layernorm_fwd_multi(xs: Sequence[Tensor], gamma: Tensor, beta: Tensor, eps: float, want_stats: bool = False, gelu: bool = False):
+    """LayerNorm (gelu=True: GELU(LayerNorm)) of up to two tensors sharing (gamma, beta) in ONE launch; returns (ys, stats)."""
     C_ = xs[0].shape[-1]
     seg = (LnSegment * len(xs))()
     ys, sts = [], []
@@ -124,12 +124,13 @@ def layernorm_fwd_multi(xs: Sequence[Tensor], gamma: Tensor, beta: Tensor, eps: 
         st = torch.empty((rows, 2), device=x.device, dtype=torch.float32) if want_stats else None
         s.x, s.y, s.stats, s.rows = _ptr(x), _ptr(y), _ptr(st), rows
         ys.append(y); sts.append(st)
-    check(lib.lmv_layernorm_fwd(seg, len(xs), _f32(gamma), _f32(beta), C_, eps, dtype_code(xs[0]), _stream()), "lmv_layernorm_fwd")
+    fn = lib.lmv_layernorm_gelu_fwd if gelu else lib.lmv_layernorm_fwd
+    check(fn(seg, len(xs), _f32(gamma), _f32(beta), C_, eps, dtype_code(xs[0]), _stream()), "lmv_layernorm_fwd")
     return ys, sts
 
 
 def layernorm_bwd_multi(dys: Sequence[Tensor], xs: Sequence[Tensor], stats: Sequence[Tensor], gamma: Tensor, dgamma: Tensor, dbeta: Tensor,
-                        dres: Sequence[Optional[Tensor]], next_scales: Optional[Sequence[Optional[Tensor]]] = None):
+                        dres: Sequence[Optional[Tensor]], next_scales: Optional[Sequence[Optional[Tensor]]] = None, gelu_beta: Optional[Tensor] = None):
     """dx_i = dres_i + LN'(dy_i) for up to two tensors in ONE launch; dgamma / dbeta (fp32) are accumulated in place.
     next_scales: per-sample DropPath vectors of the NEXT backward stage; when given, returns (dxs, scaled) where scaled[i] is
     dx_i * next_scales[i][sample] written by the same launch (or dx_i itself where the scale is None)."""
@@ -150,8 +151,12 @@ def layernorm_bwd_multi(dys: Sequence[Tensor], xs: Sequence[Tensor], stats: Sequ
         dxs.append(dx)
     code = dtype_code(xs[0])
     ws = _workspace(lib.lmv_layernorm_bwd_workspace_bytes(total, C_, code), xs[0].device)
-    check(lib.lmv_layernorm_bwd(seg, len(xs), _f32(gamma), _f32(dgamma), _f32(dbeta), C_, ws.data_ptr(), ws.numel(), code, _stream()),
-          "lmv_layernorm_bwd")
+    if gelu_beta is not None:      # backward of GELU(LayerNorm(x)): needs beta to recompute the pre-activation
+        check(lib.lmv_layernorm_gelu_bwd(seg, len(xs), _f32(gamma), _f32(gelu_beta), _f32(dgamma), _f32(dbeta), C_, ws.data_ptr(), ws.numel(), code,
+                                         _stream()), "lmv_layernorm_gelu_bwd")
+    else:
+        check(lib.lmv_layernorm_bwd(seg, len(xs), _f32(gamma), _f32(dgamma), _f32(dbeta), C_, ws.data_ptr(), ws.numel(), code, _stream()),
+              "lmv_layernorm_bwd")
     return dxs if next_scales is None else (dxs, scaled)
 
 

@@ -145,6 +145,17 @@ def test_layernorm(dtype, rows, C):
     dx = o.layernorm_bwd(dy, x, stats, g, dg, dbt, dres=dres)
     assert_close(dx, xr.grad + dres64, dtype, "ln dx", tol32=2e-5, tol16=2e-3)
     assert_close(dg, gr.grad, torch.float32, "dgamma", 2e-5); assert_close(dbt, br.grad, torch.float32, "dbeta", 2e-5)
+    # fused activation: y = GELU(LN(x)) and its backward (the meta-token MLPs)
+    (ya,), (sta,) = o.layernorm_fwd_multi([x], g, b, 1e-6, want_stats=True, gelu=True)
+    xr2 = x64.clone().requires_grad_(True); gr2 = g64.clone().requires_grad_(True); br2 = b64.clone().requires_grad_(True)
+    ya_ref = gelu64(O.layer_norm(xr2, gr2, br2, 1e-6))
+    assert_close(ya, ya_ref.detach(), dtype, "ln+gelu fwd")
+    (ya_ref * dy64).sum().backward()
+    dg2 = torch.zeros(C, device=dev()); db2 = torch.zeros(C, device=dev())
+    (dxa,) = o.layernorm_bwd_multi([dy], [x], [sta], g, dg2, db2, [None], gelu_beta=b)
+    assert_close(dxa, xr2.grad, dtype, "ln+gelu dx", tol32=2e-5, tol16=2e-3)
+    assert_close(dg2, gr2.grad, torch.float32, "ln+gelu dgamma", 2e-5 if dtype == torch.float32 else 2e-4)
+    assert_close(db2, br2.grad, torch.float32, "ln+gelu dbeta", 2e-5 if dtype == torch.float32 else 2e-4)
     # optional second output of the same launch: dx pre-scaled by the NEXT stage's per-sample DropPath vector
     if rows % 5 == 0:
         x3 = x.view(rows // 5, 5, C); sc = (det_tensor((rows // 5,), "sc", 7).abs() + 0.25).to(dev())

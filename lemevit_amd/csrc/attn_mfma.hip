@@ -25,14 +25,31 @@ typedef __attribute__((address_space(3))) bf16x4_t* lds4_t;
 
 __device__ __forceinline__ int swz(int r, int c16) { return r * 64 + ((c16 ^ (((r >> 2) & 1) << 1)) << 4); }
 
-// rows [r0, r0 + nrows) of a strided [L][32] bf16 matrix -> LDS image (rows >= L zero-filled)
+// rows [r0, r0 + nrows) of TWO strided [L][32] bf16 matrices (K and V, or Q and dO) -> their LDS images (rows >= L zero-filled).
+// Every thread fetches a batch of 4 chunks of each matrix from CLAMPED row indices with no branch around the loads, so the 8
+// loads of a batch are in flight together (a bounds branch per chunk costs one L2 / HBM round trip per chunk: the staging of a
+// 224-row K / V pair was 7 serialised round trips); out-of-range rows are zeroed on the way into LDS.
 template <int NTHREADS>
-__device__ __forceinline__ void stage_rows(unsigned char* s, const bf16_t* base, int64_t rs, int r0, int nrows, int L, int tid) {
-  for (int c = tid; c < nrows * 4; c += NTHREADS) {
-    const int r = c >> 2, cc = c & 3;
-    uint4 v = make_uint4(0, 0, 0, 0);
-    if (r0 + r < L) v = *reinterpret_cast<const uint4*>(base + (int64_t)(r0 + r) * rs + cc * 8);
-    *reinterpret_cast<uint4*>(s + swz(r, cc)) = v;
+__device__ __forceinline__ void stage_rows2(unsigned char* sa, const bf16_t* ba, int64_t rsa, unsigned char* sb, const bf16_t* bb, int64_t rsb,
+                                            int r0, int nrows, int L, int tid) {
+  const int total = nrows * 4, last = max(L - 1, 0);
+  for (int c0 = 0; c0 < total; c0 += NTHREADS * 4) {
+    uint4 va[4], vb[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int c = min(c0 + j * NTHREADS + tid, total - 1), cc = c & 3;
+      const int rr = min(r0 + (c >> 2), last);
+      va[j] = *reinterpret_cast<const uint4*>(ba + (int64_t)rr * rsa + cc * 8);
+      vb[j] = *reinterpret_cast<const uint4*>(bb + (int64_t)rr * rsb + cc * 8);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int c = c0 + j * NTHREADS + tid, r = c >> 2, cc = c & 3;
+      if (c >= total) continue;
+      const bool ok = r0 + r < L;
+      *reinterpret_cast<uint4*>(sa + swz(r, cc)) = ok ? va[j] : make_uint4(0, 0, 0, 0);
+      *reinterpret_cast<uint4*>(sb + swz(r, cc)) = ok ? vb[j] : make_uint4(0, 0, 0, 0);
+    }
   }
 }
 
@@ -78,8 +95,7 @@ __global__ __launch_bounds__(256) void mfma_fwd_kernel(const AttnArgs a, int qt_
   const bf16_t* kb = reinterpret_cast<const bf16_t*>(a.k) + b * a.k_bs + h * D;
   const bf16_t* vb = reinterpret_cast<const bf16_t*>(a.v) + b * a.v_bs + h * D;
   bf16_t* ob = reinterpret_cast<bf16_t*>(a.o) + b * a.o_bs + h * D;
-  stage_rows<256>(sK, kb, a.k_rs, 0, NKT * 16, a.Lk, tid);
-  stage_rows<256>(sV, vb, a.v_rs, 0, NKT * 16, a.Lk, tid);
+  stage_rows2<256>(sK, kb, a.k_rs, sV, vb, a.v_rs, 0, NKT * 16, a.Lk, tid);
   __syncthreads();
   const int nqt = (a.Lq + 15) >> 4;
   const int qt_end = min(nqt, (int)(blockIdx.x + 1) * qt_per_block);
@@ -147,8 +163,7 @@ __global__ __launch_bounds__(256) void mfma_bwd_dq_kernel(const AttnArgs a, floa
   const bf16_t* gb = reinterpret_cast<const bf16_t*>(a.d_o) + b * a.o_bs + h * D;
   const bf16_t* ob = reinterpret_cast<const bf16_t*>(a.o) + b * a.o_bs + h * D;
   bf16_t* dqb = reinterpret_cast<bf16_t*>(a.dq) + b * a.q_bs + h * D;
-  stage_rows<256>(sK, reinterpret_cast<const bf16_t*>(a.k) + b * a.k_bs + h * D, a.k_rs, 0, NKT * 16, a.Lk, tid);
-  stage_rows<256>(sV, reinterpret_cast<const bf16_t*>(a.v) + b * a.v_bs + h * D, a.v_rs, 0, NKT * 16, a.Lk, tid);
+  stage_rows2<256>(sK, reinterpret_cast<const bf16_t*>(a.k) + b * a.k_bs + h * D, a.k_rs, sV, reinterpret_cast<const bf16_t*>(a.v) + b * a.v_bs + h * D, a.v_rs, 0, NKT * 16, a.Lk, tid);
   __syncthreads();
   const int nqt = (a.Lq + 15) >> 4;
   const int qt_end = min(nqt, (int)(blockIdx.x + 1) * qt_per_block);
@@ -216,8 +231,7 @@ __global__ __launch_bounds__(256) void mfma_bwd_dkv_kernel(const AttnArgs a, con
   const int q0 = blockIdx.x * q_per_block, q1 = min(a.Lq, q0 + q_per_block);
   const int nrows = ((q1 - q0 + 31) >> 5) << 5;
   const int64_t bh = ((int64_t)b * a.H + h) * a.Lq;
-  stage_rows<256>(sQ, reinterpret_cast<const bf16_t*>(a.q) + b * a.q_bs + h * D, a.q_rs, q0, nrows, q1, tid);
-  stage_rows<256>(sG, reinterpret_cast<const bf16_t*>(a.d_o) + b * a.o_bs + h * D, a.o_rs, q0, nrows, q1, tid);
+  stage_rows2<256>(sQ, reinterpret_cast<const bf16_t*>(a.q) + b * a.q_bs + h * D, a.q_rs, sG, reinterpret_cast<const bf16_t*>(a.d_o) + b * a.o_bs + h * D, a.o_rs, q0, nrows, q1, tid);
   for (int i = tid; i < nrows; i += 256) {
     const bool ok = q0 + i < q1;
     sL[i] = ok ? a.lse[bh + q0 + i] : 1e30f;      // exp(s - 1e30) = 0 masks the padded queries
@@ -354,8 +368,7 @@ __global__ __launch_bounds__(256) void mfma_fwd_split_kernel(const AttnArgs a, f
   const bf16_t* vb = reinterpret_cast<const bf16_t*>(a.v) + b * a.v_bs + h * D;
   unsigned char* wK = sK + wave * RK * 64;
   unsigned char* wV = sV + wave * RK * 64;
-  stage_rows<64>(wK, kb, a.k_rs, k0, RK, a.Lk, lane);          // per-wave images: only wave-level ordering needed
-  stage_rows<64>(wV, vb, a.v_rs, k0, RK, a.Lk, lane);
+  stage_rows2<64>(wK, kb, a.k_rs, wV, vb, a.v_rs, k0, RK, a.Lk, lane);          // per-wave images: only wave-level ordering needed
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_wave_barrier();
   if (split >= nsplit) return;
@@ -415,10 +428,8 @@ __global__ __launch_bounds__(256) void mfma_bwd_fewq_kernel(const AttnArgs a, fl
   const bf16_t* vb = reinterpret_cast<const bf16_t*>(a.v) + b * a.v_bs + h * D;
   unsigned char* wK = sK + wave * RKB * 64;
   unsigned char* wV = sV + wave * RKB * 64;
-  stage_rows<64>(wK, kb, a.k_rs, k0, RKB, a.Lk, lane);
-  stage_rows<64>(wV, vb, a.v_rs, k0, RKB, a.Lk, lane);
-  stage_rows<256>(sQ, reinterpret_cast<const bf16_t*>(a.q) + b * a.q_bs + h * D, a.q_rs, 0, 32, a.Lq, tid);
-  stage_rows<256>(sG, reinterpret_cast<const bf16_t*>(a.d_o) + b * a.o_bs + h * D, a.o_rs, 0, 32, a.Lq, tid);
+  stage_rows2<64>(wK, kb, a.k_rs, wV, vb, a.v_rs, k0, RKB, a.Lk, lane);
+  stage_rows2<256>(sQ, reinterpret_cast<const bf16_t*>(a.q) + b * a.q_bs + h * D, a.q_rs, sG, reinterpret_cast<const bf16_t*>(a.d_o) + b * a.o_bs + h * D, a.o_rs, 0, 32, a.Lq, tid);
   if (tid < 32) {
     const bool ok = tid < a.Lq;
     sL[tid] = ok ? a.lse[bh + tid] : 1e30f;     // exp(s - 1e30) = 0 masks the padded queries
@@ -528,8 +539,7 @@ __global__ __launch_bounds__(256) void mfma_fwd_long_kernel(const AttnArgs a, in
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = blockIdx.y, b = blockIdx.z;
   const bf16_t* qb = reinterpret_cast<const bf16_t*>(a.q) + b * a.q_bs + h * D;
   bf16_t* ob = reinterpret_cast<bf16_t*>(a.o) + b * a.o_bs + h * D;
-  stage_rows<256>(sK, reinterpret_cast<const bf16_t*>(a.k) + b * a.k_bs + h * D, a.k_rs, 0, nkt * 16, a.Lk, tid);
-  stage_rows<256>(sV, reinterpret_cast<const bf16_t*>(a.v) + b * a.v_bs + h * D, a.v_rs, 0, nkt * 16, a.Lk, tid);
+  stage_rows2<256>(sK, reinterpret_cast<const bf16_t*>(a.k) + b * a.k_bs + h * D, a.k_rs, sV, reinterpret_cast<const bf16_t*>(a.v) + b * a.v_bs + h * D, a.v_rs, 0, nkt * 16, a.Lk, tid);
   __syncthreads();
   const int nqt = (a.Lq + 15) >> 4;
   const int qt_end = min(nqt, (int)(blockIdx.x + 1) * qt_per_block);
@@ -595,8 +605,7 @@ __global__ __launch_bounds__(256) void mfma_bwd_dq_long_kernel(const AttnArgs a,
   const bf16_t* gb = reinterpret_cast<const bf16_t*>(a.d_o) + b * a.o_bs + h * D;
   const bf16_t* ob = reinterpret_cast<const bf16_t*>(a.o) + b * a.o_bs + h * D;
   bf16_t* dqb = reinterpret_cast<bf16_t*>(a.dq) + b * a.q_bs + h * D;
-  stage_rows<256>(sK, reinterpret_cast<const bf16_t*>(a.k) + b * a.k_bs + h * D, a.k_rs, 0, nkt * 16, a.Lk, tid);
-  stage_rows<256>(sV, reinterpret_cast<const bf16_t*>(a.v) + b * a.v_bs + h * D, a.v_rs, 0, nkt * 16, a.Lk, tid);
+  stage_rows2<256>(sK, reinterpret_cast<const bf16_t*>(a.k) + b * a.k_bs + h * D, a.k_rs, sV, reinterpret_cast<const bf16_t*>(a.v) + b * a.v_bs + h * D, a.v_rs, 0, nkt * 16, a.Lk, tid);
   __syncthreads();
   const int nqt = (a.Lq + 15) >> 4;
   const int qt_end = min(nqt, (int)(blockIdx.x + 1) * qt_per_block);
@@ -668,8 +677,7 @@ __global__ __launch_bounds__(256) void mfma_bwd_dkv_long_kernel(const AttnArgs a
     const int q1 = min(a.Lq, q0 + q_chunk);
     const int nrows = ((q1 - q0 + 31) >> 5) << 5;
     __syncthreads();                                               // the previous chunk's images are consumed
-    stage_rows<256>(sQ, reinterpret_cast<const bf16_t*>(a.q) + b * a.q_bs + h * D, a.q_rs, q0, nrows, q1, tid);
-    stage_rows<256>(sG, reinterpret_cast<const bf16_t*>(a.d_o) + b * a.o_bs + h * D, a.o_rs, q0, nrows, q1, tid);
+    stage_rows2<256>(sQ, reinterpret_cast<const bf16_t*>(a.q) + b * a.q_bs + h * D, a.q_rs, sG, reinterpret_cast<const bf16_t*>(a.d_o) + b * a.o_bs + h * D, a.o_rs, q0, nrows, q1, tid);
     for (int i = tid; i < nrows; i += 256) {
       const bool ok = q0 + i < q1;
       sL[i] = ok ? a.lse[bh + q0 + i] : 1e30f;                     // exp(s - 1e30) = 0 masks the padded queries

@@ -45,6 +45,7 @@ struct Cfg {
 using C128 = Cfg<2, 2, 4>;        // 128 x 128, 4 waves of 64 x 64
 using C256x128 = Cfg<4, 2, 4>;    // 256 x 128, 8 waves of 64 x 64
 using C256 = Cfg<2, 4, 8>;        // 256 x 256, 8 waves of 128 x 64
+using C128w8 = Cfg<4, 2, 2>;      // 128 x 128, 8 waves of 32 x 64 (64-deep k-tiles at 4 waves per SIMD)
 
 struct Problem {
   const void* a; const void* b; const float* bias; const void* res; const float* row_scale; const void* aux;
@@ -59,6 +60,7 @@ struct Problem {
 struct GemmArgs {
   Problem p[2];
   int nprob, N, lda, ldb, ldc, act, tiles_n, kt_per_split;
+  int cumap;                     // fwd / dX: CU-aware tile order (see gemm_kernel)
   int ntiles, nsplits, concat;   // dW: tiles of dW, k-splits, and whether problem 1's rows extend problem 0's reduction
   float* ws;              // split-K (dW) mode: partial slabs [slab][N*K + N] fp32
   int64_t slab_stride;    // floats per slab
@@ -333,7 +335,15 @@ __global__ __launch_bounds__(CF::NTHR, MINW) void gemm_kernel(const GemmArgs g) 
     }
     if (split >= g.nsplits || bid >= g.ntiles) return;
   } else {
-    const int T_ = gridDim.x, xcd = blockIdx.x & 7, idx = blockIdx.x >> 3, q = T_ >> 3, r = T_ & 7;
+    const int T_ = gridDim.x, xcd = blockIdx.x & 7, q = T_ >> 3, r = T_ & 7, len = q + (xcd < r ? 1 : 0);
+    int idx = blockIdx.x >> 3;
+    // Inside an XCD the dispatcher deals workgroups round-robin over its 32 CUs (tools/native/hwid_probe.hip): the XCD-local
+    // workgroups i, i + 32, i + 64, i + 96 share a CU.  Hand those four CONSECUTIVE tiles (same m-tile, neighbouring n-tiles) so
+    // that their A rows can meet in the CU's vector L1 instead of each going to L2.
+    if (g.cumap) {
+      const int chunk = idx & ~127;
+      if (chunk + 128 <= len) idx = chunk + ((idx & 31) << 2) + ((idx >> 5) & 3);
+    }
     bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
   }
   const int pi = (g.nprob > 1 && !g.concat && bid >= g.p[1].tile_begin) ? 1 : 0;
@@ -471,7 +481,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
 }
 
 enum Mode { MODE_FWD = 0, MODE_DX = 1, MODE_DW = 2 };
-enum Tile { TILE_128 = 0, TILE_256x128 = 1, TILE_256 = 2 };
+enum Tile { TILE_128 = 0, TILE_256x128 = 1, TILE_256 = 2, TILE_128W8 = 3 };
 
 struct Plan { GemmArgs g; int total, splits, bk, tile, dma, nsplit[2]; size_t ws_bytes; };
 
@@ -516,17 +526,17 @@ int make_plan(const lmv_linear_problem* p, int nproblems, int N, int K, int act,
   // Occupancy beats k-tile depth whenever the launch has enough tiles to put 4 workgroups on every CU: half of a
   // workgroup's life is launch + first-load latency + epilogue + store drain, which only OTHER resident workgroups
   // hide.  The 32-deep variant needs 32 KB of LDS and <= 128 registers (4 per CU) against 64 KB / 160 (2 per CU).
+  int64_t tiles128 = 0;
+  for (int i = 0; i < nproblems; ++i) tiles128 += (int64_t)((g.p[i].M + 127) / 128) * ((out_cols + 127) / 128);
   if (bf && all32 && mode != MODE_DW) {
-    int64_t tiles128 = 0;
-    for (int i = 0; i < nproblems; ++i) tiles128 += (int64_t)((g.p[i].M + 127) / 128) * ((out_cols + 127) / 128);
     static const int min_tiles = [] { const char* e = getenv("LMV_GEMM_BK32_TILES"); return e ? atoi(e) : 512; }();
     if (tiles128 >= min_tiles) bk = 32;
   }
   // dW: 32-deep as well (3 workgroups per CU; tools/dw_sweep.py: best or within 5 % of best on every layer shape)
   const int dw_bk = [] { const char* e = getenv("LMV_DW_BK"); return e ? atoi(e) : 32; }();   // A/B testing (re-read per call)
   if (bf && all32 && mode == MODE_DW && dw_bk == 32) bk = 32;
-  if (force_bk == 32 && all32) bk = 32;
-  if (force_bk == 64 && all64) bk = 64;
+  if (bf && force_bk == 32 && all32) bk = 32;
+  if (bf && force_bk == 64 && all64) bk = 64;
   static const bool no_dma = getenv("LMV_GEMM_NO_DMA") != nullptr;     // A/B testing
   const bool dma = bf && !no_dma && (bk == 64 ? all64 : all32);
   // Tile choice.  Measured on the LeMeViT shapes (K = 96..2048, tools/bench_kernels.py): 128x128 beats 256x128 and
@@ -535,18 +545,28 @@ int make_plan(const lmv_linear_problem* p, int nproblems, int N, int K, int act,
   // the larger tiles automatically for 64-deep problems (they win for long K), 1 / 2 force them.
   static const int force_tile = [] { const char* e = getenv("LMV_GEMM_TILE"); return e ? atoi(e) : 0; }();
   int tile = TILE_128;
-  if (dma && (bk == 64 || (force_tile == TILE_256x128 && mode != MODE_DW))) {
+  // 64-deep k-tiles at FOUR waves per SIMD: the 128x128 tile on 8 waves of 32x64 (2 workgroups of 64 KB per CU).  Every operand
+  // row is then a whole 128-byte line per k-tile -- the 32-deep loop asks L2 for half lines, and L2 (82 % busy on the stage-3 fc2
+  // shape, tools/pmc_mem.sh) serves a half line in the same slot as a whole one -- at the price of 1.5x the LDS fragment reads.
+  // Measured (tools/bench_kernels.py): forward 3-12 % faster on every K % 64 == 0 shape; dX faster only on the launches that
+  // cannot fill 4 workgroups per CU (stage 4), slower elsewhere; dW much slower.
+  static const int w8_mode = [] { const char* e = getenv("LMV_GEMM_W8"); return e ? atoi(e) : 1; }();
+  const bool w8 = bf && !no_dma && all64 && w8_mode && force_bk == 0 && force_tile == 0 &&
+                  (mode == MODE_FWD || (mode == MODE_DX && (tiles128 < 512 || w8_mode == 2)));
+  if (w8) { bk = 64; tile = TILE_128W8; }
+  if (!w8 && dma && (bk == 64 || (force_tile == TILE_256x128 && mode != MODE_DW))) {
     if (force_tile < 0) {
       auto tiles_of = [&](int bm, int bn) { int64_t t = 0; for (int i = 0; i < nproblems; ++i) t += (int64_t)((g.p[i].M + bm - 1) / bm) * ((out_cols + bn - 1) / bn); return t; };
       const int64_t need = (mode == MODE_DW) ? 48 : 200;      // dW multiplies its grid by the k-splits
       const bool fits256 = out_cols % 256 == 0 || out_cols >= 1024;      // <= 12 % padded columns
       if (max_m >= 256 && fits256 && tiles_of(256, 256) >= need) tile = TILE_256;
       else if (max_m >= 256 && tiles_of(256, 128) >= need) tile = TILE_256x128;
-    } else if (force_tile <= TILE_256) {
+    } else if (force_tile <= TILE_128W8) {
       tile = force_tile;
     }
   }
-  const int bm = tile == TILE_128 ? 128 : 256, bn = tile == TILE_256 ? 256 : 128;
+  if (tile == TILE_128W8 && bk != 64) tile = TILE_128;
+  const int bm = (tile == TILE_128 || tile == TILE_128W8) ? 128 : 256, bn = tile == TILE_256 ? 256 : 128;
   g.tiles_n = (out_cols + bn - 1) / bn;
   // dW of two problems that accumulate into the same dW / db (x and c rows through shared weights): one reduction
   g.concat = mode == MODE_DW && nproblems == 2 && p[0].out == p[1].out && p[0].bias_grad == p[1].bias_grad;
@@ -596,6 +616,7 @@ int make_plan(const lmv_linear_problem* p, int nproblems, int N, int K, int act,
     g.slab_stride = (int64_t)N * K + N;
     pl->ws_bytes = (size_t)slabs * g.slab_stride * sizeof(float);
   }
+  g.cumap = [] { const char* e = getenv("LMV_GEMM_CUMAP"); return e ? atoi(e) : 1; }();      // A/B testing
   pl->total = total; pl->splits = splits; pl->bk = bk; pl->tile = tile; pl->dma = dma;
   return LMV_OK;
 }
@@ -630,6 +651,7 @@ int launch_mode(const Plan& pl, dim3 grid, bool bf, hipStream_t st) {
   switch (pl.tile) {
     case TILE_256:     return launch_one<bf16_t, ATR, BTR, SPLITK, 64, true, C256>(g, grid, st);
     case TILE_256x128: return launch_one<bf16_t, ATR, BTR, SPLITK, 64, true, C256x128>(g, grid, st);
+    case TILE_128W8:   return launch_one<bf16_t, ATR, BTR, SPLITK, 64, true, C128w8, 2>(g, grid, st);
     default:           return launch_one<bf16_t, ATR, BTR, SPLITK, 64, true, C128>(g, grid, st);
   }
 }

@@ -4,7 +4,7 @@ cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT; O=gpurun_out/pmcm; rm -rf $O
 rocprofv3 --list-avail 2>/dev/null | grep -o -E "\b(TA|TCP|TD|TCC)_[A-Za-z0-9_]+" | sort -u > $O/avail.txt
 wc -l $O/avail.txt
 i=0
-for set in "TA_TA_BUSY_sum TA_BUSY_avr GRBM_GUI_ACTIVE" "TCP_PENDING_STALL_CYCLES_sum TCP_TCP_TA_DATA_STALL_CYCLES_sum" "TCP_TCR_TCP_STALL_CYCLES_sum TCP_READ_TAGCONFLICT_STALL_CYCLES_sum" "TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum" "TCC_HIT_sum TCC_MISS_sum" "TCC_REQ_sum TCC_READ_sum" "TD_TD_BUSY_sum TD_BUSY_avr" "TCP_GATE_EN1_sum TCP_GATE_EN2_sum" "TCC_BUSY_avr TCC_BUSY_sum"; do
+for set in "TA_BUSY_avr GRBM_GUI_ACTIVE" "TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum" "TCC_HIT_sum TCC_MISS_sum" "TCC_REQ_sum TCC_READ_sum" "TD_BUSY_avr TCC_BUSY_avr" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES" "TCC_WRITE_sum TCC_EA0_WRREQ_sum"; do
   i=$((i+1))
   rocprofv3 --pmc $set --kernel-trace -d $O/s$i -o p -- python tools/gemm_pmc_probe.py $@ > $O/s$i.log 2>&1
 done

@@ -161,6 +161,11 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    # test hooks (1-GPU box): LMV_BENCH_SINGLE_DEVICE=1 puts every rank on cuda:0 and LMV_BENCH_BACKEND=gloo replaces RCCL (which
+    # refuses two ranks on one device), so the N > 1 code path can be exercised end to end without N GPUs
+    if os.environ.get("LMV_BENCH_SINGLE_DEVICE") == "1":
+        local = 0
+    backend = os.environ.get("LMV_BENCH_BACKEND", "nccl")
     torch.cuda.set_device(local)
     torch.backends.cudnn.benchmark = True      # as the reference's harness (benchmark.py:76): MIOpen searches its solvers for the stem / stage-transition convolutions
     dev = torch.device("cuda", local)
@@ -184,7 +189,10 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
         os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend)
     if train:
         # benchmark.py:559-561 create_optimizer_v2(opt='adamw', lr=1e-4), scripts/benchmark.sh:8 eps 1e-8 wd 0.05
         decay = [p for n, p in model.named_parameters() if p.ndim > 1]

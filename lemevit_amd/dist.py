@@ -161,9 +161,14 @@ def attach_flat_grad_sync(model: torch.nn.Module, opt, nchunks: int = 4, group=N
     total = opt._flat_g.numel()
     offs = [starts[b] for b in order] + [total]
     nchunks = max(1, min(nchunks, len(order)))
-    cuts, target = [0], total / nchunks
+    # Chunk sizes grow 1 : 2 : ... : nchunks in forward order: the backward pass completes the chunks last-to-first, so the big
+    # ones (late stages hold most of the parameters anyway) are exchanged under the rest of the backward pass and the one
+    # whose all-reduce cannot overlap anything -- the first blocks, differentiated last -- is the smallest.
+    tri = nchunks * (nchunks + 1) / 2
+    targets = [total * (j * (j + 1) / 2) / tri for j in range(1, nchunks)]
+    cuts = [0]
     for i in range(1, len(order)):
-        if offs[i] >= target * len(cuts) and len(cuts) < nchunks:
+        if len(cuts) < nchunks and offs[i] >= targets[len(cuts) - 1]:
             cuts.append(i)
     bounds = [(offs[c], offs[cuts[j + 1]] if j + 1 < len(cuts) else total) for j, c in enumerate(cuts)]
     block_params = {id(p) for _, p, _, _ in opt._slices}

@@ -109,6 +109,25 @@ int lmv_layernorm_bwd(const lmv_ln_segment* seg, int nseg, const float* gamma, f
                       void* workspace, size_t workspace_bytes, int dtype, void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Training-mode BatchNorm2d (+ exact GELU) over a channels-last feature map viewed as [rows = B*H*W][C]: the BatchNorm2d
+ * (-> GELU) of the stem and of every stage transition (models/lemevit.py:698-704, 714-717) and the final `norm` (:773, 822).
+ * Replaces torch.nn.BatchNorm2d.forward in training mode (+ the nn.GELU after the first stem BatchNorm) and their autograd.
+ *   fwd: batch mean / biased variance per channel (fp32 partial sums, fp64 combine); y = (x - mean) * rstd * gamma + beta
+ *        (act = LMV_ACT_GELU: GELU of that); stats[0:C] = mean, stats[C:2C] = rstd (saved for the backward);
+ *        running_mean / running_var (may be NULL) updated with `momentum` and the UNBIASED variance, as torch.
+ *   bwd: dgamma / dbeta are WRITTEN (not accumulated); dx = gamma * rstd * (dy' - mean(dy') - xhat * mean(dy' * xhat)),
+ *        dy' = dy * GELU'(xhat * gamma + beta) when act = LMV_ACT_GELU.
+ * C % 8 == 0 (bf16) / C % 4 == 0 (fp32), C <= 2048 / 1024; workspace: lmv_batchnorm_workspace_bytes(C).
+ * ------------------------------------------------------------------------------------------ */
+size_t lmv_batchnorm_workspace_bytes(int C);
+int lmv_batchnorm_train_fwd(const void* x, const float* gamma, const float* beta, float* running_mean, float* running_var, float momentum,
+                            float eps, int act, void* y, float* stats, int64_t rows, int C, void* workspace, size_t workspace_bytes,
+                            int dtype, void* stream);
+int lmv_batchnorm_train_bwd(const void* dy, const void* x, const float* gamma, const float* beta, const float* stats, int act, void* dx,
+                            float* dgamma, float* dbeta, int64_t rows, int C, void* workspace, size_t workspace_bytes, int dtype,
+                            void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * Conditional position embedding: y = x + dwconv3x3(x) + bias, NHWC (models/lemevit.py:510,546).
  * weight is the reference's [C, 1, 3, 3] fp32 tensor.
  *   bwd_data  : dx = dy + dwconv3x3^T(dy)

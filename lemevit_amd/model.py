@@ -20,6 +20,7 @@ statistics, fp32 master weights and gradients (the bf16 matrix copies are cached
 """
 from __future__ import annotations
 
+import os
 import weakref
 from collections import OrderedDict
 from typing import Dict, List, Optional, Sequence, Tuple
@@ -131,6 +132,48 @@ class _StemConv1Fn(torch.autograd.Function):
         ops.linear_dw([Prob(g, patches, dwm, bias_grad=db)], Co, 32)
         dw = dwm[:, :27].reshape(wshape).to(wdt)
         return None, dw, (None if bdt is None else db.to(bdt)), None
+
+
+class _BNActFn(torch.autograd.Function):
+    """Training-mode BatchNorm2d (+ the GELU behind the first stem BatchNorm) on a channels-last feature map
+    (models/lemevit.py:698-704, 714-717, 773): lmv_batchnorm_train_fwd / _bwd instead of MIOpen's batch-norm kernels plus
+    a separate GELU pass.  Running statistics are updated in place like nn.BatchNorm2d."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, running_mean, running_var, momentum, eps, gelu):
+        B, C, H, W = x.shape
+        x2d = x.detach().permute(0, 2, 3, 1).contiguous().view(B * H * W, C)        # no copy for channels-last input
+        g32, b32 = compute_copy(weight, torch.float32), compute_copy(bias, torch.float32)
+        y, stats = ops.batchnorm_train_fwd(x2d, g32, b32, running_mean, running_var, momentum, eps, gelu)
+        ctx.save_for_backward(x2d, stats, g32, b32)
+        ctx.meta = (gelu, (B, C, H, W), weight.dtype, bias.dtype)
+        return y.view(B, H, W, C).permute(0, 3, 1, 2)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2d, stats, g32, b32 = ctx.saved_tensors
+        gelu, (B, C, H, W), wdt, bdt = ctx.meta
+        g = dy.permute(0, 2, 3, 1).contiguous().view(B * H * W, C)
+        if g.dtype != x2d.dtype:
+            g = g.to(x2d.dtype)
+        dx, dgamma, dbeta = ops.batchnorm_train_bwd(g, x2d, g32, b32, stats, gelu)
+        return dx.view(B, H, W, C).permute(0, 3, 1, 2), dgamma.to(wdt), dbeta.to(bdt), None, None, None, None, None
+
+
+_BN_NATIVE = os.environ.get("LMV_BN_NATIVE", "1") != "0"          # A/B testing against torch / MIOpen
+
+
+def _bn_native(m: nn.Module, x: Tensor) -> bool:
+    """Can this BatchNorm2d call run on the HIP training kernels?"""
+    return (_BN_NATIVE and isinstance(m, nn.BatchNorm2d) and m.training and m.affine and m.track_running_stats and m.momentum is not None and x.is_cuda
+            and x.dim() == 4 and x.dtype in (torch.float32, torch.bfloat16) and x.shape[1] % 8 == 0 and x.shape[1] <= 1024
+            and x.shape[0] * x.shape[2] * x.shape[3] > 1 and m.weight.dtype == torch.float32)
+
+
+def _bn_train(m: nn.BatchNorm2d, x: Tensor, gelu: bool = False) -> Tensor:
+    if m.num_batches_tracked is not None:
+        m.num_batches_tracked.add_(1)
+    return _BNActFn.apply(x, m.weight, m.bias, m.running_mean, m.running_var, float(m.momentum), float(m.eps), gelu)
 
 
 class _MetaMLPFn(torch.autograd.Function):
@@ -600,6 +643,10 @@ class LeMeViT(nn.Module):
             elif _is_stem_conv1(m, x) and cd in (torch.float32, torch.bfloat16):
                 x = _StemConv1Fn.apply(x, m.weight, m.bias, cd)
                 i += 1
+            elif _bn_native(m, x):
+                gelu = i + 1 < len(mods) and isinstance(mods[i + 1], nn.GELU) and getattr(mods[i + 1], "approximate", "none") == "none"
+                x = _bn_train(m, x, gelu)
+                i += 2 if gelu else 1
             else:
                 x = m(x)
                 i += 1
@@ -655,7 +702,8 @@ class LeMeViT(nn.Module):
             c = c.to(cd).contiguous()
             for blk in self.stages[i]:
                 xt, c = blk.forward_tokens(xt, c, H, W, masks=all_masks.get(id(blk)) if all_masks else None)
-        xn = self.norm(self._to_nchw(xt, H, W))
+        xn = self._to_nchw(xt, H, W)
+        xn = _bn_train(self.norm, xn) if _bn_native(self.norm, xn) else self.norm(xn)
         xn = self.pre_logits(xn)
         cn = self.pre_logits(self.norm_c(c))
         return xn.flatten(2).mean(-1) + cn.mean(dim=1)

@@ -111,6 +111,33 @@ def linear_dw(probs: Sequence[Prob], N: int, K: int, stream: Optional[int] = Non
 
 
 # -------------------------------------------------------------------------------------------
+# BatchNorm2d (training mode) over channels-last rows
+# -------------------------------------------------------------------------------------------
+def batchnorm_train_fwd(x2d: Tensor, gamma: Tensor, beta: Tensor, running_mean: Optional[Tensor], running_var: Optional[Tensor],
+                        momentum: float, eps: float, gelu: bool = False):
+    """x2d [rows, C] (a channels-last feature map).  Returns (y, stats[2, C] = batch mean / rstd); running stats updated in place."""
+    rows, C_ = x2d.shape
+    y = torch.empty_like(x2d)
+    stats = torch.empty((2, C_), device=x2d.device, dtype=torch.float32)
+    ws = _workspace(lib.lmv_batchnorm_workspace_bytes(C_), x2d.device)
+    check(lib.lmv_batchnorm_train_fwd(_ptr(x2d), _f32(gamma), _f32(beta), _f32(running_mean), _f32(running_var), momentum, eps, ACT_GELU if gelu else ACT_NONE,
+                                      _ptr(y), _f32(stats), rows, C_, ws.data_ptr(), ws.numel(), dtype_code(x2d), _stream()), "lmv_batchnorm_train_fwd")
+    return y, stats
+
+
+def batchnorm_train_bwd(dy2d: Tensor, x2d: Tensor, gamma: Tensor, beta: Tensor, stats: Tensor, gelu: bool = False):
+    """Returns (dx, dgamma, dbeta) of batchnorm_train_fwd."""
+    rows, C_ = x2d.shape
+    dx = torch.empty_like(x2d)
+    dgamma = torch.empty((C_,), device=x2d.device, dtype=torch.float32)
+    dbeta = torch.empty((C_,), device=x2d.device, dtype=torch.float32)
+    ws = _workspace(lib.lmv_batchnorm_workspace_bytes(C_), x2d.device)
+    check(lib.lmv_batchnorm_train_bwd(_ptr(dy2d), _ptr(x2d), _f32(gamma), _f32(beta), _f32(stats), ACT_GELU if gelu else ACT_NONE, _ptr(dx), _f32(dgamma),
+                                      _f32(dbeta), rows, C_, ws.data_ptr(), ws.numel(), dtype_code(x2d), _stream()), "lmv_batchnorm_train_bwd")
+    return dx, dgamma, dbeta
+
+
+# -------------------------------------------------------------------------------------------
 # LayerNorm
 # -------------------------------------------------------------------------------------------
 def layernorm_fwd_multi(xs: Sequence[Tensor], gamma: Tensor, beta: Tensor, eps: float, want_stats: bool = False, gelu: bool = False):

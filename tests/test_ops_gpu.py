@@ -323,3 +323,42 @@ def test_im2col_stem(dtype, shape):
     o.linear_fwd([o.Prob(p, wm, y, bias=b)], Co, 32)
     conv = torch.nn.functional.conv2d(x.to(dtype).double().cpu(), w.to(dtype).double().cpu(), b.double().cpu(), stride=2, padding=1)
     assert_close(y, conv.permute(0, 2, 3, 1).reshape(-1, Co), dtype, "stem conv1 as GEMM")
+
+
+# ------------------------------------------------------------------------------------------------
+# training-mode BatchNorm2d (+ GELU) over channels-last rows (models/lemevit.py:698-704, 714-717, 773)
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("rows,C,gelu", [(2 * 56 * 56, 48, True), (3 * 28 * 28, 96, False), (2 * 7 * 7, 512, False), (4 * 5 * 3, 64, True), (37, 1024, False)])
+def test_batchnorm_train(rows, C, gelu, dtype):
+    x, x64 = rnd((rows, C), "bn.x", dtype, 1.5)
+    x64 = x64 + 0.0
+    # a per-channel offset so that mean^2 is not small against the variance
+    off = det_tensor((C,), "bn.off", 7, 2.0).to(dtype)
+    x = (x.float() + off.to(dev())).to(dtype); x64 = x.to("cpu", torch.float64)
+    g = (det_tensor((C,), "bn.g", 7, 0.3) + 1.0); b = det_tensor((C,), "bn.b", 7, 0.2)
+    rm = det_tensor((C,), "bn.rm", 7, 0.2); rv = det_tensor((C,), "bn.rv", 7, 0.3) + 1.0
+    dy, dy64 = rnd((rows, C), "bn.dy", dtype)
+    eps, mom = 1e-5, 0.1
+    # float64 reference (torch.nn.functional.batch_norm semantics)
+    mean = x64.mean(0); var = x64.var(0, unbiased=False); rstd = 1.0 / torch.sqrt(var + eps)
+    xh = (x64 - mean) * rstd
+    u = xh * g.double() + b.double()
+    y_ref = gelu64(u) if gelu else u
+    rm_ref = (1 - mom) * rm.double() + mom * mean
+    rv_ref = (1 - mom) * rv.double() + mom * x64.var(0, unbiased=True)
+    dyp = dy64 * gelu_grad64(u) if gelu else dy64
+    dbeta_ref = dyp.sum(0); dgamma_ref = (dyp * xh).sum(0)
+    dx_ref = g.double() * rstd * (dyp - dyp.mean(0) - xh * (dyp * xh).mean(0))
+
+    gd, bd, rmd, rvd = g.to(dev()), b.to(dev()), rm.to(dev()).clone(), rv.to(dev()).clone()
+    y, stats = ops().batchnorm_train_fwd(x, gd, bd, rmd, rvd, mom, eps, gelu)
+    assert_close(y, y_ref, dtype, "bn y")
+    assert_close(stats[0], mean, torch.float32, "bn mean", tol32=2e-6)
+    assert_close(stats[1], rstd, torch.float32, "bn rstd", tol32=1e-5)
+    assert_close(rmd, rm_ref, torch.float32, "running_mean", tol32=2e-6)
+    assert_close(rvd, rv_ref, torch.float32, "running_var", tol32=1e-5)
+    dx, dgamma, dbeta = ops().batchnorm_train_bwd(dy, x, gd, bd, stats, gelu)
+    assert_close(dx, dx_ref, dtype, "bn dx", tol32=2e-5)
+    tolw = 1e-5 if dtype == torch.float32 else 2e-3          # bf16 mode: GELU' through the branch-free erf
+    assert_close(dgamma, dgamma_ref, torch.float32, "bn dgamma", tol32=tolw)
+    assert_close(dbeta, dbeta_ref, torch.float32, "bn dbeta", tol32=tolw)

@@ -38,6 +38,9 @@ PARAM_NAMES = {
     "C": ["pos_embed.weight", "pos_embed.bias", "norm1.weight", "norm1.bias", "attn.q.weight", "attn.q.bias", "attn.kv.weight", "attn.kv.bias",
           "attn.proj.weight", "attn.proj.bias", "norm2.weight", "norm2.bias", "mlp.0.weight", "mlp.0.bias", "mlp.3.weight", "mlp.3.bias"],
 }
+# "Sx": the S block of the dense-prediction backbones -- attention and MLP on the image tokens only, the meta tokens pass
+# through untouched (object_detection/mmdet/models/backbones/lemevit.py:615-643); same parameters as "S"
+PARAM_NAMES["Sx"] = PARAM_NAMES["S"]
 
 
 # Weight-gradient GEMMs are off the critical path of the backward pass (nothing inside the block consumes dW), so they
@@ -281,6 +284,10 @@ def block_forward(kind: str, x: Tensor, c: Tensor, H: int, W: int, P: Dict[str, 
         c1, sa = _attn_C_fwd(P, xp, c, masks[0], save)
         (c2,), sm = _mlp_fwd(P, [c1], [masks[1]], save)
         return x, c2, ((x, sa, sm) if save else None)                                            # returns the ORIGINAL x (:610)
+    if kind == "Sx":
+        (x2,), sa = _attn_S_fwd(P, [xp], [masks[0]], save)
+        (x3,), sm = _mlp_fwd(P, [x2], [masks[1]], save)
+        return x3, c, ((x, sa, sm) if save else None)
     fwd = {"S": _attn_S_fwd, "D": _attn_D_fwd, "D2": _attn_D2_fwd}[kind]
     (x2, c1), sa = fwd(P, [xp, c], [masks[0], masks[2]], save)
     (x3, c2), sm = _mlp_fwd(P, [x2, c1], [masks[1], masks[3]], save)
@@ -298,6 +305,13 @@ def block_backward(kind: str, saved, dx: Tensor, dc: Tensor, H: int, W: int, P: 
         dx0 = ops.dwconv_residual_bwd_data(dxp, P["pos_embed.weight"], H, W)
         _join()
         return (dx0 if dx is None else dx0 + dx), dc0   # the untouched x's pass-through gradient is added by autograd
+    if kind == "Sx":
+        (dx2,), g_attn = _mlp_bwd(P, G, sm, [dx], [masks[1]], next_ds=[masks[0]])
+        (dxp,) = _attn_S_bwd(P, G, sa, [dx2], [masks[0]], g=g_attn)
+        _dwconv_w(dxp, x0, G["pos_embed.weight"], G["pos_embed.bias"], H, W)
+        dx0 = ops.dwconv_residual_bwd_data(dxp, P["pos_embed.weight"], H, W)
+        _join()
+        return dx0, dc                                      # the meta tokens' gradient passes through
     (dx2, dc1), g_attn = _mlp_bwd(P, G, sm, [dx, dc], [masks[1], masks[3]], next_ds=[masks[0], masks[2]])
     bwd = {"S": _attn_S_bwd, "D": _attn_D_bwd, "D2": _attn_D2_bwd}[kind]
     dxp, dc0 = bwd(P, G, sa, [dx2, dc1], [masks[0], masks[2]], g=g_attn)

@@ -299,6 +299,8 @@ class _BlockFn(torch.autograd.Function):
         ctx.cshape = c.shape
         if kind == "C":
             return co                      # x passes through unchanged outside the node (models/lemevit.py:610)
+        if kind == "Sx":
+            return xo                      # c passes through unchanged outside the node (dense-prediction S block)
         return xo, co
 
     @staticmethod
@@ -306,10 +308,12 @@ class _BlockFn(torch.autograd.Function):
         kind, names, P = ctx.kind, ctx.names, ctx.P
         if kind == "C":
             dx, dc = None, grads[0]
+        elif kind == "Sx":
+            dx, dc = grads[0], None
         else:
             dx, dc = grads
         x0 = ctx.saved[0]
-        if dc is None:
+        if dc is None and kind != "Sx":
             dc = torch.zeros(ctx.cshape, device=x0.device, dtype=x0.dtype)
         if dx is None and kind != "C":
             dx = torch.zeros_like(x0)
@@ -327,7 +331,7 @@ class _BlockFn(torch.autograd.Function):
             for n, (shape, _), sz, pd in zip(names, ctx.pmeta, sizes, pad):
                 G[n] = flat[off:off + sz].view(shape)
                 off += pd
-        dx0, dc0 = block_backward(kind, ctx.saved, None if dx is None else dx.contiguous(), dc.contiguous(), ctx.H, ctx.W, P, G, ctx.masks)
+        dx0, dc0 = block_backward(kind, ctx.saved, None if dx is None else dx.contiguous(), None if dc is None else dc.contiguous(), ctx.H, ctx.W, P, G, ctx.masks)
         cb = getattr(ctx.params[0], "_lmv_grad_cb", None) if inplace else None
         ctx.saved = ctx.params = None
         if cb is not None:
@@ -346,7 +350,7 @@ def run_block(kind: str, x: Tensor, c: Tensor, H: int, W: int, params: "OrderedD
     need_grad = torch.is_grad_enabled() and (x.requires_grad or c.requires_grad or any(p.requires_grad for p in plist))
     if need_grad:
         out = _BlockFn.apply(x, c, kind, H, W, tuple(masks), names, *plist)
-        return (x, out) if kind == "C" else out
+        return (x, out) if kind == "C" else ((out, c) if kind == "Sx" else out)
     cd = x.dtype
     P = {n: compute_copy(p, cd if _is_matrix(n) else torch.float32) for n, p in zip(names, plist)}
     xo, co, _ = block_forward(kind, x, c, H, W, P, masks, save=False)
@@ -476,8 +480,9 @@ class LeMeBlock(nn.Module):
     """models/lemevit.py:500-660 (pre_norm=True, no layer scale, cpe_ks=3, mlp_dwconv=False: the shipped variants)."""
 
     def __init__(self, dim, attn_drop, proj_drop, drop_path=0.0, attn_type=None, layer_scale_init_value=-1, num_heads=8, qk_dim=None,
-                 mlp_ratio=4, mlp_dwconv=False, cpe_ks=3, pre_norm=True):
+                 mlp_ratio=4, mlp_dwconv=False, cpe_ks=3, pre_norm=True, dense=False):
         super().__init__()
+        self.dense = bool(dense)            # dense-prediction backbones: an "S" block leaves the meta tokens untouched
         if layer_scale_init_value > 0 or not pre_norm or mlp_dwconv or cpe_ks != 3:
             raise NotImplementedError("lemevit_amd builds the live path of the shipped variants: pre_norm, no layer scale, cpe_ks=3, no mlp_dwconv")
         self.pos_embed = nn.Conv2d(dim, dim, kernel_size=cpe_ks, padding=1, groups=dim)
@@ -508,8 +513,12 @@ class LeMeBlock(nn.Module):
         self._pcache = None
         return super()._apply(fn, *a, **k)
 
+    @property
+    def kind(self) -> str:
+        return "Sx" if (self.dense and self.attn_type == "S") else self.attn_type
+
     def _masks(self, B: int, device) -> List[Optional[Tensor]]:
-        n = 2 if self.attn_type == "C" else 4
+        n = 2 if self.kind in ("C", "Sx") else 4
         if not self.training or self.drop_prob <= 0.0:
             return [None] * 4
         keep = 1.0 - self.drop_prob            # timm DropPath: per-sample Bernoulli(keep) / keep, drawn independently per call
@@ -520,7 +529,7 @@ class LeMeBlock(nn.Module):
         """x [B, H*W, C] token-major, c [B, M, C]."""
         if masks is None:
             masks = self._masks(x.shape[0], x.device)
-        return run_block(self.attn_type, x, c, H, W, self._params(), masks)
+        return run_block(self.kind, x, c, H, W, self._params(), masks)
 
     def forward(self, x: Tensor, c: Tensor) -> Tuple[Tensor, Tensor]:
         if torch.is_grad_enabled():
@@ -541,7 +550,7 @@ class LeMeViT(nn.Module):
     def __init__(self, depth=[2, 3, 4, 8, 3], in_chans=3, num_classes=1000, embed_dim=[64, 64, 128, 320, 512], head_dim=64,
                  mlp_ratios=[4, 4, 4, 4, 4], qkv_bias=True, qk_scale=None, drop_rate=0.0, attn_drop=0.0, drop_path_rate=0.0,
                  attn_type=["C", "D", "D", "S", "S"], queries_len=128, qk_dims=None, cpe_ks=3, pre_norm=True, mlp_dwconv=False,
-                 representation_size=None, layer_scale_init_value=-1, use_checkpoint_stages=[]):
+                 representation_size=None, layer_scale_init_value=-1, use_checkpoint_stages=[], dense_blocks=False):
         super().__init__()
         if representation_size:
             raise NotImplementedError("representation_size is unused by every registered variant")
@@ -583,7 +592,7 @@ class LeMeViT(nn.Module):
             self.stages.append(nn.ModuleList([
                 LeMeBlock(dim=embed_dim[i], attn_drop=attn_drop, proj_drop=drop_rate, drop_path=dp_rates[cur + j], attn_type=attn_type[i],
                           layer_scale_init_value=layer_scale_init_value, num_heads=nheads[i], qk_dim=qk_dims[i], mlp_ratio=mlp_ratios[i],
-                          mlp_dwconv=mlp_dwconv, cpe_ks=cpe_ks, pre_norm=pre_norm) for j in range(depth[i])]))
+                          mlp_dwconv=mlp_dwconv, cpe_ks=cpe_ks, pre_norm=pre_norm, dense=dense_blocks) for j in range(depth[i])]))
             cur += depth[i]
 
         self.norm = nn.BatchNorm2d(embed_dim[-1])
@@ -658,7 +667,7 @@ class LeMeViT(nn.Module):
         (models/lemevit.py:531,561-564; block 0 has rate 0 -> identity)."""
         if not self.training:
             return {}
-        plan = [(blk, 2 if blk.attn_type == "C" else 4) for st in self.stages for blk in st if blk.drop_prob > 0.0 and type(blk)._masks is LeMeBlock._masks
+        plan = [(blk, 2 if blk.kind in ("C", "Sx") else 4) for st in self.stages for blk in st if blk.drop_prob > 0.0 and type(blk)._masks is LeMeBlock._masks
                 and "_masks" not in blk.__dict__]
         if not plan:
             return {}
@@ -711,3 +720,84 @@ class LeMeViT(nn.Module):
     def forward(self, x: Tensor) -> Tensor:
         x = self.forward_features(x, None)
         return self.head(x)
+
+
+class LayerNorm2d(nn.LayerNorm):
+    """LayerNorm over the channels of an NCHW map (timm.models.layers.LayerNorm2d): the dense-prediction backbone declares four
+    of these (`extra_norms`) without calling them; kept so that its checkpoints load with strict=True."""
+
+    def forward(self, x: Tensor) -> Tensor:
+        return F.layer_norm(x.permute(0, 2, 3, 1), self.normalized_shape, self.weight, self.bias, self.eps).permute(0, 3, 1, 2)
+
+
+class LeMeViTBackbone(LeMeViT):
+    """The multi-scale backbone of the reference's detection / segmentation / change-detection folders
+    (object_detection/mmdet/models/backbones/lemevit.py:660-877): same stem, meta-token path and stages as the classifier,
+    but (a) the "S" blocks run attention and MLP on the image tokens only and pass the meta tokens through (:615-643), and
+    (b) forward returns the NCHW feature maps after stages 1..4 (strides 4, 8, 16, 32) instead of logits (:798-818).
+    train() keeps every BatchNorm2d / LayerNorm in eval mode and freezes `frozen_stages` as the reference does (:827-841);
+    init_weights(path) loads a classification checkpoint with the 'backbone.' / 'module.' prefixes stripped (:844-877)."""
+
+    def __init__(self, depth=[2, 3, 4, 8, 3], in_chans=3, num_classes=1000, embed_dim=[64, 64, 128, 320, 512], head_dim=64,
+                 mlp_ratios=[4, 4, 4, 4, 4], qkv_bias=True, qk_scale=None, drop_rate=0.0, attn_drop=0.0, drop_path_rate=0.0,
+                 attn_type=["C", "D", "D", "S", "S"], queries_len=128, qk_dims=None, cpe_ks=3, pre_norm=True, mlp_dwconv=False,
+                 representation_size=None, layer_scale_init_value=-1, use_checkpoint_stages=[], frozen_stages=[-1], pretrained=None):
+        super().__init__(depth=depth, in_chans=in_chans, num_classes=0, embed_dim=embed_dim, head_dim=head_dim, mlp_ratios=mlp_ratios,
+                         qkv_bias=qkv_bias, qk_scale=qk_scale, drop_rate=drop_rate, attn_drop=attn_drop, drop_path_rate=drop_path_rate,
+                         attn_type=attn_type, queries_len=queries_len, qk_dims=qk_dims, cpe_ks=cpe_ks, pre_norm=pre_norm, mlp_dwconv=mlp_dwconv,
+                         representation_size=representation_size, layer_scale_init_value=layer_scale_init_value,
+                         use_checkpoint_stages=use_checkpoint_stages, dense_blocks=True)
+        self.num_classes = num_classes
+        self.frozen_stages = list(frozen_stages)
+        self.extra_norms = nn.ModuleList([LayerNorm2d(embed_dim[i + 1]) for i in range(self.num_stages - 1)])
+        del self.head                                   # the reference's backbone has no classifier
+        if pretrained:
+            self.init_weights(pretrained)
+
+    def forward_features(self, x: Tensor, c: Optional[Tensor] = None) -> List[Tensor]:
+        cd = _resolve_dtype(x)
+        B = x.shape[0]
+        if torch.is_grad_enabled():
+            new_training_pass()
+        if c is None:
+            c = self.meta_tokens.repeat(B, 1, 1)
+        xt, H, W, outs = None, 0, 0, []
+        all_masks = self._draw_drop_path(B, x.device)
+        for i in range(self.num_stages):
+            if i == 0 or not isinstance(self.downsample_layers[i], nn.Identity):
+                x = self._run_downsample(self.downsample_layers[i], x if xt is None else self._to_nchw(xt, H, W))
+                xt, H, W = self._to_tokens(x, cd)
+            mlp = self.meta_token_downsample[i]
+            if _is_meta_mlp(mlp, c, cd):
+                l1, n1, _, l2, n2 = mlp
+                c = _MetaMLPFn.apply(c, l1.weight, l1.bias, n1.weight, n1.bias, l2.weight, l2.bias, n2.weight, n2.bias, n1.eps, n2.eps, cd)
+            else:
+                c = mlp(c)
+            c = c.to(cd).contiguous()
+            for blk in self.stages[i]:
+                xt, c = blk.forward_tokens(xt, c, H, W, masks=all_masks.get(id(blk)) if all_masks else None)
+            if i > 0:
+                outs.append(self._to_nchw(xt, H, W))
+        return outs
+
+    def forward(self, x: Tensor) -> List[Tensor]:
+        return self.forward_features(x, None)
+
+    def _freeze_stages(self):
+        for i in self.frozen_stages:
+            if i >= 0:
+                for p in self.stages[i].parameters():
+                    p.requires_grad = False
+
+    def train(self, mode: bool = True):
+        self._freeze_stages()
+        super().train(mode)
+        for m in self.modules():                        # freeze_bn = True in the reference: normalisation layers stay in eval mode
+            if isinstance(m, (nn.BatchNorm2d, nn.LayerNorm)):
+                m.eval()
+        return self
+
+    def init_weights(self, pretrained: Optional[str] = None):
+        if pretrained is not None:
+            from .registry import load_checkpoint
+            return load_checkpoint(self, pretrained, strict=False)

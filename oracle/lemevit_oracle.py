@@ -209,6 +209,10 @@ def leme_block(sd, p: str, attn_type: str, x: Tensor, c: Tensor, H: int, W: int,
         c = c + _dp(standard_attention(sd, p + "attn.", n1(c), h), m[2])
         c = c + _dp(mlp(sd, p, n2(c)), m[3])
         return x, c
+    if attn_type == "Sx":                 # dense-prediction backbones: forward_with_x touches x only and returns c as it came
+        x = x + _dp(standard_attention(sd, p + "attn.", n1(x), h), m[0])       # (object_detection/mmdet/models/backbones/lemevit.py:615-643)
+        x = x + _dp(mlp(sd, p, n2(x)), m[1])
+        return x, c
     if attn_type == "C":                  # forward_with_c :600-601, returns the ORIGINAL x :610
         c = c + _dp(cross_attention(sd, p + "attn.", n1(x), n1(c), h), m[0])
         c = c + _dp(mlp(sd, p, n2(c)), m[1])
@@ -290,6 +294,37 @@ def lemevit_forward(sd: Dict[str, Tensor], cfg: dict, img: Tensor, train: bool =
     c = layer_norm(c, sd["norm_c.weight"], sd["norm_c.bias"], META_LN_EPS)   # :818
     feat = x.flatten(2).mean(-1) + c.mean(dim=1)                             # :825-827
     return linear(feat, sd["head.weight"], sd["head.bias"])                  # :835
+
+
+def lemevit_dense_forward(sd: Dict[str, Tensor], cfg: dict, img: Tensor, train_bn: bool = False,
+                          dp_masks: Optional[Dict[Tuple[int, int], Sequence[Optional[Tensor]]]] = None) -> List[Tensor]:
+    """The multi-scale backbone of the detection / segmentation folders
+    (object_detection/mmdet/models/backbones/lemevit.py:798-824): the classifier's stem, meta-token path and stages with the
+    "S" blocks leaving the meta tokens untouched (:615-643); returns the NCHW maps after stages 1..4."""
+    depth, dims, types = cfg["depth"], cfg["embed_dim"], cfg["attn_type"]
+    heads = [d // cfg["head_dim"] for d in dims]
+    B = img.shape[0]
+    c = sd["meta_tokens"].unsqueeze(0).repeat(B, 1, 1)
+    x, outs = img, []
+    for i in range(len(types)):
+        if i == 0:
+            x = F.conv2d(x, sd["downsample_layers.0.0.weight"], sd["downsample_layers.0.0.bias"], stride=2, padding=1)
+            x = batch_norm(sd, "downsample_layers.0.1.", x, train_bn)
+            x = gelu_erf(x)
+            x = F.conv2d(x, sd["downsample_layers.0.3.weight"], sd["downsample_layers.0.3.bias"], stride=2, padding=1)
+            x = batch_norm(sd, "downsample_layers.0.4.", x, train_bn)
+        elif types[i - 1] != "C":
+            x = F.conv2d(x, sd[f"downsample_layers.{i}.0.weight"], sd[f"downsample_layers.{i}.0.bias"], stride=2, padding=1)
+            x = batch_norm(sd, f"downsample_layers.{i}.1.", x, train_bn)
+        c = meta_mlp(sd, f"meta_token_downsample.{i}.", c)
+        xt, H, W = to_tokens(x)
+        for j in range(depth[i]):
+            masks = None if dp_masks is None else dp_masks.get((i, j))
+            xt, c = leme_block(sd, f"stages.{i}.{j}.", "Sx" if types[i] == "S" else types[i], xt, c, H, W, heads[i], masks)
+        x = to_nchw(xt, H, W)
+        if i > 0:
+            outs.append(x)
+    return outs
 
 
 # ----------------------------------------------------------------------------------------

@@ -71,6 +71,40 @@ def _import_reference():
     return mod
 
 
+REF_DENSE = "/root/reference/object_detection/mmdet/models/backbones/lemevit.py"
+
+
+def _import_dense_reference():
+    """The detection backbone file, unmodified; its mmdet / mmcv imports (registry decorator, logger, checkpoint loader) and
+    timm's LayerNorm2d are replaced by minimal stand-ins.  Call after _import_reference() (timm / fairscale stubs)."""
+    def mk(name, pkg=False):
+        m = types.ModuleType(name)
+        if pkg:
+            m.__path__ = []
+        sys.modules[name] = m
+        return m
+
+    class _Registry:
+        def register_module(self, *a, **k):
+            return lambda cls: cls
+
+    class LayerNorm2d(nn.LayerNorm):
+        def forward(self, x):
+            return nn.functional.layer_norm(x.permute(0, 2, 3, 1), self.normalized_shape, self.weight, self.bias, self.eps).permute(0, 3, 1, 2)
+
+    sys.modules["timm.models.layers"].LayerNorm2d = LayerNorm2d
+    mk("mmdet", True); mk("mmdet.models", True); mk("mmdet.models.backbones", True)
+    mk("mmdet.models.builder").BACKBONES = _Registry()
+    mk("mmdet.utils").get_root_logger = lambda *a, **k: None
+    mk("mmcv", True)
+    mk("mmcv.runner")._load_checkpoint = lambda *a, **k: {}
+    spec = importlib.util.spec_from_file_location("mmdet.models.backbones.lemevit", REF_DENSE)
+    mod = importlib.util.module_from_spec(spec)
+    sys.modules["mmdet.models.backbones.lemevit"] = mod
+    spec.loader.exec_module(mod)
+    return mod
+
+
 def _load(module: nn.Module, prefix: str, seed: int):
     spec = {prefix + k: tuple(v.shape) for k, v in module.state_dict().items()}
     sd = fill_state_dict(spec, seed)
@@ -202,14 +236,49 @@ def gen_train(ref):
                          target=target.tolist(), param_names=names), arr)
 
 
+def gen_dense(refd):
+    """Dense-prediction backbone: multi-scale outputs, "S" blocks that leave the meta tokens alone."""
+    tiny = dict(depth=[1, 2, 2, 8, 2], embed_dim=[64, 64, 128, 192, 320], head_dim=32, mlp_ratios=[4, 4, 4, 4, 4],
+                attn_type=["C", "D", "D", "S", "S"], queries_len=16)
+    for name, Hh, Ww, B in [("dense_tiny_224", 224, 224, 1), ("dense_tiny_160x96", 160, 96, 2)]:
+        torch.manual_seed(0)
+        m = refd.LeMeViT(**tiny)
+        m.eval()                    # (the reference's train() override returns None)
+        _load(m, "", 51)
+        img = det_tensor((B, 3, Hh, Ww), name + ".img", 6)
+        with torch.no_grad():
+            outs = m(img)
+        arr = {f"out{i}": sample(o.flatten(2).transpose(1, 2), 8192) for i, o in enumerate(outs)}
+        _save(name, dict(kind="dense", cfg=tiny, H=Hh, W=Ww, B=B, seed=51, nkeys=len(m.state_dict()),
+                         shapes=[list(o.shape) for o in outs]), arr)
+    # one S block of the dense file, forward + backward: c must come back untouched and receive only its pass-through gradient
+    blk = refd.LeMeBlock(dim=64, attn_drop=0.0, proj_drop=0.0, drop_path=0.0, attn_type="S", layer_scale_init_value=-1, num_heads=2,
+                         mlp_ratio=4, mlp_dwconv=False, cpe_ks=3, pre_norm=True).eval()
+    _load(blk, "blk.", 52)
+    name, B, C, Hs = "blockgrad_Sx", 2, 64, 7
+    x = det_tensor((B, C, Hs, Hs), name + ".x", 3).requires_grad_(True)
+    c = det_tensor((B, 16, C), name + ".c", 3).requires_grad_(True)
+    gx = det_tensor((B, C, Hs, Hs), name + ".gx", 3); gc = det_tensor((B, 16, C), name + ".gc", 3)
+    xo, co = blk(x, c)
+    ((xo * gx).sum() + (co * gc).sum()).backward()
+    arr = dict(x_out=xo.detach().numpy(), c_out=co.detach().numpy(), dx=x.grad.numpy(), dc=c.grad.numpy())
+    for k, p in blk.named_parameters():
+        arr["grad." + k] = (p.grad if p.grad is not None else torch.zeros_like(p)).numpy()
+    _save(name, dict(kind="blockgrad", type="Sx", C=C, h=2, H=Hs, W=Hs, B=B, seed=52), arr)
+
+
 def main():
     torch.set_num_threads(os.cpu_count() or 1)
     ref = _import_reference()
     assert ref.has_torchfunc and not ref.has_flash_attn and not ref.has_xformers
+    if "--dense-only" in sys.argv:
+        gen_dense(_import_dense_reference())
+        return
     gen_attention(ref)
     gen_blocks(ref)
     gen_models(ref)
     gen_train(ref)
+    gen_dense(_import_dense_reference())
 
 
 if __name__ == "__main__":

@@ -81,3 +81,23 @@ def test_no_cpu_fallback():
         m(torch.randn(1, 3, 64, 64))
     with pytest.raises(RuntimeError, match="GPU"):
         L.ops.layernorm_fwd(torch.randn(4, 64), torch.ones(64), torch.zeros(64), 1e-6)
+
+
+def test_dense_backbone_checkpoint_remap(tmp_path):
+    """init_weights() of the dense-prediction backbone accepts the reference's checkpoint layouts: {'state_dict': ...} with
+    'backbone.' / 'module.' prefixes (object_detection/mmdet/models/backbones/lemevit.py:844-877); the classifier's head keys are
+    reported as unexpected, not loaded."""
+    import torch
+    import lemevit_amd
+    cfg = dict(depth=[1, 1, 1, 1, 1], embed_dim=[64, 64, 128, 192, 320], head_dim=32, attn_type=["C", "D", "D", "S", "S"], queries_len=16)
+    src = lemevit_amd.LeMeViT(num_classes=10, **cfg)
+    for p in src.parameters():
+        torch.nn.init.normal_(p, std=0.02)
+    path = tmp_path / "cls.pth.tar"
+    torch.save({"state_dict": {"module.backbone." + k: v for k, v in src.state_dict().items()}}, path)
+    bb = lemevit_amd.LeMeViTBackbone(pretrained=str(path), **cfg)
+    got, want = bb.state_dict(), src.state_dict()
+    assert all(torch.equal(got[k], want[k]) for k in want if not k.startswith("head."))
+    res = bb.init_weights(str(path))
+    assert sorted(res.unexpected_keys) == ["head.bias", "head.weight"] and all(k.startswith("extra_norms.") for k in res.missing_keys)
+    assert not hasattr(bb, "head") and all(blk.kind == "Sx" for st in bb.stages[3:] for blk in st)

@@ -372,3 +372,71 @@ def test_flat_grad_sync_single_rank_nccl():
     finally:
         if created:
             dist.destroy_process_group()
+
+
+# ------------------------------------------------------------------------------------------------
+# dense-prediction backbone
+def _backbone(cfg, seed):
+    from lemevit_amd.model import LeMeViTBackbone
+    m = LeMeViTBackbone(**cfg)
+    spec = {k: tuple(v.shape) for k, v in m.state_dict().items()}
+    m.load_state_dict(fill_state_dict(spec, seed))
+    return m.to(DEV)
+
+
+@pytest.mark.parametrize("name", ["dense_tiny_224", "dense_tiny_160x96"])
+def test_dense_backbone_forward(golden, name):
+    """Multi-scale feature maps of the detection / segmentation backbone vs the reference's own backbone file (fp32 1e-5, bf16 autocast 2e-2)."""
+    meta, g = golden(name)
+    m = _backbone(meta["cfg"], meta["seed"]).eval()
+    assert len(m.state_dict()) == meta["nkeys"]
+    img = det_tensor((meta["B"], 3, meta["H"], meta["W"]), name + ".img", 6).to(DEV)
+    with torch.no_grad():
+        outs = m(img)
+    assert [list(o.shape) for o in outs] == meta["shapes"]
+    for i, o in enumerate(outs):
+        close(sample(o.flatten(2).transpose(1, 2).contiguous(), 8192), g[f"out{i}"], 1e-5, f"{name}.out{i}")
+    with torch.no_grad(), torch.autocast("cuda", torch.bfloat16):
+        outs = m(img)
+    for i, o in enumerate(outs):
+        close(sample(o.float().flatten(2).transpose(1, 2).contiguous(), 8192), g[f"out{i}"], 2e-2, f"{name}.out{i} bf16")
+
+
+def test_dense_block_backward_fp32(golden):
+    """The dense S block: c passes through (bit-identical) and every gradient matches the reference."""
+    meta, g = golden("blockgrad_Sx")
+    C, h, H, W, B = meta["C"], meta["h"], meta["H"], meta["W"], meta["B"]
+    blk = L().LeMeBlock(dim=C, attn_drop=0.0, proj_drop=0.0, drop_path=0.0, attn_type="S", num_heads=h, dense=True)
+    m = load(blk, "blk.", meta["seed"]).eval()
+    x = det_tensor((B, C, H, W), "blockgrad_Sx.x", 3).to(DEV).requires_grad_(True); c = det_tensor((B, 16, C), "blockgrad_Sx.c", 3).to(DEV).requires_grad_(True)
+    gx = det_tensor((B, C, H, W), "blockgrad_Sx.gx", 3).to(DEV); gc = det_tensor((B, 16, C), "blockgrad_Sx.gc", 3).to(DEV)
+    xo, co = m(x, c)
+    ((xo * gx).sum() + (co * gc).sum()).backward()
+    close(xo, g["x_out"], 1e-5, "x_out")
+    assert torch.equal(co.detach(), c.detach()) and torch.equal(c.grad, gc)
+    close(x.grad, g["dx"], 2e-5, "dx")
+    for k, p in m.named_parameters():
+        ref = g["grad." + k]
+        if np.abs(ref).max() == 0:
+            assert p.grad is None or float(p.grad.abs().max()) == 0.0
+        else:
+            close(p.grad, ref, 3e-5, "grad " + k)
+
+
+def test_dense_backbone_train_step_bf16():
+    """Train-mode pass of the dense backbone (frozen norm layers as the reference's train()): finite multi-scale outputs and gradients,
+    meta-token gradient reaches `meta_tokens` only through the C / D stages."""
+    cfg = dict(depth=[1, 1, 1, 2, 1], embed_dim=[64, 64, 128, 192, 320], head_dim=32, mlp_ratios=[4, 4, 4, 4, 4], attn_type=["C", "D", "D", "S", "S"],
+               queries_len=16, drop_path_rate=0.1)
+    m = _backbone(cfg, 3).train()
+    assert not any(mod.training for mod in m.modules() if isinstance(mod, (torch.nn.BatchNorm2d, torch.nn.LayerNorm)))
+    img = det_tensor((2, 3, 96, 128), "dense.train.img", 6).to(DEV)
+    with torch.autocast("cuda", torch.bfloat16):
+        outs = m(img)
+        sum(o.float().square().mean() for o in outs).backward()
+    assert [tuple(o.shape) for o in outs] == [(2, 64, 24, 32), (2, 128, 12, 16), (2, 192, 6, 8), (2, 320, 3, 4)]
+    for k, p in m.named_parameters():
+        if k.startswith(("extra_norms", "norm.", "norm_c.")):
+            assert p.grad is None
+        else:
+            assert p.grad is not None and torch.isfinite(p.grad).all(), k

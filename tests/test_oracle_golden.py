@@ -159,3 +159,46 @@ def test_train_step(golden, name):
             _close(sd[k[5:]].grad, g[k], 1e-4, k)
         if k.startswith("stat."):
             _close(stats[k[5:]], g[k], 1e-5, k)
+
+
+# ------------------------------------------------------------------------------------------------
+# dense-prediction backbone: object_detection/mmdet/models/backbones/lemevit.py
+def _dense_spec(cfg):
+    spec = O.state_dict_spec(cfg, num_classes=0)
+    for i, C in enumerate(cfg["embed_dim"][1:]):          # `extra_norms` (declared, never called) :759-762
+        spec[f"extra_norms.{i}.weight"] = (C,); spec[f"extra_norms.{i}.bias"] = (C,)
+    return spec
+
+
+@pytest.mark.parametrize("name", ["dense_tiny_224", "dense_tiny_160x96"])
+def test_dense_backbone_forward(golden, name):
+    meta, g = golden(name)
+    cfg = meta["cfg"]
+    spec = _dense_spec(cfg)
+    assert len(spec) == meta["nkeys"]
+    sd = fill_state_dict(spec, meta["seed"])
+    img = det_tensor((meta["B"], 3, meta["H"], meta["W"]), name + ".img", 6)
+    with torch.no_grad():
+        outs = O.lemevit_dense_forward(sd, cfg, img)
+    assert [list(o.shape) for o in outs] == meta["shapes"]
+    for i, o in enumerate(outs):
+        _close(sample(o.flatten(2).transpose(1, 2), 8192), g[f"out{i}"], 1e-5, f"{name}.out{i}")
+
+
+def test_dense_block_backward(golden):
+    """The S block of the dense file: c comes back untouched and its gradient is the pass-through gradient only."""
+    meta, g = golden("blockgrad_Sx")
+    C, h, H, W, B = meta["C"], meta["h"], meta["H"], meta["W"], meta["B"]
+    sd = {k: v.requires_grad_(True) for k, v in fill_state_dict(block_spec("S", C), meta["seed"]).items()}
+    x = det_tensor((B, C, H, W), "blockgrad_Sx.x", 3).requires_grad_(True); c = det_tensor((B, 16, C), "blockgrad_Sx.c", 3).requires_grad_(True)
+    gx = det_tensor((B, C, H, W), "blockgrad_Sx.gx", 3); gc = det_tensor((B, 16, C), "blockgrad_Sx.gc", 3)
+    xt, _, _ = O.to_tokens(x)
+    xo, co = O.leme_block(sd, "blk.", "Sx", xt, c, H, W, h)
+    xo = O.to_nchw(xo, H, W)
+    ((xo * gx).sum() + (co * gc).sum()).backward()
+    _close(xo.detach(), g["x_out"], what="x_out"); _close(co.detach(), g["c_out"], what="c_out")
+    assert np.array_equal(g["c_out"], c.detach().numpy()) and np.array_equal(g["dc"], gc.numpy())
+    _close(x.grad, g["dx"], 1e-5, "dx"); _close(c.grad, g["dc"], 1e-5, "dc")
+    for k, v in sd.items():
+        gr = v.grad if v.grad is not None else torch.zeros_like(v)
+        _close(gr, g["grad." + k[len("blk."):]], 2e-5, "grad " + k)

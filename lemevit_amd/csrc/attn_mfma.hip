@@ -649,6 +649,173 @@ __global__ __launch_bounds__(256) void mfma_bwd_dq_long_kernel(const AttnArgs a,
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// More than LONG_MAX_NKT * 16 keys (the dense-prediction backbones: stage-3 self-attention over 4096 image tokens at 1024^2;
+// `vit_tiny` stage 0): K / V no longer fit in LDS, so they are STREAMED through it in chunks of STREAM_NKT key tiles (32 KB)
+// while each wave keeps the state of up to STREAM_MAXQ query tiles in registers.
+//   forward: online softmax across chunks -- per chunk the two passes of mfma_fwd_long_kernel (maximum, then P and P V) with
+//            the running maximum, O and the row sum rescaled by 2^((m_old - m_new) c) when the maximum moves;
+//   dQ:      dQ accumulates over the chunks (LSE and delta are chunk-independent);
+//   dK / dV: mfma_bwd_dkv_long_kernel as it is (one workgroup per 14 key tiles, queries streamed).
+// ---------------------------------------------------------------------------------------------
+constexpr int STREAM_NKT = 16, STREAM_MAXQ = 4;
+
+__global__ __launch_bounds__(256) void mfma_fwd_stream_kernel(const AttnArgs a, int qt_per_block) {
+  __shared__ __attribute__((aligned(16))) unsigned char sK[STREAM_NKT * 1024], sV[STREAM_NKT * 1024];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = blockIdx.y, b = blockIdx.z, g = lane >> 4;
+  const bf16_t* qb = reinterpret_cast<const bf16_t*>(a.q) + b * a.q_bs + h * D;
+  const bf16_t* kb = reinterpret_cast<const bf16_t*>(a.k) + b * a.k_bs + h * D;
+  const bf16_t* vb = reinterpret_cast<const bf16_t*>(a.v) + b * a.v_bs + h * D;
+  bf16_t* ob = reinterpret_cast<bf16_t*>(a.o) + b * a.o_bs + h * D;
+  const int nqt = (a.Lq + 15) >> 4;
+  const int qt_beg = blockIdx.x * qt_per_block, qt_end = min(nqt, qt_beg + qt_per_block);
+  const float sc2 = a.scale * 1.4426950408889634f;
+  bf16x8_t qf[STREAM_MAXQ];
+  float m[STREAM_MAXQ], l[STREAM_MAXQ];
+  f32x4_t o0[STREAM_MAXQ], o1[STREAM_MAXQ];
+#pragma unroll
+  for (int j = 0; j < STREAM_MAXQ; ++j) {
+    const int qt = qt_beg + wave + 4 * j;
+    qf[j] = load_frag_global(qb, a.q_rs, qt * 16 + (lane & 15), qt < qt_end ? a.Lq : 0, lane);
+    m[j] = -3e38f; l[j] = 0.f;
+    o0[j] = f32x4_t{0.f, 0.f, 0.f, 0.f}; o1[j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  }
+  for (int k0 = 0; k0 < a.Lk; k0 += STREAM_NKT * 16) {
+    __syncthreads();                                               // the previous chunk's images are consumed
+    stage_rows2<256>(sK, kb, a.k_rs, sV, vb, a.v_rs, k0, STREAM_NKT * 16, a.Lk, tid);
+    __syncthreads();
+    const int nkt = min(STREAM_NKT, (((a.Lk - k0 + 15) >> 4) + 1) & ~1);        // even; rows past Lk are zero in LDS and masked below
+    const bool tail = k0 + nkt * 16 > a.Lk;
+#pragma unroll
+    for (int j = 0; j < STREAM_MAXQ; ++j) {
+      if (qt_beg + wave + 4 * j >= qt_end) continue;               // wave-uniform
+      float mn = m[j];
+      for (int kt = 0; kt < nkt; ++kt) {
+        const f32x4_t sv = MFMA(frag_n(sK, kt * 16, lane), qf[j], (f32x4_t{0.f, 0.f, 0.f, 0.f}));
+        if (tail && k0 + kt * 16 + 16 > a.Lk) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if (k0 + kt * 16 + g * 4 + r < a.Lk) mn = fmaxf(mn, sv[r]);
+        } else {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) mn = fmaxf(mn, sv[r]);
+        }
+      }
+      mn = group_max4(mn);
+      const float alpha = __builtin_amdgcn_exp2f((m[j] - mn) * sc2), mc = mn * sc2;
+      m[j] = mn;
+      float lj = l[j] * alpha;
+      f32x4_t a0 = o0[j] * alpha, a1 = o1[j] * alpha;
+      for (int kb2 = 0; kb2 < nkt / 2; ++kb2) {
+        f32x4_t pp[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          const int kt = 2 * kb2 + t;
+          const f32x4_t sv = MFMA(frag_n(sK, kt * 16, lane), qf[j], (f32x4_t{0.f, 0.f, 0.f, 0.f}));
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            pp[t][r] = __builtin_amdgcn_exp2f(fmaf(sv[r], sc2, -mc));
+            if (tail && k0 + kt * 16 + g * 4 + r >= a.Lk) pp[t][r] = 0.f;
+            lj += pp[t][r];
+          }
+        }
+        const bf16x8_t ph = pack8(pp[0], pp[1]);                   // hi + lo parts of P: see mfma_fwd_kernel
+        f32x4_t r0, r1;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { r0[r] = pp[0][r] - (float)ph[r]; r1[r] = pp[1][r] - (float)ph[4 + r]; }
+        const bf16x8_t pl = pack8(r0, r1);
+        const bf16x8_t vt0 = frag_t(sV, kb2 * 32, kb2 * 32 + 16, 0, lane), vt1 = frag_t(sV, kb2 * 32, kb2 * 32 + 16, 16, lane);
+        a0 = MFMA(vt0, ph, a0); a0 = MFMA(vt0, pl, a0);
+        a1 = MFMA(vt1, ph, a1); a1 = MFMA(vt1, pl, a1);
+      }
+      l[j] = lj; o0[j] = a0; o1[j] = a1;
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < STREAM_MAXQ; ++j) {
+    const int qt = qt_beg + wave + 4 * j, q = qt * 16 + (lane & 15);
+    if (qt >= qt_end) continue;
+    const float lt = group_sum4(l[j]);
+    if (q < a.Lq) {
+      const float inv = 1.f / lt;
+      store4(ob + (int64_t)q * a.o_rs + g * 4, o0[j] * inv);
+      store4(ob + (int64_t)q * a.o_rs + 16 + g * 4, o1[j] * inv);
+      if (a.lse && g == 0) a.lse[((int64_t)b * a.H + h) * a.Lq + q] = m[j] * a.scale + __logf(lt);
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void mfma_bwd_dq_stream_kernel(const AttnArgs a, float* __restrict__ delta, int qt_per_block) {
+  __shared__ __attribute__((aligned(16))) unsigned char sK[STREAM_NKT * 1024], sV[STREAM_NKT * 1024];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = blockIdx.y, b = blockIdx.z, g = lane >> 4;
+  const bf16_t* qb = reinterpret_cast<const bf16_t*>(a.q) + b * a.q_bs + h * D;
+  const bf16_t* gb = reinterpret_cast<const bf16_t*>(a.d_o) + b * a.o_bs + h * D;
+  const bf16_t* ob = reinterpret_cast<const bf16_t*>(a.o) + b * a.o_bs + h * D;
+  const bf16_t* kb = reinterpret_cast<const bf16_t*>(a.k) + b * a.k_bs + h * D;
+  const bf16_t* vb = reinterpret_cast<const bf16_t*>(a.v) + b * a.v_bs + h * D;
+  bf16_t* dqb = reinterpret_cast<bf16_t*>(a.dq) + b * a.q_bs + h * D;
+  const int nqt = (a.Lq + 15) >> 4;
+  const int qt_beg = blockIdx.x * qt_per_block, qt_end = min(nqt, qt_beg + qt_per_block);
+  const int64_t bh = ((int64_t)b * a.H + h) * a.Lq;
+  bf16x8_t qf[STREAM_MAXQ], gf[STREAM_MAXQ];
+  float lse[STREAM_MAXQ], dl[STREAM_MAXQ];
+  f32x4_t dq0[STREAM_MAXQ], dq1[STREAM_MAXQ];
+#pragma unroll
+  for (int j = 0; j < STREAM_MAXQ; ++j) {
+    const int qt = qt_beg + wave + 4 * j, q = qt * 16 + (lane & 15);
+    const int Lq = qt < qt_end ? a.Lq : 0;
+    const bool vq = q < Lq;
+    qf[j] = load_frag_global(qb, a.q_rs, q, Lq, lane);
+    gf[j] = load_frag_global(gb, a.o_rs, q, Lq, lane);
+    const bf16x8_t of = load_frag_global(ob, a.o_rs, q, Lq, lane);
+    lse[j] = vq ? a.lse[bh + q] : 1e30f;                           // exp(s - 1e30) = 0 masks the padded queries
+    float d = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) d += (float)gf[j][e] * (float)of[e];
+    d = group_sum4(d);
+    if (vq && g == 0) delta[bh + q] = d;
+    dl[j] = d;
+    dq0[j] = f32x4_t{0.f, 0.f, 0.f, 0.f}; dq1[j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  }
+  for (int k0 = 0; k0 < a.Lk; k0 += STREAM_NKT * 16) {
+    __syncthreads();
+    stage_rows2<256>(sK, kb, a.k_rs, sV, vb, a.v_rs, k0, STREAM_NKT * 16, a.Lk, tid);
+    __syncthreads();
+    const int nkt = min(STREAM_NKT, (((a.Lk - k0 + 15) >> 4) + 1) & ~1);
+#pragma unroll
+    for (int j = 0; j < STREAM_MAXQ; ++j) {
+      if (qt_beg + wave + 4 * j >= qt_end) continue;               // wave-uniform
+      f32x4_t a0 = dq0[j], a1 = dq1[j];
+      for (int kb2 = 0; kb2 < nkt / 2; ++kb2) {
+        f32x4_t ds[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          const int kt = 2 * kb2 + t;
+          const f32x4_t sv = MFMA(frag_n(sK, kt * 16, lane), qf[j], (f32x4_t{0.f, 0.f, 0.f, 0.f}));
+          const f32x4_t dp = MFMA(frag_n(sV, kt * 16, lane), gf[j], (f32x4_t{0.f, 0.f, 0.f, 0.f}));
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const bool ok = k0 + kt * 16 + g * 4 + r < a.Lk;
+            const float p = ok ? __expf(sv[r] * a.scale - lse[j]) : 0.f;
+            ds[t][r] = p * (dp[r] - dl[j]) * a.scale;
+          }
+        }
+        const bf16x8_t dsf = pack8(ds[0], ds[1]);
+        a0 = MFMA(frag_t(sK, kb2 * 32, kb2 * 32 + 16, 0, lane), dsf, a0);
+        a1 = MFMA(frag_t(sK, kb2 * 32, kb2 * 32 + 16, 16, lane), dsf, a1);
+      }
+      dq0[j] = a0; dq1[j] = a1;
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < STREAM_MAXQ; ++j) {
+    const int qt = qt_beg + wave + 4 * j, q = qt * 16 + (lane & 15);
+    if (qt >= qt_end || q >= a.Lq) continue;
+    store4(dqb + (int64_t)q * a.q_rs + g * 4, dq0[j]);
+    store4(dqb + (int64_t)q * a.q_rs + 16 + g * 4, dq1[j]);
+  }
+}
+
 // dK / dV of the 14 key tiles starting at tile blockIdx.x * 14: wave w owns tiles w, w + 4, w + 8, w + 12 of the range
 // and walks ALL queries, staged chunk by chunk (Q and dO images, LSE, delta) -- no cross-wave or cross-workgroup sums.
 __global__ __launch_bounds__(256) void mfma_bwd_dkv_long_kernel(const AttnArgs a, const float* __restrict__ delta, int q_chunk) {
@@ -738,7 +905,15 @@ inline int qt_per_block_for(const AttnArgs& a) {
 
 }  // namespace
 
-bool lmv_attn_mfma_long_supported(const AttnArgs& a) { return a.Lk > 224 && a.Lk <= LONG_MAX_NKT * 16 && a.Lq > 16; }
+bool lmv_attn_mfma_long_supported(const AttnArgs& a) { return a.Lk > 224 && a.Lq > 16; }
+
+// query tiles per workgroup of the streaming kernels: <= 4 waves x STREAM_MAXQ, fewer while the grid is short of ~1024
+static int stream_per(const AttnArgs& a) {
+  const int nqt = (a.Lq + 15) / 16;
+  int per = 4 * STREAM_MAXQ;
+  while (per > 4 && (int64_t)a.B * a.H * ((nqt + per - 1) / per) < 1024) per /= 2;
+  return per;
+}
 
 static int long_geometry(const AttnArgs& a, int* nkt, int* per, int* lds) {
   *nkt = ((a.Lk + 31) / 32) * 2;                                   // even number of 16-key tiles
@@ -757,6 +932,12 @@ static int long_geometry(const AttnArgs& a, int* nkt, int* per, int* lds) {
 }
 
 int lmv_attn_mfma_long_fwd(const AttnArgs& a, hipStream_t st) {
+  if (a.Lk > LONG_MAX_NKT * 16) {                                  // K / V streamed through LDS
+    const int per = stream_per(a), nqt = (a.Lq + 15) / 16;
+    hipLaunchKernelGGL(mfma_fwd_stream_kernel, dim3((nqt + per - 1) / per, a.H, a.B), dim3(256), 0, st, a, per);
+    LMV_CHECK_LAUNCH("attn_mfma_stream_fwd");
+    return LMV_OK;
+  }
   int nkt, per, lds;
   if (int rc = long_geometry(a, &nkt, &per, &lds)) return rc;
   const int nqt = (a.Lq + 15) / 16;
@@ -767,10 +948,15 @@ int lmv_attn_mfma_long_fwd(const AttnArgs& a, hipStream_t st) {
 
 // delta: B*H*Lq floats of scratch (written by the dQ kernel, read by the dK / dV kernel)
 int lmv_attn_mfma_long_bwd(const AttnArgs& a, float* delta, hipStream_t st) {
-  int nkt, per, lds;
-  if (int rc = long_geometry(a, &nkt, &per, &lds)) return rc;
   const int nqt = (a.Lq + 15) / 16;
-  hipLaunchKernelGGL(mfma_bwd_dq_long_kernel, dim3((nqt + per - 1) / per, a.H, a.B), dim3(256), lds, st, a, delta, per, nkt);
+  if (a.Lk > LONG_MAX_NKT * 16) {
+    const int per = stream_per(a);
+    hipLaunchKernelGGL(mfma_bwd_dq_stream_kernel, dim3((nqt + per - 1) / per, a.H, a.B), dim3(256), 0, st, a, delta, per);
+  } else {
+    int nkt, per, lds;
+    if (int rc = long_geometry(a, &nkt, &per, &lds)) return rc;
+    hipLaunchKernelGGL(mfma_bwd_dq_long_kernel, dim3((nqt + per - 1) / per, a.H, a.B), dim3(256), lds, st, a, delta, per, nkt);
+  }
   const int nchunks = (a.Lq + QR_MAX - 1) / QR_MAX;
   const int q_chunk = (((a.Lq + nchunks - 1) / nchunks) + 31) / 32 * 32;     // balanced chunks, multiples of 32, <= QR_MAX
   const int nranges = ((a.Lk + 15) / 16 + 13) / 14;

@@ -198,7 +198,9 @@ ATTN_CASES = [  # name, B, Lq, Lk, C, self (packed qkv) ?
     ("fewk", 2, 3136, 16, 96, False), ("fewk_odd", 1, 1225, 16, 64, False), ("gen", 2, 100, 37, 64, False),
     # many queries x 225..640 keys: the whole-row MFMA kernels with K / V in dynamic LDS (SA at 384^2 is 576 + 16 tokens)
     ("sa592", 2, 592, 592, 384, True), ("long_640", 1, 300, 640, 64, False), ("long_225", 1, 33, 225, 64, False),
-    ("gen_long", 1, 40, 700, 64, False),     # beyond 640 keys: generic kernels
+    # beyond 640 keys (bf16): K / V streamed through LDS in 256-key chunks, online softmax (dense backbones: 4096 image tokens)
+    ("stream_700", 1, 40, 700, 64, False), ("stream_sa1040", 1, 1040, 1040, 96, True), ("stream_ragged", 2, 333, 2049, 64, False),
+    ("stream_4096", 1, 4096, 4096, 64, True),
 ]
 
 

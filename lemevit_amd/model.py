@@ -108,13 +108,15 @@ class _StemConv1Fn(torch.autograd.Function):
     implicit-GEMM kernel for this 27-deep reduction takes 455 us at B = 128; this is ~5x faster, weight gradient included.)"""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, cd):
+    def forward(ctx, x, weight, bias, cd, gelu=False):
+        """gelu=True (inference only, BatchNorm folded into the weights): the GELU behind the first stem BatchNorm rides the GEMM epilogue."""
         B, _, H, W = x.shape
         Ho, Wo, Co = (H + 1) // 2, (W + 1) // 2, weight.shape[0]
         patches = ops.im2col3x3s2_c3(x, cd)
         y = torch.empty(B * Ho * Wo, Co, device=x.device, dtype=cd)
         b32 = None if bias is None else compute_copy(bias, torch.float32)
-        ops.linear_fwd([Prob(patches, _conv1_matrix(weight, cd), y, bias=b32)], Co, 32)
+        ops.linear_fwd([Prob(patches, _conv1_matrix(weight, cd), y, bias=b32)], Co, 32, ops.ACT_GELU if gelu else ops.ACT_NONE)
+        assert not (gelu and torch.is_grad_enabled() and weight.requires_grad), "the fused GELU epilogue has no backward"
         ctx.save_for_backward(patches)
         ctx.meta = (weight.shape, weight.dtype, None if bias is None else bias.dtype)
         return y.view(B, Ho, Wo, Co).permute(0, 3, 1, 2)            # NCHW-shaped, channels-last-strided: no copy
@@ -131,7 +133,7 @@ class _StemConv1Fn(torch.autograd.Function):
         db = torch.zeros(Co, device=g.device, dtype=torch.float32)
         ops.linear_dw([Prob(g, patches, dwm, bias_grad=db)], Co, 32)
         dw = dwm[:, :27].reshape(wshape).to(wdt)
-        return None, dw, (None if bdt is None else db.to(bdt)), None
+        return None, dw, (None if bdt is None else db.to(bdt)), None, None
 
 
 class _BNActFn(torch.autograd.Function):
@@ -647,8 +649,13 @@ class LeMeViT(nn.Module):
             bn = mods[i + 1] if i + 1 < len(mods) and isinstance(mods[i + 1], nn.BatchNorm2d) and mods[i + 1].track_running_stats else None
             if fold and isinstance(m, nn.Conv2d) and bn is not None:
                 w, b, b32 = _folded_conv_bn(m, bn, cd)
-                x = _StemConv1Fn.apply(x, w, b32, cd) if _is_stem_conv1(m, x) else F.conv2d(x.to(w.dtype), w, b, m.stride, m.padding, m.dilation, m.groups)
-                i += 2
+                if _is_stem_conv1(m, x):
+                    gelu = i + 2 < len(mods) and isinstance(mods[i + 2], nn.GELU) and getattr(mods[i + 2], "approximate", "none") == "none"
+                    x = _StemConv1Fn.apply(x, w, b32, cd, gelu)
+                    i += 3 if gelu else 2
+                else:
+                    x = F.conv2d(x.to(w.dtype), w, b, m.stride, m.padding, m.dilation, m.groups)
+                    i += 2
             elif _is_stem_conv1(m, x) and cd in (torch.float32, torch.bfloat16):
                 x = _StemConv1Fn.apply(x, m.weight, m.bias, cd)
                 i += 1
@@ -711,10 +718,18 @@ class LeMeViT(nn.Module):
             c = c.to(cd).contiguous()
             for blk in self.stages[i]:
                 xt, c = blk.forward_tokens(xt, c, H, W, masks=all_masks.get(id(blk)) if all_masks else None)
-        xn = self._to_nchw(xt, H, W)
-        xn = _bn_train(self.norm, xn) if _bn_native(self.norm, xn) else self.norm(xn)
-        xn = self.pre_logits(xn)
         cn = self.pre_logits(self.norm_c(c))
+        bn = self.norm
+        if not bn.training and bn.track_running_stats and isinstance(self.pre_logits, nn.Identity):
+            # inference: BatchNorm with running statistics is affine per channel, so it commutes with the spatial mean --
+            # pool the tokens first and normalise [B, C] instead of [B, C, H, W]  (models/lemevit.py:815, 825)
+            pooled = xt.float().mean(dim=1)
+            scale = bn.weight.float() * torch.rsqrt(bn.running_var.float() + bn.eps) if bn.affine else torch.rsqrt(bn.running_var.float() + bn.eps)
+            xm = (pooled - bn.running_mean.float()) * scale + (bn.bias.float() if bn.affine else 0.0)
+            return xm.to(cn.dtype) + cn.mean(dim=1)
+        xn = self._to_nchw(xt, H, W)
+        xn = _bn_train(bn, xn) if _bn_native(bn, xn) else bn(xn)
+        xn = self.pre_logits(xn)
         return xn.flatten(2).mean(-1) + cn.mean(dim=1)
 
     def forward(self, x: Tensor) -> Tensor:

@@ -364,3 +364,32 @@ def test_batchnorm_train(rows, C, gelu, dtype):
     tolw = 1e-5 if dtype == torch.float32 else 2e-3          # bf16 mode: GELU' through the branch-free erf
     assert_close(dgamma, dgamma_ref, torch.float32, "bn dgamma", tol32=tolw)
     assert_close(dbeta, dbeta_ref, torch.float32, "bn dbeta", tol32=tolw)
+
+
+# ------------------------------------------------------------------------------------------------
+# skinny launches at full size: one n-tile over > 1024 row tiles, ragged last tile, two problems with different weights and DropPath
+# vectors (the C = 96 stage shapes of BASELINE's configuration; sampled rows against float64)
+@pytest.mark.parametrize("N,K", [(96, 384), (96, 96), (64, 256), (128, 64)])
+def test_linear_fwd_skinny(N, K):
+    o = ops()
+    dtype = torch.bfloat16
+    rows_x, rows_c = 131072 + 333, 4100                       # ragged last tile, second problem with its own weights
+    ax, _ = rnd((rows_x, K), "sk.ax", dtype); ac, _ = rnd((rows_c, K), "sk.ac", dtype)
+    w1, _ = rnd((N, K), "sk.w1", dtype, 1 / math.sqrt(K)); w2, _ = rnd((N, K), "sk.w2", dtype, 1 / math.sqrt(K))
+    b1 = det_tensor((N,), "sk.b1", 7, 0.5).to(dev()); b2 = det_tensor((N,), "sk.b2", 7, 0.5).to(dev())
+    resx, _ = rnd((rows_x, N), "sk.rx", dtype); resc, _ = rnd((rows_c, N), "sk.rc", dtype)
+    rps_x, rps_c = 1029, 41
+    rsx = (det_tensor(((rows_x + rps_x - 1) // rps_x,), "sk.sx", 7).abs() + 0.5).to(dev())
+    rsc = (det_tensor(((rows_c + rps_c - 1) // rps_c,), "sk.sc", 7).abs() + 0.5).to(dev())
+    ox = torch.empty((rows_x, N), device=dev(), dtype=dtype); oc = torch.empty((rows_c, N), device=dev(), dtype=dtype)
+    o.linear_fwd([o.Prob(ax, w1, ox, bias=b1, res=resx, row_scale=rsx, rps=rps_x), o.Prob(ac, w2, oc, bias=b2, res=resc, row_scale=rsc, rps=rps_c)], N, K)
+    for a, w, b, res, rs, rps, out, what in [(ax, w1, b1, resx, rsx, rps_x, ox, "x"), (ac, w2, b2, resc, rsc, rps_c, oc, "c")]:
+        rows = a.shape[0]
+        sel = torch.cat([torch.arange(0, min(rows, 300)), torch.arange(max(rows - 300, 0), rows), torch.arange(0, rows, 997)]).unique()
+        u = a[sel].double().cpu() @ w.double().cpu().t() + b.double().cpu()
+        ref = res[sel].double().cpu() + rs.double().cpu()[sel // rps][:, None] * u
+        assert_close(out[sel], ref, dtype, "skinny " + what)
+    # plain (no epilogue operands), single problem
+    o.linear_fwd([o.Prob(ax, w1, ox)], N, K)
+    sel = torch.arange(0, rows_x, 1013)
+    assert_close(ox[sel], ax[sel].double().cpu() @ w1.double().cpu().t(), dtype, "skinny plain")

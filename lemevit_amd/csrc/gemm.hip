@@ -13,15 +13,20 @@
 // outputs = WM x 4 MFMA tiles (v_mfma_f32_16x16x32_bf16; exact-fp32 mode: v_mfma_f32_16x16x4_f32).  With K = 96..512
 // a workgroup spends as long in launch + first-load latency + epilogue + store drain as in its k-loop, and only OTHER
 // resident workgroups hide that, so occupancy decides: 128x128 tiles over 32-deep k-tiles (32 KB of LDS) under a
-// 128-register cap put 4 workgroups on a CU (3 for dW); the larger tiles and 64-deep k-tiles (2 per CU) lose on every
-// large layer shape of the model (make_plan; measurements in DESIGN.md 4.1).
+// 128-register cap put 4 workgroups on a CU (3 for dW); the larger tiles and 4-wave 64-deep k-tiles (2 per CU) lose on
+// every large layer shape of the model (make_plan; measurements in DESIGN.md 4.1).  The forward (and dX launches that cannot
+// fill 4 workgroups per CU) runs the same 128x128 tile on EIGHT waves of 32x64 over 64-deep k-tiles (C128w8): still 4 waves
+// per SIMD, but every operand row is a whole 128-byte line per k-tile -- the k-loop is bound by the L2 -> LDS operand
+// stream, and L2 serves half a line in the slot of a whole one (15 vs 29 TB/s, tools/native/dma_probe.hip).
 //
 // Operand tiles live in LDS as 128-row (or, transposed, 128-column) PANELS, double-buffered over k-tiles of 32 / 64
 // (bf16) or 32 (fp32).  bf16 panels are filled by LDS-DMA (global_load_lds_dwordx4: wave-uniform LDS base + lane * 16, so
 // the XOR swizzle is applied to the per-lane SOURCE address); fp32 and ragged-K problems use a register-staged
 // path (global -> VGPR -> ds_write) on the 128x128 tile.  The swizzles make the 16-byte fragment reads and the
 // transpose reads bank-conflict free (derivation in DESIGN.md; SQ_LDS_BANK_CONFLICT = 0 measured).
-// Workgroup ids are remapped so that the n-tiles of one m-tile run on the same XCD and share its L2.
+// Workgroup ids are remapped so that the n-tiles of one m-tile run on the same XCD and share its L2, and so that the four
+// workgroups the dispatcher places on one CU (XCD-local ids i, i + 32, i + 64, i + 96) get consecutive tiles (shared A rows
+// can meet in the CU's vector L1).
 //
 // The MFMA operands are passed swapped (W as "A") so every lane ends up with 4 CONSECUTIVE output columns of one
 // row.  The epilogue stages the fp32 tile through swizzled LDS, 64 rows at a time, and leaves as whole row

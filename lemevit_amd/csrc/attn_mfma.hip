@@ -217,13 +217,20 @@ __global__ __launch_bounds__(256) void mfma_bwd_dq_kernel(const AttnArgs a, floa
 // =============================================================================================
 constexpr int QR_MAX = 448;   // queries staged per workgroup (Q and dO images: 2 * 448 * 64 B = 56 KB)
 
-template <int NKT, int KW, bool ATOMIC>
+// FUSEDQ (<= 32 keys, every wave holds both key tiles): the SAME kernel also produces dQ -- the D[key][q] orientation is
+// recomputed from the fragments already in registers (two more S / dP MFMAs and exponentials per 16 queries, nothing against
+// the memory traffic), delta = rowsum(dO * O) is formed while the query range is staged, and dQ rows leave complete (all keys
+// of a (b, h) live in this workgroup).  Q, dO and O are then read ONCE by the backward pass instead of twice, and the
+// separate dQ launch disappears (DCA x-direction: 3136 queries x 16 keys; the 16 x 16 meta-token self-attention).
+template <int NKT, int KW, bool ATOMIC, bool FUSEDQ = false>
 __global__ __launch_bounds__(256) void mfma_bwd_dkv_kernel(const AttnArgs a, const float* __restrict__ delta, float* __restrict__ acc_k,
                                                           float* __restrict__ acc_v, int q_per_block) {
   constexpr int QW = 4 / KW;
   constexpr int TPW = (NKT + KW - 1) / KW;     // key tiles per wave
+  static_assert(!FUSEDQ || (NKT == 2 && KW == 1), "the fused dQ path is written for two key tiles per wave");
   __shared__ __attribute__((aligned(16))) unsigned char sQG[2 * QR_MAX * 64];     // Q image | dO image (reused by the final reduce)
   __shared__ __attribute__((aligned(16))) float sL[QR_MAX], sDl[QR_MAX];
+  __shared__ __attribute__((aligned(16))) unsigned char sKV[FUSEDQ ? 2 * 32 * 64 : 16];                // FUSEDQ: K image | V image
   unsigned char* sQ = sQG;
   unsigned char* sG = sQG + QR_MAX * 64;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = blockIdx.y, b = blockIdx.z;
@@ -232,13 +239,33 @@ __global__ __launch_bounds__(256) void mfma_bwd_dkv_kernel(const AttnArgs a, con
   const int nrows = ((q1 - q0 + 31) >> 5) << 5;
   const int64_t bh = ((int64_t)b * a.H + h) * a.Lq;
   stage_rows2<256>(sQ, reinterpret_cast<const bf16_t*>(a.q) + b * a.q_bs + h * D, a.q_rs, sG, reinterpret_cast<const bf16_t*>(a.d_o) + b * a.o_bs + h * D, a.o_rs, q0, nrows, q1, tid);
+  const bf16_t* kb = reinterpret_cast<const bf16_t*>(a.k) + b * a.k_bs + h * D;
+  const bf16_t* vb = reinterpret_cast<const bf16_t*>(a.v) + b * a.v_bs + h * D;
   for (int i = tid; i < nrows; i += 256) {
     const bool ok = q0 + i < q1;
     sL[i] = ok ? a.lse[bh + q0 + i] : 1e30f;      // exp(s - 1e30) = 0 masks the padded queries
-    sDl[i] = ok ? delta[bh + q0 + i] : 0.f;
+    if constexpr (FUSEDQ) {
+      float dl = 0.f;                             // delta = rowsum(dO * O) of query q0 + i
+      if (ok) {
+        const bf16_t* gp = reinterpret_cast<const bf16_t*>(a.d_o) + b * a.o_bs + (int64_t)(q0 + i) * a.o_rs + h * D;
+        const bf16_t* op = reinterpret_cast<const bf16_t*>(a.o) + b * a.o_bs + (int64_t)(q0 + i) * a.o_rs + h * D;
+        uint4 rg[4], ro[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) { rg[c] = *reinterpret_cast<const uint4*>(gp + c * 8); ro[c] = *reinterpret_cast<const uint4*>(op + c * 8); }
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          float gv[8], ov[8];
+          chunk_to_f<bf16_t>(rg[c], gv); chunk_to_f<bf16_t>(ro[c], ov);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) dl += gv[j] * ov[j];
+        }
+      }
+      sDl[i] = dl;
+    } else {
+      sDl[i] = ok ? delta[bh + q0 + i] : 0.f;
+    }
   }
-  const bf16_t* kb = reinterpret_cast<const bf16_t*>(a.k) + b * a.k_bs + h * D;
-  const bf16_t* vb = reinterpret_cast<const bf16_t*>(a.v) + b * a.v_bs + h * D;
+  if constexpr (FUSEDQ) stage_rows2<256>(sKV, kb, a.k_rs, sKV + 32 * 64, vb, a.v_rs, 0, 32, a.Lk, tid);
   bf16x8_t kf[TPW], vf[TPW];
   f32x4_t dk[TPW][2], dv[TPW][2];
 #pragma unroll
@@ -261,6 +288,34 @@ __global__ __launch_bounds__(256) void mfma_bwd_dkv_kernel(const AttnArgs a, con
     const float4 d0 = *reinterpret_cast<const float4*>(sDl + r0 + g * 4), d1 = *reinterpret_cast<const float4*>(sDl + r0 + 16 + g * 4);
     const float lse[8] = {l0.x, l0.y, l0.z, l0.w, l1.x, l1.y, l1.z, l1.w};
     const float dl[8] = {d0.x, d0.y, d0.z, d0.w, d1.x, d1.y, d1.z, d1.w};
+    if constexpr (FUSEDQ) {
+      // D[key][q]: lane holds keys kt * 16 + g * 4 + r of query (lane & 15) -- the orientation dQ = dS K needs
+      bf16_t* dqb = reinterpret_cast<bf16_t*>(a.dq) + b * a.q_bs + h * D;
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const int qi = r0 + t * 16 + (lane & 15);
+        const float lq = sL[qi], dq_ = sDl[qi];
+        const bf16x8_t qn = t ? qn1 : qn0, gn = t ? gn1 : gn0;
+        f32x4_t dsq[2];
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt) {
+          const f32x4_t sv = MFMA(kf[kt], qn, (f32x4_t{0.f, 0.f, 0.f, 0.f}));
+          const f32x4_t dp = MFMA(vf[kt], gn, (f32x4_t{0.f, 0.f, 0.f, 0.f}));
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float pq = (kt * 16 + g * 4 + r < a.Lk) ? __expf(sv[r] * a.scale - lq) : 0.f;
+            dsq[kt][r] = pq * (dp[r] - dq_) * a.scale;
+          }
+        }
+        const bf16x8_t dsf = pack8(dsq[0], dsq[1]);
+        const f32x4_t z = {0.f, 0.f, 0.f, 0.f};
+        const f32x4_t dq0 = MFMA(frag_t(sKV, 0, 16, 0, lane), dsf, z), dq1 = MFMA(frag_t(sKV, 0, 16, 16, lane), dsf, z);
+        if (q0 + qi < q1) {
+          store4(dqb + (int64_t)(q0 + qi) * a.q_rs + g * 4, dq0);
+          store4(dqb + (int64_t)(q0 + qi) * a.q_rs + 16 + g * 4, dq1);
+        }
+      }
+    }
 #pragma unroll
     for (int i = 0; i < TPW; ++i) {
       const int kt = kw + i * KW;
@@ -1021,11 +1076,14 @@ int lmv_attn_mfma_fwd(const AttnArgs& a, hipStream_t st) {
 // acc: lmv_attn_mfma_bwd_acc_bytes() of fp32 scratch (only touched when the query range is split)
 int lmv_attn_mfma_bwd(const AttnArgs& a, float* delta, float* acc, hipStream_t st) {
   const int per = qt_per_block_for(a), nqt = (a.Lq + 15) / 16, nkt = nkt_for(a.Lk);
+  static const bool fuse_dq = [] { const char* e = getenv("LMV_ATTN_FUSE_DQ"); return e ? atoi(e) != 0 : true; }();      // A/B testing
   if (nkt == 14 && a.Lq > 16) {
     // 129..224 keys: the run-time-bound dQ loop (86 registers, 5 waves per SIMD) beats the fully unrolled one (169 registers, 2)
     int nk, pr, lds;
     if (int rc = long_geometry(a, &nk, &pr, &lds)) return rc;
     hipLaunchKernelGGL(mfma_bwd_dq_long_kernel, dim3((nqt + pr - 1) / pr, a.H, a.B), dim3(256), lds, st, a, delta, pr, nk);
+  } else if (nkt == 2 && fuse_dq) {
+    // <= 32 keys: dQ comes out of the dK / dV kernel below
   } else {
     dim3 grid((nqt + per - 1) / per, a.H, a.B), block(256);
     switch (nkt) {
@@ -1042,6 +1100,8 @@ int lmv_attn_mfma_bwd(const AttnArgs& a, float* delta, float* acc, hipStream_t s
   float* acc_k = acc; float* acc_v = acc + acc_elems;
   if (nsplit > 1) {
 #define DKV(N, K) hipLaunchKernelGGL((mfma_bwd_dkv_kernel<N, K, true>), grid, block, 0, st, a, delta, acc_k, acc_v, qpb)
+    if (nkt == 2 && fuse_dq) hipLaunchKernelGGL((mfma_bwd_dkv_kernel<2, 1, true, true>), grid, block, 0, st, a, delta, acc_k, acc_v, qpb);
+    else
     switch (nkt) { case 2: DKV(2, 1); break; case 4: DKV(4, 2); break; case 8: DKV(8, 4); break; default: DKV(14, 4); break; }
 #undef DKV
     const unsigned n = 2u * (unsigned)a.B * a.H * a.Lk * (D / 4);
@@ -1049,6 +1109,8 @@ int lmv_attn_mfma_bwd(const AttnArgs& a, float* delta, float* acc, hipStream_t s
                        a.k_bs, a.k_rs, a.v_bs, a.v_rs, a.B, a.H, a.Lk, nkt * 16, nsplit);
   } else {
 #define DKV(N, K) hipLaunchKernelGGL((mfma_bwd_dkv_kernel<N, K, false>), grid, block, 0, st, a, delta, acc_k, acc_v, qpb)
+    if (nkt == 2 && fuse_dq) hipLaunchKernelGGL((mfma_bwd_dkv_kernel<2, 1, false, true>), grid, block, 0, st, a, delta, acc_k, acc_v, qpb);
+    else
     switch (nkt) { case 2: DKV(2, 1); break; case 4: DKV(4, 2); break; case 8: DKV(8, 4); break; default: DKV(14, 4); break; }
 #undef DKV
   }

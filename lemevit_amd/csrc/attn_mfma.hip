@@ -15,6 +15,7 @@
 // LDS images are [rows][32] bf16 (64-byte rows); the 16-byte chunk c of row r is stored at c ^ (((r >> 2) & 1) << 1),
 // which is conflict-free for BOTH the 16-byte fragment reads and the transpose reads (derivation in DESIGN.md).
 #include <stdlib.h>
+#include <atomic>
 #include "common.h"
 #include "attn_internal.h"
 
@@ -975,13 +976,17 @@ static int long_geometry(const AttnArgs& a, int* nkt, int* per, int* lds) {
   *lds = 2 * *nkt * 1024;
   const int nqt = (a.Lq + 15) / 16, per0 = qt_per_block_for(a), nblk = (nqt + per0 - 1) / per0;
   *per = (nqt + nblk - 1) / nblk;                                  // balanced query-tile ranges
-  static bool attr_set = false;                                    // > 64 KiB of dynamic LDS needs an explicit opt-in
-  if (!attr_set) {
+  // > 64 KiB of dynamic LDS needs an explicit opt-in, once per device; idempotent, so a race through the first call is benign
+  static std::atomic<unsigned long long> attr_done{0};
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  const unsigned long long bit = 1ull << (dev & 63);
+  if (!(attr_done.load(std::memory_order_acquire) & bit)) {
     const int max_lds = 2 * LONG_MAX_NKT * 1024;
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(mfma_fwd_long_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, max_lds) != hipSuccess ||
         hipFuncSetAttribute(reinterpret_cast<const void*>(mfma_bwd_dq_long_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, max_lds) != hipSuccess)
       LMV_FAIL(LMV_ERR_LAUNCH, "attn_mfma_long: cannot reserve %d bytes of LDS", max_lds);
-    attr_set = true;
+    attr_done.fetch_or(bit, std::memory_order_release);
   }
   return LMV_OK;
 }

@@ -34,6 +34,7 @@
 // DropPath scale and residual add fused.  In dW mode the bias gradient (column sums of dY) rides the matrix pipe:
 // one extra MFMA per fragment against an all-ones operand.
 #include <stdlib.h>
+#include <atomic>
 #include "common.h"
 
 namespace {
@@ -630,11 +631,16 @@ template <typename T, bool ATR, bool BTR, bool SPLITK, int BK, bool DMA, typenam
 int launch_one(const GemmArgs& g, dim3 grid, hipStream_t st) {
   constexpr int lds = 2 * (CF::PA + CF::PB) * PANEL * BK * (int)sizeof(T);
   auto kern = gemm_kernel<T, ATR, BTR, SPLITK, BK, DMA, CF, MINW>;
-  static bool attr_set = false;                 // > 64 KiB of dynamic LDS needs an explicit opt-in, once per kernel
-  if (!attr_set) {
+  // > 64 KiB of dynamic LDS needs an explicit opt-in, once per kernel AND device.  The call is idempotent, so two threads racing
+  // through the first launch both make it; the per-device bit only publishes "done" (re-entrant, no lock).
+  static std::atomic<unsigned long long> attr_done{0};
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  const unsigned long long bit = 1ull << (dev & 63);
+  if (!(attr_done.load(std::memory_order_acquire) & bit)) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
       LMV_FAIL(LMV_ERR_LAUNCH, "linear: cannot reserve %d bytes of LDS", lds);
-    attr_set = true;
+    attr_done.fetch_or(bit, std::memory_order_release);
   }
   hipLaunchKernelGGL(kern, grid, dim3(CF::NTHR), lds, st, g);
   return LMV_OK;

@@ -6,6 +6,7 @@ GPU).  LeMeViT-Base has 53.1 M parameters = 212 MB of fp32 gradients: compressin
 on the per-link-bound ring, and a few LARGE buckets (default 100 MB here, vs torch's 25 MB) suit point-to-point xGMI better
 than many small ones.  Everything runs on torch.distributed so the same code is testable with gloo on CPU.
 """
+import contextlib
 import os
 from typing import Optional
 
@@ -90,26 +91,50 @@ class FlatGradSync:
         opt.zero_grad(); loss.backward(); sync.finish(); opt.step()
     """
 
-    def __init__(self, flat_grad: torch.Tensor, chunk_bounds, rest_params, group=None, force: bool = False):
+    def __init__(self, flat_grad: torch.Tensor, chunk_bounds, rest_params, group=None, force: bool = False, compress: Optional[str] = None):
         self.flat = flat_grad
         self.bounds = list(chunk_bounds)                 # [(start, end)] element ranges of flat_grad, in forward order
         self.rest = [p for p in rest_params]
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.active = self.world > 1 or (force and dist.is_initialized())      # force: run the collectives in a 1-rank group (tests)
+        self.compress = compress           # "bf16": the block gradients travel as bfloat16 (half the xGMI bytes; SURVEY section 8, row f3)
         self._work = {}
+        self._wire = {}                    # chunk -> bf16 wire buffer (compress == "bf16")
+        self._hold = False                 # no_sync(): gradient accumulation in progress, nothing is sent
+
+    @contextlib.contextmanager
+    def no_sync(self):
+        """Gradient accumulation: backward passes inside this context only accumulate locally (like DDP.no_sync()); the
+        exchange starts from the first backward pass run OUTSIDE it, whose ``finish()`` sends every chunk.  Without this, a
+        chunk would be all-reduced with the partial gradient of the first micro-batch and later micro-batches would add
+        local gradients on top of cross-rank sums."""
+        prev, self._hold = self._hold, True
+        try:
+            yield
+        finally:
+            self._hold = prev
 
     def chunk_ready(self, k: int) -> None:
         """The backward pass has finished writing chunk k: start its all-reduce (asynchronous w.r.t. the compute stream)."""
-        if not self.active or k in self._work:
+        if not self.active or self._hold or k in self._work:
             return
         s, e = self.bounds[k]
-        self._work[k] = dist.all_reduce(self.flat[s:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        if self.compress == "bf16":
+            wire = self._wire.get(k)
+            if wire is None:
+                wire = self._wire[k] = torch.empty(e - s, device=self.flat.device, dtype=torch.bfloat16)
+            wire.copy_(self.flat[s:e])
+            self._work[k] = dist.all_reduce(wire, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        else:
+            self._work[k] = dist.all_reduce(self.flat[s:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
 
     def finish(self) -> None:
         """After backward: send whatever has not been sent, wait, average, and exchange the remaining parameters' gradients."""
         if not self.active:
             return
+        if self._hold:
+            raise RuntimeError("FlatGradSync.finish() inside no_sync(): run the last micro-batch outside the context")
         for k in range(len(self.bounds) - 1, -1, -1):
             self.chunk_ready(k)
         grads = [p.grad for p in self.rest if p.grad is not None]
@@ -117,6 +142,9 @@ class FlatGradSync:
         rest_work = dist.all_reduce(rest_flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True) if rest_flat is not None else None
         for k in sorted(self._work):
             self._work[k].wait()
+            if self.compress == "bf16":
+                s, e = self.bounds[k]
+                self.flat[s:e].copy_(self._wire[k])
         self._work.clear()
         self.flat.mul_(1.0 / self.world)
         if rest_work is not None:
@@ -146,7 +174,8 @@ class FlatGradSync:
                 off += n
 
 
-def attach_flat_grad_sync(model: torch.nn.Module, opt, nchunks: int = 4, group=None, src: int = 0, force: bool = False) -> FlatGradSync:
+def attach_flat_grad_sync(model: torch.nn.Module, opt, nchunks: int = 4, group=None, src: int = 0, force: bool = False,
+                          compress: Optional[str] = None) -> FlatGradSync:
     """Wire a FlatAdamW-managed model for data parallelism: broadcast rank `src`'s parameters / buffers, cut the flat gradient
     buffer into `nchunks` runs of whole blocks and hook each run's all-reduce to the backward pass of its first block."""
     from .model import LeMeBlock
@@ -173,7 +202,7 @@ def attach_flat_grad_sync(model: torch.nn.Module, opt, nchunks: int = 4, group=N
     bounds = [(offs[c], offs[cuts[j + 1]] if j + 1 < len(cuts) else total) for j, c in enumerate(cuts)]
     block_params = {id(p) for _, p, _, _ in opt._slices}
     rest = [p for p in model.parameters() if p.requires_grad and id(p) not in block_params]
-    sync = FlatGradSync(opt._flat_g, bounds, rest, group, force)
+    sync = FlatGradSync(opt._flat_g, bounds, rest, group, force, compress)
     mods = dict(blocks)
     for k, c in enumerate(cuts):                                       # chunk k is complete when its FIRST block has been differentiated
         for p in mods[order[c]].parameters():

@@ -250,7 +250,9 @@ def _is_stem_conv1(m: nn.Module, x: Tensor) -> bool:
 def _folded_conv_bn(conv: nn.Conv2d, bn: nn.BatchNorm2d, dtype: torch.dtype):
     """(weight, bias, fp32 bias) of conv followed by eval-mode BatchNorm, cached until any of the six source tensors changes."""
     src = [conv.weight, conv.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var]
-    ver = tuple(-1 if t is None else t._version for t in src) + tuple(0 if t is None else t.data_ptr() for t in src)
+    # _train_pass: fused optimizers and the native BatchNorm kernel update these tensors in place WITHOUT bumping
+    # ``_version`` (see compute_copy), so a fold made before a training pass must not survive it
+    ver = (_train_pass,) + tuple(-1 if t is None else t._version for t in src) + tuple(0 if t is None else t.data_ptr() for t in src)
     key = (id(conv), id(bn), dtype)
     ent = _fold_cache.get(key)
     if ent is not None and ent[0] == ver:

@@ -57,6 +57,11 @@ def _workspace(nbytes: int, device, stream: Optional[int] = None) -> Tensor:
     key = (device, _stream() if stream is None else stream)
     ws = _ws_cache.get(key)
     if ws is None or ws.numel() < nbytes:
+        if ws is not None and stream is not None:
+            # The caching allocator only knows the stream that was current at allocation time.  A launch enqueued by raw
+            # handle on another stream may still be using the old scratch: tell the allocator, so the block is not handed
+            # out again before that stream has passed this point.
+            ws.record_stream(torch.cuda.ExternalStream(stream, device=device))
         ws = torch.empty(max(int(nbytes * 1.25), 1 << 22), device=device, dtype=torch.uint8)
         _ws_cache[key] = ws
     return ws

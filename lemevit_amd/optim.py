@@ -62,12 +62,14 @@ class FlatAdamW:
         self._shadow = torch.zeros(total, device=dev, dtype=torch.bfloat16)
         self._step_dev = torch.zeros((), device=dev, dtype=torch.int32)
         self._slices: List[Tuple[str, nn.Parameter, int, int]] = []
+        self._grad_views: List[Tensor] = []
         with torch.no_grad():
             for (name, p, matrix), off in zip(flat_named, offs):
                 n = p.numel()
                 self._flat_p[off:off + n].copy_(p.detach().reshape(-1))
                 p.data = self._flat_p[off:off + n].view(p.shape)
                 p.grad = self._flat_g[off:off + n].view(p.shape)
+                self._grad_views.append(p.grad)
                 p._lmv_flat_grad = True                               # _BlockFn.backward accumulates into p.grad in place
                 if not no_decay(name, p):
                     self._wd_mask[off:off + n] = 1.0
@@ -79,17 +81,36 @@ class FlatAdamW:
         rest_plain = [p for n, p in model.named_parameters() if p.requires_grad and id(p) not in seen and no_decay(n, p)]
         groups = [g for g in (dict(params=rest_decay, weight_decay=weight_decay), dict(params=rest_plain, weight_decay=0.0)) if g["params"]]
         self._rest = torch.optim.AdamW(groups, lr=lr, betas=betas, eps=eps, fused=True, capturable=capturable) if groups else None
-        self.param_groups = [dict(lr=lr, name="lemevit_blocks_flat")] + (self._rest.param_groups if self._rest else [])
+        # 'params' lists the flat-managed parameters so that code walking param_groups (GradScaler.unscale_, timm's clipping,
+        # schedulers) sees every parameter; their .grad tensors are views of the flat gradient buffer
+        self.param_groups = [dict(params=[p for _, p, _, _ in self._slices], lr=lr, betas=betas, eps=eps, weight_decay=weight_decay,
+                                  name="lemevit_blocks_flat")] + (self._rest.param_groups if self._rest else [])
         self._hook = model.register_load_state_dict_post_hook(lambda *_: self.refresh())
 
     # ---- the optimizer interface ---------------------------------------------------------------------------------
+    def _rebind(self, keep: bool) -> None:
+        """Every flat-managed ``p.grad`` must be a view of the flat gradient buffer.  ``model.zero_grad()`` (set_to_none=True) or
+        ``p.grad = None`` breaks that: the block backward then hands the gradients to autograd, which allocates fresh ``.grad``
+        tensors the fused update would never read.  keep=True copies such a stray gradient into its slice first."""
+        for i, (_, p, off, n) in enumerate(self._slices):
+            g = p.grad
+            if g is self._grad_views[i]:                               # the common case: one identity test per parameter
+                continue
+            view = self._grad_views[i]
+            if g is not None and g.data_ptr() != view.data_ptr():
+                if keep:
+                    view.copy_(g.detach().to(view.dtype).view(view.shape))
+            p.grad = view
+
     def zero_grad(self, set_to_none: bool = True) -> None:
         self._flat_g.zero_()                                           # the flat gradients stay allocated: the kernels accumulate into them
+        self._rebind(keep=False)
         if self._rest is not None:
             self._rest.zero_grad(set_to_none=set_to_none)
 
     @torch.no_grad()
     def step(self) -> None:
+        self._rebind(keep=True)
         if self._rest is not None:
             self._rest.step()
         self._step_dev += 1

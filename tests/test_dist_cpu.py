@@ -89,6 +89,40 @@ def test_flat_grad_sync_two_ranks(tmp_path):
     assert r0["rest"][2] is None and r1["rest"][2] is None
 
 
+def _sync2_worker(rank, world, port, out):
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    from lemevit_amd import dist as D
+    D.init_distributed("gloo")
+    torch.manual_seed(200 + rank)
+    micro = [torch.randn(512), torch.randn(512)]                   # two micro-batches of local gradients
+    flat = torch.zeros(512)
+    sync = D.FlatGradSync(flat, [(0, 200), (200, 512)], [], compress="bf16")
+    with sync.no_sync():                                           # gradient accumulation: nothing may be sent yet
+        flat += micro[0]
+        sync.chunk_ready(1); sync.chunk_ready(0)
+        assert not sync._work
+        with pytest.raises(RuntimeError):
+            sync.finish()
+    flat += micro[1]
+    sync.chunk_ready(1)
+    sync.finish()
+    torch.save(dict(mine=micro[0] + micro[1], flat=flat), out + f".{rank}")
+    torch.distributed.destroy_process_group()
+
+
+def test_flat_grad_sync_no_sync_and_bf16_wire(tmp_path):
+    """Gradient accumulation under no_sync() sends nothing; the exchange after it carries the ACCUMULATED gradients, as bf16
+    on the wire (compress='bf16'): the result is the mean of the ranks' sums within bf16 rounding of each addend."""
+    out = str(tmp_path / "s2.pt")
+    mp.spawn(_sync2_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    r0, r1 = torch.load(out + ".0"), torch.load(out + ".1")
+    want = (r0["mine"].bfloat16().float() + r1["mine"].bfloat16().float()) / 2
+    assert torch.equal(r0["flat"], r1["flat"])
+    assert torch.allclose(r0["flat"], want, atol=2e-2, rtol=1e-2)
+    assert (r0["flat"] - (r0["mine"] + r1["mine"]) / 2).abs().max() < 4e-2
+
+
 def test_shard_batch():
     from lemevit_amd.dist import shard_batch
     assert [list(shard_batch(8, r, 4)) for r in range(4)] == [[0, 1], [2, 3], [4, 5], [6, 7]]

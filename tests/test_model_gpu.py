@@ -440,3 +440,120 @@ def test_dense_backbone_train_step_bf16():
             assert p.grad is None
         else:
             assert p.grad is not None and torch.isfinite(p.grad).all(), k
+
+
+# ------------------------------------------------------------------------------------------------
+# round-2 regressions
+def test_eval_fold_follows_training_step():
+    """eval -> train step -> eval: the conv+BN fold made by the first evaluation must not survive the training step.  The native
+    BatchNorm kernel writes the running statistics through raw pointers and fused optimizers update weights in place, both WITHOUT
+    bumping Tensor._version, so a version-keyed fold would silently feed stale stem weights / statistics to validation."""
+    torch.manual_seed(0)
+    Lm = L()
+    m = Lm.create_model("lemevit_tiny", num_classes=10).to(DEV)
+    opt = Lm.FlatAdamW(m, lr=5e-2, weight_decay=0.05)
+    x = torch.randn(4, 3, 64, 64, device=DEV); y = torch.randint(0, 10, (4,), device=DEV)
+    m.eval()
+    with torch.no_grad():
+        first = m(x).clone()
+    m.train()
+    for _ in range(2):
+        opt.zero_grad()
+        torch.nn.functional.cross_entropy(m(x), y).backward()
+        opt.step()
+    m.eval()
+    with torch.no_grad():
+        folded = m(x)
+    unfolded = m(x).detach()               # grad enabled: conv and BatchNorm run separately from the live tensors
+    assert float((folded - first).abs().max()) > 1e-4, "evaluation ignores the training steps"
+    close(folded, unfolded.cpu().numpy(), 1e-5, "fold after training")
+
+
+def test_flat_adamw_survives_model_zero_grad():
+    """model.zero_grad() (set_to_none=True) detaches p.grad from the flat gradient buffer; FlatAdamW must re-bind (and keep a
+    gradient autograd allocated meanwhile) instead of silently stepping on zeros.  param_groups[0] lists the flat parameters."""
+    torch.manual_seed(0)
+    Lm = L()
+    m1 = Lm.create_model("lemevit_tiny", num_classes=10).to(DEV).train()
+    m2 = Lm.create_model("lemevit_tiny", num_classes=10).to(DEV).train()
+    m2.load_state_dict(m1.state_dict())
+    o1 = Lm.FlatAdamW(m1, lr=1e-3, weight_decay=0.05); o2 = Lm.FlatAdamW(m2, lr=1e-3, weight_decay=0.05)
+    assert len(o2.param_groups[0]["params"]) == len(o2._slices) > 0
+    x = torch.randn(4, 3, 64, 64, device=DEV); y = torch.randint(0, 10, (4,), device=DEV)
+    w0 = m1.stages[3][0].mlp[0].weight.detach().clone()
+    for m, o, hostile in ((m1, o1, False), (m2, o2, True)):
+        torch.manual_seed(7)
+        if hostile:
+            m.zero_grad(set_to_none=True)          # every p.grad is None now: the backward goes through autograd's accumulation
+        else:
+            o.zero_grad()
+        torch.nn.functional.cross_entropy(m(x), y).backward()
+        o.step()
+    w1, w2 = m1.stages[3][0].mlp[0].weight, m2.stages[3][0].mlp[0].weight
+    assert float((w1 - w0).abs().max()) > 1e-4, "the reference twin did not train"
+    assert torch.allclose(w1, w2, atol=1e-6), float((w1 - w2).abs().max())
+    assert w2.grad is not None and w2.grad.data_ptr() == o2._grad_views[[p is w2 for _, p, _, _ in o2._slices].index(True)].data_ptr()
+
+
+@pytest.mark.parametrize("compress", [None, "bf16"])
+def test_two_rank_gradients_equal_single_process(tmp_path, compress):
+    """SURVEY section 4 "Distributed", on the PRODUCT model: lemevit_tiny (fp32 kernels) trained by two ranks that share this GPU
+    (gloo process group), FlatAdamW + FlatGradSync, global batch 8 split 4 + 4, against one process on the whole batch.
+    LayerNorm / attention / MLP are per-sample, so block gradients must agree to fp32 rounding; the stem and stage-transition
+    BatchNorms use per-rank batch statistics exactly as the reference's DDP default (main.py:222-234, no SyncBN), so parameters
+    upstream of a BatchNorm would differ by design -- so the BatchNorms are put in eval mode (fixed statistics) on both sides and
+    EVERY parameter gradient is compared."""
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    out = str(tmp_path / "g2.pt")
+    mp.spawn(_two_rank_worker_bn_eval, args=(2, port, out, compress), nprocs=2, join=True)
+    got = torch.load(out)
+    Lm = L()
+    torch.manual_seed(0)
+    m = Lm.create_model("lemevit_tiny", num_classes=10, drop_path_rate=0.0).to(DEV).train()
+    for mod in m.modules():
+        if isinstance(mod, torch.nn.BatchNorm2d):
+            mod.eval()
+    opt = Lm.FlatAdamW(m, lr=1e-3, weight_decay=0.05)
+    torch.manual_seed(1)
+    x = torch.randn(8, 3, 64, 64, device=DEV); y = torch.randint(0, 10, (8,), device=DEV)
+    opt.zero_grad()
+    torch.nn.functional.cross_entropy(m(x), y).backward()
+    tol = 1e-2 if compress else 2e-5
+    checked = 0
+    for n, p in m.named_parameters():
+        if p.grad is None:
+            continue
+        ref = p.grad.detach().float().cpu()
+        # the mean over two half-batch gradients equals the full-batch gradient (CrossEntropyLoss averages over the batch)
+        err = float((got[n] - ref).abs().max()); scale = float(ref.abs().max()) + 1e-12
+        assert err <= tol * scale + 1e-7, f"{n}: {err:.3e} vs scale {scale:.3e}"
+        checked += 1
+    assert checked > 100
+
+
+def _two_rank_worker_bn_eval(rank, world, port, out, compress):
+    import os
+    os.environ.update(RANK=str(rank), LOCAL_RANK="0", WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import torch.distributed as dist
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo")
+    import lemevit_amd as Lm
+    from lemevit_amd.dist import attach_flat_grad_sync, shard_batch
+    torch.manual_seed(0)
+    m = Lm.create_model("lemevit_tiny", num_classes=10, drop_path_rate=0.0).to(DEV).train()
+    for mod in m.modules():
+        if isinstance(mod, torch.nn.BatchNorm2d):
+            mod.eval()                                   # fixed statistics: every remaining op is per-sample
+    opt = Lm.FlatAdamW(m, lr=1e-3, weight_decay=0.05)
+    sync = attach_flat_grad_sync(m, opt, nchunks=3, compress=compress)
+    torch.manual_seed(1)
+    x = torch.randn(8, 3, 64, 64, device=DEV); y = torch.randint(0, 10, (8,), device=DEV)
+    idx = list(shard_batch(8, rank, world))
+    opt.zero_grad()
+    torch.nn.functional.cross_entropy(m(x[idx]), y[idx]).backward()
+    sync.finish()
+    if rank == 0:
+        torch.save({n: p.grad.detach().float().cpu() for n, p in m.named_parameters() if p.grad is not None}, out)
+    dist.destroy_process_group()

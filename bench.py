@@ -52,6 +52,7 @@ def parse():
     ap.add_argument("--img", type=int, default=224)
     ap.add_argument("--mode", default="train", choices=["train", "infer"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-baseline-protocol", default="", metavar="OUT.json", help="only run the CPU oracle with benchmark.py's 10 + 40 protocol (Tiny B=1, Base B=1 / B=32) and exit")
     ap.add_argument("--ddp", action="store_true", help="N > 1: torch DistributedDataParallel + torch AdamW instead of FlatAdamW + FlatGradSync")
     ap.add_argument("--force-sync", action="store_true", help="run the FlatGradSync collectives even at world size 1 (1-rank process group)")
     ap.add_argument("--force-ddp", action="store_true", help="wrap in DDP (and use the DDP code path) even at world size 1: measures the wrapper's overhead")
@@ -149,8 +150,44 @@ def cpu_baseline(model_name: str, img: int, mode: str):
                 sample=f"{n} {'fwd+bwd' if train else 'fwd'} steps of {model_name} {img}x{img} fp32 at batch {B} (oracle/lemevit_oracle.py, PyTorch CPU)")
 
 
+def cpu_baseline_protocol(out_path: str):
+    """the oracle on the host cores with benchmark.py's inference protocol (eval, no_grad, one synthetic
+    batch, 10 warm-up + 40 timed steps, benchmark.py:120-130,320-321,517-518) -- Tiny B=1 (config 1), Base B=1 and Base B=32.
+    Takes minutes; not part of the default bench run (python bench.py --cpu-baseline-protocol gpurun_out/cpu_baseline.json)."""
+    from oracle import lemevit_oracle as O
+    res = dict(cores=torch.get_num_threads(), kind="port", protocol="eval + no_grad, 10 warm-up + 40 timed steps, fp32, oracle/lemevit_oracle.py")
+    try:
+        with open("/proc/cpuinfo") as f:
+            res["cpu_model"] = next(l.split(":", 1)[1].strip() for l in f if l.startswith("model name"))
+    except Exception:
+        pass
+    for name, B, warm, iters in (("lemevit_tiny", 1, 10, 40), ("lemevit_base", 1, 10, 40), ("lemevit_base", 32, 3, 10)):
+        cfg = O.VARIANTS[name]
+        torch.manual_seed(0)
+        sd = {}
+        for k, shp in O.state_dict_spec(cfg, 1000).items():
+            sd[k] = (torch.zeros((), dtype=torch.int64) if k.endswith("num_batches_tracked") else torch.ones(shp) if k.endswith(("running_var",)) or
+                     (len(shp) == 1 and k.endswith(".weight")) else torch.randn(shp) * 0.02 if len(shp) >= 2 else torch.zeros(shp))
+        x = torch.randn(B, 3, 224, 224)
+        with torch.no_grad():
+            for _ in range(warm):
+                O.lemevit_forward(sd, cfg, x)
+            t0 = time.perf_counter()
+            for _ in range(iters):
+                O.lemevit_forward(sd, cfg, x)
+            dt = time.perf_counter() - t0
+        res[f"{name}_b{B}"] = dict(images_per_sec=round(B * iters / dt, 3), ms_per_step=round(1e3 * dt / iters, 2), warmup=warm, iters=iters)
+        print(name, B, res[f"{name}_b{B}"], file=sys.stderr, flush=True)
+    os.makedirs(os.path.dirname(out_path) or ".", exist_ok=True)
+    with open(out_path, "w") as f:
+        json.dump(res, f, indent=1)
+    print(json.dumps(res))
+
+
 def main():
     args = parse()
+    if args.cpu_baseline_protocol:
+        return cpu_baseline_protocol(args.cpu_baseline_protocol)
     if args.graph < 0:
         args.graph = 0 if args.mode == "train" else 1
     # stdout carries exactly ONE line, the JSON record: RCCL prints a version banner through C stdio on stdout (flushed at

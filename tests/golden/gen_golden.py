@@ -26,6 +26,7 @@ from detfill import det_tensor, fill_state_dict, sample  # noqa: E402
 
 REF = "/root/reference/models/lemevit.py"
 REG = {}
+ONLY = set(sys.argv[sys.argv.index("--only") + 1].split(",")) if "--only" in sys.argv else set()
 DP_LOG = []          # DropPath masks in draw order (training fixtures)
 
 
@@ -182,7 +183,10 @@ def gen_models(ref):
     for name, variant, res, B, nc in [("model_tiny_224", "lemevit_tiny", 224, 2, 1000), ("model_base_224", "lemevit_base", 224, 2, 1000),
                                       ("model_small_224", "lemevit_small", 224, 1, 51), ("model_tiny_384", "lemevit_tiny", 384, 1, 1000),
                                       ("model_tiny_v2_224", "lemevit_tiny_v2", 224, 1, 1000), ("model_small_v2_224", "lemevit_small_v2", 224, 1, 1000),
-                                      ("model_vit_tiny_224", "vit_tiny", 224, 1, 1000)]:
+                                      ("model_vit_tiny_224", "vit_tiny", 224, 1, 1000),
+                                      ("model_base_384", "lemevit_base", 384, 1, 1000)]:      # BASELINE config 5 (round 2)
+        if ONLY and name not in ONLY:
+            continue
         torch.manual_seed(0)
         m = REG[variant](num_classes=nc).eval()
         nparams = sum(p.numel() for p in m.parameters())
@@ -271,6 +275,9 @@ def main():
     torch.set_num_threads(os.cpu_count() or 1)
     ref = _import_reference()
     assert ref.has_torchfunc and not ref.has_flash_attn and not ref.has_xformers
+    if ONLY:                       # --only model_base_384[,...]: add a model fixture without rewriting the others
+        gen_models(ref)
+        return
     if "--dense-only" in sys.argv:
         gen_dense(_import_dense_reference())
         return

@@ -86,6 +86,12 @@ def test_block_forward(golden, name, dtype, tol):
     with torch.no_grad():
         xo, co = m(x, c)                     # reference signature: NCHW in / out
     close(sample(xo.float().contiguous(), 16384), g["x_out"], tol, name + ".x"); close(co, g["c_out"], tol, name + ".c")
+    # The fixture holds 16384 strided samples of the image-token map; a bug confined to one tile could sit between them.  The FULL
+    # tensor is therefore compared with the CPU oracle (itself pinned to the reference by the same fixture, tests/test_oracle_golden.py).
+    sd = {"blk." + k: v.detach().double().cpu() for k, v in m.state_dict().items()}
+    xt, _, _ = O.to_tokens(x.detach().double().cpu())
+    xr, cr = O.leme_block(sd, "blk.", t, xt, c.detach().double().cpu(), H, W, h)
+    close(xo, O.to_nchw(xr, H, W).numpy(), tol, name + ".x (full tensor vs oracle)"); close(co, cr.numpy(), tol, name + ".c (full tensor vs oracle)")
 
 
 @pytest.mark.parametrize("name", ["blockgrad_D", "blockgrad_S", "blockgrad_C"])
@@ -143,7 +149,7 @@ def _model(variant, num_classes, seed, **kw):
 
 
 @pytest.mark.parametrize("name", ["model_tiny_224", "model_base_224", "model_small_224", "model_tiny_384", "model_small_v2_224", "model_tiny_v2_224",
-                                  "model_vit_tiny_224"])
+                                  "model_vit_tiny_224", "model_base_384"])
 def test_model_forward_fp32(golden, name):
     """BASELINE config 1 + fp32 parity: logits within 1e-5 (rel. max-abs) of the reference's CPU forward."""
     meta, g = golden(name)
@@ -177,7 +183,7 @@ def test_eval_conv_bn_folding_fp32(golden):
     close(moved, ref.detach().cpu().numpy(), 1e-5, "refreshed fold")
 
 
-@pytest.mark.parametrize("name", ["model_tiny_224", "model_base_224"])
+@pytest.mark.parametrize("name", ["model_tiny_224", "model_base_224", "model_base_384"])       # model_base_384 = BASELINE config 5
 @pytest.mark.parametrize("mode", ["autocast", "pure"])
 def test_model_forward_bf16(golden, name, mode):
     """End-to-end bf16 (both benchmark.py flavours: --amp autocast, and --precision bfloat16 whole-model cast).

@@ -201,6 +201,8 @@ ATTN_CASES = [  # name, B, Lq, Lk, C, self (packed qkv) ?
     # beyond 640 keys (bf16): K / V streamed through LDS in 256-key chunks, online softmax (dense backbones: 4096 image tokens)
     ("stream_700", 1, 40, 700, 64, False), ("stream_sa1040", 1, 1040, 1040, 96, True), ("stream_ragged", 2, 333, 2049, 64, False),
     ("stream_4096", 1, 4096, 4096, 64, True),
+    # BASELINE config 5 (Base at 384^2): DCA with N = 9216 (stage 1, C = 96) and N = 2304 (stage 2, C = 192) image tokens against 16 meta tokens
+    ("fewq_9216", 1, 16, 9216, 96, False), ("fewk_9216", 1, 9216, 16, 96, False), ("fewq_2304", 2, 16, 2304, 192, False), ("fewk_2304", 2, 2304, 16, 192, False),
 ]
 
 

@@ -92,7 +92,7 @@ def test_block_backward(golden, name):
         _close(gr, g["grad." + k[len("blk."):]], 2e-5, "grad " + k)
 
 
-@pytest.mark.parametrize("name", ["model_tiny_224", "model_base_224", "model_small_224", "model_tiny_384",
+@pytest.mark.parametrize("name", ["model_tiny_224", "model_base_224", "model_small_224", "model_tiny_384", "model_base_384",
                                   "model_tiny_v2_224", "model_small_v2_224", "model_vit_tiny_224"])
 def test_model_forward(golden, name):
     meta, g = golden(name)

@@ -457,6 +457,7 @@ extern "C" size_t lmv_attn_workspace_bytes(int B, int H, int Lq, int Lk, int bac
   a.B = B; a.H = H; a.Lq = Lq; a.Lk = Lk;
   size_t acc = 2 * (size_t)B * H * FQ * D * sizeof(float);
   if (lmv_attn_mfma_supported(a) && lmv_attn_mfma_bwd_acc_bytes(a) > acc) acc = lmv_attn_mfma_bwd_acc_bytes(a);
+  if (few_q(Lq, Lk) && lmv_attn_mfma_fewq_bwd_acc_bytes(a) > acc) acc = lmv_attn_mfma_fewq_bwd_acc_bytes(a);     // dQ slabs of the split-key path
   return align256((size_t)B * H * Lq * sizeof(float)) + align256(acc);
 }
 

@@ -18,6 +18,7 @@ int lmv_attn_mfma_bwd(const AttnArgs& a, float* delta, float* acc, hipStream_t s
 bool lmv_attn_mfma_fewq_supported(const AttnArgs& a);
 int lmv_attn_mfma_fewq_nsplit(const AttnArgs& a);
 int lmv_attn_mfma_fewq_fwd(const AttnArgs& a, float* part, hipStream_t st);
+size_t lmv_attn_mfma_fewq_bwd_acc_bytes(const AttnArgs& a);   // fp32 dQ slabs, one per workgroup of the key split
 int lmv_attn_mfma_fewq_bwd(const AttnArgs& a, float* acc, hipStream_t st);
 // many queries over 225..640 keys (bf16): whole-row kernels with K / V of a (b, h) in dynamic LDS
 bool lmv_attn_mfma_long_supported(const AttnArgs& a);

@@ -58,11 +58,16 @@ __device__ __forceinline__ void stage_rows2(unsigned char* sa, const bf16_t* ba,
 __device__ __forceinline__ bf16x8_t frag_n(const unsigned char* s, int row0, int lane) {
   return *reinterpret_cast<const bf16x8_t*>(s + swz(row0 + (lane & 15), lane >> 4));
 }
-// transposed fragment for the 32-row block {rowA + 0..15, rowB + 0..15} and the 16 columns d0..d0+15:
-// lane -> column d0 + (lane & 15); k-slot j of lane group g -> row (j < 4 ? rowA : rowB) + g * 4 + (j & 3)
+// transposed fragment for the 32-row block {rowA + 0..15, rowB + 0..15} and one HALF (d0 = 0 / 16 selects half 0 / 1) of the 32
+// columns, in the INTERLEAVED order  lane i -> column 8 * (i >> 2) + 4 * half + (i & 3):  half 0 holds d = {0-3, 8-11, 16-19,
+// 24-27}, half 1 the rest.  An output tile pair (x0, x1) = (MFMA(frag_t(.., 0), ..), MFMA(frag_t(.., 16), ..)) then leaves lane
+// group g with d = 8g .. 8g+3 in x0 and 8g+4 .. 8g+7 in x1 -- EIGHT consecutive d of one row = one 16-byte store (store8), and the
+// four lane groups cover the row's 64 bytes.  (With the natural order a lane owned two 8-byte pieces 32 bytes apart: 8-byte stores
+// in 32-byte segments ran at ~2 TB/s, tools/native/panel_probe.hip.)  The contraction only needs both operands to agree.
+// k-slot j of lane group g -> row (j < 4 ? rowA : rowB) + g * 4 + (j & 3)
 __device__ __forceinline__ bf16x8_t frag_t(const unsigned char* s, int rowA, int rowB, int d0, int lane) {
   const int g = lane >> 4, i = lane & 15, rr = i >> 2, q = i & 3;
-  const int ra = rowA + g * 4 + rr, rb = rowB + g * 4 + rr, c16 = (d0 >> 3) + (q >> 1), off = (q & 1) * 8;
+  const int ra = rowA + g * 4 + rr, rb = rowB + g * 4 + rr, c16 = q, off = (d0 >> 4) * 8;
   bf16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds4_t)(s + swz(ra, c16) + off));
   bf16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds4_t)(s + swz(rb, c16) + off));
   return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
@@ -82,41 +87,78 @@ __device__ __forceinline__ bf16x8_t load_frag_global(const bf16_t* base, int64_t
 __device__ __forceinline__ float group_max4(float v) { v = fmaxf(v, __shfl_xor(v, 16, 64)); return fmaxf(v, __shfl_xor(v, 32, 64)); }
 __device__ __forceinline__ float group_sum4(float v) { v += __shfl_xor(v, 16, 64); return v + __shfl_xor(v, 32, 64); }
 __device__ __forceinline__ void store4(bf16_t* p, const f32x4_t& v) { *reinterpret_cast<uint2*>(p) = make_uint2(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])); }
+// the tile pair (x0, x1) of a frag_t-produced output: d = 8g .. 8g+7 of the row at `row` (32 d, 64 bytes)
+__device__ __forceinline__ void store8(bf16_t* row, int g, const f32x4_t& x0, const f32x4_t& x1) {
+  *reinterpret_cast<uint4*>(row + g * 8) = make_uint4(pack_bf2(x0[0], x0[1]), pack_bf2(x0[2], x0[3]), pack_bf2(x1[0], x1[1]), pack_bf2(x1[2], x1[3]));
+}
 
 #define MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0)
 
 // =============================================================================================
 // forward: NKT = number of 16-key tiles (even), keys padded with zero rows / masked scores
+//   LK  > 0: the key count is a compile-time constant (the model's hot shapes: 196 / 49 / 16 keys): tiles past the end are not
+//            computed at all, the boundary tile is masked with one select per score, and nothing else is -- the run-time version
+//            carries a compare / select pair per score and tile plus wave-uniform branches, ~1000 VALU / SALU instructions per
+//            16 queries against 42 MFMAs (the kernel is VALU-issue bound).
+//   PV16:    P and V enter the P V product as fp16 (v_mfma_f32_16x16x32_f16): P in [0, 1] keeps 11 mantissa bits, so the
+//            hi + lo bf16 split of P (2 extra MFMAs and ~3 VALU per score) is not needed for the 1e-3 budget; V is converted once
+//            per workgroup inside LDS (bf16 -> fp16 is exact; saturated at the fp16 range).
 // =============================================================================================
-template <int NKT>
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8_t;
+typedef __attribute__((ext_vector_type(2))) _Float16 f16x2_t;
+
+__device__ __forceinline__ unsigned bf2_to_h2(unsigned w) {          // two bf16 -> two fp16 (exact inside the fp16 range, saturating)
+  const float lo = fminf(fmaxf(__uint_as_float(w << 16), -65504.f), 65504.f), hi = fminf(fmaxf(__uint_as_float(w & 0xffff0000u), -65504.f), 65504.f);
+  return __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(lo, hi));
+}
+__device__ __forceinline__ f16x8_t pack8h(const f32x4_t& a, const f32x4_t& b) {
+  typedef __attribute__((ext_vector_type(4))) unsigned u32x4_t;
+  const u32x4_t w = {__builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(a[0], a[1])), __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(a[2], a[3])),
+                     __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(b[0], b[1])), __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(b[2], b[3]))};
+  return __builtin_bit_cast(f16x8_t, w);
+}
+
+template <int NKT, int LK = 0, bool PV16 = false>
 __global__ __launch_bounds__(256) void mfma_fwd_kernel(const AttnArgs a, int qt_per_block) {
   __shared__ __attribute__((aligned(16))) unsigned char sK[NKT * 16 * 64], sV[NKT * 16 * 64];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = blockIdx.y, b = blockIdx.z;
+  const int Lk = LK ? LK : a.Lk;
   const bf16_t* qb = reinterpret_cast<const bf16_t*>(a.q) + b * a.q_bs + h * D;
   const bf16_t* kb = reinterpret_cast<const bf16_t*>(a.k) + b * a.k_bs + h * D;
   const bf16_t* vb = reinterpret_cast<const bf16_t*>(a.v) + b * a.v_bs + h * D;
   bf16_t* ob = reinterpret_cast<bf16_t*>(a.o) + b * a.o_bs + h * D;
-  stage_rows2<256>(sK, kb, a.k_rs, sV, vb, a.v_rs, 0, NKT * 16, a.Lk, tid);
+  stage_rows2<256>(sK, kb, a.k_rs, sV, vb, a.v_rs, 0, NKT * 16, Lk, tid);
   __syncthreads();
+  if constexpr (PV16) {
+    for (int c = tid; c < NKT * 16 * 4; c += 256) {
+      uint4 v = *reinterpret_cast<const uint4*>(sV + c * 16);
+      v.x = bf2_to_h2(v.x); v.y = bf2_to_h2(v.y); v.z = bf2_to_h2(v.z); v.w = bf2_to_h2(v.w);
+      *reinterpret_cast<uint4*>(sV + c * 16) = v;
+    }
+    __syncthreads();
+  }
   const int nqt = (a.Lq + 15) >> 4;
   const int qt_end = min(nqt, (int)(blockIdx.x + 1) * qt_per_block);
   const int g = lane >> 4;
   const float sc2 = a.scale * 1.4426950408889634f;
+  // the query fragment of the NEXT iteration is fetched while this one computes
+  bf16x8_t qf_next = load_frag_global(qb, a.q_rs, (blockIdx.x * qt_per_block + wave) * 16 + (lane & 15), a.Lq, lane);
   for (int qt = blockIdx.x * qt_per_block + wave; qt < qt_end; qt += 4) {
     const int q = qt * 16 + (lane & 15);
-    const bf16x8_t qf = load_frag_global(qb, a.q_rs, q, a.Lq, lane);
+    const bf16x8_t qf = qf_next;
+    if (qt + 4 < qt_end) qf_next = load_frag_global(qb, a.q_rs, q + 64, a.Lq, lane);
     // softmax on the RAW scores (scale > 0 commutes with the maximum): p = 2^(s * c - m * c), c = scale * log2(e) -- one FMA
-    // and one v_exp_f32 per score; only the tiles that reach past Lk are masked (the kernel is VALU-bound: 4 * NKT scores
-    // per lane against NKT + 4 * NKT / 2 MFMAs)
+    // and one v_exp_f32 per score
     f32x4_t s[NKT];
     float m = -3e38f;
 #pragma unroll
     for (int kt = 0; kt < NKT; ++kt) {
+      if (LK && kt * 16 >= LK) { s[kt] = f32x4_t{-3e38f, -3e38f, -3e38f, -3e38f}; continue; }      // compile-time: padding tile
       s[kt] = MFMA(frag_n(sK, kt * 16, lane), qf, (f32x4_t{0.f, 0.f, 0.f, 0.f}));
-      if (kt * 16 + 16 > a.Lk) {                            // wave-uniform: boundary / padding tile
+      if (kt * 16 + 16 > Lk) {                              // boundary / padding tile (wave-uniform; compile-time for LK > 0)
 #pragma unroll
         for (int r = 0; r < 4; ++r)
-          if (kt * 16 + g * 4 + r >= a.Lk) s[kt][r] = -3e38f;
+          if (kt * 16 + g * 4 + r >= Lk) s[kt][r] = -3e38f;
       }
 #pragma unroll
       for (int r = 0; r < 4; ++r) m = fmaxf(m, s[kt][r]);
@@ -125,29 +167,37 @@ __global__ __launch_bounds__(256) void mfma_fwd_kernel(const AttnArgs a, int qt_
     const float mc = m * sc2;
     float l = 0.f;
 #pragma unroll
-    for (int kt = 0; kt < NKT; ++kt)
+    for (int kt = 0; kt < NKT; ++kt) {
+      if (LK && kt * 16 >= LK) { s[kt] = f32x4_t{0.f, 0.f, 0.f, 0.f}; continue; }
 #pragma unroll
       for (int r = 0; r < 4; ++r) { const float p = __builtin_amdgcn_exp2f(fmaf(s[kt][r], sc2, -mc)); s[kt][r] = p; l += p; }
+    }
     l = group_sum4(l);
     f32x4_t o0 = {0.f, 0.f, 0.f, 0.f}, o1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int kb2 = 0; kb2 < NKT / 2; ++kb2) {
-      // P is fed to the matrix core as hi + lo bf16 parts (16 mantissa bits): the forward output then carries only
-      // its own bf16 rounding, which keeps the kernel inside the 1e-3 parity budget at 2 extra MFMAs per block
-      const bf16x8_t ph = pack8(s[2 * kb2], s[2 * kb2 + 1]);
-      f32x4_t r0, r1;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) { r0[r] = s[2 * kb2][r] - (float)ph[r]; r1[r] = s[2 * kb2 + 1][r] - (float)ph[4 + r]; }
-      const bf16x8_t pl = pack8(r0, r1);
+      if (LK && kb2 * 32 >= LK) continue;
       const bf16x8_t vt0 = frag_t(sV, kb2 * 32, kb2 * 32 + 16, 0, lane), vt1 = frag_t(sV, kb2 * 32, kb2 * 32 + 16, 16, lane);
-      o0 = MFMA(vt0, ph, o0); o0 = MFMA(vt0, pl, o0);
-      o1 = MFMA(vt1, ph, o1); o1 = MFMA(vt1, pl, o1);
+      if constexpr (PV16) {
+        const f16x8_t ph = pack8h(s[2 * kb2], s[2 * kb2 + 1]);
+        o0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, vt0), ph, o0, 0, 0, 0);
+        o1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, vt1), ph, o1, 0, 0, 0);
+      } else {
+        // P is fed to the matrix core as hi + lo bf16 parts (16 mantissa bits): the forward output then carries only
+        // its own bf16 rounding, which keeps the kernel inside the 1e-3 parity budget at 2 extra MFMAs per block
+        const bf16x8_t ph = pack8(s[2 * kb2], s[2 * kb2 + 1]);
+        f32x4_t r0, r1;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { r0[r] = s[2 * kb2][r] - (float)ph[r]; r1[r] = s[2 * kb2 + 1][r] - (float)ph[4 + r]; }
+        const bf16x8_t pl = pack8(r0, r1);
+        o0 = MFMA(vt0, ph, o0); o0 = MFMA(vt0, pl, o0);
+        o1 = MFMA(vt1, ph, o1); o1 = MFMA(vt1, pl, o1);
+      }
     }
     if (q < a.Lq) {
       const float inv = 1.f / l;
       o0 *= inv; o1 *= inv;
-      store4(ob + (int64_t)q * a.o_rs + g * 4, o0);
-      store4(ob + (int64_t)q * a.o_rs + 16 + g * 4, o1);
+      store8(ob + (int64_t)q * a.o_rs, g, o0, o1);
       if (a.lse && g == 0) a.lse[((int64_t)b * a.H + h) * a.Lq + q] = m * a.scale + __logf(l);
     }
   }
@@ -204,8 +254,7 @@ __global__ __launch_bounds__(256) void mfma_bwd_dq_kernel(const AttnArgs a, floa
       dq1 = MFMA(frag_t(sK, kb2 * 32, kb2 * 32 + 16, 16, lane), dsf, dq1);
     }
     if (vq) {
-      store4(dqb + (int64_t)q * a.q_rs + g * 4, dq0);
-      store4(dqb + (int64_t)q * a.q_rs + 16 + g * 4, dq1);
+      store8(dqb + (int64_t)q * a.q_rs, g, dq0, dq1);
     }
   }
 }
@@ -312,8 +361,7 @@ __global__ __launch_bounds__(256) void mfma_bwd_dkv_kernel(const AttnArgs a, con
         const f32x4_t z = {0.f, 0.f, 0.f, 0.f};
         const f32x4_t dq0 = MFMA(frag_t(sKV, 0, 16, 0, lane), dsf, z), dq1 = MFMA(frag_t(sKV, 0, 16, 16, lane), dsf, z);
         if (q0 + qi < q1) {
-          store4(dqb + (int64_t)(q0 + qi) * a.q_rs + g * 4, dq0);
-          store4(dqb + (int64_t)(q0 + qi) * a.q_rs + 16 + g * 4, dq1);
+          store8(dqb + (int64_t)(q0 + qi) * a.q_rs, g, dq0, dq1);
         }
       }
     }
@@ -365,17 +413,17 @@ __global__ __launch_bounds__(256) void mfma_bwd_dkv_kernel(const AttnArgs a, con
   for (int i = 0; i < TPW; ++i) {
     const int kt = kw + i * KW, key = kt * 16 + (lane & 15);
     if (kt >= NKT || key >= a.Lk) continue;
+    if (ATOMIC) {      // several query ranges per (b, h): this range's partial goes to ITS slab (plain stores; summed by scatter_sum_kernel)
 #pragma unroll
-    for (int dt = 0; dt < 2; ++dt) {
-      const int d = dt * 16 + g * 4;
-      if (ATOMIC) {      // several query ranges per (b, h): this range's partial goes to ITS slab (plain stores; summed by scatter_sum_kernel)
+      for (int dt = 0; dt < 2; ++dt) {
+        const int d = g * 8 + dt * 4;          // frag_t's interleaved column order
         const int64_t o = ((((int64_t)blockIdx.x * a.B + b) * a.H + h) * (NKT * 16) + key) * D + d;
         *reinterpret_cast<f32x4_t*>(acc_k + o) = dk[i][dt];
         *reinterpret_cast<f32x4_t*>(acc_v + o) = dv[i][dt];
-      } else {
-        store4(reinterpret_cast<bf16_t*>(a.dk) + b * a.k_bs + (int64_t)key * a.k_rs + h * D + d, dk[i][dt]);
-        store4(reinterpret_cast<bf16_t*>(a.dv) + b * a.v_bs + (int64_t)key * a.v_rs + h * D + d, dv[i][dt]);
       }
+    } else {
+      store8(reinterpret_cast<bf16_t*>(a.dk) + b * a.k_bs + (int64_t)key * a.k_rs + h * D, g, dk[i][0], dk[i][1]);
+      store8(reinterpret_cast<bf16_t*>(a.dv) + b * a.v_bs + (int64_t)key * a.v_rs + h * D, g, dv[i][0], dv[i][1]);
     }
   }
 }
@@ -469,7 +517,7 @@ __global__ __launch_bounds__(256) void mfma_fwd_split_kernel(const AttnArgs a, f
   }
   if (g == 0) { pp[0] = m; pp[1] = l; }
 #pragma unroll
-  for (int r = 0; r < 4; ++r) { pp[2 + g * 4 + r] = o0[r]; pp[18 + g * 4 + r] = o1[r]; }
+  for (int r = 0; r < 4; ++r) { pp[2 + g * 8 + r] = o0[r]; pp[2 + g * 8 + 4 + r] = o1[r]; }      // frag_t's interleaved column order
 }
 
 // backward of the same shape, RKB = 64 keys per wave: grid (ceil(ceil(Lk / 64) / 4), H, B)
@@ -532,9 +580,8 @@ __global__ __launch_bounds__(256) void mfma_bwd_fewq_kernel(const AttnArgs a, fl
     const f32x4_t z = {0.f, 0.f, 0.f, 0.f};
     const f32x4_t dv0 = MFMA(gt0, pf, z), dv1 = MFMA(gt1, pf, z), dk0 = MFMA(qt0, dsf, z), dk1 = MFMA(qt1, dsf, z);
     if (kvalid) {
-      bf16_t* dkp = reinterpret_cast<bf16_t*>(a.dk) + b * a.k_bs + (int64_t)key * a.k_rs + h * D + g * 4;
-      bf16_t* dvp = reinterpret_cast<bf16_t*>(a.dv) + b * a.v_bs + (int64_t)key * a.v_rs + h * D + g * 4;
-      store4(dkp, dk0); store4(dkp + 16, dk1); store4(dvp, dv0); store4(dvp + 16, dv1);
+      store8(reinterpret_cast<bf16_t*>(a.dk) + b * a.k_bs + (int64_t)key * a.k_rs + h * D, g, dk0, dk1);
+      store8(reinterpret_cast<bf16_t*>(a.dv) + b * a.v_bs + (int64_t)key * a.v_rs + h * D, g, dv0, dv1);
     }
   }
   // ---- orientation D[key][q]: this wave's share of dQ (query tile 0: rows 0..15) --------------------------------
@@ -571,10 +618,24 @@ __global__ __launch_bounds__(256) void mfma_bwd_fewq_kernel(const AttnArgs a, fl
       dq0 += *reinterpret_cast<const f32x4_t*>(&sRed[w][0][lane][0]);
       dq1 += *reinterpret_cast<const f32x4_t*>(&sRed[w][1][lane][0]);
     }
-    float* dst = acc_q + (((int64_t)b * a.H + h) * 16 + q) * D + g * 4;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) { atomicAdd(dst + r, dq0[r]); atomicAdd(dst + 16 + r, dq1[r]); }
+    // this workgroup's share of dQ goes to ITS slab (plain stores, no atomics: summed in a fixed order by scatter_sum1_kernel)
+    float* dst = acc_q + ((((int64_t)blockIdx.x * a.B + b) * a.H + h) * 16 + q) * D + g * 8;
+    *reinterpret_cast<f32x4_t*>(dst) = dq0;
+    *reinterpret_cast<f32x4_t*>(dst + 4) = dq1;
   }
+}
+
+// dst[b][l][h][:] = sum over `nslab` slabs of acc[slab][b][h][l][:] for l < L (dQ of the few-query backward)
+__global__ __launch_bounds__(256) void scatter_sum1_kernel(const float* __restrict__ acc, bf16_t* __restrict__ dst, int64_t bs, int64_t rs, int B, int H, int L,
+                                                          int LP, int nslab) {
+  const unsigned idx = blockIdx.x * 256 + threadIdx.x, total = (unsigned)B * H * L * (D / 8);
+  if (idx >= total) return;
+  const unsigned d8 = idx % (D / 8), l = (idx / (D / 8)) % L, h = (idx / ((D / 8) * L)) % H, b = idx / ((D / 8) * L * H);
+  const float* src = acc + ((((int64_t)b * H + h) * LP) + l) * D + d8 * 8;
+  const int64_t slab = (int64_t)B * H * LP * D;
+  f32x4_t s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f};
+  for (int k = 0; k < nslab; ++k) { s0 += *reinterpret_cast<const f32x4_t*>(src + k * slab); s1 += *reinterpret_cast<const f32x4_t*>(src + k * slab + 4); }
+  store8(dst + b * bs + (int64_t)l * rs + h * D, (int)d8, s0, s1);
 }
 
 // =============================================================================================
@@ -645,8 +706,7 @@ __global__ __launch_bounds__(256) void mfma_fwd_long_kernel(const AttnArgs a, in
     if (q < a.Lq) {
       const float inv = 1.f / l;
       o0 *= inv; o1 *= inv;
-      store4(ob + (int64_t)q * a.o_rs + g * 4, o0);
-      store4(ob + (int64_t)q * a.o_rs + 16 + g * 4, o1);
+      store8(ob + (int64_t)q * a.o_rs, g, o0, o1);
       if (a.lse && g == 0) a.lse[((int64_t)b * a.H + h) * a.Lq + q] = m * a.scale + __logf(l);
     }
   }
@@ -667,13 +727,21 @@ __global__ __launch_bounds__(256) void mfma_bwd_dq_long_kernel(const AttnArgs a,
   const int qt_end = min(nqt, (int)(blockIdx.x + 1) * qt_per_block);
   const int g = lane >> 4;
   const int64_t bh = ((int64_t)b * a.H + h) * a.Lq;
+  // operands of the NEXT query tile are fetched while this one computes (see mfma_fwd_kernel)
+  const int qfirst = (blockIdx.x * qt_per_block + wave) * 16 + (lane & 15);
+  bf16x8_t qf_n = load_frag_global(qb, a.q_rs, qfirst, a.Lq, lane), gf_n = load_frag_global(gb, a.o_rs, qfirst, a.Lq, lane);
+  bf16x8_t of_n = load_frag_global(ob, a.o_rs, qfirst, a.Lq, lane);
+  float lse_n = qfirst < a.Lq ? a.lse[bh + qfirst] : 0.f;
   for (int qt = blockIdx.x * qt_per_block + wave; qt < qt_end; qt += 4) {
     const int q = qt * 16 + (lane & 15);
     const bool vq = q < a.Lq;
-    const bf16x8_t qf = load_frag_global(qb, a.q_rs, q, a.Lq, lane);
-    const bf16x8_t gf = load_frag_global(gb, a.o_rs, q, a.Lq, lane);
-    const bf16x8_t of = load_frag_global(ob, a.o_rs, q, a.Lq, lane);
-    const float lse = vq ? a.lse[bh + q] : 0.f;
+    const bf16x8_t qf = qf_n, gf = gf_n, of = of_n;
+    const float lse = lse_n;
+    if (qt + 4 < qt_end) {
+      qf_n = load_frag_global(qb, a.q_rs, q + 64, a.Lq, lane); gf_n = load_frag_global(gb, a.o_rs, q + 64, a.Lq, lane);
+      of_n = load_frag_global(ob, a.o_rs, q + 64, a.Lq, lane);
+      lse_n = q + 64 < a.Lq ? a.lse[bh + q + 64] : 0.f;
+    }
     float dl = 0.f;
 #pragma unroll
     for (int j = 0; j < 8; ++j) dl += (float)gf[j] * (float)of[j];
@@ -699,8 +767,7 @@ __global__ __launch_bounds__(256) void mfma_bwd_dq_long_kernel(const AttnArgs a,
       dq1 = MFMA(frag_t(sK, kb2 * 32, kb2 * 32 + 16, 16, lane), dsf, dq1);
     }
     if (vq) {
-      store4(dqb + (int64_t)q * a.q_rs + g * 4, dq0);
-      store4(dqb + (int64_t)q * a.q_rs + 16 + g * 4, dq1);
+      store8(dqb + (int64_t)q * a.q_rs, g, dq0, dq1);
     }
   }
 }
@@ -794,8 +861,7 @@ __global__ __launch_bounds__(256) void mfma_fwd_stream_kernel(const AttnArgs a, 
     const float lt = group_sum4(l[j]);
     if (q < a.Lq) {
       const float inv = 1.f / lt;
-      store4(ob + (int64_t)q * a.o_rs + g * 4, o0[j] * inv);
-      store4(ob + (int64_t)q * a.o_rs + 16 + g * 4, o1[j] * inv);
+      store8(ob + (int64_t)q * a.o_rs, g, o0[j] * inv, o1[j] * inv);
       if (a.lse && g == 0) a.lse[((int64_t)b * a.H + h) * a.Lq + q] = m[j] * a.scale + __logf(lt);
     }
   }
@@ -867,8 +933,7 @@ __global__ __launch_bounds__(256) void mfma_bwd_dq_stream_kernel(const AttnArgs 
   for (int j = 0; j < STREAM_MAXQ; ++j) {
     const int qt = qt_beg + wave + 4 * j, q = qt * 16 + (lane & 15);
     if (qt >= qt_end || q >= a.Lq) continue;
-    store4(dqb + (int64_t)q * a.q_rs + g * 4, dq0[j]);
-    store4(dqb + (int64_t)q * a.q_rs + 16 + g * 4, dq1[j]);
+    store8(dqb + (int64_t)q * a.q_rs, g, dq0[j], dq1[j]);
   }
 }
 
@@ -940,12 +1005,8 @@ __global__ __launch_bounds__(256) void mfma_bwd_dkv_long_kernel(const AttnArgs a
   for (int i = 0; i < TPW; ++i) {
     const int lt = wave + i * KW, key = (kt0 + lt) * 16 + (lane & 15);
     if (lt >= NKT || key >= a.Lk) continue;
-#pragma unroll
-    for (int dt = 0; dt < 2; ++dt) {
-      const int d = dt * 16 + g * 4;
-      store4(reinterpret_cast<bf16_t*>(a.dk) + b * a.k_bs + (int64_t)key * a.k_rs + h * D + d, dk[i][dt]);
-      store4(reinterpret_cast<bf16_t*>(a.dv) + b * a.v_bs + (int64_t)key * a.v_rs + h * D + d, dv[i][dt]);
-    }
+    store8(reinterpret_cast<bf16_t*>(a.dk) + b * a.k_bs + (int64_t)key * a.k_rs + h * D, g, dk[i][0], dk[i][1]);
+    store8(reinterpret_cast<bf16_t*>(a.dv) + b * a.v_bs + (int64_t)key * a.v_rs + h * D, g, dv[i][0], dv[i][1]);
   }
 }
 
@@ -1037,14 +1098,17 @@ int lmv_attn_mfma_fewq_fwd(const AttnArgs& a, float* part, hipStream_t st) {
   return LMV_OK;
 }
 
-// acc: >= B*H*16*32 floats of scratch for dQ
+size_t lmv_attn_mfma_fewq_bwd_acc_bytes(const AttnArgs& a) {
+  const int nr = (a.Lk + RKB - 1) / RKB, nblk = (nr + 3) / 4;
+  return (size_t)nblk * a.B * a.H * 16 * D * sizeof(float);
+}
+
+// acc: lmv_attn_mfma_fewq_bwd_acc_bytes() of scratch: one fp32 dQ slab [B][H][16][32] per workgroup of the key split
 int lmv_attn_mfma_fewq_bwd(const AttnArgs& a, float* acc, hipStream_t st) {
-  const size_t n = (size_t)a.B * a.H * 16 * D;
-  if (hipMemsetAsync(acc, 0, n * sizeof(float), st) != hipSuccess) LMV_FAIL(LMV_ERR_LAUNCH, "attn_mfma_fewq_bwd: memset failed");
-  const int nr = (a.Lk + RKB - 1) / RKB;
-  hipLaunchKernelGGL(mfma_bwd_fewq_kernel, dim3((nr + 3) / 4, a.H, a.B), dim3(256), 0, st, a, acc);
-  const unsigned tot = (unsigned)a.B * a.H * a.Lq * D;
-  hipLaunchKernelGGL(scatter_bf16_kernel, dim3((tot + 255) / 256), dim3(256), 0, st, (const float*)acc, (bf16_t*)a.dq, a.q_bs, a.q_rs, a.B, a.H, a.Lq, 16);
+  const int nr = (a.Lk + RKB - 1) / RKB, nblk = (nr + 3) / 4;
+  hipLaunchKernelGGL(mfma_bwd_fewq_kernel, dim3(nblk, a.H, a.B), dim3(256), 0, st, a, acc);
+  const unsigned tot = (unsigned)a.B * a.H * a.Lq * (D / 8);
+  hipLaunchKernelGGL(scatter_sum1_kernel, dim3((tot + 255) / 256), dim3(256), 0, st, (const float*)acc, (bf16_t*)a.dq, a.q_bs, a.q_rs, a.B, a.H, a.Lq, 16, nblk);
   LMV_CHECK_LAUNCH("attn_mfma_fewq_bwd");
   return LMV_OK;
 }
@@ -1068,6 +1132,10 @@ size_t lmv_attn_mfma_bwd_acc_bytes(const AttnArgs& a) {
 int lmv_attn_mfma_fwd(const AttnArgs& a, hipStream_t st) {
   const int per = qt_per_block_for(a), nqt = (a.Lq + 15) / 16;
   dim3 grid((nqt + per - 1) / per, a.H, a.B), block(256);
+  static const int pv16 = [] { const char* e = getenv("LMV_ATTN_PV16"); return e ? atoi(e) : 1; }();      // A/B testing
+  if (a.Lk == 196 && pv16) hipLaunchKernelGGL((mfma_fwd_kernel<14, 196, true>), grid, block, 0, st, a, per);      // stage-3 self-attention at 224^2
+  else if (a.Lk == 49 && pv16) hipLaunchKernelGGL((mfma_fwd_kernel<4, 49, true>), grid, block, 0, st, a, per);    // stage 4
+  else
   switch (nkt_for(a.Lk)) {
     case 2: hipLaunchKernelGGL((mfma_fwd_kernel<2>), grid, block, 0, st, a, per); break;
     case 4: hipLaunchKernelGGL((mfma_fwd_kernel<4>), grid, block, 0, st, a, per); break;

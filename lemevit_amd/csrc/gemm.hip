@@ -452,6 +452,189 @@ __global__ __launch_bounds__(CF::NTHR, MINW) void gemm_kernel(const GemmArgs g) 
   }
 }
 
+// ---- "BigK" kernel: long reductions (fc2 forward, dX of qkv / fc1, every weight gradient) ----------------------------------
+// Round-2 probes (tools/native/panel_probe.hip, panel2_probe.hip): with one barrier -> ds_read -> MFMA sequence per k-tile all
+// waves of a workgroup wait out the LDS latency together, and at 64 flop per streamed byte the L2 -> LDS stream paces the loop.
+// Here a workgroup of 8 waves owns a 128 x (NSB * 128) output tile (accumulators: 64 x NSB * 32 per wave), a k-step streams ONE
+// A slot and NSB B slots of 16 KB (96 flop per streamed byte at NSB = 3), two k-steps live in LDS, and the MFMA fragments are
+// double-buffered in registers per HALF k-step: while the 4 * NSB * 2 MFMAs of one half issue, the fragments of the next half
+// (or of the next k-step's first half) stream in behind them.  One raw s_barrier per k-step; the LDS-DMA of k-step s + 2 is
+// issued in the middle of k-step s and has a whole k-step to land.  Slot images / swizzles are the ones of gemm_kernel
+// (panel_dma / frag_bf16), so the same three contractions are covered: normal x normal, normal x TR (dX), TR x TR (dW).
+template <bool ATR, bool BTR, bool SPLITK, int NSB>
+__global__ __launch_bounds__(512, 2) void bigk_kernel(const GemmArgs g) {
+  constexpr int BK = 64, SLOTB = PANEL * BK * 2, STEP = (1 + NSB) * SLOTB, BN = NSB * 128, NB = NSB * 2;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];     // [2 k-steps][A slot | NSB B slots]; reused by the epilogue
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 2, wn = wave & 3;
+  // XCD-contiguous logical order (hardware places block b on XCD b % 8): the tiles of one m-tile row -- and, for dW, the tiles of one
+  // k-split, which all read the same token rows -- share an L2.  Speed only; any placement is correct.
+  int bid, split = 0;
+  {
+    const int T_ = gridDim.x, xcd = blockIdx.x & 7, q = T_ >> 3, r = T_ & 7;
+    const int L = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (int)(blockIdx.x >> 3);
+    if constexpr (SPLITK) { split = L / g.ntiles; bid = L - split * g.ntiles; } else { bid = L; }
+  }
+  const int pi = (g.nprob > 1 && !g.concat && bid >= g.p[1].tile_begin) ? 1 : 0;
+  const Problem& P = g.p[pi];
+  bid -= P.tile_begin;
+  const int tm = bid / g.tiles_n, tn = bid % g.tiles_n;
+  const int m0 = tm * 128, n0 = tn * BN;
+  const int M = P.M, N = g.N;
+  const int kt0 = P.Kred / BK;
+  const int kt_total = kt0 + ((SPLITK && g.concat) ? g.p[1].Kred / BK : 0);
+  const int kt_beg = split * g.kt_per_split;
+  const int kt_end = min(kt_total, kt_beg + g.kt_per_split);
+  if (kt_beg >= kt_end) return;
+  auto issue = [&](unsigned char* buf, int kt) {
+    const Problem& Q = (SPLITK && kt >= kt0) ? g.p[1] : P;
+    const bf16_t* A16 = reinterpret_cast<const bf16_t*>(Q.a);
+    const bf16_t* B16 = reinterpret_cast<const bf16_t*>(Q.b);
+    const int k0 = ((SPLITK && kt >= kt0) ? kt - kt0 : kt) * BK;
+    panel_dma<ATR, BK, 8>(buf, A16, g.lda, M, m0, k0, lane, wave);
+#pragma unroll
+    for (int j = 0; j < NSB; ++j) panel_dma<BTR, BK, 8>(buf + (1 + j) * SLOTB, B16, g.ldb, N, n0 + j * 128, k0, lane, wave);
+  };
+  bf16x8_t fa0[4], fb0[NB], fa1[4], fb1[NB];        // fragments of the half k-step (hh = 0 / 1) in flight
+  auto read_half = [&](bf16x8_t (&fa)[4], bf16x8_t (&fb)[NB], const unsigned char* buf, int hh) {
+#pragma unroll
+    for (int j = 0; j < NSB; ++j)
+#pragma unroll
+      for (int t = 0; t < 2; ++t) fb[j * 2 + t] = frag_bf16<BTR, BK>(buf + (1 + j) * SLOTB, wn * 32 + t * 16, lane, hh);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) fa[t] = frag_bf16<ATR, BK>(buf, wm * 64 + t * 16, lane, hh);
+  };
+  f32x4_t acc[4][NB], accb = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < NB; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  const bool do_bsum = SPLITK && (P.bias_grad != nullptr) && tn == 0;      // workgroup-uniform; wave wn sums A tile wn of its half
+  auto mma_half = [&](const bf16x8_t (&fa)[4], const bf16x8_t (&fb)[NB]) {
+#pragma unroll
+    for (int ti = 0; ti < 4; ++ti)
+#pragma unroll
+      for (int tj = 0; tj < NB; ++tj) acc[ti][tj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[tj], fa[ti], acc[ti][tj], 0, 0, 0);
+    if constexpr (SPLITK) {
+      if (do_bsum) {          // column sums of the A tile = A^T * ones, on the matrix pipe
+        typedef __attribute__((ext_vector_type(8))) unsigned short u16x8_t;
+        const u16x8_t o16 = {0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80};
+        const bf16x8_t sel = wn == 0 ? fa[0] : (wn == 1 ? fa[1] : (wn == 2 ? fa[2] : fa[3]));
+        accb = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, o16), sel, accb, 0, 0, 0);
+      }
+    }
+  };
+
+  issue(smem, kt_beg);
+  if (kt_beg + 1 < kt_end) {
+    issue(smem + STEP, kt_beg + 1);
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (1 + NSB)) : "memory");       // the first k-step has landed (this wave's pieces) ...
+  } else {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  __builtin_amdgcn_s_barrier();                                                 // ... and everybody else's
+  asm volatile("" ::: "memory");
+  int cur = 0;
+  read_half(fa0, fb0, smem, 0);
+  for (int kt = kt_beg; kt < kt_end; ++kt) {
+    unsigned char* buf = smem + cur * STEP;
+    read_half(fa1, fb1, buf, 1);
+    mma_half(fa0, fb0);
+    // every fragment of this k-step is in registers; the next k-step has landed for this wave -- and, past the barrier, for all
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    if (kt + 2 < kt_end) issue(buf, kt + 2);                                    // into the buffer just vacated
+    cur ^= 1;
+    if (kt + 1 < kt_end) read_half(fa0, fb0, smem + cur * STEP, 0);
+    mma_half(fa1, fb1);
+  }
+
+  if constexpr (SPLITK) {
+    // partial tile -> this split's slab (plain stores; summed by splitk_reduce_kernel)
+    float* slab = g.ws + (int64_t)(g.slab_base[pi] + split) * g.slab_stride;
+#pragma unroll
+    for (int ti = 0; ti < 4; ++ti) {
+      const int m = m0 + wm * 64 + ti * 16 + (lane & 15);
+      if (m >= M) continue;
+#pragma unroll
+      for (int tj = 0; tj < NB; ++tj) {
+        const int n = n0 + (tj >> 1) * 128 + wn * 32 + (tj & 1) * 16 + (lane >> 4) * 4;
+        if (n >= N) continue;
+        *reinterpret_cast<float4*>(slab + (int64_t)m * g.ldc + n) = make_float4(acc[ti][tj][0], acc[ti][tj][1], acc[ti][tj][2], acc[ti][tj][3]);
+      }
+    }
+    if (do_bsum && lane < 16) {
+      const int m = m0 + wm * 64 + wn * 16 + lane;
+      if (m < M) slab[(int64_t)M * g.ldc + m] = accb[0];
+    }
+  } else {
+    // coalesced epilogue: every wave transposes its 64 x 32 strips through a private LDS region (the ring is dead): fp32 in,
+    // whole 16-byte bf16 row pieces out, with bias / GELU / GELU' x aux / DropPath scale / residual fused as in store_tile
+    __syncthreads();
+    constexpr int REGION = 2 * STEP / 8;
+    static_assert(REGION >= 64 * 32 * 4, "per-wave epilogue region too small");
+    float* sT = reinterpret_cast<float*>(smem + wave * REGION);
+    bf16_t* outp = reinterpret_cast<bf16_t*>(P.out);
+    bf16_t* prep = reinterpret_cast<bf16_t*>(P.out_pre);
+    const int act = g.act & 0xff;
+#pragma unroll
+    for (int j = 0; j < NSB; ++j) {
+      const int nw0 = n0 + j * 128 + wn * 32;
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int tj = 0; tj < 2; ++tj) {
+        const int n = nw0 + tj * 16 + (lane >> 4) * 4;
+        float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (P.bias && n < N) b4 = *reinterpret_cast<const float4*>(P.bias + n);
+#pragma unroll
+        for (int ti = 0; ti < 4; ++ti) {
+          const f32x4_t a = acc[ti][j * 2 + tj];
+          const int r = ti * 16 + (lane & 15), c4 = tj * 4 + (lane >> 4);
+          *reinterpret_cast<float4*>(sT + r * 32 + ((c4 ^ (r & 7)) << 2)) = make_float4(a[0] + b4.x, a[1] + b4.y, a[2] + b4.z, a[3] + b4.w);
+        }
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int c = lane + i * 64, r = c >> 2, oc = c & 3;
+        const int m = m0 + wm * 64 + r, n = nw0 + oc * 8;
+        if (m >= M || n >= N) continue;
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+          const float4 t = *reinterpret_cast<const float4*>(sT + r * 32 + (((oc * 2 + e) ^ (r & 7)) << 2));
+          v[e * 4] = t.x; v[e * 4 + 1] = t.y; v[e * 4 + 2] = t.z; v[e * 4 + 3] = t.w;
+        }
+        const int64_t o = (int64_t)m * g.ldc + n;
+        if (prep) *reinterpret_cast<uint4*>(prep + o) = f_to_chunk<bf16_t>(v);
+        if (act == LMV_ACT_GELU) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] = act_gelu<bf16_t>(v[e]);
+        } else if (act == LMV_ACT_GELU_GRAD) {
+          float u[8];
+          chunk_to_f<bf16_t>(*reinterpret_cast<const uint4*>(reinterpret_cast<const bf16_t*>(P.aux) + o), u);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] *= act_gelu_grad<bf16_t>(u[e]);
+        }
+        if (P.row_scale) {
+          const float rs = P.row_scale[m / P.rps];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] *= rs;
+        }
+        if (P.res) {
+          float r8[8];
+          chunk_to_f<bf16_t>(*reinterpret_cast<const uint4*>(reinterpret_cast<const bf16_t*>(P.res) + o), r8);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] += r8[e];
+        }
+        *reinterpret_cast<uint4*>(outp + o) = f_to_chunk<bf16_t>(v);
+      }
+    }
+  }
+}
+
 // out[i] += sum_s ws[s][i]  (i < nw: dW; nw <= i < nw + nb: db)
 // A block covers 256 / SL float4 elements x SL slab lanes: lane l sums slabs l, l + SL, ... in order, lane 0 then adds
 // the SL lane sums in order (fixed summation tree: run-to-run reproducible).  SL > 1 keeps small dW matrices with
@@ -489,7 +672,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
 enum Mode { MODE_FWD = 0, MODE_DX = 1, MODE_DW = 2 };
 enum Tile { TILE_128 = 0, TILE_256x128 = 1, TILE_256 = 2, TILE_128W8 = 3 };
 
-struct Plan { GemmArgs g; int total, splits, bk, tile, dma, nsplit[2]; size_t ws_bytes; };
+struct Plan { GemmArgs g; int total, splits, bk, tile, dma, nsplit[2]; size_t ws_bytes; int bigk; /* 0, or B slots (2 / 3) of the BigK tile */ };
 
 int make_plan(const lmv_linear_problem* p, int nproblems, int N, int K, int act, int dtype, Mode mode, Plan* pl) {
   if (nproblems < 1 || nproblems > 2) LMV_FAIL(LMV_ERR_SHAPE, "linear: nproblems must be 1 or 2 (got %d)", nproblems);
@@ -624,6 +807,71 @@ int make_plan(const lmv_linear_problem* p, int nproblems, int N, int K, int act,
   }
   g.cumap = [] { const char* e = getenv("LMV_GEMM_CUMAP"); return e ? atoi(e) : 1; }();      // A/B testing
   pl->total = total; pl->splits = splits; pl->bk = bk; pl->tile = tile; pl->dma = dma;
+  pl->bigk = 0;
+  // BigK tile (128 x 256 / 384, 8 waves, register-pipelined k-loop): long bf16 reductions whose output is at least 256 columns wide
+  // -- fc2 forward, dX of qkv / fc1, and the weight gradients -- on reductions that are whole 64-deep k-steps.
+  static const int bigk_mode = [] { const char* e = getenv("LMV_GEMM_BIGK"); return e ? atoi(e) : 1; }();     // A/B testing: 0 = off
+  const int bigk_min_k = (mode == MODE_DW) ? 1024 : 768;
+  if (bigk_mode && bf && !no_dma && all64 && min_kred >= bigk_min_k && out_cols >= 256 && force_tile == 0 && force_bk == 0) {
+    // tile width: 384 when it tiles the output without more padding than 256 does
+    const int pad3 = (out_cols + 383) / 384 * 384 - out_cols, pad2 = (out_cols + 255) / 256 * 256 - out_cols;
+    const int nsb = (pad3 * 2 <= pad2 * 3 || out_cols <= 384) && out_cols > 256 ? 3 : 2;
+    const int bn2 = nsb * 128;
+    g.tiles_n = (out_cols + bn2 - 1) / bn2;
+    int tot = 0;
+    for (int i = 0; i < nproblems; ++i) {
+      Problem& P = g.p[i];
+      P.tiles_m = (P.M + 127) / 128;
+      P.tile_begin = (g.concat && i == 1) ? 0 : tot;
+      if (!(g.concat && i == 1)) tot += P.tiles_m * g.tiles_n;
+    }
+    int kt_max = 1, kt_sum = 0;
+    for (int i = 0; i < nproblems; ++i) { const int kt = g.p[i].Kred / 64; if (kt > kt_max) kt_max = kt; kt_sum += kt; }
+    if (g.concat) kt_max = kt_sum;
+    g.ntiles = tot; g.nsplits = 1; g.kt_per_split = kt_max;
+    pl->ws_bytes = 0; pl->nsplit[0] = pl->nsplit[1] = 1;
+    int nslabs_launch = 1;
+    if (mode == MODE_DW) {
+      // one workgroup per CU (128 KB of LDS): split the token reduction so that ONE generation of workgroups covers the chip, with
+      // at least 8 k-steps per split
+      const int target = [] { const char* e = getenv("LMV_DW_TARGET_BLOCKS"); return e ? atoi(e) : 256; }();
+      int sp = target / tot;
+      const int sp_max = kt_max / 8 > 0 ? kt_max / 8 : 1;
+      if (sp > sp_max) sp = sp_max;
+      if (sp < 1) sp = 1;
+      g.kt_per_split = (kt_max + sp - 1) / sp;
+      nslabs_launch = (kt_max + g.kt_per_split - 1) / g.kt_per_split;      // every launched split is non-empty
+      g.nsplits = nslabs_launch;
+      int slabs = 0;
+      for (int i = 0; i < nproblems; ++i) {
+        if (g.concat && i == 1) { pl->nsplit[1] = 0; g.slab_base[1] = 0; break; }
+        const int kt = g.concat ? kt_max : g.p[i].Kred / 64;
+        pl->nsplit[i] = (kt + g.kt_per_split - 1) / g.kt_per_split;
+        g.slab_base[i] = slabs;
+        slabs += pl->nsplit[i];
+      }
+      g.slab_stride = (int64_t)N * K + N;
+      pl->ws_bytes = (size_t)slabs * g.slab_stride * sizeof(float);
+    }
+    pl->total = tot; pl->splits = nslabs_launch; pl->bk = 64; pl->dma = 1; pl->bigk = nsb;
+  }
+  return LMV_OK;
+}
+
+template <bool ATR, bool BTR, bool SPLITK, int NSB>
+int launch_bigk(const GemmArgs& g, dim3 grid, hipStream_t st) {
+  constexpr int lds = 2 * (1 + NSB) * PANEL * 64 * 2;
+  auto kern = bigk_kernel<ATR, BTR, SPLITK, NSB>;
+  static std::atomic<unsigned long long> attr_done{0};      // > 64 KiB of dynamic LDS: opt in once per kernel and device (idempotent)
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  const unsigned long long bit = 1ull << (dev & 63);
+  if (!(attr_done.load(std::memory_order_acquire) & bit)) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
+      LMV_FAIL(LMV_ERR_LAUNCH, "linear: cannot reserve %d bytes of LDS", lds);
+    attr_done.fetch_or(bit, std::memory_order_release);
+  }
+  hipLaunchKernelGGL(kern, grid, dim3(512), lds, st, g);
   return LMV_OK;
 }
 
@@ -677,12 +925,20 @@ int launch(const lmv_linear_problem* p, int nproblems, int N, int K, int act, in
   }
   const bool bf = dtype == LMV_BF16;
   dim3 grid(pl.total);
-  if (mode == MODE_DW) grid.x = g.nsplits >= 8 ? pl.total * g.nsplits : 8 * ((pl.total + 8 / g.nsplits - 1) / (8 / g.nsplits));
   hipStream_t st = (hipStream_t)stream;
   int rc;
-  if (mode == MODE_FWD) rc = launch_mode<false, false, false>(pl, grid, bf, st);
-  else if (mode == MODE_DX) rc = launch_mode<false, true, false>(pl, grid, bf, st);
-  else rc = launch_mode<true, true, true>(pl, grid, bf, st);
+  if (pl.bigk) {
+    if (mode == MODE_DW) grid.x = pl.total * g.nsplits;
+    const bool w3 = pl.bigk == 3;
+    if (mode == MODE_FWD) rc = w3 ? launch_bigk<false, false, false, 3>(g, grid, st) : launch_bigk<false, false, false, 2>(g, grid, st);
+    else if (mode == MODE_DX) rc = w3 ? launch_bigk<false, true, false, 3>(g, grid, st) : launch_bigk<false, true, false, 2>(g, grid, st);
+    else rc = w3 ? launch_bigk<true, true, true, 3>(g, grid, st) : launch_bigk<true, true, true, 2>(g, grid, st);
+  } else {
+    if (mode == MODE_DW) grid.x = g.nsplits >= 8 ? pl.total * g.nsplits : 8 * ((pl.total + 8 / g.nsplits - 1) / (8 / g.nsplits));
+    if (mode == MODE_FWD) rc = launch_mode<false, false, false>(pl, grid, bf, st);
+    else if (mode == MODE_DX) rc = launch_mode<false, true, false>(pl, grid, bf, st);
+    else rc = launch_mode<true, true, true>(pl, grid, bf, st);
+  }
   if (rc) return rc;
   LMV_CHECK_LAUNCH("linear");
   if (mode == MODE_DW) {

@@ -497,8 +497,15 @@ def test_flat_adamw_survives_model_zero_grad():
         o.step()
     w1, w2 = m1.stages[3][0].mlp[0].weight, m2.stages[3][0].mlp[0].weight
     assert float((w1 - w0).abs().max()) > 1e-4, "the reference twin did not train"
-    assert torch.allclose(w1, w2, atol=1e-6), float((w1 - w2).abs().max())
-    assert w2.grad is not None and w2.grad.data_ptr() == o2._grad_views[[p is w2 for _, p, _, _ in o2._slices].index(True)].data_ptr()
+    assert float((w2 - w0).abs().max()) > 1e-4, "FlatAdamW stepped on zeros after model.zero_grad()"
+    # the flat gradient buffers still hold this step's gradients: the stray autograd gradients were copied in before the update
+    i = [p is w2 for _, p, _, _ in o2._slices].index(True)
+    _, _, off, n = o2._slices[i]
+    g1, g2 = o1._flat_g[off:off + n], o2._flat_g[off:off + n]
+    assert float(g1.abs().max()) > 0 and torch.allclose(g1, g2, rtol=1e-4, atol=1e-6 * float(g1.abs().max())), float((g1 - g2).abs().max())
+    # (weights: an Adam step moves every entry by ~lr whatever the gradient's size, so entries whose gradient is rounding noise may differ by 2 lr)
+    assert float((w1 - w2).abs().max()) <= 2.5e-3 and float((w1 - w2).abs().mean()) <= 1e-5
+    assert w2.grad is o2._grad_views[i]
 
 
 @pytest.mark.parametrize("compress", [None, "bf16"])

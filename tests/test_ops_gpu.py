@@ -124,6 +124,67 @@ def test_linear_dw(dtype, rows, N, K):
     assert_close(db, ref_b, torch.float32, "db", tol32=3e-6 * math.sqrt(rows) if dtype == torch.float32 else 2e-5)
 
 
+# ---- the BigK tile (128 x 256 / 384, register-pipelined k-loop): long bf16 reductions, whole 64-deep k-steps ----------------
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("rows,rows_c,N,K", [(6400, 128, 1536, 384), (4096, 64, 384, 1536), (4160, 128, 512, 2048), (2048, 0, 1152, 384),
+                                             (1024, 2048, 2048, 512), (12800, 0, 768, 192), (1088, 64, 384, 384)])
+def test_linear_dw_bigk(dtype, rows, rows_c, N, K):
+    """Weight gradients whose token counts are whole k-steps (every LeMeViT layer at B % 4 == 0): x rows and meta-token rows accumulate
+    into the same dW / db as ONE concatenated reduction; also accumulation on top of an existing gradient."""
+    o = ops()
+    dy, dy64 = rnd((rows, N), "dy", dtype); x, x64 = rnd((rows, K), "x", dtype)
+    dw0 = det_tensor((N, K), "dw0", 7).to(dev()); db0 = det_tensor((N,), "db0", 7).to(dev())
+    dw, db = dw0.clone(), db0.clone()
+    probs = [o.Prob(dy, x, dw, bias_grad=db)]
+    ref_w = dy64.t() @ x64; ref_b = dy64.sum(0)
+    if rows_c:
+        dyc, dyc64 = rnd((rows_c, N), "dyc", dtype); xc, xc64 = rnd((rows_c, K), "xc", dtype)
+        probs.append(o.Prob(dyc, xc, dw, bias_grad=db))
+        ref_w = ref_w + dyc64.t() @ xc64; ref_b = ref_b + dyc64.sum(0)
+    o.linear_dw(probs, N, K)
+    tol = 3e-6 * math.sqrt(rows) if dtype == torch.float32 else 2e-5
+    assert_close(dw - dw0, ref_w, torch.float32, "dw", tol32=tol)
+    assert_close(db - db0, ref_b, torch.float32, "db", tol32=tol)
+    # two problems with DIFFERENT outputs (the qkv1 / qkv2 launch of a D block)
+    if rows_c:
+        dw1 = torch.zeros((N, K), device=dev()); db1 = torch.zeros((N,), device=dev()); dw2 = torch.zeros_like(dw1); db2 = torch.zeros_like(db1)
+        o.linear_dw([o.Prob(dy, x, dw1, bias_grad=db1), o.Prob(dyc, xc, dw2, bias_grad=db2)], N, K)
+        assert_close(dw1, dy64.t() @ x64, torch.float32, "dw1", tol32=tol); assert_close(db1, dy64.sum(0), torch.float32, "db1", tol32=tol)
+        assert_close(dw2, dyc64.t() @ xc64, torch.float32, "dw2", tol32=tol); assert_close(db2, dyc64.sum(0), torch.float32, "db2", tol32=tol)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("rows,rows_c,N,K", [(3000, 48, 384, 1536), (1000, 16, 512, 2048), (777, 0, 256, 768), (129, 0, 1000, 1024)])
+def test_linear_fwd_dx_bigk(dtype, rows, rows_c, N, K):
+    """Forward and dX on long reductions (fc2 forward: K = 4C; dX of qkv / fc1: reduction over 3C / 4C), dual problems, ragged rows /
+    columns, every epilogue."""
+    o = ops()
+    a, a64 = rnd((rows, K), "a", dtype); w, w64 = rnd((N, K), "w", dtype, 1 / math.sqrt(K))
+    bias = det_tensor((N,), "b", 7, 0.5).to(dev()); res, res64 = rnd((rows, N), "res", dtype)
+    rps = 7
+    rs = (det_tensor(((rows + rps - 1) // rps,), "rs", 7).abs() + 0.5).to(dev())
+    out = torch.empty((rows, N), device=dev(), dtype=dtype); pre = torch.empty_like(out)
+    probs = [o.Prob(a, w, out, bias=bias, res=res, row_scale=rs, out_pre=pre, rps=rps)]
+    if rows_c:
+        ac, ac64 = rnd((rows_c, K), "ac", dtype); oc = torch.empty((rows_c, N), device=dev(), dtype=dtype); prec = torch.empty_like(oc)
+        probs.append(o.Prob(ac, w, oc, bias=bias, out_pre=prec))
+    o.linear_fwd(probs, N, K, o.ACT_GELU)
+    u = a64 @ w64.t() + bias.cpu().double()
+    assert_close(pre, u, dtype, "pre")
+    assert_close(out, res64 + rs.cpu().double()[torch.arange(rows) // rps][:, None] * gelu64(u), dtype, "epilogue")
+    if rows_c:
+        uc = ac64 @ w64.t() + bias.cpu().double()
+        assert_close(prec, uc, dtype, "pre c"); assert_close(oc, gelu64(uc), dtype, "gelu c")
+    # dX with the roles of N and K swapped: dy [rows, K'] x W [K', N'] with K' = K (the long reduction), N' = N
+    dy, dy64 = rnd((rows, K), "dy", dtype); wt, wt64 = rnd((K, N), "wt", dtype, 1 / math.sqrt(K))
+    uu, uu64 = rnd((rows, N), "u", dtype, 2.0)
+    dx = torch.empty((rows, N), device=dev(), dtype=dtype)
+    o.linear_dx([o.Prob(dy, wt, dx)], K, N)
+    assert_close(dx, dy64 @ wt64, dtype, "dx")
+    o.linear_dx([o.Prob(dy, wt, dx, aux=uu, res=res)], K, N, o.ACT_GELU_GRAD)
+    assert_close(dx, res64 + (dy64 @ wt64) * gelu_grad64(uu64), dtype, "dx*gelu'+res")
+
+
 # ------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("rows,C", [(1000, 64), (3137, 96), (800, 192), (212, 320), (333, 384), (65, 512), (48, 1280), (16, 2048), (5, 128)])

@@ -73,6 +73,15 @@ __device__ __forceinline__ float4 lds_read16(const float* p) {
   return v;
 }
 
+template <int NS> __device__ __forceinline__ void wait_slot_st() {      // wait_slot + 8 younger stores allowed
+  if constexpr (NS == 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  else if constexpr (NS == 3) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+  else if constexpr (NS == 4) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+  else if constexpr (NS == 5) asm volatile("s_waitcnt vmcnt(14)" ::: "memory");
+  else if constexpr (NS == 6) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+  else asm volatile("s_waitcnt vmcnt(20)" ::: "memory");
+}
+
 __device__ __forceinline__ void store_tile(const f32x4_t (&acc)[2][4], const PArgs& g, const float* sBias, int r0, int R, int nt, int wm, int wn, int lane) {
   const bool full = (wm * 32 + 32 <= R) && (nt * 128 + 128 <= g.N);      // wave-uniform: no per-store exec masks on the common path
 #pragma unroll
@@ -92,7 +101,7 @@ __device__ __forceinline__ void store_tile(const f32x4_t (&acc)[2][4], const PAr
 }
 
 // ---- variant L: A panel in LDS ---------------------------------------------------------------------------------------
-template <int K, int NS>
+template <int K, int NS, int ABL = 0>
 __global__ __launch_bounds__(512, 2) void panel_fwd_lds(const PArgs g) {
   constexpr int KS = K / 64, ROWB = K * 2, A_BYTES = 128 * ROWB;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -126,10 +135,16 @@ __global__ __launch_bounds__(512, 2) void panel_fwd_lds(const PArgs g) {
       for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
-      wait_slot<NS>();
+      if constexpr ((ABL & 8) != 0) {
+        // stores of the previous tile's epilogue (8 per wave) sit in the same in-order counter BEHIND the ring's older loads:
+        // allow them to stay in flight for the first NS - 1 slots after an epilogue
+        if (ks < NS - 1 && nt > 0) wait_slot_st<NS>(); else wait_slot<NS>();
+      } else {
+        wait_slot<NS>();
+      }
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
-      issue_slot(sB + nxt_ph * SLOT, g.W, g.N, K, nxt_nt, nxt_ks, lane, wave);
+      if constexpr ((ABL & 2) == 0) issue_slot(sB + nxt_ph * SLOT, g.W, g.N, K, nxt_nt, nxt_ks, lane, wave);
       nxt_ph = (nxt_ph + 1 == NS) ? 0 : nxt_ph + 1;
       if (++nxt_ks == KS) { nxt_ks = 0; nxt_nt = (nxt_nt + 1 == NT) ? 0 : nxt_nt + 1; }
       const unsigned char* sb = sB + cur_ph * SLOT;
@@ -147,16 +162,20 @@ __global__ __launch_bounds__(512, 2) void panel_fwd_lds(const PArgs g) {
 #pragma unroll
         for (int ti = 0; ti < 2; ++ti)
 #pragma unroll
-          for (int tj = 0; tj < 4; ++tj) acc[ti][tj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[tj], af[ti], acc[ti][tj], 0, 0, 0);
+          for (int tj = 0; tj < 4; ++tj) {
+            if constexpr ((ABL & 4) == 0) acc[ti][tj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[tj], af[ti], acc[ti][tj], 0, 0, 0);
+            else { asm volatile("" :: "v"(bfr[tj]), "v"(af[ti])); }
+          }
       }
     }
-    store_tile(acc, g, sBias, r0, R, nt, wm, wn, lane);
+    if constexpr ((ABL & 1) == 0) store_tile(acc, g, sBias, r0, R, nt, wm, wn, lane);
+    else if (g.M < 0) store_tile(acc, g, sBias, r0, R, nt, wm, wn, lane);
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
 // ---- variant R: A panel in registers (MFMA fragments), LDS holds only the W ring --------------------------------------------
-template <int K, int NS>
+template <int K, int NS, int ABL = 0>
 __global__ __launch_bounds__(512, 2) void panel_fwd_reg(const PArgs g) {
   constexpr int KS = K / 64;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -194,10 +213,16 @@ __global__ __launch_bounds__(512, 2) void panel_fwd_reg(const PArgs g) {
       for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
-      wait_slot<NS>();
+      if constexpr ((ABL & 8) != 0) {
+        // stores of the previous tile's epilogue (8 per wave) sit in the same in-order counter BEHIND the ring's older loads:
+        // allow them to stay in flight for the first NS - 1 slots after an epilogue
+        if (ks < NS - 1 && nt > 0) wait_slot_st<NS>(); else wait_slot<NS>();
+      } else {
+        wait_slot<NS>();
+      }
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
-      issue_slot(sB + nxt_ph * SLOT, g.W, g.N, K, nxt_nt, nxt_ks, lane, wave);
+      if constexpr ((ABL & 2) == 0) issue_slot(sB + nxt_ph * SLOT, g.W, g.N, K, nxt_nt, nxt_ks, lane, wave);
       nxt_ph = (nxt_ph + 1 == NS) ? 0 : nxt_ph + 1;
       if (++nxt_ks == KS) { nxt_ks = 0; nxt_nt = (nxt_nt + 1 == NT) ? 0 : nxt_nt + 1; }
       const unsigned char* sb = sB + cur_ph * SLOT;
@@ -210,12 +235,95 @@ __global__ __launch_bounds__(512, 2) void panel_fwd_reg(const PArgs g) {
 #pragma unroll
         for (int ti = 0; ti < 2; ++ti)
 #pragma unroll
-          for (int tj = 0; tj < 4; ++tj) acc[ti][tj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[tj], af[ti][ks * 2 + hh], acc[ti][tj], 0, 0, 0);
+          for (int tj = 0; tj < 4; ++tj) {
+            if constexpr ((ABL & 4) == 0) acc[ti][tj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[tj], af[ti][ks * 2 + hh], acc[ti][tj], 0, 0, 0);
+            else { asm volatile("" :: "v"(bfr[tj]), "v"(af[ti][ks * 2 + hh])); }
+          }
       }
     }
-    store_tile(acc, g, sBias, r0, R, nt, wm, wn, lane);
+    if constexpr ((ABL & 1) == 0) store_tile(acc, g, sBias, r0, R, nt, wm, wn, lane);
+    else if (g.M < 0) store_tile(acc, g, sBias, r0, R, nt, wm, wn, lane);
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+
+// ---- family II: C-stationary (long reduction, narrow output: fc2 forward, dX of qkv / fc1) ------------------------------------
+// The workgroup owns 128 rows x ALL N <= NSW * 128 output columns (accumulators: 32 x NSW * 64 per wave); a k-step streams one A
+// slot [128 rows][64 k] and NSW W slots [128 n][64 k] (96 flop per streamed byte at N = 384), RD k-steps in the ring, one barrier
+// per k-step (48 MFMAs per wave at NSW = 3).
+template <int NSW, int RD>
+__global__ __launch_bounds__(512, 2) void panel_fwd_cstat(const PArgs g) {
+  constexpr int STEP = (1 + NSW) * SLOT;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  float* sBias = reinterpret_cast<float*>(smem + RD * STEP);
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  int r0, R;
+  row_range(g.M, &r0, &R);
+  if (R <= 0) return;
+  for (int i = tid; i < g.N; i += 512) sBias[i] = g.bias[i];
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  const int K = g.K, KS = K >> 6;
+  auto issue_step = [&](int ph, int ks) {
+    unsigned char* dst = smem + ph * STEP;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {          // A slot: rows of this panel (clamped), same image as a W slot
+      const int sg = wave + i * 8, r = sg * 8 + (lane >> 3), p = lane & 7, kc = p ^ ((r >> 1) & 7);
+      const bf16_t* src = g.A + (int64_t)(r0 + min(r, R - 1)) * K + ks * 64 + kc * 8;
+      __builtin_amdgcn_global_load_lds((glb_vp)src, (lds_vp)(dst + sg * 1024), 16, 0, 0);
+    }
+#pragma unroll
+    for (int j = 0; j < NSW; ++j) issue_slot(dst + (1 + j) * SLOT, g.W, g.N, K, j, ks, lane, wave);
+  };
+  f32x4_t acc[2][NSW * 4];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < NSW * 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int s = 0; s < RD - 1; ++s) issue_step(s, s % KS);
+  int nxt = (RD - 1) % KS;
+  for (int ks0 = 0; ks0 < KS; ks0 += RD) {
+#pragma unroll
+    for (int u = 0; u < RD; ++u) {
+      if (ks0 + u < KS) {
+        if constexpr (RD == 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"((RD - 2) * 2 * (1 + NSW)) : "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        issue_step((u + RD - 1) % RD, nxt);
+        nxt = (nxt + 1 == KS) ? 0 : nxt + 1;
+        const unsigned char* sa = smem + u * STEP;
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh) {
+          bf16x8_t af[2];
+#pragma unroll
+          for (int ti = 0; ti < 2; ++ti) af[ti] = bfrag(sa, wm * 32 + ti * 16 + (lane & 15), hh * 4 + (lane >> 4));
+#pragma unroll
+          for (int j = 0; j < NSW; ++j) {
+            bf16x8_t bfr[4];
+#pragma unroll
+            for (int tj = 0; tj < 4; ++tj) bfr[tj] = bfrag(sa + (1 + j) * SLOT, wn * 64 + tj * 16 + (lane & 15), hh * 4 + (lane >> 4));
+#pragma unroll
+            for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+              for (int tj = 0; tj < 4; ++tj) acc[ti][j * 4 + tj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[tj], af[ti], acc[ti][j * 4 + tj], 0, 0, 0);
+          }
+        }
+      }
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+  for (int j = 0; j < NSW; ++j) {
+    f32x4_t t[2][4];
+#pragma unroll
+    for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+      for (int tj = 0; tj < 4; ++tj) t[ti][tj] = acc[ti][j * 4 + tj];
+    store_tile(t, g, sBias, r0, R, j, wm, wn, lane);
+  }
 }
 
 // ---- host ---------------------------------------------------------------------------------------------------------------
@@ -260,23 +368,36 @@ static void bench(const char* name, Ctx& c, int grid, int lds, F launch) {
   fflush(stdout);
 }
 
-template <int K, int NS>
+template <int K, int NS, int ABL = 0>
 static void run_lds(Ctx& c, int grid) {
   const int lds = 128 * K * 2 + NS * SLOT + ((c.N + 3) / 4 * 4) * 4;
   if (lds > 163840) { printf("panel_fwd_lds<%d,%d>: %d bytes of LDS do not fit\n", K, NS, lds); return; }
-  auto kern = panel_fwd_lds<K, NS>;
+  auto kern = panel_fwd_lds<K, NS, ABL>;
   CK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
   PArgs g{c.dA, c.dW, c.db, c.dC, c.M, c.N, c.K};
-  char nm[64]; snprintf(nm, sizeof nm, "L  A-in-LDS  K=%d ring=%d", K, NS);
+  char nm[64]; snprintf(nm, sizeof nm, "L  A-in-LDS  K=%d ring=%d abl=%d", K, NS, ABL);
   bench(nm, c, grid, lds, [&] { hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, 0, g); });
 }
-template <int K, int NS>
+template <int K, int NS, int ABL = 0>
 static void run_reg(Ctx& c, int grid) {
   const int lds = NS * SLOT + ((c.N + 3) / 4 * 4) * 4;
-  auto kern = panel_fwd_reg<K, NS>;
+  auto kern = panel_fwd_reg<K, NS, ABL>;
   CK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
   PArgs g{c.dA, c.dW, c.db, c.dC, c.M, c.N, c.K};
-  char nm[64]; snprintf(nm, sizeof nm, "R  A-in-regs K=%d ring=%d", K, NS);
+  char nm[64]; snprintf(nm, sizeof nm, "R  A-in-regs K=%d ring=%d abl=%d", K, NS, ABL);
+  bench(nm, c, grid, lds, [&] { hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, 0, g); });
+}
+
+
+template <int NSW, int RD>
+static void run_cstat(Ctx& c, int grid) {
+  if (c.N > NSW * 128 || c.N <= (NSW - 1) * 128) return;
+  const int lds = RD * (1 + NSW) * SLOT + ((c.N + 3) / 4 * 4) * 4;
+  if (lds > 163840) { printf("panel_fwd_cstat<%d,%d>: %d bytes of LDS do not fit\n", NSW, RD, lds); return; }
+  auto kern = panel_fwd_cstat<NSW, RD>;
+  CK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+  PArgs g{c.dA, c.dW, c.db, c.dC, c.M, c.N, c.K};
+  char nm[64]; snprintf(nm, sizeof nm, "C  C-stationary NSW=%d ring=%d", NSW, RD);
   bench(nm, c, grid, lds, [&] { hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, 0, g); });
 }
 
@@ -297,9 +418,16 @@ int main(int argc, char** argv) {
   const int T16 = (c.M + 15) / 16;
   const int g128 = (T16 + 7) / 8;                                  // 128-row panels
   const int g256 = T16 >= 256 * 5 ? (T16 + 7) / 8 > 256 ? g128 : 256 : g128;      // <= 128 rows on exactly 256 workgroups when that fits
+  if (c.N <= 512 && c.K % 64 == 0) {
+    run_cstat<1, 2>(c, g128); run_cstat<1, 3>(c, g128); run_cstat<1, 3>(c, g256);
+    run_cstat<2, 2>(c, g128); run_cstat<2, 3>(c, g128); run_cstat<2, 3>(c, g256);
+    run_cstat<3, 2>(c, g128); run_cstat<3, 2>(c, g256);
+    run_cstat<4, 2>(c, g128); run_cstat<4, 2>(c, g256);
+  }
   if (c.K == 384) {
-    run_lds<384, 3>(c, g128); run_lds<384, 3>(c, g256); run_lds<384, 2>(c, g256);
-    run_reg<384, 3>(c, g128); run_reg<384, 3>(c, g256); run_reg<384, 4>(c, g256); run_reg<384, 6>(c, g256); run_reg<384, 8>(c, g256);
+    run_lds<384, 3>(c, g256); run_lds<384, 3, 8>(c, g256); run_lds<384, 3, 1>(c, g256); run_lds<384, 3, 2>(c, g256); run_lds<384, 3, 4>(c, g256); run_lds<384, 3, 3>(c, g256);
+    run_reg<384, 4>(c, g256); run_reg<384, 4, 8>(c, g256); run_reg<384, 6, 8>(c, g256); run_reg<384, 4, 1>(c, g256); run_reg<384, 4, 2>(c, g256); run_reg<384, 4, 4>(c, g256); run_reg<384, 4, 3>(c, g256);
+    run_reg<384, 4, 5>(c, g256); run_reg<384, 4, 6>(c, g256);
   } else if (c.K == 192) {
     run_lds<192, 3>(c, g128); run_lds<192, 4>(c, g128); run_lds<192, 6>(c, g128);
     run_reg<192, 3>(c, g128); run_reg<192, 4>(c, g128); run_reg<192, 6>(c, g128);

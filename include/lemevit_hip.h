@@ -198,6 +198,11 @@ typedef struct lmv_row_scale_segment {
   int64_t rows; int rows_per_sample;
 } lmv_row_scale_segment;
 int lmv_row_scale_multi(const lmv_row_scale_segment* seg, int nseg, int C, int dtype, void* stream);
+/* Classifier tail (models/lemevit.py:815-835, `x.flatten(2).mean(-1) + c.mean(1)`): out[b, :] = mean_l x[b, l, :] + mean_m c[b, m, :]
+ * for token-major x [B, L, C] and c [B, M, C] (c may be NULL), out [B, C] in `dtype`; and its backward, the broadcast
+ * dx[b, l, :] = g[b, :] / L, dc[b, m, :] = g[b, :] / M (dc may be NULL). */
+int lmv_token_mean2_fwd(const void* x, int L, const void* c, int M, int C, int B, void* out, int dtype, void* stream);
+int lmv_token_mean2_bwd(const void* g, void* dx, int L, void* dc, int M, int C, int B, int dtype, void* stream);
 /* Fused multi-tensor AdamW over a flat fp32 parameter / gradient / moment buffer
  * (decoupled weight decay, bias correction as torch.optim.AdamW; benchmark.py:559-561,587).
  * wd_mask (nullable): per-element 0/1 factor on weight_decay.  shadow_bf16 (nullable): bf16 copy of the updated parameters,

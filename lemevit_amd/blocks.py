@@ -90,6 +90,32 @@ def _join() -> None:
         _inflight.clear()
 
 
+# The meta-token self-attention of an S block (16 tokens: B * h tiny workgroups, ~13 us of mostly launch ramp and tail per
+# direction) is independent of the image-token attention next to it: it is launched on a SECOND side stream by raw handle and
+# joined before the projection that consumes both, so it runs inside the image-token kernel's shadow.
+_META_SIDE = os.environ.get("LMV_META_SIDE_STREAM", "1") != "0"
+_meta_streams: Dict[int, tuple] = {}
+
+
+def _meta_fork(dev) -> Optional[int]:
+    if not _META_SIDE or torch.cuda.is_current_stream_capturing():
+        return None
+    ent = _meta_streams.get(dev.index)
+    if ent is None:
+        side = torch.cuda.Stream(device=dev)
+        ent = _meta_streams[dev.index] = (side, side.cuda_stream, torch.cuda.Event(), torch.cuda.Event())
+    side, raw, fork, _ = ent
+    fork.record()
+    side.wait_event(fork)
+    return raw
+
+
+def _meta_join(dev) -> None:
+    side, _, _, join = _meta_streams[dev.index]
+    join.record(side)
+    torch.cuda.current_stream(dev).wait_event(join)
+
+
 def _empty(rows_like: Tensor, cols: int) -> Tensor:
     return torch.empty(rows_like.shape[:-1] + (cols,), device=rows_like.device, dtype=rows_like.dtype)
 
@@ -139,7 +165,15 @@ def _attn_S_fwd(P, ts, ds, save):
     xn, st = ops.layernorm_fwd_multi(ts, P["norm1.weight"], P["norm1.bias"], BLOCK_LN_EPS, want_stats=save)
     qkv = [_empty(t, 3 * C) for t in ts]
     ops.linear_fwd([Prob(a, P["attn.qkv.weight"], o, bias=P["attn.qkv.bias"]) for a, o in zip(xn, qkv)], 3 * C, C)
-    ao, lse = zip(*[ops.attn_fwd((q, 0), (q, C), (q, 2 * C), C, ops.SDPA_SCALE, want_lse=save) for q in qkv])
+    if len(qkv) == 2:
+        raw = _meta_fork(qkv[1].device)
+        ao_c, lse_c = ops.attn_fwd((qkv[1], 0), (qkv[1], C), (qkv[1], 2 * C), C, ops.SDPA_SCALE, want_lse=save, stream=raw)
+        ao_x, lse_x = ops.attn_fwd((qkv[0], 0), (qkv[0], C), (qkv[0], 2 * C), C, ops.SDPA_SCALE, want_lse=save)
+        if raw is not None:
+            _meta_join(qkv[1].device)
+        ao, lse = (ao_x, ao_c), (lse_x, lse_c)
+    else:
+        ao, lse = zip(*[ops.attn_fwd((q, 0), (q, C), (q, 2 * C), C, ops.SDPA_SCALE, want_lse=save) for q in qkv])
     out = [torch.empty_like(t) for t in ts]
     ops.linear_fwd([Prob(a, P["attn.proj.weight"], o, bias=P["attn.proj.bias"], res=t, row_scale=s, rps=_rps(t)) for a, o, t, s in zip(ao, out, ts, ds)], C, C)
     return out, ((list(ts), list(st), list(xn), qkv, list(ao), list(lse)) if save else None)
@@ -153,8 +187,12 @@ def _attn_S_bwd(P, G, saved, douts, ds, g=None):
     dao = [torch.empty_like(t) for t in ts]
     ops.linear_dx([Prob(gi, P["attn.proj.weight"], o) for gi, o in zip(g, dao)], C, C)
     dqkv = [torch.empty_like(q) for q in qkv]
-    for q, a, l, da, dq in zip(qkv, ao, lse, dao, dqkv):
-        ops.attn_bwd((q, 0), (q, C), (q, 2 * C), a, l, da, (dq, 0), (dq, C), (dq, 2 * C), C, ops.SDPA_SCALE)
+    raw = _meta_fork(qkv[1].device) if len(qkv) == 2 else None
+    for i in reversed(range(len(qkv))):              # meta tokens first (side stream), image tokens on the main stream
+        q, a, l, da, dq = qkv[i], ao[i], lse[i], dao[i], dqkv[i]
+        ops.attn_bwd((q, 0), (q, C), (q, 2 * C), a, l, da, (dq, 0), (dq, C), (dq, 2 * C), C, ops.SDPA_SCALE, stream=raw if i == 1 else None)
+    if raw is not None:
+        _meta_join(qkv[1].device)
     _dw([Prob(dq, xi, G["attn.qkv.weight"], bias_grad=G["attn.qkv.bias"]) for dq, xi in zip(dqkv, xn)], 3 * C, C)
     dxn = [torch.empty_like(t) for t in ts]
     ops.linear_dx([Prob(dq, P["attn.qkv.weight"], o) for dq, o in zip(dqkv, dxn)], 3 * C, C)

@@ -272,11 +272,14 @@ constexpr int QR_MAX = 448;   // queries staged per workgroup (Q and dO images: 
 // the memory traffic), delta = rowsum(dO * O) is formed while the query range is staged, and dQ rows leave complete (all keys
 // of a (b, h) live in this workgroup).  Q, dO and O are then read ONCE by the backward pass instead of twice, and the
 // separate dQ launch disappears (DCA x-direction: 3136 queries x 16 keys; the 16 x 16 meta-token self-attention).
-template <int NKT, int KW, bool ATOMIC, bool FUSEDQ = false>
+// LK > 0: the key count is a compile-time constant (16 meta tokens: the x direction of Dual Cross-Attention): key tiles past the end are
+// not computed at all -- with 16 keys in a 32-key block that is half of the MFMAs, exponentials and masks of the run-time version.
+template <int NKT, int KW, bool ATOMIC, bool FUSEDQ = false, int LK = 0>
 __global__ __launch_bounds__(256) void mfma_bwd_dkv_kernel(const AttnArgs a, const float* __restrict__ delta, float* __restrict__ acc_k,
                                                           float* __restrict__ acc_v, int q_per_block) {
   constexpr int QW = 4 / KW;
   constexpr int TPW = (NKT + KW - 1) / KW;     // key tiles per wave
+  const int Lk = LK ? LK : a.Lk;
   static_assert(!FUSEDQ || (NKT == 2 && KW == 1), "the fused dQ path is written for two key tiles per wave");
   __shared__ __attribute__((aligned(16))) unsigned char sQG[2 * QR_MAX * 64];     // Q image | dO image (reused by the final reduce)
   __shared__ __attribute__((aligned(16))) float sL[QR_MAX], sDl[QR_MAX];
@@ -315,14 +318,14 @@ __global__ __launch_bounds__(256) void mfma_bwd_dkv_kernel(const AttnArgs a, con
       sDl[i] = ok ? delta[bh + q0 + i] : 0.f;
     }
   }
-  if constexpr (FUSEDQ) stage_rows2<256>(sKV, kb, a.k_rs, sKV + 32 * 64, vb, a.v_rs, 0, 32, a.Lk, tid);
+  if constexpr (FUSEDQ) stage_rows2<256>(sKV, kb, a.k_rs, sKV + 32 * 64, vb, a.v_rs, 0, 32, Lk, tid);
   bf16x8_t kf[TPW], vf[TPW];
   f32x4_t dk[TPW][2], dv[TPW][2];
 #pragma unroll
   for (int i = 0; i < TPW; ++i) {
     const int kt = kw + i * KW;
-    kf[i] = load_frag_global(kb, a.k_rs, kt * 16 + (lane & 15), (kt < NKT) ? a.Lk : 0, lane);
-    vf[i] = load_frag_global(vb, a.v_rs, kt * 16 + (lane & 15), (kt < NKT) ? a.Lk : 0, lane);
+    kf[i] = load_frag_global(kb, a.k_rs, kt * 16 + (lane & 15), (kt < NKT) ? Lk : 0, lane);
+    vf[i] = load_frag_global(vb, a.v_rs, kt * 16 + (lane & 15), (kt < NKT) ? Lk : 0, lane);
 #pragma unroll
     for (int dt = 0; dt < 2; ++dt) { dk[i][dt] = f32x4_t{0.f, 0.f, 0.f, 0.f}; dv[i][dt] = f32x4_t{0.f, 0.f, 0.f, 0.f}; }
   }
@@ -349,11 +352,13 @@ __global__ __launch_bounds__(256) void mfma_bwd_dkv_kernel(const AttnArgs a, con
         f32x4_t dsq[2];
 #pragma unroll
         for (int kt = 0; kt < 2; ++kt) {
+          if (LK && kt * 16 >= LK) { dsq[kt] = f32x4_t{0.f, 0.f, 0.f, 0.f}; continue; }      // compile-time: padding tile
           const f32x4_t sv = MFMA(kf[kt], qn, (f32x4_t{0.f, 0.f, 0.f, 0.f}));
           const f32x4_t dp = MFMA(vf[kt], gn, (f32x4_t{0.f, 0.f, 0.f, 0.f}));
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            const float pq = (kt * 16 + g * 4 + r < a.Lk) ? __expf(sv[r] * a.scale - lq) : 0.f;
+            const bool kin = (LK && kt * 16 + 16 <= LK) ? true : (kt * 16 + g * 4 + r < Lk);
+            const float pq = kin ? __expf(sv[r] * a.scale - lq) : 0.f;
             dsq[kt][r] = pq * (dp[r] - dq_) * a.scale;
           }
         }
@@ -369,7 +374,8 @@ __global__ __launch_bounds__(256) void mfma_bwd_dkv_kernel(const AttnArgs a, con
     for (int i = 0; i < TPW; ++i) {
       const int kt = kw + i * KW;
       if (kt >= NKT) continue;
-      const bool kvalid = vkey && (kt * 16 + (lane & 15) < a.Lk);
+      if (LK && KW == 1 && kt * 16 >= LK) continue;                  // compile-time (KW == 1: kt = i): padding tile
+      const bool kvalid = (LK && KW == 1 && kt * 16 + 16 <= LK) ? true : (vkey && (kt * 16 + (lane & 15) < Lk));
       // D[q][key]: lane holds queries r0 + t*16 + g*4 + r of key (lane & 15)
       const f32x4_t s0 = MFMA(qn0, kf[i], (f32x4_t{0.f, 0.f, 0.f, 0.f})), s1 = MFMA(qn1, kf[i], (f32x4_t{0.f, 0.f, 0.f, 0.f}));
       const f32x4_t p0 = MFMA(gn0, vf[i], (f32x4_t{0.f, 0.f, 0.f, 0.f})), p1 = MFMA(gn1, vf[i], (f32x4_t{0.f, 0.f, 0.f, 0.f}));
@@ -412,7 +418,7 @@ __global__ __launch_bounds__(256) void mfma_bwd_dkv_kernel(const AttnArgs a, con
 #pragma unroll
   for (int i = 0; i < TPW; ++i) {
     const int kt = kw + i * KW, key = kt * 16 + (lane & 15);
-    if (kt >= NKT || key >= a.Lk) continue;
+    if (kt >= NKT || key >= Lk) continue;
     if (ATOMIC) {      // several query ranges per (b, h): this range's partial goes to ITS slab (plain stores; summed by scatter_sum_kernel)
 #pragma unroll
       for (int dt = 0; dt < 2; ++dt) {
@@ -1134,6 +1140,7 @@ int lmv_attn_mfma_fwd(const AttnArgs& a, hipStream_t st) {
   dim3 grid((nqt + per - 1) / per, a.H, a.B), block(256);
   static const int pv16 = [] { const char* e = getenv("LMV_ATTN_PV16"); return e ? atoi(e) : 1; }();      // A/B testing
   if (a.Lk == 196 && pv16) hipLaunchKernelGGL((mfma_fwd_kernel<14, 196, true>), grid, block, 0, st, a, per);      // stage-3 self-attention at 224^2
+  else if (a.Lk == 16 && pv16) hipLaunchKernelGGL((mfma_fwd_kernel<2, 16, true>), grid, block, 0, st, a, per);    // 16 meta-token keys (DCA x direction, meta self-attention)
   else if (a.Lk == 49 && pv16) hipLaunchKernelGGL((mfma_fwd_kernel<4, 49, true>), grid, block, 0, st, a, per);    // stage 4
   else
   switch (nkt_for(a.Lk)) {
@@ -1173,7 +1180,8 @@ int lmv_attn_mfma_bwd(const AttnArgs& a, float* delta, float* acc, hipStream_t s
   float* acc_k = acc; float* acc_v = acc + acc_elems;
   if (nsplit > 1) {
 #define DKV(N, K) hipLaunchKernelGGL((mfma_bwd_dkv_kernel<N, K, true>), grid, block, 0, st, a, delta, acc_k, acc_v, qpb)
-    if (nkt == 2 && fuse_dq) hipLaunchKernelGGL((mfma_bwd_dkv_kernel<2, 1, true, true>), grid, block, 0, st, a, delta, acc_k, acc_v, qpb);
+    if (nkt == 2 && fuse_dq && a.Lk == 16) hipLaunchKernelGGL((mfma_bwd_dkv_kernel<2, 1, true, true, 16>), grid, block, 0, st, a, delta, acc_k, acc_v, qpb);
+    else if (nkt == 2 && fuse_dq) hipLaunchKernelGGL((mfma_bwd_dkv_kernel<2, 1, true, true>), grid, block, 0, st, a, delta, acc_k, acc_v, qpb);
     else
     switch (nkt) { case 2: DKV(2, 1); break; case 4: DKV(4, 2); break; case 8: DKV(8, 4); break; default: DKV(14, 4); break; }
 #undef DKV
@@ -1182,7 +1190,8 @@ int lmv_attn_mfma_bwd(const AttnArgs& a, float* delta, float* acc, hipStream_t s
                        a.k_bs, a.k_rs, a.v_bs, a.v_rs, a.B, a.H, a.Lk, nkt * 16, nsplit);
   } else {
 #define DKV(N, K) hipLaunchKernelGGL((mfma_bwd_dkv_kernel<N, K, false>), grid, block, 0, st, a, delta, acc_k, acc_v, qpb)
-    if (nkt == 2 && fuse_dq) hipLaunchKernelGGL((mfma_bwd_dkv_kernel<2, 1, false, true>), grid, block, 0, st, a, delta, acc_k, acc_v, qpb);
+    if (nkt == 2 && fuse_dq && a.Lk == 16) hipLaunchKernelGGL((mfma_bwd_dkv_kernel<2, 1, false, true, 16>), grid, block, 0, st, a, delta, acc_k, acc_v, qpb);
+    else if (nkt == 2 && fuse_dq) hipLaunchKernelGGL((mfma_bwd_dkv_kernel<2, 1, false, true>), grid, block, 0, st, a, delta, acc_k, acc_v, qpb);
     else
     switch (nkt) { case 2: DKV(2, 1); break; case 4: DKV(4, 2); break; case 8: DKV(8, 4); break; default: DKV(14, 4); break; }
 #undef DKV

@@ -810,7 +810,10 @@ int make_plan(const lmv_linear_problem* p, int nproblems, int N, int K, int act,
   pl->bigk = 0;
   // BigK tile (128 x 256 / 384, 8 waves, register-pipelined k-loop): long bf16 reductions whose output is at least 256 columns wide
   // -- fc2 forward, dX of qkv / fc1, and the weight gradients -- on reductions that are whole 64-deep k-steps.
-  static const int bigk_mode = [] { const char* e = getenv("LMV_GEMM_BIGK"); return e ? atoi(e) : 1; }();     // A/B testing: 0 = off
+  // Measured (round 2, tools/bench_kernels.py + bench.py): faster than the 128 x 128 kernels only on the fc2-forward shape of stage 3
+  // (40.7 vs 44.7 us), slower on dX and dW (one workgroup per CU: the 8-instruction LDS-DMA burst behind every barrier idles the matrix
+  // pipe, and 21 splits of fat slabs cost more than 24 of thin ones) -- the train step loses 1.1 ms with it.  Off unless LMV_GEMM_BIGK=1.
+  static const int bigk_mode = [] { const char* e = getenv("LMV_GEMM_BIGK"); return e ? atoi(e) : 0; }();
   const int bigk_min_k = (mode == MODE_DW) ? 1024 : 768;
   if (bigk_mode && bf && !no_dma && all64 && min_kred >= bigk_min_k && out_cols >= 256 && force_tile == 0 && force_bk == 0) {
     // tile width: 384 when it tiles the output without more padding than 256 does

@@ -59,6 +59,64 @@ __global__ __launch_bounds__(TPB) void row_scale_kernel(const RowScaleArgs a) {
   }
 }
 
+// ---- classifier tail (models/lemevit.py:815-835): pooled[b, :] = mean_l x[b, l, :] + mean_m c[b, m, :] ----------------------------
+// One thread owns 8 (bf16) / 4 (fp32) channels of one sample and walks the tokens of both segments: the sums stay in registers,
+// the result is ONE fp32 row per sample (the operand of the head GEMM).  Backward is the broadcast dx[b, l, :] = g[b, :] / L.
+template <typename T>
+__global__ __launch_bounds__(TPB) void token_mean2_fwd_kernel(const T* __restrict__ x, int L, const T* __restrict__ c, int M, int C, int B,
+                                                            T* __restrict__ out) {
+  constexpr int EPC = DT<T>::EPC;
+  const int cpr = C / EPC;
+  const unsigned i = blockIdx.x * TPB + threadIdx.x;
+  if (i >= (unsigned)B * cpr) return;
+  const int b = i / cpr, ch = i % cpr;
+  float acc[EPC], f[EPC];
+#pragma unroll
+  for (int e = 0; e < EPC; ++e) acc[e] = 0.f;
+  const uint4* px = reinterpret_cast<const uint4*>(x) + (size_t)b * L * cpr + ch;
+  for (int l = 0; l < L; ++l) {
+    chunk_to_f<T>(px[(size_t)l * cpr], f);
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) acc[e] += f[e];
+  }
+  const float il = 1.f / (float)L;
+#pragma unroll
+  for (int e = 0; e < EPC; ++e) acc[e] *= il;
+  if (c) {
+    float a2[EPC];
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) a2[e] = 0.f;
+    const uint4* pc = reinterpret_cast<const uint4*>(c) + (size_t)b * M * cpr + ch;
+    for (int m = 0; m < M; ++m) {
+      chunk_to_f<T>(pc[(size_t)m * cpr], f);
+#pragma unroll
+      for (int e = 0; e < EPC; ++e) a2[e] += f[e];
+    }
+    const float im = 1.f / (float)M;
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) acc[e] += a2[e] * im;
+  }
+  reinterpret_cast<uint4*>(out)[i] = f_to_chunk<T>(acc);
+}
+
+template <typename T>
+__global__ __launch_bounds__(TPB) void token_mean2_bwd_kernel(const T* __restrict__ g, T* __restrict__ dx, int L, T* __restrict__ dc, int M, int C, int B) {
+  constexpr int EPC = DT<T>::EPC;
+  const int cpr = C / EPC;
+  const unsigned tot = (unsigned)B * (L + M) * cpr;
+  for (unsigned i = blockIdx.x * TPB + threadIdx.x; i < tot; i += gridDim.x * TPB) {
+    const unsigned row = i / cpr, ch = i % cpr;
+    const unsigned b = row / (L + M), t = row % (L + M);
+    float f[EPC];
+    chunk_to_f<T>(reinterpret_cast<const uint4*>(g)[(size_t)b * cpr + ch], f);
+    const float sc = t < (unsigned)L ? 1.f / (float)L : 1.f / (float)M;
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) f[e] *= sc;
+    if (t < (unsigned)L) reinterpret_cast<uint4*>(dx)[((size_t)b * L + t) * cpr + ch] = f_to_chunk<T>(f);
+    else if (dc) reinterpret_cast<uint4*>(dc)[((size_t)b * M + (t - L)) * cpr + ch] = f_to_chunk<T>(f);
+  }
+}
+
 __global__ __launch_bounds__(TPB) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                                    float* __restrict__ v, const float* __restrict__ wd_mask, bf16_t* __restrict__ shadow,
                                                    const int* __restrict__ step_dev, int64_t n, float lr, float b1, float b2, float eps, float wd,
@@ -231,6 +289,33 @@ extern "C" int lmv_row_scale_multi(const lmv_row_scale_segment* seg, int nseg, i
 extern "C" int lmv_row_scale(const void* x, const float* scale, void* y, int64_t rows, int C, int rps, int dtype, void* stream) {
   lmv_row_scale_segment s{x, scale, y, rows, rps};
   return lmv_row_scale_multi(&s, 1, C, dtype, stream);
+}
+
+extern "C" int lmv_token_mean2_fwd(const void* x, int L, const void* c, int M, int C, int B, void* out, int dtype, void* stream) {
+  if (B <= 0 || L <= 0 || C <= 0 || (c && M <= 0) || (C % 8)) LMV_FAIL(LMV_ERR_SHAPE, "token_mean2_fwd: bad shape B=%d L=%d M=%d C=%d", B, L, M, C);
+  if (dtype != LMV_F32 && dtype != LMV_BF16) LMV_FAIL(LMV_ERR_DTYPE, "token_mean2_fwd: unsupported dtype %d", dtype);
+  if (!x || !out || !lmv_aligned16(x) || !lmv_aligned16(c) || !lmv_aligned16(out)) LMV_FAIL(LMV_ERR_SHAPE, "token_mean2_fwd: null or misaligned operand");
+  const int cpr = C / (dtype == LMV_BF16 ? 8 : 4);
+  const int grid = (B * cpr + TPB - 1) / TPB;
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == LMV_BF16) hipLaunchKernelGGL((token_mean2_fwd_kernel<bf16_t>), dim3(grid), dim3(TPB), 0, st, (const bf16_t*)x, L, (const bf16_t*)c, M, C, B, (bf16_t*)out);
+  else hipLaunchKernelGGL((token_mean2_fwd_kernel<float>), dim3(grid), dim3(TPB), 0, st, (const float*)x, L, (const float*)c, M, C, B, (float*)out);
+  LMV_CHECK_LAUNCH("token_mean2_fwd");
+  return LMV_OK;
+}
+
+extern "C" int lmv_token_mean2_bwd(const void* g, void* dx, int L, void* dc, int M, int C, int B, int dtype, void* stream) {
+  if (B <= 0 || L <= 0 || C <= 0 || (dc && M <= 0) || (C % 8)) LMV_FAIL(LMV_ERR_SHAPE, "token_mean2_bwd: bad shape B=%d L=%d M=%d C=%d", B, L, M, C);
+  if (dtype != LMV_F32 && dtype != LMV_BF16) LMV_FAIL(LMV_ERR_DTYPE, "token_mean2_bwd: unsupported dtype %d", dtype);
+  if (!g || !dx || !lmv_aligned16(g) || !lmv_aligned16(dx) || !lmv_aligned16(dc)) LMV_FAIL(LMV_ERR_SHAPE, "token_mean2_bwd: null or misaligned operand");
+  const int cpr = C / (dtype == LMV_BF16 ? 8 : 4);
+  const int64_t tot = (int64_t)B * (L + (dc ? M : 0)) * cpr;
+  hipStream_t st = (hipStream_t)stream;
+  const int Mx = dc ? M : 0;
+  if (dtype == LMV_BF16) hipLaunchKernelGGL((token_mean2_bwd_kernel<bf16_t>), dim3(grid_for(tot)), dim3(TPB), 0, st, (const bf16_t*)g, (bf16_t*)dx, L, (bf16_t*)dc, Mx, C, B);
+  else hipLaunchKernelGGL((token_mean2_bwd_kernel<float>), dim3(grid_for(tot)), dim3(TPB), 0, st, (const float*)g, (float*)dx, L, (float*)dc, Mx, C, B);
+  LMV_CHECK_LAUNCH("token_mean2_bwd");
+  return LMV_OK;
 }
 
 extern "C" int lmv_adamw_flat(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, const float* wd_mask, void* shadow_bf16,

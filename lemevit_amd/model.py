@@ -230,6 +230,78 @@ class _MetaMLPFn(torch.autograd.Function):
         return (dc, *[g if dt == torch.float32 else g.to(dt) for g, (_, dt) in zip(G, pmeta)], None, None, None)
 
 
+class _TailFn(torch.autograd.Function):
+    """The classifier tail on the block kernels (models/lemevit.py:815-835):
+    logits = head(mean_tokens(x) + mean_tokens(LayerNorm(c))) for token-major x [B, L, C] (already through the final BatchNorm)
+    and the meta tokens c [B, M, C] -- lmv_layernorm_fwd -> lmv_token_mean2_fwd -> lmv_linear_fwd, and a hand-written backward
+    (lmv_linear_dx / _dw, lmv_token_mean2_bwd, lmv_layernorm_bwd) instead of ~25 library kernels.  head = None returns the
+    pooled features (forward_features)."""
+
+    @staticmethod
+    def forward(ctx, x, c, g, b, eps, hw, hb, cd):
+        xc = x.detach().to(cd).contiguous()
+        cc = c.detach().to(cd).contiguous()
+        f32 = lambda p: compute_copy(p, torch.float32)
+        (cn,), (st,) = ops.layernorm_fwd_multi([cc], f32(g), f32(b), eps, want_stats=True)
+        pooled = ops.token_mean2_fwd(xc, cn)
+        ctx.dims = (xc.shape[1], cc.shape[1])
+        ctx.meta = (x.dtype, c.dtype, g.dtype, b.dtype, None if hw is None else hw.dtype, None if hb is None else hb.dtype, None if hw is None else hw.shape)
+        if hw is None:
+            ctx.saved = (cc, st, f32(g), None, None)
+            return pooled
+        W = compute_copy(hw, cd)
+        N, K = W.shape
+        Np = (N + 7) // 8 * 8                              # the GEMM wants a multiple of 8 output columns: pad the operand, slice the result
+        if Np != N:
+            Wp = torch.zeros((Np, K), device=W.device, dtype=cd); Wp[:N] = W
+            bp = None
+            if hb is not None:
+                bp = torch.zeros((Np,), device=W.device, dtype=torch.float32); bp[:N] = f32(hb)
+        else:
+            Wp, bp = W, (None if hb is None else f32(hb))
+        out = torch.empty((pooled.shape[0], Np), device=pooled.device, dtype=cd)
+        ops.linear_fwd([Prob(pooled, Wp, out, bias=bp)], Np, K)
+        ctx.saved = (cc, st, f32(g), pooled, Wp)
+        return out[:, :N] if Np != N else out
+
+    @staticmethod
+    def backward(ctx, dout):
+        cc, st, g32, pooled, Wp = ctx.saved
+        L, M = ctx.dims
+        xdt, cdt, gdt, bdt, hwdt, hbdt, hwshape = ctx.meta
+        dW = db = None
+        if Wp is not None:
+            Np, K = Wp.shape
+            N = hwshape[0]
+            d = dout.contiguous()
+            if d.dtype != pooled.dtype:
+                d = d.to(pooled.dtype)
+            if Np != N:
+                dp = torch.zeros((d.shape[0], Np), device=d.device, dtype=d.dtype); dp[:, :N] = d
+                d = dp
+            dWf = torch.zeros((Np, K), device=d.device, dtype=torch.float32); dbf = torch.zeros((Np,), device=d.device, dtype=torch.float32)
+            ops.linear_dw([Prob(d, pooled, dWf, bias_grad=dbf)], Np, K)
+            dpooled = torch.empty_like(pooled)
+            ops.linear_dx([Prob(d, Wp, dpooled)], Np, K)
+            dW = dWf[:N].to(hwdt)
+            db = None if hbdt is None else dbf[:N].to(hbdt)
+        else:
+            dpooled = dout.contiguous().to(cc.dtype)
+        dx, dcn = ops.token_mean2_bwd(dpooled, L, M)
+        dg = torch.zeros_like(g32); dbeta = torch.zeros_like(g32)
+        (dc,) = ops.layernorm_bwd_multi([dcn], [cc], [st], g32, dg, dbeta, [None])
+        ctx.saved = None
+        return dx.to(xdt), dc.to(cdt), dg.to(gdt), dbeta.to(bdt), None, dW, db, None
+
+
+def _tail_native(norm_c: nn.Module, head: Optional[nn.Module], xt: Tensor, c: Tensor, cd: torch.dtype) -> bool:
+    ok = (isinstance(norm_c, nn.LayerNorm) and norm_c.elementwise_affine and norm_c.bias is not None and xt.is_cuda and cd in (torch.float32, torch.bfloat16)
+          and xt.shape[-1] % 8 == 0 and norm_c.weight.dtype == torch.float32 and os.environ.get("LMV_TAIL_NATIVE", "1") != "0")
+    if head is not None:
+        ok = ok and isinstance(head, nn.Linear) and head.in_features % 8 == 0 and head.weight.dtype == torch.float32
+    return ok
+
+
 def _is_meta_mlp(seq: nn.Module, c: Tensor, cd: torch.dtype) -> bool:
     if not (isinstance(seq, nn.Sequential) and len(seq) == 5 and c.is_cuda and cd in (torch.float32, torch.bfloat16)):
         return False
@@ -693,9 +765,11 @@ class LeMeViT(nn.Module):
             r += n
         return out
 
-    def forward_features(self, x: Tensor, c: Optional[Tensor] = None) -> Tensor:
-        """models/lemevit.py:809-829.  c = None hoists the batch-invariant meta-token prefix."""
+    def forward_features(self, x: Tensor, c: Optional[Tensor] = None, head=False) -> Tensor:
+        """models/lemevit.py:809-829.  c = None hoists the batch-invariant meta-token prefix.
+        head (internal): the classifier module to fuse into the tail node (forward() passes self.head); False = features only."""
         cd = _resolve_dtype(x)
+        self._tail_done = False
         B = x.shape[0]
         if torch.is_grad_enabled():
             new_training_pass()
@@ -720,8 +794,16 @@ class LeMeViT(nn.Module):
             c = c.to(cd).contiguous()
             for blk in self.stages[i]:
                 xt, c = blk.forward_tokens(xt, c, H, W, masks=all_masks.get(id(blk)) if all_masks else None)
-        cn = self.pre_logits(self.norm_c(c))
         bn = self.norm
+        if head is not False and isinstance(self.pre_logits, nn.Identity) and (self.training or torch.is_grad_enabled()) and _tail_native(self.norm_c, head, xt, c, cd):
+            # training: final BatchNorm (native kernels) -> LayerNorm(c) + both mean-pools + add (+ classifier) as ONE autograd node
+            xn = self._to_nchw(xt, H, W)
+            xn = _bn_train(bn, xn) if _bn_native(bn, xn) else bn(xn)
+            xb = xn.permute(0, 2, 3, 1).reshape(B, H * W, -1)           # token-major view of the channels-last map: no copy
+            hw, hb = (None, None) if head is None else (head.weight, head.bias)
+            self._tail_done = head is not None
+            return _TailFn.apply(xb, c, self.norm_c.weight, self.norm_c.bias, float(self.norm_c.eps), hw, hb, cd)
+        cn = self.pre_logits(self.norm_c(c))
         if not bn.training and bn.track_running_stats and isinstance(self.pre_logits, nn.Identity):
             # inference: BatchNorm with running statistics is affine per channel, so it commutes with the spatial mean --
             # pool the tokens first and normalise [B, C] instead of [B, C, H, W]  (models/lemevit.py:815, 825)
@@ -735,8 +817,9 @@ class LeMeViT(nn.Module):
         return xn.flatten(2).mean(-1) + cn.mean(dim=1)
 
     def forward(self, x: Tensor) -> Tensor:
-        x = self.forward_features(x, None)
-        return self.head(x)
+        head = self.head if isinstance(self.head, nn.Linear) else None
+        x = self.forward_features(x, None, head=head)
+        return x if self._tail_done else self.head(x)
 
 
 class LayerNorm2d(nn.LayerNorm):

@@ -249,28 +249,31 @@ def _desc(q: Tuple[Tensor, int], k: Tuple[Tensor, int], v: Tuple[Tensor, int], o
     return d
 
 
-def attn_fwd(q, k, v, C_: int, scale: float, want_lse: bool = False) -> Tuple[Tensor, Optional[Tensor]]:
-    """o[b,l,h,:] = softmax(scale q.k^T) v with q/k/v = (packed tensor [B,L,XC], column offset)."""
+def attn_fwd(q, k, v, C_: int, scale: float, want_lse: bool = False, stream: Optional[int] = None) -> Tuple[Tensor, Optional[Tensor]]:
+    """o[b,l,h,:] = softmax(scale q.k^T) v with q/k/v = (packed tensor [B,L,XC], column offset).
+    stream: raw HIP stream handle to launch on (default: the current stream); the scratch is per stream."""
     qt = q[0]
     B, Lq, Lk = qt.shape[0], qt.shape[1], k[0].shape[1]
     o = torch.empty((B, Lq, C_), device=qt.device, dtype=qt.dtype)
     lse = torch.empty((B, C_ // HEAD_DIM, Lq), device=qt.device, dtype=torch.float32) if want_lse else None
     d = _desc(q, k, v, o, lse, C_, scale)
     nb = lib.lmv_attn_workspace_bytes(d.B, d.H, Lq, Lk, 0)
-    ws = _workspace(nb, qt.device)
-    check(lib.lmv_attn_fwd(C.byref(d), ws.data_ptr(), ws.numel(), dtype_code(qt), _stream()), "lmv_attn_fwd")
+    st = _stream() if stream is None else stream
+    ws = _workspace(nb, qt.device, st)
+    check(lib.lmv_attn_fwd(C.byref(d), ws.data_ptr(), ws.numel(), dtype_code(qt), st), "lmv_attn_fwd")
     return o, lse
 
 
-def attn_bwd(q, k, v, o: Tensor, lse: Tensor, d_o: Tensor, dq, dk, dv, C_: int, scale: float) -> None:
+def attn_bwd(q, k, v, o: Tensor, lse: Tensor, d_o: Tensor, dq, dk, dv, C_: int, scale: float, stream: Optional[int] = None) -> None:
     """Writes dq/dk/dv = (packed grad tensor, column offset) with the layout of q/k/v."""
     d = _desc(q, k, v, o, lse, C_, scale)
     es = q[0].element_size()
     d.d_o = _ptr(d_o)
     d.dq, d.dk, d.dv = _ptr(dq[0]) + dq[1] * es, _ptr(dk[0]) + dk[1] * es, _ptr(dv[0]) + dv[1] * es
     nb = lib.lmv_attn_workspace_bytes(d.B, d.H, d.Lq, d.Lk, 1)
-    ws = _workspace(nb, o.device)
-    check(lib.lmv_attn_bwd(C.byref(d), ws.data_ptr(), ws.numel(), dtype_code(o), _stream()), "lmv_attn_bwd")
+    st = _stream() if stream is None else stream
+    ws = _workspace(nb, o.device, st)
+    check(lib.lmv_attn_bwd(C.byref(d), ws.data_ptr(), ws.numel(), dtype_code(o), st), "lmv_attn_bwd")
 
 
 def dca_scales(N: int, M: int, C_: int) -> Tuple[float, float]:
@@ -302,6 +305,23 @@ def im2col3x3s2_c3(x: Tensor, dtype: torch.dtype) -> Tensor:
         raise RuntimeError("lemevit_amd: tensors must be on the GPU (no CPU fallback exists)")
     check(lib.lmv_im2col3x3s2_c3(x.data_ptr(), dtype_code(x), _ptr(out), dtype_code(out), B, H, W, sb, sc, sh, sw, _stream()), "lmv_im2col3x3s2_c3")
     return out
+
+
+def token_mean2_fwd(x: Tensor, c: Optional[Tensor]) -> Tensor:
+    """out[b, :] = mean_l x[b, l, :] (+ mean_m c[b, m, :]) for token-major x [B, L, C], c [B, M, C]."""
+    B, L, C_ = x.shape
+    out = torch.empty((B, C_), device=x.device, dtype=x.dtype)
+    check(lib.lmv_token_mean2_fwd(_ptr(x), L, _ptr(c), 0 if c is None else c.shape[1], C_, B, _ptr(out), dtype_code(x), _stream()), "lmv_token_mean2_fwd")
+    return out
+
+
+def token_mean2_bwd(g: Tensor, L: int, M: int) -> Tuple[Tensor, Optional[Tensor]]:
+    """Gradient of token_mean2_fwd: dx[b, l, :] = g[b, :] / L, dc[b, m, :] = g[b, :] / M (M = 0: no second segment)."""
+    B, C_ = g.shape
+    dx = torch.empty((B, L, C_), device=g.device, dtype=g.dtype)
+    dc = torch.empty((B, M, C_), device=g.device, dtype=g.dtype) if M else None
+    check(lib.lmv_token_mean2_bwd(_ptr(g), _ptr(dx), L, _ptr(dc), M, C_, B, dtype_code(g), _stream()), "lmv_token_mean2_bwd")
+    return dx, dc
 
 
 def row_scale(x: Tensor, scale: Tensor, rows_per_sample: int) -> Tensor:

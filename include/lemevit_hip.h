@@ -198,6 +198,14 @@ typedef struct lmv_row_scale_segment {
   int64_t rows; int rows_per_sample;
 } lmv_row_scale_segment;
 int lmv_row_scale_multi(const lmv_row_scale_segment* seg, int nseg, int C, int dtype, void* stream);
+/* Dense 3x3 / stride-2 / padding-1 convolutions on channels-last maps -- the second stem convolution and the stage transitions
+ * (models/lemevit.py:701-703, :714-717) -- lowered to the block GEMM:
+ *   patches[(b, ho, wo)][(ky * 3 + kx) * C + ci] = x[b, 2 ho - 1 + ky, 2 wo - 1 + kx, ci]  (zero outside the map and in the padding
+ *   columns 9 C .. KP - 1), x = [B, H, W, C] NHWC, patches = [B * ceil(H/2) * ceil(W/2), KP], C % 8 == 0, KP >= 9 C, KP % 8 == 0.
+ * lmv_linear_fwd(patches, Wm[Cout, KP]) is the convolution (NHWC output), lmv_linear_dw its weight gradient, and
+ * lmv_col2im3x3s2_nhwc(lmv_linear_dx(dY, Wm)) its data gradient (a gather over the <= 4 output pixels that read an input pixel). */
+int lmv_im2col3x3s2_nhwc(const void* x, void* patches, int B, int H, int W, int C, int KP, int dtype, void* stream);
+int lmv_col2im3x3s2_nhwc(const void* dpatches, void* dx, int B, int H, int W, int C, int KP, int dtype, void* stream);
 /* Classifier tail (models/lemevit.py:815-835, `x.flatten(2).mean(-1) + c.mean(1)`): out[b, :] = mean_l x[b, l, :] + mean_m c[b, m, :]
  * for token-major x [B, L, C] and c [B, M, C] (c may be NULL), out [B, C] in `dtype`; and its backward, the broadcast
  * dx[b, l, :] = g[b, :] / L, dc[b, m, :] = g[b, :] / M (dc may be NULL). */

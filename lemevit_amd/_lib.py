@@ -73,6 +73,8 @@ SIGNATURES = {
     "lmv_im2col3x3s2_c3": (_I, [_P, _I, _P, _I, _I, _I, _I, _L, _L, _L, _L, _P]),
     "lmv_row_scale_multi": (_I, [_P, _I, _I, _I, _P]),
     "lmv_row_scale": (_I, [_P, _P, _P, _L, _I, _I, _I, _P]),
+    "lmv_im2col3x3s2_nhwc": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "lmv_col2im3x3s2_nhwc": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "lmv_token_mean2_fwd": (_I, [_P, _I, _P, _I, _I, _I, _P, _I, _P]),
     "lmv_token_mean2_bwd": (_I, [_P, _P, _I, _P, _I, _I, _I, _I, _P]),
     "lmv_adamw_flat": (_I, [_P, _P, _P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _I, _P, _P]),

@@ -117,6 +117,64 @@ __global__ __launch_bounds__(TPB) void token_mean2_bwd_kernel(const T* __restric
   }
 }
 
+// ---- dense 3x3 / stride-2 / pad-1 convolution on channels-last maps as im2col + the block GEMM (SURVEY section 8, row f1;
+// models/lemevit.py:701-703 second stem convolution, :714-717 stage transitions) -------------------------------------------------
+// patches[(b, ho, wo)][(ky * 3 + kx) * C + ci] = x[b, 2 ho - 1 + ky, 2 wo - 1 + kx, ci] (zero outside the map; columns 9 C .. KP - 1
+// zero: KP pads the reduction to whole 64-deep k-steps so that the GEMM takes its LDS-DMA path).  One thread per 16-byte chunk:
+// C % 8 == 0, so a chunk never straddles two taps.
+template <typename T>
+__global__ __launch_bounds__(TPB) void im2col_nhwc_kernel(const T* __restrict__ x, T* __restrict__ out, int B, int H, int W, int C, int Ho, int Wo, int KP) {
+  constexpr int EPC = DT<T>::EPC;
+  const int cpr = KP / EPC, cpt = C / EPC;                 // chunks per patch row / per tap
+  const int64_t total = (int64_t)B * Ho * Wo * cpr;
+  for (int64_t i = blockIdx.x * (int64_t)TPB + threadIdx.x; i < total; i += (int64_t)gridDim.x * TPB) {
+    const int j = (int)(i % cpr);
+    const int64_t r = i / cpr;
+    const int wo = (int)(r % Wo), ho = (int)((r / Wo) % Ho), b = (int)(r / ((int64_t)Wo * Ho));
+    const int tap = j / cpt, cc = j - tap * cpt, ky = tap / 3, kx = tap - ky * 3;
+    const int h = 2 * ho - 1 + ky, w = 2 * wo - 1 + kx;
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (tap < 9 && h >= 0 && h < H && w >= 0 && w < W) v = reinterpret_cast<const uint4*>(x)[(((int64_t)b * H + h) * W + w) * cpt + cc];
+    reinterpret_cast<uint4*>(out)[i] = v;
+  }
+}
+
+// data gradient: dx[b, h, w, ci] = sum over the taps (ky, kx) whose output pixel ((h + 1 - ky) / 2, (w + 1 - kx) / 2) exists of
+// dpatches[that pixel][(ky * 3 + kx) * C + ci] -- a GATHER (1, 2 or 4 terms per input pixel, fixed order: no atomics)
+template <typename T>
+__global__ __launch_bounds__(TPB) void col2im_nhwc_kernel(const T* __restrict__ dp, T* __restrict__ dx, int B, int H, int W, int C, int Ho, int Wo, int KP) {
+  constexpr int EPC = DT<T>::EPC;
+  const int cpr = KP / EPC, cpt = C / EPC;
+  const int64_t total = (int64_t)B * H * W * cpt;
+  for (int64_t i = blockIdx.x * (int64_t)TPB + threadIdx.x; i < total; i += (int64_t)gridDim.x * TPB) {
+    const int cc = (int)(i % cpt);
+    const int64_t p = i / cpt;
+    const int w = (int)(p % W), h = (int)((p / W) % H), b = (int)(p / ((int64_t)W * H));
+    float acc[EPC];
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) acc[e] = 0.f;
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) {
+      const int t = h + 1 - ky;
+      if (t < 0 || (t & 1)) continue;
+      const int ho = t >> 1;
+      if (ho >= Ho) continue;
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx) {
+        const int u = w + 1 - kx;
+        if (u < 0 || (u & 1)) continue;
+        const int wo = u >> 1;
+        if (wo >= Wo) continue;
+        float f[EPC];
+        chunk_to_f<T>(reinterpret_cast<const uint4*>(dp)[(((int64_t)b * Ho + ho) * Wo + wo) * cpr + (ky * 3 + kx) * cpt + cc], f);
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) acc[e] += f[e];
+      }
+    }
+    reinterpret_cast<uint4*>(dx)[i] = f_to_chunk<T>(acc);
+  }
+}
+
 __global__ __launch_bounds__(TPB) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                                    float* __restrict__ v, const float* __restrict__ wd_mask, bf16_t* __restrict__ shadow,
                                                    const int* __restrict__ step_dev, int64_t n, float lr, float b1, float b2, float eps, float wd,
@@ -315,6 +373,35 @@ extern "C" int lmv_token_mean2_bwd(const void* g, void* dx, int L, void* dc, int
   if (dtype == LMV_BF16) hipLaunchKernelGGL((token_mean2_bwd_kernel<bf16_t>), dim3(grid_for(tot)), dim3(TPB), 0, st, (const bf16_t*)g, (bf16_t*)dx, L, (bf16_t*)dc, Mx, C, B);
   else hipLaunchKernelGGL((token_mean2_bwd_kernel<float>), dim3(grid_for(tot)), dim3(TPB), 0, st, (const float*)g, (float*)dx, L, (float*)dc, Mx, C, B);
   LMV_CHECK_LAUNCH("token_mean2_bwd");
+  return LMV_OK;
+}
+
+static int conv_geom_check(const char* who, const void* a, const void* b, int B, int H, int W, int C, int KP, int dtype) {
+  if (B <= 0 || H <= 0 || W <= 0 || C <= 0 || (C % 8) || KP < 9 * C || (KP % 8)) LMV_FAIL(LMV_ERR_SHAPE, "%s: bad shape B=%d H=%d W=%d C=%d KP=%d", who, B, H, W, C, KP);
+  if (dtype != LMV_F32 && dtype != LMV_BF16) LMV_FAIL(LMV_ERR_DTYPE, "%s: unsupported dtype %d", who, dtype);
+  if (!a || !b || !lmv_aligned16(a) || !lmv_aligned16(b)) LMV_FAIL(LMV_ERR_SHAPE, "%s: null or misaligned operand", who);
+  return LMV_OK;
+}
+
+extern "C" int lmv_im2col3x3s2_nhwc(const void* x, void* patches, int B, int H, int W, int C, int KP, int dtype, void* stream) {
+  if (int rc = conv_geom_check("im2col3x3s2_nhwc", x, patches, B, H, W, C, KP, dtype)) return rc;
+  const int Ho = (H + 1) / 2, Wo = (W + 1) / 2;
+  const int64_t total = (int64_t)B * Ho * Wo * (KP / (dtype == LMV_BF16 ? 8 : 4));
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == LMV_BF16) hipLaunchKernelGGL((im2col_nhwc_kernel<bf16_t>), dim3(grid_for(total)), dim3(TPB), 0, st, (const bf16_t*)x, (bf16_t*)patches, B, H, W, C, Ho, Wo, KP);
+  else hipLaunchKernelGGL((im2col_nhwc_kernel<float>), dim3(grid_for(total)), dim3(TPB), 0, st, (const float*)x, (float*)patches, B, H, W, C, Ho, Wo, KP);
+  LMV_CHECK_LAUNCH("im2col3x3s2_nhwc");
+  return LMV_OK;
+}
+
+extern "C" int lmv_col2im3x3s2_nhwc(const void* dpatches, void* dx, int B, int H, int W, int C, int KP, int dtype, void* stream) {
+  if (int rc = conv_geom_check("col2im3x3s2_nhwc", dpatches, dx, B, H, W, C, KP, dtype)) return rc;
+  const int Ho = (H + 1) / 2, Wo = (W + 1) / 2;
+  const int64_t total = (int64_t)B * H * W * (C / (dtype == LMV_BF16 ? 8 : 4));
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == LMV_BF16) hipLaunchKernelGGL((col2im_nhwc_kernel<bf16_t>), dim3(grid_for(total)), dim3(TPB), 0, st, (const bf16_t*)dpatches, (bf16_t*)dx, B, H, W, C, Ho, Wo, KP);
+  else hipLaunchKernelGGL((col2im_nhwc_kernel<float>), dim3(grid_for(total)), dim3(TPB), 0, st, (const float*)dpatches, (float*)dx, B, H, W, C, Ho, Wo, KP);
+  LMV_CHECK_LAUNCH("col2im3x3s2_nhwc");
   return LMV_OK;
 }
 

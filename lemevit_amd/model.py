@@ -136,6 +136,75 @@ class _StemConv1Fn(torch.autograd.Function):
         return None, dw, (None if bdt is None else db.to(bdt)), None, None
 
 
+_conv_cache: dict = {}
+
+
+def _conv_matrix(weight: Tensor, dtype: torch.dtype, KP: int) -> Tensor:
+    """[Cout, Cin, 3, 3] weight -> the [Cout, KP] GEMM operand of ops.im2col3x3s2_nhwc: column (ky * 3 + kx) * Cin + ci, zero padding
+    behind 9 Cin.  Cached like _conv1_matrix (per parameter version AND training pass)."""
+    key = (id(weight), dtype, KP)
+    ent = _conv_cache.get(key)
+    stamp = (weight._version, _train_pass, torch.is_grad_enabled() and weight.requires_grad, weight.data_ptr())
+    if ent is not None and ent[0]() is weight and ent[1] == stamp:
+        return ent[2]
+    with torch.no_grad():
+        Co, Ci = weight.shape[0], weight.shape[1]
+        m = torch.zeros(Co, KP, device=weight.device, dtype=dtype)
+        m[:, :9 * Ci] = weight.detach().permute(0, 2, 3, 1).reshape(Co, 9 * Ci)
+    _conv_cache[key] = (weakref.ref(weight), stamp, m)
+    return m
+
+
+class _Conv3x3s2Fn(torch.autograd.Function):
+    """Conv2d(Cin, Cout, kernel 3, stride 2, padding 1) on a channels-last map as im2col + the block GEMM kernels (SURVEY section 8,
+    row f1; models/lemevit.py:701-703, :714-717): y = patches @ Wm^T + b, dW = dY^T @ patches, dX = col2im(dY @ Wm).  No MIOpen
+    solver search, no run-to-run differences in the gradients (the library's weight-gradient kernels are not reproducible)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, cd):
+        B, Ci, H, W = x.shape
+        Co = weight.shape[0]
+        xh = x.detach().permute(0, 2, 3, 1).to(cd).contiguous()            # NHWC; no copy for channels-last input of the right dtype
+        KP = (9 * Ci + 63) // 64 * 64 if cd == torch.bfloat16 else 9 * Ci  # bf16: whole 64-deep k-steps (the GEMM's LDS-DMA path)
+        patches = ops.im2col3x3s2_nhwc(xh, KP)
+        Wm = _conv_matrix(weight, cd, KP)
+        Ho, Wo = (H + 1) // 2, (W + 1) // 2
+        y = torch.empty(B * Ho * Wo, Co, device=x.device, dtype=cd)
+        b32 = None if bias is None else compute_copy(bias, torch.float32)
+        ops.linear_fwd([Prob(patches, Wm, y, bias=b32)], Co, KP)
+        ctx.save_for_backward(patches, Wm)
+        ctx.meta = (x.shape, x.dtype, weight.shape, weight.dtype, None if bias is None else bias.dtype)
+        return y.view(B, Ho, Wo, Co).permute(0, 3, 1, 2)                    # NCHW-shaped, channels-last-strided: no copy
+
+    @staticmethod
+    def backward(ctx, dy):
+        patches, Wm = ctx.saved_tensors
+        (B, Ci, H, W), xdt, wshape, wdt, bdt = ctx.meta
+        Co, KP = Wm.shape
+        g = dy.permute(0, 2, 3, 1).contiguous().view(-1, Co)
+        if g.dtype != patches.dtype:
+            g = g.to(patches.dtype)
+        dwm = torch.zeros(Co, KP, device=g.device, dtype=torch.float32)
+        db = torch.zeros(Co, device=g.device, dtype=torch.float32)
+        ops.linear_dw([Prob(g, patches, dwm, bias_grad=db)], Co, KP)
+        dw = dwm[:, :9 * Ci].reshape(Co, 3, 3, Ci).permute(0, 3, 1, 2).to(wdt)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dp = torch.empty_like(patches)
+            ops.linear_dx([Prob(g, Wm, dp)], Co, KP)
+            dx = ops.col2im3x3s2_nhwc(dp, B, H, W, Ci).permute(0, 3, 1, 2).to(xdt)
+        return dx, dw, (None if bdt is None else db.to(bdt)), None
+
+
+def _is_conv3x3s2(m: nn.Module, x: Tensor) -> bool:
+    return (_CONV_NATIVE and isinstance(m, nn.Conv2d) and m.kernel_size == (3, 3) and m.stride == (2, 2) and m.padding == (1, 1) and m.dilation == (1, 1)
+            and m.groups == 1 and m.in_channels % 8 == 0 and m.out_channels % 8 == 0 and m.padding_mode == "zeros" and x.is_cuda
+            and x.dtype in (torch.float32, torch.bfloat16) and m.weight.dtype == torch.float32)
+
+
+_CONV_NATIVE = os.environ.get("LMV_CONV_NATIVE", "1") != "0"          # A/B testing against MIOpen
+
+
 class _BNActFn(torch.autograd.Function):
     """Training-mode BatchNorm2d (+ the GELU behind the first stem BatchNorm) on a channels-last feature map
     (models/lemevit.py:698-704, 714-717, 773): lmv_batchnorm_train_fwd / _bwd instead of MIOpen's batch-norm kernels plus
@@ -727,11 +796,17 @@ class LeMeViT(nn.Module):
                     gelu = i + 2 < len(mods) and isinstance(mods[i + 2], nn.GELU) and getattr(mods[i + 2], "approximate", "none") == "none"
                     x = _StemConv1Fn.apply(x, w, b32, cd, gelu)
                     i += 3 if gelu else 2
+                elif _is_conv3x3s2(m, x) and cd in (torch.float32, torch.bfloat16):
+                    x = _Conv3x3s2Fn.apply(x, w, b32, cd)
+                    i += 2
                 else:
                     x = F.conv2d(x.to(w.dtype), w, b, m.stride, m.padding, m.dilation, m.groups)
                     i += 2
             elif _is_stem_conv1(m, x) and cd in (torch.float32, torch.bfloat16):
                 x = _StemConv1Fn.apply(x, m.weight, m.bias, cd)
+                i += 1
+            elif _is_conv3x3s2(m, x) and cd in (torch.float32, torch.bfloat16):
+                x = _Conv3x3s2Fn.apply(x, m.weight, m.bias, cd)
                 i += 1
             elif _bn_native(m, x):
                 gelu = i + 1 < len(mods) and isinstance(mods[i + 1], nn.GELU) and getattr(mods[i + 1], "approximate", "none") == "none"

@@ -307,6 +307,21 @@ def im2col3x3s2_c3(x: Tensor, dtype: torch.dtype) -> Tensor:
     return out
 
 
+def im2col3x3s2_nhwc(x: Tensor, KP: int) -> Tensor:
+    """x [B, H, W, C] (NHWC, contiguous) -> [B * ceil(H/2) * ceil(W/2), KP] patch matrix of a 3x3 / stride-2 / pad-1 convolution."""
+    B, H, W, C_ = x.shape
+    out = torch.empty(B * ((H + 1) // 2) * ((W + 1) // 2), KP, device=x.device, dtype=x.dtype)
+    check(lib.lmv_im2col3x3s2_nhwc(_ptr(x), _ptr(out), B, H, W, C_, KP, dtype_code(x), _stream()), "lmv_im2col3x3s2_nhwc")
+    return out
+
+
+def col2im3x3s2_nhwc(dpatches: Tensor, B: int, H: int, W: int, C_: int) -> Tensor:
+    """Gradient of im2col3x3s2_nhwc: [B * Ho * Wo, KP] -> [B, H, W, C]."""
+    dx = torch.empty((B, H, W, C_), device=dpatches.device, dtype=dpatches.dtype)
+    check(lib.lmv_col2im3x3s2_nhwc(_ptr(dpatches), _ptr(dx), B, H, W, C_, dpatches.shape[1], dtype_code(dpatches), _stream()), "lmv_col2im3x3s2_nhwc")
+    return dx
+
+
 def token_mean2_fwd(x: Tensor, c: Optional[Tensor]) -> Tensor:
     """out[b, :] = mean_l x[b, l, :] (+ mean_m c[b, m, :]) for token-major x [B, L, C], c [B, M, C]."""
     B, L, C_ = x.shape

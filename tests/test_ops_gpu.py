@@ -456,3 +456,30 @@ def test_linear_fwd_skinny(N, K):
     o.linear_fwd([o.Prob(ax, w1, ox)], N, K)
     sel = torch.arange(0, rows_x, 1013)
     assert_close(ox[sel], ax[sel].double().cpu() @ w1.double().cpu().t(), dtype, "skinny plain")
+
+
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("B,Ci,Co,H,W", [(2, 48, 96, 112, 112), (2, 96, 192, 56, 56), (2, 192, 384, 28, 28), (3, 384, 512, 14, 14), (1, 64, 128, 9, 7), (2, 8, 16, 5, 6)])
+def test_conv3x3s2_native(dtype, B, Ci, Co, H, W):
+    """Row f1: the second stem convolution and the three stage transitions of LeMeViT-Base (models/lemevit.py:701-703, :714-717) as
+    im2col + the block GEMM -- forward, data gradient (col2im gather) and weight / bias gradient vs float64 F.conv2d on the same
+    (rounded) operands; odd map sizes exercise the padding and the ragged last output row / column."""
+    from lemevit_amd.model import _Conv3x3s2Fn
+    x, x64 = rnd((B, Ci, H, W), "cx", dtype); w32 = det_tensor((Co, Ci, 3, 3), "cw", 7, 1.0 / math.sqrt(9 * Ci)); b32 = det_tensor((Co,), "cb", 7, 0.3)
+    wq = w32.to(dtype).double() if dtype == torch.bfloat16 else w32.double()
+    xg = x.contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    wg = w32.to(dev()).requires_grad_(True); bg = b32.to(dev()).requires_grad_(True)
+    y = _Conv3x3s2Fn.apply(xg, wg, bg, dtype)
+    x64 = x64.requires_grad_(True); w64 = wq.clone().requires_grad_(True); b64 = b32.double().requires_grad_(True)
+    ref = torch.nn.functional.conv2d(x64, w64, b64, stride=2, padding=1)
+    assert_close(y, ref.detach(), dtype, "conv fwd")
+    gy, gy64 = rnd(tuple(ref.shape), "cgy", dtype)
+    (y.float() * gy.float()).sum().backward()
+    (ref * gy64).sum().backward()
+    # dX = col2im(dY @ Wm): the GEMM stores its [rows, 9 Cin] result in bf16 and the gather then sums up to FOUR of those rounded
+    # partial sums per input pixel, so the bf16 bound is 4 operand roundings (4 * 2^-9 of the largest term) instead of one output
+    # rounding; measured worst case on MI355X: 1.6e-3 of max-abs beyond the single-rounding bound (Base stem shape).
+    assert_close(xg.grad, x64.grad, dtype, "conv dx", tol16=4e-3)
+    assert_close(wg.grad, w64.grad, torch.float32, "conv dw", tol32=2e-5 if dtype == torch.float32 else 2e-5 * 4)
+    assert_close(bg.grad, b64.grad, torch.float32, "conv db", tol32=2e-5)

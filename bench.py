@@ -204,7 +204,6 @@ def main():
         local = 0
     backend = os.environ.get("LMV_BENCH_BACKEND", "nccl")
     torch.cuda.set_device(local)
-    torch.backends.cudnn.benchmark = True      # as the reference's harness (benchmark.py:76): MIOpen searches its solvers for the stem / stage-transition convolutions
     dev = torch.device("cuda", local)
 
     import lemevit_amd

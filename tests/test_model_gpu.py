@@ -357,8 +357,8 @@ def test_flat_grad_sync_single_rank_nccl():
         sync = attach_flat_grad_sync(m2, o2, nchunks=3, force=True)
         assert sync.active and len(sync.bounds) == 3 and sync.bounds[0][0] == 0 and sync.bounds[-1][1] == o2._flat_g.numel()
         x = torch.randn(4, 3, 64, 64, device=DEV); y = torch.randint(0, 10, (4,), device=DEV)
-        for _ in range(1):                              # one step: MIOpen's convolution weight gradients are not run-to-run reproducible,
-            for m, o, s in ((m1, o1, None), (m2, o2, sync)):      # (neither are its data gradients), so only the LAST stage's parameters after the first step can be compared bit for bit
+        for _ in range(2):
+            for m, o, s in ((m1, o1, None), (m2, o2, sync)):
                 torch.manual_seed(7)                       # same DropPath draws for both twins
                 o.zero_grad()
                 if s is not None:
@@ -370,11 +370,10 @@ def test_flat_grad_sync_single_rank_nccl():
                     assert len(s._work) >= 1, "no chunk was released during the backward pass"
                     s.finish()
                 o.step()
+        # every kernel of the step is ours and reduces in a fixed order (round 2: the stem / stage-transition convolutions left MIOpen,
+        # whose weight gradients differed from run to run): the twins must agree BIT FOR BIT on every parameter of every stage
         for (n, p1), (_, p2) in zip(m1.named_parameters(), m2.named_parameters()):
-            if n.startswith("stages.4."):                  # the last stage: no MIOpen convolution between it and the loss
-                assert torch.equal(p1, p2), n
-            else:
-                assert float((p1 - p2).abs().max()) <= 2.5e-3, n     # at most the two lr-sized Adam moves of a ~zero-gradient entry
+            assert torch.equal(p1, p2), (n, float((p1 - p2).abs().max()))
     finally:
         if created:
             dist.destroy_process_group()

@@ -434,6 +434,149 @@ __global__ __launch_bounds__(256) void mfma_bwd_dkv_kernel(const AttnArgs a, con
   }
 }
 
+// =============================================================================================
+// backward, FUSED (round 2): ONE workgroup per (b, h) produces dQ, dK and dV for Lq, Lk <= 224 (the stage-3 / stage-4
+// self-attention).  Before, mfma_bwd_dq_long_kernel and mfma_bwd_dkv_kernel each staged their operands, recomputed S and dP and
+// exponentiated every score -- and the kernels are VALU-issue bound, so the exponentials were paid twice.  Here:
+//   * wave w owns the key tiles w, w + 4, ... (dK / dV accumulators in registers over ALL queries: no cross-wave reduce for them);
+//   * per 32-query block and key tile, S and dP come out ONCE in the D[q][key] orientation; P and dS (bf16) feed the dV / dK MFMAs
+//     directly as B operands, and dS is ALSO written to a wave-private 16 x 16 LDS tile [key][q] whose ds_read_b64_tr_b16 read is
+//     exactly the B operand dQ^T = K^T dS^T needs (k-slots = keys, lane = query): a hardware transpose instead of a recompute;
+//   * the four waves' dQ partials of a query block (each over its own key tiles) meet in LDS and leave in a fixed order.
+// LK > 0: compile-time key count (196 / 49): padding tiles are skipped, only the boundary tile is masked.
+// LDS: Q, dO, K images (<= 14 KB each) + 16 KB transposers + 16 KB dQ exchange = 77 KB: two workgroups per CU.
+// =============================================================================================
+template <int NKT, int LK = 0>
+__global__ __launch_bounds__(256, 2) void mfma_bwd_fused_kernel(const AttnArgs a) {
+  constexpr int TPW = (NKT + 3) / 4;          // key tiles per wave
+  constexpr int NP = (TPW + 1) / 2;           // 32-key pairs per wave for the dQ contraction
+  constexpr int NQ = NKT * 16;                // query rows staged (Lq <= NQ is guaranteed by the dispatcher)
+  __shared__ __attribute__((aligned(16))) unsigned char sQ[NQ * 64 + 1024], sG[NQ * 64 + 1024], sK[NQ * 64 + 1024];
+  __shared__ __attribute__((aligned(16))) float sL[NQ + 32], sDl[NQ + 32];
+  __shared__ __attribute__((aligned(16))) unsigned char sT[4][2][2 * NP][512];     // [wave][q tile][key tile slot][16 keys x 16 queries bf16]
+  __shared__ __attribute__((aligned(16))) float sRed[4][4][64][4];                  // [wave][q tile * 2 + d half][lane][4]
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), h = blockIdx.y, b = blockIdx.z;
+  const int g = lane >> 4;
+  const int Lk = LK ? LK : a.Lk, Lq = a.Lq;
+  const int nrows = ((Lq + 31) >> 5) << 5;
+  const int64_t bh = ((int64_t)b * a.H + h) * Lq;
+  const bf16_t* kb = reinterpret_cast<const bf16_t*>(a.k) + b * a.k_bs + h * D;
+  const bf16_t* vb = reinterpret_cast<const bf16_t*>(a.v) + b * a.v_bs + h * D;
+  stage_rows2<256>(sQ, reinterpret_cast<const bf16_t*>(a.q) + b * a.q_bs + h * D, a.q_rs, sG, reinterpret_cast<const bf16_t*>(a.d_o) + b * a.o_bs + h * D, a.o_rs, 0, nrows, Lq, tid);
+  stage_rows2<256>(sK, kb, a.k_rs, sK, kb, a.k_rs, 0, NKT * 16, Lk, tid);         // K image for the K^T fragments of dQ (second copy is the same store)
+  for (int i = tid; i < nrows; i += 256) {
+    const bool ok = i < Lq;
+    sL[i] = ok ? a.lse[bh + i] : 1e30f;           // exp(s - 1e30) = 0 masks the padded queries
+    float dl = 0.f;                               // delta = rowsum(dO * O) of query i
+    if (ok) {
+      const bf16_t* gp = reinterpret_cast<const bf16_t*>(a.d_o) + b * a.o_bs + (int64_t)i * a.o_rs + h * D;
+      const bf16_t* op = reinterpret_cast<const bf16_t*>(a.o) + b * a.o_bs + (int64_t)i * a.o_rs + h * D;
+      uint4 rg[4], ro[4];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) { rg[c] = *reinterpret_cast<const uint4*>(gp + c * 8); ro[c] = *reinterpret_cast<const uint4*>(op + c * 8); }
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        float gv[8], ov[8];
+        chunk_to_f<bf16_t>(rg[c], gv); chunk_to_f<bf16_t>(ro[c], ov);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) dl += gv[j] * ov[j];
+      }
+    }
+    sDl[i] = dl;
+  }
+  bf16x8_t kf[TPW], vf[TPW];
+  f32x4_t dk[TPW][2], dv[TPW][2];
+#pragma unroll
+  for (int i = 0; i < TPW; ++i) {
+    const int kt = wave + i * 4;
+    kf[i] = load_frag_global(kb, a.k_rs, kt * 16 + (lane & 15), (kt < NKT) ? Lk : 0, lane);
+    vf[i] = load_frag_global(vb, a.v_rs, kt * 16 + (lane & 15), (kt < NKT) ? Lk : 0, lane);
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt) { dk[i][dt] = f32x4_t{0.f, 0.f, 0.f, 0.f}; dv[i][dt] = f32x4_t{0.f, 0.f, 0.f, 0.f}; }
+  }
+  // the transposer tiles of key-tile slots this wave never fills stay zero (odd TPW, or tiles past the end)
+  for (int i = lane; i < 2 * 2 * NP * 512 / 16; i += 64) reinterpret_cast<uint4*>(&sT[wave][0][0][0])[i] = make_uint4(0, 0, 0, 0);
+  __syncthreads();
+  bf16_t* dqb = reinterpret_cast<bf16_t*>(a.dq) + b * a.q_bs + h * D;
+  for (int r0 = 0; r0 < nrows; r0 += 32) {
+    const bf16x8_t qn0 = frag_n(sQ, r0, lane), qn1 = frag_n(sQ, r0 + 16, lane);
+    const bf16x8_t gn0 = frag_n(sG, r0, lane), gn1 = frag_n(sG, r0 + 16, lane);
+    const bf16x8_t qt0 = frag_t(sQ, r0, r0 + 16, 0, lane), qt1 = frag_t(sQ, r0, r0 + 16, 16, lane);
+    const bf16x8_t gt0 = frag_t(sG, r0, r0 + 16, 0, lane), gt1 = frag_t(sG, r0, r0 + 16, 16, lane);
+    const float4 l0 = *reinterpret_cast<const float4*>(sL + r0 + g * 4), l1 = *reinterpret_cast<const float4*>(sL + r0 + 16 + g * 4);
+    const float4 d0 = *reinterpret_cast<const float4*>(sDl + r0 + g * 4), d1 = *reinterpret_cast<const float4*>(sDl + r0 + 16 + g * 4);
+    const float lse[8] = {l0.x, l0.y, l0.z, l0.w, l1.x, l1.y, l1.z, l1.w};
+    const float dl[8] = {d0.x, d0.y, d0.z, d0.w, d1.x, d1.y, d1.z, d1.w};
+#pragma unroll
+    for (int i = 0; i < TPW; ++i) {
+      const int kt = wave + i * 4;
+      if (kt >= NKT || kt * 16 >= Lk) continue;                      // wave-uniform: tile past the end
+      const bool kvalid = kt * 16 + (lane & 15) < Lk;
+      // D[q][key]: lane holds queries r0 + t * 16 + g * 4 + r of key (lane & 15)
+      const f32x4_t s0 = MFMA(qn0, kf[i], (f32x4_t{0.f, 0.f, 0.f, 0.f})), s1 = MFMA(qn1, kf[i], (f32x4_t{0.f, 0.f, 0.f, 0.f}));
+      const f32x4_t p0 = MFMA(gn0, vf[i], (f32x4_t{0.f, 0.f, 0.f, 0.f})), p1 = MFMA(gn1, vf[i], (f32x4_t{0.f, 0.f, 0.f, 0.f}));
+      f32x4_t pr[2], ds[2];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float e0 = kvalid ? __expf(s0[r] * a.scale - lse[r]) : 0.f, e1 = kvalid ? __expf(s1[r] * a.scale - lse[4 + r]) : 0.f;
+        pr[0][r] = e0; pr[1][r] = e1;
+        ds[0][r] = e0 * (p0[r] - dl[r]) * a.scale; ds[1][r] = e1 * (p1[r] - dl[4 + r]) * a.scale;
+      }
+      const bf16x8_t pf = pack8(pr[0], pr[1]), dsf = pack8(ds[0], ds[1]);
+      dv[i][0] = MFMA(gt0, pf, dv[i][0]); dv[i][1] = MFMA(gt1, pf, dv[i][1]);
+      dk[i][0] = MFMA(qt0, dsf, dk[i][0]); dk[i][1] = MFMA(qt1, dsf, dk[i][1]);
+      // dS tiles -> the wave's transposers: row = key, 4 consecutive queries (8 bytes) at column g * 4
+      const uint4 w = __builtin_bit_cast(uint4, dsf);
+      *reinterpret_cast<uint2*>(&sT[wave][0][i][(lane & 15) * 32 + g * 8]) = make_uint2(w.x, w.y);
+      *reinterpret_cast<uint2*>(&sT[wave][1][i][(lane & 15) * 32 + g * 8]) = make_uint2(w.z, w.w);
+    }
+    // ---- this wave's share of dQ^T[d][q] = sum over its keys of K^T[d][key] dS^T[key][q] ------------------------------------
+    f32x4_t dq[2][2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) { dq[t][0] = f32x4_t{0.f, 0.f, 0.f, 0.f}; dq[t][1] = f32x4_t{0.f, 0.f, 0.f, 0.f}; }
+    {
+      const int rr = (lane & 15) >> 2, qq = lane & 3;
+#pragma unroll
+      for (int pp = 0; pp < NP; ++pp) {
+        const int kta = wave + (2 * pp) * 4, ktb = wave + (2 * pp + 1) * 4;       // the two key tiles of this 32-key pair
+        if (kta >= NKT || kta * 16 >= Lk) continue;
+        const int rowb = (2 * pp + 1 < TPW && ktb < NKT) ? ktb * 16 : kta * 16;    // (a missing second tile multiplies zeros)
+        const bf16x8_t ka = frag_t(sK, kta * 16, rowb, 0, lane), kb2 = frag_t(sK, kta * 16, rowb, 16, lane);
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          const bf16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds4_t)(&sT[wave][t][2 * pp][(g * 4 + rr) * 32 + qq * 8]));
+          const bf16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds4_t)(&sT[wave][t][2 * pp + 1][(g * 4 + rr) * 32 + qq * 8]));
+          const bf16x8_t dst = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+          dq[t][0] = MFMA(ka, dst, dq[t][0]); dq[t][1] = MFMA(kb2, dst, dq[t][1]);
+        }
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int hh = 0; hh < 2; ++hh) *reinterpret_cast<f32x4_t*>(&sRed[wave][t * 2 + hh][lane][0]) = dq[t][hh];
+    __syncthreads();
+    if (wave < 2) {                               // wave t sums the four partials of query tile t in wave order and stores the rows
+      f32x4_t x0 = {0.f, 0.f, 0.f, 0.f}, x1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int w = 0; w < 4; ++w) {
+        x0 += *reinterpret_cast<const f32x4_t*>(&sRed[w][wave * 2][lane][0]);
+        x1 += *reinterpret_cast<const f32x4_t*>(&sRed[w][wave * 2 + 1][lane][0]);
+      }
+      const int q = r0 + wave * 16 + (lane & 15);
+      if (q < Lq) store8(dqb + (int64_t)q * a.q_rs, g, x0, x1);
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int i = 0; i < TPW; ++i) {
+    const int kt = wave + i * 4, key = kt * 16 + (lane & 15);
+    if (kt >= NKT || key >= Lk) continue;
+    store8(reinterpret_cast<bf16_t*>(a.dk) + b * a.k_bs + (int64_t)key * a.k_rs + h * D, g, dk[i][0], dk[i][1]);
+    store8(reinterpret_cast<bf16_t*>(a.dv) + b * a.v_bs + (int64_t)key * a.v_rs + h * D, g, dv[i][0], dv[i][1]);
+  }
+}
+
 // fp32 [B][H][LP][32] accumulator -> strided bf16 rows (first L rows)
 __global__ __launch_bounds__(256) void scatter_bf16_kernel(const float* __restrict__ acc, bf16_t* __restrict__ dst, int64_t bs, int64_t rs, int B, int H,
                                                           int L, int LP) {
@@ -1157,6 +1300,18 @@ int lmv_attn_mfma_fwd(const AttnArgs& a, hipStream_t st) {
 int lmv_attn_mfma_bwd(const AttnArgs& a, float* delta, float* acc, hipStream_t st) {
   const int per = qt_per_block_for(a), nqt = (a.Lq + 15) / 16, nkt = nkt_for(a.Lk);
   static const bool fuse_dq = [] { const char* e = getenv("LMV_ATTN_FUSE_DQ"); return e ? atoi(e) != 0 : true; }();      // A/B testing
+  static const bool fused_bwd = [] { const char* e = getenv("LMV_ATTN_FUSED_BWD"); return e ? atoi(e) != 0 : true; }();  // A/B testing
+  if (fused_bwd && nkt >= 4 && a.Lq > 16 && a.Lq <= nkt * 16) {
+    // one workgroup per (b, h): dQ, dK and dV from ONE pass over the scores
+    dim3 grid(1, a.H, a.B), block(256);
+    if (a.Lk == 196) hipLaunchKernelGGL((mfma_bwd_fused_kernel<14, 196>), grid, block, 0, st, a);
+    else if (a.Lk == 49) hipLaunchKernelGGL((mfma_bwd_fused_kernel<4, 49>), grid, block, 0, st, a);
+    else if (nkt == 4) hipLaunchKernelGGL((mfma_bwd_fused_kernel<4>), grid, block, 0, st, a);
+    else if (nkt == 8) hipLaunchKernelGGL((mfma_bwd_fused_kernel<8>), grid, block, 0, st, a);
+    else hipLaunchKernelGGL((mfma_bwd_fused_kernel<14>), grid, block, 0, st, a);
+    LMV_CHECK_LAUNCH("attn_mfma_bwd_fused");
+    return LMV_OK;
+  }
   if (nkt == 14 && a.Lq > 16) {
     // 129..224 keys: the run-time-bound dQ loop (86 registers, 5 waves per SIMD) beats the fully unrolled one (169 registers, 2)
     int nk, pr, lds;

@@ -72,6 +72,22 @@ int lmv_linear_fwd(const lmv_linear_problem* p, int nproblems, int N, int K, int
 int lmv_linear_dx(const lmv_linear_problem* p, int nproblems, int N, int K, int act, int dtype, void* stream);
 size_t lmv_linear_dw_workspace_bytes(const lmv_linear_problem* p, int nproblems, int N, int K, int dtype);
 int lmv_linear_dw(const lmv_linear_problem* p, int nproblems, int N, int K, void* workspace, size_t workspace_bytes, int dtype, void* stream);
+/* Deferred form: only the split-K GEMM is launched; the partial slabs stay in `workspace` (which must then stay untouched until
+ * they are summed) and up to 2 reduce segments describing them are written to segs[0 .. *nsegs).  lmv_reduce_batch sums the slabs
+ * of any number of segments -- the weight gradients of a whole block -- into their out_w / out_b (accumulating, fixed summation
+ * order: bit-identical to lmv_linear_dw) in ONE launch per LMV_REDUCE_MAX_SEGS segments. */
+#define LMV_REDUCE_MAX_SEGS 12
+typedef struct {
+  const float* ws;        /* first slab of the segment: [nslabs][slab_stride] fp32, a slab = [nw weights | nb bias sums]   */
+  float* out_w;           /* fp32 [nw], accumulated                                                                          */
+  float* out_b;           /* fp32 [nb], accumulated; NULL = no bias gradient                                                  */
+  int64_t slab_stride;    /* floats between consecutive slabs                                                                 */
+  int64_t nw;
+  int32_t nslabs, nb;
+} lmv_reduce_seg;
+int lmv_linear_dw_partial(const lmv_linear_problem* p, int nproblems, int N, int K, void* workspace, size_t workspace_bytes, int dtype, void* stream,
+                          lmv_reduce_seg* segs, int* nsegs);
+int lmv_reduce_batch(const lmv_reduce_seg* segs, int nsegs, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * LayerNorm over the last dim (nn.LayerNorm, models/lemevit.py:513,525 eps 1e-6; :731-743,774

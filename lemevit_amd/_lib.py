@@ -23,6 +23,11 @@ class LinearProblem(C.Structure):
                 ("bias_grad", C.c_void_p), ("rows", C.c_int64), ("rows_per_sample", C.c_int32), ("_pad", C.c_int32)]
 
 
+class ReduceSeg(C.Structure):
+    _fields_ = [("ws", C.c_void_p), ("out_w", C.c_void_p), ("out_b", C.c_void_p), ("slab_stride", C.c_int64), ("nw", C.c_int64),
+                ("nslabs", C.c_int32), ("nb", C.c_int32)]
+
+
 class LnSegment(C.Structure):
     _fields_ = [("x", C.c_void_p), ("y", C.c_void_p), ("stats", C.c_void_p), ("dy", C.c_void_p), ("dres", C.c_void_p),
                 ("dx", C.c_void_p), ("rows", C.c_int64), ("dx_scale", C.c_void_p), ("dx_scaled", C.c_void_p), ("rows_per_sample", C.c_int64)]
@@ -51,6 +56,8 @@ SIGNATURES = {
     "lmv_linear_dx": (_I, [C.POINTER(LinearProblem), _I, _I, _I, _I, _I, _P]),
     "lmv_linear_dw_workspace_bytes": (_Z, [C.POINTER(LinearProblem), _I, _I, _I, _I]),
     "lmv_linear_dw": (_I, [C.POINTER(LinearProblem), _I, _I, _I, _P, _Z, _I, _P]),
+    "lmv_linear_dw_partial": (_I, [C.POINTER(LinearProblem), _I, _I, _I, _P, _Z, _I, _P, C.POINTER(ReduceSeg), C.POINTER(C.c_int)]),
+    "lmv_reduce_batch": (_I, [C.POINTER(ReduceSeg), _I, _P]),
     "lmv_layernorm_fwd": (_I, [C.POINTER(LnSegment), _I, _P, _P, _I, _F, _I, _P]),
     "lmv_layernorm_gelu_fwd": (_I, [C.POINTER(LnSegment), _I, _P, _P, _I, _F, _I, _P]),
     "lmv_layernorm_gelu_bwd": (_I, [C.POINTER(LnSegment), _I, _P, _P, _P, _P, _I, _P, _Z, _I, _P]),

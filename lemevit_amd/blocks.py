@@ -68,11 +68,25 @@ def _fork(dev) -> Optional[int]:
     return raw
 
 
+# The split-K reductions of a block's weight gradients are deferred (ops.DwBatch) and summed by ONE launch at the end of the block's
+# backward pass instead of one ~7 us launch behind every GEMM (LMV_DW_BATCH=0: the per-GEMM path, for A/B runs).
+_DW_BATCH = os.environ.get("LMV_DW_BATCH", "0") != "0"      # measured: 0.5 ms SLOWER per step (the slabs of a whole block leave the MALL before they are read back)
+_batches: Dict[tuple, "ops.DwBatch"] = {}
+
+
 def _dw(probs, N: int, K: int) -> None:
-    raw = _fork(probs[0].a.device)
-    ops.linear_dw(probs, N, K, stream=raw)          # launched on the side stream by handle: no current-stream switch
+    dev = probs[0].a.device
+    raw = _fork(dev)
+    batch = None
+    if _DW_BATCH:
+        batch = _batches.get((dev.index, raw))
+        if batch is None:
+            batch = _batches[(dev.index, raw)] = ops.DwBatch()
+    ops.linear_dw(probs, N, K, stream=raw, batch=batch)          # launched on the side stream by handle: no current-stream switch
     if raw is not None:
-        _inflight.append((probs[0].a.device.index, probs))
+        _inflight.append((dev.index, probs))
+    elif batch is not None:
+        batch.keep.append(probs)
 
 
 def _dwconv_w(dy: Tensor, x: Tensor, dweight: Tensor, dbias: Tensor, H: int, W: int) -> None:
@@ -83,6 +97,9 @@ def _dwconv_w(dy: Tensor, x: Tensor, dweight: Tensor, dbias: Tensor, H: int, W: 
 
 
 def _join() -> None:
+    for (di, raw), batch in _batches.items():
+        if batch.segs:
+            batch.flush(stream=raw)                 # one reduce launch for every weight gradient of the block, behind its GEMMs
     if _inflight:
         side, _, _, join = _side_streams[_inflight[-1][0]]
         join.record(side)
@@ -93,7 +110,7 @@ def _join() -> None:
 # The meta-token self-attention of an S block (16 tokens: B * h tiny workgroups, ~13 us of mostly launch ramp and tail per
 # direction) is independent of the image-token attention next to it: it is launched on a SECOND side stream by raw handle and
 # joined before the projection that consumes both, so it runs inside the image-token kernel's shadow.
-_META_SIDE = os.environ.get("LMV_META_SIDE_STREAM", "1") != "0"
+_META_SIDE = os.environ.get("LMV_META_SIDE_STREAM", "0") != "0"      # measured: 0.3 ms SLOWER per step (4 stream-wait API calls per block for ~20 us of hidden kernels); kept as an A/B switch
 _meta_streams: Dict[int, tuple] = {}
 
 

@@ -669,6 +669,51 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
   *reinterpret_cast<float4*>(o) = c;
 }
 
+// The same reduction for up to LMV_REDUCE_MAX_SEGS weight gradients in ONE launch (lmv_reduce_batch): a block-backward pass used to
+// end every dW GEMM with its own ~7 us reduce launch (~160 per train step, mostly launch ramp and tail); the GEMMs of a block now
+// leave their slabs in distinct workspace regions and one launch sums them all.  Same fixed summation tree per element as
+// splitk_reduce_kernel<SL> (sl slab lanes per element, chosen per segment), so results are bit-identical to the per-GEMM path.
+struct ReduceSegDev { const float* ws; float* out_w; float* out_b; int64_t stride, nw; int nslabs, nb, sl, blk0; };
+struct ReduceBatch { ReduceSegDev s[LMV_REDUCE_MAX_SEGS]; int n; };
+
+__global__ __launch_bounds__(256) void splitk_reduce_batch_kernel(const ReduceBatch rb) {
+  __shared__ float4 red[256];
+  int si = 0;
+#pragma unroll
+  for (int k = 1; k < LMV_REDUCE_MAX_SEGS; ++k) if (k < rb.n && (int)blockIdx.x >= rb.s[k].blk0) si = k;
+  const ReduceSegDev& g = rb.s[si];
+  const int SL = g.sl, EL = 256 / SL;
+  const int64_t n4 = (g.nw + (g.out_b ? g.nb : 0)) >> 2;
+  const int e = threadIdx.x % EL, sl = threadIdx.x / EL;
+  const int64_t i = (int64_t)((int)blockIdx.x - g.blk0) * EL + e;
+  float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (i < n4) {
+    const float* p = g.ws + i * 4;
+#pragma unroll 8
+    for (int s = sl; s < g.nslabs; s += SL) {
+      const float4 v = *reinterpret_cast<const float4*>(p + (int64_t)s * g.stride);
+      a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+    }
+  }
+  if (SL > 1) {                                   // block-uniform
+    red[threadIdx.x] = a;
+    __syncthreads();
+    if (sl != 0) return;
+    for (int l = 1; l < SL; ++l) { const float4 v = red[l * EL + e]; a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w; }
+  }
+  if (i >= n4) return;
+  float* o = (i * 4 < g.nw) ? g.out_w + i * 4 : g.out_b + (i * 4 - g.nw);
+  float4 c = *reinterpret_cast<float4*>(o);
+  c.x += a.x; c.y += a.y; c.z += a.z; c.w += a.w;
+  *reinterpret_cast<float4*>(o) = c;
+}
+
+static int reduce_lanes(int64_t n4, int nslabs) {      // slab lanes: enough blocks to fill the chip, and at most ~32 serial slab reads per thread
+  int sl = 1;
+  while (sl < 16 && (n4 * sl < 256 * 256 || nslabs > 32 * sl) && nslabs >= 4 * sl) sl *= 4;
+  return sl;
+}
+
 enum Mode { MODE_FWD = 0, MODE_DX = 1, MODE_DW = 2 };
 enum Tile { TILE_128 = 0, TILE_256x128 = 1, TILE_256 = 2, TILE_128W8 = 3 };
 
@@ -918,7 +963,8 @@ int launch_mode(const Plan& pl, dim3 grid, bool bf, hipStream_t st) {
   }
 }
 
-int launch(const lmv_linear_problem* p, int nproblems, int N, int K, int act, int dtype, void* stream, Mode mode, void* ws, size_t ws_bytes) {
+int launch(const lmv_linear_problem* p, int nproblems, int N, int K, int act, int dtype, void* stream, Mode mode, void* ws, size_t ws_bytes,
+           lmv_reduce_seg* segs = nullptr, int* nsegs = nullptr) {
   Plan pl;
   if (int rc = make_plan(p, nproblems, N, K, act, dtype, mode, &pl)) return rc;
   GemmArgs& g = pl.g;
@@ -954,9 +1000,12 @@ int launch(const lmv_linear_problem* p, int nproblems, int N, int K, int act, in
       const float* base = g.ws + (int64_t)g.slab_base[i] * g.slab_stride;
       const int64_t n4 = (nw + (p[i].bias_grad ? N : 0)) / 4;
       float* outw = reinterpret_cast<float*>(p[i].out);
-      // slab lanes: enough blocks to fill the chip, and at most ~32 serial slab reads per thread
-      int sl = 1;
-      while (sl < 16 && (n4 * sl < 256 * 256 || nslabs > 32 * sl) && nslabs >= 4 * sl) sl *= 4;
+      if (segs) {                                  // deferred: the caller sums the slabs later with lmv_reduce_batch
+        lmv_reduce_seg& sg = segs[(*nsegs)++];
+        sg.ws = base; sg.nslabs = nslabs; sg.slab_stride = g.slab_stride; sg.out_w = outw; sg.nw = nw; sg.out_b = p[i].bias_grad; sg.nb = N;
+        continue;
+      }
+      const int sl = reduce_lanes(n4, nslabs);
       const int blocks = (int)((n4 * sl + 255) / 256);
       if (sl == 1) hipLaunchKernelGGL(splitk_reduce_kernel<1>, dim3(blocks), dim3(256), 0, st, base, nslabs, g.slab_stride, outw, nw, p[i].bias_grad, N);
       else if (sl == 4) hipLaunchKernelGGL(splitk_reduce_kernel<4>, dim3(blocks), dim3(256), 0, st, base, nslabs, g.slab_stride, outw, nw, p[i].bias_grad, N);
@@ -986,4 +1035,37 @@ extern "C" size_t lmv_linear_dw_workspace_bytes(const lmv_linear_problem* p, int
 }
 extern "C" int lmv_linear_dw(const lmv_linear_problem* p, int nproblems, int N, int K, void* workspace, size_t workspace_bytes, int dtype, void* stream) {
   return launch(p, nproblems, N, K, LMV_ACT_NONE, dtype, stream, MODE_DW, workspace, workspace_bytes);
+}
+
+extern "C" int lmv_linear_dw_partial(const lmv_linear_problem* p, int nproblems, int N, int K, void* workspace, size_t workspace_bytes, int dtype, void* stream,
+                                     lmv_reduce_seg* segs, int* nsegs) {
+  if (!segs || !nsegs) LMV_FAIL(LMV_ERR_SHAPE, "linear_dw_partial: segs / nsegs must not be NULL");
+  *nsegs = 0;
+  return launch(p, nproblems, N, K, LMV_ACT_NONE, dtype, stream, MODE_DW, workspace, workspace_bytes, segs, nsegs);
+}
+
+extern "C" int lmv_reduce_batch(const lmv_reduce_seg* segs, int nsegs, void* stream) {
+  if (nsegs <= 0) return LMV_OK;
+  if (!segs) LMV_FAIL(LMV_ERR_SHAPE, "reduce_batch: segs is NULL");
+  hipStream_t st = (hipStream_t)stream;
+  for (int s0 = 0; s0 < nsegs; s0 += LMV_REDUCE_MAX_SEGS) {
+    ReduceBatch rb{};
+    rb.n = nsegs - s0 < LMV_REDUCE_MAX_SEGS ? nsegs - s0 : LMV_REDUCE_MAX_SEGS;
+    int blocks = 0;
+    for (int i = 0; i < rb.n; ++i) {
+      const lmv_reduce_seg& q = segs[s0 + i];
+      if (!q.ws || !q.out_w || q.nslabs <= 0 || q.nw <= 0 || (q.nw % 4) || (q.out_b && (q.nb % 4)) || !lmv_aligned16(q.ws) || !lmv_aligned16(q.out_w) ||
+          !lmv_aligned16(q.out_b) || (q.slab_stride % 4))
+        LMV_FAIL(LMV_ERR_SHAPE, "reduce_batch: bad segment %d", s0 + i);
+      const int64_t n4 = (q.nw + (q.out_b ? q.nb : 0)) / 4;
+      ReduceSegDev& d = rb.s[i];
+      d.ws = q.ws; d.out_w = q.out_w; d.out_b = q.out_b; d.stride = q.slab_stride; d.nw = q.nw; d.nslabs = q.nslabs; d.nb = q.nb;
+      d.sl = reduce_lanes(n4, q.nslabs);
+      d.blk0 = blocks;
+      blocks += (int)((n4 * d.sl + 255) / 256);
+    }
+    hipLaunchKernelGGL(splitk_reduce_batch_kernel, dim3(blocks), dim3(256), 0, st, rb);
+  }
+  LMV_CHECK_LAUNCH("reduce_batch");
+  return LMV_OK;
 }

@@ -106,11 +106,52 @@ def linear_dx(probs: Sequence[Prob], N: int, K: int, act: int = ACT_NONE) -> Non
     check(lib.lmv_linear_dx(_pack(probs), len(probs), N, K, act, dtype_code(probs[0].a), _stream()), "lmv_linear_dx")
 
 
-def linear_dw(probs: Sequence[Prob], N: int, K: int, stream: Optional[int] = None) -> None:
+class DwBatch:
+    """Deferred split-K reductions (lmv_linear_dw_partial / lmv_reduce_batch): the weight-gradient GEMMs of a block leave their
+    partial slabs in distinct regions of one arena; flush() sums them all in one launch."""
+
+    def __init__(self):
+        self.segs: List[_lib.ReduceSeg] = []
+        self.keep: List[object] = []          # arenas (and operands) that must outlive the pending launches
+        self.arena: Optional[Tensor] = None
+        self.used = 0
+
+    def alloc(self, nbytes: int, device, stream: int) -> int:
+        nbytes = (nbytes + 255) // 256 * 256
+        if self.arena is None or self.used + nbytes > self.arena.numel():
+            if self.arena is not None:
+                self.keep.append(self.arena)      # pending segments still point into it
+            size = max(nbytes * 4, (self.arena.numel() * 2 if self.arena is not None else 1 << 26))
+            self.arena = torch.empty(size, device=device, dtype=torch.uint8)
+            self.arena.record_stream(torch.cuda.ExternalStream(stream, device=device))
+            self.used = 0
+        off = self.used
+        self.used += nbytes
+        return self.arena.data_ptr() + off
+
+    def flush(self, stream: Optional[int] = None) -> None:
+        if self.segs:
+            arr = (_lib.ReduceSeg * len(self.segs))(*self.segs)
+            check(lib.lmv_reduce_batch(arr, len(self.segs), _stream() if stream is None else stream), "lmv_reduce_batch")
+        self.segs.clear(); self.keep.clear()
+        self.used = 0
+
+
+def linear_dw(probs: Sequence[Prob], N: int, K: int, stream: Optional[int] = None, batch: Optional[DwBatch] = None) -> None:
     """out (fp32 [N,K]) += a^T @ w ; bias_grad (fp32 [N]) += colsum(a); a = dY [rows,N], w = X [rows,K].
-    stream: raw HIP stream handle to launch on (default: the current stream); the scratch is per stream."""
+    stream: raw HIP stream handle to launch on (default: the current stream); the scratch is per stream.
+    batch: defer the slab reduction to batch.flush() (same stream), which sums the slabs of every pending GEMM in one launch."""
     arr, code = _pack(probs), dtype_code(probs[0].a)
     st = _stream() if stream is None else stream
+    if batch is not None:
+        nb = lib.lmv_linear_dw_workspace_bytes(arr, len(probs), N, K, code)
+        ws = batch.alloc(max(nb, 256), probs[0].a.device, st)
+        segs = (_lib.ReduceSeg * 2)()
+        n = C.c_int(0)
+        check(lib.lmv_linear_dw_partial(arr, len(probs), N, K, ws, max(nb, 256), code, st, segs, C.byref(n)), "lmv_linear_dw_partial")
+        for i in range(n.value):
+            batch.segs.append(_lib.ReduceSeg.from_buffer_copy(segs[i]))
+        return
     ws = _workspace(lib.lmv_linear_dw_workspace_bytes(arr, len(probs), N, K, code), probs[0].a.device, st)
     check(lib.lmv_linear_dw(arr, len(probs), N, K, ws.data_ptr(), ws.numel(), code, st), "lmv_linear_dw")
 

@@ -182,6 +182,11 @@ typedef struct {
 size_t lmv_attn_workspace_bytes(int B, int H, int Lq, int Lk, int backward);
 int lmv_attn_fwd(const lmv_attn_desc* d, void* workspace, size_t workspace_bytes, int dtype, void* stream);
 int lmv_attn_bwd(const lmv_attn_desc* d, void* workspace, size_t workspace_bytes, int dtype, void* stream);
+/* Two independent problems d[0], d[1] with the same B and H -- the image-token and the meta-token self-attention of an "S" block
+ * (models/lemevit.py:632,634) -- in ONE launch where the shapes allow (bf16, 196 / 49 + 16 tokens), otherwise as two launches.
+ * The workspace must be large enough for either problem (max of lmv_attn_workspace_bytes). */
+int lmv_attn_fwd_pair(const lmv_attn_desc* d, void* workspace, size_t workspace_bytes, int dtype, void* stream);
+int lmv_attn_bwd_pair(const lmv_attn_desc* d, void* workspace, size_t workspace_bytes, int dtype, void* stream);
 
 /* Named cores of the reference seam; thin wrappers that fill an lmv_attn_desc.
  *   sa : StandardAttention      qkv [B,L,3C] -> o [B,L,C]                        (:199-205)

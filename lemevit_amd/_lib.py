@@ -73,6 +73,8 @@ SIGNATURES = {
     "lmv_attn_workspace_bytes": (_Z, [_I, _I, _I, _I, _I]),
     "lmv_attn_fwd": (_I, [C.POINTER(AttnDesc), _P, _Z, _I, _P]),
     "lmv_attn_bwd": (_I, [C.POINTER(AttnDesc), _P, _Z, _I, _P]),
+    "lmv_attn_fwd_pair": (_I, [C.POINTER(AttnDesc), _P, _Z, _I, _P]),
+    "lmv_attn_bwd_pair": (_I, [C.POINTER(AttnDesc), _P, _Z, _I, _P]),
     "lmv_sa_core_fwd": (_I, [_P, _P, _P, _I, _I, _I, _P, _Z, _I, _P]),
     "lmv_ca_core_fwd": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P, _Z, _I, _P]),
     "lmv_dca_core_fwd": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _Z, _I, _P]),

@@ -182,7 +182,9 @@ def _attn_S_fwd(P, ts, ds, save):
     xn, st = ops.layernorm_fwd_multi(ts, P["norm1.weight"], P["norm1.bias"], BLOCK_LN_EPS, want_stats=save)
     qkv = [_empty(t, 3 * C) for t in ts]
     ops.linear_fwd([Prob(a, P["attn.qkv.weight"], o, bias=P["attn.qkv.bias"]) for a, o in zip(xn, qkv)], 3 * C, C)
-    if len(qkv) == 2:
+    if len(qkv) == 2 and not _META_SIDE:
+        ao, lse = ops.attn_fwd_pair(qkv, C, ops.SDPA_SCALE, want_lse=save)      # image tokens + meta tokens: one launch
+    elif len(qkv) == 2:
         raw = _meta_fork(qkv[1].device)
         ao_c, lse_c = ops.attn_fwd((qkv[1], 0), (qkv[1], C), (qkv[1], 2 * C), C, ops.SDPA_SCALE, want_lse=save, stream=raw)
         ao_x, lse_x = ops.attn_fwd((qkv[0], 0), (qkv[0], C), (qkv[0], 2 * C), C, ops.SDPA_SCALE, want_lse=save)
@@ -204,12 +206,15 @@ def _attn_S_bwd(P, G, saved, douts, ds, g=None):
     dao = [torch.empty_like(t) for t in ts]
     ops.linear_dx([Prob(gi, P["attn.proj.weight"], o) for gi, o in zip(g, dao)], C, C)
     dqkv = [torch.empty_like(q) for q in qkv]
-    raw = _meta_fork(qkv[1].device) if len(qkv) == 2 else None
-    for i in reversed(range(len(qkv))):              # meta tokens first (side stream), image tokens on the main stream
-        q, a, l, da, dq = qkv[i], ao[i], lse[i], dao[i], dqkv[i]
-        ops.attn_bwd((q, 0), (q, C), (q, 2 * C), a, l, da, (dq, 0), (dq, C), (dq, 2 * C), C, ops.SDPA_SCALE, stream=raw if i == 1 else None)
-    if raw is not None:
-        _meta_join(qkv[1].device)
+    if len(qkv) == 2 and not _META_SIDE:
+        ops.attn_bwd_pair(qkv, ao, lse, dao, dqkv, C, ops.SDPA_SCALE)
+    else:
+        raw = _meta_fork(qkv[1].device) if len(qkv) == 2 else None
+        for i in reversed(range(len(qkv))):              # meta tokens first (side stream), image tokens on the main stream
+            q, a, l, da, dq = qkv[i], ao[i], lse[i], dao[i], dqkv[i]
+            ops.attn_bwd((q, 0), (q, C), (q, 2 * C), a, l, da, (dq, 0), (dq, C), (dq, 2 * C), C, ops.SDPA_SCALE, stream=raw if i == 1 else None)
+        if raw is not None:
+            _meta_join(qkv[1].device)
     _dw([Prob(dq, xi, G["attn.qkv.weight"], bias_grad=G["attn.qkv.bias"]) for dq, xi in zip(dqkv, xn)], 3 * C, C)
     dxn = [torch.empty_like(t) for t in ts]
     ops.linear_dx([Prob(dq, P["attn.qkv.weight"], o) for dq, o in zip(dqkv, dxn)], 3 * C, C)

@@ -461,6 +461,41 @@ extern "C" size_t lmv_attn_workspace_bytes(int B, int H, int Lq, int Lk, int bac
   return align256((size_t)B * H * Lq * sizeof(float)) + align256(acc);
 }
 
+/* Two independent attention problems (same B and H): the image-token and the meta-token self-attention of an S block.  bf16 problems
+ * of the model's hot shapes run as ONE launch; anything else as two.  The workspace must satisfy lmv_attn_workspace_bytes of both. */
+extern "C" int lmv_attn_fwd_pair(const lmv_attn_desc* d, void* ws, size_t ws_bytes, int dtype, void* stream) {
+  for (int i = 0; i < 2; ++i)
+    if (int rc = check_desc(d + i, dtype, false)) return rc;
+  if (dtype == LMV_BF16) {
+    const Args a1 = to_args(d), a2 = to_args(d + 1);
+    if (lmv_attn_mfma_supported(a1) && lmv_attn_mfma_supported(a2) && lmv_attn_mfma_fwd_pair(a1, a2, (hipStream_t)stream)) {
+      LMV_CHECK_LAUNCH("attn_fwd_pair");
+      return LMV_OK;
+    }
+  }
+  for (int i = 0; i < 2; ++i) {
+    const int rc = dtype == LMV_BF16 ? fwd_impl<bf16_t>(d + i, ws, ws_bytes, (hipStream_t)stream) : fwd_impl<float>(d + i, ws, ws_bytes, (hipStream_t)stream);
+    if (rc) return rc;
+  }
+  return LMV_OK;
+}
+extern "C" int lmv_attn_bwd_pair(const lmv_attn_desc* d, void* ws, size_t ws_bytes, int dtype, void* stream) {
+  for (int i = 0; i < 2; ++i)
+    if (int rc = check_desc(d + i, dtype, true)) return rc;
+  if (dtype == LMV_BF16) {
+    const Args a1 = to_args(d), a2 = to_args(d + 1);
+    if (lmv_attn_mfma_supported(a1) && lmv_attn_mfma_supported(a2) && lmv_attn_mfma_bwd_pair(a1, a2, (hipStream_t)stream)) {
+      LMV_CHECK_LAUNCH("attn_bwd_pair");
+      return LMV_OK;
+    }
+  }
+  for (int i = 0; i < 2; ++i) {
+    const int rc = dtype == LMV_BF16 ? bwd_impl<bf16_t>(d + i, ws, ws_bytes, (hipStream_t)stream) : bwd_impl<float>(d + i, ws, ws_bytes, (hipStream_t)stream);
+    if (rc) return rc;
+  }
+  return LMV_OK;
+}
+
 extern "C" int lmv_attn_fwd(const lmv_attn_desc* d, void* ws, size_t ws_bytes, int dtype, void* stream) {
   if (int rc = check_desc(d, dtype, false)) return rc;
   return dtype == LMV_BF16 ? fwd_impl<bf16_t>(d, ws, ws_bytes, (hipStream_t)stream) : fwd_impl<float>(d, ws, ws_bytes, (hipStream_t)stream);

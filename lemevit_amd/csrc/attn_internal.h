@@ -24,3 +24,6 @@ int lmv_attn_mfma_fewq_bwd(const AttnArgs& a, float* acc, hipStream_t st);
 bool lmv_attn_mfma_long_supported(const AttnArgs& a);
 int lmv_attn_mfma_long_fwd(const AttnArgs& a, hipStream_t st);
 int lmv_attn_mfma_long_bwd(const AttnArgs& a, float* delta, hipStream_t st);
+// two independent problems (same B, H) in one launch: returns 1 when the merged kernel ran, 0 when the shapes do not qualify
+int lmv_attn_mfma_fwd_pair(const AttnArgs& a1, const AttnArgs& a2, hipStream_t st);
+int lmv_attn_mfma_bwd_pair(const AttnArgs& a1, const AttnArgs& a2, hipStream_t st);

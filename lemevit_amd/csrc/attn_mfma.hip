@@ -119,9 +119,9 @@ __device__ __forceinline__ f16x8_t pack8h(const f32x4_t& a, const f32x4_t& b) {
 }
 
 template <int NKT, int LK = 0, bool PV16 = false>
-__global__ __launch_bounds__(256) void mfma_fwd_kernel(const AttnArgs a, int qt_per_block) {
+__device__ __forceinline__ void mfma_fwd_body(const AttnArgs& a, int qt_per_block, const int bx, const int h, const int b) {
   __shared__ __attribute__((aligned(16))) unsigned char sK[NKT * 16 * 64], sV[NKT * 16 * 64];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = blockIdx.y, b = blockIdx.z;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int Lk = LK ? LK : a.Lk;
   const bf16_t* qb = reinterpret_cast<const bf16_t*>(a.q) + b * a.q_bs + h * D;
   const bf16_t* kb = reinterpret_cast<const bf16_t*>(a.k) + b * a.k_bs + h * D;
@@ -138,12 +138,12 @@ __global__ __launch_bounds__(256) void mfma_fwd_kernel(const AttnArgs a, int qt_
     __syncthreads();
   }
   const int nqt = (a.Lq + 15) >> 4;
-  const int qt_end = min(nqt, (int)(blockIdx.x + 1) * qt_per_block);
+  const int qt_end = min(nqt, (bx + 1) * qt_per_block);
   const int g = lane >> 4;
   const float sc2 = a.scale * 1.4426950408889634f;
   // the query fragment of the NEXT iteration is fetched while this one computes
-  bf16x8_t qf_next = load_frag_global(qb, a.q_rs, (blockIdx.x * qt_per_block + wave) * 16 + (lane & 15), a.Lq, lane);
-  for (int qt = blockIdx.x * qt_per_block + wave; qt < qt_end; qt += 4) {
+  bf16x8_t qf_next = load_frag_global(qb, a.q_rs, (bx * qt_per_block + wave) * 16 + (lane & 15), a.Lq, lane);
+  for (int qt = bx * qt_per_block + wave; qt < qt_end; qt += 4) {
     const int q = qt * 16 + (lane & 15);
     const bf16x8_t qf = qf_next;
     if (qt + 4 < qt_end) qf_next = load_frag_global(qb, a.q_rs, q + 64, a.Lq, lane);
@@ -201,6 +201,21 @@ __global__ __launch_bounds__(256) void mfma_fwd_kernel(const AttnArgs a, int qt_
       if (a.lse && g == 0) a.lse[((int64_t)b * a.H + h) * a.Lq + q] = m * a.scale + __logf(l);
     }
   }
+}
+
+template <int NKT, int LK = 0, bool PV16 = false>
+__global__ __launch_bounds__(256) void mfma_fwd_kernel(const AttnArgs a, int qt_per_block) { mfma_fwd_body<NKT, LK, PV16>(a, qt_per_block, (int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z); }
+
+// Two independent attention problems in ONE launch (lmv_attn_fwd_pair): the image-token and the meta-token self-attention of an S
+// block (models/lemevit.py:632,634).  The 16-token problem is B * h tiny workgroups -- ~12 us as a launch of its own, mostly ramp and
+// tail -- and rides as extra workgroups behind the image-token ones here.
+template <int NKT1, int LK1, int NKT2, int LK2>
+__global__ __launch_bounds__(256) void mfma_fwd_pair_kernel(const AttnArgs a1, const AttnArgs a2, int per1, int per2, int nblk1) {
+  // 1-D grid, all workgroups of problem 1 first: the hardware deals consecutive workgroup ids round-robin over the 8 XCDs, so a 3-D grid
+  // with the two problems interleaved along x would put every heavy workgroup on the even XCDs (measured: 52 vs 36 us)
+  const int n1 = nblk1 * a1.H * a1.B, id = (int)blockIdx.x;
+  if (id < n1) { const int bx = id % nblk1, t = id / nblk1; mfma_fwd_body<NKT1, LK1, true>(a1, per1, bx, t % a1.H, t / a1.H); }
+  else { const int t = id - n1; mfma_fwd_body<NKT2, LK2, true>(a2, per2, 0, t % a2.H, t / a2.H); }
 }
 
 // =============================================================================================
@@ -274,21 +289,21 @@ constexpr int QR_MAX = 448;   // queries staged per workgroup (Q and dO images: 
 // separate dQ launch disappears (DCA x-direction: 3136 queries x 16 keys; the 16 x 16 meta-token self-attention).
 // LK > 0: the key count is a compile-time constant (16 meta tokens: the x direction of Dual Cross-Attention): key tiles past the end are
 // not computed at all -- with 16 keys in a 32-key block that is half of the MFMAs, exponentials and masks of the run-time version.
-template <int NKT, int KW, bool ATOMIC, bool FUSEDQ = false, int LK = 0>
-__global__ __launch_bounds__(256) void mfma_bwd_dkv_kernel(const AttnArgs a, const float* __restrict__ delta, float* __restrict__ acc_k,
-                                                          float* __restrict__ acc_v, int q_per_block) {
+template <int NKT, int KW, bool ATOMIC, bool FUSEDQ = false, int LK = 0, int QRM = QR_MAX>
+__device__ __forceinline__ void mfma_bwd_dkv_body(const AttnArgs& a, const float* __restrict__ delta, float* __restrict__ acc_k,
+                                                  float* __restrict__ acc_v, int q_per_block, const int bx, const int h, const int b) {
   constexpr int QW = 4 / KW;
   constexpr int TPW = (NKT + KW - 1) / KW;     // key tiles per wave
   const int Lk = LK ? LK : a.Lk;
   static_assert(!FUSEDQ || (NKT == 2 && KW == 1), "the fused dQ path is written for two key tiles per wave");
-  __shared__ __attribute__((aligned(16))) unsigned char sQG[2 * QR_MAX * 64];     // Q image | dO image (reused by the final reduce)
-  __shared__ __attribute__((aligned(16))) float sL[QR_MAX], sDl[QR_MAX];
+  __shared__ __attribute__((aligned(16))) unsigned char sQG[2 * QRM * 64];     // Q image | dO image (reused by the final reduce)
+  __shared__ __attribute__((aligned(16))) float sL[QRM], sDl[QRM];
   __shared__ __attribute__((aligned(16))) unsigned char sKV[FUSEDQ ? 2 * 32 * 64 : 16];                // FUSEDQ: K image | V image
   unsigned char* sQ = sQG;
-  unsigned char* sG = sQG + QR_MAX * 64;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = blockIdx.y, b = blockIdx.z;
+  unsigned char* sG = sQG + QRM * 64;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int kw = wave % KW, qw = wave / KW, g = lane >> 4;
-  const int q0 = blockIdx.x * q_per_block, q1 = min(a.Lq, q0 + q_per_block);
+  const int q0 = bx * q_per_block, q1 = min(a.Lq, q0 + q_per_block);
   const int nrows = ((q1 - q0 + 31) >> 5) << 5;
   const int64_t bh = ((int64_t)b * a.H + h) * a.Lq;
   stage_rows2<256>(sQ, reinterpret_cast<const bf16_t*>(a.q) + b * a.q_bs + h * D, a.q_rs, sG, reinterpret_cast<const bf16_t*>(a.d_o) + b * a.o_bs + h * D, a.o_rs, q0, nrows, q1, tid);
@@ -423,7 +438,7 @@ __global__ __launch_bounds__(256) void mfma_bwd_dkv_kernel(const AttnArgs a, con
 #pragma unroll
       for (int dt = 0; dt < 2; ++dt) {
         const int d = g * 8 + dt * 4;          // frag_t's interleaved column order
-        const int64_t o = ((((int64_t)blockIdx.x * a.B + b) * a.H + h) * (NKT * 16) + key) * D + d;
+        const int64_t o = ((((int64_t)bx * a.B + b) * a.H + h) * (NKT * 16) + key) * D + d;
         *reinterpret_cast<f32x4_t*>(acc_k + o) = dk[i][dt];
         *reinterpret_cast<f32x4_t*>(acc_v + o) = dv[i][dt];
       }
@@ -432,6 +447,12 @@ __global__ __launch_bounds__(256) void mfma_bwd_dkv_kernel(const AttnArgs a, con
       store8(reinterpret_cast<bf16_t*>(a.dv) + b * a.v_bs + (int64_t)key * a.v_rs + h * D, g, dv[i][0], dv[i][1]);
     }
   }
+}
+
+template <int NKT, int KW, bool ATOMIC, bool FUSEDQ = false, int LK = 0>
+__global__ __launch_bounds__(256) void mfma_bwd_dkv_kernel(const AttnArgs a, const float* __restrict__ delta, float* __restrict__ acc_k,
+                                                          float* __restrict__ acc_v, int q_per_block) {
+  mfma_bwd_dkv_body<NKT, KW, ATOMIC, FUSEDQ, LK>(a, delta, acc_k, acc_v, q_per_block, (int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z);
 }
 
 // =============================================================================================
@@ -447,15 +468,19 @@ __global__ __launch_bounds__(256) void mfma_bwd_dkv_kernel(const AttnArgs a, con
 // LDS: Q, dO, K images (<= 14 KB each) + 16 KB transposers + 16 KB dQ exchange = 77 KB: two workgroups per CU.
 // =============================================================================================
 template <int NKT, int LK = 0>
-__global__ __launch_bounds__(256, 2) void mfma_bwd_fused_kernel(const AttnArgs a) {
+__device__ __forceinline__ void mfma_bwd_fused_body(const AttnArgs& a, const int h, const int b) {
   constexpr int TPW = (NKT + 3) / 4;          // key tiles per wave
   constexpr int NP = (TPW + 1) / 2;           // 32-key pairs per wave for the dQ contraction
   constexpr int NQ = NKT * 16;                // query rows staged (Lq <= NQ is guaranteed by the dispatcher)
-  __shared__ __attribute__((aligned(16))) unsigned char sQ[NQ * 64 + 1024], sG[NQ * 64 + 1024], sK[NQ * 64 + 1024];
-  __shared__ __attribute__((aligned(16))) float sL[NQ + 32], sDl[NQ + 32];
-  __shared__ __attribute__((aligned(16))) unsigned char sT[4][2][2 * NP][512];     // [wave][q tile][key tile slot][16 keys x 16 queries bf16]
-  __shared__ __attribute__((aligned(16))) float sRed[4][4][64][4];                  // [wave][q tile * 2 + d half][lane][4]
-  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), h = blockIdx.y, b = blockIdx.z;
+  __shared__ __attribute__((aligned(16))) unsigned char sQ[NQ * 64], sG[NQ * 64], sK[NQ * 64];
+  __shared__ __attribute__((aligned(16))) float sL[NQ], sDl[NQ];
+  // [wave][q tile][key tile slot][16 keys x 16 queries bf16] transposers; the SAME 4 KB per wave then carry that wave's dQ partial to
+  // the exchange ([q tile * 2 + d half][lane][4] fp32): a wave has read its tiles before it overwrites them, nobody else touches them
+  constexpr int TSZ = (2 * 2 * NP * 512 > 4096) ? 2 * 2 * NP * 512 : 4096;
+  __shared__ __attribute__((aligned(16))) unsigned char sTR[4][TSZ];
+  auto sT = [&](int w, int t, int slot) -> unsigned char* { return &sTR[w][(t * 2 * NP + slot) * 512]; };
+  auto sRed = [&](int w, int idx) -> float* { return reinterpret_cast<float*>(&sTR[w][idx * 1024]); };
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int g = lane >> 4;
   const int Lk = LK ? LK : a.Lk, Lq = a.Lq;
   const int nrows = ((Lq + 31) >> 5) << 5;
@@ -494,8 +519,6 @@ __global__ __launch_bounds__(256, 2) void mfma_bwd_fused_kernel(const AttnArgs a
 #pragma unroll
     for (int dt = 0; dt < 2; ++dt) { dk[i][dt] = f32x4_t{0.f, 0.f, 0.f, 0.f}; dv[i][dt] = f32x4_t{0.f, 0.f, 0.f, 0.f}; }
   }
-  // the transposer tiles of key-tile slots this wave never fills stay zero (odd TPW, or tiles past the end)
-  for (int i = lane; i < 2 * 2 * NP * 512 / 16; i += 64) reinterpret_cast<uint4*>(&sT[wave][0][0][0])[i] = make_uint4(0, 0, 0, 0);
   __syncthreads();
   bf16_t* dqb = reinterpret_cast<bf16_t*>(a.dq) + b * a.q_bs + h * D;
   for (int r0 = 0; r0 < nrows; r0 += 32) {
@@ -527,8 +550,8 @@ __global__ __launch_bounds__(256, 2) void mfma_bwd_fused_kernel(const AttnArgs a
       dk[i][0] = MFMA(qt0, dsf, dk[i][0]); dk[i][1] = MFMA(qt1, dsf, dk[i][1]);
       // dS tiles -> the wave's transposers: row = key, 4 consecutive queries (8 bytes) at column g * 4
       const uint4 w = __builtin_bit_cast(uint4, dsf);
-      *reinterpret_cast<uint2*>(&sT[wave][0][i][(lane & 15) * 32 + g * 8]) = make_uint2(w.x, w.y);
-      *reinterpret_cast<uint2*>(&sT[wave][1][i][(lane & 15) * 32 + g * 8]) = make_uint2(w.z, w.w);
+      *reinterpret_cast<uint2*>(sT(wave, 0, i) + (lane & 15) * 32 + g * 8) = make_uint2(w.x, w.y);
+      *reinterpret_cast<uint2*>(sT(wave, 1, i) + (lane & 15) * 32 + g * 8) = make_uint2(w.z, w.w);
     }
     // ---- this wave's share of dQ^T[d][q] = sum over its keys of K^T[d][key] dS^T[key][q] ------------------------------------
     f32x4_t dq[2][2];
@@ -540,12 +563,14 @@ __global__ __launch_bounds__(256, 2) void mfma_bwd_fused_kernel(const AttnArgs a
       for (int pp = 0; pp < NP; ++pp) {
         const int kta = wave + (2 * pp) * 4, ktb = wave + (2 * pp + 1) * 4;       // the two key tiles of this 32-key pair
         if (kta >= NKT || kta * 16 >= Lk) continue;
-        const int rowb = (2 * pp + 1 < TPW && ktb < NKT) ? ktb * 16 : kta * 16;    // (a missing second tile multiplies zeros)
+        const bool has_b = 2 * pp + 1 < TPW && ktb < NKT && ktb * 16 < Lk;          // wave-uniform: a missing second tile contributes zeros
+        const int rowb = has_b ? ktb * 16 : kta * 16;
         const bf16x8_t ka = frag_t(sK, kta * 16, rowb, 0, lane), kb2 = frag_t(sK, kta * 16, rowb, 16, lane);
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
-          const bf16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds4_t)(&sT[wave][t][2 * pp][(g * 4 + rr) * 32 + qq * 8]));
-          const bf16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds4_t)(&sT[wave][t][2 * pp + 1][(g * 4 + rr) * 32 + qq * 8]));
+          const bf16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds4_t)(sT(wave, t, 2 * pp) + (g * 4 + rr) * 32 + qq * 8));
+          bf16x4_t hi = {(__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f};
+          if (has_b) hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds4_t)(sT(wave, t, 2 * pp + (2 * pp + 1 < TPW ? 1 : 0)) + (g * 4 + rr) * 32 + qq * 8));
           const bf16x8_t dst = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
           dq[t][0] = MFMA(ka, dst, dq[t][0]); dq[t][1] = MFMA(kb2, dst, dq[t][1]);
         }
@@ -554,14 +579,14 @@ __global__ __launch_bounds__(256, 2) void mfma_bwd_fused_kernel(const AttnArgs a
 #pragma unroll
     for (int t = 0; t < 2; ++t)
 #pragma unroll
-      for (int hh = 0; hh < 2; ++hh) *reinterpret_cast<f32x4_t*>(&sRed[wave][t * 2 + hh][lane][0]) = dq[t][hh];
+      for (int hh = 0; hh < 2; ++hh) *reinterpret_cast<f32x4_t*>(sRed(wave, t * 2 + hh) + lane * 4) = dq[t][hh];
     __syncthreads();
     if (wave < 2) {                               // wave t sums the four partials of query tile t in wave order and stores the rows
       f32x4_t x0 = {0.f, 0.f, 0.f, 0.f}, x1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int w = 0; w < 4; ++w) {
-        x0 += *reinterpret_cast<const f32x4_t*>(&sRed[w][wave * 2][lane][0]);
-        x1 += *reinterpret_cast<const f32x4_t*>(&sRed[w][wave * 2 + 1][lane][0]);
+        x0 += *reinterpret_cast<const f32x4_t*>(sRed(w, wave * 2) + lane * 4);
+        x1 += *reinterpret_cast<const f32x4_t*>(sRed(w, wave * 2 + 1) + lane * 4);
       }
       const int q = r0 + wave * 16 + (lane & 15);
       if (q < Lq) store8(dqb + (int64_t)q * a.q_rs, g, x0, x1);
@@ -575,6 +600,18 @@ __global__ __launch_bounds__(256, 2) void mfma_bwd_fused_kernel(const AttnArgs a
     store8(reinterpret_cast<bf16_t*>(a.dk) + b * a.k_bs + (int64_t)key * a.k_rs + h * D, g, dk[i][0], dk[i][1]);
     store8(reinterpret_cast<bf16_t*>(a.dv) + b * a.v_bs + (int64_t)key * a.v_rs + h * D, g, dv[i][0], dv[i][1]);
   }
+}
+
+template <int NKT, int LK = 0>
+__global__ __launch_bounds__(256, 2) void mfma_bwd_fused_kernel(const AttnArgs a) { mfma_bwd_fused_body<NKT, LK>(a, (int)blockIdx.y, (int)blockIdx.z); }
+
+// backward of the pair launch: workgroup (0, h, b) differentiates the image-token problem (fused kernel), workgroup (1, h, b) the
+// 16-token problem (the <= 32-key kernel that also produces dQ, with 32-row staging images instead of 448-row ones)
+template <int NKT1, int LK1>
+__global__ __launch_bounds__(256, 2) void mfma_bwd_pair_kernel(const AttnArgs a1, const AttnArgs a2) {
+  const int n1 = a1.H * a1.B, id = (int)blockIdx.x;          // 1-D grid, problem 1 first (see mfma_fwd_pair_kernel)
+  if (id < n1) mfma_bwd_fused_body<NKT1, LK1>(a1, id % a1.H, id / a1.H);
+  else mfma_bwd_dkv_body<2, 1, false, true, 16, 32>(a2, nullptr, nullptr, nullptr, 32, 0, (id - n1) % a2.H, (id - n1) / a2.H);
 }
 
 // fp32 [B][H][LP][32] accumulator -> strided bf16 rows (first L rows)
@@ -1353,4 +1390,25 @@ int lmv_attn_mfma_bwd(const AttnArgs& a, float* delta, float* acc, hipStream_t s
   }
   LMV_CHECK_LAUNCH("attn_mfma_bwd");
   return LMV_OK;
+}
+
+// Pair launches (two independent problems with the same B and H): merged when problem 1 is the stage-3 / stage-4 image-token
+// self-attention (196 / 49 keys, Lq == Lk) and problem 2 the 16 x 16 meta-token one; 1 = merged, 0 = not applicable
+int lmv_attn_mfma_fwd_pair(const AttnArgs& a1, const AttnArgs& a2, hipStream_t st) {
+  static const int on = [] { const char* e = getenv("LMV_ATTN_PAIR"); return e ? atoi(e) : 1; }();      // A/B testing
+  if (!on || a1.B != a2.B || a1.H != a2.H || a2.Lk != 16 || a2.Lq != 16 || a1.Lq != a1.Lk || (a1.Lk != 196 && a1.Lk != 49)) return 0;
+  const int per1 = qt_per_block_for(a1), nqt1 = (a1.Lq + 15) / 16, nblk1 = (nqt1 + per1 - 1) / per1;
+  dim3 grid((nblk1 + 1) * a1.H * a1.B), block(256);
+  if (a1.Lk == 196) hipLaunchKernelGGL((mfma_fwd_pair_kernel<14, 196, 2, 16>), grid, block, 0, st, a1, a2, per1, 1, nblk1);
+  else hipLaunchKernelGGL((mfma_fwd_pair_kernel<4, 49, 2, 16>), grid, block, 0, st, a1, a2, per1, 1, nblk1);
+  return 1;
+}
+
+int lmv_attn_mfma_bwd_pair(const AttnArgs& a1, const AttnArgs& a2, hipStream_t st) {
+  static const int on = [] { const char* e = getenv("LMV_ATTN_PAIR"); return e ? atoi(e) : 1; }();
+  if (!on || a1.B != a2.B || a1.H != a2.H || a2.Lk != 16 || a2.Lq != 16 || a1.Lq != a1.Lk || (a1.Lk != 196 && a1.Lk != 49)) return 0;
+  dim3 grid(2 * a1.H * a1.B), block(256);
+  if (a1.Lk == 196) hipLaunchKernelGGL((mfma_bwd_pair_kernel<14, 196>), grid, block, 0, st, a1, a2);
+  else hipLaunchKernelGGL((mfma_bwd_pair_kernel<4, 49>), grid, block, 0, st, a1, a2);
+  return 1;
 }

@@ -317,6 +317,39 @@ def attn_bwd(q, k, v, o: Tensor, lse: Tensor, d_o: Tensor, dq, dk, dv, C_: int, 
     check(lib.lmv_attn_bwd(C.byref(d), ws.data_ptr(), ws.numel(), dtype_code(o), st), "lmv_attn_bwd")
 
 
+def attn_fwd_pair(qkvs: Sequence[Tensor], C_: int, scale: float, want_lse: bool = False):
+    """Self-attention of TWO packed qkv tensors [B, L_i, 3C] (same B and C) in one launch where the kernels allow (lmv_attn_fwd_pair);
+    returns ([o_0, o_1], [lse_0, lse_1])."""
+    descs = (AttnDesc * 2)()
+    outs, lses, nb = [], [], 256
+    for i, t in enumerate(qkvs):
+        B, L = t.shape[0], t.shape[1]
+        o = torch.empty((B, L, C_), device=t.device, dtype=t.dtype)
+        lse = torch.empty((B, C_ // HEAD_DIM, L), device=t.device, dtype=torch.float32) if want_lse else None
+        descs[i] = _desc((t, 0), (t, C_), (t, 2 * C_), o, lse, C_, scale)
+        nb = max(nb, lib.lmv_attn_workspace_bytes(B, C_ // HEAD_DIM, L, L, 0))
+        outs.append(o); lses.append(lse)
+    ws = _workspace(nb, qkvs[0].device)
+    check(lib.lmv_attn_fwd_pair(descs, ws.data_ptr(), ws.numel(), dtype_code(qkvs[0]), _stream()), "lmv_attn_fwd_pair")
+    return outs, lses
+
+
+def attn_bwd_pair(qkvs: Sequence[Tensor], os_: Sequence[Tensor], lses: Sequence[Tensor], d_os: Sequence[Tensor], dqkvs: Sequence[Tensor], C_: int,
+                  scale: float) -> None:
+    """Backward of attn_fwd_pair: dqkvs[i] (packed like qkvs[i]) is written."""
+    descs = (AttnDesc * 2)()
+    nb = 256
+    for i, (t, o, l, g, dq) in enumerate(zip(qkvs, os_, lses, d_os, dqkvs)):
+        d = _desc((t, 0), (t, C_), (t, 2 * C_), o, l, C_, scale)
+        es = t.element_size()
+        d.d_o = _ptr(g)
+        d.dq, d.dk, d.dv = _ptr(dq), _ptr(dq) + C_ * es, _ptr(dq) + 2 * C_ * es
+        descs[i] = d
+        nb = max(nb, lib.lmv_attn_workspace_bytes(d.B, d.H, d.Lq, d.Lk, 1))
+    ws = _workspace(nb, qkvs[0].device)
+    check(lib.lmv_attn_bwd_pair(descs, ws.data_ptr(), ws.numel(), dtype_code(qkvs[0]), _stream()), "lmv_attn_bwd_pair")
+
+
 def dca_scales(N: int, M: int, C_: int) -> Tuple[float, float]:
     """models/lemevit.py:235,255-256."""
     base = C_ ** (-0.5)

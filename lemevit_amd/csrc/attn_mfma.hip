@@ -19,6 +19,10 @@
 #include "common.h"
 #include "attn_internal.h"
 
+#ifndef LMV_XCD_REMAP
+#define LMV_XCD_REMAP 1
+#endif
+
 namespace {
 
 constexpr int D = 32;
@@ -93,6 +97,15 @@ __device__ __forceinline__ void store8(bf16_t* row, int g, const f32x4_t& x0, co
 }
 
 #define MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0)
+
+// XCD-contiguous workgroup order: the hardware deals consecutive workgroup ids round-robin over the 8 XCDs (each with its own L2).
+// The heads of one image read 64-byte pieces of the SAME rows (two heads per 128-byte line) and write 64-byte pieces of the same
+// output rows: dealt to different XCDs, every line is fetched from HBM by two L2s and written back in halves.  Remapped, XCD x works
+// on the contiguous range [x * n / 8, (x + 1) * n / 8) of logical ids = whole images.  (Speed only; any placement is correct.)
+__device__ __forceinline__ int xcd_contiguous(int id, int n) {
+  if (n & 7) return id;
+  return (id & 7) * (n >> 3) + (id >> 3);
+}
 
 // =============================================================================================
 // forward: NKT = number of 16-key tiles (even), keys padded with zero rows / masked scores
@@ -204,7 +217,11 @@ __device__ __forceinline__ void mfma_fwd_body(const AttnArgs& a, int qt_per_bloc
 }
 
 template <int NKT, int LK = 0, bool PV16 = false>
-__global__ __launch_bounds__(256) void mfma_fwd_kernel(const AttnArgs a, int qt_per_block) { mfma_fwd_body<NKT, LK, PV16>(a, qt_per_block, (int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z); }
+__global__ __launch_bounds__(256) void mfma_fwd_kernel(const AttnArgs a, int qt_per_block) {
+  const int nb = gridDim.x, n = nb * a.H * a.B;
+  const int L = LMV_XCD_REMAP ? xcd_contiguous((int)blockIdx.x + nb * ((int)blockIdx.y + a.H * (int)blockIdx.z), n) : (int)blockIdx.x + nb * ((int)blockIdx.y + a.H * (int)blockIdx.z);
+  mfma_fwd_body<NKT, LK, PV16>(a, qt_per_block, L % nb, (L / nb) % a.H, L / (nb * a.H));
+}
 
 // Two independent attention problems in ONE launch (lmv_attn_fwd_pair): the image-token and the meta-token self-attention of an S
 // block (models/lemevit.py:632,634).  The 16-token problem is B * h tiny workgroups -- ~12 us as a launch of its own, mostly ramp and
@@ -213,7 +230,9 @@ template <int NKT1, int LK1, int NKT2, int LK2>
 __global__ __launch_bounds__(256) void mfma_fwd_pair_kernel(const AttnArgs a1, const AttnArgs a2, int per1, int per2, int nblk1) {
   // 1-D grid, all workgroups of problem 1 first: the hardware deals consecutive workgroup ids round-robin over the 8 XCDs, so a 3-D grid
   // with the two problems interleaved along x would put every heavy workgroup on the even XCDs (measured: 52 vs 36 us)
-  const int n1 = nblk1 * a1.H * a1.B, id = (int)blockIdx.x;
+  const int n1 = nblk1 * a1.H * a1.B;
+  int id = (int)blockIdx.x;
+  if (id < n1 && LMV_XCD_REMAP) id = xcd_contiguous(id, n1);
   if (id < n1) { const int bx = id % nblk1, t = id / nblk1; mfma_fwd_body<NKT1, LK1, true>(a1, per1, bx, t % a1.H, t / a1.H); }
   else { const int t = id - n1; mfma_fwd_body<NKT2, LK2, true>(a2, per2, 0, t % a2.H, t / a2.H); }
 }
@@ -452,7 +471,9 @@ __device__ __forceinline__ void mfma_bwd_dkv_body(const AttnArgs& a, const float
 template <int NKT, int KW, bool ATOMIC, bool FUSEDQ = false, int LK = 0>
 __global__ __launch_bounds__(256) void mfma_bwd_dkv_kernel(const AttnArgs a, const float* __restrict__ delta, float* __restrict__ acc_k,
                                                           float* __restrict__ acc_v, int q_per_block) {
-  mfma_bwd_dkv_body<NKT, KW, ATOMIC, FUSEDQ, LK>(a, delta, acc_k, acc_v, q_per_block, (int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z);
+  const int nb = gridDim.x, n = nb * a.H * a.B, id = (int)blockIdx.x + nb * ((int)blockIdx.y + a.H * (int)blockIdx.z);
+  const int L = LMV_XCD_REMAP ? xcd_contiguous(id, n) : id;
+  mfma_bwd_dkv_body<NKT, KW, ATOMIC, FUSEDQ, LK>(a, delta, acc_k, acc_v, q_per_block, L % nb, (L / nb) % a.H, L / (nb * a.H));
 }
 
 // =============================================================================================
@@ -603,13 +624,19 @@ __device__ __forceinline__ void mfma_bwd_fused_body(const AttnArgs& a, const int
 }
 
 template <int NKT, int LK = 0>
-__global__ __launch_bounds__(256, 2) void mfma_bwd_fused_kernel(const AttnArgs a) { mfma_bwd_fused_body<NKT, LK>(a, (int)blockIdx.y, (int)blockIdx.z); }
+__global__ __launch_bounds__(256, 2) void mfma_bwd_fused_kernel(const AttnArgs a) {
+  const int n = a.H * a.B, id = (int)blockIdx.y + a.H * (int)blockIdx.z;
+  const int L = LMV_XCD_REMAP ? xcd_contiguous(id, n) : id;
+  mfma_bwd_fused_body<NKT, LK>(a, L % a.H, L / a.H);
+}
 
 // backward of the pair launch: workgroup (0, h, b) differentiates the image-token problem (fused kernel), workgroup (1, h, b) the
 // 16-token problem (the <= 32-key kernel that also produces dQ, with 32-row staging images instead of 448-row ones)
 template <int NKT1, int LK1>
 __global__ __launch_bounds__(256, 2) void mfma_bwd_pair_kernel(const AttnArgs a1, const AttnArgs a2) {
-  const int n1 = a1.H * a1.B, id = (int)blockIdx.x;          // 1-D grid, problem 1 first (see mfma_fwd_pair_kernel)
+  const int n1 = a1.H * a1.B;                                 // 1-D grid, problem 1 first (see mfma_fwd_pair_kernel)
+  int id = (int)blockIdx.x;
+  if (id < n1 && LMV_XCD_REMAP) id = xcd_contiguous(id, n1);
   if (id < n1) mfma_bwd_fused_body<NKT1, LK1>(a1, id % a1.H, id / a1.H);
   else mfma_bwd_dkv_body<2, 1, false, true, 16, 32>(a2, nullptr, nullptr, nullptr, 32, 0, (id - n1) % a2.H, (id - n1) / a2.H);
 }
@@ -652,8 +679,11 @@ constexpr int RKT_B = 4, RKB = RKT_B * 16; // backward (more LDS per key: Q / dO
 
 __global__ __launch_bounds__(256) void mfma_fwd_split_kernel(const AttnArgs a, float* __restrict__ part, int nsplit) {
   __shared__ __attribute__((aligned(16))) unsigned char sK[4 * RK * 64], sV[4 * RK * 64];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = blockIdx.y, b = blockIdx.z, g = lane >> 4;
-  const int split = blockIdx.x * 4 + wave, k0 = split * RK;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4;
+  const int nbx = gridDim.x, Lid = LMV_XCD_REMAP ? xcd_contiguous((int)blockIdx.x + nbx * ((int)blockIdx.y + a.H * (int)blockIdx.z), nbx * a.H * a.B)
+                                                 : (int)blockIdx.x + nbx * ((int)blockIdx.y + a.H * (int)blockIdx.z);
+  const int bx = Lid % nbx, h = (Lid / nbx) % a.H, b = Lid / (nbx * a.H);
+  const int split = bx * 4 + wave, k0 = split * RK;
   const bf16_t* kb = reinterpret_cast<const bf16_t*>(a.k) + b * a.k_bs + h * D;
   const bf16_t* vb = reinterpret_cast<const bf16_t*>(a.v) + b * a.v_bs + h * D;
   unsigned char* wK = sK + wave * RK * 64;
@@ -711,8 +741,11 @@ __global__ __launch_bounds__(256) void mfma_bwd_fewq_kernel(const AttnArgs a, fl
   __shared__ __attribute__((aligned(16))) unsigned char sK[4 * RKB * 64], sV[4 * RKB * 64];
   __shared__ __attribute__((aligned(16))) unsigned char sQ[32 * 64], sG[32 * 64];
   __shared__ __attribute__((aligned(16))) float sL[32], sDl[32], sRed[4][2][64][4];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = blockIdx.y, b = blockIdx.z, g = lane >> 4;
-  const int k0 = (blockIdx.x * 4 + wave) * RKB;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4;
+  const int nbx = gridDim.x, Lid = LMV_XCD_REMAP ? xcd_contiguous((int)blockIdx.x + nbx * ((int)blockIdx.y + a.H * (int)blockIdx.z), nbx * a.H * a.B)
+                                                 : (int)blockIdx.x + nbx * ((int)blockIdx.y + a.H * (int)blockIdx.z);
+  const int bx = Lid % nbx, h = (Lid / nbx) % a.H, b = Lid / (nbx * a.H);
+  const int k0 = (bx * 4 + wave) * RKB;
   const int64_t bh = ((int64_t)b * a.H + h) * a.Lq;
   const bf16_t* kb = reinterpret_cast<const bf16_t*>(a.k) + b * a.k_bs + h * D;
   const bf16_t* vb = reinterpret_cast<const bf16_t*>(a.v) + b * a.v_bs + h * D;
@@ -805,7 +838,7 @@ __global__ __launch_bounds__(256) void mfma_bwd_fewq_kernel(const AttnArgs a, fl
       dq1 += *reinterpret_cast<const f32x4_t*>(&sRed[w][1][lane][0]);
     }
     // this workgroup's share of dQ goes to ITS slab (plain stores, no atomics: summed in a fixed order by scatter_sum1_kernel)
-    float* dst = acc_q + ((((int64_t)blockIdx.x * a.B + b) * a.H + h) * 16 + q) * D + g * 8;
+    float* dst = acc_q + ((((int64_t)bx * a.B + b) * a.H + h) * 16 + q) * D + g * 8;
     *reinterpret_cast<f32x4_t*>(dst) = dq0;
     *reinterpret_cast<f32x4_t*>(dst + 4) = dq1;
   }

@@ -125,7 +125,11 @@ def cpu_baseline(model_name: str, img: int, mode: str):
         for k, v in sd.items():
             if v.dtype.is_floating_point and not k.endswith(("running_mean", "running_var")):
                 v.requires_grad_(True)
-    B = 4
+    # 128 host threads on a batch of 8 images thrash (measured on the GPU box: Base B=1 forward 0.83 img/s with 128 threads, 3.2 img/s
+    # with 8): the baseline uses at most 32, and `cores` reports the threads actually used
+    prev_threads = torch.get_num_threads()
+    torch.set_num_threads(min(prev_threads, 32))
+    B = 8
     x = torch.randn(B, 3, img, img)
     tgt = torch.randint(0, 1000, (B,))
 
@@ -143,10 +147,12 @@ def cpu_baseline(model_name: str, img: int, mode: str):
     t0, n = time.perf_counter(), 0
     while True:
         step(); n += 1
-        if time.perf_counter() - t0 > 12.0 or n >= 8:
+        if time.perf_counter() - t0 > 15.0 or n >= 16:
             break
     dt = time.perf_counter() - t0
-    return dict(value=round(B * n / dt, 3), unit="images/sec", cores=torch.get_num_threads(), kind="port",
+    used = torch.get_num_threads()
+    torch.set_num_threads(prev_threads)
+    return dict(value=round(B * n / dt, 3), unit="images/sec", cores=used, kind="port",
                 sample=f"{n} {'fwd+bwd' if train else 'fwd'} steps of {model_name} {img}x{img} fp32 at batch {B} (oracle/lemevit_oracle.py, PyTorch CPU)")
 
 
@@ -279,6 +285,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
+    t_issued = time.perf_counter() - t0        # host time to ENQUEUE the K steps (the device is still working)
     sync()
     dt = time.perf_counter() - t0
     kernel_timing_note = None
@@ -310,11 +317,12 @@ def main():
             # HBM bytes per launch of the same kernel from the PMC passes committed under profiles/ (tools/pmc_traffic.sh: FETCH_SIZE x 2
             # per the gfx950 correction + WRITE_SIZE, separate passes); only quoted for the workload it was collected on
             traffic, traffic_src = None, None
-            pmc = os.path.join(ROOT, "profiles", "r01_gemm_fwd_pmc_traffic.json")
+            pmc = os.path.join(ROOT, "profiles", "r02_gemm_fwd_pmc_traffic.json")
             if train and args.model == "lemevit_base" and args.img == 224 and args.batch == 128 and os.path.exists(pmc):
                 with open(pmc) as f:
                     traffic = round(json.load(f)["traffic_bytes_per_launch"] / 1e6, 2)
-                traffic_src = "profiles/r01_gemm_fwd_pmc_traffic.json (MB per launch, rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command)"
+                traffic_src = ("canned: profiles/r02_gemm_fwd_pmc_traffic.json (MB per launch from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this "
+                               "command, tools/pmc_traffic.sh; NOT measured in this run)")
             # SURVEY 8(d) grades the path against the MFMA roof (94 % of the MACs are Linear GEMMs), so that is the primary figure.  The
             # launch mix itself has K = 96..512 on the big-row stages: its arithmetic intensity is below the ridge point of the chip
             # (2500 TFLOP/s / 8 TB/s = 312 flop/B), i.e. by the roofline model HBM is the binding roof -- reported beside it (`hbm_*`).
@@ -334,6 +342,7 @@ def main():
             "config": {"workload": f"{args.model} {args.img}x{args.img} bf16-autocast {'train step (fwd+bwd+AdamW)' if train else 'forward'}, "
                                    f"batch {args.batch}/GPU, drop_path 0.1, random-init weights", "global_batch": args.batch * world,
                        "parallelism": f"dp{world}", "launch": graph_note},
+            "host_issue_ms_per_step": round(1e3 * t_issued / args.steps, 3),
             "model_tflops": None if gflop is None else round(value * gflop * mult / 1e3, 2),
             "model_frac_of_bf16_peak": None if gflop is None else round(value * gflop * mult / 1e3 / (PEAK_BF16_TFLOPS * world), 4),
             "roofline": roof,

@@ -243,77 +243,109 @@ template <> __device__ __forceinline__ float act_gelu_grad<float>(float x) { ret
 template <> __device__ __forceinline__ float act_gelu_grad<bf16_t>(float x) { return gelu_grad_fast_f(x); }
 
 // ---- coalesced epilogue: fp32 tile -> swizzled LDS (64 rows per pass) -> 16-byte row-major stores --------------
-// out_pre = acc + bias (optional pre-activation copy for the backward pass) and out = res + row_scale * act(acc + bias)
-// (act = GELU, or x GELU'(aux) for dX) leave in ONE pass: the transposed fp32 tile is read back once and stored twice.
-// Every wave transposes ITS OWN 64-column strip through a private LDS region (no workgroup barrier, all waves busy):
-// RPP rows per pass, a row of 64 fp32 = 16 float4 chunks, chunk c of row r stored at c ^ (r & 7).
-template <typename T, typename CF, int REGION_BYTES>
-__device__ __forceinline__ void store_tile(unsigned char* smem, const f32x4_t (&acc)[CF::WM][4], const Problem& P, int act, int N, int64_t ldc,
-                                           int m0, int n0, int wm, int wn, int lane, int wave) {
-  constexpr int EPC = DT<T>::EPC;
-  constexpr int CPR = 64 / EPC;                 // output chunks per 64-column row
-  constexpr int RPP = REGION_BYTES >= 16384 ? 64 : (REGION_BYTES >= 8192 ? 32 : 16);
+template <typename T, typename CF, int REGION_BYTES> struct Epi {
+  static constexpr int EPC = DT<T>::EPC;
+  static constexpr int CPR = 64 / EPC;                 // output chunks per 64-column row
+  static constexpr int RPP = REGION_BYTES >= 16384 ? 64 : (REGION_BYTES >= 8192 ? 32 : 16);
   static_assert(REGION_BYTES >= RPP * 256 && (CF::WM * 16) % RPP == 0, "per-wave epilogue region too small");
-  float* sT = reinterpret_cast<float*>(smem + wave * REGION_BYTES);
-  T* outp = reinterpret_cast<T*>(P.out);
-  T* prep = reinterpret_cast<T*>(P.out_pre);
-  const int nw0 = n0 + wn * 64;                 // first column of this wave's strip
+  static constexpr int NPASS = CF::WM * 16 / RPP, NITER = RPP * CPR / 64;
+  // Everything the epilogue READS from global memory, issued for the wave's whole strip before the first LDS transpose: one
+  // 16-byte chunk per output chunk (the GELU' operand u, or the residual), the DropPath scale of each chunk's row and the bias.
+  // Issued at the point of use these loads stalled every pass for a memory round trip: 0.75 ms of a 33.6 ms Base train step.
+  static constexpr bool HOIST_BIAS = CF::NW >= 8;     // bias + row scales: 24 more live registers -- the 4-wave kernels (128-register budget) would spill
+  uint4 pf[NPASS][NITER];
+  float rs[HOIST_BIAS ? NPASS : 1][HOIST_BIAS ? NITER : 1];
+  float4 b4[HOIST_BIAS ? 4 : 1];
+
+  __device__ __forceinline__ void prefetch(const Problem& P, int act, int N, int64_t ldc, int m0, int n0, int wm, int wn, int lane) {
+    const int nw0 = n0 + wn * 64;
+    const T* src = reinterpret_cast<const T*>(act == LMV_ACT_GELU_GRAD ? P.aux : P.res);      // wave-uniform
 #pragma unroll
-  for (int p = 0; p < CF::WM * 16 / RPP; ++p) {
-    __builtin_amdgcn_wave_barrier();
+    for (int p = 0; p < NPASS; ++p)
 #pragma unroll
-    for (int tj = 0; tj < 4; ++tj) {
-      const int n = nw0 + tj * 16 + (lane >> 4) * 4;
-      float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (P.bias && n < N) b4 = *reinterpret_cast<const float4*>(P.bias + n);
-#pragma unroll
-      for (int i = 0; i < RPP / 16; ++i) {
-        const f32x4_t a = acc[p * (RPP / 16) + i][tj];
-        const float4 v = make_float4(a[0] + b4.x, a[1] + b4.y, a[2] + b4.z, a[3] + b4.w);
-        const int r = i * 16 + (lane & 15), c4 = tj * 4 + (lane >> 4);
-        *reinterpret_cast<float4*>(sT + r * 64 + ((c4 ^ (r & 7)) << 2)) = v;
+      for (int i = 0; i < NITER; ++i) {
+        const int c = lane + i * 64, r = c / CPR, oc = c % CPR;
+        const int m = min(m0 + wm * (CF::WM * 16) + p * RPP + r, P.M - 1), n = min(nw0 + oc * EPC, N - EPC);      // clamped, never masked
+        if (src) pf[p][i] = *reinterpret_cast<const uint4*>(src + (int64_t)m * ldc + n);
+        if constexpr (HOIST_BIAS) rs[p][i] = P.row_scale ? P.row_scale[m / P.rps] : 1.0f;
       }
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // this wave's LDS writes are visible to all of its lanes
-    __builtin_amdgcn_wave_barrier();
+    if constexpr (HOIST_BIAS) {
 #pragma unroll
-    for (int i = 0; i < RPP * CPR / 64; ++i) {
-      const int c = lane + i * 64, r = c / CPR, oc = c % CPR;
-      const int m = m0 + wm * (CF::WM * 16) + p * RPP + r, n = nw0 + oc * EPC;
-      if (m >= P.M || n >= N) continue;
-      float v[EPC];
-#pragma unroll
-      for (int e = 0; e < EPC; e += 4) {
-        const int c4 = (oc * EPC + e) >> 2;
-        const float4 t = *reinterpret_cast<const float4*>(sT + r * 64 + ((c4 ^ (r & 7)) << 2));
-        v[e] = t.x; v[e + 1] = t.y; v[e + 2] = t.z; v[e + 3] = t.w;
-      }
-      const int64_t o = (int64_t)m * ldc + n;
-      if (prep) *reinterpret_cast<uint4*>(prep + o) = f_to_chunk<T>(v);      // pre-activation copy kept for the backward pass (same pass)
-      if (act == LMV_ACT_GELU) {
-#pragma unroll
-        for (int e = 0; e < EPC; ++e) v[e] = act_gelu<T>(v[e]);
-      } else if (act == LMV_ACT_GELU_GRAD) {
-        float u[EPC];
-        chunk_to_f<T>(*reinterpret_cast<const uint4*>(reinterpret_cast<const T*>(P.aux) + o), u);
-#pragma unroll
-        for (int e = 0; e < EPC; ++e) v[e] *= act_gelu_grad<T>(u[e]);
-      }
-      if (P.row_scale) {
-        const float rs = P.row_scale[m / P.rps];
-#pragma unroll
-        for (int e = 0; e < EPC; ++e) v[e] *= rs;
-      }
-      if (P.res) {
-        float r8[EPC];
-        chunk_to_f<T>(*reinterpret_cast<const uint4*>(reinterpret_cast<const T*>(P.res) + o), r8);
-#pragma unroll
-        for (int e = 0; e < EPC; ++e) v[e] += r8[e];
-      }
-      *reinterpret_cast<uint4*>(outp + o) = f_to_chunk<T>(v);
+      for (int tj = 0; tj < 4; ++tj) b4[tj] = bias_at(P, N, nw0 + tj * 16 + (lane >> 4) * 4);
     }
   }
-}
+  static __device__ __forceinline__ float4 bias_at(const Problem& P, int N, int n) {
+    return (P.bias && n < N) ? *reinterpret_cast<const float4*>(P.bias + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+
+  // out_pre = acc + bias (optional pre-activation copy for the backward pass) and out = res + row_scale * act(acc + bias)
+  // (act = GELU, or x GELU'(aux) for dX) leave in ONE pass: the transposed fp32 tile is read back once and stored twice.
+  // Every wave transposes ITS OWN 64-column strip through a private LDS region (no workgroup barrier, all waves busy):
+  // RPP rows per pass, a row of 64 fp32 = 16 float4 chunks, chunk c of row r stored at c ^ (r & 7).
+  __device__ __forceinline__ void store(unsigned char* smem, const f32x4_t (&acc)[CF::WM][4], const Problem& P, int act, int N, int64_t ldc,
+                                        int m0, int n0, int wm, int wn, int lane, int wave) const {
+    float* sT = reinterpret_cast<float*>(smem + wave * REGION_BYTES);
+    T* outp = reinterpret_cast<T*>(P.out);
+    T* prep = reinterpret_cast<T*>(P.out_pre);
+    const int nw0 = n0 + wn * 64;                 // first column of this wave's strip
+#pragma unroll
+    for (int p = 0; p < NPASS; ++p) {
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int tj = 0; tj < 4; ++tj) {
+        float4 b;
+        if constexpr (HOIST_BIAS) b = b4[tj]; else b = bias_at(P, N, nw0 + tj * 16 + (lane >> 4) * 4);
+#pragma unroll
+        for (int i = 0; i < RPP / 16; ++i) {
+          const f32x4_t a = acc[p * (RPP / 16) + i][tj];
+          const float4 v = make_float4(a[0] + b.x, a[1] + b.y, a[2] + b.z, a[3] + b.w);
+          const int r = i * 16 + (lane & 15), c4 = tj * 4 + (lane >> 4);
+          *reinterpret_cast<float4*>(sT + r * 64 + ((c4 ^ (r & 7)) << 2)) = v;
+        }
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // this wave's LDS writes are visible to all of its lanes
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int i = 0; i < NITER; ++i) {
+        const int c = lane + i * 64, r = c / CPR, oc = c % CPR;
+        const int m = m0 + wm * (CF::WM * 16) + p * RPP + r, n = nw0 + oc * EPC;
+        if (m >= P.M || n >= N) continue;
+        float v[EPC];
+#pragma unroll
+        for (int e = 0; e < EPC; e += 4) {
+          const int c4 = (oc * EPC + e) >> 2;
+          const float4 t = *reinterpret_cast<const float4*>(sT + r * 64 + ((c4 ^ (r & 7)) << 2));
+          v[e] = t.x; v[e + 1] = t.y; v[e + 2] = t.z; v[e + 3] = t.w;
+        }
+        const int64_t o = (int64_t)m * ldc + n;
+        if (prep) *reinterpret_cast<uint4*>(prep + o) = f_to_chunk<T>(v);      // pre-activation copy kept for the backward pass (same pass)
+        if (act == LMV_ACT_GELU) {
+#pragma unroll
+          for (int e = 0; e < EPC; ++e) v[e] = act_gelu<T>(v[e]);
+        } else if (act == LMV_ACT_GELU_GRAD) {
+          float u[EPC];
+          chunk_to_f<T>(pf[p][i], u);
+#pragma unroll
+          for (int e = 0; e < EPC; ++e) v[e] *= act_gelu_grad<T>(u[e]);
+        }
+        if (P.row_scale) {
+          float sc;
+          if constexpr (HOIST_BIAS) sc = rs[p][i]; else sc = P.row_scale[m / P.rps];
+#pragma unroll
+          for (int e = 0; e < EPC; ++e) v[e] *= sc;
+        }
+        if (P.res) {
+          float r8[EPC];
+          if (act == LMV_ACT_GELU_GRAD) chunk_to_f<T>(*reinterpret_cast<const uint4*>(reinterpret_cast<const T*>(P.res) + o), r8);
+          else chunk_to_f<T>(pf[p][i], r8);
+#pragma unroll
+          for (int e = 0; e < EPC; ++e) v[e] += r8[e];
+        }
+        *reinterpret_cast<uint4*>(outp + o) = f_to_chunk<T>(v);
+      }
+    }
+  }
+};
 
 template <typename T, bool ATR, bool BTR, bool SPLITK, int BK, bool DMA, typename CF, int MINW = 1>
 __global__ __launch_bounds__(CF::NTHR, MINW) void gemm_kernel(const GemmArgs g) {
@@ -383,6 +415,13 @@ __global__ __launch_bounds__(CF::NTHR, MINW) void gemm_kernel(const GemmArgs g) 
   const int pa = ra0 / PANEL, oa = ra0 % PANEL, pb = cb0 / PANEL, ob = cb0 % PANEL;
   const bool do_bsum = SPLITK && (P.bias_grad != nullptr) && tn == 0 && wn == 0;      // wave-uniform
 
+  // epilogue operands (GELU' operand / residual, DropPath scales, bias): the 8-wave kernels have the registers to fetch them
+  // under the whole k-loop, the 4-wave kernels (128-register budget) fetch the 16-byte chunks right after it
+  constexpr int REGION = 2 * BUF_BYTES / CF::NW;        // epilogue: the operand buffers, carved into one private region per wave
+  constexpr bool EPI_EARLY = !SPLITK && CF::NW >= 8;
+  Epi<T, CF, SPLITK ? 4096 : REGION> epi;      // (unused by the split-K kernels)
+  if constexpr (EPI_EARLY) epi.prefetch(P, g.act & 0xff, N, g.ldc, m0, n0, wm, wn, lane);
+
   int cur = 0;
   if constexpr (DMA) {
     static_assert(sizeof(T) == 2, "the direct-to-LDS path is bf16 only");
@@ -447,8 +486,8 @@ __global__ __launch_bounds__(CF::NTHR, MINW) void gemm_kernel(const GemmArgs g) 
       if (do_bsum && lane < 16) slab[(int64_t)M * g.ldc + m] = accb[ti][0];
     }
   } else {
-    constexpr int REGION = 2 * BUF_BYTES / CF::NW;      // the operand buffers, carved into one private region per wave
-    store_tile<T, CF, REGION>(smem, acc, P, g.act & 0xff, N, g.ldc, m0, n0, wm, wn, lane, wave);
+    if constexpr (!EPI_EARLY) epi.prefetch(P, g.act & 0xff, N, g.ldc, m0, n0, wm, wn, lane);
+    epi.store(smem, acc, P, g.act & 0xff, N, g.ldc, m0, n0, wm, wn, lane, wave);
   }
 }
 
@@ -570,7 +609,7 @@ __global__ __launch_bounds__(512, 2) void bigk_kernel(const GemmArgs g) {
     }
   } else {
     // coalesced epilogue: every wave transposes its 64 x 32 strips through a private LDS region (the ring is dead): fp32 in,
-    // whole 16-byte bf16 row pieces out, with bias / GELU / GELU' x aux / DropPath scale / residual fused as in store_tile
+    // whole 16-byte bf16 row pieces out, with bias / GELU / GELU' x aux / DropPath scale / residual fused as in Epi::store
     __syncthreads();
     constexpr int REGION = 2 * STEP / 8;
     static_assert(REGION >= 64 * 32 * 4, "per-wave epilogue region too small");
@@ -958,7 +997,7 @@ int launch_mode(const Plan& pl, dim3 grid, bool bf, hipStream_t st) {
   switch (pl.tile) {
     case TILE_256:     return launch_one<bf16_t, ATR, BTR, SPLITK, 64, true, C256>(g, grid, st);
     case TILE_256x128: return launch_one<bf16_t, ATR, BTR, SPLITK, 64, true, C256x128>(g, grid, st);
-    case TILE_128W8:   return launch_one<bf16_t, ATR, BTR, SPLITK, 64, true, C128w8, 2>(g, grid, st);
+    case TILE_128W8:   return launch_one<bf16_t, ATR, BTR, SPLITK, 64, true, C128w8, 4>(g, grid, st);
     default:           return launch_one<bf16_t, ATR, BTR, SPLITK, 64, true, C128>(g, grid, st);
   }
 }

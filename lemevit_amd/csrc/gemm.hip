@@ -35,6 +35,7 @@
 // one extra MFMA per fragment against an all-ones operand.
 #include <stdlib.h>
 #include <atomic>
+#include <utility>
 #include "common.h"
 
 namespace {
@@ -180,6 +181,101 @@ __device__ __forceinline__ void frag_f32(const unsigned char* s, int base, int l
     const int col = base + (lane & 15), r0 = hh * 16 + (lane >> 4) * 4;
 #pragma unroll
     for (int q = 0; q < 4; ++q) f[q] = *reinterpret_cast<const float*>(s + (r0 + q) * 512 + col * 4);
+  }
+}
+
+template <typename F, int... I> __device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, I...>) { (f(std::integral_constant<int, I>{}), ...); }
+template <int N, typename F> __device__ __forceinline__ void static_for(F&& f) { static_for_impl(f, std::make_integer_sequence<int, N>{}); }
+
+// ---- the same fragments through inline asm (LDS-DMA loop) -----------------------------------------------------------
+// hipcc orders every LDS read it can SEE behind all pending LDS-DMA writes with s_waitcnt vmcnt(0) -- in a double-buffered loop that
+// is the k-tile just requested, i.e. the prefetch never overlaps the MFMAs of the workgroup that issued it.  The DMA loop therefore
+// reads its fragments with asm ds_read (byte offsets into LDS) and places its own counted waits.
+template <bool TR, int BK>
+__device__ __forceinline__ unsigned frag_off(int base, int lane, int hh) {          // byte offset of the lane's (first) read inside the panel
+  if (!TR) {
+    constexpr int ROWB = BK * 2;
+    const int row = base + (lane & 15), kc = hh * 4 + (lane >> 4);
+    return row * ROWB + ((kc ^ swz_n<ROWB>(row)) << 4);
+  } else {
+    const int g = lane >> 4, i = lane & 15, rr = i >> 2, q = i & 3;
+    const int r1 = hh * 32 + g * 8 + rr, ch = base >> 4;
+    return r1 * 256 + ((ch ^ swz_t(r1)) << 5) + q * 8;                              // second read: row r1 + 4 = + 1024 bytes, same swizzle
+  }
+}
+template <bool TR>
+__device__ __forceinline__ bf16x8_t frag_ld(unsigned addr) {
+  if (!TR) {
+    bf16x8_t v;
+    asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(addr) : "memory");
+    return v;
+  } else {
+    bf16x4_t lo, hi;
+    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(lo) : "v"(addr) : "memory");
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:1024" : "=v"(hi) : "v"(addr) : "memory");
+    return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+  }
+}
+template <int N_> __device__ __forceinline__ void wait_vm() {
+  static_assert(N_ >= 0 && N_ < 64, "vmcnt is 6 bits");
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N_) : "memory");
+}
+
+#ifndef LMV_DUAL_HALF
+#define LMV_DUAL_HALF 1
+#endif
+template <int N_> __device__ __forceinline__ void wait_lgkm() {
+  static_assert(N_ >= 0 && N_ < 16, "lgkmcnt is 4 bits");
+  asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N_) : "memory");
+}
+
+// MFMAs of one 32-deep half k-tile whose fragment reads are in flight, followed by PEND younger LDS reads (LDS returns in order).
+// ONE wait for the whole half: waiting per A row (counted lgkmcnt before each group of 4 MFMAs) measured 1.5 % slower per train step.
+template <bool BSUM, int WM, int PEND>
+__device__ __forceinline__ void mma_half(bf16x8_t (&af)[WM], bf16x8_t (&bf)[4], f32x4_t (&acc)[WM][4], f32x4_t (&accb)[WM], bool do_bsum) {
+  wait_lgkm<PEND>();
+#pragma unroll
+  for (int t = 0; t < 4; ++t) asm volatile("" : "+v"(bf[t]));          // the MFMAs below must not be scheduled above the wait
+#pragma unroll
+  for (int t = 0; t < WM; ++t) asm volatile("" : "+v"(af[t]));
+#pragma unroll
+  for (int ti = 0; ti < WM; ++ti)
+#pragma unroll
+    for (int tj = 0; tj < 4; ++tj) acc[ti][tj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[tj], af[ti], acc[ti][tj], 0, 0, 0);
+  if constexpr (BSUM) {
+    if (do_bsum) {          // wave-uniform: column sums of the A tile = A^T * ones
+      typedef __attribute__((ext_vector_type(8))) unsigned short u16x8_t;
+      const u16x8_t o16 = {0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80};
+      const bf16x8_t ones = __builtin_bit_cast(bf16x8_t, o16);
+#pragma unroll
+      for (int ti = 0; ti < WM; ++ti) accb[ti] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, af[ti], accb[ti], 0, 0, 0);
+    }
+  }
+}
+
+// one k-tile of the DMA loop: aA / aB = LDS byte address of the wave's A / B panel, oa / ob = its first row / column inside that panel
+template <bool ATR, bool BTR, int BK, bool BSUM, int WM>
+__device__ __forceinline__ void tile_mma_dma(unsigned aA, int oa, unsigned aB, int ob, f32x4_t (&acc)[WM][4], f32x4_t (&accb)[WM], bool do_bsum, int lane) {
+  constexpr int IA = ATR ? 2 : 1, IB = BTR ? 2 : 1, NH = 4 * IB + WM * IA;      // LDS instructions per fragment / per half k-tile
+  auto rd = [&](bf16x8_t (&af)[WM], bf16x8_t (&bf)[4], int hh) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t) bf[t] = frag_ld<BTR>(aB + frag_off<BTR, BK>(ob + t * 16, lane, hh));
+#pragma unroll
+    for (int t = 0; t < WM; ++t) af[t] = frag_ld<ATR>(aA + frag_off<ATR, BK>(oa + t * 16, lane, hh));
+  };
+  bf16x8_t af0[WM], bf0[4];
+  rd(af0, bf0, 0);
+  if constexpr (BK == 32) {
+    mma_half<BSUM, WM, 0>(af0, bf0, acc, accb, do_bsum);
+  } else if constexpr (LMV_DUAL_HALF && NH <= 15) {      // 64-deep: the second half's reads fly under the first half's MFMAs
+    bf16x8_t af1[WM], bf1[4];
+    rd(af1, bf1, 1);
+    mma_half<BSUM, WM, NH>(af0, bf0, acc, accb, do_bsum);
+    mma_half<BSUM, WM, 0>(af1, bf1, acc, accb, do_bsum);
+  } else {
+    mma_half<BSUM, WM, 0>(af0, bf0, acc, accb, do_bsum);
+    rd(af0, bf0, 1);
+    mma_half<BSUM, WM, 0>(af0, bf0, acc, accb, do_bsum);
   }
 }
 
@@ -347,13 +443,13 @@ template <typename T, typename CF, int REGION_BYTES> struct Epi {
   }
 };
 
-template <typename T, bool ATR, bool BTR, bool SPLITK, int BK, bool DMA, typename CF, int MINW = 1>
+template <typename T, bool ATR, bool BTR, bool SPLITK, int BK, bool DMA, typename CF, int MINW = 1, int NST = 2>
 __global__ __launch_bounds__(CF::NTHR, MINW) void gemm_kernel(const GemmArgs g) {
   constexpr int PANEL_BYTES = PANEL * BK * (int)sizeof(T);
   constexpr int BUF_BYTES = (CF::PA + CF::PB) * PANEL_BYTES;
   constexpr int WM = CF::WM;
   static_assert(DMA || (CF::PA == 1 && CF::PB == 1 && CF::NTHR == 256), "the register-staged loop is written for the 128x128 tile");
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];     // [2 buffers][A panels | B panels]; reused by the epilogue
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];     // [NST buffers][A panels | B panels]; reused by the epilogue
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / CF::NWN, wn = wave % CF::NWN;
@@ -415,10 +511,10 @@ __global__ __launch_bounds__(CF::NTHR, MINW) void gemm_kernel(const GemmArgs g) 
   const int pa = ra0 / PANEL, oa = ra0 % PANEL, pb = cb0 / PANEL, ob = cb0 % PANEL;
   const bool do_bsum = SPLITK && (P.bias_grad != nullptr) && tn == 0 && wn == 0;      // wave-uniform
 
-  // epilogue operands (GELU' operand / residual, DropPath scales, bias): the 8-wave kernels have the registers to fetch them
-  // under the whole k-loop, the 4-wave kernels (128-register budget) fetch the 16-byte chunks right after it
-  constexpr int REGION = 2 * BUF_BYTES / CF::NW;        // epilogue: the operand buffers, carved into one private region per wave
-  constexpr bool EPI_EARLY = !SPLITK && CF::NW >= 8;
+  // epilogue operands (GELU' operand / residual; on the 8-wave kernels also DropPath scales and bias) are requested right after the
+  // k-loop, before the first LDS transpose (requesting them before the loop costs the 64-deep kernels their double-buffered fragments)
+  constexpr int REGION = NST * BUF_BYTES / CF::NW;      // epilogue: the operand buffers, carved into one private region per wave
+  constexpr bool EPI_EARLY = false;
   Epi<T, CF, SPLITK ? 4096 : REGION> epi;      // (unused by the split-K kernels)
   if constexpr (EPI_EARLY) epi.prefetch(P, g.act & 0xff, N, g.ldc, m0, n0, wm, wn, lane);
 
@@ -433,14 +529,43 @@ __global__ __launch_bounds__(CF::NTHR, MINW) void gemm_kernel(const GemmArgs g) 
 #pragma unroll
       for (int q = 0; q < CF::PB; ++q) panel_dma<BTR, BK, CF::NW>(buf + (CF::PA + q) * PANEL_BYTES, B16, g.ldb, N, n0 + q * PANEL, k0, lane, wave);
     };
-    issue(smem, kt_beg);
-    __syncthreads();                                  // (the compiler drains vmcnt before the barrier: the LDS-DMA landed)
+    if constexpr (CF::NW >= 8 && NST == 2) {
+      // 8-wave kernels (64-deep k-tiles, 1.5x the fragment reads): the plain loop -- hipcc waits for the requested k-tile BEFORE this
+      // tile's fragment reads, so LDS-DMA writes and ds_reads never share the LDS; measured 3 % faster here than the overlapped loop below
+      issue(smem, kt_beg);
+      __syncthreads();                                  // (the compiler drains vmcnt before the barrier: the LDS-DMA landed)
+      for (int kt = kt_beg; kt < kt_end; ++kt) {
+        if (kt + 1 < kt_end) issue(smem + (cur ^ 1) * BUF_BYTES, kt + 1);
+        const unsigned char* buf = smem + cur * BUF_BYTES;
+        tile_mma<T, ATR, BTR, BK, SPLITK, WM>(buf + pa * PANEL_BYTES, oa, buf + (CF::PA + pb) * PANEL_BYTES, ob, acc, accb, do_bsum, lane);
+        __syncthreads();
+        cur ^= 1;
+      }
+    } else {
+    // NST-deep ring, one raw s_barrier per k-tile.  Iteration kt: request k-tile kt + NST - 1 into the buffer everybody left at the
+    // last barrier, run the MFMAs of k-tile kt, THEN wait until this wave's pieces of k-tile kt + 1 have landed (counted vmcnt: the
+    // NLD * (NST - 2) youngest requests stay in flight) and meet the other waves.  Loads are retired in order, so whatever was
+    // requested before the loop (the epilogue's operands) is older than every count used here.
+    constexpr int NLD = (CF::PA + CF::PB) * (PANEL * BK * 2 / 1024) / CF::NW;      // LDS-DMA instructions per lane and k-tile
+    static_assert(NST == 2 || NST == 3, "ring depth");
+    const unsigned lds0 = (unsigned)(uintptr_t)smem;
+#pragma unroll
+    for (int s = 0; s < NST - 1; ++s)
+      if (kt_beg + s < kt_end) issue(smem + s * BUF_BYTES, kt_beg + s);
+    if (NST == 3 && kt_beg + 1 < kt_end) wait_vm<NLD>(); else wait_vm<0>();
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    int nxt = NST - 1;                                 // buffer of k-tile kt + NST - 1
     for (int kt = kt_beg; kt < kt_end; ++kt) {
-      if (kt + 1 < kt_end) issue(smem + (cur ^ 1) * BUF_BYTES, kt + 1);   // streams under this tile's MFMAs
-      const unsigned char* buf = smem + cur * BUF_BYTES;
-      tile_mma<T, ATR, BTR, BK, SPLITK, WM>(buf + pa * PANEL_BYTES, oa, buf + (CF::PA + pb) * PANEL_BYTES, ob, acc, accb, do_bsum, lane);
-      __syncthreads();
-      cur ^= 1;
+      if (kt + NST - 1 < kt_end) issue(smem + nxt * BUF_BYTES, kt + NST - 1);
+      const unsigned buf = lds0 + cur * BUF_BYTES;
+      tile_mma_dma<ATR, BTR, BK, SPLITK, WM>(buf + pa * PANEL_BYTES, oa, buf + (CF::PA + pb) * PANEL_BYTES, ob, acc, accb, do_bsum, lane);
+      if (NST == 3 && kt + 2 < kt_end) wait_vm<NLD>(); else wait_vm<0>();
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      cur = (cur + 1 == NST) ? 0 : cur + 1;
+      nxt = (nxt + 1 == NST) ? 0 : nxt + 1;
+    }
     }
   } else {
     constexpr int NCH = PANEL_BYTES / 16 / 256;
@@ -962,10 +1087,10 @@ int launch_bigk(const GemmArgs& g, dim3 grid, hipStream_t st) {
   return LMV_OK;
 }
 
-template <typename T, bool ATR, bool BTR, bool SPLITK, int BK, bool DMA, typename CF, int MINW = 1>
+template <typename T, bool ATR, bool BTR, bool SPLITK, int BK, bool DMA, typename CF, int MINW = 1, int NST = 2>
 int launch_one(const GemmArgs& g, dim3 grid, hipStream_t st) {
-  constexpr int lds = 2 * (CF::PA + CF::PB) * PANEL * BK * (int)sizeof(T);
-  auto kern = gemm_kernel<T, ATR, BTR, SPLITK, BK, DMA, CF, MINW>;
+  constexpr int lds = NST * (CF::PA + CF::PB) * PANEL * BK * (int)sizeof(T);
+  auto kern = gemm_kernel<T, ATR, BTR, SPLITK, BK, DMA, CF, MINW, NST>;
   // > 64 KiB of dynamic LDS needs an explicit opt-in, once per kernel AND device.  The call is idempotent, so two threads racing
   // through the first launch both make it; the per-device bit only publishes "done" (re-entrant, no lock).
   static std::atomic<unsigned long long> attr_done{0};
@@ -992,6 +1117,9 @@ int launch_mode(const Plan& pl, dim3 grid, bool bf, hipStream_t st) {
     if constexpr (!SPLITK) {
       if (pl.tile == TILE_256x128) return launch_one<bf16_t, ATR, BTR, SPLITK, 32, true, C256x128, 4>(g, grid, st);
     }
+    static const int nst_dw = [] { const char* e = getenv("LMV_GEMM_NST_DW"); return e ? atoi(e) : 3; }();      // dW: 3-deep ring (140 registers cap it at 3 workgroups per CU anyway); A/B testing
+    static const int nst = [] { const char* e = getenv("LMV_GEMM_NST"); return e ? atoi(e) : 2; }();
+    if ((SPLITK ? nst_dw : nst) == 3) return launch_one<bf16_t, ATR, BTR, SPLITK, 32, true, C128, 3, 3>(g, grid, st);      // 48 KB: 3 workgroups per CU
     return launch_one<bf16_t, ATR, BTR, SPLITK, 32, true, C128, SPLITK ? 3 : 4>(g, grid, st);
   }
   switch (pl.tile) {

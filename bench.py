@@ -285,9 +285,18 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
-    t_issued = time.perf_counter() - t0        # host time to ENQUEUE the K steps (the device is still working)
     sync()
     dt = time.perf_counter() - t0
+    # host time to ENQUEUE one step, measured on an EMPTY launch queue (issuing K steps back to back only measures the queue's
+    # back-pressure: the host blocks once the device is a queue depth behind) -- median of 5 single steps, each preceded by a sync
+    issue = []
+    for _ in range(5):
+        sync()
+        ti = time.perf_counter()
+        step()
+        issue.append(time.perf_counter() - ti)
+    sync()
+    t_issued = sorted(issue)[len(issue) // 2] * args.steps
     kernel_timing_note = None
     if not args.no_kernel_timing:
         # Same kernels, same shapes: every forward-GEMM launch of 3 eager steps run right AFTER the timed region is bracketed by HIP

@@ -242,6 +242,40 @@ int lmv_adamw_flat(float* param, const float* grad, float* exp_avg, float* exp_a
                    int64_t n, float lr, float beta1, float beta2, float eps, float weight_decay, int step, const int* step_dev,
                    void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Whole-block schedules: ONE call enqueues every launch of a LeMeBlock (models/lemevit.py:500-660) on token-major tensors
+ * x [B, H*W, C], c [B, M, C] -- `LeMeBlock.forward_with_x` ("S", :615-650), `forward_with_xc` ("D", :542-582), `forward_with_c`
+ * ("C", :584-613; x is returned untouched by the caller, x_out / dx_out may be NULL).  Replaces the ~12 / ~30 per-op calls a Python
+ * scheduler makes per block and pass (lemevit_amd/blocks.py keeps that schedule for the variants not covered here).
+ *   params: matrices (attn_w, fc1_w, fc2_w) in `dtype`, vectors (biases, LayerNorm affine, pos_embed weight [C, 9] and bias) fp32.
+ *     attn_w / attn_b by kind:  S: {qkv, proj}   D: {qkv1, qkv2, proj_x, proj_c}   C: {q, kv, proj}
+ *   masks: per-sample DropPath scale vectors [B] fp32 or NULL, in the reference's draw order (S / D: x-attn, x-mlp, c-attn, c-mlp; C: c-attn, c-mlp).
+ *   g_*: fp32 gradient accumulators of the same shapes (backward only; accumulated, split reductions: deterministic).
+ * Memory: the library allocates nothing.  `arena` (lmv_block_arena_bytes) receives every forward intermediate and IS the saved state
+ * of the backward pass when save != 0 (keep it until lmv_block_bwd; with save == 0 it is scratch).  `scratch`
+ * (lmv_block_bwd_scratch_bytes) holds the backward temporaries; one buffer may serve all blocks.  side_stream (nullable): the
+ * weight-gradient launches are enqueued there behind an event on `stream`, and `stream` waits for them before the call returns.
+ * ------------------------------------------------------------------------------------------ */
+enum { LMV_BLOCK_S = 0, LMV_BLOCK_D = 1, LMV_BLOCK_C = 2 };
+typedef struct lmv_block_desc {
+  int32_t kind, dtype, B, H, W, M, C, hidden;      /* hidden: MLP width (0 = 4 C) */
+  float eps;                                       /* LayerNorm eps of norm1 / norm2 (1e-6, models/lemevit.py:513,525) */
+  int32_t _pad;
+  const float* pos_w; const float* pos_b; const float* n1_w; const float* n1_b;
+  const void* attn_w[4]; const float* attn_b[4];
+  const float* n2_w; const float* n2_b; const void* fc1_w; const float* fc1_b; const void* fc2_w; const float* fc2_b;
+  const float* masks[4];
+  float* g_pos_w; float* g_pos_b; float* g_n1_w; float* g_n1_b;
+  float* g_attn_w[4]; float* g_attn_b[4];
+  float* g_n2_w; float* g_n2_b; float* g_fc1_w; float* g_fc1_b; float* g_fc2_w; float* g_fc2_b;
+} lmv_block_desc;
+size_t lmv_block_arena_bytes(const lmv_block_desc* d);
+size_t lmv_block_bwd_scratch_bytes(const lmv_block_desc* d);
+int lmv_block_fwd(const lmv_block_desc* d, const void* x, const void* c, void* x_out, void* c_out, void* arena, size_t arena_bytes, int save, void* stream);
+/* x, c: the block inputs of the forward call; dx_out / dc_out: gradients of x_out / c_out; dx / dc: gradients of x / c (written). */
+int lmv_block_bwd(const lmv_block_desc* d, const void* x, const void* c, const void* arena, size_t arena_bytes, const void* dx_out, const void* dc_out,
+                  void* dx, void* dc, void* scratch, size_t scratch_bytes, void* stream, void* side_stream);
+
 #ifdef __cplusplus
 }
 #endif

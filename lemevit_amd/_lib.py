@@ -46,6 +46,14 @@ class AttnDesc(C.Structure):
                 ("scale", C.c_float), ("_pad", C.c_int32)]
 
 
+class BlockDesc(C.Structure):
+    _fields_ = ([(n, C.c_int32) for n in ("kind", "dtype", "B", "H", "W", "M", "C", "hidden")] + [("eps", C.c_float), ("_pad", C.c_int32)] +
+                [(n, C.c_void_p) for n in ("pos_w", "pos_b", "n1_w", "n1_b")] + [("attn_w", C.c_void_p * 4), ("attn_b", C.c_void_p * 4)] +
+                [(n, C.c_void_p) for n in ("n2_w", "n2_b", "fc1_w", "fc1_b", "fc2_w", "fc2_b")] + [("masks", C.c_void_p * 4)] +
+                [(n, C.c_void_p) for n in ("g_pos_w", "g_pos_b", "g_n1_w", "g_n1_b")] + [("g_attn_w", C.c_void_p * 4), ("g_attn_b", C.c_void_p * 4)] +
+                [(n, C.c_void_p) for n in ("g_n2_w", "g_n2_b", "g_fc1_w", "g_fc1_b", "g_fc2_w", "g_fc2_b")])
+
+
 _P, _I, _L, _F, _Z = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_size_t
 
 # name -> (restype, argtypes); the complete export list of include/lemevit_hip.h
@@ -87,6 +95,10 @@ SIGNATURES = {
     "lmv_token_mean2_fwd": (_I, [_P, _I, _P, _I, _I, _I, _P, _I, _P]),
     "lmv_token_mean2_bwd": (_I, [_P, _P, _I, _P, _I, _I, _I, _I, _P]),
     "lmv_adamw_flat": (_I, [_P, _P, _P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _I, _P, _P]),
+    "lmv_block_arena_bytes": (_Z, [C.POINTER(BlockDesc)]),
+    "lmv_block_bwd_scratch_bytes": (_Z, [C.POINTER(BlockDesc)]),
+    "lmv_block_fwd": (_I, [C.POINTER(BlockDesc), _P, _P, _P, _P, _P, _Z, _I, _P]),
+    "lmv_block_bwd": (_I, [C.POINTER(BlockDesc), _P, _P, _P, _Z, _P, _P, _P, _P, _P, _Z, _P, _P]),
 }
 
 

@@ -68,6 +68,17 @@ def _fork(dev) -> Optional[int]:
     return raw
 
 
+def side_stream_handle(dev) -> Optional[int]:
+    """Raw handle of the weight-gradient side stream for the native block schedule (lmv_block_bwd forks / joins it itself); None = in line."""
+    if not _SIDE or torch.cuda.is_current_stream_capturing():
+        return None
+    ent = _side_streams.get(dev.index)
+    if ent is None:
+        side = torch.cuda.Stream(device=dev)
+        ent = _side_streams[dev.index] = (side, side.cuda_stream, torch.cuda.Event(), torch.cuda.Event())
+    return ent[1]
+
+
 # The split-K reductions of a block's weight gradients are deferred (ops.DwBatch) and summed by ONE launch at the end of the block's
 # backward pass instead of one ~7 us launch behind every GEMM (LMV_DW_BATCH=0: the per-GEMM path, for A/B runs).
 _DW_BATCH = os.environ.get("LMV_DW_BATCH", "0") != "0"      # measured: 0.5 ms SLOWER per step (the slabs of a whole block leave the MALL before they are read back)

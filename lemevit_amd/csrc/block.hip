@@ -1,0 +1,438 @@
+// block.hip -- native schedule of one LeMeBlock (models/lemevit.py:500-660) over the kernels of this library: ONE C-ABI call runs the
+// 12 (forward) / ~30 (backward) launches of a block, so the host spends ~40 us per block instead of ~25 Python -> ctypes round trips.
+//
+//   "S" block (:615-650)  forward_with_x : x, c share norm1 / attn / norm2 / mlp weights -> every Linear is one dual-problem launch
+//   "D" block (:542-582)  forward_with_xc: dual cross attention, qkv1 / qkv2 and proj_x / proj_c differ
+//   "C" block (:584-613)  forward_with_c : only c is updated (cross attention over the image tokens); x is returned untouched
+//
+// Host code only.  The library still never allocates device memory: every intermediate lives in the caller's `arena` (forward: it doubles
+// as the saved-for-backward state, the caller keeps it alive until lmv_block_bwd) or `scratch` (backward; one buffer can serve every
+// block of a model: the weight-gradient launches that run on the side stream are joined into the main stream before the call returns).
+#include <math.h>
+#include <mutex>
+#include "common.h"
+
+namespace {
+
+struct Bump {                     // 256-byte aligned bump allocator; base == nullptr: size pass
+  unsigned char* base; size_t off, cap;
+  void* take(size_t n) {
+    const size_t a = (off + 255) & ~(size_t)255;
+    off = a + n;
+    return base ? (void*)(base + a) : (void*)(uintptr_t)256;      // size pass: any aligned non-null value
+  }
+};
+
+struct Dims {
+  int kind, dtype, B, H, W, N, M, C, Hd, heads;
+  size_t es;
+  int64_t rows[2];                // image-token rows, meta-token rows
+};
+
+int dims_of(const lmv_block_desc* d, Dims* o) {
+  if (!d) LMV_FAIL(LMV_ERR_SHAPE, "block: null descriptor");
+  if (d->kind < LMV_BLOCK_S || d->kind > LMV_BLOCK_C) LMV_FAIL(LMV_ERR_SHAPE, "block: kind %d (0 = S, 1 = D, 2 = C)", d->kind);
+  if (d->dtype != LMV_F32 && d->dtype != LMV_BF16) LMV_FAIL(LMV_ERR_DTYPE, "block: unsupported dtype %d", d->dtype);
+  if (d->B <= 0 || d->H <= 0 || d->W <= 0 || d->M <= 0 || d->C <= 0 || (d->C % 32)) LMV_FAIL(LMV_ERR_SHAPE, "block: bad dims B=%d H=%d W=%d M=%d C=%d", d->B, d->H, d->W, d->M, d->C);
+  o->kind = d->kind; o->dtype = d->dtype; o->B = d->B; o->H = d->H; o->W = d->W; o->N = d->H * d->W; o->M = d->M; o->C = d->C;
+  o->Hd = d->hidden > 0 ? d->hidden : 4 * d->C; o->heads = d->C / 32;
+  o->es = d->dtype == LMV_BF16 ? 2 : 4;
+  o->rows[0] = (int64_t)d->B * o->N; o->rows[1] = (int64_t)d->B * d->M;
+  return LMV_OK;
+}
+
+// widths of the packed projections: S / D: qkv of both streams; C: kv of the image tokens, q of the meta tokens
+inline int proj_w(const Dims& D, int s) { return D.kind == LMV_BLOCK_C ? (s == 0 ? 2 * D.C : D.C) : 3 * D.C; }
+
+struct Fwd {                      // forward intermediates = saved state of the backward pass ([0] image tokens, [1] meta tokens)
+  void *xp, *n1[2], *pj[2], *ao[2], *t2[2], *n2[2], *u[2], *h[2], *ws;
+  float *st1[2], *lse[2], *st2[2];
+  size_t ws_bytes;
+};
+
+void layout_fwd(const Dims& D, Bump& a, Fwd* f) {
+  const bool cb = D.kind == LMV_BLOCK_C;
+  f->xp = a.take(D.rows[0] * D.C * D.es);
+  for (int s = 0; s < 2; ++s) {
+    f->n1[s] = a.take(D.rows[s] * D.C * D.es);
+    f->st1[s] = (float*)a.take(D.rows[s] * 2 * sizeof(float));
+    f->pj[s] = a.take(D.rows[s] * proj_w(D, s) * D.es);
+    const bool has = !(cb && s == 0);                       // C block: nothing of the image-token stream past the kv projection
+    f->ao[s] = has ? a.take(D.rows[s] * D.C * D.es) : nullptr;
+    f->lse[s] = has ? (float*)a.take((size_t)D.B * D.heads * (s == 0 ? D.N : D.M) * sizeof(float)) : nullptr;
+    f->t2[s] = has ? a.take(D.rows[s] * D.C * D.es) : nullptr;
+    f->n2[s] = has ? a.take(D.rows[s] * D.C * D.es) : nullptr;
+    f->st2[s] = has ? (float*)a.take(D.rows[s] * 2 * sizeof(float)) : nullptr;
+    f->u[s] = has ? a.take(D.rows[s] * D.Hd * D.es) : nullptr;
+    f->h[s] = has ? a.take(D.rows[s] * D.Hd * D.es) : nullptr;
+  }
+  size_t w = 256;
+  if (cb) w = lmv_attn_workspace_bytes(D.B, D.heads, D.M, D.N, 0);
+  else if (D.kind == LMV_BLOCK_D) { w = lmv_attn_workspace_bytes(D.B, D.heads, D.N, D.M, 0); const size_t w2 = lmv_attn_workspace_bytes(D.B, D.heads, D.M, D.N, 0); if (w2 > w) w = w2; }
+  else { w = lmv_attn_workspace_bytes(D.B, D.heads, D.N, D.N, 0); const size_t w2 = lmv_attn_workspace_bytes(D.B, D.heads, D.M, D.M, 0); if (w2 > w) w = w2; }
+  if (w < 256) w = 256;
+  f->ws_bytes = w;
+  f->ws = a.take(w);
+}
+
+void attn_desc(lmv_attn_desc* a, const Dims& D, const void* q, int qw, int qo, const void* k, int kw, int ko, const void* v, int vw, int vo,
+               void* o, float* lse, int Lq, int Lk, float scale) {
+  *a = lmv_attn_desc{};
+  a->q = (const unsigned char*)q + qo * D.es; a->k = (const unsigned char*)k + ko * D.es; a->v = (const unsigned char*)v + vo * D.es;
+  a->o = o; a->lse = lse;
+  a->q_bs = (int64_t)Lq * qw; a->q_rs = qw; a->k_bs = (int64_t)Lk * kw; a->k_rs = kw; a->v_bs = (int64_t)Lk * vw; a->v_rs = vw;
+  a->o_bs = (int64_t)Lq * D.C; a->o_rs = D.C;
+  a->B = D.B; a->H = D.heads; a->Lq = Lq; a->Lk = Lk; a->scale = scale;
+}
+void attn_grads(lmv_attn_desc* a, const Dims& D, const void* d_o, void* dq, int qo, void* dk, int ko, void* dv, int vo) {
+  a->d_o = d_o;
+  a->dq = (unsigned char*)dq + qo * D.es; a->dk = (unsigned char*)dk + ko * D.es; a->dv = (unsigned char*)dv + vo * D.es;
+}
+
+lmv_linear_problem prob(const void* a, const void* w, void* out, int64_t rows) {
+  lmv_linear_problem p{};
+  p.a = a; p.w = w; p.out = out; p.rows = rows;
+  return p;
+}
+
+#define LMV_TRY(expr) do { const int rc__ = (expr); if (rc__) return rc__; } while (0)
+
+const float SDPA_SCALE = 0.17677669529663687f;        // 32^-1/2 (models/lemevit.py:175: head_dim ** -0.5)
+inline void dca_scales(const Dims& D, float* sx, float* sc) {      // models/lemevit.py:235,255-256
+  const double base = pow((double)D.C, -0.5);
+  *sx = (float)(log((double)D.M) / log((double)D.N) * base);
+  *sc = (float)base;
+}
+
+// ---- MLP half:  out_s = t_s + ds_s * fc2(GELU(fc1(LN2(t_s))))  for the streams s in [s0, 2) -------------------------------------------
+int mlp_fwd(const lmv_block_desc* d, const Dims& D, const Fwd& f, int s0, void* const* outs, const float* const* ds, int save, void* st) {
+  const int ns = 2 - s0;
+  lmv_ln_segment seg[2] = {};
+  for (int i = 0; i < ns; ++i) { const int s = s0 + i; seg[i].x = f.t2[s]; seg[i].y = f.n2[s]; seg[i].stats = save ? f.st2[s] : nullptr; seg[i].rows = D.rows[s]; }
+  LMV_TRY(lmv_layernorm_fwd(seg, ns, d->n2_w, d->n2_b, D.C, d->eps, D.dtype, st));
+  lmv_linear_problem p[2];
+  for (int i = 0; i < ns; ++i) { const int s = s0 + i; p[i] = prob(f.n2[s], d->fc1_w, f.h[s], D.rows[s]); p[i].bias = d->fc1_b; p[i].out_pre = save ? f.u[s] : nullptr; }
+  LMV_TRY(lmv_linear_fwd(p, ns, D.Hd, D.C, LMV_ACT_GELU, D.dtype, st));
+  for (int i = 0; i < ns; ++i) {
+    const int s = s0 + i;
+    p[i] = prob(f.h[s], d->fc2_w, outs[s], D.rows[s]); p[i].bias = d->fc2_b; p[i].res = f.t2[s]; p[i].row_scale = ds[s];
+    p[i].rows_per_sample = s == 0 ? D.N : D.M;
+  }
+  return lmv_linear_fwd(p, ns, D.C, D.Hd, LMV_ACT_NONE, D.dtype, st);
+}
+
+// ---- backward plumbing: weight-gradient launches go to the side stream ---------------------------------------------------------------
+struct Side {
+  hipStream_t main, side; hipEvent_t fork, join; bool used;
+  void* ws; size_t ws_bytes;
+  hipStream_t begin() {           // the stream a weight-gradient launch goes to, made to wait for everything enqueued on `main` so far
+    if (!side) return main;
+    (void)hipEventRecord(fork, main);
+    (void)hipStreamWaitEvent(side, fork, 0);
+    used = true;
+    return side;
+  }
+  void finish() {
+    if (side && used) { (void)hipEventRecord(join, side); (void)hipStreamWaitEvent(main, join, 0); used = false; }
+  }
+};
+
+int side_events(hipEvent_t* fork, hipEvent_t* join) {
+  static std::mutex mu;
+  static hipEvent_t ev[64][2];
+  static bool have[64] = {};
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  dev &= 63;
+  std::lock_guard<std::mutex> lk(mu);
+  if (!have[dev]) {
+    if (hipEventCreateWithFlags(&ev[dev][0], hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&ev[dev][1], hipEventDisableTiming) != hipSuccess)
+      LMV_FAIL(LMV_ERR_LAUNCH, "block_bwd: cannot create stream events");
+    have[dev] = true;
+  }
+  *fork = ev[dev][0]; *join = ev[dev][1];
+  return LMV_OK;
+}
+
+int dw(Side& sd, const lmv_linear_problem* p, int np, int N, int K, int dtype) {
+  const size_t need = lmv_linear_dw_workspace_bytes(p, np, N, K, dtype);
+  if (need > sd.ws_bytes) LMV_FAIL(LMV_ERR_WORKSPACE, "block_bwd: weight-gradient workspace %zu > %zu bytes", need, sd.ws_bytes);
+  return lmv_linear_dw(p, np, N, K, sd.ws, sd.ws_bytes, dtype, sd.begin());
+}
+
+struct Bwd {                      // backward temporaries ([0] image tokens, [1] meta tokens)
+  void *g[2], *du[2], *dn2[2], *dt2[2], *g2[2], *dao[2], *dpj[2], *dn1[2], *dxp, *ws_main, *ws_side;
+  size_t ws_main_bytes, ws_side_bytes;
+};
+
+size_t max_dw_ws(const Dims& D) {
+  // the weight-gradient GEMMs of a block: (N, K) per layer, rows = image + meta tokens (shared weights) or one stream each
+  const void* fake = (const void*)(uintptr_t)256;
+  size_t m = 256;
+  auto one = [&](int np, int64_t r0, int64_t r1, int N, int K, bool shared) {
+    lmv_linear_problem p[2];
+    float* o0 = (float*)(uintptr_t)256; float* o1 = shared ? o0 : (float*)(uintptr_t)512;
+    p[0] = prob(fake, fake, o0, r0); p[0].bias_grad = (float*)(uintptr_t)1024;
+    p[1] = prob(fake, fake, o1, r1); p[1].bias_grad = shared ? p[0].bias_grad : (float*)(uintptr_t)2048;
+    const size_t w = lmv_linear_dw_workspace_bytes(p, np, N, K, D.dtype);
+    if (w > m) m = w;
+  };
+  const int C = D.C, Hd = D.Hd;
+  if (D.kind == LMV_BLOCK_C) {
+    one(1, D.rows[1], 0, C, Hd, true); one(1, D.rows[1], 0, Hd, C, true); one(1, D.rows[1], 0, C, C, true); one(1, D.rows[0], 0, 2 * C, C, true);
+  } else {
+    const bool sh = D.kind == LMV_BLOCK_S;
+    one(2, D.rows[0], D.rows[1], C, Hd, true); one(2, D.rows[0], D.rows[1], Hd, C, true);
+    one(2, D.rows[0], D.rows[1], C, C, sh); one(2, D.rows[0], D.rows[1], 3 * C, C, sh);
+  }
+  const size_t wc = lmv_dwconv3x3_bwd_weight_workspace_bytes(D.B, D.H, D.W, D.C, D.dtype);
+  return wc > m ? wc : m;
+}
+
+void layout_bwd(const Dims& D, Bump& a, Bwd* b) {
+  const bool cb = D.kind == LMV_BLOCK_C;
+  for (int s = 0; s < 2; ++s) {
+    const bool has = !(cb && s == 0);
+    b->g[s] = has ? a.take(D.rows[s] * D.C * D.es) : nullptr;
+    b->du[s] = has ? a.take(D.rows[s] * D.Hd * D.es) : nullptr;
+    b->dn2[s] = has ? a.take(D.rows[s] * D.C * D.es) : nullptr;
+    b->dt2[s] = has ? a.take(D.rows[s] * D.C * D.es) : nullptr;
+    b->g2[s] = has ? a.take(D.rows[s] * D.C * D.es) : nullptr;
+    b->dao[s] = has ? a.take(D.rows[s] * D.C * D.es) : nullptr;
+    b->dpj[s] = a.take(D.rows[s] * proj_w(D, s) * D.es);
+    b->dn1[s] = a.take(D.rows[s] * D.C * D.es);
+  }
+  b->dxp = a.take(D.rows[0] * D.C * D.es);
+  size_t w = lmv_layernorm_bwd_workspace_bytes(D.rows[0] + D.rows[1], D.C, D.dtype);
+  size_t w2;
+  if (cb) w2 = lmv_attn_workspace_bytes(D.B, D.heads, D.M, D.N, 1);
+  else if (D.kind == LMV_BLOCK_D) { w2 = lmv_attn_workspace_bytes(D.B, D.heads, D.N, D.M, 1); const size_t w3 = lmv_attn_workspace_bytes(D.B, D.heads, D.M, D.N, 1); if (w3 > w2) w2 = w3; }
+  else { w2 = lmv_attn_workspace_bytes(D.B, D.heads, D.N, D.N, 1); const size_t w3 = lmv_attn_workspace_bytes(D.B, D.heads, D.M, D.M, 1); if (w3 > w2) w2 = w3; }
+  if (w2 > w) w = w2;
+  if (w < 256) w = 256;
+  b->ws_main_bytes = w; b->ws_main = a.take(w);
+  b->ws_side_bytes = max_dw_ws(D); b->ws_side = a.take(b->ws_side_bytes);
+}
+
+// MLP half backward (blocks.py::_mlp_bwd): douts = gradients of the block outputs, returns dt2 (gradient of the MLP half's input) and, where the
+// attention half's DropPath vector nds[s] is set, g2[s] = dt2[s] pre-scaled by it (written by the same LayerNorm-backward launch)
+int mlp_bwd(const lmv_block_desc* d, const Dims& D, const Fwd& f, const Bwd& b, int s0, const void* const* douts, const float* const* ds, const float* const* nds,
+            const void** g2_out, Side& sd) {
+  const int ns = 2 - s0;
+  hipStream_t st = sd.main;
+  const void* g[2];
+  lmv_row_scale_segment rs[2]; int nrs = 0;
+  for (int s = s0; s < 2; ++s) {
+    g[s] = douts[s];
+    if (ds[s]) { rs[nrs].x = douts[s]; rs[nrs].scale = ds[s]; rs[nrs].y = b.g[s]; rs[nrs].rows = D.rows[s]; rs[nrs].rows_per_sample = s == 0 ? D.N : D.M; ++nrs; g[s] = b.g[s]; }
+  }
+  if (nrs) LMV_TRY(lmv_row_scale_multi(rs, nrs, D.C, D.dtype, st));
+  lmv_linear_problem p[2];
+  for (int i = 0; i < ns; ++i) { const int s = s0 + i; p[i] = prob(g[s], f.h[s], d->g_fc2_w, D.rows[s]); p[i].bias_grad = d->g_fc2_b; }
+  LMV_TRY(dw(sd, p, ns, D.C, D.Hd, D.dtype));
+  for (int i = 0; i < ns; ++i) { const int s = s0 + i; p[i] = prob(g[s], d->fc2_w, b.du[s], D.rows[s]); p[i].aux = f.u[s]; }
+  LMV_TRY(lmv_linear_dx(p, ns, D.C, D.Hd, LMV_ACT_GELU_GRAD, D.dtype, st));
+  for (int i = 0; i < ns; ++i) { const int s = s0 + i; p[i] = prob(b.du[s], f.n2[s], d->g_fc1_w, D.rows[s]); p[i].bias_grad = d->g_fc1_b; }
+  LMV_TRY(dw(sd, p, ns, D.Hd, D.C, D.dtype));
+  for (int i = 0; i < ns; ++i) { const int s = s0 + i; p[i] = prob(b.du[s], d->fc1_w, b.dn2[s], D.rows[s]); }
+  LMV_TRY(lmv_linear_dx(p, ns, D.Hd, D.C, LMV_ACT_NONE, D.dtype, st));
+  lmv_ln_segment seg[2] = {};
+  for (int i = 0; i < ns; ++i) {
+    const int s = s0 + i;
+    seg[i].x = f.t2[s]; seg[i].dy = b.dn2[s]; seg[i].stats = f.st2[s]; seg[i].dres = douts[s]; seg[i].dx = b.dt2[s]; seg[i].rows = D.rows[s];
+    g2_out[s] = b.dt2[s];
+    if (nds && nds[s]) { seg[i].dx_scale = nds[s]; seg[i].dx_scaled = b.g2[s]; seg[i].rows_per_sample = s == 0 ? D.N : D.M; g2_out[s] = b.g2[s]; }
+  }
+  return lmv_layernorm_bwd(seg, ns, d->n2_w, d->g_n2_w, d->g_n2_b, D.C, b.ws_main, b.ws_main_bytes, D.dtype, st);
+}
+
+int check_ptrs(const lmv_block_desc* d, bool grads) {
+  const void* need[] = {d->pos_w, d->pos_b, d->n1_w, d->n1_b, d->attn_w[0], d->attn_b[0], d->attn_w[1], d->attn_b[1], d->n2_w, d->n2_b, d->fc1_w, d->fc1_b, d->fc2_w, d->fc2_b};
+  for (const void* p : need) if (!p) LMV_FAIL(LMV_ERR_SHAPE, "block: null parameter pointer");
+  if (d->kind != LMV_BLOCK_S && (!d->attn_w[2] || !d->attn_b[2])) LMV_FAIL(LMV_ERR_SHAPE, "block: null parameter pointer");
+  if (d->kind == LMV_BLOCK_D && (!d->attn_w[3] || !d->attn_b[3])) LMV_FAIL(LMV_ERR_SHAPE, "block: null parameter pointer");
+  if (grads) {
+    const void* gn[] = {d->g_pos_w, d->g_pos_b, d->g_n1_w, d->g_n1_b, d->g_attn_w[0], d->g_attn_b[0], d->g_attn_w[1], d->g_attn_b[1], d->g_n2_w, d->g_n2_b, d->g_fc1_w, d->g_fc1_b,
+                        d->g_fc2_w, d->g_fc2_b};
+    for (const void* p : gn) if (!p) LMV_FAIL(LMV_ERR_SHAPE, "block_bwd: null gradient pointer");
+    if (d->kind != LMV_BLOCK_S && (!d->g_attn_w[2] || !d->g_attn_b[2])) LMV_FAIL(LMV_ERR_SHAPE, "block_bwd: null gradient pointer");
+    if (d->kind == LMV_BLOCK_D && (!d->g_attn_w[3] || !d->g_attn_b[3])) LMV_FAIL(LMV_ERR_SHAPE, "block_bwd: null gradient pointer");
+  }
+  return LMV_OK;
+}
+
+}  // namespace
+
+extern "C" size_t lmv_block_arena_bytes(const lmv_block_desc* d) {
+  Dims D;
+  if (dims_of(d, &D)) return 0;
+  Bump a{nullptr, 0, 0};
+  Fwd f;
+  layout_fwd(D, a, &f);
+  return a.off + 256;
+}
+
+extern "C" size_t lmv_block_bwd_scratch_bytes(const lmv_block_desc* d) {
+  Dims D;
+  if (dims_of(d, &D)) return 0;
+  Bump a{nullptr, 0, 0};
+  Bwd b;
+  layout_bwd(D, a, &b);
+  return a.off + 256;
+}
+
+extern "C" int lmv_block_fwd(const lmv_block_desc* d, const void* x, const void* c, void* x_out, void* c_out, void* arena, size_t arena_bytes, int save, void* stream) {
+  Dims D;
+  LMV_TRY(dims_of(d, &D));
+  LMV_TRY(check_ptrs(d, false));
+  const bool cb = D.kind == LMV_BLOCK_C;
+  if (!x || !c || !c_out || (!cb && !x_out) || !arena || !lmv_aligned16(arena)) LMV_FAIL(LMV_ERR_SHAPE, "block_fwd: null / misaligned tensor");
+  Bump a{(unsigned char*)arena, 0, arena_bytes};
+  Fwd f;
+  layout_fwd(D, a, &f);
+  if (a.off > arena_bytes) LMV_FAIL(LMV_ERR_WORKSPACE, "block_fwd: arena %zu < %zu bytes", arena_bytes, a.off);
+  const int C = D.C, N = D.N, M = D.M;
+  LMV_TRY(lmv_dwconv3x3_residual_fwd(x, d->pos_w, d->pos_b, f.xp, D.B, D.H, D.W, C, D.dtype, stream));          // :546
+  lmv_ln_segment seg[2] = {};
+  seg[0].x = f.xp; seg[0].y = f.n1[0]; seg[0].stats = save ? f.st1[0] : nullptr; seg[0].rows = D.rows[0];
+  seg[1].x = c; seg[1].y = f.n1[1]; seg[1].stats = save ? f.st1[1] : nullptr; seg[1].rows = D.rows[1];
+  LMV_TRY(lmv_layernorm_fwd(seg, 2, d->n1_w, d->n1_b, C, d->eps, D.dtype, stream));
+  lmv_linear_problem p[2];
+  lmv_attn_desc ad[2];
+  void* outs[2] = {x_out, c_out};
+  if (D.kind == LMV_BLOCK_S) {                    // the SAME weights for x and c (:632,634)
+    for (int s = 0; s < 2; ++s) { p[s] = prob(f.n1[s], d->attn_w[0], f.pj[s], D.rows[s]); p[s].bias = d->attn_b[0]; }
+    LMV_TRY(lmv_linear_fwd(p, 2, 3 * C, C, LMV_ACT_NONE, D.dtype, stream));
+    for (int s = 0; s < 2; ++s) { const int L = s == 0 ? N : M; attn_desc(&ad[s], D, f.pj[s], 3 * C, 0, f.pj[s], 3 * C, C, f.pj[s], 3 * C, 2 * C, f.ao[s], save ? f.lse[s] : nullptr, L, L, SDPA_SCALE); }
+    LMV_TRY(lmv_attn_fwd_pair(ad, f.ws, f.ws_bytes, D.dtype, stream));
+    for (int s = 0; s < 2; ++s) {
+      p[s] = prob(f.ao[s], d->attn_w[1], f.t2[s], D.rows[s]); p[s].bias = d->attn_b[1]; p[s].res = s == 0 ? f.xp : c;
+      p[s].row_scale = d->masks[s == 0 ? 0 : 2]; p[s].rows_per_sample = s == 0 ? N : M;
+    }
+    LMV_TRY(lmv_linear_fwd(p, 2, C, C, LMV_ACT_NONE, D.dtype, stream));
+  } else if (D.kind == LMV_BLOCK_D) {             // :288-302
+    float sx, sc;
+    dca_scales(D, &sx, &sc);
+    for (int s = 0; s < 2; ++s) { p[s] = prob(f.n1[s], d->attn_w[s], f.pj[s], D.rows[s]); p[s].bias = d->attn_b[s]; }
+    LMV_TRY(lmv_linear_fwd(p, 2, 3 * C, C, LMV_ACT_NONE, D.dtype, stream));
+    attn_desc(&ad[0], D, f.pj[0], 3 * C, 0, f.pj[1], 3 * C, C, f.pj[1], 3 * C, 2 * C, f.ao[0], save ? f.lse[0] : nullptr, N, M, sx);      // image -> meta (:297)
+    attn_desc(&ad[1], D, f.pj[1], 3 * C, 0, f.pj[0], 3 * C, C, f.pj[0], 3 * C, 2 * C, f.ao[1], save ? f.lse[1] : nullptr, M, N, sc);      // meta -> image (:300)
+    LMV_TRY(lmv_attn_fwd(&ad[0], f.ws, f.ws_bytes, D.dtype, stream));
+    LMV_TRY(lmv_attn_fwd(&ad[1], f.ws, f.ws_bytes, D.dtype, stream));
+    for (int s = 0; s < 2; ++s) {
+      p[s] = prob(f.ao[s], d->attn_w[2 + s], f.t2[s], D.rows[s]); p[s].bias = d->attn_b[2 + s]; p[s].res = s == 0 ? f.xp : c;
+      p[s].row_scale = d->masks[s == 0 ? 0 : 2]; p[s].rows_per_sample = s == 0 ? N : M;
+    }
+    LMV_TRY(lmv_linear_fwd(p, 2, C, C, LMV_ACT_NONE, D.dtype, stream));
+  } else {                                        // :477-486,600  q = attn_w[0] (meta tokens), kv = attn_w[1] (image tokens), proj = attn_w[2]
+    p[0] = prob(f.n1[0], d->attn_w[1], f.pj[0], D.rows[0]); p[0].bias = d->attn_b[1];
+    LMV_TRY(lmv_linear_fwd(p, 1, 2 * C, C, LMV_ACT_NONE, D.dtype, stream));
+    p[0] = prob(f.n1[1], d->attn_w[0], f.pj[1], D.rows[1]); p[0].bias = d->attn_b[0];
+    LMV_TRY(lmv_linear_fwd(p, 1, C, C, LMV_ACT_NONE, D.dtype, stream));
+    attn_desc(&ad[0], D, f.pj[1], C, 0, f.pj[0], 2 * C, 0, f.pj[0], 2 * C, C, f.ao[1], save ? f.lse[1] : nullptr, M, N, SDPA_SCALE);
+    LMV_TRY(lmv_attn_fwd(&ad[0], f.ws, f.ws_bytes, D.dtype, stream));
+    p[0] = prob(f.ao[1], d->attn_w[2], f.t2[1], D.rows[1]); p[0].bias = d->attn_b[2]; p[0].res = c; p[0].row_scale = d->masks[0]; p[0].rows_per_sample = M;
+    LMV_TRY(lmv_linear_fwd(p, 1, C, C, LMV_ACT_NONE, D.dtype, stream));
+  }
+  const float* ds[2] = {cb ? nullptr : d->masks[1], cb ? d->masks[1] : d->masks[3]};
+  return mlp_fwd(d, D, f, cb ? 1 : 0, outs, ds, save, stream);
+}
+
+extern "C" int lmv_block_bwd(const lmv_block_desc* d, const void* x, const void* c, const void* arena, size_t arena_bytes, const void* dx_out, const void* dc_out, void* dx, void* dc,
+                             void* scratch, size_t scratch_bytes, void* stream, void* side_stream) {
+  Dims D;
+  LMV_TRY(dims_of(d, &D));
+  LMV_TRY(check_ptrs(d, true));
+  const bool cb = D.kind == LMV_BLOCK_C;
+  if (!x || !c || !arena || !dc_out || (!cb && !dx_out) || !dx || !dc || !scratch || !lmv_aligned16(scratch)) LMV_FAIL(LMV_ERR_SHAPE, "block_bwd: null / misaligned tensor");
+  Bump a{(unsigned char*)const_cast<void*>(arena), 0, arena_bytes};
+  Fwd f;
+  layout_fwd(D, a, &f);
+  if (a.off > arena_bytes) LMV_FAIL(LMV_ERR_WORKSPACE, "block_bwd: arena %zu < %zu bytes", arena_bytes, a.off);
+  Bump s{(unsigned char*)scratch, 0, scratch_bytes};
+  Bwd b;
+  layout_bwd(D, s, &b);
+  if (s.off > scratch_bytes) LMV_FAIL(LMV_ERR_WORKSPACE, "block_bwd: scratch %zu < %zu bytes", scratch_bytes, s.off);
+  Side sd{(hipStream_t)stream, (hipStream_t)side_stream, nullptr, nullptr, false, b.ws_side, b.ws_side_bytes};
+  if (side_stream) LMV_TRY(side_events(&sd.fork, &sd.join));
+  hipStream_t st = sd.main;
+  const int C = D.C, N = D.N, M = D.M;
+  lmv_linear_problem p[2];
+  lmv_attn_desc ad[2];
+  const void* g2[2] = {nullptr, nullptr};
+  int rc = LMV_OK;
+  auto body = [&]() -> int {
+    if (cb) {
+      const void* douts[2] = {nullptr, dc_out};
+      const float* ds[2] = {nullptr, d->masks[1]};
+      LMV_TRY(mlp_bwd(d, D, f, b, 1, douts, ds, nullptr, g2, sd));                    // g2[1] = b.dt2[1]: gradient of c1
+      const void* dc1 = b.dt2[1];
+      const void* g = dc1;
+      if (d->masks[0]) { LMV_TRY(lmv_row_scale(dc1, d->masks[0], b.g2[1], D.rows[1], C, M, D.dtype, st)); g = b.g2[1]; }
+      p[0] = prob(g, f.ao[1], d->g_attn_w[2], D.rows[1]); p[0].bias_grad = d->g_attn_b[2];
+      LMV_TRY(dw(sd, p, 1, C, C, D.dtype));
+      p[0] = prob(g, d->attn_w[2], b.dao[1], D.rows[1]);
+      LMV_TRY(lmv_linear_dx(p, 1, C, C, LMV_ACT_NONE, D.dtype, st));
+      attn_desc(&ad[0], D, f.pj[1], C, 0, f.pj[0], 2 * C, 0, f.pj[0], 2 * C, C, f.ao[1], f.lse[1], M, N, SDPA_SCALE);
+      attn_grads(&ad[0], D, b.dao[1], b.dpj[1], 0, b.dpj[0], 0, b.dpj[0], C);
+      LMV_TRY(lmv_attn_bwd(&ad[0], b.ws_main, b.ws_main_bytes, D.dtype, st));
+      p[0] = prob(b.dpj[1], f.n1[1], d->g_attn_w[0], D.rows[1]); p[0].bias_grad = d->g_attn_b[0];
+      LMV_TRY(dw(sd, p, 1, C, C, D.dtype));
+      p[0] = prob(b.dpj[0], f.n1[0], d->g_attn_w[1], D.rows[0]); p[0].bias_grad = d->g_attn_b[1];
+      LMV_TRY(dw(sd, p, 1, 2 * C, C, D.dtype));
+      p[0] = prob(b.dpj[1], d->attn_w[0], b.dn1[1], D.rows[1]);
+      LMV_TRY(lmv_linear_dx(p, 1, C, C, LMV_ACT_NONE, D.dtype, st));
+      p[0] = prob(b.dpj[0], d->attn_w[1], b.dn1[0], D.rows[0]);
+      LMV_TRY(lmv_linear_dx(p, 1, 2 * C, C, LMV_ACT_NONE, D.dtype, st));
+      lmv_ln_segment seg[2] = {};
+      seg[0].x = c; seg[0].dy = b.dn1[1]; seg[0].stats = f.st1[1]; seg[0].dres = dc1; seg[0].dx = dc; seg[0].rows = D.rows[1];
+      seg[1].x = f.xp; seg[1].dy = b.dn1[0]; seg[1].stats = f.st1[0]; seg[1].dres = nullptr; seg[1].dx = b.dxp; seg[1].rows = D.rows[0];
+      LMV_TRY(lmv_layernorm_bwd(seg, 2, d->n1_w, d->g_n1_w, d->g_n1_b, C, b.ws_main, b.ws_main_bytes, D.dtype, st));
+    } else {
+      const void* douts[2] = {dx_out, dc_out};
+      const float* ds[2] = {d->masks[1], d->masks[3]};
+      const float* nds[2] = {d->masks[0], d->masks[2]};
+      LMV_TRY(mlp_bwd(d, D, f, b, 0, douts, ds, nds, g2, sd));
+      const bool sh = D.kind == LMV_BLOCK_S;
+      for (int s2 = 0; s2 < 2; ++s2) { p[s2] = prob(g2[s2], f.ao[s2], sh ? d->g_attn_w[1] : d->g_attn_w[2 + s2], D.rows[s2]); p[s2].bias_grad = sh ? d->g_attn_b[1] : d->g_attn_b[2 + s2]; }
+      LMV_TRY(dw(sd, p, 2, C, C, D.dtype));
+      for (int s2 = 0; s2 < 2; ++s2) p[s2] = prob(g2[s2], sh ? d->attn_w[1] : d->attn_w[2 + s2], b.dao[s2], D.rows[s2]);
+      LMV_TRY(lmv_linear_dx(p, 2, C, C, LMV_ACT_NONE, D.dtype, st));
+      if (sh) {
+        for (int s2 = 0; s2 < 2; ++s2) {
+          const int L = s2 == 0 ? N : M;
+          attn_desc(&ad[s2], D, f.pj[s2], 3 * C, 0, f.pj[s2], 3 * C, C, f.pj[s2], 3 * C, 2 * C, f.ao[s2], f.lse[s2], L, L, SDPA_SCALE);
+          attn_grads(&ad[s2], D, b.dao[s2], b.dpj[s2], 0, b.dpj[s2], C, b.dpj[s2], 2 * C);
+        }
+        LMV_TRY(lmv_attn_bwd_pair(ad, b.ws_main, b.ws_main_bytes, D.dtype, st));
+      } else {
+        float sx, sc;
+        dca_scales(D, &sx, &sc);
+        attn_desc(&ad[0], D, f.pj[0], 3 * C, 0, f.pj[1], 3 * C, C, f.pj[1], 3 * C, 2 * C, f.ao[0], f.lse[0], N, M, sx);
+        attn_grads(&ad[0], D, b.dao[0], b.dpj[0], 0, b.dpj[1], C, b.dpj[1], 2 * C);
+        attn_desc(&ad[1], D, f.pj[1], 3 * C, 0, f.pj[0], 3 * C, C, f.pj[0], 3 * C, 2 * C, f.ao[1], f.lse[1], M, N, sc);
+        attn_grads(&ad[1], D, b.dao[1], b.dpj[1], 0, b.dpj[0], C, b.dpj[0], 2 * C);
+        LMV_TRY(lmv_attn_bwd(&ad[0], b.ws_main, b.ws_main_bytes, D.dtype, st));
+        LMV_TRY(lmv_attn_bwd(&ad[1], b.ws_main, b.ws_main_bytes, D.dtype, st));
+      }
+      for (int s2 = 0; s2 < 2; ++s2) { p[s2] = prob(b.dpj[s2], f.n1[s2], sh ? d->g_attn_w[0] : d->g_attn_w[s2], D.rows[s2]); p[s2].bias_grad = sh ? d->g_attn_b[0] : d->g_attn_b[s2]; }
+      LMV_TRY(dw(sd, p, 2, 3 * C, C, D.dtype));
+      for (int s2 = 0; s2 < 2; ++s2) p[s2] = prob(b.dpj[s2], sh ? d->attn_w[0] : d->attn_w[s2], b.dn1[s2], D.rows[s2]);
+      LMV_TRY(lmv_linear_dx(p, 2, 3 * C, C, LMV_ACT_NONE, D.dtype, st));
+      lmv_ln_segment seg[2] = {};
+      seg[0].x = f.xp; seg[0].dy = b.dn1[0]; seg[0].stats = f.st1[0]; seg[0].dres = b.dt2[0]; seg[0].dx = b.dxp; seg[0].rows = D.rows[0];
+      seg[1].x = c; seg[1].dy = b.dn1[1]; seg[1].stats = f.st1[1]; seg[1].dres = b.dt2[1]; seg[1].dx = dc; seg[1].rows = D.rows[1];
+      LMV_TRY(lmv_layernorm_bwd(seg, 2, d->n1_w, d->g_n1_w, d->g_n1_b, C, b.ws_main, b.ws_main_bytes, D.dtype, st));
+    }
+    {
+      hipStream_t ss = sd.begin();
+      const size_t need = lmv_dwconv3x3_bwd_weight_workspace_bytes(D.B, D.H, D.W, C, D.dtype);
+      if (need > sd.ws_bytes) LMV_FAIL(LMV_ERR_WORKSPACE, "block_bwd: dwconv workspace %zu > %zu bytes", need, sd.ws_bytes);
+      LMV_TRY(lmv_dwconv3x3_bwd_weight(b.dxp, x, d->g_pos_w, d->g_pos_b, D.B, D.H, D.W, C, sd.ws, sd.ws_bytes, D.dtype, ss));
+    }
+    return lmv_dwconv3x3_residual_bwd_data(b.dxp, d->pos_w, dx, D.B, D.H, D.W, C, D.dtype, st);
+  };
+  rc = body();
+  sd.finish();                    // also on errors: never leave the main stream un-joined
+  return rc;
+}

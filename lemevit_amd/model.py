@@ -30,7 +30,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from . import ops
-from .blocks import PARAM_NAMES, block_backward, block_forward
+from .blocks import BLOCK_LN_EPS, PARAM_NAMES, block_backward, block_forward
 from .ops import Prob
 
 Tensor = torch.Tensor
@@ -429,6 +429,106 @@ def _resolve_dtype(x: Tensor) -> torch.dtype:
 
 
 # ------------------------------------------------------------------------------------------------
+# native block schedules (csrc/block.hip): ONE C-ABI call per block and pass instead of ~12 / ~30 per-op calls from blocks.py
+# ------------------------------------------------------------------------------------------------
+_NATIVE = os.environ.get("LMV_BLOCK_NATIVE", "1") != "0"      # 0: the Python schedules of blocks.py (A/B runs; they also serve "D2" / "Sx")
+_KIND_CODE = {"S": 0, "D": 1, "C": 2}
+_COMMON_FIELDS = {"pos_embed.weight": "pos_w", "pos_embed.bias": "pos_b", "norm1.weight": "n1_w", "norm1.bias": "n1_b", "norm2.weight": "n2_w",
+                  "norm2.bias": "n2_b", "mlp.0.weight": "fc1_w", "mlp.0.bias": "fc1_b", "mlp.3.weight": "fc2_w", "mlp.3.bias": "fc2_b"}
+_ATTN_SLOTS = {"S": {"attn.qkv": 0, "attn.proj": 1}, "D": {"attn.qkv1": 0, "attn.qkv2": 1, "attn.proj_x": 2, "attn.proj_c": 3},
+               "C": {"attn.q": 0, "attn.kv": 1, "attn.proj": 2}}
+_size_cache: dict = {}
+_scratch_cache: dict = {}
+
+
+def _native_ok(kind: str, x: Tensor, c: Tensor) -> bool:
+    return (_NATIVE and kind in _KIND_CODE and x.is_cuda and x.dtype in (torch.bfloat16, torch.float32) and c.dtype == x.dtype
+            and x.is_contiguous() and c.is_contiguous() and x.shape[-1] % 32 == 0)
+
+
+def _fill_ptrs(desc, kind: str, names, tensors: Dict[str, Tensor], prefix: str) -> None:
+    slots = _ATTN_SLOTS[kind]
+    for n in names:
+        t = tensors[n]
+        if not t.is_contiguous() or not t.is_cuda:
+            raise RuntimeError(f"lemevit_amd: block operand {n} must be a contiguous GPU tensor")
+        f = _COMMON_FIELDS.get(n)
+        if f is not None:
+            setattr(desc, prefix + f, t.data_ptr())
+        else:
+            base, kindof = n.rsplit(".", 1)
+            getattr(desc, prefix + ("attn_w" if kindof == "weight" else "attn_b"))[slots[base]] = t.data_ptr()
+
+
+def _block_desc(kind: str, x: Tensor, c: Tensor, H: int, W: int, names, P: Dict[str, Tensor], masks):
+    from ._lib import BlockDesc
+    d = BlockDesc()
+    d.kind, d.dtype = _KIND_CODE[kind], ops.dtype_code(x)
+    d.B, d.H, d.W, d.M, d.C = x.shape[0], H, W, c.shape[1], x.shape[2]
+    d.hidden = P["mlp.0.weight"].shape[0]
+    d.eps = BLOCK_LN_EPS
+    for n in names:
+        want = x.dtype if _is_matrix(n) else torch.float32
+        if P[n].dtype != want:
+            raise TypeError(f"lemevit_amd: block operand {n} must be {want}")
+    _fill_ptrs(d, kind, names, P, "")
+    for i, m in enumerate(masks):
+        if m is not None:
+            if m.dtype != torch.float32 or not m.is_contiguous():
+                raise TypeError("lemevit_amd: DropPath scale vectors must be contiguous float32")
+            d.masks[i] = m.data_ptr()
+    return d
+
+
+def _sized(fn, d, kind, x, c, H, W) -> int:
+    key = (fn.__name__, kind, x.shape[0], H, W, c.shape[1], x.shape[2], x.dtype, d.hidden)
+    n = _size_cache.get(key)
+    if n is None:
+        n = _size_cache[key] = int(fn(d))
+        if n == 0:
+            raise RuntimeError(f"{fn.__name__} failed: {ops.lib.lmv_last_error().decode(errors='replace')}")
+    return n
+
+
+def _persistent(tag: str, nbytes: int, device) -> Tensor:
+    """Stream-ordered scratch that outlives the call (one per device, stream and use)."""
+    key = (tag, device, ops._stream())
+    t = _scratch_cache.get(key)
+    if t is None or t.numel() < nbytes:
+        t = _scratch_cache[key] = torch.empty(int(nbytes * 1.1) + 4096, device=device, dtype=torch.uint8)
+    return t
+
+
+def native_block_forward(kind: str, x: Tensor, c: Tensor, H: int, W: int, names, P: Dict[str, Tensor], masks, save: bool):
+    """lmv_block_fwd: returns (x_out, c_out, state) with state = (descriptor, arena) for native_block_backward (save=True)."""
+    from ._lib import lib, check
+    d = _block_desc(kind, x, c, H, W, names, P, masks)
+    nbytes = _sized(lib.lmv_block_arena_bytes, d, kind, x, c, H, W)
+    arena = torch.empty(nbytes, device=x.device, dtype=torch.uint8) if save else _persistent("fwd", nbytes, x.device)
+    xo = torch.empty_like(x) if kind != "C" else None
+    co = torch.empty_like(c)
+    check(lib.lmv_block_fwd(d, x.data_ptr(), c.data_ptr(), None if xo is None else xo.data_ptr(), co.data_ptr(), arena.data_ptr(), arena.numel(), 1 if save else 0,
+                            ops._stream()), "lmv_block_fwd")
+    return (x if xo is None else xo), co, ((d, arena) if save else None)
+
+
+def native_block_backward(kind: str, state, x: Tensor, c: Tensor, dx: Optional[Tensor], dc: Tensor, H: int, W: int, names, G: Dict[str, Tensor]):
+    from ._lib import lib, check
+    from .blocks import side_stream_handle
+    d, arena = state
+    for n in names:
+        if G[n].dtype != torch.float32:
+            raise TypeError("lemevit_amd: gradient accumulators must be float32")
+    _fill_ptrs(d, kind, names, G, "g_")
+    nbytes = _sized(lib.lmv_block_bwd_scratch_bytes, d, kind, x, c, H, W)
+    scratch = _persistent("bwd", nbytes, x.device)
+    dx0, dc0 = torch.empty_like(x), torch.empty_like(c)
+    check(lib.lmv_block_bwd(d, x.data_ptr(), c.data_ptr(), arena.data_ptr(), arena.numel(), None if dx is None else dx.data_ptr(), dc.data_ptr(), dx0.data_ptr(),
+                            dc0.data_ptr(), scratch.data_ptr(), scratch.numel(), ops._stream(), side_stream_handle(x.device)), "lmv_block_bwd")
+    return dx0, dc0
+
+
+# ------------------------------------------------------------------------------------------------
 # one autograd node per block
 # ------------------------------------------------------------------------------------------------
 class _BlockFn(torch.autograd.Function):
@@ -436,7 +536,12 @@ class _BlockFn(torch.autograd.Function):
     def forward(ctx, x, c, kind, H, W, masks, names, *params):
         cd = x.dtype
         P = {n: compute_copy(p, cd if _is_matrix(n) else torch.float32) for n, p in zip(names, params)}
-        xo, co, saved = block_forward(kind, x, c, H, W, P, masks, save=True)
+        ctx.native = _native_ok(kind, x, c)
+        if ctx.native:
+            xo, co, state = native_block_forward(kind, x, c, H, W, names, P, masks, save=True)
+            saved = (x, c, state)
+        else:
+            xo, co, saved = block_forward(kind, x, c, H, W, P, masks, save=True)
         ctx.kind, ctx.H, ctx.W, ctx.masks, ctx.names = kind, H, W, masks, names
         ctx.saved, ctx.P = saved, P
         ctx.pmeta = [(p.shape, p.dtype) for p in params]
@@ -476,7 +581,13 @@ class _BlockFn(torch.autograd.Function):
             for n, (shape, _), sz, pd in zip(names, ctx.pmeta, sizes, pad):
                 G[n] = flat[off:off + sz].view(shape)
                 off += pd
-        dx0, dc0 = block_backward(kind, ctx.saved, None if dx is None else dx.contiguous(), None if dc is None else dc.contiguous(), ctx.H, ctx.W, P, G, ctx.masks)
+        if ctx.native:
+            xin, cin, state = ctx.saved
+            dx0, dc0 = native_block_backward(kind, state, xin, cin, None if dx is None else dx.contiguous(), dc.contiguous(), ctx.H, ctx.W, names, G)
+            if kind == "C" and dx is not None:
+                dx0 = dx0 + dx                      # the untouched x's pass-through gradient (as blocks.block_backward)
+        else:
+            dx0, dc0 = block_backward(kind, ctx.saved, None if dx is None else dx.contiguous(), None if dc is None else dc.contiguous(), ctx.H, ctx.W, P, G, ctx.masks)
         cb = getattr(ctx.params[0], "_lmv_grad_cb", None) if inplace else None
         ctx.saved = ctx.params = None
         if cb is not None:
@@ -498,6 +609,9 @@ def run_block(kind: str, x: Tensor, c: Tensor, H: int, W: int, params: "OrderedD
         return (x, out) if kind == "C" else ((out, c) if kind == "Sx" else out)
     cd = x.dtype
     P = {n: compute_copy(p, cd if _is_matrix(n) else torch.float32) for n, p in zip(names, plist)}
+    if _native_ok(kind, x, c):
+        xo, co, _ = native_block_forward(kind, x, c, H, W, names, P, masks, save=False)
+        return xo, co
     xo, co, _ = block_forward(kind, x, c, H, W, P, masks, save=False)
     return xo, co
 

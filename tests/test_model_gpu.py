@@ -569,3 +569,37 @@ def _two_rank_worker_bn_eval(rank, world, port, out, compress):
     if rank == 0:
         torch.save({n: p.grad.detach().float().cpu() for n, p in m.named_parameters() if p.grad is not None}, out)
     dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("kind,C,h,Hs", [("S", 192, 6, 7), ("D", 96, 3, 14), ("C", 64, 2, 14)])
+def test_native_block_schedule_equals_python_schedule(monkeypatch, kind, C, h, Hs, dtype):
+    """lmv_block_fwd / lmv_block_bwd (csrc/block.hip) run the SAME kernels in the same order as lemevit_amd/blocks.py: outputs, input
+    gradients and every parameter gradient must be bit-identical -- with DropPath scale vectors on all four branches and the weight
+    gradients on the side stream.  (Parity of either schedule with the reference: test_block_backward_*.)"""
+    import lemevit_amd.model as M
+    from lemevit_amd.blocks import PARAM_NAMES
+    B, N, Mt = 5, Hs * Hs, 16
+    names = PARAM_NAMES[kind]
+    blk = load(_block(kind, C, h), "blk.", 11)
+    allp = dict(blk.named_parameters())
+    params = {n: allp[n] for n in names}
+    nm = 2 if kind == "C" else 4
+    masks = tuple((det_tensor((B,), f"mask{i}", 4).abs() > 0.3).float().to(DEV) / 0.7 for i in range(nm))
+    res = {}
+    for native in (True, False):
+        monkeypatch.setattr(M, "_NATIVE", native)
+        for p in params.values():
+            p.grad = None
+        x = det_tensor((B, N, C), "x", 6).to(DEV, dtype).requires_grad_(True); c = det_tensor((B, Mt, C), "c", 6).to(DEV, dtype).requires_grad_(True)
+        gx = det_tensor((B, N, C), "gx", 6).to(DEV, dtype); gc = det_tensor((B, Mt, C), "gc", 6).to(DEV, dtype)
+        xo, co = M.run_block(kind, x, c, Hs, Hs, params, masks)
+        ((xo.float() * gx.float()).sum() + (co.float() * gc.float()).sum()).backward()
+        torch.cuda.synchronize()
+        res[native] = [xo.detach().clone(), co.detach().clone(), x.grad.clone(), c.grad.clone()] + [p.grad.clone() for p in params.values()]
+        with torch.no_grad():                 # the no-grad (inference) entry of the same schedule
+            xe, ce = M.run_block(kind, x.detach(), c.detach(), Hs, Hs, params, masks)
+        assert torch.equal(xe, xo.detach()) and torch.equal(ce, co.detach())
+    labels = ["x_out", "c_out", "dx", "dc"] + ["grad " + n for n in names]
+    for a, b, what in zip(res[True], res[False], labels):
+        assert torch.equal(a, b), f"{kind} {dtype} {what}: native and Python schedules differ by {float((a.float() - b.float()).abs().max()):.3e}"

@@ -257,10 +257,12 @@ int lmv_adamw_flat(float* param, const float* grad, float* exp_avg, float* exp_a
  * weight-gradient launches are enqueued there behind an event on `stream`, and `stream` waits for them before the call returns.
  * ------------------------------------------------------------------------------------------ */
 enum { LMV_BLOCK_S = 0, LMV_BLOCK_D = 1, LMV_BLOCK_C = 2 };
+enum { LMV_BLOCK_NO_JOIN = 1 };
 typedef struct lmv_block_desc {
   int32_t kind, dtype, B, H, W, M, C, hidden;      /* hidden: MLP width (0 = 4 C) */
   float eps;                                       /* LayerNorm eps of norm1 / norm2 (1e-6, models/lemevit.py:513,525) */
-  int32_t _pad;
+  int32_t flags;                                   /* LMV_BLOCK_NO_JOIN: lmv_block_bwd leaves the side stream un-joined (the caller records an
+                                                      event on it and makes `stream` wait later; scratch and arena must then outlive that wait) */
   const float* pos_w; const float* pos_b; const float* n1_w; const float* n1_b;
   const void* attn_w[4]; const float* attn_b[4];
   const float* n2_w; const float* n2_b; const void* fc1_w; const float* fc1_b; const void* fc2_w; const float* fc2_b;

@@ -47,7 +47,7 @@ class AttnDesc(C.Structure):
 
 
 class BlockDesc(C.Structure):
-    _fields_ = ([(n, C.c_int32) for n in ("kind", "dtype", "B", "H", "W", "M", "C", "hidden")] + [("eps", C.c_float), ("_pad", C.c_int32)] +
+    _fields_ = ([(n, C.c_int32) for n in ("kind", "dtype", "B", "H", "W", "M", "C", "hidden")] + [("eps", C.c_float), ("flags", C.c_int32)] +
                 [(n, C.c_void_p) for n in ("pos_w", "pos_b", "n1_w", "n1_b")] + [("attn_w", C.c_void_p * 4), ("attn_b", C.c_void_p * 4)] +
                 [(n, C.c_void_p) for n in ("n2_w", "n2_b", "fc1_w", "fc1_b", "fc2_w", "fc2_b")] + [("masks", C.c_void_p * 4)] +
                 [(n, C.c_void_p) for n in ("g_pos_w", "g_pos_b", "g_n1_w", "g_n1_b")] + [("g_attn_w", C.c_void_p * 4), ("g_attn_b", C.c_void_p * 4)] +

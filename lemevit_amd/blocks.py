@@ -14,6 +14,7 @@ node per block (lemevit_amd/model.py::_BlockFn).
 """
 from __future__ import annotations
 
+import collections
 import os
 from typing import Dict, List, Optional, Sequence, Tuple
 
@@ -107,15 +108,54 @@ def _dwconv_w(dy: Tensor, x: Tensor, dweight: Tensor, dbias: Tensor, H: int, W: 
         _inflight.append((dy.device.index, (dy, x)))
 
 
+# The join of a block's side-stream launches is DEFERRED: the main stream does not wait at the end of the block that issued them (its
+# last weight-gradient GEMM and the dwconv weight gradient were requested moments before: the main stream idled ~10-20 us per block
+# there) but at the end of the NEXT block's backward pass, when they have long finished; whatever they read stays referenced until
+# then.  The last blocks of a backward pass are joined by an autograd final callback, i.e. before .backward() returns to the caller.
+_DEFER = int(os.environ.get("LMV_JOIN_DEFER", "1"))       # blocks a join may trail behind (0: join at the end of every block)
+_pending: "collections.deque" = collections.deque()       # (device index, event recorded on the side stream, references)
+_event_pool: List[torch.cuda.Event] = []
+_cb_queued = False
+
+
+def _wait_pending(keep: int) -> None:
+    while len(_pending) > keep:
+        di, ev, _refs = _pending.popleft()
+        torch.cuda.current_stream(torch.device("cuda", di)).wait_event(ev)
+        _event_pool.append(ev)
+
+
+def _final_join() -> None:
+    global _cb_queued
+    _cb_queued = False
+    _wait_pending(0)
+
+
+def defer_join(dev_index: int, refs) -> None:
+    """Record the side stream's position; the main stream waits for it `_DEFER` blocks later (or when the backward pass ends)."""
+    global _cb_queued
+    side = _side_streams[dev_index][0]
+    ev = _event_pool.pop() if _event_pool else torch.cuda.Event()
+    ev.record(side)
+    _pending.append((dev_index, ev, refs))
+    keep = _DEFER
+    if keep > 0 and not _cb_queued:
+        try:
+            torch.autograd.Variable._execution_engine.queue_callback(_final_join)
+            _cb_queued = True
+        except RuntimeError:              # not inside a backward pass (a schedule driven by hand): join now
+            keep = 0
+    _wait_pending(keep)
+
+
 def _join() -> None:
     for (di, raw), batch in _batches.items():
         if batch.segs:
             batch.flush(stream=raw)                 # one reduce launch for every weight gradient of the block, behind its GEMMs
     if _inflight:
-        side, _, _, join = _side_streams[_inflight[-1][0]]
-        join.record(side)
-        torch.cuda.current_stream(side.device).wait_event(join)
+        refs = list(_inflight)
         _inflight.clear()
+        defer_join(refs[-1][0], refs)
 
 
 # The meta-token self-attention of an S block (16 tokens: B * h tiny workgroups, ~13 us of mostly launch ramp and tail per

@@ -433,6 +433,6 @@ extern "C" int lmv_block_bwd(const lmv_block_desc* d, const void* x, const void*
     return lmv_dwconv3x3_residual_bwd_data(b.dxp, d->pos_w, dx, D.B, D.H, D.W, C, D.dtype, st);
   };
   rc = body();
-  sd.finish();                    // also on errors: never leave the main stream un-joined
+  if (rc || !(d->flags & LMV_BLOCK_NO_JOIN)) sd.finish();      // on errors always: never leave the main stream un-joined
   return rc;
 }

@@ -348,7 +348,7 @@ template <typename T, typename CF, int REGION_BYTES> struct Epi {
   // Everything the epilogue READS from global memory, issued for the wave's whole strip before the first LDS transpose: one
   // 16-byte chunk per output chunk (the GELU' operand u, or the residual), the DropPath scale of each chunk's row and the bias.
   // Issued at the point of use these loads stalled every pass for a memory round trip: 0.75 ms of a 33.6 ms Base train step.
-  static constexpr bool HOIST_BIAS = CF::NW >= 8;     // bias + row scales: 24 more live registers -- the 4-wave kernels (128-register budget) would spill
+  static constexpr bool HOIST_BIAS = CF::NW >= 8 && CF::WM == 2;     // bias + row scales: 24 more live registers -- the 4-wave kernels (128-register budget) would spill
   uint4 pf[NPASS][NITER];
   float rs[HOIST_BIAS ? NPASS : 1][HOIST_BIAS ? NITER : 1];
   float4 b4[HOIST_BIAS ? 4 : 1];
@@ -529,7 +529,7 @@ __global__ __launch_bounds__(CF::NTHR, MINW) void gemm_kernel(const GemmArgs g) 
 #pragma unroll
       for (int q = 0; q < CF::PB; ++q) panel_dma<BTR, BK, CF::NW>(buf + (CF::PA + q) * PANEL_BYTES, B16, g.ldb, N, n0 + q * PANEL, k0, lane, wave);
     };
-    if constexpr (CF::NW >= 8 && NST == 2) {
+    if constexpr (CF::NW >= 8 && CF::WM == 2 && NST == 2) {
       // 8-wave kernels (64-deep k-tiles, 1.5x the fragment reads): the plain loop -- hipcc waits for the requested k-tile BEFORE this
       // tile's fragment reads, so LDS-DMA writes and ds_reads never share the LDS; measured 3 % faster here than the overlapped loop below
       issue(smem, kt_beg);
@@ -1115,7 +1115,9 @@ int launch_mode(const Plan& pl, dim3 grid, bool bf, hipStream_t st) {
   // 32-deep k-tiles: 32 KB of LDS and (capped by MINW) <= 128 / 168 registers: 4 (fwd, dX) or 3 (dW) workgroups per CU
   if (pl.bk == 32) {
     if constexpr (!SPLITK) {
-      if (pl.tile == TILE_256x128) return launch_one<bf16_t, ATR, BTR, SPLITK, 32, true, C256x128, 4>(g, grid, st);
+      static const int nst_big = [] { const char* e = getenv("LMV_GEMM_NST"); return e ? atoi(e) : 2; }();
+      if (pl.tile == TILE_256x128) return nst_big == 3 ? launch_one<bf16_t, ATR, BTR, SPLITK, 32, true, C256x128, 4, 3>(g, grid, st)
+                                                       : launch_one<bf16_t, ATR, BTR, SPLITK, 32, true, C256x128, 4>(g, grid, st);
     }
     static const int nst_dw = [] { const char* e = getenv("LMV_GEMM_NST_DW"); return e ? atoi(e) : 3; }();      // dW: 3-deep ring (140 registers cap it at 3 workgroups per CU anyway); A/B testing
     static const int nst = [] { const char* e = getenv("LMV_GEMM_NST"); return e ? atoi(e) : 2; }();

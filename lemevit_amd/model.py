@@ -439,6 +439,7 @@ _ATTN_SLOTS = {"S": {"attn.qkv": 0, "attn.proj": 1}, "D": {"attn.qkv1": 0, "attn
                "C": {"attn.q": 0, "attn.kv": 1, "attn.proj": 2}}
 _size_cache: dict = {}
 _scratch_cache: dict = {}
+_bwd_slot = 0
 
 
 def _native_ok(kind: str, x: Tensor, c: Tensor) -> bool:
@@ -514,6 +515,7 @@ def native_block_forward(kind: str, x: Tensor, c: Tensor, H: int, W: int, names,
 
 def native_block_backward(kind: str, state, x: Tensor, c: Tensor, dx: Optional[Tensor], dc: Tensor, H: int, W: int, names, G: Dict[str, Tensor]):
     from ._lib import lib, check
+    from . import blocks as blocks_mod
     from .blocks import side_stream_handle
     d, arena = state
     for n in names:
@@ -521,10 +523,18 @@ def native_block_backward(kind: str, state, x: Tensor, c: Tensor, dx: Optional[T
             raise TypeError("lemevit_amd: gradient accumulators must be float32")
     _fill_ptrs(d, kind, names, G, "g_")
     nbytes = _sized(lib.lmv_block_bwd_scratch_bytes, d, kind, x, c, H, W)
-    scratch = _persistent("bwd", nbytes, x.device)
+    side = side_stream_handle(x.device)
+    defer = side is not None and blocks_mod._DEFER > 0
+    # deferred join (blocks.defer_join): the side stream may still read this block's scratch while the next blocks run -> rotate buffers
+    global _bwd_slot
+    _bwd_slot = (_bwd_slot + 1) % (blocks_mod._DEFER + 1) if defer else 0
+    scratch = _persistent(("bwd", _bwd_slot), nbytes, x.device)
     dx0, dc0 = torch.empty_like(x), torch.empty_like(c)
+    d.flags = 1 if defer else 0          # LMV_BLOCK_NO_JOIN
     check(lib.lmv_block_bwd(d, x.data_ptr(), c.data_ptr(), arena.data_ptr(), arena.numel(), None if dx is None else dx.data_ptr(), dc.data_ptr(), dx0.data_ptr(),
-                            dc0.data_ptr(), scratch.data_ptr(), scratch.numel(), ops._stream(), side_stream_handle(x.device)), "lmv_block_bwd")
+                            dc0.data_ptr(), scratch.data_ptr(), scratch.numel(), ops._stream(), side), "lmv_block_bwd")
+    if defer:
+        blocks_mod.defer_join(x.device.index, (arena, x, c, dx, dc, scratch))
     return dx0, dc0
 
 
@@ -590,6 +600,11 @@ class _BlockFn(torch.autograd.Function):
             dx0, dc0 = block_backward(kind, ctx.saved, None if dx is None else dx.contiguous(), None if dc is None else dc.contiguous(), ctx.H, ctx.W, P, G, ctx.masks)
         cb = getattr(ctx.params[0], "_lmv_grad_cb", None) if inplace else None
         ctx.saved = ctx.params = None
+        if cb is not None or not inplace:
+            # the parameter gradients leave this node now (all-reduce of the chunk / autograd's accumulation on the current stream):
+            # the deferred joins of the weight-gradient side stream (blocks.defer_join) are due
+            from . import blocks as _blocks
+            _blocks._wait_pending(0)
         if cb is not None:
             cb()                     # lemevit_amd.dist.FlatGradSync: this block closes a chunk of the flat gradient buffer -> start its all-reduce
         if inplace:

@@ -493,10 +493,15 @@ __global__ __launch_bounds__(CF::NTHR, MINW) void gemm_kernel(const GemmArgs g) 
   const int kt_end = min(kt_total, kt_beg + g.kt_per_split);
   if (kt_beg >= kt_end) return;
   // operands of k-tile kt
+  // (operand bases and reduction lengths are copied out of the kernel arguments ONCE: addressed through `P` / `g.p[1]` they were
+  //  re-read with s_load + s_waitcnt in front of every k-tile's requests)
+  const T* const a0 = reinterpret_cast<const T*>(P.a); const T* const b0 = reinterpret_cast<const T*>(P.b);
+  const T* const a1 = SPLITK ? reinterpret_cast<const T*>(g.p[1].a) : a0; const T* const b1 = SPLITK ? reinterpret_cast<const T*>(g.p[1].b) : b0;
+  const int kred0 = P.Kred, kred1 = SPLITK ? g.p[1].Kred : P.Kred;
   auto src_of = [&](int kt, const T** a, const T** b, int* kred, int* k0) {
-    const Problem& Q = (SPLITK && kt >= kt0) ? g.p[1] : P;
-    *a = reinterpret_cast<const T*>(Q.a); *b = reinterpret_cast<const T*>(Q.b);
-    *kred = Q.Kred; *k0 = ((SPLITK && kt >= kt0) ? kt - kt0 : kt) * BK;
+    const bool second = SPLITK && kt >= kt0;
+    *a = second ? a1 : a0; *b = second ? b1 : b0;
+    *kred = second ? kred1 : kred0; *k0 = (second ? kt - kt0 : kt) * BK;
   };
 
   f32x4_t acc[WM][4], accb[WM];

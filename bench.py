@@ -302,12 +302,18 @@ def main():
         # Same kernels, same shapes: every forward-GEMM launch of 3 eager steps run right AFTER the timed region is bracketed by HIP
         # events on rank 0 (events cannot be timed inside a captured graph, and in eager mode they cost ~1 ms per step, which
         # must not leak into `value`).  All ranks run the 3 steps: they contain the gradient collectives.
+        # The timed region runs each block through ONE native call (lmv_block_fwd / _bwd), whose launches Python cannot bracket; these 3
+        # steps take the Python schedule of the same blocks (lemevit_amd/blocks.py: the same kernels on the same shapes, launch by launch).
+        import lemevit_amd.model as _model
+        native_was, _model._NATIVE = _model._NATIVE, False
         timer.enabled = rank == 0
         for _ in range(3):
             eager_step()
         sync()
         timer.enabled = False
-        kernel_timing_note = "HIP events around every launch of 3 eager steps run right after the timed region"
+        _model._NATIVE = native_was
+        kernel_timing_note = ("HIP events around every forward-Linear launch of 3 eager steps run right after the timed region (blocks on the per-launch "
+                              "Python schedule for these steps: same kernels and shapes as the native block calls of the timed region)")
     tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)

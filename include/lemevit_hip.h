@@ -90,6 +90,44 @@ int lmv_linear_dw_partial(const lmv_linear_problem* p, int nproblems, int N, int
 int lmv_reduce_batch(const lmv_reduce_seg* segs, int nsegs, void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Fused block entry points (`ln_linear`, `mlp_fused`, `attn_out_proj_residual`).
+ *
+ * LayerNorm folded into the Linear that consumes it (norm1 -> qkv / q / kv, models/lemevit.py:560,599,632,634; norm2 -> mlp.0,
+ * :563-564,:633,635).  With x_hat = (x - mean) rstd:
+ *     LN(x) W^T + b  =  rstd (x W'^T - mean colsum(W'))  +  b',      W' = gamma . W  (rounded to `dtype`),  b' = b + W beta
+ * so the GEMM reads the RAW residual-stream rows and the normalised copy never exists in HBM.
+ *   lmv_ln_fold       : (W fp32 [N, K], bias [N] or NULL, gamma [K], beta [K]) -> wf [N, K] in `dtype`, colsum [N], bf [N] (fp32);
+ *                       colsum is taken over the ROUNDED wf, so the mean term cancels exactly.  Run once per weight version.
+ *   lmv_ln_linear_fwd : out[r, n] = act(LN(x[r, :]) . W[n, :] + b[n]) from the folded operands; the row statistics are accumulated
+ *                       from the MFMA operand fragments inside the k-loop (one-pass, fp32).  p[i].a = x, p[i].w = wf, p[i].bias = bf,
+ *                       p[i].aux = colsum (fp32 [N]); res / row_scale / out_pre as in lmv_linear_fwd.
+ *   lmv_mlp_fused_fwd : out = x + row_scale * fc2(GELU(fc1(LN(x))))  -- the whole MLP half of a LeMeBlock in ONE kernel: a workgroup
+ *                       keeps 128 token rows in LDS, streams the weights, and the 4C-wide hidden activations never leave the chip
+ *                       (C in + C out per token instead of 17 C).  bf16, C in {64, 96, 128, 192, 256, 320, 384}, hidden % 128 == 0
+ *                       (lmv_mlp_fused_supported); inference form: nothing is saved for a backward pass.
+ *   lmv_attn_out_proj_residual : out = res + row_scale * (attn_out W^T + b) -- the output projection of an attention module with the
+ *                       block's residual add and DropPath folded into the GEMM epilogue (:205 + :562 / :601 / :632,634).
+ * ------------------------------------------------------------------------------------------ */
+int lmv_ln_fold(const float* w, const float* bias, const float* gamma, const float* beta, int N, int K, void* wf, float* colsum, float* bf,
+                int dtype, void* stream);
+int lmv_ln_linear_fwd(const lmv_linear_problem* p, int nproblems, int N, int K, float eps, int act, int dtype, void* stream);
+typedef struct {
+  const void* x;            /* [rows, C]: input of the MLP half (= its residual)                 */
+  void* out;                /* [rows, C]                                                          */
+  const float* row_scale;   /* per-sample DropPath scale [rows / rows_per_sample] or NULL        */
+  int64_t rows;
+  int32_t rows_per_sample;
+  int32_t _pad;
+} lmv_mlp_problem;
+typedef struct {
+  const void* w1f; const float* colsum1; const float* b1f;   /* lmv_ln_fold(mlp.0, norm2): [hidden, C], [hidden], [hidden] */
+  const void* w2; const float* b2;                           /* mlp.3: [C, hidden] in `dtype`, [C] fp32                    */
+} lmv_mlp_weights;
+int lmv_mlp_fused_supported(int C, int hidden, int dtype);
+int lmv_mlp_fused_fwd(const lmv_mlp_problem* p, int nproblems, const lmv_mlp_weights* w, int C, int hidden, float eps, int dtype, void* stream);
+int lmv_attn_out_proj_residual(const lmv_linear_problem* p, int nproblems, int C, int dtype, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * LayerNorm over the last dim (nn.LayerNorm, models/lemevit.py:513,525 eps 1e-6; :731-743,774
  * eps 1e-5).  One launch normalises up to TWO row segments with the same (gamma, beta): the image-token
  * and the meta-token matrix of a block share norm1 / norm2 (:560-564,:632-635).

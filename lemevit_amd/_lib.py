@@ -23,6 +23,14 @@ class LinearProblem(C.Structure):
                 ("bias_grad", C.c_void_p), ("rows", C.c_int64), ("rows_per_sample", C.c_int32), ("_pad", C.c_int32)]
 
 
+class MlpProblem(C.Structure):
+    _fields_ = [("x", C.c_void_p), ("out", C.c_void_p), ("row_scale", C.c_void_p), ("rows", C.c_int64), ("rows_per_sample", C.c_int32), ("_pad", C.c_int32)]
+
+
+class MlpWeights(C.Structure):
+    _fields_ = [("w1f", C.c_void_p), ("colsum1", C.c_void_p), ("b1f", C.c_void_p), ("w2", C.c_void_p), ("b2", C.c_void_p)]
+
+
 class ReduceSeg(C.Structure):
     _fields_ = [("ws", C.c_void_p), ("out_w", C.c_void_p), ("out_b", C.c_void_p), ("slab_stride", C.c_int64), ("nw", C.c_int64),
                 ("nslabs", C.c_int32), ("nb", C.c_int32)]
@@ -66,6 +74,11 @@ SIGNATURES = {
     "lmv_linear_dw": (_I, [C.POINTER(LinearProblem), _I, _I, _I, _P, _Z, _I, _P]),
     "lmv_linear_dw_partial": (_I, [C.POINTER(LinearProblem), _I, _I, _I, _P, _Z, _I, _P, C.POINTER(ReduceSeg), C.POINTER(C.c_int)]),
     "lmv_reduce_batch": (_I, [C.POINTER(ReduceSeg), _I, _P]),
+    "lmv_ln_fold": (_I, [_P, _P, _P, _P, _I, _I, _P, _P, _P, _I, _P]),
+    "lmv_ln_linear_fwd": (_I, [C.POINTER(LinearProblem), _I, _I, _I, _F, _I, _I, _P]),
+    "lmv_mlp_fused_supported": (_I, [_I, _I, _I]),
+    "lmv_mlp_fused_fwd": (_I, [C.POINTER(MlpProblem), _I, C.POINTER(MlpWeights), _I, _I, _F, _I, _P]),
+    "lmv_attn_out_proj_residual": (_I, [C.POINTER(LinearProblem), _I, _I, _I, _P]),
     "lmv_layernorm_fwd": (_I, [C.POINTER(LnSegment), _I, _P, _P, _I, _F, _I, _P]),
     "lmv_layernorm_gelu_fwd": (_I, [C.POINTER(LnSegment), _I, _P, _P, _I, _F, _I, _P]),
     "lmv_layernorm_gelu_bwd": (_I, [C.POINTER(LnSegment), _I, _P, _P, _P, _P, _I, _P, _Z, _I, _P]),

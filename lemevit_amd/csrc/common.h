@@ -107,6 +107,28 @@ __device__ __forceinline__ float gelu_grad_fast_f(float x) {
   return 0.5f * (1.0f + e) + x * 0.39894228040143268f * g;
 }
 
+// GELU of TWO values for the fused MLP kernel (fused.hip), where the activation is the binding VALU cost (4 C values per token, all
+// produced on-chip between two MFMA phases): Phi(x) = 0.5 + s q(s^2), s = clamp(x / 4, -1, 1), q = degree-7 minimax fit of
+// erf(x / sqrt 2) / 2 on [-4, 4] with q(1) = 1/2 exactly (so GELU(x <= -4) = 0 and GELU(x >= 4) = x).  No transcendental, and every
+// step is a packed-fp32 instruction (v_pk_mul_f32 / v_pk_fma_f32: two values per lane and issue).  |Phi error| <= 4.8e-5,
+// |GELU error| <= 1.9e-4 absolute (3.2e-5 for |x| <= 2) -- below half a bf16 ulp of the stored activation for |h| >= 0.05, and the
+// hidden activations only ever exist as bf16 MFMA operands.  (The stand-alone GEMM epilogues keep the erf formula above.)
+__device__ __forceinline__ f32x2_t gelu_poly2(f32x2_t x) {
+  f32x2_t s = x * 0.25f;
+  s[0] = __builtin_amdgcn_fmed3f(s[0], -1.0f, 1.0f); s[1] = __builtin_amdgcn_fmed3f(s[1], -1.0f, 1.0f);
+  const f32x2_t u = s * s;
+  f32x2_t q = {-1.6300047636032104f, -1.6300047636032104f};
+  q = __builtin_elementwise_fma(q, u, f32x2_t{7.93373966217041f, 7.93373966217041f});
+  q = __builtin_elementwise_fma(q, u, f32x2_t{-16.877059936523438f, -16.877059936523438f});
+  q = __builtin_elementwise_fma(q, u, f32x2_t{20.921268463134766f, 20.921268463134766f});
+  q = __builtin_elementwise_fma(q, u, f32x2_t{-17.09065055847168f, -17.09065055847168f});
+  q = __builtin_elementwise_fma(q, u, f32x2_t{9.8812894821167f, 9.8812894821167f});
+  q = __builtin_elementwise_fma(q, u, f32x2_t{-4.233964920043945f, -4.233964920043945f});
+  q = __builtin_elementwise_fma(q, u, f32x2_t{1.595382571220398f, 1.595382571220398f});
+  const f32x2_t phi = __builtin_elementwise_fma(s, q, f32x2_t{0.5f, 0.5f});
+  return x * phi;
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

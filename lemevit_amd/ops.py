@@ -106,6 +106,61 @@ def linear_dx(probs: Sequence[Prob], N: int, K: int, act: int = ACT_NONE) -> Non
     check(lib.lmv_linear_dx(_pack(probs), len(probs), N, K, act, dtype_code(probs[0].a), _stream()), "lmv_linear_dx")
 
 
+# -------------------------------------------------------------------------------------------
+# Fused entry points: LayerNorm folded into the consuming Linear, the whole MLP half in one kernel
+# -------------------------------------------------------------------------------------------
+class Folded:
+    """(W', colsum, b') of lmv_ln_fold: LN(x) W^T + b = rstd (x W'^T - mean colsum) + b'."""
+    __slots__ = ("wf", "colsum", "bf")
+
+    def __init__(self, wf, colsum, bf):
+        self.wf, self.colsum, self.bf = wf, colsum, bf
+
+
+def ln_fold(weight: Tensor, bias: Optional[Tensor], gamma: Tensor, beta: Tensor, dtype: torch.dtype) -> Folded:
+    """Fold LayerNorm(gamma, beta) into the Linear (weight [N, K] fp32 master, bias [N] or None) that consumes it."""
+    N, K = weight.shape
+    if weight.dtype != torch.float32:
+        raise TypeError("lemevit_amd: ln_fold takes the fp32 master weight")
+    wf = torch.empty((N, K), device=weight.device, dtype=dtype)
+    colsum = torch.empty(N, device=weight.device, dtype=torch.float32)
+    bf = torch.empty(N, device=weight.device, dtype=torch.float32)
+    check(lib.lmv_ln_fold(_ptr(weight), _f32(bias), _f32(gamma), _f32(beta), N, K, _ptr(wf), _ptr(colsum), _ptr(bf), dtype_code(wf), _stream()), "lmv_ln_fold")
+    return Folded(wf, colsum, bf)
+
+
+def ln_linear_fwd(probs: Sequence[Prob], N: int, K: int, eps: float, act: int = ACT_NONE) -> None:
+    """out = res + row_scale * act(LN(a) @ W^T + b) from folded operands: Prob(a=x, w=F.wf, out, bias=F.bf, aux=F.colsum)."""
+    arr = _pack(probs)
+    for s, p in zip(arr, probs):
+        s.aux = _f32(p.aux)
+    check(lib.lmv_ln_linear_fwd(arr, len(probs), N, K, eps, act, dtype_code(probs[0].a), _stream()), "lmv_ln_linear_fwd")
+
+
+def mlp_fused_supported(C_: int, hidden: int, dtype: torch.dtype) -> bool:
+    return dtype == torch.bfloat16 and bool(lib.lmv_mlp_fused_supported(C_, hidden, _lib.LMV_BF16))
+
+
+def mlp_fused_fwd(xs: Sequence[Tensor], fc1: Folded, w2: Tensor, b2: Tensor, eps: float, scales: Optional[Sequence[Optional[Tensor]]] = None) -> List[Tensor]:
+    """out_i = x_i + scale_i * fc2(GELU(fc1(LN(x_i)))) for up to two token matrices sharing the weights, ONE launch, hidden on chip."""
+    C_ = xs[0].shape[-1]
+    Hd = w2.shape[1]
+    outs = [torch.empty_like(x) for x in xs]
+    arr = (_lib.MlpProblem * len(xs))()
+    for i, (s, x, o) in enumerate(zip(arr, xs, outs)):
+        s.x, s.out, s.rows = _ptr(x), _ptr(o), x.numel() // C_
+        sc = scales[i] if scales is not None else None
+        s.row_scale, s.rows_per_sample = _f32(sc), (x.shape[1] if sc is not None else 0)
+    w = _lib.MlpWeights(_ptr(fc1.wf), _f32(fc1.colsum), _f32(fc1.bf), _ptr(w2), _f32(b2))
+    check(lib.lmv_mlp_fused_fwd(arr, len(xs), C.byref(w), C_, Hd, eps, dtype_code(xs[0]), _stream()), "lmv_mlp_fused_fwd")
+    return outs
+
+
+def attn_out_proj_residual(probs: Sequence[Prob], C_: int) -> None:
+    """out = res + row_scale * (a @ W^T + b): attention output projection with the block's residual / DropPath in the epilogue."""
+    check(lib.lmv_attn_out_proj_residual(_pack(probs), len(probs), C_, dtype_code(probs[0].a), _stream()), "lmv_attn_out_proj_residual")
+
+
 class DwBatch:
     """Deferred split-K reductions (lmv_linear_dw_partial / lmv_reduce_batch): the weight-gradient GEMMs of a block leave their
     partial slabs in distinct regions of one arena; flush() sums them all in one launch."""

@@ -97,6 +97,49 @@ def conv():
         print(f"s{si+1} dwconv {H}x{H} C={C:4d}: fwd {t1:8.1f} us {2*by/t1/1e6:6.2f} TB/s  bwd_data {t2:8.1f} us  bwd_w {t3:8.1f} us {2*by/t3/1e6:6.2f} TB/s")
 
 
+def fused():
+    """MLP half of a block: LayerNorm + fc1(GELU) + fc2(+residual) launches vs lmv_mlp_fused_fwd; and LN + qkv vs lmv_ln_linear_fwd"""
+    print(f"{'case':34s} {'unfused us':>11s} {'fused us':>9s} {'fused TF':>9s} {'speed-up':>9s}")
+    nblk = [4, 4, 18, 4]
+    tu = tfz = 0
+    for si, (N, C) in enumerate(STAGES):
+        Hd = 4 * C
+        x = torch.randn(B, N, C, device=dev).to(bf); c = torch.randn(B, 16, C, device=dev).to(bf)
+        g = torch.ones(C, device=dev); be = torch.zeros(C, device=dev)
+        w1 = torch.randn(Hd, C, device=dev) * 0.05; b1 = torch.zeros(Hd, device=dev)
+        w2 = (torch.randn(C, Hd, device=dev) * 0.05).to(bf); b2 = torch.zeros(C, device=dev)
+        w1b = w1.to(bf)
+        hx = torch.empty(B, N, Hd, device=dev, dtype=bf); hc = torch.empty(B, 16, Hd, device=dev, dtype=bf)
+        ox = torch.empty_like(x); oc = torch.empty_like(c)
+
+        def unfused():
+            (xn, cn), _ = ops.layernorm_fwd_multi([x, c], g, be, 1e-6)
+            ops.linear_fwd([Prob(xn, w1b, hx, bias=b1), Prob(cn, w1b, hc, bias=b1)], Hd, C, ops.ACT_GELU)
+            ops.linear_fwd([Prob(hx, w2, ox, bias=b2, res=x), Prob(hc, w2, oc, bias=b2, res=c)], C, Hd)
+        t_u = timeit(unfused)
+        fl = 4.0 * B * (N + 16) * C * Hd
+        if ops.mlp_fused_supported(C, Hd, bf):
+            F = ops.ln_fold(w1, b1, g, be, bf)
+            t_f = timeit(lambda: ops.mlp_fused_fwd([x, c], F, w2, b2, 1e-6))
+            print(f"s{si+1} mlp  rows={B*(N+16):7d} C={C:4d}      {t_u:11.1f} {t_f:9.1f} {fl/t_f/1e6:9.1f} {t_u/t_f:9.2f}")
+            tu += t_u * nblk[si]; tfz += t_f * nblk[si]
+        else:
+            print(f"s{si+1} mlp  rows={B*(N+16):7d} C={C:4d}      {t_u:11.1f}   (unsupported C)")
+        # LayerNorm + qkv projection
+        wq = torch.randn(3 * C, C, device=dev) * 0.05; bq = torch.zeros(3 * C, device=dev); wqb = wq.to(bf)
+        qx = torch.empty(B, N, 3 * C, device=dev, dtype=bf); qc = torch.empty(B, 16, 3 * C, device=dev, dtype=bf)
+
+        def unfused_qkv():
+            (xn, cn), _ = ops.layernorm_fwd_multi([x, c], g, be, 1e-6)
+            ops.linear_fwd([Prob(xn, wqb, qx, bias=bq), Prob(cn, wqb, qc, bias=bq)], 3 * C, C)
+        Fq = ops.ln_fold(wq, bq, g, be, bf)
+        t_u = timeit(unfused_qkv)
+        t_f = timeit(lambda: ops.ln_linear_fwd([Prob(x, Fq.wf, qx, bias=Fq.bf, aux=Fq.colsum), Prob(c, Fq.wf, qc, bias=Fq.bf, aux=Fq.colsum)], 3 * C, C, 1e-6))
+        flq = 2.0 * B * (N + 16) * C * 3 * C
+        print(f"s{si+1} ln+qkv rows={B*(N+16):7d} C={C:4d}    {t_u:11.1f} {t_f:9.1f} {flq/t_f/1e6:9.1f} {t_u/t_f:9.2f}")
+    print(f"MLP halves per forward pass (x blocks per stage, fused stages only): unfused {tu/1e3:.2f} ms, fused {tfz/1e3:.2f} ms")
+
+
 if __name__ == "__main__":
     what = sys.argv[1:] or ["gemm", "attn", "ln", "conv"]
     for w in what:

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define LMV_ABI_VERSION 1
+#define LMV_ABI_VERSION 2
 
 enum { LMV_F32 = 0, LMV_BF16 = 1 };
 enum {
@@ -293,9 +293,11 @@ int lmv_adamw_flat(float* param, const float* grad, float* exp_avg, float* exp_a
  * of the backward pass when save != 0 (keep it until lmv_block_bwd; with save == 0 it is scratch).  `scratch`
  * (lmv_block_bwd_scratch_bytes) holds the backward temporaries; one buffer may serve all blocks.  side_stream (nullable): the
  * weight-gradient launches are enqueued there behind an event on `stream`, and `stream` waits for them before the call returns.
+ * Inference (save == 0) with flags & LMV_BLOCK_FUSED takes the fused entry points above (LayerNorm folded into qkv / q / kv, the MLP
+ * half in one kernel); the training form keeps the per-layer launches, whose intermediates the backward pass reads.
  * ------------------------------------------------------------------------------------------ */
 enum { LMV_BLOCK_S = 0, LMV_BLOCK_D = 1, LMV_BLOCK_C = 2 };
-enum { LMV_BLOCK_NO_JOIN = 1 };
+enum { LMV_BLOCK_NO_JOIN = 1, LMV_BLOCK_FUSED = 2 };
 typedef struct lmv_block_desc {
   int32_t kind, dtype, B, H, W, M, C, hidden;      /* hidden: MLP width (0 = 4 C) */
   float eps;                                       /* LayerNorm eps of norm1 / norm2 (1e-6, models/lemevit.py:513,525) */
@@ -308,6 +310,11 @@ typedef struct lmv_block_desc {
   float* g_pos_w; float* g_pos_b; float* g_n1_w; float* g_n1_b;
   float* g_attn_w[4]; float* g_attn_b[4];
   float* g_n2_w; float* g_n2_b; float* g_fc1_w; float* g_fc1_b; float* g_fc2_w; float* g_fc2_b;
+  /* LMV_BLOCK_FUSED (lmv_block_fwd with save == 0, bf16): lmv_ln_fold operands (folded weight, colsum, folded bias) of the Linears that
+   * consume norm1 -- S: {qkv, -}, D: {qkv1, qkv2}, C: {q, kv} -- and of mlp.0 (norm2).  The block then runs lmv_ln_linear_fwd instead of
+   * LayerNorm + Linear where that is the faster form and lmv_mlp_fused_fwd for the MLP half where lmv_mlp_fused_supported. */
+  const void* fold_attn_w[2]; const float* fold_attn_s[2]; const float* fold_attn_b[2];
+  const void* fold_fc1_w; const float* fold_fc1_s; const float* fold_fc1_b;
 } lmv_block_desc;
 size_t lmv_block_arena_bytes(const lmv_block_desc* d);
 size_t lmv_block_bwd_scratch_bytes(const lmv_block_desc* d);

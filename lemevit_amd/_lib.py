@@ -14,7 +14,7 @@ LIB_PATH = os.path.join(_HERE, "csrc", "liblemevit_hip.so")
 
 LMV_F32, LMV_BF16 = 0, 1
 ACT_NONE, ACT_GELU, ACT_GELU_GRAD = 0, 1, 2
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 
 class LinearProblem(C.Structure):
@@ -59,7 +59,9 @@ class BlockDesc(C.Structure):
                 [(n, C.c_void_p) for n in ("pos_w", "pos_b", "n1_w", "n1_b")] + [("attn_w", C.c_void_p * 4), ("attn_b", C.c_void_p * 4)] +
                 [(n, C.c_void_p) for n in ("n2_w", "n2_b", "fc1_w", "fc1_b", "fc2_w", "fc2_b")] + [("masks", C.c_void_p * 4)] +
                 [(n, C.c_void_p) for n in ("g_pos_w", "g_pos_b", "g_n1_w", "g_n1_b")] + [("g_attn_w", C.c_void_p * 4), ("g_attn_b", C.c_void_p * 4)] +
-                [(n, C.c_void_p) for n in ("g_n2_w", "g_n2_b", "g_fc1_w", "g_fc1_b", "g_fc2_w", "g_fc2_b")])
+                [(n, C.c_void_p) for n in ("g_n2_w", "g_n2_b", "g_fc1_w", "g_fc1_b", "g_fc2_w", "g_fc2_b")] +
+                [("fold_attn_w", C.c_void_p * 2), ("fold_attn_s", C.c_void_p * 2), ("fold_attn_b", C.c_void_p * 2)] +
+                [(n, C.c_void_p) for n in ("fold_fc1_w", "fold_fc1_s", "fold_fc1_b")])
 
 
 _P, _I, _L, _F, _Z = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_size_t

@@ -195,9 +195,12 @@ def _rps(t: Tensor) -> int:
 # ------------------------------------------------------------------------------------------------
 # MLP half of a block:  t <- t + ds * fc2(GELU(fc1(LN2(t))))   for every stream t in `ts`
 # ------------------------------------------------------------------------------------------------
-def _mlp_fwd(P: Dict[str, Tensor], ts: Sequence[Tensor], ds: Sequence[Optional[Tensor]], save: bool):
+def _mlp_fwd(P: Dict[str, Tensor], ts: Sequence[Tensor], ds: Sequence[Optional[Tensor]], save: bool, fc1_fold=None):
     C = ts[0].shape[-1]
     Hd = P["mlp.0.weight"].shape[0]
+    if fc1_fold is not None and not save and ops.mlp_fused_supported(C, Hd, ts[0].dtype):
+        # inference: LN2 -> fc1 -> GELU -> fc2 -> + residual in ONE kernel, the hidden activations never leave the chip
+        return ops.mlp_fused_fwd(ts, fc1_fold, P["mlp.3.weight"], P["mlp.3.bias"], BLOCK_LN_EPS, ds), None
     xn, st = ops.layernorm_fwd_multi(ts, P["norm2.weight"], P["norm2.bias"], BLOCK_LN_EPS, want_stats=save)
     h = [_empty(t, Hd) for t in ts]
     u = [_empty(t, Hd) if save else None for t in ts]
@@ -387,21 +390,22 @@ def _attn_C_bwd(P, G, saved, dout, ds):
 # whole blocks
 # ------------------------------------------------------------------------------------------------
 def block_forward(kind: str, x: Tensor, c: Tensor, H: int, W: int, P: Dict[str, Tensor],
-                  masks: Sequence[Optional[Tensor]], save: bool):
+                  masks: Sequence[Optional[Tensor]], save: bool, folds=None):
     """LeMeBlock.forward (models/lemevit.py:652-660) on token-major x [B,HW,C], c [B,M,C].
     masks: per-sample DropPath scales in the reference's draw order (D/S: x-attn, x-mlp, c-attn, c-mlp; C: c-attn, c-mlp)."""
     xp = ops.dwconv_residual_fwd(x, P["pos_embed.weight"], P["pos_embed.bias"], H, W)          # :546
+    fc1_fold = None if folds is None else folds[1]      # (lemevit_amd.model.block_folds; the attention halves keep LayerNorm + Linear here)
     if kind == "C":
         c1, sa = _attn_C_fwd(P, xp, c, masks[0], save)
-        (c2,), sm = _mlp_fwd(P, [c1], [masks[1]], save)
+        (c2,), sm = _mlp_fwd(P, [c1], [masks[1]], save, fc1_fold)
         return x, c2, ((x, sa, sm) if save else None)                                            # returns the ORIGINAL x (:610)
     if kind == "Sx":
         (x2,), sa = _attn_S_fwd(P, [xp], [masks[0]], save)
-        (x3,), sm = _mlp_fwd(P, [x2], [masks[1]], save)
+        (x3,), sm = _mlp_fwd(P, [x2], [masks[1]], save, fc1_fold)
         return x3, c, ((x, sa, sm) if save else None)
     fwd = {"S": _attn_S_fwd, "D": _attn_D_fwd, "D2": _attn_D2_fwd}[kind]
     (x2, c1), sa = fwd(P, [xp, c], [masks[0], masks[2]], save)
-    (x3, c2), sm = _mlp_fwd(P, [x2, c1], [masks[1], masks[3]], save)
+    (x3, c2), sm = _mlp_fwd(P, [x2, c1], [masks[1], masks[3]], save, fc1_fold)
     return x3, c2, ((x, sa, sm) if save else None)
 
 

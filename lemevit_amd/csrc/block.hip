@@ -105,8 +105,34 @@ inline void dca_scales(const Dims& D, float* sx, float* sc) {      // models/lem
 }
 
 // ---- MLP half:  out_s = t_s + ds_s * fc2(GELU(fc1(LN2(t_s))))  for the streams s in [s0, 2) -------------------------------------------
+// LMV_BLOCK_FUSED without a backward pass: which Linears take the LayerNorm-folded GEMM (lmv_ln_linear_fwd).  Measured on the Base
+// shapes at batch 128 (tools/bench_kernels.py fused): LayerNorm + qkv vs the folded launch is 0.97x at C = 96 (the K = 96 kernel loses
+// a resident workgroup to the statistics registers) and 1.0 - 1.08x from C = 192 up.
+inline bool fused_on(const lmv_block_desc* d, const Dims& D, int save) {
+  return (d->flags & LMV_BLOCK_FUSED) && !save && D.dtype == LMV_BF16 && d->fold_fc1_w && d->fold_fc1_s && d->fold_fc1_b && d->fold_attn_w[0] && d->fold_attn_s[0] &&
+         d->fold_attn_b[0] && (D.kind == LMV_BLOCK_S || (d->fold_attn_w[1] && d->fold_attn_s[1] && d->fold_attn_b[1]));
+}
+inline bool fold_qkv(const Dims& D) { return D.C >= 192; }
+
 int mlp_fwd(const lmv_block_desc* d, const Dims& D, const Fwd& f, int s0, void* const* outs, const float* const* ds, int save, void* st) {
   const int ns = 2 - s0;
+  if (fused_on(d, D, save)) {
+    if (lmv_mlp_fused_supported(D.C, D.Hd, D.dtype)) {      // LN2 -> fc1 -> GELU -> fc2 -> + residual: one kernel, hidden on chip
+      lmv_mlp_problem q[2] = {};
+      for (int i = 0; i < ns; ++i) { const int s = s0 + i; q[i].x = f.t2[s]; q[i].out = outs[s]; q[i].row_scale = ds[s]; q[i].rows = D.rows[s]; q[i].rows_per_sample = s == 0 ? D.N : D.M; }
+      lmv_mlp_weights w{d->fold_fc1_w, d->fold_fc1_s, d->fold_fc1_b, d->fc2_w, d->fc2_b};
+      return lmv_mlp_fused_fwd(q, ns, &w, D.C, D.Hd, d->eps, D.dtype, st);
+    }
+    lmv_linear_problem p[2];                                 // (C = 512: LN2 folded into fc1, then fc2)
+    for (int i = 0; i < ns; ++i) { const int s = s0 + i; p[i] = prob(f.t2[s], d->fold_fc1_w, f.h[s], D.rows[s]); p[i].bias = d->fold_fc1_b; p[i].aux = d->fold_fc1_s; }
+    LMV_TRY(lmv_ln_linear_fwd(p, ns, D.Hd, D.C, d->eps, LMV_ACT_GELU, D.dtype, st));
+    for (int i = 0; i < ns; ++i) {
+      const int s = s0 + i;
+      p[i] = prob(f.h[s], d->fc2_w, outs[s], D.rows[s]); p[i].bias = d->fc2_b; p[i].res = f.t2[s]; p[i].row_scale = ds[s];
+      p[i].rows_per_sample = s == 0 ? D.N : D.M;
+    }
+    return lmv_linear_fwd(p, ns, D.C, D.Hd, LMV_ACT_NONE, D.dtype, st);
+  }
   lmv_ln_segment seg[2] = {};
   for (int i = 0; i < ns; ++i) { const int s = s0 + i; seg[i].x = f.t2[s]; seg[i].y = f.n2[s]; seg[i].stats = save ? f.st2[s] : nullptr; seg[i].rows = D.rows[s]; }
   LMV_TRY(lmv_layernorm_fwd(seg, ns, d->n2_w, d->n2_b, D.C, d->eps, D.dtype, st));
@@ -293,16 +319,30 @@ extern "C" int lmv_block_fwd(const lmv_block_desc* d, const void* x, const void*
   if (a.off > arena_bytes) LMV_FAIL(LMV_ERR_WORKSPACE, "block_fwd: arena %zu < %zu bytes", arena_bytes, a.off);
   const int C = D.C, N = D.N, M = D.M;
   LMV_TRY(lmv_dwconv3x3_residual_fwd(x, d->pos_w, d->pos_b, f.xp, D.B, D.H, D.W, C, D.dtype, stream));          // :546
-  lmv_ln_segment seg[2] = {};
-  seg[0].x = f.xp; seg[0].y = f.n1[0]; seg[0].stats = save ? f.st1[0] : nullptr; seg[0].rows = D.rows[0];
-  seg[1].x = c; seg[1].y = f.n1[1]; seg[1].stats = save ? f.st1[1] : nullptr; seg[1].rows = D.rows[1];
-  LMV_TRY(lmv_layernorm_fwd(seg, 2, d->n1_w, d->n1_b, C, d->eps, D.dtype, stream));
+  const bool fq = fused_on(d, D, save) && fold_qkv(D);      // norm1 folded into the projections: no LayerNorm launch, no normalised copy
+  const void* src[2] = {f.xp, c};                           // token rows the projections read (fq: raw; else LN1 output)
+  if (!fq) {
+    lmv_ln_segment seg[2] = {};
+    seg[0].x = f.xp; seg[0].y = f.n1[0]; seg[0].stats = save ? f.st1[0] : nullptr; seg[0].rows = D.rows[0];
+    seg[1].x = c; seg[1].y = f.n1[1]; seg[1].stats = save ? f.st1[1] : nullptr; seg[1].rows = D.rows[1];
+    LMV_TRY(lmv_layernorm_fwd(seg, 2, d->n1_w, d->n1_b, C, d->eps, D.dtype, stream));
+    src[0] = f.n1[0]; src[1] = f.n1[1];
+  }
+  // one projection launch: stream s through attention weight slot `slot[s]` (folded or plain operands)
+  auto project = [&](lmv_linear_problem* p, int np, const int* streams, const int* slots, int width) -> int {
+    for (int i = 0; i < np; ++i) {
+      const int s = streams[i], k = slots[i];
+      p[i] = prob(src[s], fq ? d->fold_attn_w[k] : d->attn_w[k], f.pj[s], D.rows[s]);
+      p[i].bias = fq ? d->fold_attn_b[k] : d->attn_b[k];
+      if (fq) p[i].aux = d->fold_attn_s[k];
+    }
+    return fq ? lmv_ln_linear_fwd(p, np, width, C, d->eps, LMV_ACT_NONE, D.dtype, stream) : lmv_linear_fwd(p, np, width, C, LMV_ACT_NONE, D.dtype, stream);
+  };
   lmv_linear_problem p[2];
   lmv_attn_desc ad[2];
   void* outs[2] = {x_out, c_out};
   if (D.kind == LMV_BLOCK_S) {                    // the SAME weights for x and c (:632,634)
-    for (int s = 0; s < 2; ++s) { p[s] = prob(f.n1[s], d->attn_w[0], f.pj[s], D.rows[s]); p[s].bias = d->attn_b[0]; }
-    LMV_TRY(lmv_linear_fwd(p, 2, 3 * C, C, LMV_ACT_NONE, D.dtype, stream));
+    { const int st_[2] = {0, 1}, sl_[2] = {0, 0}; LMV_TRY(project(p, 2, st_, sl_, 3 * C)); }
     for (int s = 0; s < 2; ++s) { const int L = s == 0 ? N : M; attn_desc(&ad[s], D, f.pj[s], 3 * C, 0, f.pj[s], 3 * C, C, f.pj[s], 3 * C, 2 * C, f.ao[s], save ? f.lse[s] : nullptr, L, L, SDPA_SCALE); }
     LMV_TRY(lmv_attn_fwd_pair(ad, f.ws, f.ws_bytes, D.dtype, stream));
     for (int s = 0; s < 2; ++s) {
@@ -313,8 +353,7 @@ extern "C" int lmv_block_fwd(const lmv_block_desc* d, const void* x, const void*
   } else if (D.kind == LMV_BLOCK_D) {             // :288-302
     float sx, sc;
     dca_scales(D, &sx, &sc);
-    for (int s = 0; s < 2; ++s) { p[s] = prob(f.n1[s], d->attn_w[s], f.pj[s], D.rows[s]); p[s].bias = d->attn_b[s]; }
-    LMV_TRY(lmv_linear_fwd(p, 2, 3 * C, C, LMV_ACT_NONE, D.dtype, stream));
+    { const int st_[2] = {0, 1}, sl_[2] = {0, 1}; LMV_TRY(project(p, 2, st_, sl_, 3 * C)); }
     attn_desc(&ad[0], D, f.pj[0], 3 * C, 0, f.pj[1], 3 * C, C, f.pj[1], 3 * C, 2 * C, f.ao[0], save ? f.lse[0] : nullptr, N, M, sx);      // image -> meta (:297)
     attn_desc(&ad[1], D, f.pj[1], 3 * C, 0, f.pj[0], 3 * C, C, f.pj[0], 3 * C, 2 * C, f.ao[1], save ? f.lse[1] : nullptr, M, N, sc);      // meta -> image (:300)
     LMV_TRY(lmv_attn_fwd(&ad[0], f.ws, f.ws_bytes, D.dtype, stream));
@@ -325,10 +364,8 @@ extern "C" int lmv_block_fwd(const lmv_block_desc* d, const void* x, const void*
     }
     LMV_TRY(lmv_linear_fwd(p, 2, C, C, LMV_ACT_NONE, D.dtype, stream));
   } else {                                        // :477-486,600  q = attn_w[0] (meta tokens), kv = attn_w[1] (image tokens), proj = attn_w[2]
-    p[0] = prob(f.n1[0], d->attn_w[1], f.pj[0], D.rows[0]); p[0].bias = d->attn_b[1];
-    LMV_TRY(lmv_linear_fwd(p, 1, 2 * C, C, LMV_ACT_NONE, D.dtype, stream));
-    p[0] = prob(f.n1[1], d->attn_w[0], f.pj[1], D.rows[1]); p[0].bias = d->attn_b[0];
-    LMV_TRY(lmv_linear_fwd(p, 1, C, C, LMV_ACT_NONE, D.dtype, stream));
+    { const int st_[1] = {0}, sl_[1] = {1}; LMV_TRY(project(p, 1, st_, sl_, 2 * C)); }
+    { const int st_[1] = {1}, sl_[1] = {0}; LMV_TRY(project(p, 1, st_, sl_, C)); }
     attn_desc(&ad[0], D, f.pj[1], C, 0, f.pj[0], 2 * C, 0, f.pj[0], 2 * C, C, f.ao[1], save ? f.lse[1] : nullptr, M, N, SDPA_SCALE);
     LMV_TRY(lmv_attn_fwd(&ad[0], f.ws, f.ws_bytes, D.dtype, stream));
     p[0] = prob(f.ao[1], d->attn_w[2], f.t2[1], D.rows[1]); p[0].bias = d->attn_b[2]; p[0].res = c; p[0].row_scale = d->masks[0]; p[0].rows_per_sample = M;

@@ -87,6 +87,34 @@ def compute_copy(p: Tensor, want: torch.dtype) -> Tensor:
 _fold_cache: dict = {}
 _conv1_cache: dict = {}
 
+# Inference: LayerNorm folded into the Linear that consumes it (ops.ln_fold -> lmv_ln_linear_fwd / lmv_mlp_fused_fwd).  The folded
+# operands are cached per version of the four parameters involved (and per training pass, see compute_copy).
+_FUSED = os.environ.get("LMV_FUSED", "1") != "0"          # 0: LayerNorm + Linear launches as in the training schedule (A/B runs)
+_ln_fold_cache: dict = {}
+_FOLD_PAIRS = {"S": (("attn.qkv", "norm1"),), "D": (("attn.qkv1", "norm1"), ("attn.qkv2", "norm1")), "C": (("attn.q", "norm1"), ("attn.kv", "norm1"))}
+
+
+def _ln_fold_cached(w: Tensor, b: Optional[Tensor], g: Tensor, be: Tensor, dtype: torch.dtype) -> "ops.Folded":
+    key = (id(w), dtype)
+    stamp = tuple(t._version for t in (w, g, be)) + (None if b is None else b._version, _train_pass, id(g), id(be))
+    ent = _ln_fold_cache.get(key)
+    if ent is not None and ent[0]() is w and ent[1] == stamp:
+        return ent[2]
+    with torch.no_grad():
+        f32 = lambda t: None if t is None else t.detach().float().contiguous()
+        F = ops.ln_fold(f32(w), f32(b), f32(g), f32(be), dtype)
+    _ln_fold_cache[key] = (weakref.ref(w), stamp, F)
+    return F
+
+
+def block_folds(kind: str, params: "Dict[str, Tensor]", dtype: torch.dtype):
+    """[(folded attention projections in slot order), folded mlp.0] of a S / D / C block, or None where the fused path does not apply."""
+    if not _FUSED or dtype != torch.bfloat16:
+        return None
+    g1, b1, g2, b2 = params["norm1.weight"], params["norm1.bias"], params["norm2.weight"], params["norm2.bias"]
+    attn = [_ln_fold_cached(params[n + ".weight"], params.get(n + ".bias"), g1, b1, dtype) for n, _ in _FOLD_PAIRS.get(kind, ())]      # "D2" / "Sx" (Python schedule): the MLP half only
+    return attn, _ln_fold_cached(params["mlp.0.weight"], params.get("mlp.0.bias"), g2, b2, dtype)
+
 
 def _conv1_matrix(weight: Tensor, dtype: torch.dtype) -> Tensor:
     """[Cout, 3, 3, 3] stem weight -> the [Cout, 32] GEMM operand of ops.im2col3x3s2_c3 (columns 27..31 zero), cached per version."""
@@ -461,7 +489,7 @@ def _fill_ptrs(desc, kind: str, names, tensors: Dict[str, Tensor], prefix: str) 
             getattr(desc, prefix + ("attn_w" if kindof == "weight" else "attn_b"))[slots[base]] = t.data_ptr()
 
 
-def _block_desc(kind: str, x: Tensor, c: Tensor, H: int, W: int, names, P: Dict[str, Tensor], masks):
+def _block_desc(kind: str, x: Tensor, c: Tensor, H: int, W: int, names, P: Dict[str, Tensor], masks, folds=None):
     from ._lib import BlockDesc
     d = BlockDesc()
     d.kind, d.dtype = _KIND_CODE[kind], ops.dtype_code(x)
@@ -478,6 +506,13 @@ def _block_desc(kind: str, x: Tensor, c: Tensor, H: int, W: int, names, P: Dict[
             if m.dtype != torch.float32 or not m.is_contiguous():
                 raise TypeError("lemevit_amd: DropPath scale vectors must be contiguous float32")
             d.masks[i] = m.data_ptr()
+    if folds is not None:                   # LMV_BLOCK_FUSED: inference with LayerNorm folded into the projections / the one-kernel MLP half
+        attn, fc1 = folds
+        for k, F in enumerate(attn):
+            d.fold_attn_w[k], d.fold_attn_s[k], d.fold_attn_b[k] = F.wf.data_ptr(), F.colsum.data_ptr(), F.bf.data_ptr()
+        d.fold_fc1_w, d.fold_fc1_s, d.fold_fc1_b = fc1.wf.data_ptr(), fc1.colsum.data_ptr(), fc1.bf.data_ptr()
+        d.flags |= 2
+        d._folds = folds                    # keep the operands alive as long as the descriptor
     return d
 
 
@@ -500,10 +535,10 @@ def _persistent(tag: str, nbytes: int, device) -> Tensor:
     return t
 
 
-def native_block_forward(kind: str, x: Tensor, c: Tensor, H: int, W: int, names, P: Dict[str, Tensor], masks, save: bool):
+def native_block_forward(kind: str, x: Tensor, c: Tensor, H: int, W: int, names, P: Dict[str, Tensor], masks, save: bool, folds=None):
     """lmv_block_fwd: returns (x_out, c_out, state) with state = (descriptor, arena) for native_block_backward (save=True)."""
     from ._lib import lib, check
-    d = _block_desc(kind, x, c, H, W, names, P, masks)
+    d = _block_desc(kind, x, c, H, W, names, P, masks, None if save else folds)
     nbytes = _sized(lib.lmv_block_arena_bytes, d, kind, x, c, H, W)
     arena = torch.empty(nbytes, device=x.device, dtype=torch.uint8) if save else _persistent("fwd", nbytes, x.device)
     xo = torch.empty_like(x) if kind != "C" else None
@@ -624,10 +659,11 @@ def run_block(kind: str, x: Tensor, c: Tensor, H: int, W: int, params: "OrderedD
         return (x, out) if kind == "C" else ((out, c) if kind == "Sx" else out)
     cd = x.dtype
     P = {n: compute_copy(p, cd if _is_matrix(n) else torch.float32) for n, p in zip(names, plist)}
+    folds = block_folds(kind, params, cd)
     if _native_ok(kind, x, c):
-        xo, co, _ = native_block_forward(kind, x, c, H, W, names, P, masks, save=False)
+        xo, co, _ = native_block_forward(kind, x, c, H, W, names, P, masks, save=False, folds=folds)
         return xo, co
-    xo, co, _ = block_forward(kind, x, c, H, W, P, masks, save=False)
+    xo, co, _ = block_forward(kind, x, c, H, W, P, masks, save=False, folds=folds)
     return xo, co
 
 

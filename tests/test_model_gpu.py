@@ -202,6 +202,41 @@ def test_model_forward_bf16(golden, name, mode):
     print(f"{name} [{mode}]: bf16 logits rel err {e:.2e}")
 
 
+@pytest.mark.parametrize("name", ["model_tiny_224", "model_base_224", "model_small_v2_224", "model_tiny_v2_224"])
+def test_fused_inference_path(golden, name, monkeypatch):
+    """The inference schedule with LayerNorm folded into the projections and the one-kernel MLP half (lmv_ln_linear_fwd /
+    lmv_mlp_fused_fwd through LMV_BLOCK_FUSED, and the Python schedule of the "D2" blocks) against the golden logits of the
+    reference AND against the unfused schedule of the same model: both must sit inside the bf16 end-to-end budget, and the
+    two schedules within 3e-2 of each other (they round at different places: gamma . W instead of W and LN(x))."""
+    import lemevit_amd.model as M
+    meta, g = golden(name)
+    m = _model(meta["variant"], meta["num_classes"], meta["seed"]).eval()
+    img = det_tensor((meta["B"], 3, meta["res"], meta["res"]), name + ".img", 4).to(DEV)
+    outs = {}
+    for fused in (True, False):
+        monkeypatch.setattr(M, "_FUSED", fused)
+        with torch.no_grad(), torch.autocast("cuda", torch.bfloat16):
+            outs[fused] = m(img).float()
+    e1 = close(outs[True], g["logits"], 5e-2, f"{name} fused")
+    e0 = close(outs[False], g["logits"], 5e-2, f"{name} unfused")
+    ref = outs[False].abs().max().item()
+    d = (outs[True] - outs[False]).abs().max().item() / ref
+    print(f"{name}: fused {e1:.2e} / unfused {e0:.2e} off the golden logits, fused vs unfused {d:.2e}")
+    assert d <= 3e-2
+    # the folded operands follow the parameters: perturb a LayerNorm affine and a fc1 weight in place (version bump) -> new logits
+    blk = m.stages[3][0] if len(m.stages) > 3 else m.stages[-1][0]
+    monkeypatch.setattr(M, "_FUSED", True)
+    with torch.no_grad():
+        blk.norm2.weight.mul_(1.5); blk.mlp[0].weight.add_(0.01)
+        with torch.autocast("cuda", torch.bfloat16):
+            a = m(img).float()
+        monkeypatch.setattr(M, "_FUSED", False)
+        with torch.autocast("cuda", torch.bfloat16):
+            b = m(img).float()
+    assert (a - outs[True]).abs().max().item() > 1e-3 * ref, "stale folded weights"
+    assert (a - b).abs().max().item() <= 3e-2 * b.abs().max().item()
+
+
 @pytest.mark.parametrize("name", ["train_tiny_96", "train_tiny_96_dp"])
 def test_train_step_fp32(golden, name):
     """Train-mode step (BatchNorm batch statistics, DropPath with the reference's recorded masks): loss, logits, every
@@ -597,9 +632,19 @@ def test_native_block_schedule_equals_python_schedule(monkeypatch, kind, C, h, H
         ((xo.float() * gx.float()).sum() + (co.float() * gc.float()).sum()).backward()
         torch.cuda.synchronize()
         res[native] = [xo.detach().clone(), co.detach().clone(), x.grad.clone(), c.grad.clone()] + [p.grad.clone() for p in params.values()]
+        monkeypatch.setattr(M, "_FUSED", False)
         with torch.no_grad():                 # the no-grad (inference) entry of the same schedule
             xe, ce = M.run_block(kind, x.detach(), c.detach(), Hs, Hs, params, masks)
         assert torch.equal(xe, xo.detach()) and torch.equal(ce, co.detach())
+        monkeypatch.setattr(M, "_FUSED", True)
+        with torch.no_grad():                 # ... and its fused form (bf16: LayerNorm folded into the projections, one-kernel MLP half; DropPath scales included)
+            xf, cf = M.run_block(kind, x.detach(), c.detach(), Hs, Hs, params, masks)
+        if dtype == torch.float32:
+            assert torch.equal(xf, xe) and torch.equal(cf, ce)          # the fused path is bf16 only
+        else:
+            for a, b, what in ((xf, xe, "x"), (cf, ce, "c")):
+                err = float((a.float() - b.float()).abs().max()) / float(b.float().abs().max())
+                assert err <= 2e-2, f"{kind} fused inference {what}: {err:.2e}"
     labels = ["x_out", "c_out", "dx", "dc"] + ["grad " + n for n in names]
     for a, b, what in zip(res[True], res[False], labels):
         assert torch.equal(a, b), f"{kind} {dtype} {what}: native and Python schedules differ by {float((a.float() - b.float()).abs().max()):.3e}"

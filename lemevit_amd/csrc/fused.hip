@@ -91,6 +91,8 @@ template <int C, int TM> struct MlpCfg {
   static constexpr int younger(int t) { int n = 0; for (int k = 2; k <= NSLOT - 1; ++k) n += nld(t + k); return n; }
 };
 
+// (Measured and dropped: issuing the next panel's LDS-DMA requests INSIDE the step, behind the fragment reads, instead of up front --
+//  C = 384: 101 -> 119 us, C = 192: 128 -> 141 us, C = 96: 179 -> 175 us: a request issued while ds_reads are in flight costs more.)
 // One panel step: the wave's 32 x 64 output tile += A[32 rows x BK] . B[64 cols x BK]^T, both operands in LDS panel images.
 // a0 / a1 (b0 / b1): LDS byte address of this lane's fragment of row (column) tile 0 for the k-half hh = 0 / 1; the other tiles are
 // 16 rows = 16 * ROWB bytes further (the swizzles repeat every 16 rows), which rides in the instruction's immediate offset -- so a
@@ -139,12 +141,15 @@ __device__ __forceinline__ void lds_st_b64(unsigned addr, unsigned lo, unsigned 
 // an address the compiler must re-derive inside the loop (one v_add per step) instead of keeping one register per k-tile alive
 __device__ __forceinline__ unsigned opaque(unsigned v) { asm volatile("" : "+v"(v)); return v; }
 
+#ifndef LMV_DUAL_MAXC
+#define LMV_DUAL_MAXC 384      // widest C whose steps keep BOTH k-halves' fragments in registers (second half's reads under the first half's MFMAs)
+#endif
 template <int C, int TM>
 __global__ __launch_bounds__(TM * 4) void mlp_fused_kernel(const MlpArgs g) {
   using K = MlpCfg<C, TM>;
   using CF = Cfg<TM / 32, 2, 2>;                             // waves of 32 x 64 over a TM x 128 step tile
   constexpr int BK1 = K::BK1, KT1 = K::KT1, NP = K::NP, STEPS = K::STEPS, NW = K::NW, NTHR = TM * 4;
-  constexpr bool DUAL = C <= 256;                            // register budget: 256 per lane at 2 waves per SIMD
+  constexpr bool DUAL = C <= LMV_DUAL_MAXC;                  // register budget: 256 per lane at 2 waves per SIMD (C = 384: 234)
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int NSLOT = K::NSLOT, D = NSLOT - 1;             // ring depth, prefetch distance in steps
   unsigned char* const sX = smem;
@@ -324,14 +329,27 @@ __global__ __launch_bounds__(TM * 4) void mlp_fused_kernel(const MlpArgs g) {
     });
   }
 
-  // out = x + row_scale * (acc2 + b2): per-wave LDS transpose, 16-byte row-segment stores (every LDS image is dead now)
+  // out = x + row_scale * (acc2 + b2): per-wave LDS transpose (scratch: the H / ring images, dead now), 16-byte row-segment stores.
+  // The residual x is still in LDS -- the raw rows the kernel loaded once -- so it is NOT read from HBM a second time: the kernel's
+  // HBM traffic is C in + C out per token.
+  static_assert(K::LDS - K::X_BYTES >= NW * 8192, "mlp_fused: epilogue scratch does not fit behind the X images");
   Problem P{};
   P.bias = g.b2; P.res = Q.x; P.row_scale = Q.row_scale; P.out = Q.out; P.M = M; P.rps = Q.rps > 0 ? Q.rps : 1;
+  Problem Pn = P;
+  Pn.res = nullptr;                                          // prefetch: bias and DropPath scales only
   Epi<bf16_t, CF, 8192> epi;
+  static_assert(sizeof(epi.pf) == 4 * sizeof(uint4), "one pass of 32 rows x 8 chunks per wave");
 #pragma unroll
   for (int p = 0; p < NP; ++p) {
-    epi.prefetch(P, LMV_ACT_NONE, C, C, m0, p * 128, wm, wn, lane);
-    epi.store(smem, acc2[p], P, LMV_ACT_NONE, C, C, m0, p * 128, wm, wn, lane, wave);
+    epi.prefetch(Pn, LMV_ACT_NONE, C, C, m0, p * 128, wm, wn, lane);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      constexpr int ROWB = BK1 * 2;
+      const int cidx = lane + i * 64, r = wm * 32 + (cidx >> 3), n = min(p * 128 + wn * 64 + (cidx & 7) * 8, C - 8);
+      const int kt = n / BK1, kc = (n % BK1) >> 3;
+      epi.pf[0][i] = *reinterpret_cast<const uint4*>(sX + kt * K::XT + r * ROWB + ((kc ^ swz_n<ROWB>(r)) << 4));
+    }
+    epi.store(sH, acc2[p], P, LMV_ACT_NONE, C, C, m0, p * 128, wm, wn, lane, wave);
   }
 }
 

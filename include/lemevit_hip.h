@@ -161,6 +161,12 @@ int lmv_layernorm_gelu_bwd(const lmv_ln_segment* seg, int nseg, const float* gam
 size_t lmv_layernorm_bwd_workspace_bytes(int64_t total_rows, int C, int dtype);
 int lmv_layernorm_bwd(const lmv_ln_segment* seg, int nseg, const float* gamma, float* dgamma, float* dbeta, int C,
                       void* workspace, size_t workspace_bytes, int dtype, void* stream);
+/* The same in two calls: _partial writes dx and leaves `*partial_rows` per-workgroup rows of (dgamma | dbeta) partial sums in
+ * `workspace`; _reduce accumulates them into dgamma / dbeta -- on any stream that is ordered behind _partial (the block scheduler
+ * keeps it off the critical path).  Results are bit-identical to lmv_layernorm_bwd. */
+int lmv_layernorm_bwd_partial(const lmv_ln_segment* seg, int nseg, const float* gamma, int C, void* workspace, size_t workspace_bytes,
+                              int* partial_rows, int dtype, void* stream);
+int lmv_layernorm_bwd_reduce(const void* workspace, int partial_rows, int C, float* dgamma, float* dbeta, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Training-mode BatchNorm2d (+ exact GELU) over a channels-last feature map viewed as [rows = B*H*W][C]: the BatchNorm2d

@@ -187,8 +187,8 @@ int dw(Side& sd, const lmv_linear_problem* p, int np, int N, int K, int dtype) {
 }
 
 struct Bwd {                      // backward temporaries ([0] image tokens, [1] meta tokens)
-  void *g[2], *du[2], *dn2[2], *dt2[2], *g2[2], *dao[2], *dpj[2], *dn1[2], *dxp, *ws_main, *ws_side;
-  size_t ws_main_bytes, ws_side_bytes;
+  void *g[2], *du[2], *dn2[2], *dt2[2], *g2[2], *dao[2], *dpj[2], *dn1[2], *dxp, *ws_main, *ws_side, *ws_ln[2];
+  size_t ws_main_bytes, ws_side_bytes, ws_ln_bytes;
 };
 
 size_t max_dw_ws(const Dims& D) {
@@ -238,6 +238,18 @@ void layout_bwd(const Dims& D, Bump& a, Bwd* b) {
   if (w < 256) w = 256;
   b->ws_main_bytes = w; b->ws_main = a.take(w);
   b->ws_side_bytes = max_dw_ws(D); b->ws_side = a.take(b->ws_side_bytes);
+  // LayerNorm dgamma / dbeta partial rows of norm2 and norm1: their reduces run on the side stream, so each keeps its own buffer
+  b->ws_ln_bytes = lmv_layernorm_bwd_workspace_bytes(D.rows[0] + D.rows[1], D.C, D.dtype);
+  for (int i = 0; i < 2; ++i) b->ws_ln[i] = a.take(b->ws_ln_bytes);
+}
+
+// LayerNorm backward with the dgamma / dbeta reduce off the critical path: dx on the main stream, the ~5 us reduce launch behind a
+// fork on the weight-gradient side stream (in line when there is none)
+int ln_bwd(Side& sd, const lmv_ln_segment* seg, int nseg, const float* gamma, float* dgamma, float* dbeta, const Dims& D, void* ws, size_t ws_bytes) {
+  if (!sd.side) return lmv_layernorm_bwd(seg, nseg, gamma, dgamma, dbeta, D.C, ws, ws_bytes, D.dtype, sd.main);
+  int rows = 0;
+  LMV_TRY(lmv_layernorm_bwd_partial(seg, nseg, gamma, D.C, ws, ws_bytes, &rows, D.dtype, sd.main));
+  return lmv_layernorm_bwd_reduce(ws, rows, D.C, dgamma, dbeta, sd.begin());
 }
 
 // MLP half backward (blocks.py::_mlp_bwd): douts = gradients of the block outputs, returns dt2 (gradient of the MLP half's input) and, where the
@@ -269,7 +281,7 @@ int mlp_bwd(const lmv_block_desc* d, const Dims& D, const Fwd& f, const Bwd& b, 
     g2_out[s] = b.dt2[s];
     if (nds && nds[s]) { seg[i].dx_scale = nds[s]; seg[i].dx_scaled = b.g2[s]; seg[i].rows_per_sample = s == 0 ? D.N : D.M; g2_out[s] = b.g2[s]; }
   }
-  return lmv_layernorm_bwd(seg, ns, d->n2_w, d->g_n2_w, d->g_n2_b, D.C, b.ws_main, b.ws_main_bytes, D.dtype, st);
+  return ln_bwd(sd, seg, ns, d->n2_w, d->g_n2_w, d->g_n2_b, D, b.ws_ln[0], b.ws_ln_bytes);
 }
 
 int check_ptrs(const lmv_block_desc* d, bool grads) {
@@ -424,7 +436,7 @@ extern "C" int lmv_block_bwd(const lmv_block_desc* d, const void* x, const void*
       lmv_ln_segment seg[2] = {};
       seg[0].x = c; seg[0].dy = b.dn1[1]; seg[0].stats = f.st1[1]; seg[0].dres = dc1; seg[0].dx = dc; seg[0].rows = D.rows[1];
       seg[1].x = f.xp; seg[1].dy = b.dn1[0]; seg[1].stats = f.st1[0]; seg[1].dres = nullptr; seg[1].dx = b.dxp; seg[1].rows = D.rows[0];
-      LMV_TRY(lmv_layernorm_bwd(seg, 2, d->n1_w, d->g_n1_w, d->g_n1_b, C, b.ws_main, b.ws_main_bytes, D.dtype, st));
+      LMV_TRY(ln_bwd(sd, seg, 2, d->n1_w, d->g_n1_w, d->g_n1_b, D, b.ws_ln[1], b.ws_ln_bytes));
     } else {
       const void* douts[2] = {dx_out, dc_out};
       const float* ds[2] = {d->masks[1], d->masks[3]};
@@ -459,7 +471,7 @@ extern "C" int lmv_block_bwd(const lmv_block_desc* d, const void* x, const void*
       lmv_ln_segment seg[2] = {};
       seg[0].x = f.xp; seg[0].dy = b.dn1[0]; seg[0].stats = f.st1[0]; seg[0].dres = b.dt2[0]; seg[0].dx = b.dxp; seg[0].rows = D.rows[0];
       seg[1].x = c; seg[1].dy = b.dn1[1]; seg[1].stats = f.st1[1]; seg[1].dres = b.dt2[1]; seg[1].dx = dc; seg[1].rows = D.rows[1];
-      LMV_TRY(lmv_layernorm_bwd(seg, 2, d->n1_w, d->g_n1_w, d->g_n1_b, C, b.ws_main, b.ws_main_bytes, D.dtype, st));
+      LMV_TRY(ln_bwd(sd, seg, 2, d->n1_w, d->g_n1_w, d->g_n1_b, D, b.ws_ln[1], b.ws_ln_bytes));
     }
     {
       hipStream_t ss = sd.begin();

@@ -275,7 +275,7 @@ int launch_fwd(const lmv_ln_segment* seg, int nseg, const float* gamma, const fl
 
 template <typename T, bool ACT>
 int launch_bwd(const lmv_ln_segment* seg, int nseg, const float* gamma, const float* beta, float* dgamma, float* dbeta, int C, void* ws, size_t ws_bytes,
-               hipStream_t st) {
+               hipStream_t st, int* partial_rows = nullptr) {
   Segs<T> sg;
   if (int rc = fill(&sg, seg, nseg, true, "layernorm_bwd")) return rc;
   int l2, nit;
@@ -294,6 +294,7 @@ int launch_bwd(const lmv_ln_segment* seg, int nseg, const float* gamma, const fl
   }
 #undef LN_BWD_CASE
   LMV_CHECK_LAUNCH("layernorm_bwd");
+  if (partial_rows) { *partial_rows = blocks; return LMV_OK; }      // the caller sums the per-workgroup rows (lmv_layernorm_bwd_reduce), e.g. on another stream
   return lmv_launch_partial_reduce(partial, blocks, 2 * C, dgamma, C, dbeta, 0, st);
 }
 
@@ -331,6 +332,22 @@ extern "C" int lmv_layernorm_bwd(const lmv_ln_segment* seg, int nseg, const floa
   if (dtype == LMV_BF16) return launch_bwd<bf16_t, false>(seg, nseg, gamma, nullptr, dgamma, dbeta, C, workspace, workspace_bytes, (hipStream_t)stream);
   if (dtype == LMV_F32) return launch_bwd<float, false>(seg, nseg, gamma, nullptr, dgamma, dbeta, C, workspace, workspace_bytes, (hipStream_t)stream);
   LMV_FAIL(LMV_ERR_DTYPE, "layernorm_bwd: unsupported dtype %d", dtype);
+}
+
+// The two halves of lmv_layernorm_bwd as separate calls: nothing inside a block consumes dgamma / dbeta, so a scheduler can leave the
+// ~5 us reduce launch off the critical path (lmv_block_bwd enqueues it on the weight-gradient side stream).  Bit-identical results.
+extern "C" int lmv_layernorm_bwd_partial(const lmv_ln_segment* seg, int nseg, const float* gamma, int C, void* workspace, size_t workspace_bytes,
+                                         int* partial_rows, int dtype, void* stream) {
+  if (!seg || !partial_rows) LMV_FAIL(LMV_ERR_SHAPE, "layernorm_bwd_partial: null segments / partial_rows");
+  if (C <= 0 || (C % 8)) LMV_FAIL(LMV_ERR_SHAPE, "layernorm_bwd_partial: C=%d must be a positive multiple of 8", C);
+  if (!gamma) LMV_FAIL(LMV_ERR_SHAPE, "layernorm_bwd_partial: null affine");
+  if (dtype == LMV_BF16) return launch_bwd<bf16_t, false>(seg, nseg, gamma, nullptr, nullptr, nullptr, C, workspace, workspace_bytes, (hipStream_t)stream, partial_rows);
+  if (dtype == LMV_F32) return launch_bwd<float, false>(seg, nseg, gamma, nullptr, nullptr, nullptr, C, workspace, workspace_bytes, (hipStream_t)stream, partial_rows);
+  LMV_FAIL(LMV_ERR_DTYPE, "layernorm_bwd_partial: unsupported dtype %d", dtype);
+}
+extern "C" int lmv_layernorm_bwd_reduce(const void* workspace, int partial_rows, int C, float* dgamma, float* dbeta, void* stream) {
+  if (!workspace || partial_rows <= 0 || C <= 0 || (C % 8) || !dgamma || !dbeta) LMV_FAIL(LMV_ERR_SHAPE, "layernorm_bwd_reduce: bad arguments");
+  return lmv_launch_partial_reduce(reinterpret_cast<const float*>(workspace), partial_rows, 2 * C, dgamma, C, dbeta, 0, (hipStream_t)stream);
 }
 
 extern "C" int lmv_layernorm_gelu_bwd(const lmv_ln_segment* seg, int nseg, const float* gamma, const float* beta, float* dgamma, float* dbeta, int C,

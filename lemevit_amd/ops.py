@@ -258,7 +258,8 @@ def layernorm_fwd_multi(xs: Sequence[Tensor], gamma: Tensor, beta: Tensor, eps: 
 
 
 def layernorm_bwd_multi(dys: Sequence[Tensor], xs: Sequence[Tensor], stats: Sequence[Tensor], gamma: Tensor, dgamma: Tensor, dbeta: Tensor,
-                        dres: Sequence[Optional[Tensor]], next_scales: Optional[Sequence[Optional[Tensor]]] = None, gelu_beta: Optional[Tensor] = None):
+                        dres: Sequence[Optional[Tensor]], next_scales: Optional[Sequence[Optional[Tensor]]] = None, gelu_beta: Optional[Tensor] = None,
+                        split_reduce: bool = False):
     """dx_i = dres_i + LN'(dy_i) for up to two tensors in ONE launch; dgamma / dbeta (fp32) are accumulated in place.
     next_scales: per-sample DropPath vectors of the NEXT backward stage; when given, returns (dxs, scaled) where scaled[i] is
     dx_i * next_scales[i][sample] written by the same launch (or dx_i itself where the scale is None)."""
@@ -279,6 +280,11 @@ def layernorm_bwd_multi(dys: Sequence[Tensor], xs: Sequence[Tensor], stats: Sequ
         dxs.append(dx)
     code = dtype_code(xs[0])
     ws = _workspace(lib.lmv_layernorm_bwd_workspace_bytes(total, C_, code), xs[0].device)
+    if split_reduce:               # the two-call form the native block scheduler uses (reduce on another stream there); same stream here
+        rows = C.c_int(0)
+        check(lib.lmv_layernorm_bwd_partial(seg, len(xs), _f32(gamma), C_, ws.data_ptr(), ws.numel(), C.byref(rows), code, _stream()), "lmv_layernorm_bwd_partial")
+        check(lib.lmv_layernorm_bwd_reduce(ws.data_ptr(), rows.value, C_, _f32(dgamma), _f32(dbeta), _stream()), "lmv_layernorm_bwd_reduce")
+        return dxs if next_scales is None else (dxs, scaled)
     if gelu_beta is not None:      # backward of GELU(LayerNorm(x)): needs beta to recompute the pre-activation
         check(lib.lmv_layernorm_gelu_bwd(seg, len(xs), _f32(gamma), _f32(gelu_beta), _f32(dgamma), _f32(dbeta), C_, ws.data_ptr(), ws.numel(), code,
                                          _stream()), "lmv_layernorm_gelu_bwd")

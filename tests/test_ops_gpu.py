@@ -483,3 +483,22 @@ def test_conv3x3s2_native(dtype, B, Ci, Co, H, W):
     assert_close(xg.grad, x64.grad, dtype, "conv dx", tol16=4e-3)
     assert_close(wg.grad, w64.grad, torch.float32, "conv dw", tol32=2e-5 if dtype == torch.float32 else 2e-5 * 4)
     assert_close(bg.grad, b64.grad, torch.float32, "conv db", tol32=2e-5)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_layernorm_bwd_two_call_form(dtype):
+    """lmv_layernorm_bwd_partial + lmv_layernorm_bwd_reduce (the native block scheduler runs the reduce on its side stream) are
+    bit-identical to lmv_layernorm_bwd: dx and the accumulated dgamma / dbeta."""
+    o = ops()
+    C_, rows_x, rows_c = 192, 5000, 48
+    g = (1.0 + 0.2 * det_tensor((C_,), "g", 7)).to(dev()); b = det_tensor((C_,), "b", 7, 0.1).to(dev())
+    xs = [rnd((rows_x, C_), "x", dtype)[0].view(1, rows_x, C_), rnd((rows_c, C_), "c", dtype)[0].view(1, rows_c, C_)]
+    dys = [rnd((rows_x, C_), "dy", dtype)[0].view(1, rows_x, C_), rnd((rows_c, C_), "dyc", dtype)[0].view(1, rows_c, C_)]
+    _, st = o.layernorm_fwd_multi(xs, g, b, 1e-6, want_stats=True)
+    outs = []
+    for split in (False, True):
+        dg = torch.full((C_,), 0.25, device=dev()); db = torch.full((C_,), -0.5, device=dev())
+        dxs = o.layernorm_bwd_multi(dys, xs, st, g, dg, db, [None, None], split_reduce=split)
+        outs.append([t.clone() for t in dxs] + [dg, db])
+    for a, c in zip(*outs):
+        assert torch.equal(a, c)

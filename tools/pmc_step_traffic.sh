@@ -22,7 +22,7 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
     kb = sum(r[1] for r in sel) / 4
     by = {}
     for k, v, _ in sel:
-        k = k.split('(')[0].replace('(anonymous namespace)::', '').replace('void ', '')[:60]
+        k = k.replace('(anonymous namespace)::', '').replace('void ', '').split('(')[0][:60]
         by[k] = by.get(k, 0) + v / 4
     res[c] = dict(kb_per_step=kb, launches_per_step=per, top=sorted(((round(v / 1024, 1), k) for k, v in by.items()), reverse=True)[:12])
 batch = 128

@@ -15,7 +15,7 @@ agg = collections.OrderedDict()
 for n, s, e in rows:
     n = re.sub(r'\(anonymous namespace\)::|void ', '', n)[:110]
     agg.setdefault(n, []).append((e - s) / 1e3)
-steps = 15
+steps = 20          # bench.py --steps 10 --warmup 5 runs 5 + 10 timed + 5 single-step host-issue probes
 tot = 0.0
 out = []
 for n, v in agg.items():

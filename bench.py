@@ -58,6 +58,8 @@ def parse():
     ap.add_argument("--force-ddp", action="store_true", help="wrap in DDP (and use the DDP code path) even at world size 1: measures the wrapper's overhead")
     ap.add_argument("--torch-adamw", action="store_true", help="use torch.optim.AdamW(fused=True) instead of lemevit_amd.FlatAdamW at N=1")
     ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--no-issue-probe", action="store_true", help="skip the 5 synchronised single steps that measure host issue time (profiling runs: "
+                    "they would sit in the 'last steps' window of a kernel trace)")
     ap.add_argument("--graph", type=int, default=-1, help="(-1 = auto: eager for train, graph replay for infer)  1 = capture the step into a hipGraph (lemevit_amd.graph.GraphedStep) and replay it; default 0 = "
                     "eager launches, which are faster here: the weight-gradient GEMMs overlap the dX chain on a side stream, and the "
                     "runtime serialises the branches of a captured graph (38.0 vs 39.6 ms per step)")
@@ -290,13 +292,13 @@ def main():
     # host time to ENQUEUE one step, measured on an EMPTY launch queue (issuing K steps back to back only measures the queue's
     # back-pressure: the host blocks once the device is a queue depth behind) -- median of 5 single steps, each preceded by a sync
     issue = []
-    for _ in range(5):
+    for _ in range(0 if args.no_issue_probe else 5):
         sync()
         ti = time.perf_counter()
         step()
         issue.append(time.perf_counter() - ti)
     sync()
-    t_issued = sorted(issue)[len(issue) // 2] * args.steps
+    t_issued = sorted(issue)[len(issue) // 2] * args.steps if issue else None
     kernel_timing_note = None
     if not args.no_kernel_timing:
         # Same kernels, same shapes: every forward-GEMM launch of 3 eager steps run right AFTER the timed region is bracketed by HIP
@@ -357,7 +359,7 @@ def main():
             "config": {"workload": f"{args.model} {args.img}x{args.img} bf16-autocast {'train step (fwd+bwd+AdamW)' if train else 'forward'}, "
                                    f"batch {args.batch}/GPU, drop_path 0.1, random-init weights", "global_batch": args.batch * world,
                        "parallelism": f"dp{world}", "launch": graph_note},
-            "host_issue_ms_per_step": round(1e3 * t_issued / args.steps, 3),
+            "host_issue_ms_per_step": None if t_issued is None else round(1e3 * t_issued / args.steps, 3),
             "model_tflops": None if gflop is None else round(value * gflop * mult / 1e3, 2),
             "model_frac_of_bf16_peak": None if gflop is None else round(value * gflop * mult / 1e3 / (PEAK_BF16_TFLOPS * world), 4),
             "roofline": roof,

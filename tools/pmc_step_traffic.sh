@@ -4,7 +4,7 @@
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT; OUT=$1; shift
 D=gpurun_out/pst; rm -rf $D; mkdir -p $D
 for c in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $c --kernel-trace -d $D/$c -o p -- python bench.py --graph 0 --steps 4 --warmup 2 --no-cpu-baseline --no-kernel-timing "$@" > $D/$c.log 2>&1
+  rocprofv3 --pmc $c --kernel-trace -d $D/$c -o p -- python bench.py --graph 0 --steps 4 --warmup 2 --no-cpu-baseline --no-kernel-timing --no-issue-probe "$@" > $D/$c.log 2>&1
 done
 python - "$OUT" "$@" <<PY
 import sqlite3, glob, json, sys
@@ -15,10 +15,12 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
     tabs = [r[0] for r in db.execute("select name from sqlite_master where type in ('table','view')")]
     cc = [t for t in tabs if t.startswith('counters_collection')][0]
     rows = db.execute(f"select kernel_name, value, start from {cc} where counter_name = '{c}' order by start").fetchall()
-    n = len(rows)
-    # steps: 2 warm-up + 4 timed + 5 issue-time probes = 11 equal passes; take passes 3..6
-    per = n // 11
-    sel = rows[2 * per: 6 * per]
+    # steps: 2 warm-up + 4 timed (--no-issue-probe); a step starts at the stem's im2col launch (once per pass), the first passes carry
+    # one-time kernels (weight folds, casts), so count from the 3rd marker to the end = the 4 timed passes
+    marks = [i for i, r in enumerate(rows) if 'im2col_c3_kernel' in r[0]]
+    assert len(marks) == 6, len(marks)
+    sel = rows[marks[2]:]
+    per = len(sel) // 4
     kb = sum(r[1] for r in sel) / 4
     by = {}
     for k, v, _ in sel:

@@ -3,7 +3,7 @@
 # usage (on the GPU box): bash tools/prof_infer.sh <out.csv> [bench args]
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT; OUT=${1:-gpurun_out/infer_kernel_stats.csv}; shift
 D=gpurun_out/pi; rm -rf $D; mkdir -p $D
-rocprofv3 --kernel-trace -d $D -o t -- python bench.py --mode infer --graph 0 --steps 10 --warmup 5 --no-cpu-baseline --no-kernel-timing "$@" > $D/log.txt 2>&1
+rocprofv3 --kernel-trace -d $D -o t -- python bench.py --mode infer --graph 0 --steps 10 --warmup 5 --no-cpu-baseline --no-kernel-timing --no-issue-probe "$@" > $D/log.txt 2>&1
 DB=$(find $D -name "*.db" | head -1)
 python - <<PY > $OUT
 import sqlite3, re, collections
@@ -15,7 +15,7 @@ agg = collections.OrderedDict()
 for n, s, e in rows:
     n = re.sub(r'\(anonymous namespace\)::|void ', '', n)[:110]
     agg.setdefault(n, []).append((e - s) / 1e3)
-steps = 20          # bench.py --steps 10 --warmup 5 runs 5 + 10 timed + 5 single-step host-issue probes
+steps = 15          # bench.py --steps 10 --warmup 5 --no-issue-probe: 5 warm-up + 10 timed passes
 tot = 0.0
 out = []
 for n, v in agg.items():

@@ -177,6 +177,39 @@ def test_mlp_fused_full_shapes(C, B, N):
         assert_close(fused, unfused.double().cpu(), dtype, f"fused vs unfused C={C}", tol16=6e-3)
 
 
+@pytest.mark.parametrize("C,Hd,rows", [(64, 128, 1), (128, 256, 63), (96, 384, 65), (192, 384, 129), (384, 1536, 127), (320, 640, 257)])
+def test_mlp_fused_edges(C, Hd, rows):
+    """row counts around the tile heights (1, 63 / 65, 127 / 129, 257) and MLP widths below 4 C (hidden = 2 C)"""
+    dtype = torch.bfloat16
+    o, F, masters, w2, b2 = _mlp_case(C, Hd)
+    x, x64 = _tokens(rows, C, "x", dtype)
+    (out,) = o.mlp_fused_fwd([x.view(1, rows, C)], F, w2, b2, EPS)
+    rk, rm = _mlp_refs(x64, F, w2.cpu().double(), b2.cpu(), masters, torch.ones(rows, 1, dtype=torch.float64))
+    assert_close(out.view(rows, C), rk, dtype, f"mlp_fused edge C={C} rows={rows} (kernel math)")
+    assert_close(out.view(rows, C), rm, dtype, f"mlp_fused edge C={C} rows={rows} (reference math)", tol16=4e-3)
+
+
+def test_fused_abi_errors():
+    """status codes of the raw C ABI (no exception crosses it): bad dtype, unsupported width, missing folded operands"""
+    import ctypes as C_
+    from lemevit_amd import _lib
+    lib = _lib.lib
+    x = torch.zeros(128, 96, device=dev(), dtype=torch.bfloat16)
+    prob = (_lib.MlpProblem * 1)()
+    prob[0].x, prob[0].out, prob[0].rows = x.data_ptr(), x.data_ptr(), 128
+    w = _lib.MlpWeights(x.data_ptr(), x.data_ptr(), x.data_ptr(), x.data_ptr(), x.data_ptr())
+    assert lib.lmv_mlp_fused_fwd(prob, 1, C_.byref(w), 96, 384, 1e-6, _lib.LMV_F32, None) == -2          # LMV_ERR_DTYPE
+    assert lib.lmv_mlp_fused_fwd(prob, 1, C_.byref(w), 512, 2048, 1e-6, _lib.LMV_BF16, None) == -1       # LMV_ERR_SHAPE
+    assert b"unsupported" in lib.lmv_last_error()
+    w0 = _lib.MlpWeights(None, x.data_ptr(), x.data_ptr(), x.data_ptr(), x.data_ptr())
+    assert lib.lmv_mlp_fused_fwd(prob, 1, C_.byref(w0), 96, 384, 1e-6, _lib.LMV_BF16, None) == -1
+    lp = (_lib.LinearProblem * 1)()
+    lp[0].a, lp[0].w, lp[0].out, lp[0].rows = x.data_ptr(), x.data_ptr(), x.data_ptr(), 128
+    assert lib.lmv_ln_linear_fwd(lp, 1, 96, 96, 1e-6, 0, _lib.LMV_BF16, None) == -1                        # colsum / folded bias missing
+    assert lib.lmv_attn_out_proj_residual(lp, 1, 96, _lib.LMV_BF16, None) == -1                            # residual missing
+    assert lib.lmv_ln_fold(None, None, None, None, 96, 96, None, None, None, _lib.LMV_BF16, None) == -1
+
+
 def test_mlp_fused_rejects():
     o = ops()
     assert not o.mlp_fused_supported(512, 2048, torch.bfloat16)

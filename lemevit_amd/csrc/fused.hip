@@ -93,6 +93,8 @@ template <int C, int TM> struct MlpCfg {
 
 // (Measured and dropped: issuing the next panel's LDS-DMA requests INSIDE the step, behind the fragment reads, instead of up front --
 //  C = 384: 101 -> 119 us, C = 192: 128 -> 141 us, C = 96: 179 -> 175 us: a request issued while ds_reads are in flight costs more.)
+// (Also measured and dropped: only the upper half of the waves requesting the panels, twice the pieces each, so that the lower wave of
+//  every SIMD starts its MFMAs at once -- C = 384: 105 -> 129 us, C = 192: 125 -> 140 us, C = 96: 180 -> 193 us.)
 // One panel step: the wave's 32 x 64 output tile += A[32 rows x BK] . B[64 cols x BK]^T, both operands in LDS panel images.
 // a0 / a1 (b0 / b1): LDS byte address of this lane's fragment of row (column) tile 0 for the k-half hh = 0 / 1; the other tiles are
 // 16 rows = 16 * ROWB bytes further (the swizzles repeat every 16 rows), which rides in the instruction's immediate offset -- so a

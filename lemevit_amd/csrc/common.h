@@ -113,6 +113,8 @@ __device__ __forceinline__ float gelu_grad_fast_f(float x) {
 // step is a packed-fp32 instruction (v_pk_mul_f32 / v_pk_fma_f32: two values per lane and issue).  |Phi error| <= 4.8e-5,
 // |GELU error| <= 1.9e-4 absolute (3.2e-5 for |x| <= 2) -- below half a bf16 ulp of the stored activation for |h| >= 0.05, and the
 // hidden activations only ever exist as bf16 MFMA operands.  (The stand-alone GEMM epilogues keep the erf formula above.)
+// (hipcc SLP-packs a scalar-float version of the same code into the same v_pk_* instructions; with -fno-slp-vectorize the pass is
+//  10 - 15 % slower, tools/mlp_timeline.py.)
 __device__ __forceinline__ f32x2_t gelu_poly2(f32x2_t x) {
   f32x2_t s = x * 0.25f;
   s[0] = __builtin_amdgcn_fmed3f(s[0], -1.0f, 1.0f); s[1] = __builtin_amdgcn_fmed3f(s[1], -1.0f, 1.0f);

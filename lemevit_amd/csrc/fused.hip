@@ -58,6 +58,9 @@ struct MlpArgs {
   const bf16_t* w2; const float* b2;                       // fc2: [C, Hd], [C]
   int nprob, Hd;
   float eps;
+#ifdef LMV_MLP_TIMING
+  unsigned long long* dbg;      // [2 waves][steps][5] s_memtime stamps of workgroup 0 (tools/mlp_timeline.py)
+#endif
 };
 
 template <int C, int TM> struct MlpCfg {
@@ -144,14 +147,14 @@ __device__ __forceinline__ void lds_st_b64(unsigned addr, unsigned lo, unsigned 
 __device__ __forceinline__ unsigned opaque(unsigned v) { asm volatile("" : "+v"(v)); return v; }
 
 #ifndef LMV_DUAL_MAXC
-#define LMV_DUAL_MAXC 384      // widest C whose steps keep BOTH k-halves' fragments in registers (second half's reads under the first half's MFMAs)
+#define LMV_DUAL_MAXC 320      // widest C whose steps keep BOTH k-halves' fragments in registers (second half's reads under the first half's MFMAs)
 #endif
 template <int C, int TM>
 __global__ __launch_bounds__(TM * 4) void mlp_fused_kernel(const MlpArgs g) {
   using K = MlpCfg<C, TM>;
   using CF = Cfg<TM / 32, 2, 2>;                             // waves of 32 x 64 over a TM x 128 step tile
   constexpr int BK1 = K::BK1, KT1 = K::KT1, NP = K::NP, STEPS = K::STEPS, NW = K::NW, NTHR = TM * 4;
-  constexpr bool DUAL = C <= LMV_DUAL_MAXC;                  // register budget: 256 per lane at 2 waves per SIMD (C = 384: 234)
+  constexpr bool DUAL = C <= LMV_DUAL_MAXC;                  // register budget: 256 per lane at 2 waves per SIMD (C = 384: no room beside the prefetched colsum / bias; measured equal anyway)
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int NSLOT = K::NSLOT, D = NSLOT - 1;             // ring depth, prefetch distance in steps
   unsigned char* const sX = smem;
@@ -260,6 +263,14 @@ __global__ __launch_bounds__(TM * 4) void mlp_fused_kernel(const MlpArgs g) {
   const unsigned fb1_0 = frag_off<false, BK1>(wn * 64, lane, 0), fb1_1 = BK1 == 64 ? frag_off<false, BK1>(wn * 64, lane, 1) : 0u;
   const unsigned fa2_0 = frag_off<false, 64>(wm * 32, lane, 0), fa2_1 = frag_off<false, 64>(wm * 32, lane, 1);
   const unsigned fb2_0 = frag_off<false, 64>(wn * 64, lane, 0), fb2_1 = frag_off<false, 64>(wn * 64, lane, 1);
+#ifdef LMV_MLP_TIMING
+  const bool stampw = blockIdx.x == 0 && (wave == 0 || wave == NW - 1) && lane == 0 && g.dbg;
+  unsigned long long* const dbg = g.dbg + (wave == 0 ? 0 : 4096);
+  int nst = 0;
+#define STAMP(k) do { if (stampw && nst < 800) dbg[nst * 5 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define STAMP(k) do { } while (0)
+#endif
   int cur = 0;                                                // ring slot of the current step
   for (int j = 0; j < nchunks; ++j) {
     f32x4_t acc1[2][4];
@@ -268,14 +279,27 @@ __global__ __launch_bounds__(TM * 4) void mlp_fused_kernel(const MlpArgs g) {
 #pragma unroll
       for (int q = 0; q < 4; ++q) acc1[i][q] = f32x4_t{0.f, 0.f, 0.f, 0.f};
     const bool more = j + 1 < nchunks;                        // wave-uniform: panels of the next chunk exist
+    f32x4_t s4[4], b4[4];                                     // folded colsum / bias of this lane's 16 hidden columns of the chunk
     static_for<STEPS>([&](auto tc) {
       constexpr int t = decltype(tc)::value;
+      STAMP(0);
+      if constexpr (t == KT1 - 1 && !K::SB) {
+        // no room for them in LDS (C = 384): requested from L2 one whole step before the GELU pass needs them -- at the point of use
+        // the round trip (~2k cycles under load, s_memtime timeline) stood exposed in every chunk: 17 % of the kernel
+        const int n0 = j * 128 + wn * 64 + (lane >> 4) * 4;
+#pragma unroll
+        for (int tj = 0; tj < 4; ++tj) {
+          const float4 sv = *reinterpret_cast<const float4*>(g.s1 + n0 + tj * 16), bv = *reinterpret_cast<const float4*>(g.b1 + n0 + tj * 16);
+          s4[tj] = f32x4_t{sv.x, sv.y, sv.z, sv.w}; b4[tj] = f32x4_t{bv.x, bv.y, bv.z, bv.w};
+        }
+      }
       // the panel of step t + D goes into the slot everybody left at the barrier that closed the previous step
       {
         const int nxt = cur == 0 ? NSLOT - 1 : cur - 1;
         if constexpr (t + D < STEPS) issue_step(j, std::integral_constant<int, t + D>{}, sR + nxt * K::SLOT);
         else if (more) issue_step(j + 1, std::integral_constant<int, t + D - STEPS>{}, sR + nxt * K::SLOT);
       }
+      STAMP(1);
       const unsigned slot = opaque(lR + cur * K::SLOT);
       if constexpr (t < KT1) {
         const unsigned xa = opaque(lX) + t * K::XT;
@@ -287,27 +311,26 @@ __global__ __launch_bounds__(TM * 4) void mlp_fused_kernel(const MlpArgs g) {
       }
       // the panel of step t + 1 has landed (this wave's pieces: the requests of steps t + 2 .. t + D stay in flight; loads retire in
       // order) -- and, past the barrier, everybody's; in the last chunk the ring runs dry, so drain instead of counting
+      STAMP(2);
       if (more || t + D < STEPS) wait_vm<K::younger(t)>(); else wait_vm<0>();
+      STAMP(3);
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
+      STAMP(4);
+#ifdef LMV_MLP_TIMING
+      ++nst;
+#endif
       cur = cur + 1 == NSLOT ? 0 : cur + 1;
       if constexpr (t == KT1 - 1) {
         // LayerNorm (folded) + bias + exact GELU on the fc1 accumulators -> H.  This wave's 64 hidden columns are exactly k-tile `wn` of H.
-        const int n0 = j * 128 + wn * 64 + (lane >> 4) * 4;
-        f32x4_t s4[4], b4[4];
         if constexpr (K::SB) {
+          const int n0 = j * 128 + wn * 64 + (lane >> 4) * 4;
           const unsigned a = lSB + n0 * 4;
 #pragma unroll
           for (int tj = 0; tj < 4; ++tj) { s4[tj] = lds_ld_f4(a + tj * 64); b4[tj] = lds_ld_f4(a + Hd * 4 + tj * 64); }
           wait_lgkm<0>();
 #pragma unroll
           for (int tj = 0; tj < 4; ++tj) { asm volatile("" : "+v"(s4[tj])); asm volatile("" : "+v"(b4[tj])); }
-        } else {
-#pragma unroll
-          for (int tj = 0; tj < 4; ++tj) {
-            const float4 sv = *reinterpret_cast<const float4*>(g.s1 + n0 + tj * 16), bv = *reinterpret_cast<const float4*>(g.b1 + n0 + tj * 16);
-            s4[tj] = f32x4_t{sv.x, sv.y, sv.z, sv.w}; b4[tj] = f32x4_t{bv.x, bv.y, bv.z, bv.w};
-          }
         }
 #pragma unroll
         for (int tj = 0; tj < 4; ++tj)
@@ -418,6 +441,9 @@ extern "C" int lmv_mlp_fused_fwd(const lmv_mlp_problem* p, int nproblems, const 
   MlpArgs g{};
   g.w1 = (const bf16_t*)w->w1f; g.s1 = w->colsum1; g.b1 = w->b1f; g.w2 = (const bf16_t*)w->w2; g.b2 = w->b2;
   g.nprob = nproblems; g.Hd = hidden; g.eps = eps;
+#ifdef LMV_MLP_TIMING
+  { const char* e = getenv("LMV_MLP_DBG_PTR"); g.dbg = e ? (unsigned long long*)strtoull(e, nullptr, 0) : nullptr; }
+#endif
   for (int i = 0; i < nproblems; ++i) {
     const lmv_mlp_problem& q = p[i];
     if (q.rows <= 0 || q.rows > 0x7fffffffLL / 4) LMV_FAIL(LMV_ERR_SHAPE, "mlp_fused: bad rows %lld", (long long)q.rows);

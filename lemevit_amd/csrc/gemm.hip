@@ -48,6 +48,17 @@ __global__ __launch_bounds__(CF::NTHR, MINW) void gemm_kernel(const GemmArgs g) 
   using RS = typename std::conditional<LNP, RowStat<CF::WM>, NoStat>::type;
   RS rstat;
   if constexpr (LNP) rstat.clear();
+#ifdef LMV_GEMM_TIMING
+  // timeline of wave 0 of the first and of a middle workgroup: [0] entry, [1] first requests issued, [2] first k-tile landed, then per k-tile
+  // (request, MFMAs done, barrier passed), then [k-loop end], [epilogue operands requested], [stores issued]
+  const bool tstamp = g.dbg && (threadIdx.x == 0) && (blockIdx.x == 0 || blockIdx.x == gridDim.x / 2);
+  unsigned long long* const tdbg = g.dbg + (blockIdx.x == 0 ? 0 : 256);
+  int tstn = 0;
+#define GSTAMP() do { if (tstamp && tstn < 250) tdbg[tstn++] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define GSTAMP() do { } while (0)
+#endif
+  GSTAMP();
   constexpr int PANEL_BYTES = PANEL * BK * (int)sizeof(T);
   constexpr int BUF_BYTES = (CF::PA + CF::PB) * PANEL_BYTES;
   constexpr int WM = CF::WM;
@@ -83,8 +94,17 @@ __global__ __launch_bounds__(CF::NTHR, MINW) void gemm_kernel(const GemmArgs g) 
     }
     bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
   }
-  const int pi = (g.nprob > 1 && !g.concat && bid >= g.p[1].tile_begin) ? 1 : 0;
-  const Problem& P = g.p[pi];
+  const bool second = g.nprob > 1 && !g.concat && bid >= g.p[1].tile_begin;      // workgroup-uniform
+  const int pi = second ? 1 : 0;
+  // The problem descriptor is SELECTED field by field instead of indexed (`g.p[pi]`): an indexed kernel-argument read is a scalar load
+  // whose address depends on pi, i.e. one dependent s_load + s_waitcnt round trip per use site -- the s_memtime timeline of a stage-3
+  // forward launch showed 1.6 - 2.5k cycles between kernel entry and the first LDS-DMA request (of a 22k-cycle workgroup life) and
+  // another such chain in front of the epilogue.  With constant addresses all of both problems' fields load in one batch at entry.
+  Problem P;
+#define LMV_SEL(f) P.f = second ? g.p[1].f : g.p[0].f
+  LMV_SEL(a); LMV_SEL(b); LMV_SEL(bias); LMV_SEL(res); LMV_SEL(row_scale); LMV_SEL(aux); LMV_SEL(out); LMV_SEL(out_pre); LMV_SEL(bias_grad);
+  LMV_SEL(M); LMV_SEL(Kred); LMV_SEL(rps); LMV_SEL(tiles_m); LMV_SEL(tile_begin);
+#undef LMV_SEL
   bid -= P.tile_begin;
   const int tm = bid / g.tiles_n, tn = bid % g.tiles_n;
   const int m0 = tm * CF::BM, n0 = tn * CF::BN;
@@ -141,12 +161,17 @@ __global__ __launch_bounds__(CF::NTHR, MINW) void gemm_kernel(const GemmArgs g) 
       // 8-wave kernels (64-deep k-tiles, 1.5x the fragment reads): the plain loop -- hipcc waits for the requested k-tile BEFORE this
       // tile's fragment reads, so LDS-DMA writes and ds_reads never share the LDS; measured 3 % faster here than the overlapped loop below
       issue(smem, kt_beg);
+      GSTAMP();
       __syncthreads();                                  // (the compiler drains vmcnt before the barrier: the LDS-DMA landed)
+      GSTAMP();
       for (int kt = kt_beg; kt < kt_end; ++kt) {
         if (kt + 1 < kt_end) issue(smem + (cur ^ 1) * BUF_BYTES, kt + 1);
+        GSTAMP();
         const unsigned char* buf = smem + cur * BUF_BYTES;
         tile_mma<T, ATR, BTR, BK, SPLITK, WM, RS>(buf + pa * PANEL_BYTES, oa, buf + (CF::PA + pb) * PANEL_BYTES, ob, acc, accb, do_bsum, lane, &rstat);
+        GSTAMP();
         __syncthreads();
+        GSTAMP();
         cur ^= 1;
       }
     } else {
@@ -164,13 +189,17 @@ __global__ __launch_bounds__(CF::NTHR, MINW) void gemm_kernel(const GemmArgs g) 
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
     int nxt = NST - 1;                                 // buffer of k-tile kt + NST - 1
+    GSTAMP(); GSTAMP();
     for (int kt = kt_beg; kt < kt_end; ++kt) {
       if (kt + NST - 1 < kt_end) issue(smem + nxt * BUF_BYTES, kt + NST - 1);
+      GSTAMP();
       const unsigned buf = lds0 + cur * BUF_BYTES;
       tile_mma_dma<ATR, BTR, BK, SPLITK, WM, RS>(buf + pa * PANEL_BYTES, oa, buf + (CF::PA + pb) * PANEL_BYTES, ob, acc, accb, do_bsum, lane, &rstat);
+      GSTAMP();
       if (NST == 3 && kt + 2 < kt_end) wait_vm<NLD>(); else wait_vm<0>();
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
+      GSTAMP();
       cur = (cur + 1 == NST) ? 0 : cur + 1;
       nxt = (nxt + 1 == NST) ? 0 : nxt + 1;
     }
@@ -219,6 +248,7 @@ __global__ __launch_bounds__(CF::NTHR, MINW) void gemm_kernel(const GemmArgs g) 
       if (do_bsum && lane < 16) slab[(int64_t)M * g.ldc + m] = accb[ti][0];
     }
   } else {
+    GSTAMP();
     if constexpr (LNP) {
       // LayerNorm-folded forward: the GELU' operand slot (aux) carries colsum(W'), which the epilogue reads itself
       rstat.finish(P.Kred, g.ln_eps);
@@ -226,7 +256,9 @@ __global__ __launch_bounds__(CF::NTHR, MINW) void gemm_kernel(const GemmArgs g) 
       epi.template store<true>(smem, acc, P, g.act & 0xff, N, g.ldc, m0, n0, wm, wn, lane, wave, rstat.s, rstat.q);
     } else {
       if constexpr (!EPI_EARLY) epi.prefetch(P, g.act & 0xff, N, g.ldc, m0, n0, wm, wn, lane);
+      GSTAMP();
       epi.store(smem, acc, P, g.act & 0xff, N, g.ldc, m0, n0, wm, wn, lane, wave);
+      GSTAMP();
     }
   }
 }
@@ -630,6 +662,9 @@ int make_plan(const lmv_linear_problem* p, int nproblems, int N, int K, int act,
     pl->ws_bytes = (size_t)slabs * g.slab_stride * sizeof(float);
   }
   g.cumap = [] { const char* e = getenv("LMV_GEMM_CUMAP"); return e ? atoi(e) : 1; }();      // A/B testing
+#ifdef LMV_GEMM_TIMING
+  { const char* e = getenv("LMV_GEMM_DBG_PTR"); g.dbg = e ? (unsigned long long*)strtoull(e, nullptr, 0) : nullptr; }
+#endif
   pl->total = total; pl->splits = splits; pl->bk = bk; pl->tile = tile; pl->dma = dma;
   pl->bigk = 0;
   // BigK tile (128 x 256 / 384, 8 waves, register-pipelined k-loop): long bf16 reductions whose output is at least 256 columns wide

@@ -37,6 +37,9 @@ struct GemmArgs {
   int cumap;                     // fwd / dX: CU-aware tile order (see gemm_kernel)
   int ntiles, nsplits, concat;   // dW: tiles of dW, k-splits, and whether problem 1's rows extend problem 0's reduction
   float ln_eps;           // LayerNorm-folded forward (lmv_ln_linear_fwd): eps of the folded LayerNorm
+#ifdef LMV_GEMM_TIMING
+  unsigned long long* dbg;      // s_memtime stamps of two workgroups (tools/gemm_timeline.py)
+#endif
   float* ws;              // split-K (dW) mode: partial slabs [slab][N*K + N] fp32
   int64_t slab_stride;    // floats per slab
   int slab_base[2];       // first slab of each problem

@@ -58,6 +58,10 @@ __global__ __launch_bounds__(CF::NTHR, MINW) void gemm_kernel(const GemmArgs g) 
 #else
 #define GSTAMP() do { } while (0)
 #endif
+  // (Measured and dropped: staggering the first generation of workgroups by a start delay per resident slot, so that the store bursts of
+  //  one half of the chip meet the k-loops of the other -- the s_memtime timeline shows every workgroup of a generation storing at once,
+  //  each 16-byte store round then takes ~1k cycles = the chip's whole write bandwidth.  Every delay from 4k to 12k cycles only lengthened
+  //  the launches by about the delay itself: 5 generations of ~20k-cycle workgroups are too short to win it back.)
   GSTAMP();
   constexpr int PANEL_BYTES = PANEL * BK * (int)sizeof(T);
   constexpr int BUF_BYTES = (CF::PA + CF::PB) * PANEL_BYTES;
@@ -257,7 +261,12 @@ __global__ __launch_bounds__(CF::NTHR, MINW) void gemm_kernel(const GemmArgs g) 
     } else {
       if constexpr (!EPI_EARLY) epi.prefetch(P, g.act & 0xff, N, g.ldc, m0, n0, wm, wn, lane);
       GSTAMP();
+#ifdef LMV_GEMM_TIMING
+      auto est = [&]() { GSTAMP(); };
+      epi.template store<false, decltype(est)>(smem, acc, P, g.act & 0xff, N, g.ldc, m0, n0, wm, wn, lane, wave, nullptr, nullptr, est);
+#else
       epi.store(smem, acc, P, g.act & 0xff, N, g.ldc, m0, n0, wm, wn, lane, wave);
+#endif
       GSTAMP();
     }
   }

@@ -398,9 +398,11 @@ template <typename T, typename CF, int REGION_BYTES> struct Epi {
   // RPP rows per pass, a row of 64 fp32 = 16 float4 chunks, chunk c of row r stored at c ^ (r & 7).
   // LN = true (lmv_ln_linear_fwd): the accumulators hold x W'^T of the RAW rows; the folded LayerNorm is applied on the way into the
   // transpose: v = rstd[row] * (acc - mean[row] * colsum[n]) + bias'[n]  (ln_mean / ln_rstd: per row tile, row = lane & 15; colsum = P.aux)
-  template <bool LN = false>
+  struct NoStamp { __device__ __forceinline__ void operator()() const {} };
+  template <bool LN = false, typename ST = NoStamp>
   __device__ __forceinline__ void store(unsigned char* smem, const f32x4_t (&acc)[CF::WM][4], const Problem& P, int act, int N, int64_t ldc,
-                                        int m0, int n0, int wm, int wn, int lane, int wave, const float* ln_mean = nullptr, const float* ln_rstd = nullptr) const {
+                                        int m0, int n0, int wm, int wn, int lane, int wave, const float* ln_mean = nullptr, const float* ln_rstd = nullptr,
+                                        ST stamp = ST{}) const {
     float* sT = reinterpret_cast<float*>(smem + wave * REGION_BYTES);
     T* outp = reinterpret_cast<T*>(P.out);
     T* prep = reinterpret_cast<T*>(P.out_pre);
@@ -431,6 +433,7 @@ template <typename T, typename CF, int REGION_BYTES> struct Epi {
       }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // this wave's LDS writes are visible to all of its lanes
       __builtin_amdgcn_wave_barrier();
+      stamp();
 #pragma unroll
       for (int i = 0; i < NITER; ++i) {
         const int c = lane + i * 64, r = c / CPR, oc = c % CPR;
@@ -468,6 +471,7 @@ template <typename T, typename CF, int REGION_BYTES> struct Epi {
           for (int e = 0; e < EPC; ++e) v[e] += r8[e];
         }
         *reinterpret_cast<uint4*>(outp + o) = f_to_chunk<T>(v);
+        stamp();
       }
     }
   }

@@ -24,10 +24,12 @@ for wgi, name in enumerate(("first workgroup", "middle workgroup")):
     t = [int(v) for v in d[wgi] if int(v) != 0]
     if len(t) < 6: print(name, "no stamps"); continue
     t0 = t[0]; rel = [v - t0 for v in t]
-    nk = (len(t) - 3 - 3) // 3
+    nk = K // 64 if (K % 64 == 0 and mode == "fwd") else (K if mode == "fwd" else N) // 32
+    if 3 + 3 * nk + 3 > len(t): nk = (len(t) - 6) // 3
     print(f"{name}: entry 0 | requests issued {rel[1]} | first k-tile landed {rel[2]}")
     for k in range(nk):
         b = 3 + 3 * k
         print(f"   k-tile {k}: request +{t[b] - t[b - 1]:5d}  reads+mfma +{t[b + 1] - t[b]:5d}  wait+barrier +{t[b + 2] - t[b + 1]:5d}   (at {rel[b + 2]})")
     e = 3 + 3 * nk
-    print(f"   k-loop end {rel[e]} | epilogue operands requested +{t[e + 1] - t[e]} | transposes + stores issued +{t[e + 2] - t[e + 1]} | total {rel[e + 2]} cycles")
+    tail = t[e + 1:]
+    print(f"   k-loop end {rel[e]} | epilogue operands requested +{t[e + 1] - t[e]} | then (LDS transpose done, then each 16-byte store issued): " + " ".join(f"+{b - a}" for a, b in zip(tail, tail[1:])) + f" | total {rel[-1]} cycles")

@@ -58,7 +58,8 @@ def gelu_grad64(x):
 
 # ------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("rows,N,K", [(300, 96, 64), (4096, 288, 96), (1000, 1152, 384), (129, 384, 1536), (16, 64, 256), (2051, 1000, 512)])
+@pytest.mark.parametrize("rows,N,K", [(300, 96, 64), (4096, 288, 96), (1000, 1152, 384), (129, 384, 1536), (16, 64, 256), (2051, 1000, 512),
+                                      (140001, 384, 128), (70003, 200, 64)])      # the last two: > 1024 tiles (several generations of workgroups)
 def test_linear_fwd(dtype, rows, N, K):
     o = ops()
     a, a64 = rnd((rows, K), "a", dtype)

@@ -381,8 +381,20 @@ template <typename T, typename CF, int REGION_BYTES> struct Epi {
         const int c = lane + i * 64, r = c / CPR, oc = c % CPR;
         const int m = min(m0 + wm * (CF::WM * 16) + p * RPP + r, P.M - 1), n = min(nw0 + oc * EPC, N - EPC);      // clamped, never masked
         if (src) pf[p][i] = *reinterpret_cast<const uint4*>(src + (int64_t)m * ldc + n);
-        if constexpr (HOIST_BIAS) rs[p][i] = P.row_scale ? P.row_scale[m / P.rps] : 1.0f;
+        if constexpr (HOIST_BIAS) rs[p][i] = 1.0f;
       }
+    if constexpr (HOIST_BIAS) {
+      if (P.row_scale) {      // workgroup-uniform branch: the per-chunk integer division by rows-per-sample only where DropPath is live
+#pragma unroll
+        for (int p = 0; p < NPASS; ++p)
+#pragma unroll
+          for (int i = 0; i < NITER; ++i) {
+            const int c = lane + i * 64, r = c / CPR;
+            const int m = min(m0 + wm * (CF::WM * 16) + p * RPP + r, P.M - 1);
+            rs[p][i] = P.row_scale[m / P.rps];
+          }
+      }
+    }
     if constexpr (HOIST_BIAS) {
 #pragma unroll
       for (int tj = 0; tj < 4; ++tj) b4[tj] = bias_at(P, N, nw0 + tj * 16 + (lane >> 4) * 4);

@@ -6,6 +6,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 rows, N, K = [int(v) for v in sys.argv[1:4]] if len(sys.argv) >= 4 else (27136, 1536, 384)
 mode = sys.argv[4] if len(sys.argv) > 4 else "fwd"
+plain = os.environ.get("PLAIN", "0") == "1"          # forward without bias / GELU: is the epilogue's time VALU or the store path?
 dbg = torch.zeros(512, device="cuda:0", dtype=torch.int64)
 os.environ["LMV_GEMM_DBG_PTR"] = str(dbg.data_ptr())
 from lemevit_amd import ops
@@ -16,7 +17,7 @@ bias = torch.zeros(N, device=dev)
 out = torch.empty(rows, N if mode == "fwd" else K, device=dev, dtype=bf)
 for _ in range(3):
     dbg.zero_()
-    if mode == "fwd": ops.linear_fwd([Prob(a, w, out, bias=bias)], N, K, ops.ACT_GELU)
+    if mode == "fwd": ops.linear_fwd([Prob(a, w, out, bias=None if plain else bias)], N, K, ops.ACT_NONE if plain else ops.ACT_GELU)
     else: ops.linear_dx([Prob(a, w, out)], N, K)
 torch.cuda.synchronize()
 d = dbg.cpu().view(2, 256)

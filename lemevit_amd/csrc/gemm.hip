@@ -683,7 +683,7 @@ int make_plan(const lmv_linear_problem* p, int nproblems, int N, int K, int act,
   // pipe, and 21 splits of fat slabs cost more than 24 of thin ones) -- the train step loses 1.1 ms with it.  Off unless LMV_GEMM_BIGK=1.
   static const int bigk_mode = [] { const char* e = getenv("LMV_GEMM_BIGK"); return e ? atoi(e) : 0; }();
   const int bigk_min_k = (mode == MODE_DW) ? 1024 : 768;
-  if (bigk_mode && bf && !no_dma && all64 && min_kred >= bigk_min_k && out_cols >= 256 && force_tile == 0 && force_bk == 0) {
+  if (bigk_mode && (bigk_mode != 2 || mode == MODE_FWD) && bf && !no_dma && all64 && min_kred >= bigk_min_k && out_cols >= 256 && force_tile == 0 && force_bk == 0) {      // 2: forward launches only
     // tile width: 384 when it tiles the output without more padding than 256 does
     const int pad3 = (out_cols + 383) / 384 * 384 - out_cols, pad2 = (out_cols + 255) / 256 * 256 - out_cols;
     const int nsb = (pad3 * 2 <= pad2 * 3 || out_cols <= 384) && out_cols > 256 ? 3 : 2;

@@ -2,13 +2,13 @@
 # Per-kernel PMC table of bench.py's train step (SURVEY 8(d) evidence): HBM bytes per launch (FETCH_SIZE x 2 per the gfx950
 # correction + WRITE_SIZE), achieved GB/s, and matrix-pipe utilisation (SQ_VALU_MFMA_BUSY_CYCLES over the launch's SIMD-cycles:
 # GRBM_GUI_ACTIVE is summed over the 8 XCDs, a launch offers GRBM_GUI_ACTIVE / 8 x 1024 SIMD-cycles).  Separate passes per set.
-# usage (GPU box): bash tools/pmc_kernels.sh out.csv
+# usage (GPU box): bash tools/pmc_kernels.sh out.csv [bench args, e.g. --mode infer]
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
-OUT=${1:-gpurun_out/pmc_per_kernel.csv}; W=gpurun_out/pmc_k; rm -rf $W; mkdir -p $W
+OUT=${1:-gpurun_out/pmc_per_kernel.csv}; shift; W=gpurun_out/pmc_k; rm -rf $W; mkdir -p $W
 i=0
 for set in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE"; do
   i=$((i+1))
-  rocprofv3 --pmc $set --kernel-trace -d $W/s$i -o p -- python bench.py --graph 0 --steps 3 --warmup 2 --no-cpu-baseline --no-kernel-timing > $W/s$i.log 2>&1
+  rocprofv3 --pmc $set --kernel-trace -d $W/s$i -o p -- python bench.py --graph 0 --steps 3 --warmup 2 --no-cpu-baseline --no-kernel-timing --no-issue-probe "$@" > $W/s$i.log 2>&1
 done
 python - <<PY
 import sqlite3, glob, re, collections

@@ -60,6 +60,7 @@ def parse():
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--no-issue-probe", action="store_true", help="skip the 5 synchronised single steps that measure host issue time (profiling runs: "
                     "they would sit in the 'last steps' window of a kernel trace)")
+    ap.add_argument("--no-forward-probe", action="store_true", help="train mode: skip the forward-only pass timed after the train region (forward_* keys)")
     ap.add_argument("--graph", type=int, default=-1, help="(-1 = auto: eager for train, graph replay for infer)  1 = capture the step into a hipGraph (lemevit_amd.graph.GraphedStep) and replay it; default 0 = "
                     "eager launches, which are faster here: the weight-gradient GEMMs overlap the dX chain on a side stream, and the "
                     "runtime serialises the branches of a captured graph (38.0 vs 39.6 ms per step)")
@@ -316,10 +317,36 @@ def main():
         _model._NATIVE = native_was
         kernel_timing_note = ("HIP events around every forward-Linear launch of 3 eager steps run right after the timed region (blocks on the per-launch "
                               "Python schedule for these steps: same kernels and shapes as the native block calls of the timed region)")
-    tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
+    # The north-star target is FORWARD throughput (BASELINE.json): in train mode the same process times the forward pass of the same
+    # model on the same batch right after the train region (eval mode, no_grad, bf16 autocast, hipGraph replay as in --mode infer) and
+    # reports it as extra keys of the same JSON line.  The timed train region above is not touched by it.
+    fwd_dt, fwd_iters, fwd_note = None, 0, None
+    if train and not args.no_forward_probe:
+        model.eval()
+
+        def fwd_step():
+            with torch.no_grad(), torch.autocast("cuda", torch.bfloat16):
+                model(x)
+
+        from lemevit_amd.graph import try_graphed
+        fstep, why = try_graphed(fwd_step, warmup=3)
+        fwd_note = "hipGraph replay" if why is None else f"eager (graph capture failed: {why})"
+        for _ in range(3):
+            fstep()
+        sync()
+        fwd_iters = max(10, args.steps)
+        tf0 = time.perf_counter()
+        for _ in range(fwd_iters):
+            fstep()
+        sync()
+        fwd_dt = time.perf_counter() - tf0
+        model.train(True)
+    tmax = torch.tensor([dt, fwd_dt or 0.0], device=dev, dtype=torch.float64)
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    dt = float(tmax.item())
+    dt = float(tmax[0].item())
+    if fwd_dt is not None:
+        fwd_dt = float(tmax[1].item())
 
     if rank == 0:
         pretty = {"lemevit_tiny": "LeMeViT-Tiny", "lemevit_small": "LeMeViT-Small", "lemevit_base": "LeMeViT-Base"}.get(args.model, args.model)
@@ -364,6 +391,13 @@ def main():
             "model_frac_of_bf16_peak": None if gflop is None else round(value * gflop * mult / 1e3 / (PEAK_BF16_TFLOPS * world), 4),
             "roofline": roof,
         }
+        if fwd_dt is not None:
+            fv = args.batch * world * fwd_iters / fwd_dt
+            line["forward_images_per_sec"] = round(fv, 2)
+            line["forward_ms"] = round(1e3 * fwd_dt / fwd_iters, 3)
+            line["forward_frac_of_bf16_peak"] = None if gflop is None else round(fv * gflop / 1e3 / (PEAK_BF16_TFLOPS * world), 4)
+            line["forward_note"] = (f"forward pass of the same model / batch timed after the train region: eval mode, no_grad, bf16 autocast, {fwd_note}, "
+                                    f"{fwd_iters} iterations, fused inference schedule")
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args.model, args.img, args.mode)
         os.write(json_fd, (json.dumps(line) + "\n").encode())

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define LMV_ABI_VERSION 2
+#define LMV_ABI_VERSION 3
 
 enum { LMV_F32 = 0, LMV_BF16 = 1 };
 enum {
@@ -39,6 +39,13 @@ enum {
 
 int lmv_abi_version(void);
 const char* lmv_last_error(void);
+/* Tuning switches (A/B runs, parity tests of alternative code paths).  The LMV_* environment variables are read ONCE when the library
+ * is loaded -- never on a launch path; these two change / read a switch at run time.  Keys: "gemm_bk", "gemm_bk32_tiles", "dw_bk",
+ * "dw_target_blocks", "gemm_no_dma", "gemm_w8", "gemm_cumap", "gemm_nst", "gemm_nst_dw", "gemm_rs", "dwconv_v", "mlp_tm", "attn_pv16",
+ * "attn_fuse_dq", "attn_fused_bwd", "attn_pair", "ln_bwd_blocks", "ln_bwd_minrows" (lemevit_amd/csrc/common.h: LmvConfig).
+ * Process-wide, not synchronised: set them between launches. */
+int lmv_config_set(const char* key, int value);
+int lmv_config_get(const char* key, int* value);
 
 /* ------------------------------------------------------------------------------------------
  * Linear layers (nn.Linear calls of models/lemevit.py:200,205,289,291,299,302,478-479,486 and
@@ -124,6 +131,9 @@ typedef struct {
   const void* w2; const float* b2;                           /* mlp.3: [C, hidden] in `dtype`, [C] fp32                    */
 } lmv_mlp_weights;
 int lmv_mlp_fused_supported(int C, int hidden, int dtype);
+/* Test hook: y[i] = the activation lmv_mlp_fused_fwd applies to the hidden values (a degree-7 minimax fit of GELU in packed fp32,
+ * |y - GELU_erf(x)| <= 1.9e-4 absolute, exact 0 / identity beyond |x| >= 4), for x, y fp32 [n] on the device. */
+int lmv_gelu_poly_eval(const float* x, float* y, int64_t n, void* stream);
 int lmv_mlp_fused_fwd(const lmv_mlp_problem* p, int nproblems, const lmv_mlp_weights* w, int C, int hidden, float eps, int dtype, void* stream);
 int lmv_attn_out_proj_residual(const lmv_linear_problem* p, int nproblems, int C, int dtype, void* stream);
 
@@ -276,6 +286,11 @@ int lmv_col2im3x3s2_nhwc(const void* dpatches, void* dx, int B, int H, int W, in
  * dx[b, l, :] = g[b, :] / L, dc[b, m, :] = g[b, :] / M (dc may be NULL). */
 int lmv_token_mean2_fwd(const void* x, int L, const void* c, int M, int C, int B, void* out, int dtype, void* stream);
 int lmv_token_mean2_bwd(const void* g, void* dx, int L, void* dc, int M, int C, int B, int dtype, void* stream);
+/* Inference tail (models/lemevit.py:815, 825 with the final BatchNorm in eval mode): BatchNorm with running statistics is affine per channel and
+ * commutes with the spatial mean, so out[b, :] = xscale * mean_l x[b, l, :] + xshift + mean_m c[b, m, :] with
+ * xscale = gamma / sqrt(running_var + eps), xshift = beta - running_mean * xscale (fp32 [C]). */
+int lmv_token_mean2_affine_fwd(const void* x, int L, const void* c, int M, int C, int B, const float* xscale, const float* xshift, void* out, int dtype,
+                               void* stream);
 /* Fused multi-tensor AdamW over a flat fp32 parameter / gradient / moment buffer
  * (decoupled weight decay, bias correction as torch.optim.AdamW; benchmark.py:559-561,587).
  * wd_mask (nullable): per-element 0/1 factor on weight_decay.  shadow_bf16 (nullable): bf16 copy of the updated parameters,

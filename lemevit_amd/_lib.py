@@ -14,7 +14,7 @@ LIB_PATH = os.path.join(_HERE, "csrc", "liblemevit_hip.so")
 
 LMV_F32, LMV_BF16 = 0, 1
 ACT_NONE, ACT_GELU, ACT_GELU_GRAD = 0, 1, 2
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 
 class LinearProblem(C.Structure):
@@ -69,6 +69,8 @@ _P, _I, _L, _F, _Z = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_size_t
 # name -> (restype, argtypes); the complete export list of include/lemevit_hip.h
 SIGNATURES = {
     "lmv_abi_version": (_I, []),
+    "lmv_config_set": (_I, [C.c_char_p, _I]),
+    "lmv_config_get": (_I, [C.c_char_p, C.POINTER(C.c_int)]),
     "lmv_last_error": (C.c_char_p, []),
     "lmv_linear_fwd": (_I, [C.POINTER(LinearProblem), _I, _I, _I, _I, _I, _P]),
     "lmv_linear_dx": (_I, [C.POINTER(LinearProblem), _I, _I, _I, _I, _I, _P]),
@@ -79,6 +81,7 @@ SIGNATURES = {
     "lmv_ln_fold": (_I, [_P, _P, _P, _P, _I, _I, _P, _P, _P, _I, _P]),
     "lmv_ln_linear_fwd": (_I, [C.POINTER(LinearProblem), _I, _I, _I, _F, _I, _I, _P]),
     "lmv_mlp_fused_supported": (_I, [_I, _I, _I]),
+    "lmv_gelu_poly_eval": (_I, [_P, _P, C.c_int64, _P]),
     "lmv_mlp_fused_fwd": (_I, [C.POINTER(MlpProblem), _I, C.POINTER(MlpWeights), _I, _I, _F, _I, _P]),
     "lmv_attn_out_proj_residual": (_I, [C.POINTER(LinearProblem), _I, _I, _I, _P]),
     "lmv_layernorm_fwd": (_I, [C.POINTER(LnSegment), _I, _P, _P, _I, _F, _I, _P]),
@@ -110,6 +113,7 @@ SIGNATURES = {
     "lmv_im2col3x3s2_nhwc": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "lmv_col2im3x3s2_nhwc": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "lmv_token_mean2_fwd": (_I, [_P, _I, _P, _I, _I, _I, _P, _I, _P]),
+    "lmv_token_mean2_affine_fwd": (_I, [_P, _I, _P, _I, _I, _I, _P, _P, _P, _I, _P]),
     "lmv_token_mean2_bwd": (_I, [_P, _P, _I, _P, _I, _I, _I, _I, _P]),
     "lmv_adamw_flat": (_I, [_P, _P, _P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _I, _P, _P]),
     "lmv_block_arena_bytes": (_Z, [C.POINTER(BlockDesc)]),
@@ -139,6 +143,19 @@ def _load():
 
 
 lib = _load()
+
+
+def config_set(key: str, value: int) -> None:
+    """lmv_config_set: change a tuning switch of the library at run time (tests, tools/ sweeps)."""
+    if lib.lmv_config_set(key.encode(), int(value)):
+        raise RuntimeError(f"lmv_config_set: {lib.lmv_last_error().decode(errors='replace')}")
+
+
+def config_get(key: str) -> int:
+    v = C.c_int(0)
+    if lib.lmv_config_get(key.encode(), C.byref(v)):
+        raise RuntimeError(f"lmv_config_get: {lib.lmv_last_error().decode(errors='replace')}")
+    return int(v.value)
 
 
 def check(rc: int, what: str) -> None:

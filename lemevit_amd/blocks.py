@@ -113,39 +113,62 @@ def _dwconv_w(dy: Tensor, x: Tensor, dweight: Tensor, dbias: Tensor, H: int, W: 
 # there) but at the end of the NEXT block's backward pass, when they have long finished; whatever they read stays referenced until
 # then.  The last blocks of a backward pass are joined by an autograd final callback, i.e. before .backward() returns to the caller.
 _DEFER = int(os.environ.get("LMV_JOIN_DEFER", "1"))       # blocks a join may trail behind (0: join at the end of every block)
-_pending: "collections.deque" = collections.deque()       # (device index, event recorded on the side stream, references)
-_event_pool: List[torch.cuda.Event] = []
-_cb_queued = False
+_pending: "Dict[int, collections.deque]" = {}              # device index -> deque of (event recorded on that device's side stream, references)
+_event_pool: "Dict[int, List[torch.cuda.Event]]" = {}      # device index -> reusable events
+_cb_token = None                                           # identity of the backward pass whose final callback is queued (see defer_join)
 
 
-def _wait_pending(keep: int) -> None:
-    while len(_pending) > keep:
-        di, ev, _refs = _pending.popleft()
-        torch.cuda.current_stream(torch.device("cuda", di)).wait_event(ev)
-        _event_pool.append(ev)
+def _wait_pending(keep: int, dev_index: Optional[int] = None) -> None:
+    """Make the CURRENT stream of each device wait for its deferred side-stream positions (all but the `keep` newest)."""
+    for di in ([dev_index] if dev_index is not None else list(_pending)):
+        q = _pending.get(di)
+        while q and len(q) > keep:
+            ev, _refs = q.popleft()
+            torch.cuda.current_stream(torch.device("cuda", di)).wait_event(ev)
+            _event_pool.setdefault(di, []).append(ev)
+
+
+def drain_deferred() -> None:
+    """Join everything that is still deferred and forget the queued-callback marker.  Called at the start of every training-mode forward
+    pass (model.new_training_pass), by FlatAdamW.step() and by FlatGradSync.finish(): when a backward pass RAISES (out of memory,
+    anomaly mode), autograd drops its queued final callbacks, so relying on `_final_join` alone would leave the last blocks un-joined --
+    and a sticky "callback queued" flag would keep every later backward pass from queueing its own."""
+    global _cb_token
+    _cb_token = None
+    _wait_pending(0)
 
 
 def _final_join() -> None:
-    global _cb_queued
-    _cb_queued = False
+    global _cb_token
+    _cb_token = None
     _wait_pending(0)
 
 
 def defer_join(dev_index: int, refs) -> None:
     """Record the side stream's position; the main stream waits for it `_DEFER` blocks later (or when the backward pass ends)."""
-    global _cb_queued
+    global _cb_token
     side = _side_streams[dev_index][0]
-    ev = _event_pool.pop() if _event_pool else torch.cuda.Event()
+    pool = _event_pool.setdefault(dev_index, [])
+    ev = pool.pop() if pool else torch.cuda.Event()
     ev.record(side)
-    _pending.append((dev_index, ev, refs))
+    _pending.setdefault(dev_index, collections.deque()).append((ev, refs))
     keep = _DEFER
-    if keep > 0 and not _cb_queued:
+    if keep > 0:
+        # one final callback per backward pass: the marker is the pass's graph task (a new pass -- also one that follows a pass which
+        # raised before its callbacks ran -- has a different one), not a process-wide flag
         try:
-            torch.autograd.Variable._execution_engine.queue_callback(_final_join)
-            _cb_queued = True
-        except RuntimeError:              # not inside a backward pass (a schedule driven by hand): join now
+            token = torch._C._current_graph_task_id()
+        except Exception:
+            token = -1
+        if token == -1:                   # not inside a backward pass (a schedule driven by hand): join now
             keep = 0
-    _wait_pending(keep)
+        elif _cb_token != token:
+            try:
+                torch.autograd.Variable._execution_engine.queue_callback(_final_join)
+                _cb_token = token
+            except RuntimeError:
+                keep = 0
+    _wait_pending(keep, dev_index)
 
 
 def _join() -> None:

@@ -1351,7 +1351,7 @@ size_t lmv_attn_mfma_bwd_acc_bytes(const AttnArgs& a) {
 int lmv_attn_mfma_fwd(const AttnArgs& a, hipStream_t st) {
   const int per = qt_per_block_for(a), nqt = (a.Lq + 15) / 16;
   dim3 grid((nqt + per - 1) / per, a.H, a.B), block(256);
-  static const int pv16 = [] { const char* e = getenv("LMV_ATTN_PV16"); return e ? atoi(e) : 1; }();      // A/B testing
+  const int pv16 = lmv_config().attn_pv16;      // A/B testing
   if (a.Lk == 196 && pv16) hipLaunchKernelGGL((mfma_fwd_kernel<14, 196, true>), grid, block, 0, st, a, per);      // stage-3 self-attention at 224^2
   else if (a.Lk == 16 && pv16) hipLaunchKernelGGL((mfma_fwd_kernel<2, 16, true>), grid, block, 0, st, a, per);    // 16 meta-token keys (DCA x direction, meta self-attention)
   else if (a.Lk == 49 && pv16) hipLaunchKernelGGL((mfma_fwd_kernel<4, 49, true>), grid, block, 0, st, a, per);    // stage 4
@@ -1369,8 +1369,7 @@ int lmv_attn_mfma_fwd(const AttnArgs& a, hipStream_t st) {
 // acc: lmv_attn_mfma_bwd_acc_bytes() of fp32 scratch (only touched when the query range is split)
 int lmv_attn_mfma_bwd(const AttnArgs& a, float* delta, float* acc, hipStream_t st) {
   const int per = qt_per_block_for(a), nqt = (a.Lq + 15) / 16, nkt = nkt_for(a.Lk);
-  static const bool fuse_dq = [] { const char* e = getenv("LMV_ATTN_FUSE_DQ"); return e ? atoi(e) != 0 : true; }();      // A/B testing
-  static const bool fused_bwd = [] { const char* e = getenv("LMV_ATTN_FUSED_BWD"); return e ? atoi(e) != 0 : true; }();  // A/B testing
+  const bool fuse_dq = lmv_config().attn_fuse_dq != 0, fused_bwd = lmv_config().attn_fused_bwd != 0;      // A/B testing
   if (fused_bwd && nkt >= 4 && a.Lq > 16 && a.Lq <= nkt * 16) {
     // one workgroup per (b, h): dQ, dK and dV from ONE pass over the scores
     dim3 grid(1, a.H, a.B), block(256);
@@ -1428,7 +1427,7 @@ int lmv_attn_mfma_bwd(const AttnArgs& a, float* delta, float* acc, hipStream_t s
 // Pair launches (two independent problems with the same B and H): merged when problem 1 is the stage-3 / stage-4 image-token
 // self-attention (196 / 49 keys, Lq == Lk) and problem 2 the 16 x 16 meta-token one; 1 = merged, 0 = not applicable
 int lmv_attn_mfma_fwd_pair(const AttnArgs& a1, const AttnArgs& a2, hipStream_t st) {
-  static const int on = [] { const char* e = getenv("LMV_ATTN_PAIR"); return e ? atoi(e) : 1; }();      // A/B testing
+  const int on = lmv_config().attn_pair;      // A/B testing
   if (!on || a1.B != a2.B || a1.H != a2.H || a2.Lk != 16 || a2.Lq != 16 || a1.Lq != a1.Lk || (a1.Lk != 196 && a1.Lk != 49)) return 0;
   const int per1 = qt_per_block_for(a1), nqt1 = (a1.Lq + 15) / 16, nblk1 = (nqt1 + per1 - 1) / per1;
   dim3 grid((nblk1 + 1) * a1.H * a1.B), block(256);
@@ -1438,7 +1437,7 @@ int lmv_attn_mfma_fwd_pair(const AttnArgs& a1, const AttnArgs& a2, hipStream_t s
 }
 
 int lmv_attn_mfma_bwd_pair(const AttnArgs& a1, const AttnArgs& a2, hipStream_t st) {
-  static const int on = [] { const char* e = getenv("LMV_ATTN_PAIR"); return e ? atoi(e) : 1; }();
+  const int on = lmv_config().attn_pair;
   if (!on || a1.B != a2.B || a1.H != a2.H || a2.Lk != 16 || a2.Lq != 16 || a1.Lq != a1.Lk || (a1.Lk != 196 && a1.Lk != 49)) return 0;
   dim3 grid(2 * a1.H * a1.B), block(256);
   if (a1.Lk == 196) hipLaunchKernelGGL((mfma_bwd_pair_kernel<14, 196>), grid, block, 0, st, a1, a2);

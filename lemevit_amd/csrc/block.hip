@@ -163,22 +163,48 @@ struct Side {
   }
 };
 
-int side_events(hipEvent_t* fork, hipEvent_t* join) {
-  static std::mutex mu;
-  static hipEvent_t ev[64][2];
-  static bool have[64] = {};
-  int dev = 0;
-  (void)hipGetDevice(&dev);
-  dev &= 63;
-  std::lock_guard<std::mutex> lk(mu);
-  if (!have[dev]) {
-    if (hipEventCreateWithFlags(&ev[dev][0], hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&ev[dev][1], hipEventDisableTiming) != hipSuccess)
-      LMV_FAIL(LMV_ERR_LAUNCH, "block_bwd: cannot create stream events");
-    have[dev] = true;
+// Fork / join events of ONE lmv_block_bwd call.  They come from a per-device free list and are owned exclusively by the call until it
+// returns, so two host threads (autograd's per-device backward threads under DDP, or two caller threads on two streams) can run
+// lmv_block_bwd on one device at the same time: with ONE shared pair, thread A's hipStreamWaitEvent(side, fork) could pick up the
+// hipEventRecord(fork, ...) thread B had just made on ITS stream.  An event that is handed back may still be referenced by a wait that has
+// not executed yet: a stream wait binds to the record that was current when the wait was ENQUEUED, so re-recording it later is safe.
+struct EventPool {
+  std::mutex mu;
+  hipEvent_t free_ev[64][32];
+  int nfree[64] = {};
+  int take(hipEvent_t* fork, hipEvent_t* join) {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    dev &= 63;
+    hipEvent_t out[2];
+    int got = 0;
+    {
+      std::lock_guard<std::mutex> lk(mu);
+      while (got < 2 && nfree[dev] > 0) out[got++] = free_ev[dev][--nfree[dev]];
+    }
+    for (; got < 2; ++got)
+      if (hipEventCreateWithFlags(&out[got], hipEventDisableTiming) != hipSuccess) {
+        give(dev, out, got);
+        LMV_FAIL(LMV_ERR_LAUNCH, "block_bwd: cannot create stream events");
+      }
+    *fork = out[0]; *join = out[1];
+    return LMV_OK;
   }
-  *fork = ev[dev][0]; *join = ev[dev][1];
-  return LMV_OK;
-}
+  void give(int dev, const hipEvent_t* ev, int n) {
+    std::lock_guard<std::mutex> lk(mu);
+    for (int i = 0; i < n; ++i) {
+      if (nfree[dev] < 32) free_ev[dev][nfree[dev]++] = ev[i];
+      else (void)hipEventDestroy(ev[i]);
+    }
+  }
+  void give(hipEvent_t fork, hipEvent_t join) {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    const hipEvent_t ev[2] = {fork, join};
+    give(dev & 63, ev, 2);
+  }
+};
+EventPool& event_pool() { static EventPool p; return p; }
 
 int dw(Side& sd, const lmv_linear_problem* p, int np, int N, int K, int dtype) {
   const size_t need = lmv_linear_dw_workspace_bytes(p, np, N, K, dtype);
@@ -403,7 +429,7 @@ extern "C" int lmv_block_bwd(const lmv_block_desc* d, const void* x, const void*
   layout_bwd(D, s, &b);
   if (s.off > scratch_bytes) LMV_FAIL(LMV_ERR_WORKSPACE, "block_bwd: scratch %zu < %zu bytes", scratch_bytes, s.off);
   Side sd{(hipStream_t)stream, (hipStream_t)side_stream, nullptr, nullptr, false, b.ws_side, b.ws_side_bytes};
-  if (side_stream) LMV_TRY(side_events(&sd.fork, &sd.join));
+  if (side_stream) LMV_TRY(event_pool().take(&sd.fork, &sd.join));
   hipStream_t st = sd.main;
   const int C = D.C, N = D.N, M = D.M;
   lmv_linear_problem p[2];
@@ -483,5 +509,6 @@ extern "C" int lmv_block_bwd(const lmv_block_desc* d, const void* x, const void*
   };
   rc = body();
   if (rc || !(d->flags & LMV_BLOCK_NO_JOIN)) sd.finish();      // on errors always: never leave the main stream un-joined
+  if (side_stream) event_pool().give(sd.fork, sd.join);
   return rc;
 }

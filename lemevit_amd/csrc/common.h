@@ -29,6 +29,26 @@ void lmv_set_error(const char* fmt, ...);
 // mode 1 (dwconv, partial index i = tap * C + c with na = C): tap < 9 -> out_a[c * 9 + tap], tap == 9 -> out_b[c].
 int lmv_launch_partial_reduce(const float* partial, int nrows, int width, float* out_a, int na, float* out_b, int mode, hipStream_t st);
 
+// ---- A/B switches ------------------------------------------------------------------------------
+// Every tuning switch of the library lives here.  The environment (LMV_*) is read ONCE, when the library is loaded -- never on a launch
+// path -- and lmv_config_set(key, value) changes a switch at run time (tests and the tools/ sweeps use it).  Defaults = measured best.
+struct LmvConfig {
+  int gemm_bk;            // LMV_GEMM_BK            0 = auto, 32 / 64 force the k-tile depth of the bf16 GEMMs
+  int gemm_bk32_tiles;    // LMV_GEMM_BK32_TILES    fwd / dX launches with at least this many 128 x 128 tiles use 32-deep k-tiles (4 workgroups per CU)
+  int dw_bk;              // LMV_DW_BK              k-tile depth of the weight-gradient GEMM (32)
+  int dw_target_blocks;   // LMV_DW_TARGET_BLOCKS   0 = auto: workgroups one generation of a weight-gradient launch should have
+  int gemm_no_dma;        // LMV_GEMM_NO_DMA        1: register-staged operand path instead of LDS-DMA
+  int gemm_w8;            // LMV_GEMM_W8            1: 8-wave 64-deep forward kernel; 2: also for every dX launch; 0: off
+  int gemm_cumap;         // LMV_GEMM_CUMAP         1: CU-aware tile order
+  int gemm_nst, gemm_nst_dw;   // LMV_GEMM_NST / _DW ring depth of the 32-deep loop (2 / 3)
+  int gemm_rs;            // LMV_GEMM_RS            1: register-stationary kernels (rsgemm.hip) where they measured faster; 0: off; 2: wherever they apply
+  int dwconv_v;           // LMV_DWCONV_V           0 = auto: rows per thread of the depth-wise convolution kernels
+  int mlp_tm;             // LMV_MLP_TM             0 = auto: token rows per workgroup of the fused MLP kernel (64 / 128)
+  int attn_pv16, attn_fuse_dq, attn_fused_bwd, attn_pair;      // LMV_ATTN_*
+  int ln_bwd_blocks, ln_bwd_minrows;                           // LMV_LN_BWD_*
+};
+LmvConfig& lmv_config();
+
 static inline bool lmv_aligned16(const void* p) { return (((uintptr_t)p) & 15u) == 0; }
 
 // ---- bf16 <-> f32 ---------------------------------------------------------------------------

@@ -230,9 +230,8 @@ inline Geo make_geo(int B, int H, int W, int C, int dtype, int R, bool wgrad = f
   g.B = B; g.H = H; g.W = W; g.C = C;
   g.nstrips = (W + R - 1) / R;
   const int nch = C / (dtype == LMV_BF16 ? 8 : 4);
-  const char* e = getenv("LMV_DWCONV_V");
-  if (e && atoi(e) > 0) {
-    g.V = atoi(e);
+  if (lmv_config().dwconv_v > 0) {
+    g.V = lmv_config().dwconv_v;
   } else if (wgrad) {
     g.V = H < 14 ? H : 14;      // weight gradient: long strips (more accumulation per thread, fewer partial rows) win on every stage
   } else {

@@ -400,8 +400,7 @@ int launch_mlp(const MlpArgs& g, hipStream_t st) {
 // rows per workgroup: 64 (two workgroups per CU) where its LDS image fits 80 KB, else 128 (LMV_MLP_TM = 64 / 128 forces one: A/B runs)
 template <int C>
 int launch_mlp_c(const MlpArgs& g, hipStream_t st) {
-  const char* e = getenv("LMV_MLP_TM");      // re-read per call: the parity tests run both tile heights in one process
-  const int force = e ? atoi(e) : 0;
+  const int force = lmv_config().mlp_tm;     // (the parity tests run both tile heights in one process through lmv_config_set)
   constexpr bool fits64 = C <= 192;
   if constexpr (fits64) {
     if (force != 128) return launch_mlp<C, 64>(g, st);
@@ -422,6 +421,26 @@ extern "C" int lmv_ln_fold(const float* w, const float* bias, const float* gamma
   if (dtype == LMV_BF16) hipLaunchKernelGGL(ln_fold_kernel<bf16_t>, grid, block, 0, st, w, bias, gamma, beta, N, K, (bf16_t*)wf, colsum, bf);
   else hipLaunchKernelGGL(ln_fold_kernel<float>, grid, block, 0, st, w, bias, gamma, beta, N, K, (float*)wf, colsum, bf);
   LMV_CHECK_LAUNCH("ln_fold");
+  return LMV_OK;
+}
+
+// Test hook: the activation the fused MLP kernel applies to its hidden values (gelu_poly2, common.h), on its own -- so that the bound on
+// |gelu_poly2(u) - GELU_erf(u)| can be tested without a residual / second GEMM hiding it (tests/test_fused_gpu.py::test_gelu_poly_bound).
+namespace {
+__global__ __launch_bounds__(256) void gelu_poly_eval_kernel(const float* __restrict__ x, float* __restrict__ y, int64_t n) {
+  const int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 2;
+  if (i + 1 < n) {
+    const f32x2_t v = gelu_poly2(f32x2_t{x[i], x[i + 1]});
+    y[i] = v[0]; y[i + 1] = v[1];
+  } else if (i < n) {
+    y[i] = gelu_poly2(f32x2_t{x[i], 0.f})[0];
+  }
+}
+}  // namespace
+extern "C" int lmv_gelu_poly_eval(const float* x, float* y, int64_t n, void* stream) {
+  if (!x || !y || n <= 0) LMV_FAIL(LMV_ERR_SHAPE, "gelu_poly_eval: null operand or n <= 0");
+  hipLaunchKernelGGL(gelu_poly_eval_kernel, dim3((unsigned)((n + 511) / 512)), dim3(256), 0, (hipStream_t)stream, x, y, n);
+  LMV_CHECK_LAUNCH("gelu_poly_eval");
   return LMV_OK;
 }
 

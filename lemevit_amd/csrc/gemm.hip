@@ -272,189 +272,6 @@ __global__ __launch_bounds__(CF::NTHR, MINW) void gemm_kernel(const GemmArgs g) 
   }
 }
 
-// ---- "BigK" kernel: long reductions (fc2 forward, dX of qkv / fc1, every weight gradient) ----------------------------------
-// Round-2 probes (tools/native/panel_probe.hip, panel2_probe.hip): with one barrier -> ds_read -> MFMA sequence per k-tile all
-// waves of a workgroup wait out the LDS latency together, and at 64 flop per streamed byte the L2 -> LDS stream paces the loop.
-// Here a workgroup of 8 waves owns a 128 x (NSB * 128) output tile (accumulators: 64 x NSB * 32 per wave), a k-step streams ONE
-// A slot and NSB B slots of 16 KB (96 flop per streamed byte at NSB = 3), two k-steps live in LDS, and the MFMA fragments are
-// double-buffered in registers per HALF k-step: while the 4 * NSB * 2 MFMAs of one half issue, the fragments of the next half
-// (or of the next k-step's first half) stream in behind them.  One raw s_barrier per k-step; the LDS-DMA of k-step s + 2 is
-// issued in the middle of k-step s and has a whole k-step to land.  Slot images / swizzles are the ones of gemm_kernel
-// (panel_dma / frag_bf16), so the same three contractions are covered: normal x normal, normal x TR (dX), TR x TR (dW).
-template <bool ATR, bool BTR, bool SPLITK, int NSB>
-__global__ __launch_bounds__(512, 2) void bigk_kernel(const GemmArgs g) {
-  constexpr int BK = 64, SLOTB = PANEL * BK * 2, STEP = (1 + NSB) * SLOTB, BN = NSB * 128, NB = NSB * 2;
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];     // [2 k-steps][A slot | NSB B slots]; reused by the epilogue
-  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave >> 2, wn = wave & 3;
-  // XCD-contiguous logical order (hardware places block b on XCD b % 8): the tiles of one m-tile row -- and, for dW, the tiles of one
-  // k-split, which all read the same token rows -- share an L2.  Speed only; any placement is correct.
-  int bid, split = 0;
-  {
-    const int T_ = gridDim.x, xcd = blockIdx.x & 7, q = T_ >> 3, r = T_ & 7;
-    const int L = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (int)(blockIdx.x >> 3);
-    if constexpr (SPLITK) { split = L / g.ntiles; bid = L - split * g.ntiles; } else { bid = L; }
-  }
-  const int pi = (g.nprob > 1 && !g.concat && bid >= g.p[1].tile_begin) ? 1 : 0;
-  const Problem& P = g.p[pi];
-  bid -= P.tile_begin;
-  const int tm = bid / g.tiles_n, tn = bid % g.tiles_n;
-  const int m0 = tm * 128, n0 = tn * BN;
-  const int M = P.M, N = g.N;
-  const int kt0 = P.Kred / BK;
-  const int kt_total = kt0 + ((SPLITK && g.concat) ? g.p[1].Kred / BK : 0);
-  const int kt_beg = split * g.kt_per_split;
-  const int kt_end = min(kt_total, kt_beg + g.kt_per_split);
-  if (kt_beg >= kt_end) return;
-  auto issue = [&](unsigned char* buf, int kt) {
-    const Problem& Q = (SPLITK && kt >= kt0) ? g.p[1] : P;
-    const bf16_t* A16 = reinterpret_cast<const bf16_t*>(Q.a);
-    const bf16_t* B16 = reinterpret_cast<const bf16_t*>(Q.b);
-    const int k0 = ((SPLITK && kt >= kt0) ? kt - kt0 : kt) * BK;
-    panel_dma<ATR, BK, 8>(buf, A16, g.lda, M, m0, k0, lane, wave);
-#pragma unroll
-    for (int j = 0; j < NSB; ++j) panel_dma<BTR, BK, 8>(buf + (1 + j) * SLOTB, B16, g.ldb, N, n0 + j * 128, k0, lane, wave);
-  };
-  bf16x8_t fa0[4], fb0[NB], fa1[4], fb1[NB];        // fragments of the half k-step (hh = 0 / 1) in flight
-  auto read_half = [&](bf16x8_t (&fa)[4], bf16x8_t (&fb)[NB], const unsigned char* buf, int hh) {
-#pragma unroll
-    for (int j = 0; j < NSB; ++j)
-#pragma unroll
-      for (int t = 0; t < 2; ++t) fb[j * 2 + t] = frag_bf16<BTR, BK>(buf + (1 + j) * SLOTB, wn * 32 + t * 16, lane, hh);
-#pragma unroll
-    for (int t = 0; t < 4; ++t) fa[t] = frag_bf16<ATR, BK>(buf, wm * 64 + t * 16, lane, hh);
-  };
-  f32x4_t acc[4][NB], accb = f32x4_t{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < NB; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-  const bool do_bsum = SPLITK && (P.bias_grad != nullptr) && tn == 0;      // workgroup-uniform; wave wn sums A tile wn of its half
-  auto mma_half = [&](const bf16x8_t (&fa)[4], const bf16x8_t (&fb)[NB]) {
-#pragma unroll
-    for (int ti = 0; ti < 4; ++ti)
-#pragma unroll
-      for (int tj = 0; tj < NB; ++tj) acc[ti][tj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[tj], fa[ti], acc[ti][tj], 0, 0, 0);
-    if constexpr (SPLITK) {
-      if (do_bsum) {          // column sums of the A tile = A^T * ones, on the matrix pipe
-        typedef __attribute__((ext_vector_type(8))) unsigned short u16x8_t;
-        const u16x8_t o16 = {0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80};
-        const bf16x8_t sel = wn == 0 ? fa[0] : (wn == 1 ? fa[1] : (wn == 2 ? fa[2] : fa[3]));
-        accb = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, o16), sel, accb, 0, 0, 0);
-      }
-    }
-  };
-
-  issue(smem, kt_beg);
-  if (kt_beg + 1 < kt_end) {
-    issue(smem + STEP, kt_beg + 1);
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (1 + NSB)) : "memory");       // the first k-step has landed (this wave's pieces) ...
-  } else {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  }
-  __builtin_amdgcn_s_barrier();                                                 // ... and everybody else's
-  asm volatile("" ::: "memory");
-  int cur = 0;
-  read_half(fa0, fb0, smem, 0);
-  for (int kt = kt_beg; kt < kt_end; ++kt) {
-    unsigned char* buf = smem + cur * STEP;
-    read_half(fa1, fb1, buf, 1);
-    mma_half(fa0, fb0);
-    // every fragment of this k-step is in registers; the next k-step has landed for this wave -- and, past the barrier, for all
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-    if (kt + 2 < kt_end) issue(buf, kt + 2);                                    // into the buffer just vacated
-    cur ^= 1;
-    if (kt + 1 < kt_end) read_half(fa0, fb0, smem + cur * STEP, 0);
-    mma_half(fa1, fb1);
-  }
-
-  if constexpr (SPLITK) {
-    // partial tile -> this split's slab (plain stores; summed by splitk_reduce_kernel)
-    float* slab = g.ws + (int64_t)(g.slab_base[pi] + split) * g.slab_stride;
-#pragma unroll
-    for (int ti = 0; ti < 4; ++ti) {
-      const int m = m0 + wm * 64 + ti * 16 + (lane & 15);
-      if (m >= M) continue;
-#pragma unroll
-      for (int tj = 0; tj < NB; ++tj) {
-        const int n = n0 + (tj >> 1) * 128 + wn * 32 + (tj & 1) * 16 + (lane >> 4) * 4;
-        if (n >= N) continue;
-        *reinterpret_cast<float4*>(slab + (int64_t)m * g.ldc + n) = make_float4(acc[ti][tj][0], acc[ti][tj][1], acc[ti][tj][2], acc[ti][tj][3]);
-      }
-    }
-    if (do_bsum && lane < 16) {
-      const int m = m0 + wm * 64 + wn * 16 + lane;
-      if (m < M) slab[(int64_t)M * g.ldc + m] = accb[0];
-    }
-  } else {
-    // coalesced epilogue: every wave transposes its 64 x 32 strips through a private LDS region (the ring is dead): fp32 in,
-    // whole 16-byte bf16 row pieces out, with bias / GELU / GELU' x aux / DropPath scale / residual fused as in Epi::store
-    __syncthreads();
-    constexpr int REGION = 2 * STEP / 8;
-    static_assert(REGION >= 64 * 32 * 4, "per-wave epilogue region too small");
-    float* sT = reinterpret_cast<float*>(smem + wave * REGION);
-    bf16_t* outp = reinterpret_cast<bf16_t*>(P.out);
-    bf16_t* prep = reinterpret_cast<bf16_t*>(P.out_pre);
-    const int act = g.act & 0xff;
-#pragma unroll
-    for (int j = 0; j < NSB; ++j) {
-      const int nw0 = n0 + j * 128 + wn * 32;
-      __builtin_amdgcn_wave_barrier();
-#pragma unroll
-      for (int tj = 0; tj < 2; ++tj) {
-        const int n = nw0 + tj * 16 + (lane >> 4) * 4;
-        float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (P.bias && n < N) b4 = *reinterpret_cast<const float4*>(P.bias + n);
-#pragma unroll
-        for (int ti = 0; ti < 4; ++ti) {
-          const f32x4_t a = acc[ti][j * 2 + tj];
-          const int r = ti * 16 + (lane & 15), c4 = tj * 4 + (lane >> 4);
-          *reinterpret_cast<float4*>(sT + r * 32 + ((c4 ^ (r & 7)) << 2)) = make_float4(a[0] + b4.x, a[1] + b4.y, a[2] + b4.z, a[3] + b4.w);
-        }
-      }
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_wave_barrier();
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int c = lane + i * 64, r = c >> 2, oc = c & 3;
-        const int m = m0 + wm * 64 + r, n = nw0 + oc * 8;
-        if (m >= M || n >= N) continue;
-        float v[8];
-#pragma unroll
-        for (int e = 0; e < 2; ++e) {
-          const float4 t = *reinterpret_cast<const float4*>(sT + r * 32 + (((oc * 2 + e) ^ (r & 7)) << 2));
-          v[e * 4] = t.x; v[e * 4 + 1] = t.y; v[e * 4 + 2] = t.z; v[e * 4 + 3] = t.w;
-        }
-        const int64_t o = (int64_t)m * g.ldc + n;
-        if (prep) *reinterpret_cast<uint4*>(prep + o) = f_to_chunk<bf16_t>(v);
-        if (act == LMV_ACT_GELU) {
-#pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] = act_gelu<bf16_t>(v[e]);
-        } else if (act == LMV_ACT_GELU_GRAD) {
-          float u[8];
-          chunk_to_f<bf16_t>(*reinterpret_cast<const uint4*>(reinterpret_cast<const bf16_t*>(P.aux) + o), u);
-#pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] *= act_gelu_grad<bf16_t>(u[e]);
-        }
-        if (P.row_scale) {
-          const float rs = P.row_scale[m / P.rps];
-#pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] *= rs;
-        }
-        if (P.res) {
-          float r8[8];
-          chunk_to_f<bf16_t>(*reinterpret_cast<const uint4*>(reinterpret_cast<const bf16_t*>(P.res) + o), r8);
-#pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] += r8[e];
-        }
-        *reinterpret_cast<uint4*>(outp + o) = f_to_chunk<bf16_t>(v);
-      }
-    }
-  }
-}
-
 // out[i] += sum_s ws[s][i]  (i < nw: dW; nw <= i < nw + nb: db)
 // A block covers 256 / SL float4 elements x SL slab lanes: lane l sums slabs l, l + SL, ... in order, lane 0 then adds
 // the SL lane sums in order (fixed summation tree: run-to-run reproducible).  SL > 1 keeps small dW matrices with
@@ -535,9 +352,9 @@ static int reduce_lanes(int64_t n4, int nslabs) {      // slab lanes: enough blo
 }
 
 enum Mode { MODE_FWD = 0, MODE_DX = 1, MODE_DW = 2 };
-enum Tile { TILE_128 = 0, TILE_256x128 = 1, TILE_256 = 2, TILE_128W8 = 3 };
+enum Tile { TILE_128 = 0, TILE_128W8 = 3 };
 
-struct Plan { GemmArgs g; int total, splits, bk, tile, dma, nsplit[2]; size_t ws_bytes; int bigk; /* 0, or B slots (2 / 3) of the BigK tile */ };
+struct Plan { GemmArgs g; int total, splits, bk, tile, dma, nsplit[2]; size_t ws_bytes; };
 
 int make_plan(const lmv_linear_problem* p, int nproblems, int N, int K, int act, int dtype, Mode mode, Plan* pl) {
   if (nproblems < 1 || nproblems > 2) LMV_FAIL(LMV_ERR_SHAPE, "linear: nproblems must be 1 or 2 (got %d)", nproblems);
@@ -574,53 +391,34 @@ int make_plan(const lmv_linear_problem* p, int nproblems, int N, int K, int act,
     if (P.Kred % 32) all32 = false;
   }
   const bool bf = dtype == LMV_BF16;
+  const LmvConfig& cf = lmv_config();      // A/B switches: read from the environment ONCE at library load (lmv_config_set changes them at run time)
   // bf16: 64-deep k-tiles unless the reduction is a short non-multiple of 64 (C = 96 layers); fp32: 32-deep
-  static const int force_bk = [] { const char* e = getenv("LMV_GEMM_BK"); return e ? atoi(e) : 0; }();   // A/B testing
   int bk = (bf && (mode == MODE_DW || all64 || min_kred >= 512)) ? 64 : 32;
   // Occupancy beats k-tile depth whenever the launch has enough tiles to put 4 workgroups on every CU: half of a
   // workgroup's life is launch + first-load latency + epilogue + store drain, which only OTHER resident workgroups
   // hide.  The 32-deep variant needs 32 KB of LDS and <= 128 registers (4 per CU) against 64 KB / 160 (2 per CU).
   int64_t tiles128 = 0;
   for (int i = 0; i < nproblems; ++i) tiles128 += (int64_t)((g.p[i].M + 127) / 128) * ((out_cols + 127) / 128);
-  if (bf && all32 && mode != MODE_DW) {
-    static const int min_tiles = [] { const char* e = getenv("LMV_GEMM_BK32_TILES"); return e ? atoi(e) : 512; }();
-    if (tiles128 >= min_tiles) bk = 32;
-  }
+  if (bf && all32 && mode != MODE_DW && tiles128 >= cf.gemm_bk32_tiles) bk = 32;
   // dW: 32-deep as well (3 workgroups per CU; tools/dw_sweep.py: best or within 5 % of best on every layer shape)
-  const int dw_bk = [] { const char* e = getenv("LMV_DW_BK"); return e ? atoi(e) : 32; }();   // A/B testing (re-read per call)
-  if (bf && all32 && mode == MODE_DW && dw_bk == 32) bk = 32;
-  if (bf && force_bk == 32 && all32) bk = 32;
-  if (bf && force_bk == 64 && all64) bk = 64;
-  static const bool no_dma = getenv("LMV_GEMM_NO_DMA") != nullptr;     // A/B testing
+  if (bf && all32 && mode == MODE_DW && cf.dw_bk == 32) bk = 32;
+  if (bf && cf.gemm_bk == 32 && all32) bk = 32;
+  if (bf && cf.gemm_bk == 64 && all64) bk = 64;
+  const bool no_dma = cf.gemm_no_dma != 0;
   const bool dma = bf && !no_dma && (bk == 64 ? all64 : all32);
-  // Tile choice.  Measured on the LeMeViT shapes (K = 96..2048, tools/bench_kernels.py): 128x128 beats 256x128 and
-  // 256x256 on every shape of the model -- at 64-deep k-tiles because the large tiles leave one workgroup per CU, and at
-  // 32-deep k-tiles / 4 waves per SIMD (256x128 only) by a few per cent -- so it is the default; LMV_GEMM_TILE=-1 selects
-  // the larger tiles automatically for 64-deep problems (they win for long K), 1 / 2 force them.
-  static const int force_tile = [] { const char* e = getenv("LMV_GEMM_TILE"); return e ? atoi(e) : 0; }();
+  // Tile: 128 x 128 everywhere.  (256 x 128 / 256 x 256 tiles and the 128 x 384 "BigK" tile were measured slower on every layer shape of
+  // the model in rounds 1 - 2 -- tile quantisation on 636 / 2544-tile launches, one workgroup per CU -- and left the library in round 3;
+  // they live on the branch r02-gemm-experiments.)
   int tile = TILE_128;
   // 64-deep k-tiles at FOUR waves per SIMD: the 128x128 tile on 8 waves of 32x64 (2 workgroups of 64 KB per CU).  Every operand
   // row is then a whole 128-byte line per k-tile -- the 32-deep loop asks L2 for half lines, and L2 (82 % busy on the stage-3 fc2
   // shape, tools/pmc_mem.sh) serves a half line in the same slot as a whole one -- at the price of 1.5x the LDS fragment reads.
   // Measured (tools/bench_kernels.py): forward 3-12 % faster on every K % 64 == 0 shape; dX faster only on the launches that
   // cannot fill 4 workgroups per CU (stage 4), slower elsewhere; dW much slower.
-  static const int w8_mode = [] { const char* e = getenv("LMV_GEMM_W8"); return e ? atoi(e) : 1; }();
-  const bool w8 = bf && !no_dma && all64 && w8_mode && force_bk == 0 && force_tile == 0 &&
-                  (mode == MODE_FWD || (mode == MODE_DX && (tiles128 < 512 || w8_mode == 2)));
+  const bool w8 = bf && !no_dma && all64 && cf.gemm_w8 && cf.gemm_bk == 0 &&
+                  (mode == MODE_FWD || (mode == MODE_DX && (tiles128 < 512 || cf.gemm_w8 == 2)));
   if (w8) { bk = 64; tile = TILE_128W8; }
-  if (!w8 && dma && (bk == 64 || (force_tile == TILE_256x128 && mode != MODE_DW))) {
-    if (force_tile < 0) {
-      auto tiles_of = [&](int bm, int bn) { int64_t t = 0; for (int i = 0; i < nproblems; ++i) t += (int64_t)((g.p[i].M + bm - 1) / bm) * ((out_cols + bn - 1) / bn); return t; };
-      const int64_t need = (mode == MODE_DW) ? 48 : 200;      // dW multiplies its grid by the k-splits
-      const bool fits256 = out_cols % 256 == 0 || out_cols >= 1024;      // <= 12 % padded columns
-      if (max_m >= 256 && fits256 && tiles_of(256, 256) >= need) tile = TILE_256;
-      else if (max_m >= 256 && tiles_of(256, 128) >= need) tile = TILE_256x128;
-    } else if (force_tile <= TILE_128W8) {
-      tile = force_tile;
-    }
-  }
-  if (tile == TILE_128W8 && bk != 64) tile = TILE_128;
-  const int bm = (tile == TILE_128 || tile == TILE_128W8) ? 128 : 256, bn = tile == TILE_256 ? 256 : 128;
+  const int bm = 128, bn = 128;
   g.tiles_n = (out_cols + bn - 1) / bn;
   // dW of two problems that accumulate into the same dW / db (x and c rows through shared weights): one reduction
   g.concat = mode == MODE_DW && nproblems == 2 && p[0].out == p[1].out && p[0].bias_grad == p[1].bias_grad;
@@ -642,7 +440,7 @@ int make_plan(const lmv_linear_problem* p, int nproblems, int N, int K, int act,
   if (mode == MODE_DW) {
     // Split the token reduction so that ONE generation of workgroups fills the chip: slots = CUs x resident workgroups
     // (3 at 32-deep k-tiles, 2 at 64-deep); each split ends in a plain store of its partial tile.
-    const int target = [] { const char* e = getenv("LMV_DW_TARGET_BLOCKS"); return e ? atoi(e) : 0; }();
+    const int target = cf.dw_target_blocks;
     int per_xcd = target > 0 ? target / 8 : 32 * (bk == 32 && dma ? 3 : 2);
     if (tile != TILE_128) per_xcd /= 2;      // 8-wave workgroups
     // The workgroups of one split run on one XCD (they share the token rows through its L2), so the split count is a
@@ -670,79 +468,11 @@ int make_plan(const lmv_linear_problem* p, int nproblems, int N, int K, int act,
     g.slab_stride = (int64_t)N * K + N;
     pl->ws_bytes = (size_t)slabs * g.slab_stride * sizeof(float);
   }
-  g.cumap = [] { const char* e = getenv("LMV_GEMM_CUMAP"); return e ? atoi(e) : 1; }();      // A/B testing
+  g.cumap = cf.gemm_cumap;
 #ifdef LMV_GEMM_TIMING
   { const char* e = getenv("LMV_GEMM_DBG_PTR"); g.dbg = e ? (unsigned long long*)strtoull(e, nullptr, 0) : nullptr; }
 #endif
   pl->total = total; pl->splits = splits; pl->bk = bk; pl->tile = tile; pl->dma = dma;
-  pl->bigk = 0;
-  // BigK tile (128 x 256 / 384, 8 waves, register-pipelined k-loop): long bf16 reductions whose output is at least 256 columns wide
-  // -- fc2 forward, dX of qkv / fc1, and the weight gradients -- on reductions that are whole 64-deep k-steps.
-  // Measured (round 2, tools/bench_kernels.py + bench.py): faster than the 128 x 128 kernels only on the fc2-forward shape of stage 3
-  // (40.7 vs 44.7 us), slower on dX and dW (one workgroup per CU: the 8-instruction LDS-DMA burst behind every barrier idles the matrix
-  // pipe, and 21 splits of fat slabs cost more than 24 of thin ones) -- the train step loses 1.1 ms with it.  Off unless LMV_GEMM_BIGK=1.
-  static const int bigk_mode = [] { const char* e = getenv("LMV_GEMM_BIGK"); return e ? atoi(e) : 0; }();
-  const int bigk_min_k = (mode == MODE_DW) ? 1024 : 768;
-  if (bigk_mode && (bigk_mode != 2 || mode == MODE_FWD) && bf && !no_dma && all64 && min_kred >= bigk_min_k && out_cols >= 256 && force_tile == 0 && force_bk == 0) {      // 2: forward launches only
-    // tile width: 384 when it tiles the output without more padding than 256 does
-    const int pad3 = (out_cols + 383) / 384 * 384 - out_cols, pad2 = (out_cols + 255) / 256 * 256 - out_cols;
-    const int nsb = (pad3 * 2 <= pad2 * 3 || out_cols <= 384) && out_cols > 256 ? 3 : 2;
-    const int bn2 = nsb * 128;
-    g.tiles_n = (out_cols + bn2 - 1) / bn2;
-    int tot = 0;
-    for (int i = 0; i < nproblems; ++i) {
-      Problem& P = g.p[i];
-      P.tiles_m = (P.M + 127) / 128;
-      P.tile_begin = (g.concat && i == 1) ? 0 : tot;
-      if (!(g.concat && i == 1)) tot += P.tiles_m * g.tiles_n;
-    }
-    int kt_max = 1, kt_sum = 0;
-    for (int i = 0; i < nproblems; ++i) { const int kt = g.p[i].Kred / 64; if (kt > kt_max) kt_max = kt; kt_sum += kt; }
-    if (g.concat) kt_max = kt_sum;
-    g.ntiles = tot; g.nsplits = 1; g.kt_per_split = kt_max;
-    pl->ws_bytes = 0; pl->nsplit[0] = pl->nsplit[1] = 1;
-    int nslabs_launch = 1;
-    if (mode == MODE_DW) {
-      // one workgroup per CU (128 KB of LDS): split the token reduction so that ONE generation of workgroups covers the chip, with
-      // at least 8 k-steps per split
-      const int target = [] { const char* e = getenv("LMV_DW_TARGET_BLOCKS"); return e ? atoi(e) : 256; }();
-      int sp = target / tot;
-      const int sp_max = kt_max / 8 > 0 ? kt_max / 8 : 1;
-      if (sp > sp_max) sp = sp_max;
-      if (sp < 1) sp = 1;
-      g.kt_per_split = (kt_max + sp - 1) / sp;
-      nslabs_launch = (kt_max + g.kt_per_split - 1) / g.kt_per_split;      // every launched split is non-empty
-      g.nsplits = nslabs_launch;
-      int slabs = 0;
-      for (int i = 0; i < nproblems; ++i) {
-        if (g.concat && i == 1) { pl->nsplit[1] = 0; g.slab_base[1] = 0; break; }
-        const int kt = g.concat ? kt_max : g.p[i].Kred / 64;
-        pl->nsplit[i] = (kt + g.kt_per_split - 1) / g.kt_per_split;
-        g.slab_base[i] = slabs;
-        slabs += pl->nsplit[i];
-      }
-      g.slab_stride = (int64_t)N * K + N;
-      pl->ws_bytes = (size_t)slabs * g.slab_stride * sizeof(float);
-    }
-    pl->total = tot; pl->splits = nslabs_launch; pl->bk = 64; pl->dma = 1; pl->bigk = nsb;
-  }
-  return LMV_OK;
-}
-
-template <bool ATR, bool BTR, bool SPLITK, int NSB>
-int launch_bigk(const GemmArgs& g, dim3 grid, hipStream_t st) {
-  constexpr int lds = 2 * (1 + NSB) * PANEL * 64 * 2;
-  auto kern = bigk_kernel<ATR, BTR, SPLITK, NSB>;
-  static std::atomic<unsigned long long> attr_done{0};      // > 64 KiB of dynamic LDS: opt in once per kernel and device (idempotent)
-  int dev = 0;
-  (void)hipGetDevice(&dev);
-  const unsigned long long bit = 1ull << (dev & 63);
-  if (!(attr_done.load(std::memory_order_acquire) & bit)) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
-      LMV_FAIL(LMV_ERR_LAUNCH, "linear: cannot reserve %d bytes of LDS", lds);
-    attr_done.fetch_or(bit, std::memory_order_release);
-  }
-  hipLaunchKernelGGL(kern, grid, dim3(512), lds, st, g);
   return LMV_OK;
 }
 
@@ -773,22 +503,12 @@ int launch_mode(const Plan& pl, dim3 grid, bool bf, hipStream_t st) {
                                   : launch_one<bf16_t, ATR, BTR, SPLITK, 32, false, C128>(g, grid, st);
   // 32-deep k-tiles: 32 KB of LDS and (capped by MINW) <= 128 / 168 registers: 4 (fwd, dX) or 3 (dW) workgroups per CU
   if (pl.bk == 32) {
-    if constexpr (!SPLITK) {
-      static const int nst_big = [] { const char* e = getenv("LMV_GEMM_NST"); return e ? atoi(e) : 2; }();
-      if (pl.tile == TILE_256x128) return nst_big == 3 ? launch_one<bf16_t, ATR, BTR, SPLITK, 32, true, C256x128, 4, 3>(g, grid, st)
-                                                       : launch_one<bf16_t, ATR, BTR, SPLITK, 32, true, C256x128, 4>(g, grid, st);
-    }
-    static const int nst_dw = [] { const char* e = getenv("LMV_GEMM_NST_DW"); return e ? atoi(e) : 3; }();      // dW: 3-deep ring (140 registers cap it at 3 workgroups per CU anyway); A/B testing
-    static const int nst = [] { const char* e = getenv("LMV_GEMM_NST"); return e ? atoi(e) : 2; }();
-    if ((SPLITK ? nst_dw : nst) == 3) return launch_one<bf16_t, ATR, BTR, SPLITK, 32, true, C128, 3, 3>(g, grid, st);      // 48 KB: 3 workgroups per CU
+    const LmvConfig& cf = lmv_config();
+    if ((SPLITK ? cf.gemm_nst_dw : cf.gemm_nst) == 3) return launch_one<bf16_t, ATR, BTR, SPLITK, 32, true, C128, 3, 3>(g, grid, st);      // 3-deep ring, 48 KB: 3 workgroups per CU (dW: 140 registers cap it at 3 anyway)
     return launch_one<bf16_t, ATR, BTR, SPLITK, 32, true, C128, SPLITK ? 3 : 4>(g, grid, st);
   }
-  switch (pl.tile) {
-    case TILE_256:     return launch_one<bf16_t, ATR, BTR, SPLITK, 64, true, C256>(g, grid, st);
-    case TILE_256x128: return launch_one<bf16_t, ATR, BTR, SPLITK, 64, true, C256x128>(g, grid, st);
-    case TILE_128W8:   return launch_one<bf16_t, ATR, BTR, SPLITK, 64, true, C128w8, 4>(g, grid, st);
-    default:           return launch_one<bf16_t, ATR, BTR, SPLITK, 64, true, C128>(g, grid, st);
-  }
+  if (pl.tile == TILE_128W8) return launch_one<bf16_t, ATR, BTR, SPLITK, 64, true, C128w8, 4>(g, grid, st);
+  return launch_one<bf16_t, ATR, BTR, SPLITK, 64, true, C128>(g, grid, st);
 }
 
 int launch(const lmv_linear_problem* p, int nproblems, int N, int K, int act, int dtype, void* stream, Mode mode, void* ws, size_t ws_bytes,
@@ -804,18 +524,10 @@ int launch(const lmv_linear_problem* p, int nproblems, int N, int K, int act, in
   dim3 grid(pl.total);
   hipStream_t st = (hipStream_t)stream;
   int rc;
-  if (pl.bigk) {
-    if (mode == MODE_DW) grid.x = pl.total * g.nsplits;
-    const bool w3 = pl.bigk == 3;
-    if (mode == MODE_FWD) rc = w3 ? launch_bigk<false, false, false, 3>(g, grid, st) : launch_bigk<false, false, false, 2>(g, grid, st);
-    else if (mode == MODE_DX) rc = w3 ? launch_bigk<false, true, false, 3>(g, grid, st) : launch_bigk<false, true, false, 2>(g, grid, st);
-    else rc = w3 ? launch_bigk<true, true, true, 3>(g, grid, st) : launch_bigk<true, true, true, 2>(g, grid, st);
-  } else {
-    if (mode == MODE_DW) grid.x = g.nsplits >= 8 ? pl.total * g.nsplits : 8 * ((pl.total + 8 / g.nsplits - 1) / (8 / g.nsplits));
-    if (mode == MODE_FWD) rc = launch_mode<false, false, false>(pl, grid, bf, st);
-    else if (mode == MODE_DX) rc = launch_mode<false, true, false>(pl, grid, bf, st);
-    else rc = launch_mode<true, true, true>(pl, grid, bf, st);
-  }
+  if (mode == MODE_DW) grid.x = g.nsplits >= 8 ? pl.total * g.nsplits : 8 * ((pl.total + 8 / g.nsplits - 1) / (8 / g.nsplits));
+  if (mode == MODE_FWD) rc = launch_mode<false, false, false>(pl, grid, bf, st);
+  else if (mode == MODE_DX) rc = launch_mode<false, true, false>(pl, grid, bf, st);
+  else rc = launch_mode<true, true, true>(pl, grid, bf, st);
   if (rc) return rc;
   LMV_CHECK_LAUNCH("linear");
   if (mode == MODE_DW) {
@@ -852,7 +564,6 @@ int launch_ln(const lmv_linear_problem* p, int nproblems, int N, int K, float ep
   for (int i = 0; i < nproblems; ++i)
     if (!p[i].aux || !p[i].bias) LMV_FAIL(LMV_ERR_SHAPE, "ln_linear_fwd: aux (colsum of the folded weight) and bias (folded bias) are required");
   if (!(eps > 0.f)) LMV_FAIL(LMV_ERR_SHAPE, "ln_linear_fwd: eps must be > 0");
-  if (pl.bigk || (pl.tile != TILE_128 && pl.tile != TILE_128W8)) LMV_FAIL(LMV_ERR_SHAPE, "ln_linear_fwd: only the 128 x 128 tiles carry the folded epilogue (unset LMV_GEMM_TILE / LMV_GEMM_BIGK)");
   GemmArgs& g = pl.g;
   g.ln_eps = eps;
   const dim3 grid(pl.total);

@@ -17,8 +17,6 @@ struct Cfg {
   static constexpr int PA = BM / PANEL, PB = BN / PANEL;      // operand panels per k-tile
 };
 using C128 = Cfg<2, 2, 4>;        // 128 x 128, 4 waves of 64 x 64
-using C256x128 = Cfg<4, 2, 4>;    // 256 x 128, 8 waves of 64 x 64
-using C256 = Cfg<2, 4, 8>;        // 256 x 256, 8 waves of 128 x 64
 using C128w8 = Cfg<4, 2, 2>;      // 128 x 128, 8 waves of 32 x 64 (64-deep k-tiles at 4 waves per SIMD)
 
 struct Problem {

@@ -14,6 +14,48 @@ void lmv_set_error(const char* fmt, ...) {
 extern "C" const char* lmv_last_error(void) { return g_err; }
 extern "C" int lmv_abi_version(void) { return LMV_ABI_VERSION; }
 
+// ---- A/B switches: the environment is read once, here ------------------------------------------------------------------------------------
+#include <stdlib.h>
+#include <string.h>
+namespace {
+int env_int(const char* name, int dflt) { const char* e = getenv(name); return e && *e ? atoi(e) : dflt; }
+struct ConfigKey { const char* key; const char* env; int LmvConfig::*field; int dflt; };
+const ConfigKey kConfigKeys[] = {
+    {"gemm_bk", "LMV_GEMM_BK", &LmvConfig::gemm_bk, 0}, {"gemm_bk32_tiles", "LMV_GEMM_BK32_TILES", &LmvConfig::gemm_bk32_tiles, 512},
+    {"dw_bk", "LMV_DW_BK", &LmvConfig::dw_bk, 32}, {"dw_target_blocks", "LMV_DW_TARGET_BLOCKS", &LmvConfig::dw_target_blocks, 0},
+    {"gemm_no_dma", "LMV_GEMM_NO_DMA", &LmvConfig::gemm_no_dma, 0}, {"gemm_w8", "LMV_GEMM_W8", &LmvConfig::gemm_w8, 1},
+    {"gemm_cumap", "LMV_GEMM_CUMAP", &LmvConfig::gemm_cumap, 1}, {"gemm_nst", "LMV_GEMM_NST", &LmvConfig::gemm_nst, 2},
+    {"gemm_nst_dw", "LMV_GEMM_NST_DW", &LmvConfig::gemm_nst_dw, 3}, {"gemm_rs", "LMV_GEMM_RS", &LmvConfig::gemm_rs, 1},
+    {"dwconv_v", "LMV_DWCONV_V", &LmvConfig::dwconv_v, 0},
+    {"mlp_tm", "LMV_MLP_TM", &LmvConfig::mlp_tm, 0}, {"attn_pv16", "LMV_ATTN_PV16", &LmvConfig::attn_pv16, 1},
+    {"attn_fuse_dq", "LMV_ATTN_FUSE_DQ", &LmvConfig::attn_fuse_dq, 1}, {"attn_fused_bwd", "LMV_ATTN_FUSED_BWD", &LmvConfig::attn_fused_bwd, 1},
+    {"attn_pair", "LMV_ATTN_PAIR", &LmvConfig::attn_pair, 1}, {"ln_bwd_blocks", "LMV_LN_BWD_BLOCKS", &LmvConfig::ln_bwd_blocks, 512},
+    {"ln_bwd_minrows", "LMV_LN_BWD_MINROWS", &LmvConfig::ln_bwd_minrows, 2},
+};
+LmvConfig config_from_env() {
+  LmvConfig c{};
+  for (const ConfigKey& k : kConfigKeys) c.*(k.field) = env_int(k.env, k.dflt);
+  if (c.gemm_no_dma == 0 && getenv("LMV_GEMM_NO_DMA")) c.gemm_no_dma = 1;      // (historically: set = on, whatever the value)
+  if (c.ln_bwd_blocks <= 0 || c.ln_bwd_blocks > 2048) c.ln_bwd_blocks = 512;
+  if (c.ln_bwd_minrows <= 0) c.ln_bwd_minrows = 2;
+  return c;
+}
+LmvConfig g_config = config_from_env();      // static initialisation = library load
+}  // namespace
+LmvConfig& lmv_config() { return g_config; }
+extern "C" int lmv_config_set(const char* key, int value) {
+  if (!key) LMV_FAIL(LMV_ERR_SHAPE, "config_set: null key");
+  for (const ConfigKey& k : kConfigKeys)
+    if (!strcmp(k.key, key)) { g_config.*(k.field) = value; return LMV_OK; }
+  LMV_FAIL(LMV_ERR_SHAPE, "config_set: unknown key '%s'", key);
+}
+extern "C" int lmv_config_get(const char* key, int* value) {
+  if (!key || !value) LMV_FAIL(LMV_ERR_SHAPE, "config_get: null argument");
+  for (const ConfigKey& k : kConfigKeys)
+    if (!strcmp(k.key, key)) { *value = g_config.*(k.field); return LMV_OK; }
+  LMV_FAIL(LMV_ERR_SHAPE, "config_get: unknown key '%s'", key);
+}
+
 namespace {
 
 constexpr int TPB = 256;
@@ -64,7 +106,7 @@ __global__ __launch_bounds__(TPB) void row_scale_kernel(const RowScaleArgs a) {
 // the result is ONE fp32 row per sample (the operand of the head GEMM).  Backward is the broadcast dx[b, l, :] = g[b, :] / L.
 template <typename T>
 __global__ __launch_bounds__(TPB) void token_mean2_fwd_kernel(const T* __restrict__ x, int L, const T* __restrict__ c, int M, int C, int B,
-                                                            T* __restrict__ out) {
+                                                            T* __restrict__ out, const float* __restrict__ xs = nullptr, const float* __restrict__ xb = nullptr) {
   constexpr int EPC = DT<T>::EPC;
   const int cpr = C / EPC;
   const unsigned i = blockIdx.x * TPB + threadIdx.x;
@@ -82,6 +124,10 @@ __global__ __launch_bounds__(TPB) void token_mean2_fwd_kernel(const T* __restric
   const float il = 1.f / (float)L;
 #pragma unroll
   for (int e = 0; e < EPC; ++e) acc[e] *= il;
+  if (xs) {      // eval-mode BatchNorm is affine per channel, so it commutes with the spatial mean: mean(BN(x)) = xs * mean(x) + xb
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) acc[e] = fmaf(acc[e], xs[ch * EPC + e], xb[ch * EPC + e]);
+  }
   if (c) {
     float a2[EPC];
 #pragma unroll
@@ -359,6 +405,21 @@ extern "C" int lmv_token_mean2_fwd(const void* x, int L, const void* c, int M, i
   if (dtype == LMV_BF16) hipLaunchKernelGGL((token_mean2_fwd_kernel<bf16_t>), dim3(grid), dim3(TPB), 0, st, (const bf16_t*)x, L, (const bf16_t*)c, M, C, B, (bf16_t*)out);
   else hipLaunchKernelGGL((token_mean2_fwd_kernel<float>), dim3(grid), dim3(TPB), 0, st, (const float*)x, L, (const float*)c, M, C, B, (float*)out);
   LMV_CHECK_LAUNCH("token_mean2_fwd");
+  return LMV_OK;
+}
+
+// out[b, :] = xscale * mean_l x[b, l, :] + xshift + mean_m c[b, m, :]: the inference tail with the final (eval-mode) BatchNorm folded into the pool
+extern "C" int lmv_token_mean2_affine_fwd(const void* x, int L, const void* c, int M, int C, int B, const float* xscale, const float* xshift, void* out, int dtype,
+                                          void* stream) {
+  if (B <= 0 || L <= 0 || C <= 0 || (c && M <= 0) || (C % 8)) LMV_FAIL(LMV_ERR_SHAPE, "token_mean2_affine_fwd: bad shape B=%d L=%d M=%d C=%d", B, L, M, C);
+  if (dtype != LMV_F32 && dtype != LMV_BF16) LMV_FAIL(LMV_ERR_DTYPE, "token_mean2_affine_fwd: unsupported dtype %d", dtype);
+  if (!x || !out || !xscale || !xshift || !lmv_aligned16(x) || !lmv_aligned16(c) || !lmv_aligned16(out)) LMV_FAIL(LMV_ERR_SHAPE, "token_mean2_affine_fwd: null or misaligned operand");
+  hipStream_t st = (hipStream_t)stream;
+  const int cpr = C / (dtype == LMV_BF16 ? 8 : 4);
+  const int grid = (int)(((int64_t)B * cpr + TPB - 1) / TPB);
+  if (dtype == LMV_BF16) hipLaunchKernelGGL((token_mean2_fwd_kernel<bf16_t>), dim3(grid), dim3(TPB), 0, st, (const bf16_t*)x, L, (const bf16_t*)c, M, C, B, (bf16_t*)out, xscale, xshift);
+  else hipLaunchKernelGGL((token_mean2_fwd_kernel<float>), dim3(grid), dim3(TPB), 0, st, (const float*)x, L, (const float*)c, M, C, B, (float*)out, xscale, xshift);
+  LMV_CHECK_LAUNCH("token_mean2_affine_fwd");
   return LMV_OK;
 }
 

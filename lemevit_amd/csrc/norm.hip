@@ -223,8 +223,7 @@ inline bool pick_geometry(int nch, int max_it, int* lpr_log2, int* nit) {
 
 inline int bwd_blocks(int64_t rows, int l2) {
   const int rpb = TPB >> l2;
-  static const int cap = [] { const char* e = getenv("LMV_LN_BWD_BLOCKS"); const int v = e ? atoi(e) : 0; return v > 0 && v <= 2048 ? v : 512; }();
-  static const int minrows = [] { const char* e = getenv("LMV_LN_BWD_MINROWS"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 2; }();
+  const int cap = lmv_config().ln_bwd_blocks, minrows = lmv_config().ln_bwd_minrows;
   int64_t blocks = (rows + minrows * rpb - 1) / (minrows * rpb);           // >= 2 rows per row group
   return (int)(blocks > cap ? cap : (blocks < 1 ? 1 : blocks));
 }

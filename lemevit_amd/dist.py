@@ -91,8 +91,9 @@ class FlatGradSync:
         opt.zero_grad(); loss.backward(); sync.finish(); opt.step()
     """
 
-    def __init__(self, flat_grad: torch.Tensor, chunk_bounds, rest_params, group=None, force: bool = False, compress: Optional[str] = None):
+    def __init__(self, flat_grad: torch.Tensor, chunk_bounds, rest_params, group=None, force: bool = False, compress: Optional[str] = None, opt=None):
         self.flat = flat_grad
+        self._opt = opt                                  # the FlatAdamW that owns `flat_grad` (None in unit tests that drive a bare buffer)
         self.bounds = list(chunk_bounds)                 # [(start, end)] element ranges of flat_grad, in forward order
         self.rest = [p for p in rest_params]
         self.group = group
@@ -135,6 +136,13 @@ class FlatGradSync:
             return
         if self._hold:
             raise RuntimeError("FlatGradSync.finish() inside no_sync(): run the last micro-batch outside the context")
+        if self._opt is not None:
+            # model.zero_grad() (set_to_none) un-binds p.grad from the flat buffer: the block backward then hands its gradients to autograd,
+            # no chunk callback fires, and the flat buffer would be exchanged stale.  Re-bind (copying stray gradients in) BEFORE sending.
+            self._opt.rebind_grads()
+        if self.flat.is_cuda:
+            from . import blocks as _blocks
+            _blocks.drain_deferred()                     # the weight-gradient side stream has written every slice that is about to travel
         for k in range(len(self.bounds) - 1, -1, -1):
             self.chunk_ready(k)
         grads = [p.grad for p in self.rest if p.grad is not None]
@@ -202,7 +210,7 @@ def attach_flat_grad_sync(model: torch.nn.Module, opt, nchunks: int = 4, group=N
     bounds = [(offs[c], offs[cuts[j + 1]] if j + 1 < len(cuts) else total) for j, c in enumerate(cuts)]
     block_params = {id(p) for _, p, _, _ in opt._slices}
     rest = [p for p in model.parameters() if p.requires_grad and id(p) not in block_params]
-    sync = FlatGradSync(opt._flat_g, bounds, rest, group, force, compress)
+    sync = FlatGradSync(opt._flat_g, bounds, rest, group, force, compress, opt=opt)
     mods = dict(blocks)
     for k, c in enumerate(cuts):                                       # chunk k is complete when its FIRST block has been differentiated
         for p in mods[order[c]].parameters():

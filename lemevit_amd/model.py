@@ -59,6 +59,8 @@ _train_pass = 0          # bumped by every training-mode forward pass: casts mad
 def new_training_pass() -> None:
     global _train_pass
     _train_pass += 1
+    from . import blocks as _blocks
+    _blocks.drain_deferred()        # a backward pass that raised leaves deferred side-stream joins (and its final callback) behind
 
 
 def compute_copy(p: Tensor, want: torch.dtype) -> Tensor:
@@ -103,7 +105,7 @@ def _ln_fold_cached(w: Tensor, b: Optional[Tensor], g: Tensor, be: Tensor, dtype
     with torch.no_grad():
         f32 = lambda t: None if t is None else t.detach().float().contiguous()
         F = ops.ln_fold(f32(w), f32(b), f32(g), f32(be), dtype)
-    _ln_fold_cache[key] = (weakref.ref(w), stamp, F)
+    _ln_fold_cache[key] = (weakref.ref(w, lambda _r, k=key: _ln_fold_cache.pop(k, None)), stamp, F)      # dropped with the parameter (a deleted model does not leak its folds)
     return F
 
 
@@ -126,7 +128,7 @@ def _conv1_matrix(weight: Tensor, dtype: torch.dtype) -> Tensor:
     with torch.no_grad():
         m = torch.zeros(weight.shape[0], 32, device=weight.device, dtype=dtype)
         m[:, :27] = weight.detach().reshape(weight.shape[0], 27)
-    _conv1_cache[key] = (weakref.ref(weight), stamp, m)
+    _conv1_cache[key] = (weakref.ref(weight, lambda _r, k=key: _conv1_cache.pop(k, None)), stamp, m)
     return m
 
 
@@ -179,7 +181,9 @@ def _conv_matrix(weight: Tensor, dtype: torch.dtype, KP: int) -> Tensor:
         Co, Ci = weight.shape[0], weight.shape[1]
         m = torch.zeros(Co, KP, device=weight.device, dtype=dtype)
         m[:, :9 * Ci] = weight.detach().permute(0, 2, 3, 1).reshape(Co, 9 * Ci)
-    _conv_cache[key] = (weakref.ref(weight), stamp, m)
+    # dropped with `weight`: the eval-mode conv + BatchNorm fold builds a NEW folded weight after every training pass, whose matrix would
+    # otherwise stay cached under the dead tensor's id (~5 MB per train -> eval cycle for Base)
+    _conv_cache[key] = (weakref.ref(weight, lambda _r, k=key: _conv_cache.pop(k, None)), stamp, m)
     return m
 
 
@@ -389,6 +393,42 @@ class _TailFn(torch.autograd.Function):
         (dc,) = ops.layernorm_bwd_multi([dcn], [cc], [st], g32, dg, dbeta, [None])
         ctx.saved = None
         return dx.to(xdt), dc.to(cdt), dg.to(gdt), dbeta.to(bdt), None, dW, db, None
+
+
+_tail_cache: dict = {}
+
+
+def _tail_infer(norm_c: nn.LayerNorm, bn: nn.BatchNorm2d, head: nn.Linear, xt: Tensor, c: Tensor, cd: torch.dtype) -> Tensor:
+    """No-grad classifier tail (models/lemevit.py:815-835): logits = head(mean(BN_eval(x)) + mean(LayerNorm(c))).  The BatchNorm affine
+    (scale, shift), the fp32 LayerNorm affine and the padded classifier operands are cached until one of their source tensors changes."""
+    src = [bn.weight, bn.bias, bn.running_mean, bn.running_var, norm_c.weight, norm_c.bias, head.weight, head.bias]
+    ver = (_train_pass, cd) + tuple(-1 if t is None else t._version for t in src) + tuple(0 if t is None else t.data_ptr() for t in src)
+    key = (id(bn), id(head))
+    ent = _tail_cache.get(key)
+    if ent is None or ent[0] != ver:
+        with torch.no_grad():
+            a = torch.rsqrt(bn.running_var.float() + bn.eps)
+            if bn.weight is not None:
+                a = a * bn.weight.float()
+            b = -bn.running_mean.float() * a
+            if bn.bias is not None:
+                b = b + bn.bias.float()
+            N, K = head.weight.shape
+            Np = (N + 7) // 8 * 8
+            Wp = torch.zeros((Np, K), device=xt.device, dtype=cd); Wp[:N] = head.weight.detach().to(cd)
+            bp = torch.zeros((Np,), device=xt.device, dtype=torch.float32)
+            if head.bias is not None:
+                bp[:N] = head.bias.detach().float()
+            ent = (ver, a.contiguous(), b.contiguous(), norm_c.weight.detach().float().contiguous(), norm_c.bias.detach().float().contiguous(), Wp, bp, N)
+        _tail_cache[key] = ent
+    _, a, b, g32, b32, Wp, bp, N = ent
+    cc = c.detach().to(cd).contiguous()
+    (cn,), _ = ops.layernorm_fwd_multi([cc], g32, b32, float(norm_c.eps), want_stats=False)
+    pooled = ops.token_mean2_affine_fwd(xt.detach().to(cd).contiguous(), cn, a, b)
+    Np, K = Wp.shape
+    out = torch.empty((pooled.shape[0], Np), device=pooled.device, dtype=cd)
+    ops.linear_fwd([Prob(pooled, Wp, out, bias=bp)], Np, K)
+    return out[:, :N] if Np != N else out
 
 
 def _tail_native(norm_c: nn.Module, head: Optional[nn.Module], xt: Tensor, c: Tensor, cd: torch.dtype) -> bool:
@@ -639,7 +679,7 @@ class _BlockFn(torch.autograd.Function):
             # the parameter gradients leave this node now (all-reduce of the chunk / autograd's accumulation on the current stream):
             # the deferred joins of the weight-gradient side stream (blocks.defer_join) are due
             from . import blocks as _blocks
-            _blocks._wait_pending(0)
+            _blocks._wait_pending(0, x0.device.index)
         if cb is not None:
             cb()                     # lemevit_amd.dist.FlatGradSync: this block closes a chunk of the flat gradient buffer -> start its all-reduce
         if inplace:
@@ -1043,6 +1083,12 @@ class LeMeViT(nn.Module):
             hw, hb = (None, None) if head is None else (head.weight, head.bias)
             self._tail_done = head is not None
             return _TailFn.apply(xb, c, self.norm_c.weight, self.norm_c.bias, float(self.norm_c.eps), hw, hb, cd)
+        if (head is not False and head is not None and not bn.training and bn.track_running_stats and isinstance(self.pre_logits, nn.Identity)
+                and not torch.is_grad_enabled() and _tail_native(self.norm_c, head, xt, c, cd) and bn.running_var is not None):
+            # inference: LayerNorm(c) -> both mean-pools + add with the eval-mode BatchNorm folded into the pool -> classifier: three launches
+            # of the library (lmv_layernorm_fwd, lmv_token_mean2_affine_fwd, lmv_linear_fwd) instead of ~20 ATen kernels + a hipBLASLt GEMM
+            self._tail_done = True
+            return _tail_infer(self.norm_c, bn, head, xt, c, cd)
         cn = self.pre_logits(self.norm_c(c))
         if not bn.training and bn.track_running_stats and isinstance(self.pre_logits, nn.Identity):
             # inference: BatchNorm with running statistics is affine per channel, so it commutes with the spatial mean --

@@ -465,6 +465,17 @@ def token_mean2_fwd(x: Tensor, c: Optional[Tensor]) -> Tensor:
     return out
 
 
+def token_mean2_affine_fwd(x: Tensor, c: Optional[Tensor], xscale: Tensor, xshift: Tensor) -> Tensor:
+    """out[b, :] = xscale * mean_l x[b, l, :] + xshift (+ mean_m c[b, m, :]): the pool with an eval-mode BatchNorm folded in (fp32 scale / shift [C])."""
+    B, L, C_ = x.shape
+    if xscale.dtype != torch.float32 or xshift.dtype != torch.float32 or xscale.numel() != C_ or xshift.numel() != C_:
+        raise TypeError("token_mean2_affine_fwd: xscale / xshift must be float32 [C]")
+    out = torch.empty((B, C_), device=x.device, dtype=x.dtype)
+    check(lib.lmv_token_mean2_affine_fwd(_ptr(x), L, _ptr(c), 0 if c is None else c.shape[1], C_, B, _ptr(xscale), _ptr(xshift), _ptr(out), dtype_code(x), _stream()),
+          "lmv_token_mean2_affine_fwd")
+    return out
+
+
 def token_mean2_bwd(g: Tensor, L: int, M: int) -> Tuple[Tensor, Optional[Tensor]]:
     """Gradient of token_mean2_fwd: dx[b, l, :] = g[b, :] / L, dc[b, m, :] = g[b, :] / M (M = 0: no second segment)."""
     B, C_ = g.shape

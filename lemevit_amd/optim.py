@@ -91,7 +91,10 @@ class FlatAdamW:
     def _rebind(self, keep: bool) -> None:
         """Every flat-managed ``p.grad`` must be a view of the flat gradient buffer.  ``model.zero_grad()`` (set_to_none=True) or
         ``p.grad = None`` breaks that: the block backward then hands the gradients to autograd, which allocates fresh ``.grad``
-        tensors the fused update would never read.  keep=True copies such a stray gradient into its slice first."""
+        tensors the fused update would never read.  keep=True copies such a stray gradient into its slice first (COPY, not add: a ``.grad`` that
+        is not our view means the caller cleared or replaced the gradients since the slice was last bound, so whatever the slice still holds
+        is stale -- e.g. the previous step's gradients after ``model.zero_grad()`` -- and autograd has accumulated every micro-batch since then
+        into the stray tensor)."""
         for i, (_, p, off, n) in enumerate(self._slices):
             g = p.grad
             if g is self._grad_views[i]:                               # the common case: one identity test per parameter
@@ -100,6 +103,8 @@ class FlatAdamW:
             if g is not None and g.data_ptr() != view.data_ptr():
                 if keep:
                     view.copy_(g.detach().to(view.dtype).view(view.shape))
+            elif g is None and keep:
+                view.zero_()                                               # cleared and not re-computed: no gradient (the slice would be stale)
             p.grad = view
 
     def zero_grad(self, set_to_none: bool = True) -> None:
@@ -108,14 +113,22 @@ class FlatAdamW:
         if self._rest is not None:
             self._rest.zero_grad(set_to_none=set_to_none)
 
+    def rebind_grads(self) -> None:
+        """Public form of ``_rebind(keep=True)``: call before anything reads the flat gradient buffer directly (FlatGradSync.finish does)."""
+        self._rebind(keep=True)
+
     @torch.no_grad()
     def step(self) -> None:
+        from . import blocks as _blocks
+        _blocks.drain_deferred()           # backstop: the weight-gradient side stream must have been joined before the update reads the gradients
         self._rebind(keep=True)
         if self._rest is not None:
             self._rest.step()
         self._step_dev += 1
-        ops.adamw_flat(self._flat_p, self._flat_g, self._exp_avg, self._exp_avg_sq, self._wd_mask, float(self.param_groups[0]["lr"]),
-                       self.betas[0], self.betas[1], self.eps, self.weight_decay, 0, shadow=self._shadow, step_dev=self._step_dev)
+        g0 = self.param_groups[0]          # schedulers / users may edit any of these (as for torch.optim.AdamW)
+        b1, b2 = g0["betas"]
+        ops.adamw_flat(self._flat_p, self._flat_g, self._exp_avg, self._exp_avg_sq, self._wd_mask, float(g0["lr"]),
+                       float(b1), float(b2), float(g0["eps"]), float(g0["weight_decay"]), 0, shadow=self._shadow, step_dev=self._step_dev)
 
     @torch.no_grad()
     def refresh(self) -> None:
@@ -124,7 +137,8 @@ class FlatAdamW:
 
     def state_dict(self) -> Dict[str, object]:
         return dict(step=int(self._step_dev.item()), exp_avg=self._exp_avg.clone(), exp_avg_sq=self._exp_avg_sq.clone(),
-                    names=[(n, off, k) for n, _, off, k in self._slices], lr=self.param_groups[0]["lr"],
+                    names=[(n, off, k) for n, _, off, k in self._slices], lr=self.param_groups[0]["lr"], betas=tuple(self.param_groups[0]["betas"]),
+                    eps=self.param_groups[0]["eps"], weight_decay=self.param_groups[0]["weight_decay"],
                     rest=None if self._rest is None else self._rest.state_dict())
 
     def load_state_dict(self, sd: Dict[str, object]) -> None:
@@ -133,5 +147,8 @@ class FlatAdamW:
         self._step_dev.fill_(int(sd["step"]))
         self._exp_avg.copy_(sd["exp_avg"]); self._exp_avg_sq.copy_(sd["exp_avg_sq"])
         self.param_groups[0]["lr"] = sd["lr"]
+        for k in ("betas", "eps", "weight_decay"):
+            if k in sd:
+                self.param_groups[0][k] = sd[k]
         if self._rest is not None and sd.get("rest") is not None:
             self._rest.load_state_dict(sd["rest"])

@@ -125,11 +125,12 @@ def _mlp_refs(x64, F, w2r64, b2, masters, scale_rows):
 
 @pytest.mark.parametrize("tm", [0, 128])
 @pytest.mark.parametrize("C", [64, 96, 128, 192, 256, 320, 384])
-def test_mlp_fused_fwd(C, tm, monkeypatch):
+def test_mlp_fused_fwd(C, tm, monkeypatch, request):
     """x + fc2(GELU(fc1(LN(x)))) in one kernel: image tokens (ragged row count) + meta tokens in one launch, with / without DropPath;
     tm = 0: the library's choice of rows per workgroup (64 where two workgroups fit a CU), 128: the one-workgroup-per-CU form"""
-    if tm:
-        monkeypatch.setenv("LMV_MLP_TM", str(tm))
+    from lemevit_amd import _lib
+    _lib.config_set("mlp_tm", tm)
+    request.addfinalizer(lambda: _lib.config_set("mlp_tm", 0))
     dtype = torch.bfloat16
     Hd = 4 * C
     o, F, masters, w2, b2 = _mlp_case(C, Hd)
@@ -235,3 +236,25 @@ def test_attn_out_proj_residual(dtype):
     assert_close(oc, c64 + aoc64 @ w64.t() + bias.cpu().double(), dtype, "proj c")
     with pytest.raises(RuntimeError):
         o.attn_out_proj_residual([o.Prob(ao, w, ox, bias=bias)], C)
+
+
+def test_gelu_poly_bound():
+    """The activation of the fused MLP kernel ON ITS OWN (lmv_gelu_poly_eval = the kernel's gelu_poly2): |poly(u) - GELU_erf(u)| against the
+    bound DESIGN.md / INTEGRATION.md state -- 1.9e-4 absolute everywhere, 3.2e-5 for |u| <= 2 -- and exact saturation beyond |u| >= 4, so a
+    future refit cannot hide behind the residual of the full-kernel tests."""
+    import ctypes as C
+    from lemevit_amd._lib import lib, check
+    u = torch.cat([torch.linspace(-8.0, 8.0, 1 << 20), torch.tensor([0.0, -0.0, 4.0, -4.0, 3.999, -3.999, 1e-8, -1e-8, 30.0, -30.0])]).to(dev())
+    y = torch.empty_like(u)
+    check(lib.lmv_gelu_poly_eval(u.data_ptr(), y.data_ptr(), u.numel(), torch.cuda.current_stream().cuda_stream), "lmv_gelu_poly_eval")
+    torch.cuda.synchronize()
+    ref = (0.5 * u.double() * (1.0 + torch.erf(u.double() / 2.0 ** 0.5)))
+    err = (y.double() - ref).abs()
+    assert float(err.max()) <= 1.9e-4, f"max |gelu_poly - gelu_erf| = {float(err.max()):.3e}"
+    inner = u.abs() <= 2.0
+    assert float(err[inner].max()) <= 3.2e-5, f"|u| <= 2: {float(err[inner].max()):.3e}"
+    hi, lo = u >= 4.0, u <= -4.0
+    assert torch.equal(y[hi], u[hi]) and float(y[lo].abs().max()) == 0.0
+    # relative to a stored bf16 activation: below half an ulp for |h| >= 0.05
+    big = ref.abs() >= 0.05
+    assert float((err[big] / ref[big].abs()).max()) <= 2.0 ** -9 + 1e-6

@@ -612,9 +612,20 @@ def test_native_block_schedule_equals_python_schedule(monkeypatch, kind, C, h, H
     """lmv_block_fwd / lmv_block_bwd (csrc/block.hip) run the SAME kernels in the same order as lemevit_amd/blocks.py: outputs, input
     gradients and every parameter gradient must be bit-identical -- with DropPath scale vectors on all four branches and the weight
     gradients on the side stream.  (Parity of either schedule with the reference: test_block_backward_*.)"""
+    _native_vs_python(monkeypatch, kind, C, h, Hs, dtype, 5)
+
+
+@pytest.mark.parametrize("kind,C,h,Hs", [("S", 384, 12, 14), ("D", 96, 3, 56)])
+def test_native_block_schedule_equals_python_schedule_full_size(monkeypatch, kind, C, h, Hs):
+    """The same bit-equality at the FULL Base shapes of config 3 (B = 128: stage 3 = 196 + 16 tokens x 384, stage 1 = 3136 + 16 tokens x 96):
+    arena / scratch layouts, split-K plans and 32-bit index arithmetic only show their bugs at size."""
+    _native_vs_python(monkeypatch, kind, C, h, Hs, torch.bfloat16, 128)
+
+
+def _native_vs_python(monkeypatch, kind, C, h, Hs, dtype, B):
     import lemevit_amd.model as M
     from lemevit_amd.blocks import PARAM_NAMES
-    B, N, Mt = 5, Hs * Hs, 16
+    N, Mt = Hs * Hs, 16
     names = PARAM_NAMES[kind]
     blk = load(_block(kind, C, h), "blk.", 11)
     allp = dict(blk.named_parameters())
@@ -648,3 +659,74 @@ def test_native_block_schedule_equals_python_schedule(monkeypatch, kind, C, h, H
     labels = ["x_out", "c_out", "dx", "dc"] + ["grad " + n for n in names]
     for a, b, what in zip(res[True], res[False], labels):
         assert torch.equal(a, b), f"{kind} {dtype} {what}: native and Python schedules differ by {float((a.float() - b.float()).abs().max()):.3e}"
+
+
+def test_block_bwd_two_threads_two_streams():
+    """include/lemevit_hip.h promises a stateless, re-entrant library: two host threads run lmv_block_bwd (raw C ABI) on the SAME device at the
+    same time, each on its own main + side stream, 12 rounds -- every output and every parameter gradient must be bit-identical to the
+    one-thread run.  (Round 2 shared ONE fork / join event pair per device between all calls: thread A's side stream could then wait on the
+    record thread B had just made; csrc/block.hip now hands every call its own pair.)"""
+    import threading
+    import lemevit_amd.model as M
+    from lemevit_amd import ops
+    from lemevit_amd._lib import lib, check
+    from lemevit_amd.blocks import PARAM_NAMES
+    kind, C, h, Hs, B, Mt = "S", 192, 6, 14, 16, 16
+    N = Hs * Hs
+    names = PARAM_NAMES[kind]
+    dtype = torch.bfloat16
+    probs = []
+    for i in range(2):
+        blk = load(_block(kind, C, h), "blk.", 21 + i)
+        allp = dict(blk.named_parameters())
+        P = {n: M.compute_copy(allp[n], dtype if M._is_matrix(n) else torch.float32).contiguous() for n in names}
+        masks = tuple((det_tensor((B,), f"tmask{i}{q}", 4).abs() > 0.3).float().to(DEV) / 0.7 for q in range(4))
+        main, side = torch.cuda.Stream(), torch.cuda.Stream()
+        x = det_tensor((B, N, C), f"tx{i}", 6).to(DEV, dtype); c = det_tensor((B, Mt, C), f"tc{i}", 6).to(DEV, dtype)
+        gx = det_tensor((B, N, C), f"tgx{i}", 6).to(DEV, dtype); gc = det_tensor((B, Mt, C), f"tgc{i}", 6).to(DEV, dtype)
+        torch.cuda.synchronize()
+        with torch.cuda.stream(main):
+            xo, co, (d, arena) = M.native_block_forward(kind, x, c, Hs, Hs, names, P, masks, save=True)
+        nb = M._sized(lib.lmv_block_bwd_scratch_bytes, d, kind, x, c, Hs, Hs)
+        scratch = torch.empty(nb + 4096, device=DEV, dtype=torch.uint8)
+        G = {n: torch.zeros(P[n].shape, device=DEV, dtype=torch.float32) for n in names}
+        M._fill_ptrs(d, kind, names, G, "g_")
+        d.flags = 0
+        probs.append(dict(d=d, arena=arena, x=x, c=c, gx=gx, gc=gc, dx=torch.empty_like(x), dc=torch.empty_like(c), scratch=scratch, G=G, main=main, side=side, P=P, masks=masks))
+    torch.cuda.synchronize()
+
+    def run(p, rounds):
+        torch.cuda.set_device(0)
+        for _ in range(rounds):
+            for g in p["G"].values():
+                with torch.cuda.stream(p["main"]):
+                    g.zero_()
+            check(lib.lmv_block_bwd(p["d"], p["x"].data_ptr(), p["c"].data_ptr(), p["arena"].data_ptr(), p["arena"].numel(), p["gx"].data_ptr(), p["gc"].data_ptr(),
+                                    p["dx"].data_ptr(), p["dc"].data_ptr(), p["scratch"].data_ptr(), p["scratch"].numel(), p["main"].cuda_stream, p["side"].cuda_stream),
+                  "lmv_block_bwd")
+        p["main"].synchronize(); p["side"].synchronize()
+
+    ref = []
+    for p in probs:                       # one thread, one problem at a time
+        run(p, 1)
+        torch.cuda.synchronize()
+        ref.append([p["dx"].clone(), p["dc"].clone()] + [p["G"][n].clone() for n in names])
+    errs = []
+
+    def worker(p):
+        try:
+            run(p, 12)
+        except Exception as e:            # pragma: no cover
+            errs.append(e)
+
+    th = [threading.Thread(target=worker, args=(p,)) for p in probs]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    torch.cuda.synchronize()
+    assert not errs, errs
+    for i, p in enumerate(probs):
+        got = [p["dx"], p["dc"]] + [p["G"][n] for n in names]
+        for a, b, what in zip(got, ref[i], ["dx", "dc"] + ["grad " + n for n in names]):
+            assert torch.equal(a, b), f"problem {i} {what}: threaded run differs from the serial one by {float((a.float() - b.float()).abs().max()):.3e}"

@@ -3,7 +3,7 @@
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
-from lemevit_amd import ops
+from lemevit_amd import ops, _lib
 from lemevit_amd.ops import Prob
 dev = "cuda:0"; bf = torch.bfloat16
 B = 128
@@ -28,9 +28,9 @@ for name, rx, rc, n, k in SHAPES:
     dyx = torch.randn(rx, n, device=dev).to(bf); dyc = torch.randn(rc, n, device=dev).to(bf)
     dw = torch.zeros(n, k, device=dev); db = torch.zeros(n, device=dev)
     for bk in (64, 32):
-        os.environ["LMV_DW_BK"] = str(bk)
+        _lib.config_set("dw_bk", bk)
         row = []
         for s in slots:
-            os.environ["LMV_DW_TARGET_BLOCKS"] = str(s)
+            _lib.config_set("dw_target_blocks", s)
             row.append(timeit(lambda: ops.linear_dw([Prob(dyx, ax, dw, bias_grad=db), Prob(dyc, ac, dw, bias_grad=db)], n, k)))
         print(f"{name:10s} {bk:2d} " + " ".join(f"{t:6.1f}" for t in row), flush=True)

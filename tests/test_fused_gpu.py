@@ -240,7 +240,7 @@ def test_attn_out_proj_residual(dtype):
 
 def test_gelu_poly_bound():
     """The activation of the fused MLP kernel ON ITS OWN (lmv_gelu_poly_eval = the kernel's gelu_poly2): |poly(u) - GELU_erf(u)| against the
-    bound DESIGN.md / INTEGRATION.md state -- 1.9e-4 absolute everywhere, 3.2e-5 for |u| <= 2 -- and exact saturation beyond |u| >= 4, so a
+    bound DESIGN.md / INTEGRATION.md state -- 1.9e-4 absolute everywhere, 3.2e-5 for |u| <= 2 -- and saturation (identity / zero to fp32 rounding) beyond |u| >= 4, so a
     future refit cannot hide behind the residual of the full-kernel tests."""
     import ctypes as C
     from lemevit_amd._lib import lib, check
@@ -254,7 +254,8 @@ def test_gelu_poly_bound():
     inner = u.abs() <= 2.0
     assert float(err[inner].max()) <= 3.2e-5, f"|u| <= 2: {float(err[inner].max()):.3e}"
     hi, lo = u >= 4.0, u <= -4.0
-    assert torch.equal(y[hi], u[hi]) and float(y[lo].abs().max()) == 0.0
+    # saturation: q(1) = 1/2 up to the fp32 rounding of the Horner evaluation -> identity / zero to a few ulp
+    assert float(((y[hi] - u[hi]).abs() / u[hi]).max()) <= 1e-6 and float((y[lo].abs() / u[lo].abs()).max()) <= 1e-6
     # relative to a stored bf16 activation: below half an ulp for |h| >= 0.05
     big = ref.abs() >= 0.05
     assert float((err[big] / ref[big].abs()).max()) <= 2.0 ** -9 + 1e-6

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define LMV_ABI_VERSION 3
+#define LMV_ABI_VERSION 4
 
 enum { LMV_F32 = 0, LMV_BF16 = 1 };
 enum {
@@ -54,6 +54,8 @@ int lmv_config_get(const char* key, int* value);
  * attention -- weights, :560-564,:632-635).
  *
  *   fwd : out[r, n] = res[r, n] + row_scale[r / rows_per_sample] * act(sum_k a[r,k] w[n,k] + bias[n])
+ *         (act == LMV_ACT_GELU_GRAD: out[r, n] = row_scale * (sum_k a[r,k] w[n,k] + bias[n]) * gelu'(aux[r, n]), no residual: a dX through
+ *          a TRANSPOSED weight copy)
  *   dx  : out[r, k] = (sum_n a[r,n] w[n,k]) (* gelu'(aux[r,k]) if act == LMV_ACT_GELU_GRAD)
  *   dw  : dw[n, k] += sum_r dy[r,n] x[r,k] ;  db[n] += sum_r dy[r,n]      (fp32; split-K partial slabs in
  *         `workspace` + a reduce kernel: deterministic, no atomics)
@@ -273,6 +275,11 @@ typedef struct lmv_row_scale_segment {
   int64_t rows; int rows_per_sample;
 } lmv_row_scale_segment;
 int lmv_row_scale_multi(const lmv_row_scale_segment* seg, int nseg, int C, int dtype, void* stream);
+/* dst[c][r] = src[r][c] for any number of bf16 matrices (src [rows, cols] -> dst [cols, rows]) in one launch per LMV_TRANSPOSE_MAX_SEGS:
+ * the transposed weight copies that let a dX run as a forward-form GEMM (lmv_block_desc.fc2_wt). */
+#define LMV_TRANSPOSE_MAX_SEGS 48
+typedef struct { const void* src; void* dst; int32_t rows, cols; } lmv_transpose_seg;
+int lmv_transpose_batch(const lmv_transpose_seg* segs, int nsegs, int dtype, void* stream);
 /* Dense 3x3 / stride-2 / padding-1 convolutions on channels-last maps -- the second stem convolution and the stage transitions
  * (models/lemevit.py:701-703, :714-717) -- lowered to the block GEMM:
  *   patches[(b, ho, wo)][(ky * 3 + kx) * C + ci] = x[b, 2 ho - 1 + ky, 2 wo - 1 + kx, ci]  (zero outside the map and in the padding
@@ -336,6 +343,10 @@ typedef struct lmv_block_desc {
    * LayerNorm + Linear where that is the faster form and lmv_mlp_fused_fwd for the MLP half where lmv_mlp_fused_supported. */
   const void* fold_attn_w[2]; const float* fold_attn_s[2]; const float* fold_attn_b[2];
   const void* fold_fc1_w; const float* fold_fc1_s; const float* fold_fc1_b;
+  /* optional (NULL = absent): mlp.3.weight TRANSPOSED, [hidden, C] in `dtype` (lmv_transpose_batch of fc2_w).  With it lmv_block_bwd runs the dX
+   * of fc2 -- du = (dOut W2) * GELU'(u) -- as the forward-form GEMM  dOut [rows, C] x fc2_wt^T  with the GELU' epilogue, which the
+   * register-stationary kernel (csrc/rsgemm.hip) takes for C = 192 / 384.  Must hold the same values as fc2_w. */
+  const void* fc2_wt;
 } lmv_block_desc;
 size_t lmv_block_arena_bytes(const lmv_block_desc* d);
 size_t lmv_block_bwd_scratch_bytes(const lmv_block_desc* d);

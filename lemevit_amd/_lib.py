@@ -14,7 +14,7 @@ LIB_PATH = os.path.join(_HERE, "csrc", "liblemevit_hip.so")
 
 LMV_F32, LMV_BF16 = 0, 1
 ACT_NONE, ACT_GELU, ACT_GELU_GRAD = 0, 1, 2
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 
 class LinearProblem(C.Structure):
@@ -61,7 +61,11 @@ class BlockDesc(C.Structure):
                 [(n, C.c_void_p) for n in ("g_pos_w", "g_pos_b", "g_n1_w", "g_n1_b")] + [("g_attn_w", C.c_void_p * 4), ("g_attn_b", C.c_void_p * 4)] +
                 [(n, C.c_void_p) for n in ("g_n2_w", "g_n2_b", "g_fc1_w", "g_fc1_b", "g_fc2_w", "g_fc2_b")] +
                 [("fold_attn_w", C.c_void_p * 2), ("fold_attn_s", C.c_void_p * 2), ("fold_attn_b", C.c_void_p * 2)] +
-                [(n, C.c_void_p) for n in ("fold_fc1_w", "fold_fc1_s", "fold_fc1_b")])
+                [(n, C.c_void_p) for n in ("fold_fc1_w", "fold_fc1_s", "fold_fc1_b", "fc2_wt")])
+
+
+class TransposeSeg(C.Structure):
+    _fields_ = [("src", C.c_void_p), ("dst", C.c_void_p), ("rows", C.c_int32), ("cols", C.c_int32)]
 
 
 _P, _I, _L, _F, _Z = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_size_t
@@ -109,6 +113,7 @@ SIGNATURES = {
     "lmv_cast": (_I, [_P, _I, _P, _I, _L, _P]),
     "lmv_im2col3x3s2_c3": (_I, [_P, _I, _P, _I, _I, _I, _I, _L, _L, _L, _L, _P]),
     "lmv_row_scale_multi": (_I, [_P, _I, _I, _I, _P]),
+    "lmv_transpose_batch": (_I, [C.POINTER(TransposeSeg), _I, _I, _P]),
     "lmv_row_scale": (_I, [_P, _P, _P, _L, _I, _I, _I, _P]),
     "lmv_im2col3x3s2_nhwc": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "lmv_col2im3x3s2_nhwc": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _P]),

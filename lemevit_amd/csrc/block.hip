@@ -294,8 +294,15 @@ int mlp_bwd(const lmv_block_desc* d, const Dims& D, const Fwd& f, const Bwd& b, 
   lmv_linear_problem p[2];
   for (int i = 0; i < ns; ++i) { const int s = s0 + i; p[i] = prob(g[s], f.h[s], d->g_fc2_w, D.rows[s]); p[i].bias_grad = d->g_fc2_b; }
   LMV_TRY(dw(sd, p, ns, D.C, D.Hd, D.dtype));
-  for (int i = 0; i < ns; ++i) { const int s = s0 + i; p[i] = prob(g[s], d->fc2_w, b.du[s], D.rows[s]); p[i].aux = f.u[s]; }
-  LMV_TRY(lmv_linear_dx(p, ns, D.C, D.Hd, LMV_ACT_GELU_GRAD, D.dtype, st));
+  if (d->fc2_wt && D.dtype == LMV_BF16) {
+    // dX of fc2 as a forward-form GEMM on the transposed weight copy [hidden, C]: du = (g W2) * GELU'(u) = (g . fc2_wt^T) * GELU'(u)
+    // (the register-stationary kernel takes it for C = 192 / 384: csrc/rsgemm.hip)
+    for (int i = 0; i < ns; ++i) { const int s = s0 + i; p[i] = prob(g[s], d->fc2_wt, b.du[s], D.rows[s]); p[i].aux = f.u[s]; }
+    LMV_TRY(lmv_linear_fwd(p, ns, D.Hd, D.C, LMV_ACT_GELU_GRAD, D.dtype, st));
+  } else {
+    for (int i = 0; i < ns; ++i) { const int s = s0 + i; p[i] = prob(g[s], d->fc2_w, b.du[s], D.rows[s]); p[i].aux = f.u[s]; }
+    LMV_TRY(lmv_linear_dx(p, ns, D.C, D.Hd, LMV_ACT_GELU_GRAD, D.dtype, st));
+  }
   for (int i = 0; i < ns; ++i) { const int s = s0 + i; p[i] = prob(b.du[s], f.n2[s], d->g_fc1_w, D.rows[s]); p[i].bias_grad = d->g_fc1_b; }
   LMV_TRY(dw(sd, p, ns, D.Hd, D.C, D.dtype));
   for (int i = 0; i < ns; ++i) { const int s = s0 + i; p[i] = prob(b.du[s], d->fc1_w, b.dn2[s], D.rows[s]); }

@@ -49,6 +49,10 @@ struct LmvConfig {
 };
 LmvConfig& lmv_config();
 
+// rsgemm.hip: the register-stationary GEMM for wide short-reduction forward-form launches (bf16)
+bool lmv_rs_eligible(const lmv_linear_problem* p, int nproblems, int N, int K, int act, bool force);
+int lmv_rs_linear(const lmv_linear_problem* p, int nproblems, int N, int K, int act, hipStream_t st);
+
 static inline bool lmv_aligned16(const void* p) { return (((uintptr_t)p) & 15u) == 0; }
 
 // ---- bf16 <-> f32 ---------------------------------------------------------------------------

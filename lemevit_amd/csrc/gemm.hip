@@ -514,7 +514,9 @@ int launch_mode(const Plan& pl, dim3 grid, bool bf, hipStream_t st) {
 int launch(const lmv_linear_problem* p, int nproblems, int N, int K, int act, int dtype, void* stream, Mode mode, void* ws, size_t ws_bytes,
            lmv_reduce_seg* segs = nullptr, int* nsegs = nullptr) {
   Plan pl;
-  if (int rc = make_plan(p, nproblems, N, K, act, dtype, mode, &pl)) return rc;
+  if (int rc = make_plan(p, nproblems, N, K, act, dtype, mode, &pl)) return rc;      // (validates the operands)
+  if (mode == MODE_FWD && dtype == LMV_BF16 && lmv_config().gemm_rs && lmv_rs_eligible(p, nproblems, N, K, act, lmv_config().gemm_rs == 2))
+    return lmv_rs_linear(p, nproblems, N, K, act, (hipStream_t)stream);              // register-stationary kernel (rsgemm.hip)
   GemmArgs& g = pl.g;
   if (mode == MODE_DW) {
     if (!ws || ws_bytes < pl.ws_bytes || !lmv_aligned16(ws)) LMV_FAIL(LMV_ERR_WORKSPACE, "linear_dw: workspace %zu < %zu bytes", ws_bytes, pl.ws_bytes);
@@ -594,7 +596,9 @@ extern "C" int lmv_attn_out_proj_residual(const lmv_linear_problem* p, int nprob
 }
 
 extern "C" int lmv_linear_fwd(const lmv_linear_problem* p, int nproblems, int N, int K, int act, int dtype, void* stream) {
-  if (act != LMV_ACT_NONE && act != LMV_ACT_GELU) LMV_FAIL(LMV_ERR_SHAPE, "linear_fwd: act must be NONE or GELU");
+  if (act != LMV_ACT_NONE && act != LMV_ACT_GELU && act != LMV_ACT_GELU_GRAD) LMV_FAIL(LMV_ERR_SHAPE, "linear_fwd: act must be NONE, GELU or GELU_GRAD");
+  for (int i = 0; i < nproblems && i < 2; ++i)
+    if (act == LMV_ACT_GELU_GRAD && (!p[i].aux || p[i].res)) LMV_FAIL(LMV_ERR_SHAPE, "linear_fwd: GELU_GRAD needs aux and takes no residual");
   return launch(p, nproblems, N, K, act, dtype, stream, MODE_FWD, nullptr, 0);
 }
 extern "C" int lmv_linear_dx(const lmv_linear_problem* p, int nproblems, int N, int K, int act, int dtype, void* stream) {

@@ -483,3 +483,54 @@ extern "C" int lmv_adamw_flat(float* param, const float* grad, float* exp_avg, f
   LMV_CHECK_LAUNCH("adamw_flat");
   return LMV_OK;
 }
+
+// ---- batched 2-byte matrix transpose: dst[c][r] = src[r][c] for up to LMV_TRANSPOSE_MAX_SEGS matrices in ONE launch ----------------------
+// (the transposed bf16 copies of the mlp.3 weights that let the dX of fc2 run as a forward-form GEMM on the register-stationary kernel,
+//  rsgemm.hip; refreshed once per optimizer step by FlatAdamW)
+namespace {
+struct TrSegDev { const unsigned short* src; unsigned short* dst; int rows, cols, tiles_c, tile0; };
+struct TrBatch { TrSegDev s[LMV_TRANSPOSE_MAX_SEGS]; int n; };
+__global__ __launch_bounds__(256) void transpose16_batch_kernel(const TrBatch tb) {
+  __shared__ unsigned short tile[64][66];
+  int si = 0;
+#pragma unroll 1
+  for (int k = 1; k < tb.n; ++k) if ((int)blockIdx.x >= tb.s[k].tile0) si = k;
+  const TrSegDev g = tb.s[si];
+  const int t = blockIdx.x - g.tile0, tr = t / g.tiles_c, tc = t % g.tiles_c;
+  const int r0 = tr * 64, c0 = tc * 64;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int r = r0 + ty * 16 + i, c = c0 + tx;
+    tile[ty * 16 + i][tx] = (r < g.rows && c < g.cols) ? g.src[(int64_t)r * g.cols + c] : (unsigned short)0;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int c = c0 + ty * 16 + i, r = r0 + tx;
+    if (r < g.rows && c < g.cols) g.dst[(int64_t)c * g.rows + r] = tile[tx][ty * 16 + i];
+  }
+}
+}  // namespace
+extern "C" int lmv_transpose_batch(const lmv_transpose_seg* segs, int nsegs, int dtype, void* stream) {
+  if (nsegs <= 0) return LMV_OK;
+  if (!segs) LMV_FAIL(LMV_ERR_SHAPE, "transpose_batch: segs is NULL");
+  if (dtype != LMV_BF16) LMV_FAIL(LMV_ERR_DTYPE, "transpose_batch: 2-byte elements (bf16) only");
+  hipStream_t st = (hipStream_t)stream;
+  for (int s0 = 0; s0 < nsegs; s0 += LMV_TRANSPOSE_MAX_SEGS) {
+    TrBatch tb{};
+    tb.n = nsegs - s0 < LMV_TRANSPOSE_MAX_SEGS ? nsegs - s0 : LMV_TRANSPOSE_MAX_SEGS;
+    int tiles = 0;
+    for (int i = 0; i < tb.n; ++i) {
+      const lmv_transpose_seg& q = segs[s0 + i];
+      if (!q.src || !q.dst || q.rows <= 0 || q.cols <= 0 || q.src == q.dst) LMV_FAIL(LMV_ERR_SHAPE, "transpose_batch: bad segment %d", s0 + i);
+      TrSegDev& d = tb.s[i];
+      d.src = (const unsigned short*)q.src; d.dst = (unsigned short*)q.dst; d.rows = q.rows; d.cols = q.cols;
+      d.tiles_c = (q.cols + 63) / 64; d.tile0 = tiles;
+      tiles += ((q.rows + 63) / 64) * d.tiles_c;
+    }
+    hipLaunchKernelGGL(transpose16_batch_kernel, dim3(tiles), dim3(256), 0, st, tb);
+  }
+  LMV_CHECK_LAUNCH("transpose_batch");
+  return LMV_OK;
+}

@@ -512,6 +512,19 @@ def row_scale_multi(xs: Sequence[Tensor], scales: Sequence[Optional[Tensor]]) ->
     return [x if s is None else next(it) for x, s in zip(xs, scales)]
 
 
+def transpose_batch(pairs: Sequence[Tuple[Tensor, Tensor]]) -> None:
+    """dst = src^T for every (src [R, C], dst [C, R]) pair of contiguous bf16 matrices, in one launch per 48 pairs."""
+    if not pairs:
+        return
+    arr = (_lib.TransposeSeg * len(pairs))()
+    for sg, (src, dst) in zip(arr, pairs):
+        if src.dtype != torch.bfloat16 or dst.dtype != torch.bfloat16 or src.dim() != 2 or dst.shape != (src.shape[1], src.shape[0]) \
+                or not src.is_contiguous() or not dst.is_contiguous():
+            raise TypeError("transpose_batch: contiguous bfloat16 [R, C] -> [C, R] pairs")
+        sg.src, sg.dst, sg.rows, sg.cols = _ptr(src), _ptr(dst), src.shape[0], src.shape[1]
+    check(lib.lmv_transpose_batch(arr, len(pairs), _lib.LMV_BF16, _stream()), "lmv_transpose_batch")
+
+
 def adamw_flat(param: Tensor, grad: Tensor, exp_avg: Tensor, exp_avg_sq: Tensor, wd_mask: Optional[Tensor], lr: float, beta1: float,
                beta2: float, eps: float, weight_decay: float, step: int, shadow: Optional[Tensor] = None, step_dev: Optional[Tensor] = None) -> None:
     if shadow is not None and (shadow.dtype != torch.bfloat16 or shadow.numel() != param.numel()):

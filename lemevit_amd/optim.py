@@ -76,6 +76,14 @@ class FlatAdamW:
                 if matrix:
                     p._lmv_shadow = self._shadow[off:off + n].view(p.shape)
                 self._slices.append((name, p, off, n))
+        # transposed bf16 copies of the mlp.3 weights of the blocks whose fc2 dX runs on the register-stationary GEMM (C = 192 / 384 and a
+        # hidden width that is a multiple of 64, csrc/rsgemm.hip): refreshed by ONE lmv_transpose_batch launch behind every update
+        self._tpairs: List[Tuple[Tensor, Tensor]] = []
+        for name, p, off, n in self._slices:
+            if name.endswith("mlp.3.weight") and p.dim() == 2 and p.shape[0] in (192, 384) and p.shape[1] % 64 == 0 and p.shape[1] >= 512:
+                wt = torch.empty((p.shape[1], p.shape[0]), device=dev, dtype=torch.bfloat16)
+                p._lmv_shadow_t = wt
+                self._tpairs.append((p._lmv_shadow, wt))
         self.refresh()
         rest_decay = [p for n, p in model.named_parameters() if p.requires_grad and id(p) not in seen and not no_decay(n, p)]
         rest_plain = [p for n, p in model.named_parameters() if p.requires_grad and id(p) not in seen and no_decay(n, p)]
@@ -129,11 +137,13 @@ class FlatAdamW:
         b1, b2 = g0["betas"]
         ops.adamw_flat(self._flat_p, self._flat_g, self._exp_avg, self._exp_avg_sq, self._wd_mask, float(g0["lr"]),
                        float(b1), float(b2), float(g0["eps"]), float(g0["weight_decay"]), 0, shadow=self._shadow, step_dev=self._step_dev)
+        ops.transpose_batch(self._tpairs)
 
     @torch.no_grad()
     def refresh(self) -> None:
-        """bf16 operand copies <- current fp32 parameters."""
+        """bf16 operand copies (and their transposed forms) <- current fp32 parameters."""
         self._shadow.copy_(self._flat_p)
+        ops.transpose_batch(self._tpairs)
 
     def state_dict(self) -> Dict[str, object]:
         return dict(step=int(self._step_dev.item()), exp_avg=self._exp_avg.clone(), exp_avg_sq=self._exp_avg_sq.clone(),

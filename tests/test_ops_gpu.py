@@ -503,3 +503,68 @@ def test_layernorm_bwd_two_call_form(dtype):
         outs.append([t.clone() for t in dxs] + [dg, db])
     for a, c in zip(*outs):
         assert torch.equal(a, c)
+
+
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("rows,rows_c,N,K", [(27136 // 8, 256, 1536, 384), (1000, 48, 576, 192), (129, 0, 64, 384), (4133, 16, 768, 192), (6400, 0, 1152, 384),
+                                             (300, 300, 128, 192)])
+def test_linear_rs_kernel(rows, rows_c, N, K):
+    """csrc/rsgemm.hip (register-stationary token panel GEMM, bf16, K = 192 / 384, N % 64 == 0) forced on for every shape it can run
+    (lmv_config_set("gemm_rs", 2)): plain / bias, GELU with and without the pre-activation copy, residual + DropPath scale, and the GELU'
+    epilogue of the dX-through-transposed-weight form -- ragged row counts, a second problem with its OWN weight and bias (the qkv1 / qkv2
+    launch of a D block), against float64 math on the operands the kernel reads; and against the 128 x 128 tile kernel on the same inputs."""
+    from lemevit_amd import _lib
+    o = ops()
+    dtype = torch.bfloat16
+    a, a64 = rnd((rows, K), "a", dtype); w, w64 = rnd((N, K), "w", dtype, 1 / math.sqrt(K))
+    bias = det_tensor((N,), "b", 7, 0.5).to(dev()); res, res64 = rnd((rows, N), "res", dtype)
+    uu, uu64 = rnd((rows, N), "u", dtype, 2.0)
+    rps = 7
+    rs = (det_tensor(((rows + rps - 1) // rps,), "rs", 7).abs() + 0.5).to(dev())
+    rs_rows = rs.cpu().double()[torch.arange(rows) // rps][:, None]
+    if rows_c:
+        ac, ac64 = rnd((rows_c, K), "ac", dtype); wc, wc64 = rnd((N, K), "wc", dtype, 1 / math.sqrt(K))
+        bc = det_tensor((N,), "bc", 7, 0.5).to(dev()); resc, resc64 = rnd((rows_c, N), "resc", dtype); uc, uc64 = rnd((rows_c, N), "uc", dtype, 2.0)
+    u = a64 @ w64.t() + bias.cpu().double()
+    outs = {}
+    try:
+        for mode in (2, 0):
+            _lib.config_set("gemm_rs", mode)
+            got = {}
+            out = torch.zeros((rows, N), device=dev(), dtype=dtype); pre = torch.zeros_like(out)
+            oc = torch.zeros((max(rows_c, 1), N), device=dev(), dtype=dtype); prec = torch.zeros_like(oc)
+
+            def probs(**kw):
+                ps = [o.Prob(a, w, out, **{k: v[0] for k, v in kw.items()})]
+                if rows_c:
+                    ps.append(o.Prob(ac, wc, oc, **{k: v[1] for k, v in kw.items()}))
+                return ps
+            o.linear_fwd(probs(), N, K)
+            got["plain"] = (out.clone(), oc.clone())
+            o.linear_fwd(probs(bias=(bias, bc if rows_c else None)), N, K)
+            got["bias"] = (out.clone(), oc.clone())
+            o.linear_fwd(probs(bias=(bias, bc if rows_c else None)), N, K, o.ACT_GELU)
+            got["gelu"] = (out.clone(), oc.clone())
+            o.linear_fwd(probs(bias=(bias, bc if rows_c else None), out_pre=(pre, prec)), N, K, o.ACT_GELU)
+            got["gelu+pre"] = (out.clone(), oc.clone()); got["pre"] = (pre.clone(), prec.clone())
+            o.linear_fwd(probs(bias=(bias, bc if rows_c else None), res=(res, resc if rows_c else None), row_scale=(rs, None), rps=(rps, 1)), N, K)
+            got["res"] = (out.clone(), oc.clone())
+            o.linear_fwd(probs(aux=(uu, uc if rows_c else None), row_scale=(rs, None), rps=(rps, 1)), N, K, o.ACT_GELU_GRAD)
+            got["ggrad"] = (out.clone(), oc.clone())
+            outs[mode] = got
+    finally:
+        _lib.config_set("gemm_rs", 1)
+    ref = {"plain": a64 @ w64.t(), "bias": u, "gelu": gelu64(u), "gelu+pre": gelu64(u), "pre": u, "res": res64 + rs_rows * u,
+           "ggrad": (a64 @ w64.t()) * gelu_grad64(uu64) * rs_rows}
+    if rows_c:
+        ucc = ac64 @ wc64.t() + bc.cpu().double()
+        refc = {"plain": ac64 @ wc64.t(), "bias": ucc, "gelu": gelu64(ucc), "gelu+pre": gelu64(ucc), "pre": ucc, "res": resc64 + ucc,
+                "ggrad": (ac64 @ wc64.t()) * gelu_grad64(uc64)}
+    for k, r in ref.items():
+        for mode in (2, 0):
+            assert_close(outs[mode][k][0], r, dtype, f"{k} (gemm_rs={mode})")
+            if rows_c:
+                assert_close(outs[mode][k][1], refc[k], dtype, f"{k} meta rows (gemm_rs={mode})")
+        # both kernels round the same fp32 accumulations: they may differ by the summation order only
+        d = float((outs[2][k][0].float() - outs[0][k][0].float()).abs().max()); m = float(r.abs().max())
+        assert d <= 8e-3 * m, f"{k}: RS and tile kernels differ by {d:.3e} (max-abs {m:.3e})"

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define LMV_ABI_VERSION 4
+#define LMV_ABI_VERSION 5
 
 enum { LMV_F32 = 0, LMV_BF16 = 1 };
 enum {
@@ -86,13 +86,19 @@ int lmv_linear_dw(const lmv_linear_problem* p, int nproblems, int N, int K, void
  * of any number of segments -- the weight gradients of a whole block -- into their out_w / out_b (accumulating, fixed summation
  * order: bit-identical to lmv_linear_dw) in ONE launch per LMV_REDUCE_MAX_SEGS segments. */
 #define LMV_REDUCE_MAX_SEGS 12
+#define LMV_REDUCE_SLABS 0   /* split-K slabs of a weight-gradient GEMM (summation tree of lmv_linear_dw)                              */
+#define LMV_REDUCE_ROWS  1   /* per-workgroup partial rows of a column reduction: LayerNorm dgamma | dbeta (lmv_layernorm_bwd_partial,  */
+                             /* mode 0) or the depth-wise convolution's [10][C] tap sums (lmv_dwconv3x3_bwd_weight_partial, mode 1:     */
+                             /* partial column tap * C + c -> out_w[c * 9 + tap], tap 9 -> out_b[c]); summation tree of the stand-alone */
+                             /* reduce of those ops, so the merged launch is bit-identical to them                                       */
 typedef struct {
   const float* ws;        /* first slab of the segment: [nslabs][slab_stride] fp32, a slab = [nw weights | nb bias sums]   */
   float* out_w;           /* fp32 [nw], accumulated                                                                          */
   float* out_b;           /* fp32 [nb], accumulated; NULL = no bias gradient                                                  */
-  int64_t slab_stride;    /* floats between consecutive slabs                                                                 */
+  int64_t slab_stride;    /* floats between consecutive slabs (LMV_REDUCE_ROWS: row width = nw + nb, or 10 * nw in mode 1)    */
   int64_t nw;
   int32_t nslabs, nb;
+  int32_t kind, mode;     /* LMV_REDUCE_SLABS (mode ignored) or LMV_REDUCE_ROWS with the output mapping `mode`                */
 } lmv_reduce_seg;
 int lmv_linear_dw_partial(const lmv_linear_problem* p, int nproblems, int N, int K, void* workspace, size_t workspace_bytes, int dtype, void* stream,
                           lmv_reduce_seg* segs, int* nsegs);
@@ -212,6 +218,10 @@ int lmv_dwconv3x3_residual_bwd_data(const void* dy, const float* weight, void* d
 size_t lmv_dwconv3x3_bwd_weight_workspace_bytes(int B, int H, int W, int C, int dtype);
 int lmv_dwconv3x3_bwd_weight(const void* dy, const void* x, float* dweight, float* dbias,
                              int B, int H, int W, int C, void* workspace, size_t workspace_bytes, int dtype, void* stream);
+/* Deferred form: only the tap-sum kernel runs; `*partial_rows` rows of [10][C] partial sums stay in `workspace` and are accumulated into
+ * dweight / dbias later by lmv_reduce_batch (segment kind LMV_REDUCE_ROWS, mode 1, nw = C, nb = C, slab_stride = 10 C, nslabs = rows). */
+int lmv_dwconv3x3_bwd_weight_partial(const void* dy, const void* x, int B, int H, int W, int C, void* workspace, size_t workspace_bytes,
+                                     int* partial_rows, int dtype, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Attention cores, head dim 32 (all registered variants, models/lemevit.py:851,881,911).

@@ -14,7 +14,7 @@ LIB_PATH = os.path.join(_HERE, "csrc", "liblemevit_hip.so")
 
 LMV_F32, LMV_BF16 = 0, 1
 ACT_NONE, ACT_GELU, ACT_GELU_GRAD = 0, 1, 2
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 
 class LinearProblem(C.Structure):
@@ -33,7 +33,7 @@ class MlpWeights(C.Structure):
 
 class ReduceSeg(C.Structure):
     _fields_ = [("ws", C.c_void_p), ("out_w", C.c_void_p), ("out_b", C.c_void_p), ("slab_stride", C.c_int64), ("nw", C.c_int64),
-                ("nslabs", C.c_int32), ("nb", C.c_int32)]
+                ("nslabs", C.c_int32), ("nb", C.c_int32), ("kind", C.c_int32), ("mode", C.c_int32)]
 
 
 class LnSegment(C.Structure):
@@ -102,6 +102,7 @@ SIGNATURES = {
     "lmv_dwconv3x3_residual_bwd_data": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "lmv_dwconv3x3_bwd_weight_workspace_bytes": (_Z, [_I, _I, _I, _I, _I]),
     "lmv_dwconv3x3_bwd_weight": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P, _Z, _I, _P]),
+    "lmv_dwconv3x3_bwd_weight_partial": (_I, [_P, _P, _I, _I, _I, _I, _P, _Z, C.POINTER(C.c_int), _I, _P]),
     "lmv_attn_workspace_bytes": (_Z, [_I, _I, _I, _I, _I]),
     "lmv_attn_fwd": (_I, [C.POINTER(AttnDesc), _P, _Z, _I, _P]),
     "lmv_attn_bwd": (_I, [C.POINTER(AttnDesc), _P, _Z, _I, _P]),

@@ -151,6 +151,14 @@ int mlp_fwd(const lmv_block_desc* d, const Dims& D, const Fwd& f, int s0, void* 
 struct Side {
   hipStream_t main, side; hipEvent_t fork, join; bool used;
   void* ws; size_t ws_bytes;
+  // The small column reductions of a block -- LayerNorm dgamma | dbeta rows of norm2 and norm1, the depth-wise convolution's tap sums --
+  // are DEFERRED: each keeps its own partial-sum buffer, describes it in `segs`, and ONE lmv_reduce_batch launch at the end of the
+  // block sums them all (same summation trees: bit-identical to the per-op reduces; 3 launches of ~5 us per block become one).
+  // The split-K slabs of the weight-gradient GEMMs are NOT deferred: summed right behind their GEMM they are read back out of the
+  // 256 MB MALL; kept until the end of the block (165 MB per stage-3 block) they go to HBM and back -- measured twice: +0.5 (round 2)
+  // and +0.8 ms per train step (round 3).
+  void* ws_tail; size_t ws_tail_bytes;         // region of the side workspace behind the weight-gradient slabs (dwconv tap sums)
+  lmv_reduce_seg segs[LMV_REDUCE_MAX_SEGS]; int nsegs = 0;
   hipStream_t begin() {           // the stream a weight-gradient launch goes to, made to wait for everything enqueued on `main` so far
     if (!side) return main;
     (void)hipEventRecord(fork, main);
@@ -211,10 +219,17 @@ int dw(Side& sd, const lmv_linear_problem* p, int np, int N, int K, int dtype) {
   if (need > sd.ws_bytes) LMV_FAIL(LMV_ERR_WORKSPACE, "block_bwd: weight-gradient workspace %zu > %zu bytes", need, sd.ws_bytes);
   return lmv_linear_dw(p, np, N, K, sd.ws, sd.ws_bytes, dtype, sd.begin());
 }
+// every deferred reduction of the block in one launch, on the side stream behind the launches that produced the partial sums
+int flush_reduces(Side& sd) {
+  if (!sd.nsegs) return LMV_OK;
+  const int rc = lmv_reduce_batch(sd.segs, sd.nsegs, sd.begin());
+  sd.nsegs = 0;
+  return rc;
+}
 
 struct Bwd {                      // backward temporaries ([0] image tokens, [1] meta tokens)
-  void *g[2], *du[2], *dn2[2], *dt2[2], *g2[2], *dao[2], *dpj[2], *dn1[2], *dxp, *ws_main, *ws_side, *ws_ln[2];
-  size_t ws_main_bytes, ws_side_bytes, ws_ln_bytes;
+  void *g[2], *du[2], *dn2[2], *dt2[2], *g2[2], *dao[2], *dpj[2], *dn1[2], *dxp, *ws_main, *ws_side, *ws_conv, *ws_ln[2];
+  size_t ws_main_bytes, ws_side_bytes, ws_conv_bytes, ws_ln_bytes;
 };
 
 size_t max_dw_ws(const Dims& D) {
@@ -231,14 +246,14 @@ size_t max_dw_ws(const Dims& D) {
   };
   const int C = D.C, Hd = D.Hd;
   if (D.kind == LMV_BLOCK_C) {
-    one(1, D.rows[1], 0, C, Hd, true); one(1, D.rows[1], 0, Hd, C, true); one(1, D.rows[1], 0, C, C, true); one(1, D.rows[0], 0, 2 * C, C, true);
+    one(1, D.rows[1], 0, C, Hd, true); one(1, D.rows[1], 0, Hd, C, true);                                           // fc2, fc1 (meta tokens)
+    one(1, D.rows[1], 0, C, C, true); one(1, D.rows[1], 0, C, C, true); one(1, D.rows[0], 0, 2 * C, C, true);      // proj, q (meta tokens), kv (image tokens)
   } else {
     const bool sh = D.kind == LMV_BLOCK_S;
     one(2, D.rows[0], D.rows[1], C, Hd, true); one(2, D.rows[0], D.rows[1], Hd, C, true);
     one(2, D.rows[0], D.rows[1], C, C, sh); one(2, D.rows[0], D.rows[1], 3 * C, C, sh);
   }
-  const size_t wc = lmv_dwconv3x3_bwd_weight_workspace_bytes(D.B, D.H, D.W, D.C, D.dtype);
-  return wc > m ? wc : m;
+  return (m + 255) & ~(size_t)255;
 }
 
 void layout_bwd(const Dims& D, Bump& a, Bwd* b) {
@@ -264,6 +279,7 @@ void layout_bwd(const Dims& D, Bump& a, Bwd* b) {
   if (w < 256) w = 256;
   b->ws_main_bytes = w; b->ws_main = a.take(w);
   b->ws_side_bytes = max_dw_ws(D); b->ws_side = a.take(b->ws_side_bytes);
+  b->ws_conv_bytes = lmv_dwconv3x3_bwd_weight_workspace_bytes(D.B, D.H, D.W, D.C, D.dtype); b->ws_conv = a.take(b->ws_conv_bytes);
   // LayerNorm dgamma / dbeta partial rows of norm2 and norm1: their reduces run on the side stream, so each keeps its own buffer
   b->ws_ln_bytes = lmv_layernorm_bwd_workspace_bytes(D.rows[0] + D.rows[1], D.C, D.dtype);
   for (int i = 0; i < 2; ++i) b->ws_ln[i] = a.take(b->ws_ln_bytes);
@@ -272,10 +288,14 @@ void layout_bwd(const Dims& D, Bump& a, Bwd* b) {
 // LayerNorm backward with the dgamma / dbeta reduce off the critical path: dx on the main stream, the ~5 us reduce launch behind a
 // fork on the weight-gradient side stream (in line when there is none)
 int ln_bwd(Side& sd, const lmv_ln_segment* seg, int nseg, const float* gamma, float* dgamma, float* dbeta, const Dims& D, void* ws, size_t ws_bytes) {
-  if (!sd.side) return lmv_layernorm_bwd(seg, nseg, gamma, dgamma, dbeta, D.C, ws, ws_bytes, D.dtype, sd.main);
   int rows = 0;
   LMV_TRY(lmv_layernorm_bwd_partial(seg, nseg, gamma, D.C, ws, ws_bytes, &rows, D.dtype, sd.main));
-  return lmv_layernorm_bwd_reduce(ws, rows, D.C, dgamma, dbeta, sd.begin());
+  if (sd.nsegs + 1 > LMV_REDUCE_MAX_SEGS) LMV_FAIL(LMV_ERR_WORKSPACE, "block_bwd: too many deferred reductions");
+  lmv_reduce_seg& sg = sd.segs[sd.nsegs++];      // (dgamma | dbeta) rows of the per-workgroup partial sums: summed by the block's reduce launch
+  sg = lmv_reduce_seg{};
+  sg.ws = (const float*)ws; sg.out_w = dgamma; sg.out_b = dbeta; sg.slab_stride = 2 * D.C; sg.nw = D.C; sg.nslabs = rows; sg.nb = D.C;
+  sg.kind = LMV_REDUCE_ROWS; sg.mode = 0;
+  return LMV_OK;
 }
 
 // MLP half backward (blocks.py::_mlp_bwd): douts = gradients of the block outputs, returns dt2 (gradient of the MLP half's input) and, where the
@@ -435,7 +455,9 @@ extern "C" int lmv_block_bwd(const lmv_block_desc* d, const void* x, const void*
   Bwd b;
   layout_bwd(D, s, &b);
   if (s.off > scratch_bytes) LMV_FAIL(LMV_ERR_WORKSPACE, "block_bwd: scratch %zu < %zu bytes", scratch_bytes, s.off);
-  Side sd{(hipStream_t)stream, (hipStream_t)side_stream, nullptr, nullptr, false, b.ws_side, b.ws_side_bytes};
+  Side sd{};
+  sd.main = (hipStream_t)stream; sd.side = (hipStream_t)side_stream; sd.ws = b.ws_side; sd.ws_bytes = b.ws_side_bytes;
+  sd.ws_tail = b.ws_conv; sd.ws_tail_bytes = b.ws_conv_bytes;
   if (side_stream) LMV_TRY(event_pool().take(&sd.fork, &sd.join));
   hipStream_t st = sd.main;
   const int C = D.C, N = D.N, M = D.M;
@@ -507,11 +529,16 @@ extern "C" int lmv_block_bwd(const lmv_block_desc* d, const void* x, const void*
       LMV_TRY(ln_bwd(sd, seg, 2, d->n1_w, d->g_n1_w, d->g_n1_b, D, b.ws_ln[1], b.ws_ln_bytes));
     }
     {
-      hipStream_t ss = sd.begin();
-      const size_t need = lmv_dwconv3x3_bwd_weight_workspace_bytes(D.B, D.H, D.W, C, D.dtype);
-      if (need > sd.ws_bytes) LMV_FAIL(LMV_ERR_WORKSPACE, "block_bwd: dwconv workspace %zu > %zu bytes", need, sd.ws_bytes);
-      LMV_TRY(lmv_dwconv3x3_bwd_weight(b.dxp, x, d->g_pos_w, d->g_pos_b, D.B, D.H, D.W, C, sd.ws, sd.ws_bytes, D.dtype, ss));
+      void* ws = sd.ws_tail;
+      if (sd.nsegs + 1 > LMV_REDUCE_MAX_SEGS) LMV_FAIL(LMV_ERR_WORKSPACE, "block_bwd: too many deferred reductions");
+      int rows = 0;
+      LMV_TRY(lmv_dwconv3x3_bwd_weight_partial(b.dxp, x, D.B, D.H, D.W, C, ws, sd.ws_tail_bytes, &rows, D.dtype, sd.begin()));
+      lmv_reduce_seg& sg = sd.segs[sd.nsegs++];
+      sg = lmv_reduce_seg{};
+      sg.ws = (const float*)ws; sg.out_w = d->g_pos_w; sg.out_b = d->g_pos_b; sg.slab_stride = 10 * C; sg.nw = C; sg.nslabs = rows; sg.nb = C;
+      sg.kind = LMV_REDUCE_ROWS; sg.mode = 1;
     }
+    LMV_TRY(flush_reduces(sd));
     return lmv_dwconv3x3_residual_bwd_data(b.dxp, d->pos_w, dx, D.B, D.H, D.W, C, D.dtype, st);
   };
   rc = body();

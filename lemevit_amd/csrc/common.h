@@ -29,6 +29,45 @@ void lmv_set_error(const char* fmt, ...);
 // mode 1 (dwconv, partial index i = tap * C + c with na = C): tap < 9 -> out_a[c * 9 + tap], tap == 9 -> out_b[c].
 int lmv_launch_partial_reduce(const float* partial, int nrows, int width, float* out_a, int na, float* out_b, int mode, hipStream_t st);
 
+// Workgroup body of the partial-row reduction (partial_reduce_kernel, misc.hip; also run by the blocks of lmv_reduce_batch that own a
+// LMV_REDUCE_ROWS segment, gemm.hip -- ONE summation tree, so the merged launch is bit-identical to the stand-alone one):
+// 8 float4 columns (128 B of each partial row) x 32 row-groups per workgroup `blk`; every thread sums rows rg, rg + 32, ... with four
+// independent 16-byte loads in flight, then the 32 row-groups are combined through LDS (red: 256 float4).
+static __device__ __forceinline__ void lmv_partial_reduce_block(float4* red, int blk, const float* __restrict__ partial, int nrows, int width,
+                                                                float* __restrict__ out_a, int na, float* __restrict__ out_b, int mode) {
+  const int cx = threadIdx.x & 7, rg = threadIdx.x >> 3, i = (blk * 8 + cx) * 4;
+  float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (i < width) {
+    const float* p = partial + i;
+    int r = rg;
+    for (; r + 96 < nrows; r += 128) {
+      const float4 v0 = *reinterpret_cast<const float4*>(p + (int64_t)r * width);
+      const float4 v1 = *reinterpret_cast<const float4*>(p + (int64_t)(r + 32) * width);
+      const float4 v2 = *reinterpret_cast<const float4*>(p + (int64_t)(r + 64) * width);
+      const float4 v3 = *reinterpret_cast<const float4*>(p + (int64_t)(r + 96) * width);
+      a.x += (v0.x + v1.x) + (v2.x + v3.x); a.y += (v0.y + v1.y) + (v2.y + v3.y);
+      a.z += (v0.z + v1.z) + (v2.z + v3.z); a.w += (v0.w + v1.w) + (v2.w + v3.w);
+    }
+    for (; r < nrows; r += 32) {
+      const float4 v = *reinterpret_cast<const float4*>(p + (int64_t)r * width);
+      a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+    }
+  }
+  red[rg * 8 + cx] = a;
+  __syncthreads();
+  if (rg == 0 && i < width) {
+#pragma unroll 8
+    for (int k = 1; k < 32; ++k) { const float4 v = red[k * 8 + cx]; a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w; }
+    const float s[4] = {a.x, a.y, a.z, a.w};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int j = i + e;
+      if (mode == 0) { if (j < na) out_a[j] += s[e]; else out_b[j - na] += s[e]; }
+      else { const int t = j / na, ch = j - t * na; if (t < 9) out_a[ch * 9 + t] += s[e]; else out_b[ch] += s[e]; }
+    }
+  }
+}
+
 // ---- A/B switches ------------------------------------------------------------------------------
 // Every tuning switch of the library lives here.  The environment (LMV_*) is read ONCE, when the library is loaded -- never on a launch
 // path -- and lmv_config_set(key, value) changes a switch at run time (tests and the tools/ sweeps use it).  Defaults = measured best.

@@ -288,21 +288,35 @@ extern "C" size_t lmv_dwconv3x3_bwd_weight_workspace_bytes(int B, int H, int W, 
   return (size_t)bwd_w_blocks(make_geo(B, H, W, C, dtype, RW, true), TPB / nch) * 10 * C * sizeof(float);
 }
 
-extern "C" int lmv_dwconv3x3_bwd_weight(const void* dy, const void* x, float* dweight, float* dbias, int B, int H, int W, int C,
-                                        void* workspace, size_t workspace_bytes, int dtype, void* stream) {
-  if (int rc = check("dwconv_bwd_weight", dy, x, B, H, W, C, dtype)) return rc;
-  if (!dweight || !dbias) LMV_FAIL(LMV_ERR_SHAPE, "dwconv_bwd_weight: null gradient buffer");
-  hipStream_t st = (hipStream_t)stream;
+namespace {
+int dwconv_bwd_weight_launch(const char* who, const void* dy, const void* x, int B, int H, int W, int C, void* workspace, size_t workspace_bytes, int dtype,
+                             hipStream_t st, int* rows) {
+  if (int rc = check(who, dy, x, B, H, W, C, dtype)) return rc;
   const int nch = C / (dtype == LMV_BF16 ? 8 : 4);
-  if (nch > TPB) LMV_FAIL(LMV_ERR_SHAPE, "dwconv_bwd_weight: C=%d too wide", C);
+  if (nch > TPB) LMV_FAIL(LMV_ERR_SHAPE, "%s: C=%d too wide", who, C);
   const Geo g = make_geo(B, H, W, C, dtype, RW, true);
   const int slots = TPB / nch, threads = slots * nch;
   const int blocks = bwd_w_blocks(g, slots);
   const size_t need = (size_t)blocks * 10 * C * sizeof(float);
-  if (!workspace || workspace_bytes < need) LMV_FAIL(LMV_ERR_WORKSPACE, "dwconv_bwd_weight: workspace %zu < %zu bytes", workspace_bytes, need);
+  if (!workspace || workspace_bytes < need) LMV_FAIL(LMV_ERR_WORKSPACE, "%s: workspace %zu < %zu bytes", who, workspace_bytes, need);
   float* partial = reinterpret_cast<float*>(workspace);
   if (dtype == LMV_BF16) hipLaunchKernelGGL((dwconv_bwd_w_kernel<bf16_t>), dim3(blocks), dim3(threads), 0, st, (const bf16_t*)dy, (const bf16_t*)x, partial, g, slots);
   else hipLaunchKernelGGL((dwconv_bwd_w_kernel<float>), dim3(blocks), dim3(threads), 0, st, (const float*)dy, (const float*)x, partial, g, slots);
-  LMV_CHECK_LAUNCH("dwconv_bwd_weight");
-  return lmv_launch_partial_reduce(partial, blocks, 10 * C, dweight, C, dbias, 1, st);
+  LMV_CHECK_LAUNCH(who);
+  *rows = blocks;
+  return LMV_OK;
+}
+}  // namespace
+
+extern "C" int lmv_dwconv3x3_bwd_weight(const void* dy, const void* x, float* dweight, float* dbias, int B, int H, int W, int C,
+                                        void* workspace, size_t workspace_bytes, int dtype, void* stream) {
+  if (!dweight || !dbias) LMV_FAIL(LMV_ERR_SHAPE, "dwconv_bwd_weight: null gradient buffer");
+  int rows = 0;
+  if (int rc = dwconv_bwd_weight_launch("dwconv_bwd_weight", dy, x, B, H, W, C, workspace, workspace_bytes, dtype, (hipStream_t)stream, &rows)) return rc;
+  return lmv_launch_partial_reduce(reinterpret_cast<const float*>(workspace), rows, 10 * C, dweight, C, dbias, 1, (hipStream_t)stream);
+}
+extern "C" int lmv_dwconv3x3_bwd_weight_partial(const void* dy, const void* x, int B, int H, int W, int C, void* workspace, size_t workspace_bytes,
+                                                int* partial_rows, int dtype, void* stream) {
+  if (!partial_rows) LMV_FAIL(LMV_ERR_SHAPE, "dwconv_bwd_weight_partial: partial_rows must not be NULL");
+  return dwconv_bwd_weight_launch("dwconv_bwd_weight_partial", dy, x, B, H, W, C, workspace, workspace_bytes, dtype, (hipStream_t)stream, partial_rows);
 }

@@ -310,7 +310,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
 // end every dW GEMM with its own ~7 us reduce launch (~160 per train step, mostly launch ramp and tail); the GEMMs of a block now
 // leave their slabs in distinct workspace regions and one launch sums them all.  Same fixed summation tree per element as
 // splitk_reduce_kernel<SL> (sl slab lanes per element, chosen per segment), so results are bit-identical to the per-GEMM path.
-struct ReduceSegDev { const float* ws; float* out_w; float* out_b; int64_t stride, nw; int nslabs, nb, sl, blk0; };
+struct ReduceSegDev { const float* ws; float* out_w; float* out_b; int64_t stride, nw; int nslabs, nb, sl, blk0, kind, mode; };
 struct ReduceBatch { ReduceSegDev s[LMV_REDUCE_MAX_SEGS]; int n; };
 
 __global__ __launch_bounds__(256) void splitk_reduce_batch_kernel(const ReduceBatch rb) {
@@ -319,6 +319,10 @@ __global__ __launch_bounds__(256) void splitk_reduce_batch_kernel(const ReduceBa
 #pragma unroll
   for (int k = 1; k < LMV_REDUCE_MAX_SEGS; ++k) if (k < rb.n && (int)blockIdx.x >= rb.s[k].blk0) si = k;
   const ReduceSegDev& g = rb.s[si];
+  if (g.kind == LMV_REDUCE_ROWS) {              // block-uniform: partial rows of a column reduction (LayerNorm dgamma | dbeta, dwconv tap sums)
+    lmv_partial_reduce_block(red, (int)blockIdx.x - g.blk0, g.ws, g.nslabs, (int)g.stride, g.out_w, (int)g.nw, g.out_b, g.mode);
+    return;
+  }
   const int SL = g.sl, EL = 256 / SL;
   const int64_t n4 = (g.nw + (g.out_b ? g.nb : 0)) >> 2;
   const int e = threadIdx.x % EL, sl = threadIdx.x / EL;
@@ -545,6 +549,7 @@ int launch(const lmv_linear_problem* p, int nproblems, int N, int K, int act, in
       if (segs) {                                  // deferred: the caller sums the slabs later with lmv_reduce_batch
         lmv_reduce_seg& sg = segs[(*nsegs)++];
         sg.ws = base; sg.nslabs = nslabs; sg.slab_stride = g.slab_stride; sg.out_w = outw; sg.nw = nw; sg.out_b = p[i].bias_grad; sg.nb = N;
+        sg.kind = LMV_REDUCE_SLABS; sg.mode = 0;
         continue;
       }
       const int sl = reduce_lanes(n4, nslabs);
@@ -634,13 +639,22 @@ extern "C" int lmv_reduce_batch(const lmv_reduce_seg* segs, int nsegs, void* str
     for (int i = 0; i < rb.n; ++i) {
       const lmv_reduce_seg& q = segs[s0 + i];
       if (!q.ws || !q.out_w || q.nslabs <= 0 || q.nw <= 0 || (q.nw % 4) || (q.out_b && (q.nb % 4)) || !lmv_aligned16(q.ws) || !lmv_aligned16(q.out_w) ||
-          !lmv_aligned16(q.out_b) || (q.slab_stride % 4))
+          !lmv_aligned16(q.out_b) || (q.slab_stride % 4) || (q.kind != LMV_REDUCE_SLABS && q.kind != LMV_REDUCE_ROWS))
         LMV_FAIL(LMV_ERR_SHAPE, "reduce_batch: bad segment %d", s0 + i);
       const int64_t n4 = (q.nw + (q.out_b ? q.nb : 0)) / 4;
       ReduceSegDev& d = rb.s[i];
       d.ws = q.ws; d.out_w = q.out_w; d.out_b = q.out_b; d.stride = q.slab_stride; d.nw = q.nw; d.nslabs = q.nslabs; d.nb = q.nb;
-      d.sl = reduce_lanes(n4, q.nslabs);
+      d.kind = q.kind; d.mode = q.mode;
       d.blk0 = blocks;
+      if (q.kind == LMV_REDUCE_ROWS) {           // 32 columns per block (partial_reduce_kernel's geometry); the row width is the slab stride
+        if (!q.out_b || q.slab_stride > 0x7fffffff || q.nw > 0x7fffffff || (q.mode != 0 && q.mode != 1) ||
+            (q.mode == 0 && q.slab_stride != q.nw + q.nb) || (q.mode == 1 && q.slab_stride != 10 * q.nw))
+          LMV_FAIL(LMV_ERR_SHAPE, "reduce_batch: bad partial-row segment %d", s0 + i);
+        d.sl = 1;
+        blocks += (int)((q.slab_stride / 4 + 7) / 8);
+        continue;
+      }
+      d.sl = reduce_lanes(n4, q.nslabs);
       blocks += (int)((n4 * d.sl + 255) / 256);
     }
     hipLaunchKernelGGL(splitk_reduce_batch_kernel, dim3(blocks), dim3(256), 0, st, rb);

@@ -249,42 +249,11 @@ __global__ __launch_bounds__(TPB) void adamw_kernel(float* __restrict__ p, const
   }
 }
 
-// 8 float4 columns (128 B of each partial row) x 32 row-groups per workgroup; every thread sums rows rg, rg+32, ...
-// with four independent 16-byte loads in flight, then the 32 row-groups are combined through LDS.
+// out[map(i)] += sum_r partial[r][i]: the workgroup body lives in common.h (lmv_partial_reduce_block), shared with lmv_reduce_batch
 __global__ __launch_bounds__(256) void partial_reduce_kernel(const float* __restrict__ partial, int nrows, int width, float* __restrict__ out_a, int na,
                                                             float* __restrict__ out_b, int mode) {
-  __shared__ float4 red[32][8];
-  const int cx = threadIdx.x & 7, rg = threadIdx.x >> 3, i = (blockIdx.x * 8 + cx) * 4;
-  float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (i < width) {
-    const float* p = partial + i;
-    int r = rg;
-    for (; r + 96 < nrows; r += 128) {
-      const float4 v0 = *reinterpret_cast<const float4*>(p + (int64_t)r * width);
-      const float4 v1 = *reinterpret_cast<const float4*>(p + (int64_t)(r + 32) * width);
-      const float4 v2 = *reinterpret_cast<const float4*>(p + (int64_t)(r + 64) * width);
-      const float4 v3 = *reinterpret_cast<const float4*>(p + (int64_t)(r + 96) * width);
-      a.x += (v0.x + v1.x) + (v2.x + v3.x); a.y += (v0.y + v1.y) + (v2.y + v3.y);
-      a.z += (v0.z + v1.z) + (v2.z + v3.z); a.w += (v0.w + v1.w) + (v2.w + v3.w);
-    }
-    for (; r < nrows; r += 32) {
-      const float4 v = *reinterpret_cast<const float4*>(p + (int64_t)r * width);
-      a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
-    }
-  }
-  red[rg][cx] = a;
-  __syncthreads();
-  if (rg == 0 && i < width) {
-#pragma unroll 8
-    for (int k = 1; k < 32; ++k) { const float4 v = red[k][cx]; a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w; }
-    const float s[4] = {a.x, a.y, a.z, a.w};
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const int j = i + e;
-      if (mode == 0) { if (j < na) out_a[j] += s[e]; else out_b[j - na] += s[e]; }
-      else { const int t = j / na, ch = j - t * na; if (t < 9) out_a[ch * 9 + t] += s[e]; else out_b[ch] += s[e]; }
-    }
-  }
+  __shared__ float4 red[256];
+  lmv_partial_reduce_block(red, blockIdx.x, partial, nrows, width, out_a, na, out_b, mode);
 }
 
 }  // namespace

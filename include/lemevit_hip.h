@@ -357,6 +357,10 @@ typedef struct lmv_block_desc {
    * of fc2 -- du = (dOut W2) * GELU'(u) -- as the forward-form GEMM  dOut [rows, C] x fc2_wt^T  with the GELU' epilogue, which the
    * register-stationary kernel (csrc/rsgemm.hip) takes for C = 192 / 384.  Must hold the same values as fc2_w. */
   const void* fc2_wt;
+  /* optional (NULL = absent), S blocks: mlp.0.weight TRANSPOSED [C, hidden] and the attention weights attn_w[0] (qkv) / attn_w[1] (proj)
+   * TRANSPOSED [C, 3C] / [C, C] in `dtype`.  With them lmv_block_bwd runs the dX of fc1 / qkv / proj as forward-form GEMMs
+   * dY [rows, N] x wt^T -> [rows, C], which the whole-width kernel (csrc/wngemm.hip) takes for C = 384.  Same values as the weights. */
+  const void* fc1_wt; const void* attn_wt[2];
 } lmv_block_desc;
 size_t lmv_block_arena_bytes(const lmv_block_desc* d);
 size_t lmv_block_bwd_scratch_bytes(const lmv_block_desc* d);

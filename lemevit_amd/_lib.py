@@ -61,7 +61,7 @@ class BlockDesc(C.Structure):
                 [(n, C.c_void_p) for n in ("g_pos_w", "g_pos_b", "g_n1_w", "g_n1_b")] + [("g_attn_w", C.c_void_p * 4), ("g_attn_b", C.c_void_p * 4)] +
                 [(n, C.c_void_p) for n in ("g_n2_w", "g_n2_b", "g_fc1_w", "g_fc1_b", "g_fc2_w", "g_fc2_b")] +
                 [("fold_attn_w", C.c_void_p * 2), ("fold_attn_s", C.c_void_p * 2), ("fold_attn_b", C.c_void_p * 2)] +
-                [(n, C.c_void_p) for n in ("fold_fc1_w", "fold_fc1_s", "fold_fc1_b", "fc2_wt")])
+                [(n, C.c_void_p) for n in ("fold_fc1_w", "fold_fc1_s", "fold_fc1_b", "fc2_wt", "fc1_wt")] + [("attn_wt", C.c_void_p * 2)])
 
 
 class TransposeSeg(C.Structure):

@@ -325,8 +325,13 @@ int mlp_bwd(const lmv_block_desc* d, const Dims& D, const Fwd& f, const Bwd& b, 
   }
   for (int i = 0; i < ns; ++i) { const int s = s0 + i; p[i] = prob(b.du[s], f.n2[s], d->g_fc1_w, D.rows[s]); p[i].bias_grad = d->g_fc1_b; }
   LMV_TRY(dw(sd, p, ns, D.Hd, D.C, D.dtype));
-  for (int i = 0; i < ns; ++i) { const int s = s0 + i; p[i] = prob(b.du[s], d->fc1_w, b.dn2[s], D.rows[s]); }
-  LMV_TRY(lmv_linear_dx(p, ns, D.Hd, D.C, LMV_ACT_NONE, D.dtype, st));
+  if (d->fc1_wt && D.dtype == LMV_BF16) {      // dX of fc1 as a forward-form GEMM on the transposed weight copy [C, hidden] (csrc/wngemm.hip at C = 384)
+    for (int i = 0; i < ns; ++i) { const int s = s0 + i; p[i] = prob(b.du[s], d->fc1_wt, b.dn2[s], D.rows[s]); }
+    LMV_TRY(lmv_linear_fwd(p, ns, D.C, D.Hd, LMV_ACT_NONE, D.dtype, st));
+  } else {
+    for (int i = 0; i < ns; ++i) { const int s = s0 + i; p[i] = prob(b.du[s], d->fc1_w, b.dn2[s], D.rows[s]); }
+    LMV_TRY(lmv_linear_dx(p, ns, D.Hd, D.C, LMV_ACT_NONE, D.dtype, st));
+  }
   lmv_ln_segment seg[2] = {};
   for (int i = 0; i < ns; ++i) {
     const int s = s0 + i;
@@ -500,8 +505,13 @@ extern "C" int lmv_block_bwd(const lmv_block_desc* d, const void* x, const void*
       const bool sh = D.kind == LMV_BLOCK_S;
       for (int s2 = 0; s2 < 2; ++s2) { p[s2] = prob(g2[s2], f.ao[s2], sh ? d->g_attn_w[1] : d->g_attn_w[2 + s2], D.rows[s2]); p[s2].bias_grad = sh ? d->g_attn_b[1] : d->g_attn_b[2 + s2]; }
       LMV_TRY(dw(sd, p, 2, C, C, D.dtype));
-      for (int s2 = 0; s2 < 2; ++s2) p[s2] = prob(g2[s2], sh ? d->attn_w[1] : d->attn_w[2 + s2], b.dao[s2], D.rows[s2]);
-      LMV_TRY(lmv_linear_dx(p, 2, C, C, LMV_ACT_NONE, D.dtype, st));
+      if (sh && d->attn_wt[1] && D.dtype == LMV_BF16) {      // dX of proj / qkv on the transposed weight copies (forward-form GEMM, csrc/wngemm.hip)
+        for (int s2 = 0; s2 < 2; ++s2) p[s2] = prob(g2[s2], d->attn_wt[1], b.dao[s2], D.rows[s2]);
+        LMV_TRY(lmv_linear_fwd(p, 2, C, C, LMV_ACT_NONE, D.dtype, st));
+      } else {
+        for (int s2 = 0; s2 < 2; ++s2) p[s2] = prob(g2[s2], sh ? d->attn_w[1] : d->attn_w[2 + s2], b.dao[s2], D.rows[s2]);
+        LMV_TRY(lmv_linear_dx(p, 2, C, C, LMV_ACT_NONE, D.dtype, st));
+      }
       if (sh) {
         for (int s2 = 0; s2 < 2; ++s2) {
           const int L = s2 == 0 ? N : M;
@@ -521,8 +531,13 @@ extern "C" int lmv_block_bwd(const lmv_block_desc* d, const void* x, const void*
       }
       for (int s2 = 0; s2 < 2; ++s2) { p[s2] = prob(b.dpj[s2], f.n1[s2], sh ? d->g_attn_w[0] : d->g_attn_w[s2], D.rows[s2]); p[s2].bias_grad = sh ? d->g_attn_b[0] : d->g_attn_b[s2]; }
       LMV_TRY(dw(sd, p, 2, 3 * C, C, D.dtype));
-      for (int s2 = 0; s2 < 2; ++s2) p[s2] = prob(b.dpj[s2], sh ? d->attn_w[0] : d->attn_w[s2], b.dn1[s2], D.rows[s2]);
-      LMV_TRY(lmv_linear_dx(p, 2, 3 * C, C, LMV_ACT_NONE, D.dtype, st));
+      if (sh && d->attn_wt[0] && D.dtype == LMV_BF16) {
+        for (int s2 = 0; s2 < 2; ++s2) p[s2] = prob(b.dpj[s2], d->attn_wt[0], b.dn1[s2], D.rows[s2]);
+        LMV_TRY(lmv_linear_fwd(p, 2, C, 3 * C, LMV_ACT_NONE, D.dtype, st));
+      } else {
+        for (int s2 = 0; s2 < 2; ++s2) p[s2] = prob(b.dpj[s2], sh ? d->attn_w[0] : d->attn_w[s2], b.dn1[s2], D.rows[s2]);
+        LMV_TRY(lmv_linear_dx(p, 2, 3 * C, C, LMV_ACT_NONE, D.dtype, st));
+      }
       lmv_ln_segment seg[2] = {};
       seg[0].x = f.xp; seg[0].dy = b.dn1[0]; seg[0].stats = f.st1[0]; seg[0].dres = b.dt2[0]; seg[0].dx = b.dxp; seg[0].rows = D.rows[0];
       seg[1].x = c; seg[1].dy = b.dn1[1]; seg[1].stats = f.st1[1]; seg[1].dres = b.dt2[1]; seg[1].dx = dc; seg[1].rows = D.rows[1];

@@ -80,6 +80,7 @@ struct LmvConfig {
   int gemm_w8;            // LMV_GEMM_W8            1: 8-wave 64-deep forward kernel; 2: also for every dX launch; 0: off
   int gemm_cumap;         // LMV_GEMM_CUMAP         1: CU-aware tile order
   int gemm_nst, gemm_nst_dw;   // LMV_GEMM_NST / _DW ring depth of the 32-deep loop (2 / 3)
+  int gemm_wn;            // LMV_GEMM_WN            1: whole-width kernel (wngemm.hip) for the 384-wide forward-form launches where it measured faster; 0: off; 2: wherever it applies
   int gemm_rs;            // LMV_GEMM_RS            1: register-stationary kernels (rsgemm.hip) where they measured faster; 0: off; 2: wherever they apply
   int dwconv_v;           // LMV_DWCONV_V           0 = auto: rows per thread of the depth-wise convolution kernels
   int mlp_tm;             // LMV_MLP_TM             0 = auto: token rows per workgroup of the fused MLP kernel (64 / 128)
@@ -91,6 +92,9 @@ LmvConfig& lmv_config();
 // rsgemm.hip: the register-stationary GEMM for wide short-reduction forward-form launches (bf16)
 bool lmv_rs_eligible(const lmv_linear_problem* p, int nproblems, int N, int K, int act, bool force);
 int lmv_rs_linear(const lmv_linear_problem* p, int nproblems, int N, int K, int act, hipStream_t st);
+// wngemm.hip: one workgroup per 128-row token panel and ALL 384 output columns (bf16, forward form)
+bool lmv_wn_eligible(const lmv_linear_problem* p, int nproblems, int N, int K, int act, bool force);
+int lmv_wn_linear(const lmv_linear_problem* p, int nproblems, int N, int K, int act, hipStream_t st);
 
 static inline bool lmv_aligned16(const void* p) { return (((uintptr_t)p) & 15u) == 0; }
 

@@ -521,6 +521,8 @@ int launch(const lmv_linear_problem* p, int nproblems, int N, int K, int act, in
   if (int rc = make_plan(p, nproblems, N, K, act, dtype, mode, &pl)) return rc;      // (validates the operands)
   if (mode == MODE_FWD && dtype == LMV_BF16 && lmv_config().gemm_rs && lmv_rs_eligible(p, nproblems, N, K, act, lmv_config().gemm_rs == 2))
     return lmv_rs_linear(p, nproblems, N, K, act, (hipStream_t)stream);              // register-stationary kernel (rsgemm.hip)
+  if (mode == MODE_FWD && dtype == LMV_BF16 && lmv_config().gemm_wn && lmv_wn_eligible(p, nproblems, N, K, act, lmv_config().gemm_wn == 2))
+    return lmv_wn_linear(p, nproblems, N, K, act, (hipStream_t)stream);              // whole-width kernel (wngemm.hip)
   GemmArgs& g = pl.g;
   if (mode == MODE_DW) {
     if (!ws || ws_bytes < pl.ws_bytes || !lmv_aligned16(ws)) LMV_FAIL(LMV_ERR_WORKSPACE, "linear_dw: workspace %zu < %zu bytes", ws_bytes, pl.ws_bytes);

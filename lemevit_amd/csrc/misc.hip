@@ -25,7 +25,7 @@ const ConfigKey kConfigKeys[] = {
     {"dw_bk", "LMV_DW_BK", &LmvConfig::dw_bk, 32}, {"dw_target_blocks", "LMV_DW_TARGET_BLOCKS", &LmvConfig::dw_target_blocks, 0},
     {"gemm_no_dma", "LMV_GEMM_NO_DMA", &LmvConfig::gemm_no_dma, 0}, {"gemm_w8", "LMV_GEMM_W8", &LmvConfig::gemm_w8, 1},
     {"gemm_cumap", "LMV_GEMM_CUMAP", &LmvConfig::gemm_cumap, 1}, {"gemm_nst", "LMV_GEMM_NST", &LmvConfig::gemm_nst, 2},
-    {"gemm_nst_dw", "LMV_GEMM_NST_DW", &LmvConfig::gemm_nst_dw, 3}, {"gemm_rs", "LMV_GEMM_RS", &LmvConfig::gemm_rs, 1},
+    {"gemm_nst_dw", "LMV_GEMM_NST_DW", &LmvConfig::gemm_nst_dw, 3}, {"gemm_rs", "LMV_GEMM_RS", &LmvConfig::gemm_rs, 1}, {"gemm_wn", "LMV_GEMM_WN", &LmvConfig::gemm_wn, 1},
     {"dwconv_v", "LMV_DWCONV_V", &LmvConfig::dwconv_v, 0},
     {"mlp_tm", "LMV_MLP_TM", &LmvConfig::mlp_tm, 0}, {"attn_pv16", "LMV_ATTN_PV16", &LmvConfig::attn_pv16, 1},
     {"attn_fuse_dq", "LMV_ATTN_FUSE_DQ", &LmvConfig::attn_fuse_dq, 1}, {"attn_fused_bwd", "LMV_ATTN_FUSED_BWD", &LmvConfig::attn_fused_bwd, 1},

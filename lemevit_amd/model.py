@@ -529,7 +529,10 @@ def _fill_ptrs(desc, kind: str, names, tensors: Dict[str, Tensor], prefix: str) 
             getattr(desc, prefix + ("attn_w" if kindof == "weight" else "attn_b"))[slots[base]] = t.data_ptr()
 
 
-def _block_desc(kind: str, x: Tensor, c: Tensor, H: int, W: int, names, P: Dict[str, Tensor], masks, folds=None, fc2_wt: Optional[Tensor] = None):
+_WT_FIELDS = {"mlp.3.weight": ("fc2_wt", None), "mlp.0.weight": ("fc1_wt", None), "attn.qkv.weight": ("attn_wt", 0), "attn.proj.weight": ("attn_wt", 1)}
+
+
+def _block_desc(kind: str, x: Tensor, c: Tensor, H: int, W: int, names, P: Dict[str, Tensor], masks, folds=None, wts: Optional[Dict[str, Tensor]] = None):
     from ._lib import BlockDesc
     d = BlockDesc()
     d.kind, d.dtype = _KIND_CODE[kind], ops.dtype_code(x)
@@ -546,11 +549,15 @@ def _block_desc(kind: str, x: Tensor, c: Tensor, H: int, W: int, names, P: Dict[
             if m.dtype != torch.float32 or not m.is_contiguous():
                 raise TypeError("lemevit_amd: DropPath scale vectors must be contiguous float32")
             d.masks[i] = m.data_ptr()
-    if fc2_wt is not None:                  # transposed mlp.3 weight (FlatAdamW keeps it): the dX of fc2 runs as a forward-form GEMM
-        w2 = P["mlp.3.weight"]
-        if fc2_wt.dtype == w2.dtype == torch.bfloat16 and fc2_wt.shape == (w2.shape[1], w2.shape[0]) and fc2_wt.is_contiguous() and fc2_wt.device == w2.device:
-            d.fc2_wt = fc2_wt.data_ptr()
-            d._fc2_wt = fc2_wt
+    if wts:                                 # transposed weight copies (FlatAdamW keeps them): those dX run as forward-form GEMMs
+        d._wts = wts
+        for n, wt in wts.items():
+            w, (field, slot) = P[n], _WT_FIELDS[n]
+            if wt.dtype == w.dtype == torch.bfloat16 and wt.shape == (w.shape[1], w.shape[0]) and wt.is_contiguous() and wt.device == w.device:
+                if slot is None:
+                    setattr(d, field, wt.data_ptr())
+                else:
+                    getattr(d, field)[slot] = wt.data_ptr()
     if folds is not None:                   # LMV_BLOCK_FUSED: inference with LayerNorm folded into the projections / the one-kernel MLP half
         attn, fc1 = folds
         for k, F in enumerate(attn):
@@ -580,10 +587,10 @@ def _persistent(tag: str, nbytes: int, device) -> Tensor:
     return t
 
 
-def native_block_forward(kind: str, x: Tensor, c: Tensor, H: int, W: int, names, P: Dict[str, Tensor], masks, save: bool, folds=None, fc2_wt=None):
+def native_block_forward(kind: str, x: Tensor, c: Tensor, H: int, W: int, names, P: Dict[str, Tensor], masks, save: bool, folds=None, wts=None):
     """lmv_block_fwd: returns (x_out, c_out, state) with state = (descriptor, arena) for native_block_backward (save=True)."""
     from ._lib import lib, check
-    d = _block_desc(kind, x, c, H, W, names, P, masks, None if save else folds, fc2_wt if save else None)
+    d = _block_desc(kind, x, c, H, W, names, P, masks, None if save else folds, wts if save else None)
     nbytes = _sized(lib.lmv_block_arena_bytes, d, kind, x, c, H, W)
     arena = torch.empty(nbytes, device=x.device, dtype=torch.uint8) if save else _persistent("fwd", nbytes, x.device)
     xo = torch.empty_like(x) if kind != "C" else None
@@ -628,11 +635,15 @@ class _BlockFn(torch.autograd.Function):
         P = {n: compute_copy(p, cd if _is_matrix(n) else torch.float32) for n, p in zip(names, params)}
         ctx.native = _native_ok(kind, x, c)
         if ctx.native:
-            # the transposed mlp.3 copy is only valid next to the shadow it was made from (FlatAdamW refreshes both in one step)
-            w2 = params[names.index("mlp.3.weight")]
-            wt = getattr(w2, "_lmv_shadow_t", None) if P["mlp.3.weight"] is getattr(w2, "_lmv_shadow", None) or (
-                getattr(w2, "_lmv_shadow", None) is not None and P["mlp.3.weight"].data_ptr() == w2._lmv_shadow.data_ptr()) else None
-            xo, co, state = native_block_forward(kind, x, c, H, W, names, P, masks, save=True, fc2_wt=wt)
+            # a transposed copy is only valid next to the shadow it was made from (FlatAdamW refreshes both in one step)
+            wts = {}
+            for n in _WT_FIELDS:
+                if n in names:
+                    w = params[names.index(n)]
+                    sh, wt = getattr(w, "_lmv_shadow", None), getattr(w, "_lmv_shadow_t", None)
+                    if wt is not None and sh is not None and (P[n] is sh or P[n].data_ptr() == sh.data_ptr()):
+                        wts[n] = wt
+            xo, co, state = native_block_forward(kind, x, c, H, W, names, P, masks, save=True, wts=wts)
             saved = (x, c, state)
         else:
             xo, co, saved = block_forward(kind, x, c, H, W, P, masks, save=True)

@@ -79,8 +79,11 @@ class FlatAdamW:
         # transposed bf16 copies of the mlp.3 weights of the blocks whose fc2 dX runs on the register-stationary GEMM (C = 192 / 384 and a
         # hidden width that is a multiple of 64, csrc/rsgemm.hip): refreshed by ONE lmv_transpose_batch launch behind every update
         self._tpairs: List[Tuple[Tensor, Tensor]] = []
+        # ... and of mlp.0 / attn.qkv / attn.proj of the C = 384 "S" blocks, whose dX then runs on the whole-width kernel (csrc/wngemm.hip)
         for name, p, off, n in self._slices:
-            if name.endswith("mlp.3.weight") and p.dim() == 2 and p.shape[0] in (192, 384) and p.shape[1] % 64 == 0 and p.shape[1] >= 512:
+            fc2 = name.endswith("mlp.3.weight") and p.dim() == 2 and p.shape[0] in (192, 384) and p.shape[1] % 64 == 0 and p.shape[1] >= 512
+            wide = p.dim() == 2 and p.shape[1] == 384 and p.shape[0] % 64 == 0 and name.endswith(("mlp.0.weight", "attn.qkv.weight", "attn.proj.weight"))
+            if fc2 or wide:
                 wt = torch.empty((p.shape[1], p.shape[0]), device=dev, dtype=torch.bfloat16)
                 p._lmv_shadow_t = wt
                 self._tpairs.append((p._lmv_shadow, wt))

@@ -568,3 +568,56 @@ def test_linear_rs_kernel(rows, rows_c, N, K):
         # both kernels round the same fp32 accumulations: they may differ by the summation order only
         d = float((outs[2][k][0].float() - outs[0][k][0].float()).abs().max()); m = float(r.abs().max())
         assert d <= 8e-3 * m, f"{k}: RS and tile kernels differ by {d:.3e} (max-abs {m:.3e})"
+
+
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("rows,rows_c,K", [(27136 // 8, 256, 1536), (1000, 48, 384), (129, 0, 64), (4133, 16, 1152), (300, 300, 128), (128, 0, 2048)])
+def test_linear_wn_kernel(rows, rows_c, K):
+    """csrc/wngemm.hip (one workgroup per 128-row token panel and all 384 output columns, bf16, K % 64 == 0) forced on for every shape it
+    can run (lmv_config_set("gemm_wn", 2)): plain, bias, residual + DropPath scale -- ragged row counts, a second problem with its OWN
+    weight and bias, against float64 math on the operands the kernel reads; and against the 128 x 128 tile kernel on the same inputs."""
+    from lemevit_amd import _lib
+    o = ops()
+    dtype, N = torch.bfloat16, 384
+    a, a64 = rnd((rows, K), "a", dtype); w, w64 = rnd((N, K), "w", dtype, 1 / math.sqrt(K))
+    bias = det_tensor((N,), "b", 7, 0.5).to(dev()); res, res64 = rnd((rows, N), "res", dtype)
+    rps = 7
+    rs = (det_tensor(((rows + rps - 1) // rps,), "rs", 7).abs() + 0.5).to(dev())
+    rs_rows = rs.cpu().double()[torch.arange(rows) // rps][:, None]
+    if rows_c:
+        ac, ac64 = rnd((rows_c, K), "ac", dtype); wc, wc64 = rnd((N, K), "wc", dtype, 1 / math.sqrt(K))
+        bc = det_tensor((N,), "bc", 7, 0.5).to(dev()); resc, resc64 = rnd((rows_c, N), "resc", dtype)
+    u = a64 @ w64.t() + bias.cpu().double()
+    outs = {}
+    try:
+        for mode in (2, 0):
+            _lib.config_set("gemm_wn", mode)
+            got = {}
+            out = torch.zeros((rows, N), device=dev(), dtype=dtype)
+            oc = torch.zeros((max(rows_c, 1), N), device=dev(), dtype=dtype)
+
+            def probs(**kw):
+                ps = [o.Prob(a, w, out, **{k: v[0] for k, v in kw.items()})]
+                if rows_c:
+                    ps.append(o.Prob(ac, wc, oc, **{k: v[1] for k, v in kw.items()}))
+                return ps
+            o.linear_fwd(probs(), N, K)
+            got["plain"] = (out.clone(), oc.clone())
+            o.linear_fwd(probs(bias=(bias, bc if rows_c else None)), N, K)
+            got["bias"] = (out.clone(), oc.clone())
+            o.linear_fwd(probs(bias=(bias, bc if rows_c else None), res=(res, resc if rows_c else None), row_scale=(rs, None), rps=(rps, 1)), N, K)
+            got["res"] = (out.clone(), oc.clone())
+            outs[mode] = got
+    finally:
+        _lib.config_set("gemm_wn", 1)
+    ref = {"plain": a64 @ w64.t(), "bias": u, "res": res64 + rs_rows * u}
+    if rows_c:
+        ucc = ac64 @ wc64.t() + bc.cpu().double()
+        refc = {"plain": ac64 @ wc64.t(), "bias": ucc, "res": resc64 + ucc}
+    for k, r in ref.items():
+        for mode in (2, 0):
+            assert_close(outs[mode][k][0], r, dtype, f"{k} (gemm_wn={mode})")
+            if rows_c:
+                assert_close(outs[mode][k][1], refc[k], dtype, f"{k} meta rows (gemm_wn={mode})")
+        d = float((outs[2][k][0].float() - outs[0][k][0].float()).abs().max()); m = float(r.abs().max())
+        assert d <= 8e-3 * m, f"{k}: whole-width and tile kernels differ by {d:.3e} (max-abs {m:.3e})"

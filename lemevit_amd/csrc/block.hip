@@ -116,7 +116,10 @@ inline bool fold_qkv(const Dims& D) { return D.C >= 192; }
 
 int mlp_fwd(const lmv_block_desc* d, const Dims& D, const Fwd& f, int s0, void* const* outs, const float* const* ds, int save, void* st) {
   const int ns = 2 - s0;
-  if (fused_on(d, D, save)) {
+  // C = 384 with enough rows to fill the chip: LayerNorm + register-stationary fc1 (csrc/rsgemm.hip) + whole-width fc2 (csrc/wngemm.hip)
+  // beat the one-kernel MLP (one 160 KB workgroup per CU at this width): Base 224 forward pass 9.51 -> 9.38 ms (LMV_MLP_SPLIT384=0: A/B)
+  const bool split384 = lmv_config().mlp_split384 && D.C == 384 && D.Hd == 1536 && D.rows[0] + D.rows[1] >= 16384;
+  if (fused_on(d, D, save) && !split384) {
     if (lmv_mlp_fused_supported(D.C, D.Hd, D.dtype)) {      // LN2 -> fc1 -> GELU -> fc2 -> + residual: one kernel, hidden on chip
       lmv_mlp_problem q[2] = {};
       for (int i = 0; i < ns; ++i) { const int s = s0 + i; q[i].x = f.t2[s]; q[i].out = outs[s]; q[i].row_scale = ds[s]; q[i].rows = D.rows[s]; q[i].rows_per_sample = s == 0 ? D.N : D.M; }

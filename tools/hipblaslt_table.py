@@ -19,7 +19,8 @@ def t(fn, it=30):
     e.record(); torch.cuda.synchronize(); return s.elapsed_time(e) / it * 1e3
 
 
-lines = [f"{'shape':38s} | {'hipBLASLt fwd':>14s} {'dx':>8s} {'dw':>8s} | {'lmv fwd':>8s} {'dx':>8s} {'dw':>8s}   (TFLOP/s; us in brackets for fwd)"]
+lines = [f"{'shape':38s} | {'hipBLASLt fwd':>14s} {'dx':>8s} {'dw':>8s} | {'lmv fwd':>8s} {'dx':>8s} {'dx(W^T)':>8s} {'dw':>8s}   (TFLOP/s; us in brackets for fwd; dx(W^T): the dX as a forward-form",
+         f"{'':38s} | {'':>14s} {'':>8s} {'':>8s} | {'':>8s} {'':>8s} {'':>8s} {'':>8s}    launch on the transposed weight copy FlatAdamW keeps -- what lmv_block_bwd runs for fc2 at C = 192 / 384 and for qkv / proj / fc1 at C = 384)"]
 for si, (N_, C) in enumerate([(3136, 96), (784, 192), (196, 384), (49, 512)]):
     rows = B * (N_ + 16)
     for name, n, k in [("qkv", 3 * C, C), ("proj", C, C), ("fc1", 4 * C, C), ("fc2", C, 4 * C)]:
@@ -31,8 +32,10 @@ for si, (N_, C) in enumerate([(3136, 96), (784, 192), (196, 384), (49, 512)]):
         dw = torch.zeros(n, k, device=dev); db = torch.zeros(n, device=dev)
         l_f = t(lambda: ops.linear_fwd([Prob(a, w, o, bias=bias)], n, k)); l_x = t(lambda: ops.linear_dx([Prob(dy, w, dx)], n, k))
         l_w = t(lambda: ops.linear_dw([Prob(dy, a, dw, bias_grad=db)], n, k))
+        wt = w.t().contiguous()
+        l_xt = t(lambda: ops.linear_fwd([Prob(dy, wt, dx)], k, n))
         tf = lambda us: fl / us / 1e6
-        lines.append(f"s{si+1} {name:5s} rows={rows:7d} N={n:5d} K={k:5d} | {tf(h_f):7.0f} [{h_f:5.1f}] {tf(h_x):8.0f} {tf(h_w):8.0f} | {tf(l_f):5.0f} [{l_f:5.1f}] {tf(l_x):5.0f} {tf(l_w):8.0f}")
+        lines.append(f"s{si+1} {name:5s} rows={rows:7d} N={n:5d} K={k:5d} | {tf(h_f):7.0f} [{h_f:5.1f}] {tf(h_x):8.0f} {tf(h_w):8.0f} | {tf(l_f):5.0f} [{l_f:5.1f}] {tf(l_x):5.0f} {tf(l_xt):8.0f} {tf(l_w):8.0f}")
 out = "\n".join(lines)
 print(out)
 os.makedirs("gpurun_out", exist_ok=True)

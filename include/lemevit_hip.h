@@ -185,6 +185,16 @@ int lmv_layernorm_bwd(const lmv_ln_segment* seg, int nseg, const float* gamma, f
 int lmv_layernorm_bwd_partial(const lmv_ln_segment* seg, int nseg, const float* gamma, int C, void* workspace, size_t workspace_bytes,
                               int* partial_rows, int dtype, void* stream);
 int lmv_layernorm_bwd_reduce(const void* workspace, int partial_rows, int C, float* dgamma, float* dbeta, void* stream);
+/* The dX of a Linear fused with the LayerNorm backward of the Linear's INPUT (models/lemevit.py:560,563: norm -> Linear; csrc/wngemm.hip,
+ * bf16, C = 384, N % 64 == 0: lmv_linear_dx_ln_bwd_supported):
+ *     dy = dY wt^T   (wt = the Linear's weight TRANSPOSED, [C, N]: lmv_transpose_batch),     dx = dres + LN'(dy),     dx_scaled = dx * dx_scale[sample]
+ * p[i].a = dY [rows, N], p[i].w = wt; seg[i] as for lmv_layernorm_bwd_partial (x, stats, dres, dx, rows, dx_scale / dx_scaled /
+ * rows_per_sample; seg[i].dy is ignored -- dy never reaches memory, the LayerNorm sees it in fp32).  `*partial_rows` rows of (dgamma | dbeta)
+ * partial sums are left in `workspace` for lmv_layernorm_bwd_reduce / an LMV_REDUCE_ROWS segment of lmv_reduce_batch. */
+int lmv_linear_dx_ln_bwd_supported(int C, int N, int dtype);
+size_t lmv_linear_dx_ln_bwd_workspace_bytes(int64_t total_rows, int C);
+int lmv_linear_dx_ln_bwd(const lmv_linear_problem* p, const lmv_ln_segment* seg, int nproblems, int C, int N, const float* gamma,
+                         void* workspace, size_t workspace_bytes, int* partial_rows, int dtype, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Training-mode BatchNorm2d (+ exact GELU) over a channels-last feature map viewed as [rows = B*H*W][C]: the BatchNorm2d

@@ -95,6 +95,9 @@ SIGNATURES = {
     "lmv_layernorm_bwd": (_I, [C.POINTER(LnSegment), _I, _P, _P, _P, _I, _P, _Z, _I, _P]),
     "lmv_layernorm_bwd_partial": (_I, [C.POINTER(LnSegment), _I, _P, _I, _P, _Z, C.POINTER(C.c_int), _I, _P]),
     "lmv_layernorm_bwd_reduce": (_I, [_P, _I, _I, _P, _P, _P]),
+    "lmv_linear_dx_ln_bwd_supported": (_I, [_I, _I, _I]),
+    "lmv_linear_dx_ln_bwd_workspace_bytes": (_Z, [_L, _I]),
+    "lmv_linear_dx_ln_bwd": (_I, [C.POINTER(LinearProblem), C.POINTER(LnSegment), _I, _I, _I, _P, _P, _Z, C.POINTER(C.c_int), _I, _P]),
     "lmv_batchnorm_workspace_bytes": (_Z, [_I]),
     "lmv_batchnorm_train_fwd": (_I, [_P, _P, _P, _P, _P, _F, _F, _I, _P, _P, _L, _I, _P, _Z, _I, _P]),
     "lmv_batchnorm_train_bwd": (_I, [_P, _P, _P, _P, _P, _I, _P, _P, _P, _L, _I, _P, _Z, _I, _P]),

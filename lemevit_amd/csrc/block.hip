@@ -285,6 +285,7 @@ void layout_bwd(const Dims& D, Bump& a, Bwd* b) {
   b->ws_conv_bytes = lmv_dwconv3x3_bwd_weight_workspace_bytes(D.B, D.H, D.W, D.C, D.dtype); b->ws_conv = a.take(b->ws_conv_bytes);
   // LayerNorm dgamma / dbeta partial rows of norm2 and norm1: their reduces run on the side stream, so each keeps its own buffer
   b->ws_ln_bytes = lmv_layernorm_bwd_workspace_bytes(D.rows[0] + D.rows[1], D.C, D.dtype);
+  { const size_t w2 = lmv_linear_dx_ln_bwd_workspace_bytes(D.rows[0] + D.rows[1], D.C); if (w2 > b->ws_ln_bytes) b->ws_ln_bytes = w2; }      // (the fused dX + LayerNorm form: one row per 128-row panel)
   for (int i = 0; i < 2; ++i) b->ws_ln[i] = a.take(b->ws_ln_bytes);
 }
 
@@ -295,6 +296,23 @@ int ln_bwd(Side& sd, const lmv_ln_segment* seg, int nseg, const float* gamma, fl
   LMV_TRY(lmv_layernorm_bwd_partial(seg, nseg, gamma, D.C, ws, ws_bytes, &rows, D.dtype, sd.main));
   if (sd.nsegs + 1 > LMV_REDUCE_MAX_SEGS) LMV_FAIL(LMV_ERR_WORKSPACE, "block_bwd: too many deferred reductions");
   lmv_reduce_seg& sg = sd.segs[sd.nsegs++];      // (dgamma | dbeta) rows of the per-workgroup partial sums: summed by the block's reduce launch
+  sg = lmv_reduce_seg{};
+  sg.ws = (const float*)ws; sg.out_w = dgamma; sg.out_b = dbeta; sg.slab_stride = 2 * D.C; sg.nw = D.C; sg.nslabs = rows; sg.nb = D.C;
+  sg.kind = LMV_REDUCE_ROWS; sg.mode = 0;
+  return LMV_OK;
+}
+
+// The same LayerNorm backward fused into the dX GEMM that produces its dy (csrc/wngemm.hip: C = 384, bf16, transposed weight copy present,
+// enough rows to fill the chip): dy never reaches memory.  p[i].a = dY, p[i].w = the transposed weight; seg as for ln_bwd.
+inline bool dx_ln_fused_ok(const Dims& D, const void* wt, int N) {
+  return wt && D.dtype == LMV_BF16 && lmv_config().dx_ln_fused && lmv_linear_dx_ln_bwd_supported(D.C, N, D.dtype) && D.rows[0] + D.rows[1] >= 16384;
+}
+int dx_ln_bwd(Side& sd, const lmv_linear_problem* p, const lmv_ln_segment* seg, int nseg, int N, const float* gamma, float* dgamma, float* dbeta, const Dims& D,
+              void* ws, size_t ws_bytes) {
+  int rows = 0;
+  LMV_TRY(lmv_linear_dx_ln_bwd(p, seg, nseg, D.C, N, gamma, ws, ws_bytes, &rows, D.dtype, sd.main));
+  if (sd.nsegs + 1 > LMV_REDUCE_MAX_SEGS) LMV_FAIL(LMV_ERR_WORKSPACE, "block_bwd: too many deferred reductions");
+  lmv_reduce_seg& sg = sd.segs[sd.nsegs++];
   sg = lmv_reduce_seg{};
   sg.ws = (const float*)ws; sg.out_w = dgamma; sg.out_b = dbeta; sg.slab_stride = 2 * D.C; sg.nw = D.C; sg.nslabs = rows; sg.nb = D.C;
   sg.kind = LMV_REDUCE_ROWS; sg.mode = 0;
@@ -328,7 +346,9 @@ int mlp_bwd(const lmv_block_desc* d, const Dims& D, const Fwd& f, const Bwd& b, 
   }
   for (int i = 0; i < ns; ++i) { const int s = s0 + i; p[i] = prob(b.du[s], f.n2[s], d->g_fc1_w, D.rows[s]); p[i].bias_grad = d->g_fc1_b; }
   LMV_TRY(dw(sd, p, ns, D.Hd, D.C, D.dtype));
-  if (d->fc1_wt && D.dtype == LMV_BF16) {      // dX of fc1 as a forward-form GEMM on the transposed weight copy [C, hidden] (csrc/wngemm.hip at C = 384)
+  const bool fuse2 = dx_ln_fused_ok(D, d->fc1_wt, D.Hd);      // dX of fc1 + LayerNorm-2 backward in one kernel
+  if (fuse2) {
+  } else if (d->fc1_wt && D.dtype == LMV_BF16) {      // dX of fc1 as a forward-form GEMM on the transposed weight copy [C, hidden] (csrc/wngemm.hip at C = 384)
     for (int i = 0; i < ns; ++i) { const int s = s0 + i; p[i] = prob(b.du[s], d->fc1_wt, b.dn2[s], D.rows[s]); }
     LMV_TRY(lmv_linear_fwd(p, ns, D.C, D.Hd, LMV_ACT_NONE, D.dtype, st));
   } else {
@@ -341,6 +361,10 @@ int mlp_bwd(const lmv_block_desc* d, const Dims& D, const Fwd& f, const Bwd& b, 
     seg[i].x = f.t2[s]; seg[i].dy = b.dn2[s]; seg[i].stats = f.st2[s]; seg[i].dres = douts[s]; seg[i].dx = b.dt2[s]; seg[i].rows = D.rows[s];
     g2_out[s] = b.dt2[s];
     if (nds && nds[s]) { seg[i].dx_scale = nds[s]; seg[i].dx_scaled = b.g2[s]; seg[i].rows_per_sample = s == 0 ? D.N : D.M; g2_out[s] = b.g2[s]; }
+  }
+  if (fuse2) {
+    for (int i = 0; i < ns; ++i) { const int s = s0 + i; p[i] = prob(b.du[s], d->fc1_wt, b.dn2[s], D.rows[s]); }
+    return dx_ln_bwd(sd, p, seg, ns, D.Hd, d->n2_w, d->g_n2_w, d->g_n2_b, D, b.ws_ln[0], b.ws_ln_bytes);
   }
   return ln_bwd(sd, seg, ns, d->n2_w, d->g_n2_w, d->g_n2_b, D, b.ws_ln[0], b.ws_ln_bytes);
 }
@@ -534,7 +558,9 @@ extern "C" int lmv_block_bwd(const lmv_block_desc* d, const void* x, const void*
       }
       for (int s2 = 0; s2 < 2; ++s2) { p[s2] = prob(b.dpj[s2], f.n1[s2], sh ? d->g_attn_w[0] : d->g_attn_w[s2], D.rows[s2]); p[s2].bias_grad = sh ? d->g_attn_b[0] : d->g_attn_b[s2]; }
       LMV_TRY(dw(sd, p, 2, 3 * C, C, D.dtype));
-      if (sh && d->attn_wt[0] && D.dtype == LMV_BF16) {
+      const bool fuse1 = sh && dx_ln_fused_ok(D, d->attn_wt[0], 3 * C);      // dX of qkv + LayerNorm-1 backward in one kernel
+      if (fuse1) {
+      } else if (sh && d->attn_wt[0] && D.dtype == LMV_BF16) {
         for (int s2 = 0; s2 < 2; ++s2) p[s2] = prob(b.dpj[s2], d->attn_wt[0], b.dn1[s2], D.rows[s2]);
         LMV_TRY(lmv_linear_fwd(p, 2, C, 3 * C, LMV_ACT_NONE, D.dtype, st));
       } else {
@@ -544,7 +570,12 @@ extern "C" int lmv_block_bwd(const lmv_block_desc* d, const void* x, const void*
       lmv_ln_segment seg[2] = {};
       seg[0].x = f.xp; seg[0].dy = b.dn1[0]; seg[0].stats = f.st1[0]; seg[0].dres = b.dt2[0]; seg[0].dx = b.dxp; seg[0].rows = D.rows[0];
       seg[1].x = c; seg[1].dy = b.dn1[1]; seg[1].stats = f.st1[1]; seg[1].dres = b.dt2[1]; seg[1].dx = dc; seg[1].rows = D.rows[1];
-      LMV_TRY(ln_bwd(sd, seg, 2, d->n1_w, d->g_n1_w, d->g_n1_b, D, b.ws_ln[1], b.ws_ln_bytes));
+      if (fuse1) {
+        for (int s2 = 0; s2 < 2; ++s2) p[s2] = prob(b.dpj[s2], d->attn_wt[0], b.dn1[s2], D.rows[s2]);
+        LMV_TRY(dx_ln_bwd(sd, p, seg, 2, 3 * C, d->n1_w, d->g_n1_w, d->g_n1_b, D, b.ws_ln[1], b.ws_ln_bytes));
+      } else {
+        LMV_TRY(ln_bwd(sd, seg, 2, d->n1_w, d->g_n1_w, d->g_n1_b, D, b.ws_ln[1], b.ws_ln_bytes));
+      }
     }
     {
       void* ws = sd.ws_tail;

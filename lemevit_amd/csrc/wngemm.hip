@@ -31,16 +31,19 @@ __device__ float g_wn_zero[512];       // bias == NULL reads zeros from here (ze
 struct WnProb {
   const bf16_t* A; const bf16_t* W; const float* bias; bf16_t* C; const bf16_t* res; const float* row_scale;
   int M, rps;
+  // WN_LNBWD: LayerNorm input rows, their (mean, rstd), optional second output C * row_scale[sample] (res = the residual-path gradient)
+  const bf16_t* lnx; const float* stats; bf16_t* Cs;
 };
 struct WnArgs {
   WnProb p[2];
   int K, npanels0, npanels;
+  const float* gamma; float* partial;      // WN_LNBWD: LayerNorm weight; per-workgroup (dgamma | dbeta) rows [npanels][768]
 #ifdef LMV_WN_TIMING
   unsigned long long* dbg;      // s_memtime stamps of wave 0 of workgroups 0 and npanels / 2 (tools/wn_timeline.py)
 #endif
 };
 
-enum { WN_BIAS = 0, WN_RES = 1 };
+enum { WN_BIAS = 0, WN_RES = 1, WN_LNBWD = 2 };
 constexpr int WN_BM = 128, WN_BN = 384, WN_BK = 64;
 constexpr int WN_A_BYTES = WN_BM * WN_BK * 2, WN_W_BYTES = WN_BN * WN_BK * 2;      // token slot 16 KB, weight stage 48 KB
 constexpr int WN_A_OFF = 2 * WN_W_BYTES, WN_LDS = 2 * WN_W_BYTES + 4 * WN_A_BYTES;    // [weights: 2 stages | tokens: 4 slots] = 160 KB
@@ -92,6 +95,7 @@ __global__ __launch_bounds__(512, 2) void wn_gemm_kernel(const WnArgs g) {
   WnProb P;
 #define WN_SEL(f) P.f = second ? g.p[1].f : g.p[0].f
   WN_SEL(A); WN_SEL(W); WN_SEL(bias); WN_SEL(C); WN_SEL(res); WN_SEL(row_scale); WN_SEL(M); WN_SEL(rps);
+  if (EPI == WN_LNBWD) { WN_SEL(lnx); WN_SEL(stats); WN_SEL(Cs); }
 #undef WN_SEL
   if (!P.bias) P.bias = g_wn_zero;
   const int m0 = (second ? panel - g.npanels0 : panel) * WN_BM;
@@ -204,6 +208,115 @@ __global__ __launch_bounds__(512, 2) void wn_gemm_kernel(const WnArgs g) {
 
   // ---- epilogue: 16-byte stores straight from the accumulators ----------------------------------------------------------------------
   const int cw = 96 * wn + 8 * (lane >> 4);                  // first column of the lane's 8-column group in pair 0
+  if constexpr (EPI == WN_LNBWD) {
+    // The accumulators hold dy = dY W (the gradient of a LayerNorm's OUTPUT) for 128 whole rows: the LayerNorm backward runs right here
+    // (norm.hip::ln_bwd_kernel's formulas on the fp32 dy):  g = dy gamma, x^ = (x - mean) rstd, s1 = mean_c(g), s2 = mean_c(g x^),
+    //   dx = rstd (g - s1 - x^ s2) + dres,   dgamma += sum_r dy x^,   dbeta += sum_r dy
+    // A row's 384 columns sit in 4 lane groups x 3 column pairs x the 4 waves of a wave row: the row sums meet through LDS (the operand
+    // stages are free now); the column sums are reduced over the 16 rows of a lane group by shuffles, over the row tiles in registers and
+    // over the two wave rows through LDS -- fixed order, one (dgamma | dbeta) row per workgroup for the caller's partial-row reduce.
+    float* const red = reinterpret_cast<float*>(smem);       // [8 waves][64 rows][2] row sums, then [2 wave rows][768] column sums
+    f32x4_t gm[3][2];
+#pragma unroll
+    for (int p = 0; p < 3; ++p) {
+      gm[p][0] = *reinterpret_cast<const f32x4_t*>(g.gamma + cw + 32 * p);
+      gm[p][1] = *reinterpret_cast<const f32x4_t*>(g.gamma + cw + 32 * p + 4);
+    }
+    const float invC = 1.f / (float)WN_BN;
+    float mean[4], rstd[4], s1[4], s2[4];
+    {
+      f32x4_t xr[4][3];
+#pragma unroll
+      for (int ti = 0; ti < 4; ++ti) {
+        const int rowc = min(m0 + 64 * wm + 16 * ti + (lane & 15), P.M - 1);
+        mean[ti] = P.stats[2 * (long long)rowc]; rstd[ti] = P.stats[2 * (long long)rowc + 1];
+#pragma unroll
+        for (int p = 0; p < 3; ++p) xr[ti][p] = *reinterpret_cast<const f32x4_t*>(P.lnx + (long long)rowc * WN_BN + cw + 32 * p);
+      }
+#pragma unroll
+      for (int ti = 0; ti < 4; ++ti) {
+        float a1 = 0.f, a2 = 0.f;
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+          float xv[8];
+          wn_unpack8(xr[ti][p], xv);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const float gg = acc[ti][2 * p + (e >> 2)][e & 3] * gm[p][e >> 2][e & 3], xh = (xv[e] - mean[ti]) * rstd[ti];
+            a1 += gg; a2 = fmaf(gg, xh, a2);
+          }
+        }
+        a1 += __shfl_xor(a1, 16, 64); a1 += __shfl_xor(a1, 32, 64);
+        a2 += __shfl_xor(a2, 16, 64); a2 += __shfl_xor(a2, 32, 64);
+        s1[ti] = a1; s2[ti] = a2;
+        if (lane < 16) { red[(wave * 64 + ti * 16 + lane) * 2] = a1; red[(wave * 64 + ti * 16 + lane) * 2 + 1] = a2; }
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int ti = 0; ti < 4; ++ti) {           // the four waves of this wave row, in a fixed order
+      float a1 = 0.f, a2 = 0.f;
+#pragma unroll
+      for (int w4 = 0; w4 < 4; ++w4) { const int o = (((wm * 4 + w4) * 64) + ti * 16 + (lane & 15)) * 2; a1 += red[o]; a2 += red[o + 1]; }
+      s1[ti] = a1 * invC; s2[ti] = a2 * invC;
+    }
+    float cg[3][8], cb[3][8];
+#pragma unroll
+    for (int p = 0; p < 3; ++p)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { cg[p][e] = 0.f; cb[p][e] = 0.f; }
+#pragma unroll
+    for (int ti = 0; ti < 4; ++ti) {
+      const int row = m0 + 64 * wm + 16 * ti + (lane & 15);
+      const int rowc = min(row, P.M - 1);
+      const float live = row < P.M ? 1.f : 0.f;
+      const float sc = P.row_scale ? P.row_scale[rowc / P.rps] : 1.f;
+#pragma unroll
+      for (int p = 0; p < 3; ++p) {
+        const long long o = (long long)rowc * WN_BN + cw + 32 * p;
+        float xv[8], rv[8], ov[8];
+        wn_unpack8(*reinterpret_cast<const f32x4_t*>(P.lnx + o), xv);
+        if (P.res) wn_unpack8(*reinterpret_cast<const f32x4_t*>(P.res + o), rv);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float dy = acc[ti][2 * p + (e >> 2)][e & 3] * live, xh = (xv[e] - mean[ti]) * rstd[ti];
+          const float gg = dy * gm[p][e >> 2][e & 3];
+          ov[e] = rstd[ti] * (gg - s1[ti] - xh * s2[ti]);
+          if (P.res) ov[e] += rv[e];
+          cg[p][e] = fmaf(dy, xh, cg[p][e]); cb[p][e] += dy;
+        }
+        if (row < P.M) {
+          wn_gstore16(P.C + o, wn_pack8(ov));
+          if (P.Cs) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) ov[e] *= sc;
+            wn_gstore16(P.Cs + o, wn_pack8(ov));
+          }
+        }
+      }
+    }
+    // column sums: over the 16 rows of the lane group (shuffles), then over the two wave rows (LDS)
+#pragma unroll
+    for (int p = 0; p < 3; ++p)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        float a = cg[p][e], b = cb[p][e];
+#pragma unroll
+        for (int m = 1; m < 16; m <<= 1) { a += __shfl_xor(a, m, 64); b += __shfl_xor(b, m, 64); }
+        cg[p][e] = a; cb[p][e] = b;
+      }
+    __syncthreads();                             // everybody has read the row sums
+    if ((lane & 15) == 0) {
+#pragma unroll
+      for (int p = 0; p < 3; ++p)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { red[wm * 768 + cw + 32 * p + e] = cg[p][e]; red[wm * 768 + WN_BN + cw + 32 * p + e] = cb[p][e]; }
+    }
+    __syncthreads();
+    float* prow = g.partial + (long long)panel * 768;
+    for (int j = tid; j < 768; j += 512) prow[j] = red[j] + red[768 + j];
+    return;
+  }
   f32x4_t b4[3][2];
 #pragma unroll
   for (int p = 0; p < 3; ++p) {
@@ -277,6 +390,46 @@ bool lmv_wn_eligible(const lmv_linear_problem* p, int nproblems, int N, int K, i
   // stream, whose 48 KB workgroups keep the CUs' LDS occupied -- a 128 KB workgroup waits for a whole CU to drain (train step + 0.3 ms).
   if (!p[0].res) return false;
   return rows >= 16384;          // at least ~128 panels: below that the 128 x 128 tiles fill the chip better
+}
+
+// dX of a Linear through its transposed weight fused with the LayerNorm backward of the Linear's input (include/lemevit_hip.h)
+extern "C" int lmv_linear_dx_ln_bwd_supported(int C, int N, int dtype) {
+  return dtype == LMV_BF16 && C == WN_BN && N >= WN_BK && (N % WN_BK) == 0;
+}
+extern "C" size_t lmv_linear_dx_ln_bwd_workspace_bytes(int64_t total_rows, int C) {
+  if (total_rows <= 0 || C != WN_BN) return 0;
+  return (size_t)((total_rows + WN_BM - 1) / WN_BM + 2) * 2 * C * sizeof(float);
+}
+extern "C" int lmv_linear_dx_ln_bwd(const lmv_linear_problem* p, const lmv_ln_segment* seg, int nproblems, int C, int N, const float* gamma,
+                                    void* workspace, size_t workspace_bytes, int* partial_rows, int dtype, void* stream) {
+  if (!lmv_linear_dx_ln_bwd_supported(C, N, dtype)) LMV_FAIL(LMV_ERR_SHAPE, "linear_dx_ln_bwd: C=%d N=%d dtype=%d (bf16, C = 384, N %% 64 == 0)", C, N, dtype);
+  if (nproblems < 1 || nproblems > 2 || !p || !seg || !gamma || !workspace || !partial_rows) LMV_FAIL(LMV_ERR_SHAPE, "linear_dx_ln_bwd: null argument / nproblems must be 1 or 2");
+  WnArgs a{};
+  int npan[2] = {0, 0};
+  for (int i = 0; i < nproblems; ++i) {
+    const lmv_ln_segment& q = seg[i];
+    if (p[i].rows <= 0 || p[i].rows != q.rows || p[i].rows > 0x7fffffffLL / 2048) LMV_FAIL(LMV_ERR_SHAPE, "linear_dx_ln_bwd: bad rows");
+    if (!p[i].a || !p[i].w || !q.x || !q.stats || !q.dx || (q.dx_scale && (!q.dx_scaled || q.rows_per_sample <= 0)))
+      LMV_FAIL(LMV_ERR_SHAPE, "linear_dx_ln_bwd: null operand");
+    if (!lmv_aligned16(p[i].a) || !lmv_aligned16(p[i].w) || !lmv_aligned16(q.x) || !lmv_aligned16(q.dx) || !lmv_aligned16(q.dres) || !lmv_aligned16(q.dx_scaled) || !lmv_aligned16(gamma))
+      LMV_FAIL(LMV_ERR_SHAPE, "linear_dx_ln_bwd: operands must be 16-byte aligned");
+    WnProb& w = a.p[i];
+    w.A = (const bf16_t*)p[i].a; w.W = (const bf16_t*)p[i].w; w.bias = nullptr; w.C = (bf16_t*)q.dx; w.res = (const bf16_t*)q.dres;
+    w.row_scale = q.dx_scale; w.M = (int)q.rows; w.rps = q.dx_scale ? (int)q.rows_per_sample : 1;
+    w.lnx = (const bf16_t*)q.x; w.stats = q.stats; w.Cs = q.dx_scale ? (bf16_t*)q.dx_scaled : nullptr;
+    npan[i] = (int)((q.rows + WN_BM - 1) / WN_BM);
+  }
+  a.K = N; a.npanels0 = npan[0]; a.npanels = npan[0] + npan[1];
+  if (workspace_bytes < (size_t)a.npanels * 768 * sizeof(float) || !lmv_aligned16(workspace))
+    LMV_FAIL(LMV_ERR_WORKSPACE, "linear_dx_ln_bwd: workspace %zu < %zu bytes", workspace_bytes, (size_t)a.npanels * 768 * sizeof(float));
+  a.gamma = gamma; a.partial = (float*)workspace;
+#ifdef LMV_WN_TIMING
+  a.dbg = nullptr;
+#endif
+  if (int rc = wn_launch<WN_LNBWD>(a, (hipStream_t)stream)) return rc;
+  LMV_CHECK_LAUNCH("linear_dx_ln_bwd");
+  *partial_rows = a.npanels;
+  return LMV_OK;
 }
 
 int lmv_wn_linear(const lmv_linear_problem* p, int nproblems, int N, int K, int act, hipStream_t st) {

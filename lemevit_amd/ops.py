@@ -294,6 +294,35 @@ def layernorm_bwd_multi(dys: Sequence[Tensor], xs: Sequence[Tensor], stats: Sequ
     return dxs if next_scales is None else (dxs, scaled)
 
 
+def linear_dx_ln_bwd(dys: Sequence[Tensor], wt: Tensor, xs: Sequence[Tensor], stats: Sequence[Tensor], gamma: Tensor, dgamma: Tensor, dbeta: Tensor,
+                     dres: Sequence[Optional[Tensor]], next_scales: Optional[Sequence[Optional[Tensor]]] = None):
+    """The dX of a Linear through its TRANSPOSED weight `wt` [C, N] fused with the LayerNorm backward of the Linear's input
+    (lmv_linear_dx_ln_bwd; bf16, C = 384): dx_i = dres_i + LN'(dys_i @ wt^T); dgamma / dbeta accumulated; (dxs, scaled) as layernorm_bwd_multi."""
+    C_, N = wt.shape
+    seg = (LnSegment * len(xs))()
+    pr = (LinearProblem * len(xs))()
+    dxs, scaled, total = [], [], 0
+    for i, (s, q, dy, x, st, dr) in enumerate(zip(seg, pr, dys, xs, stats, dres)):
+        dx = torch.empty_like(x)
+        s.x, s.stats, s.dres, s.dx, s.rows = _ptr(x), _f32(st), _ptr(dr), _ptr(dx), x.numel() // C_
+        q.a, q.w, q.rows = _ptr(dy), _ptr(wt), s.rows
+        sc = None if next_scales is None else next_scales[i]
+        if sc is not None:
+            d2 = torch.empty_like(x)
+            s.dx_scale, s.dx_scaled, s.rows_per_sample = _f32(sc), _ptr(d2), x.shape[1]
+            scaled.append(d2)
+        else:
+            scaled.append(dx)
+        total += s.rows
+        dxs.append(dx)
+    code = dtype_code(xs[0])
+    ws = _workspace(lib.lmv_linear_dx_ln_bwd_workspace_bytes(total, C_), xs[0].device)
+    rows = C.c_int(0)
+    check(lib.lmv_linear_dx_ln_bwd(pr, seg, len(xs), C_, N, _f32(gamma), ws.data_ptr(), ws.numel(), C.byref(rows), code, _stream()), "lmv_linear_dx_ln_bwd")
+    check(lib.lmv_layernorm_bwd_reduce(ws.data_ptr(), rows.value, C_, _f32(dgamma), _f32(dbeta), _stream()), "lmv_layernorm_bwd_reduce")
+    return dxs if next_scales is None else (dxs, scaled)
+
+
 def layernorm_fwd(x: Tensor, gamma: Tensor, beta: Tensor, eps: float, want_stats: bool = False) -> Tuple[Tensor, Optional[Tensor]]:
     ys, sts = layernorm_fwd_multi([x], gamma, beta, eps, want_stats)
     return ys[0], sts[0]

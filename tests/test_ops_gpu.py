@@ -621,3 +621,73 @@ def test_linear_wn_kernel(rows, rows_c, K):
                 assert_close(outs[mode][k][1], refc[k], dtype, f"{k} meta rows (gemm_wn={mode})")
         d = float((outs[2][k][0].float() - outs[0][k][0].float()).abs().max()); m = float(r.abs().max())
         assert d <= 8e-3 * m, f"{k}: whole-width and tile kernels differ by {d:.3e} (max-abs {m:.3e})"
+
+
+@pytest.mark.parametrize("rows,rows_c,N", [(27136 // 8, 256, 1536), (1000, 48, 1152), (129, 0, 64), (4133, 16, 384)])
+def test_linear_dx_ln_bwd_fused(rows, rows_c, N):
+    """lmv_linear_dx_ln_bwd (csrc/wngemm.hip, bf16, C = 384): dx = dres + LN'(dY @ wt^T) with dy never written -- against float64 math on the
+    operands the kernel reads (dy stays fp32 inside the kernel, so it is compared with the UNROUNDED product), with and without the
+    residual-path gradient, with the DropPath-scaled second output, a second problem (meta-token rows), dgamma / dbeta accumulated on top of
+    existing values; and against the two-launch form (forward-form GEMM on wt, then lmv_layernorm_bwd) on the same inputs."""
+    o = ops()
+    dtype, C = torch.bfloat16, 384
+    wt, wt64 = rnd((C, N), "wt", dtype, 1 / math.sqrt(N))
+    gamma = (det_tensor((C,), "gam", 5, 0.3) + 1.0).to(dev())
+    g64 = gamma.cpu().double()
+    rps = 7
+    sets = []
+    for tag, r in (("x", rows), ("c", rows_c)):
+        if not r:
+            continue
+        dy, dy64 = rnd((r, N), "dy" + tag, dtype); x, x64 = rnd((r, C), "x" + tag, dtype, 1.5); dres, dres64 = rnd((r, C), "dr" + tag, dtype)
+        mean = x64.mean(1, keepdim=True); var = ((x64 - mean) ** 2).mean(1, keepdim=True); rstd = 1 / torch.sqrt(var + 1e-6)
+        stats = torch.cat([mean, rstd], 1).float().to(dev()).contiguous()
+        m64, r64 = stats.cpu().double()[:, :1], stats.cpu().double()[:, 1:]
+        sc = (det_tensor(((r + rps - 1) // rps,), "sc" + tag, 7).abs() + 0.5).to(dev())
+        sets.append(dict(dy=dy, dy64=dy64, x=x.view(1, r, C), x64=x64, dres=dres.view(1, r, C), dres64=dres64, stats=stats, m=m64, r=r64, sc=sc,
+                         scr=sc.cpu().double()[torch.arange(r) // rps][:, None]))
+    for with_res in (True, False):
+        dgam = torch.full((C,), 0.25, device=dev()); dbet = torch.full((C,), -0.5, device=dev())
+        dgam2, dbet2 = dgam.clone(), dbet.clone()
+        # (the scaled output indexes rows by x.shape[1] = rows per sample: give the wrapper [samples, rps, C] views where the row count allows)
+        xs = [t["x"] for t in sets]
+        dxs = o.linear_dx_ln_bwd([t["dy"] for t in sets], wt, xs, [t["stats"] for t in sets], gamma, dgam, dbet, [t["dres"] if with_res else None for t in sets])
+        # two-launch form
+        dns = []
+        for t in sets:
+            dn = torch.empty((t["dy"].shape[0], C), device=dev(), dtype=dtype)
+            o.linear_fwd([o.Prob(t["dy"], wt, dn)], C, N)
+            dns.append(dn.view(1, -1, C))
+        dxs2 = o.layernorm_bwd_multi(dns, xs, [t["stats"] for t in sets], gamma, dgam2, dbet2, [t["dres"] if with_res else None for t in sets])
+        rg, rb = torch.full((C,), 0.25, dtype=torch.float64), torch.full((C,), -0.5, dtype=torch.float64)
+        for t, dx, dx2 in zip(sets, dxs, dxs2):
+            dyv = t["dy64"] @ wt64.t()
+            xh = (t["x64"] - t["m"]) * t["r"]
+            gg = dyv * g64
+            ref = t["r"] * (gg - gg.mean(1, keepdim=True) - xh * (gg * xh).mean(1, keepdim=True)) + (t["dres64"] if with_res else 0)
+            rg += (dyv * xh).sum(0); rb += dyv.sum(0)
+            assert_close(dx.view(-1, C), ref, dtype, f"dx (res={with_res})")
+            d = float((dx.float() - dx2.float()).abs().max()); m = float(ref.abs().max())
+            assert d <= 1.6e-2 * m, f"fused and two-launch forms differ by {d:.3e} (max-abs {m:.3e})"      # the two-launch form rounds dy to bf16 first
+        for got, ref, what in ((dgam, rg, "dgamma"), (dbet, rb, "dbeta")):
+            err = float((got.cpu().double() - ref).abs().max()) / float(ref.abs().max())
+            assert err <= 2e-3, f"{what}: {err:.2e}"
+    # the DropPath-scaled second output (rows per sample = rps): through the raw segments
+    from lemevit_amd import _lib
+    import ctypes as CT
+    t = sets[0]
+    r = t["dy"].shape[0]
+    seg = (_lib.LnSegment * 1)(); pr = (_lib.LinearProblem * 1)()
+    dx = torch.empty((r, C), device=dev(), dtype=dtype); dxs_ = torch.empty_like(dx)
+    seg[0].x, seg[0].stats, seg[0].dres, seg[0].dx, seg[0].rows = t["x"].data_ptr(), t["stats"].data_ptr(), t["dres"].data_ptr(), dx.data_ptr(), r
+    seg[0].dx_scale, seg[0].dx_scaled, seg[0].rows_per_sample = t["sc"].data_ptr(), dxs_.data_ptr(), rps
+    pr[0].a, pr[0].w, pr[0].rows = t["dy"].data_ptr(), wt.data_ptr(), r
+    ws = torch.empty(_lib.lib.lmv_linear_dx_ln_bwd_workspace_bytes(r, C), device=dev(), dtype=torch.uint8)
+    nrows = CT.c_int(0)
+    _lib.check(_lib.lib.lmv_linear_dx_ln_bwd(pr, seg, 1, C, N, gamma.data_ptr(), ws.data_ptr(), ws.numel(), CT.byref(nrows), _lib.LMV_BF16, o._stream()), "lmv_linear_dx_ln_bwd")
+    torch.cuda.synchronize()
+    assert nrows.value == (r + 127) // 128
+    dyv = t["dy64"] @ wt64.t(); xh = (t["x64"] - t["m"]) * t["r"]; gg = dyv * g64
+    ref = t["r"] * (gg - gg.mean(1, keepdim=True) - xh * (gg * xh).mean(1, keepdim=True)) + t["dres64"]
+    assert_close(dx, ref, dtype, "dx (raw segments)")
+    assert_close(dxs_, ref * t["scr"], dtype, "dx_scaled")      # scaled in fp32, rounded once

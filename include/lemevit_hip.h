@@ -191,6 +191,12 @@ int lmv_layernorm_bwd_reduce(const void* workspace, int partial_rows, int C, flo
  * p[i].a = dY [rows, N], p[i].w = wt; seg[i] as for lmv_layernorm_bwd_partial (x, stats, dres, dx, rows, dx_scale / dx_scaled /
  * rows_per_sample; seg[i].dy is ignored -- dy never reaches memory, the LayerNorm sees it in fp32).  `*partial_rows` rows of (dgamma | dbeta)
  * partial sums are left in `workspace` for lmv_layernorm_bwd_reduce / an LMV_REDUCE_ROWS segment of lmv_reduce_batch. */
+/* The forward mirror: a Linear with the residual epilogue followed by the LayerNorm of its output (proj + norm2, models/lemevit.py:562-563,
+ * 632-635) in one launch:  out = res + row_scale (a W^T + bias);  seg[i].y = LN(out) (of the ROUNDED out, as a separate launch would read
+ * it), seg[i].stats = (mean, rstd) when non-NULL.  bf16, N = 384, K % 64 == 0 (lmv_linear_res_ln_fwd_supported). */
+int lmv_linear_res_ln_fwd_supported(int N, int K, int dtype);
+int lmv_linear_res_ln_fwd(const lmv_linear_problem* p, const lmv_ln_segment* seg, int nproblems, int N, int K, const float* gamma, const float* beta,
+                          float eps, int dtype, void* stream);
 int lmv_linear_dx_ln_bwd_supported(int C, int N, int dtype);
 size_t lmv_linear_dx_ln_bwd_workspace_bytes(int64_t total_rows, int C);
 int lmv_linear_dx_ln_bwd(const lmv_linear_problem* p, const lmv_ln_segment* seg, int nproblems, int C, int N, const float* gamma,

@@ -218,13 +218,21 @@ def _rps(t: Tensor) -> int:
 # ------------------------------------------------------------------------------------------------
 # MLP half of a block:  t <- t + ds * fc2(GELU(fc1(LN2(t))))   for every stream t in `ts`
 # ------------------------------------------------------------------------------------------------
-def _mlp_fwd(P: Dict[str, Tensor], ts: Sequence[Tensor], ds: Sequence[Optional[Tensor]], save: bool, fc1_fold=None):
+def _lib_config(key: str) -> int:
+    from . import _lib
+    return _lib.config_get(key)
+
+
+def _mlp_fwd(P: Dict[str, Tensor], ts: Sequence[Tensor], ds: Sequence[Optional[Tensor]], save: bool, fc1_fold=None, pre_ln=None):
     C = ts[0].shape[-1]
     Hd = P["mlp.0.weight"].shape[0]
-    if fc1_fold is not None and not save and ops.mlp_fused_supported(C, Hd, ts[0].dtype):
+    if pre_ln is None and fc1_fold is not None and not save and ops.mlp_fused_supported(C, Hd, ts[0].dtype):
         # inference: LN2 -> fc1 -> GELU -> fc2 -> + residual in ONE kernel, the hidden activations never leave the chip
         return ops.mlp_fused_fwd(ts, fc1_fold, P["mlp.3.weight"], P["mlp.3.bias"], BLOCK_LN_EPS, ds), None
-    xn, st = ops.layernorm_fwd_multi(ts, P["norm2.weight"], P["norm2.bias"], BLOCK_LN_EPS, want_stats=save)
+    if pre_ln is not None:                       # norm2 came out of the attention projection's launch (_attn_S_fwd, ops.linear_res_ln_fwd)
+        xn, st = pre_ln
+    else:
+        xn, st = ops.layernorm_fwd_multi(ts, P["norm2.weight"], P["norm2.bias"], BLOCK_LN_EPS, want_stats=save)
     h = [_empty(t, Hd) for t in ts]
     u = [_empty(t, Hd) if save else None for t in ts]
     ops.linear_fwd([Prob(a, P["mlp.0.weight"], o, bias=P["mlp.0.bias"], out_pre=pre) for a, o, pre in zip(xn, h, u)], Hd, C, ACT_GELU)
@@ -253,8 +261,10 @@ def _mlp_bwd(P, G, saved, douts: Sequence[Tensor], ds: Sequence[Optional[Tensor]
 # ------------------------------------------------------------------------------------------------
 # attention halves
 # ------------------------------------------------------------------------------------------------
-def _attn_S_fwd(P, ts, ds, save):
-    """t <- t + ds * proj(SA(qkv(LN1(t)))) for x and c with the SAME weights (models/lemevit.py:632,634)."""
+def _attn_S_fwd(P, ts, ds, save, want_ln2=False):
+    """t <- t + ds * proj(SA(qkv(LN1(t)))) for x and c with the SAME weights (models/lemevit.py:632,634).
+    want_ln2: where the library fuses the projection with the norm2 that follows it (ops.res_ln_fused), run that launch and return
+    norm2's outputs as a third element: (xn2, st2) or None."""
     C = ts[0].shape[-1]
     xn, st = ops.layernorm_fwd_multi(ts, P["norm1.weight"], P["norm1.bias"], BLOCK_LN_EPS, want_stats=save)
     qkv = [_empty(t, 3 * C) for t in ts]
@@ -271,8 +281,17 @@ def _attn_S_fwd(P, ts, ds, save):
     else:
         ao, lse = zip(*[ops.attn_fwd((q, 0), (q, C), (q, 2 * C), C, ops.SDPA_SCALE, want_lse=save) for q in qkv])
     out = [torch.empty_like(t) for t in ts]
-    ops.linear_fwd([Prob(a, P["attn.proj.weight"], o, bias=P["attn.proj.bias"], res=t, row_scale=s, rps=_rps(t)) for a, o, t, s in zip(ao, out, ts, ds)], C, C)
-    return out, ((list(ts), list(st), list(xn), qkv, list(ao), list(lse)) if save else None)
+    probs = [Prob(a, P["attn.proj.weight"], o, bias=P["attn.proj.bias"], res=t, row_scale=s, rps=_rps(t)) for a, o, t, s in zip(ao, out, ts, ds)]
+    saved = (list(ts), list(st), list(xn), qkv, list(ao), list(lse)) if save else None
+    if want_ln2:
+        ln2 = None
+        if ops.res_ln_fused(C, C, sum(p.rows for p in probs), ts[0].dtype):
+            ln2 = ops.linear_res_ln_fwd(probs, C, C, P["norm2.weight"], P["norm2.bias"], BLOCK_LN_EPS, want_stats=save)
+        else:
+            ops.linear_fwd(probs, C, C)
+        return out, saved, ln2
+    ops.linear_fwd(probs, C, C)
+    return out, saved
 
 
 def _attn_S_bwd(P, G, saved, douts, ds, g=None):
@@ -426,7 +445,16 @@ def block_forward(kind: str, x: Tensor, c: Tensor, H: int, W: int, P: Dict[str, 
         (x2,), sa = _attn_S_fwd(P, [xp], [masks[0]], save)
         (x3,), sm = _mlp_fwd(P, [x2], [masks[1]], save, fc1_fold)
         return x3, c, ((x, sa, sm) if save else None)
-    fwd = {"S": _attn_S_fwd, "D": _attn_D_fwd, "D2": _attn_D2_fwd}[kind]
+    if kind == "S":
+        # (the one-kernel / LayerNorm-folded MLP half of the fused inference schedule has no use for norm2's output: csrc/block.hip::res_ln_ok)
+        Hd = P["mlp.0.weight"].shape[0]
+        rows = xp.numel() // xp.shape[-1] + c.numel() // c.shape[-1]
+        folded = fc1_fold is not None and not save and not (xp.shape[-1] == 384 and Hd == 1536 and rows >= 16384 and _lib_config("mlp_split384"))
+        r = _attn_S_fwd(P, [xp, c], [masks[0], masks[2]], save, want_ln2=not folded)
+        (x2, c1), sa, ln2 = r if not folded else (r[0], r[1], None)
+        (x3, c2), sm = _mlp_fwd(P, [x2, c1], [masks[1], masks[3]], save, fc1_fold, pre_ln=ln2)
+        return x3, c2, ((x, sa, sm) if save else None)
+    fwd = {"D": _attn_D_fwd, "D2": _attn_D2_fwd}[kind]
     (x2, c1), sa = fwd(P, [xp, c], [masks[0], masks[2]], save)
     (x3, c2), sm = _mlp_fwd(P, [x2, c1], [masks[1], masks[3]], save, fc1_fold)
     return x3, c2, ((x, sa, sm) if save else None)

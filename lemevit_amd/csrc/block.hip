@@ -114,11 +114,21 @@ inline bool fused_on(const lmv_block_desc* d, const Dims& D, int save) {
 }
 inline bool fold_qkv(const Dims& D) { return D.C >= 192; }
 
-int mlp_fwd(const lmv_block_desc* d, const Dims& D, const Fwd& f, int s0, void* const* outs, const float* const* ds, int save, void* st) {
+// split384 (below): the C = 384 MLP half of the fused inference schedule as three launches instead of the one-kernel form
+inline bool mlp_split384(const Dims& D) { return lmv_config().mlp_split384 && D.C == 384 && D.Hd == 1536 && D.rows[0] + D.rows[1] >= 16384; }
+// "S" blocks: the attention projection (residual epilogue) and the norm2 that follows it in ONE launch (lmv_linear_res_ln_fwd), wherever
+// the MLP half reads norm2's output from memory (training; the split inference form) -- lemevit_amd/ops.py::res_ln_fused is the same rule
+inline bool res_ln_ok(const lmv_block_desc* d, const Dims& D, int save) {
+  if (D.kind != LMV_BLOCK_S || D.dtype != LMV_BF16 || !lmv_config().res_ln_fused || D.rows[0] + D.rows[1] < 16384) return false;
+  if (!lmv_linear_res_ln_fwd_supported(D.C, D.C, D.dtype)) return false;
+  return !(fused_on(d, D, save) && !mlp_split384(D));
+}
+
+int mlp_fwd(const lmv_block_desc* d, const Dims& D, const Fwd& f, int s0, void* const* outs, const float* const* ds, int save, void* st, bool ln_done = false) {
   const int ns = 2 - s0;
   // C = 384 with enough rows to fill the chip: LayerNorm + register-stationary fc1 (csrc/rsgemm.hip) + whole-width fc2 (csrc/wngemm.hip)
   // beat the one-kernel MLP (one 160 KB workgroup per CU at this width): Base 224 forward pass 9.51 -> 9.38 ms (LMV_MLP_SPLIT384=0: A/B)
-  const bool split384 = lmv_config().mlp_split384 && D.C == 384 && D.Hd == 1536 && D.rows[0] + D.rows[1] >= 16384;
+  const bool split384 = mlp_split384(D);
   if (fused_on(d, D, save) && !split384) {
     if (lmv_mlp_fused_supported(D.C, D.Hd, D.dtype)) {      // LN2 -> fc1 -> GELU -> fc2 -> + residual: one kernel, hidden on chip
       lmv_mlp_problem q[2] = {};
@@ -136,9 +146,11 @@ int mlp_fwd(const lmv_block_desc* d, const Dims& D, const Fwd& f, int s0, void* 
     }
     return lmv_linear_fwd(p, ns, D.C, D.Hd, LMV_ACT_NONE, D.dtype, st);
   }
-  lmv_ln_segment seg[2] = {};
-  for (int i = 0; i < ns; ++i) { const int s = s0 + i; seg[i].x = f.t2[s]; seg[i].y = f.n2[s]; seg[i].stats = save ? f.st2[s] : nullptr; seg[i].rows = D.rows[s]; }
-  LMV_TRY(lmv_layernorm_fwd(seg, ns, d->n2_w, d->n2_b, D.C, d->eps, D.dtype, st));
+  if (!ln_done) {
+    lmv_ln_segment seg[2] = {};
+    for (int i = 0; i < ns; ++i) { const int s = s0 + i; seg[i].x = f.t2[s]; seg[i].y = f.n2[s]; seg[i].stats = save ? f.st2[s] : nullptr; seg[i].rows = D.rows[s]; }
+    LMV_TRY(lmv_layernorm_fwd(seg, ns, d->n2_w, d->n2_b, D.C, d->eps, D.dtype, st));
+  }
   lmv_linear_problem p[2];
   for (int i = 0; i < ns; ++i) { const int s = s0 + i; p[i] = prob(f.n2[s], d->fc1_w, f.h[s], D.rows[s]); p[i].bias = d->fc1_b; p[i].out_pre = save ? f.u[s] : nullptr; }
   LMV_TRY(lmv_linear_fwd(p, ns, D.Hd, D.C, LMV_ACT_GELU, D.dtype, st));
@@ -438,6 +450,7 @@ extern "C" int lmv_block_fwd(const lmv_block_desc* d, const void* x, const void*
   lmv_linear_problem p[2];
   lmv_attn_desc ad[2];
   void* outs[2] = {x_out, c_out};
+  bool ln2_done = false;
   if (D.kind == LMV_BLOCK_S) {                    // the SAME weights for x and c (:632,634)
     { const int st_[2] = {0, 1}, sl_[2] = {0, 0}; LMV_TRY(project(p, 2, st_, sl_, 3 * C)); }
     for (int s = 0; s < 2; ++s) { const int L = s == 0 ? N : M; attn_desc(&ad[s], D, f.pj[s], 3 * C, 0, f.pj[s], 3 * C, C, f.pj[s], 3 * C, 2 * C, f.ao[s], save ? f.lse[s] : nullptr, L, L, SDPA_SCALE); }
@@ -446,7 +459,14 @@ extern "C" int lmv_block_fwd(const lmv_block_desc* d, const void* x, const void*
       p[s] = prob(f.ao[s], d->attn_w[1], f.t2[s], D.rows[s]); p[s].bias = d->attn_b[1]; p[s].res = s == 0 ? f.xp : c;
       p[s].row_scale = d->masks[s == 0 ? 0 : 2]; p[s].rows_per_sample = s == 0 ? N : M;
     }
-    LMV_TRY(lmv_linear_fwd(p, 2, C, C, LMV_ACT_NONE, D.dtype, stream));
+    if (res_ln_ok(d, D, save)) {              // ... together with norm2 (csrc/wngemm.hip)
+      lmv_ln_segment seg[2] = {};
+      for (int s = 0; s < 2; ++s) { seg[s].y = f.n2[s]; seg[s].stats = save ? f.st2[s] : nullptr; seg[s].rows = D.rows[s]; }
+      LMV_TRY(lmv_linear_res_ln_fwd(p, seg, 2, C, C, d->n2_w, d->n2_b, d->eps, D.dtype, stream));
+      ln2_done = true;
+    } else {
+      LMV_TRY(lmv_linear_fwd(p, 2, C, C, LMV_ACT_NONE, D.dtype, stream));
+    }
   } else if (D.kind == LMV_BLOCK_D) {             // :288-302
     float sx, sc;
     dca_scales(D, &sx, &sc);
@@ -469,7 +489,7 @@ extern "C" int lmv_block_fwd(const lmv_block_desc* d, const void* x, const void*
     LMV_TRY(lmv_linear_fwd(p, 1, C, C, LMV_ACT_NONE, D.dtype, stream));
   }
   const float* ds[2] = {cb ? nullptr : d->masks[1], cb ? d->masks[1] : d->masks[3]};
-  return mlp_fwd(d, D, f, cb ? 1 : 0, outs, ds, save, stream);
+  return mlp_fwd(d, D, f, cb ? 1 : 0, outs, ds, save, stream, ln2_done);
 }
 
 extern "C" int lmv_block_bwd(const lmv_block_desc* d, const void* x, const void* c, const void* arena, size_t arena_bytes, const void* dx_out, const void* dc_out, void* dx, void* dc,

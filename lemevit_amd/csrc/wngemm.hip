@@ -33,17 +33,19 @@ struct WnProb {
   int M, rps;
   // WN_LNBWD: LayerNorm input rows, their (mean, rstd), optional second output C * row_scale[sample] (res = the residual-path gradient)
   const bf16_t* lnx; const float* stats; bf16_t* Cs;
+  float* stats_out;                       // WN_RES_LN: (mean, rstd) of the LayerNorm over the output rows (Cs = its normalised output), may be NULL
 };
 struct WnArgs {
   WnProb p[2];
   int K, npanels0, npanels;
   const float* gamma; float* partial;      // WN_LNBWD: LayerNorm weight; per-workgroup (dgamma | dbeta) rows [npanels][768]
+  const float* beta; float eps;            // WN_RES_LN: LayerNorm bias and epsilon (gamma above)
 #ifdef LMV_WN_TIMING
   unsigned long long* dbg;      // s_memtime stamps of wave 0 of workgroups 0 and npanels / 2 (tools/wn_timeline.py)
 #endif
 };
 
-enum { WN_BIAS = 0, WN_RES = 1, WN_LNBWD = 2 };
+enum { WN_BIAS = 0, WN_RES = 1, WN_LNBWD = 2, WN_RES_LN = 3 };
 constexpr int WN_BM = 128, WN_BN = 384, WN_BK = 64;
 constexpr int WN_A_BYTES = WN_BM * WN_BK * 2, WN_W_BYTES = WN_BN * WN_BK * 2;      // token slot 16 KB, weight stage 48 KB
 constexpr int WN_A_OFF = 2 * WN_W_BYTES, WN_LDS = 2 * WN_W_BYTES + 4 * WN_A_BYTES;    // [weights: 2 stages | tokens: 4 slots] = 160 KB
@@ -96,6 +98,7 @@ __global__ __launch_bounds__(512, 2) void wn_gemm_kernel(const WnArgs g) {
 #define WN_SEL(f) P.f = second ? g.p[1].f : g.p[0].f
   WN_SEL(A); WN_SEL(W); WN_SEL(bias); WN_SEL(C); WN_SEL(res); WN_SEL(row_scale); WN_SEL(M); WN_SEL(rps);
   if (EPI == WN_LNBWD) { WN_SEL(lnx); WN_SEL(stats); WN_SEL(Cs); }
+  if (EPI == WN_RES_LN) { WN_SEL(Cs); WN_SEL(stats_out); }
 #undef WN_SEL
   if (!P.bias) P.bias = g_wn_zero;
   const int m0 = (second ? panel - g.npanels0 : panel) * WN_BM;
@@ -323,29 +326,82 @@ __global__ __launch_bounds__(512, 2) void wn_gemm_kernel(const WnArgs g) {
     b4[p][0] = *reinterpret_cast<const f32x4_t*>(P.bias + cw + 32 * p);
     b4[p][1] = *reinterpret_cast<const f32x4_t*>(P.bias + cw + 32 * p + 4);
   }
+  constexpr bool RES = EPI == WN_RES || EPI == WN_RES_LN;
+  float rs1[4], rs2[4];                      // WN_RES_LN: sum and sum of squares of the lane's 24 (rounded) outputs of each row
 #pragma unroll
   for (int ti = 0; ti < 4; ++ti) {
     const int row = m0 + 64 * wm + 16 * ti + (lane & 15);
     const int rowc = min(row, P.M - 1);
     float sc = 1.f;
     f32x4_t r4[3];
-    if (EPI == WN_RES) {
+    if (RES) {
       if (P.row_scale) sc = P.row_scale[rowc / P.rps];
 #pragma unroll
       for (int p = 0; p < 3; ++p) r4[p] = *reinterpret_cast<const f32x4_t*>(P.res + (long long)rowc * WN_BN + cw + 32 * p);
     }
+    float a1 = 0.f, a2 = 0.f;
 #pragma unroll
     for (int p = 0; p < 3; ++p) {
       float v[8];
 #pragma unroll
       for (int e = 0; e < 4; ++e) { v[e] = acc[ti][2 * p][e] + b4[p][0][e]; v[4 + e] = acc[ti][2 * p + 1][e] + b4[p][1][e]; }
-      if (EPI == WN_RES) {
+      if (RES) {
         float r8[8];
         wn_unpack8(r4[p], r8);
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] = r8[e] + sc * v[e];
       }
-      if (row < P.M) wn_gstore16(P.C + (long long)row * WN_BN + cw + 32 * p, wn_pack8(v));
+      const f32x4_t packed = wn_pack8(v);
+      if (row < P.M) wn_gstore16(P.C + (long long)row * WN_BN + cw + 32 * p, packed);
+      if (EPI == WN_RES_LN) {                  // the LayerNorm below sees what a separate launch would read back: the ROUNDED outputs
+        wn_unpack8(packed, v);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { acc[ti][2 * p][e] = v[e]; acc[ti][2 * p + 1][e] = v[4 + e]; }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { a1 += v[e]; a2 = fmaf(v[e], v[e], a2); }
+      }
+    }
+    if (EPI == WN_RES_LN) {
+      a1 += __shfl_xor(a1, 16, 64); a1 += __shfl_xor(a1, 32, 64);
+      a2 += __shfl_xor(a2, 16, 64); a2 += __shfl_xor(a2, 32, 64);
+      rs1[ti] = a1; rs2[ti] = a2;
+    }
+  }
+  if constexpr (EPI == WN_RES_LN) {
+    // LayerNorm over the 128 finished rows (models/lemevit.py:563: norm2 follows the attention half's residual add): the sums of a row's
+    // 384 columns meet through LDS across the four waves of the wave row (one-pass fp32 statistics, variance clamped at 0)
+    float* const red = reinterpret_cast<float*>(smem);
+    if (lane < 16) {
+#pragma unroll
+      for (int ti = 0; ti < 4; ++ti) { red[(wave * 64 + ti * 16 + lane) * 2] = rs1[ti]; red[(wave * 64 + ti * 16 + lane) * 2 + 1] = rs2[ti]; }
+    }
+    __syncthreads();
+    f32x4_t gm[3][2], bt[3][2];
+#pragma unroll
+    for (int p = 0; p < 3; ++p)
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        gm[p][q] = *reinterpret_cast<const f32x4_t*>(g.gamma + cw + 32 * p + 4 * q);
+        bt[p][q] = *reinterpret_cast<const f32x4_t*>(g.beta + cw + 32 * p + 4 * q);
+      }
+    const float invC = 1.f / (float)WN_BN;
+#pragma unroll
+    for (int ti = 0; ti < 4; ++ti) {
+      float a1 = 0.f, a2 = 0.f;
+#pragma unroll
+      for (int w4 = 0; w4 < 4; ++w4) { const int o = (((wm * 4 + w4) * 64) + ti * 16 + (lane & 15)) * 2; a1 += red[o]; a2 += red[o + 1]; }
+      const float mean = a1 * invC, var = fmaxf(a2 * invC - mean * mean, 0.f), rstd = rsqrtf(var + g.eps);
+      const int row = m0 + 64 * wm + 16 * ti + (lane & 15);
+      if (row < P.M) {
+        if (P.stats_out && wn == 0 && lane < 16) { P.stats_out[2 * (long long)row] = mean; P.stats_out[2 * (long long)row + 1] = rstd; }
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+          float v[8];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] = (acc[ti][2 * p + (e >> 2)][e & 3] - mean) * rstd * gm[p][e >> 2][e & 3] + bt[p][e >> 2][e & 3];
+          wn_gstore16(P.Cs + (long long)row * WN_BN + cw + 32 * p, wn_pack8(v));
+        }
+      }
     }
   }
   WSTAMP();
@@ -429,6 +485,38 @@ extern "C" int lmv_linear_dx_ln_bwd(const lmv_linear_problem* p, const lmv_ln_se
   if (int rc = wn_launch<WN_LNBWD>(a, (hipStream_t)stream)) return rc;
   LMV_CHECK_LAUNCH("linear_dx_ln_bwd");
   *partial_rows = a.npanels;
+  return LMV_OK;
+}
+
+// out = res + row_scale (a W^T + bias);  y = LayerNorm(out) -- the attention projection of a block with the norm2 that follows it
+extern "C" int lmv_linear_res_ln_fwd_supported(int N, int K, int dtype) { return dtype == LMV_BF16 && N == WN_BN && K >= WN_BK && (K % WN_BK) == 0; }
+extern "C" int lmv_linear_res_ln_fwd(const lmv_linear_problem* p, const lmv_ln_segment* seg, int nproblems, int N, int K, const float* gamma, const float* beta,
+                                     float eps, int dtype, void* stream) {
+  if (!lmv_linear_res_ln_fwd_supported(N, K, dtype)) LMV_FAIL(LMV_ERR_SHAPE, "linear_res_ln_fwd: N=%d K=%d dtype=%d (bf16, N = 384, K %% 64 == 0)", N, K, dtype);
+  if (nproblems < 1 || nproblems > 2 || !p || !seg || !gamma || !beta || !(eps > 0.f)) LMV_FAIL(LMV_ERR_SHAPE, "linear_res_ln_fwd: null argument / nproblems must be 1 or 2");
+  WnArgs a{};
+  int npan[2] = {0, 0};
+  for (int i = 0; i < nproblems; ++i) {
+    const lmv_ln_segment& q = seg[i];
+    if (p[i].rows <= 0 || p[i].rows != q.rows || p[i].rows > 0x7fffffffLL / 2048) LMV_FAIL(LMV_ERR_SHAPE, "linear_res_ln_fwd: bad rows");
+    if (!p[i].a || !p[i].w || !p[i].out || !p[i].res || !q.y || p[i].out_pre || p[i].aux || (p[i].row_scale && p[i].rows_per_sample <= 0))
+      LMV_FAIL(LMV_ERR_SHAPE, "linear_res_ln_fwd: a, w, out, res and seg.y are required; no out_pre / aux");
+    if (!lmv_aligned16(p[i].a) || !lmv_aligned16(p[i].w) || !lmv_aligned16(p[i].out) || !lmv_aligned16(p[i].res) || !lmv_aligned16(q.y) || !lmv_aligned16(p[i].bias) ||
+        !lmv_aligned16(gamma) || !lmv_aligned16(beta))
+      LMV_FAIL(LMV_ERR_SHAPE, "linear_res_ln_fwd: operands must be 16-byte aligned");
+    WnProb& w = a.p[i];
+    w.A = (const bf16_t*)p[i].a; w.W = (const bf16_t*)p[i].w; w.bias = p[i].bias; w.C = (bf16_t*)p[i].out; w.res = (const bf16_t*)p[i].res;
+    w.row_scale = p[i].row_scale; w.M = (int)p[i].rows; w.rps = p[i].rows_per_sample > 0 ? p[i].rows_per_sample : 1;
+    w.Cs = (bf16_t*)q.y; w.stats_out = q.stats;
+    npan[i] = (int)((p[i].rows + WN_BM - 1) / WN_BM);
+  }
+  a.K = K; a.npanels0 = npan[0]; a.npanels = npan[0] + npan[1];
+  a.gamma = gamma; a.beta = beta; a.eps = eps;
+#ifdef LMV_WN_TIMING
+  a.dbg = nullptr;
+#endif
+  if (int rc = wn_launch<WN_RES_LN>(a, (hipStream_t)stream)) return rc;
+  LMV_CHECK_LAUNCH("linear_res_ln_fwd");
   return LMV_OK;
 }
 

@@ -294,6 +294,26 @@ def layernorm_bwd_multi(dys: Sequence[Tensor], xs: Sequence[Tensor], stats: Sequ
     return dxs if next_scales is None else (dxs, scaled)
 
 
+def res_ln_fused(C_: int, K: int, rows: int, dtype) -> bool:
+    """Does the block schedule run `out = res + s (a W^T + b)` and the LayerNorm of `out` as ONE launch (lmv_linear_res_ln_fwd)?  The same
+    rule as csrc/block.hip::res_ln_ok: supported shape, enough rows to fill the chip with 128-row panels, switch on."""
+    return (dtype == torch.bfloat16 and rows >= 16384 and bool(lib.lmv_linear_res_ln_fwd_supported(C_, K, _lib.LMV_BF16)) and _lib.config_get("res_ln_fused") != 0)
+
+
+def linear_res_ln_fwd(probs: Sequence[Prob], N: int, K: int, gamma: Tensor, beta: Tensor, eps: float, want_stats: bool):
+    """probs as for linear_fwd (res required): writes p.out; returns (ys, stats) = LayerNorm of the outputs (lmv_linear_res_ln_fwd)."""
+    arr = _pack(probs)
+    seg = (LnSegment * len(probs))()
+    ys, sts = [], []
+    for s, p in zip(seg, probs):
+        y = torch.empty_like(p.out)
+        st = torch.empty((p.rows, 2), device=p.out.device, dtype=torch.float32) if want_stats else None
+        s.y, s.stats, s.rows = _ptr(y), _f32(st), p.rows
+        ys.append(y); sts.append(st)
+    check(lib.lmv_linear_res_ln_fwd(arr, seg, len(probs), N, K, _f32(gamma), _f32(beta), eps, dtype_code(probs[0].a), _stream()), "lmv_linear_res_ln_fwd")
+    return ys, sts
+
+
 def linear_dx_ln_bwd(dys: Sequence[Tensor], wt: Tensor, xs: Sequence[Tensor], stats: Sequence[Tensor], gamma: Tensor, dgamma: Tensor, dbeta: Tensor,
                      dres: Sequence[Optional[Tensor]], next_scales: Optional[Sequence[Optional[Tensor]]] = None):
     """The dX of a Linear through its TRANSPOSED weight `wt` [C, N] fused with the LayerNorm backward of the Linear's input

@@ -691,3 +691,35 @@ def test_linear_dx_ln_bwd_fused(rows, rows_c, N):
     ref = t["r"] * (gg - gg.mean(1, keepdim=True) - xh * (gg * xh).mean(1, keepdim=True)) + t["dres64"]
     assert_close(dx, ref, dtype, "dx (raw segments)")
     assert_close(dxs_, ref * t["scr"], dtype, "dx_scaled")      # scaled in fp32, rounded once
+
+
+@pytest.mark.parametrize("rows,rows_c,K", [(27136 // 8, 256, 384), (1000, 48, 1536), (129, 0, 64)])
+def test_linear_res_ln_fwd_fused(rows, rows_c, K):
+    """lmv_linear_res_ln_fwd (csrc/wngemm.hip, bf16, N = 384): out = res + s (a W^T + b) and y = LayerNorm(out) in one launch -- `out` against
+    float64 math, `y` and the (mean, rstd) rows against the float64 LayerNorm of the kernel's own ROUNDED `out` (what a separate launch
+    would normalise), with a second problem that has its own weight; and `y` against lmv_layernorm_fwd on the same `out`."""
+    o = ops()
+    dtype, N, eps = torch.bfloat16, 384, 1e-6
+    gamma = (det_tensor((N,), "gam", 5, 0.3) + 1.0).to(dev()); beta = det_tensor((N,), "bet", 5, 0.2).to(dev())
+    rps = 7
+    probs, refs = [], []
+    for tag, r in (("x", rows), ("c", rows_c)):
+        if not r:
+            continue
+        a, a64 = rnd((r, K), "a" + tag, dtype); w, w64 = rnd((N, K), "w" + tag, dtype, 1 / math.sqrt(K)); res, res64 = rnd((r, N), "res" + tag, dtype)
+        bias = det_tensor((N,), "b" + tag, 7, 0.5).to(dev())
+        sc = (det_tensor(((r + rps - 1) // rps,), "sc" + tag, 7).abs() + 0.5).to(dev())
+        out = torch.zeros((r, N), device=dev(), dtype=dtype)
+        probs.append(o.Prob(a, w, out, bias=bias, res=res, row_scale=sc, rps=rps))
+        refs.append(res64 + sc.cpu().double()[torch.arange(r) // rps][:, None] * (a64 @ w64.t() + bias.cpu().double()))
+    ys, sts = o.linear_res_ln_fwd(probs, N, K, gamma, beta, eps, want_stats=True)
+    for p, ref, y, st in zip(probs, refs, ys, sts):
+        assert_close(p.out, ref, dtype, "out")
+        o64 = p.out.float().cpu().double()
+        mean = o64.mean(1, keepdim=True); var = ((o64 - mean) ** 2).mean(1, keepdim=True); rstd = 1 / torch.sqrt(var + eps)
+        assert_close(y, (o64 - mean) * rstd * gamma.cpu().double() + beta.cpu().double(), dtype, "LayerNorm(out)")
+        assert float((st[:, 0].cpu().double() - mean[:, 0]).abs().max()) <= 1e-5 * float(o64.abs().max())
+        assert float((st[:, 1].cpu().double() / rstd[:, 0] - 1).abs().max()) <= 1e-4
+        y2, _ = o.layernorm_fwd(p.out.view(1, -1, N), gamma, beta, eps)
+        d = float((y.float() - y2.view(-1, N).float()).abs().max()); m = float(y2.float().abs().max())
+        assert d <= 8e-3 * m, f"fused and separate LayerNorm differ by {d:.3e} (max-abs {m:.3e})"      # one bf16 ulp where the two round differently

@@ -8,7 +8,7 @@ OUT=${1:-gpurun_out/pmc_per_kernel.csv}; shift; W=gpurun_out/pmc_k; rm -rf $W; m
 i=0
 for set in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE"; do
   i=$((i+1))
-  rocprofv3 --pmc $set --kernel-trace -d $W/s$i -o p -- python bench.py --graph 0 --steps 3 --warmup 2 --no-cpu-baseline --no-kernel-timing --no-issue-probe "$@" > $W/s$i.log 2>&1
+  rocprofv3 --pmc $set --kernel-trace -d $W/s$i -o p -- python bench.py --graph 0 --steps 3 --warmup 2 --no-cpu-baseline --no-kernel-timing --no-issue-probe --no-forward-probe "$@" > $W/s$i.log 2>&1
 done
 python - <<PY
 import sqlite3, glob, re, collections

@@ -4,7 +4,7 @@
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT; OUT=$1; shift
 D=gpurun_out/pst; rm -rf $D; mkdir -p $D
 for c in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $c --kernel-trace -d $D/$c -o p -- python bench.py --graph 0 --steps 4 --warmup 2 --no-cpu-baseline --no-kernel-timing --no-issue-probe "$@" > $D/$c.log 2>&1
+  rocprofv3 --pmc $c --kernel-trace -d $D/$c -o p -- python bench.py --graph 0 --steps 4 --warmup 2 --no-cpu-baseline --no-kernel-timing --no-issue-probe --no-forward-probe "$@" > $D/$c.log 2>&1
 done
 python - "$OUT" "$@" <<PY
 import sqlite3, glob, json, sys

@@ -6,19 +6,21 @@
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 OUT=${1:-gpurun_out/pmc_traffic.json}; W=gpurun_out/pmc_work; rm -rf $W; mkdir -p $W
 for c in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $c --kernel-trace -d $W/$c -o p -- python bench.py --graph 0 --steps 3 --warmup 2 --no-cpu-baseline > $W/$c.log 2>&1
+  rocprofv3 --pmc $c --kernel-trace -d $W/$c -o p -- python bench.py --graph 0 --steps 3 --warmup 2 --no-cpu-baseline --no-kernel-timing --no-issue-probe --no-forward-probe > $W/$c.log 2>&1
 done
 python - <<PY
 import sqlite3, json, glob
 res = {}
 for c in ("FETCH_SIZE", "WRITE_SIZE"):
     db = sqlite3.connect(glob.glob("$W/%s/*.db" % c)[0])
-    # forward Linear GEMMs: gemm_kernel<unsigned short, false, false, false, ...>; last 3 steps = last 3/5 of the launches
-    rows = db.execute("select value, duration from counters_collection where counter_name=? and kernel_name like '%gemm_kernel<unsigned short, false, false, false%' order by start", (c,)).fetchall()
+    # forward-form Linear launches (lmv_linear_fwd and its fused forms): the 128 x 128 tile kernel gemm_kernel<unsigned short, false, false, false, ...>,
+    # the register-stationary kernel and the whole-width kernel (rsgemm.hip / wngemm.hip); 2 warm-up + 3 timed steps: last 3/5 of the launches
+    rows = db.execute("select value, duration from counters_collection where counter_name=? and (kernel_name like '%gemm_kernel<unsigned short, false, false, false%' "
+                      "or kernel_name like '%rs_gemm_kernel%' or kernel_name like '%wn_gemm_kernel%') order by start", (c,)).fetchall()
     n = len(rows); rows = rows[n * 2 // 5:]
     res[c] = {"launches": len(rows), "avg_kb": sum(r[0] for r in rows) / len(rows), "avg_us": sum(r[1] for r in rows) / len(rows) / 1e3}
 fetch = 2.0 * res["FETCH_SIZE"]["avg_kb"] * 1024; write = res["WRITE_SIZE"]["avg_kb"] * 1024
-out = {"kernel": "gemm_kernel<bf16,NT> (Linear forward), bench.py train step, eager", "launches_averaged": res["FETCH_SIZE"]["launches"],
+out = {"kernel": "forward-form Linear launches (gemm_kernel<bf16,NT>, rs_gemm_kernel, wn_gemm_kernel) of bench.py's train step (native block schedule: forward layers, and the dX launches that run as forward-form GEMMs on transposed weights)", "launches_averaged": res["FETCH_SIZE"]["launches"],
        "fetch_bytes_per_launch_corrected_x2": fetch, "write_bytes_per_launch": write, "traffic_bytes_per_launch": fetch + write,
        "avg_launch_us_under_pmc": res["FETCH_SIZE"]["avg_us"], "raw": res}
 json.dump(out, open("$OUT", "w"), indent=1); print(json.dumps(out))

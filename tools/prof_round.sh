@@ -6,13 +6,13 @@ cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT; T=${1:-r01}; O=gpurun_out/$T
 python bench.py > $O/bench_train.json 2> $O/bench_train.err
 python bench.py --mode infer > $O/bench_infer.json 2>> $O/bench_train.err
 # (--no-kernel-timing --no-issue-probe: the 3 event-bracketed steps bench.py appends run the per-launch Python schedule and would skew a "last steps" window)
-rocprofv3 --kernel-trace --stats -d $O/kt -o trace -- python bench.py --no-cpu-baseline --no-kernel-timing --no-issue-probe > $O/bench_under_rocprof.log 2>&1
+rocprofv3 --kernel-trace --stats -d $O/kt -o trace -- python bench.py --no-cpu-baseline --no-kernel-timing --no-issue-probe --no-forward-probe > $O/bench_under_rocprof.log 2>&1
 DB=$(find $O/kt -name "*.db" | head -1)
 python tools/rocpd_stats.py $DB > $O/train_kernel_stats_full.csv
 python tools/rocpd_stats.py $DB 400 > $O/train_kernel_stats_steady.csv
 rm -rf $O/kt
 # per-step breakdown with the weight-gradient GEMMs in line (side-stream overlap inflates per-kernel durations)
-LMV_SIDE_STREAM=0 rocprofv3 --kernel-trace -d $O/kt2 -o trace -- python bench.py --steps 6 --warmup 3 --no-cpu-baseline --no-kernel-timing --no-issue-probe > $O/bench_inline_under_rocprof.log 2>&1
+LMV_SIDE_STREAM=0 rocprofv3 --kernel-trace -d $O/kt2 -o trace -- python bench.py --steps 6 --warmup 3 --no-cpu-baseline --no-kernel-timing --no-issue-probe --no-forward-probe > $O/bench_inline_under_rocprof.log 2>&1
 DB2=$(find $O/kt2 -name "*.db" | head -1)
 python tools/step_breakdown.py $DB2 $O/bench_inline_under_rocprof.log 3 > $O/train_step_breakdown.csv
 rm -rf $O/kt2

@@ -114,12 +114,13 @@ inline bool fused_on(const lmv_block_desc* d, const Dims& D, int save) {
 }
 inline bool fold_qkv(const Dims& D) { return D.C >= 192; }
 
-// split384 (below): the C = 384 MLP half of the fused inference schedule as three launches instead of the one-kernel form
-inline bool mlp_split384(const Dims& D) { return lmv_config().mlp_split384 && D.C == 384 && D.Hd == 1536 && D.rows[0] + D.rows[1] >= 16384; }
+// split384 (below): the C = 384 MLP half of the fused inference schedule as three launches instead of the one-kernel form (measured faster
+// at 27136 rows -- 9.51 -> 9.38 ms -- and at 37888 rows -- Base 384^2 forward 16.5 -> 16.1 ms)
+inline bool mlp_split384(const Dims& D) { const int64_t r = D.rows[0] + D.rows[1]; return lmv_config().mlp_split384 && D.C == 384 && D.Hd == 1536 && r >= 16384 && r <= 65536; }
 // "S" blocks: the attention projection (residual epilogue) and the norm2 that follows it in ONE launch (lmv_linear_res_ln_fwd), wherever
 // the MLP half reads norm2's output from memory (training; the split inference form) -- lemevit_amd/ops.py::res_ln_fused is the same rule
 inline bool res_ln_ok(const lmv_block_desc* d, const Dims& D, int save) {
-  if (D.kind != LMV_BLOCK_S || D.dtype != LMV_BF16 || !lmv_config().res_ln_fused || D.rows[0] + D.rows[1] < 16384) return false;
+  if (D.kind != LMV_BLOCK_S || D.dtype != LMV_BF16 || !lmv_config().res_ln_fused || D.rows[0] + D.rows[1] < 16384 || D.rows[0] + D.rows[1] > 32768) return false;
   if (!lmv_linear_res_ln_fwd_supported(D.C, D.C, D.dtype)) return false;
   return !(fused_on(d, D, save) && !mlp_split384(D));
 }
@@ -317,7 +318,8 @@ int ln_bwd(Side& sd, const lmv_ln_segment* seg, int nseg, const float* gamma, fl
 // The same LayerNorm backward fused into the dX GEMM that produces its dy (csrc/wngemm.hip: C = 384, bf16, transposed weight copy present,
 // enough rows to fill the chip): dy never reaches memory.  p[i].a = dY, p[i].w = the transposed weight; seg as for ln_bwd.
 inline bool dx_ln_fused_ok(const Dims& D, const void* wt, int N) {
-  return wt && D.dtype == LMV_BF16 && lmv_config().dx_ln_fused && lmv_linear_dx_ln_bwd_supported(D.C, N, D.dtype) && D.rows[0] + D.rows[1] >= 16384;
+  const int64_t rows = D.rows[0] + D.rows[1];      // one round of 128-row panels on the chip (csrc/wngemm.hip::lmv_wn_eligible)
+  return wt && D.dtype == LMV_BF16 && lmv_config().dx_ln_fused && lmv_linear_dx_ln_bwd_supported(D.C, N, D.dtype) && rows >= 16384 && rows <= 32768;
 }
 int dx_ln_bwd(Side& sd, const lmv_linear_problem* p, const lmv_ln_segment* seg, int nseg, int N, const float* gamma, float* dgamma, float* dbeta, const Dims& D,
               void* ws, size_t ws_bytes) {

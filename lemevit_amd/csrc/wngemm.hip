@@ -2,8 +2,9 @@
 //
 //   out[r, n] = epilogue( sum_k A[r, k] W[n, k] + bias[n] )
 //
-// Which launches: the 384-wide outputs of the stage-3 blocks -- attention projection and fc2 forward, and (through transposed weight
-// copies, lmv_block_desc.*_wt) the dX of qkv, proj and fc1 -- five of the eight forward / dX GEMMs of an S block.  On the 128 x 128 tile
+// Which launches: the 384-wide outputs of the stage-3 blocks -- attention projection and fc2 forward (residual epilogue; the projection
+// together with the norm2 behind it: lmv_linear_res_ln_fwd) and, through transposed weight copies (lmv_block_desc.*_wt), the dX of qkv and
+// fc1 together with the LayerNorm backward of their input (lmv_linear_dx_ln_bwd): a workgroup here owns whole rows.  On the 128 x 128 tile
 // kernels of gemm.hip these are 636-tile launches over 512 (8-wave kernel) or 1024 (4-wave kernel) resident slots: 1.24 rounds cost two
 // (tools/quant_probe.py: 510 tiles 32 us, 513 tiles 47 us at K = 1536), every token row is fetched by three n-tiles, and a workgroup
 // issues one LDS-DMA instruction per four MFMAs (a 128 x 128 tile needs 64 B / clk of operands at the full MFMA rate -- the CU's whole
@@ -441,11 +442,15 @@ bool lmv_wn_eligible(const lmv_linear_problem* p, int nproblems, int N, int K, i
   }
   if (nproblems == 2 && (p[0].res != nullptr) != (p[1].res != nullptr)) return false;      // one kernel instance: one epilogue
   if (force) return true;
-  // Measured wins only.  Forward launches with the residual epilogue (attention projection, fc2): 44.7 -> 41.7 us at K = 1536.  NOT the
-  // dX launches of the backward pass, although the kernel is 7 - 16 % faster there in isolation: they run next to the weight-gradient
-  // stream, whose 48 KB workgroups keep the CUs' LDS occupied -- a 128 KB workgroup waits for a whole CU to drain (train step + 0.3 ms).
+  // Measured wins only (tools/quant_probe.py wn, tools/cold_probe.py, profiles/r03_wn_probe.txt).  Forward launches with the residual
+  // epilogue (attention projection, fc2): 45.1 -> 39.6 us at K = 1536 with the operands in the MALL, 66 -> 52 us with cold operands.
+  // Plain launches (the dX of proj through the transposed weight) stay on the tile kernel: next to the weight-gradient stream a 160 KB
+  // workgroup waits for a whole CU to drain, and the step does not gain (profiles/r03_ab_switches.txt).
   if (!p[0].res) return false;
-  return rows >= 16384;          // at least ~128 panels: below that the 128 x 128 tiles fill the chip better
+  // ONE round of 128-row panels on the 256 CUs: with fewer than ~128 panels the 128 x 128 tiles fill the chip better (8320 rows: 13 vs 8 us);
+  // beyond one round the one-per-CU workgroups lose (102400 rows = 3.1 rounds: 190 vs 178 us at K = 1536; Base at 384^2, B = 64 = 1.2 rounds:
+  // train step 49.5 vs 48.1 ms with / without)
+  return rows >= 16384 && rows <= 32768;
 }
 
 // dX of a Linear through its transposed weight fused with the LayerNorm backward of the Linear's input (include/lemevit_hip.h)

@@ -297,7 +297,7 @@ def layernorm_bwd_multi(dys: Sequence[Tensor], xs: Sequence[Tensor], stats: Sequ
 def res_ln_fused(C_: int, K: int, rows: int, dtype) -> bool:
     """Does the block schedule run `out = res + s (a W^T + b)` and the LayerNorm of `out` as ONE launch (lmv_linear_res_ln_fwd)?  The same
     rule as csrc/block.hip::res_ln_ok: supported shape, enough rows to fill the chip with 128-row panels, switch on."""
-    return (dtype == torch.bfloat16 and rows >= 16384 and bool(lib.lmv_linear_res_ln_fwd_supported(C_, K, _lib.LMV_BF16)) and _lib.config_get("res_ln_fused") != 0)
+    return (dtype == torch.bfloat16 and 16384 <= rows <= 32768 and bool(lib.lmv_linear_res_ln_fwd_supported(C_, K, _lib.LMV_BF16)) and _lib.config_get("res_ln_fused") != 0)
 
 
 def linear_res_ln_fwd(probs: Sequence[Prob], N: int, K: int, gamma: Tensor, beta: Tensor, eps: float, want_stats: bool):

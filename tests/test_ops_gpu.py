@@ -723,3 +723,49 @@ def test_linear_res_ln_fwd_fused(rows, rows_c, K):
         y2, _ = o.layernorm_fwd(p.out.view(1, -1, N), gamma, beta, eps)
         d = float((y.float() - y2.view(-1, N).float()).abs().max()); m = float(y2.float().abs().max())
         assert d <= 8e-3 * m, f"fused and separate LayerNorm differ by {d:.3e} (max-abs {m:.3e})"      # one bf16 ulp where the two round differently
+
+
+def test_whole_width_kernels_under_load():
+    """Race screen for csrc/wngemm.hip (hand-counted vmcnt, requests split by wave, LDS reuse in the fused epilogues) and csrc/rsgemm.hip: their entry
+    points at the full stage-3 shape of config 3, once on an idle chip and then 8 times while a second stream streams 1 GB copies and runs GEMMs -- every
+    output must be BIT-identical to the idle run (the kernels reduce in a fixed order; an early LDS read or a short wait shows up as a mismatch
+    that comes and goes with timing)."""
+    o = ops()
+    dtype, C, rows, rows_c, Hd = torch.bfloat16, 384, 25088, 2048, 1536
+    a, _ = rnd((rows, Hd), "la", dtype); ac, _ = rnd((rows_c, Hd), "lac", dtype)
+    w, _ = rnd((C, Hd), "lw", dtype, 1 / math.sqrt(Hd)); bias = det_tensor((C,), "lb", 7, 0.5).to(dev())
+    res, _ = rnd((rows, C), "lres", dtype); resc, _ = rnd((rows_c, C), "lresc", dtype)
+    gamma = (det_tensor((C,), "lg", 5, 0.3) + 1.0).to(dev()); beta = det_tensor((C,), "lbt", 5, 0.2).to(dev())
+    sc = (det_tensor((128,), "lsc", 7).abs() + 0.5).to(dev())
+    x3, _ = rnd((128, 196, C), "lx", dtype, 1.5); c3, _ = rnd((128, 16, C), "lc", dtype, 1.5)
+    stx = torch.stack([x3.float().mean(-1).reshape(-1), 1 / torch.sqrt(x3.float().var(-1, unbiased=False).reshape(-1) + 1e-6)], 1).contiguous()
+    stc = torch.stack([c3.float().mean(-1).reshape(-1), 1 / torch.sqrt(c3.float().var(-1, unbiased=False).reshape(-1) + 1e-6)], 1).contiguous()
+
+    def run():
+        out, outc = torch.empty((rows, C), device=dev(), dtype=dtype), torch.empty((rows_c, C), device=dev(), dtype=dtype)
+        probs = [o.Prob(a, w, out, bias=bias, res=res, row_scale=sc, rps=196), o.Prob(ac, w, outc, bias=bias, res=resc, row_scale=sc, rps=16)]
+        o.linear_fwd(probs, C, Hd)                                                   # residual epilogue (fc2 forward)
+        r1 = (out.clone(), outc.clone())
+        ys, sts = o.linear_res_ln_fwd(probs, C, Hd, gamma, beta, 1e-6, want_stats=True)      # + LayerNorm
+        dg, db = torch.zeros(C, device=dev()), torch.zeros(C, device=dev())
+        dxs, dxsc = o.linear_dx_ln_bwd([a, ac], w, [x3, c3], [stx, stc], gamma, dg, db, [res.view(128, 196, C), resc.view(128, 16, C)], next_scales=[sc, sc])
+        # the register-stationary kernel (csrc/rsgemm.hip, counted waits of its own): fc1 forward with the pre-activation copy, GELU' dX of fc2
+        h = torch.empty((rows, Hd), device=dev(), dtype=dtype); u = torch.empty_like(h); du = torch.empty_like(h)
+        o.linear_fwd([o.Prob(res, w1, h, bias=b1, out_pre=u)], Hd, C, o.ACT_GELU)
+        o.linear_fwd([o.Prob(res, w1, du, aux=a, row_scale=sc, rps=196)], Hd, C, o.ACT_GELU_GRAD)
+        return [*r1, out, outc, *ys, *sts, *dxs, *dxsc, dg, db, h, u, du]
+
+    w1, _ = rnd((Hd, C), "lw1", dtype, 1 / math.sqrt(C)); b1 = det_tensor((Hd,), "lb1", 7, 0.5).to(dev())
+    idle = [t.clone() for t in run()]
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream()
+    big = torch.empty(256 << 20, device=dev(), dtype=torch.float32); big2 = torch.empty_like(big)
+    ga = torch.randn(4096, 4096, device=dev(), dtype=dtype); gb = torch.randn(4096, 4096, device=dev(), dtype=dtype)
+    for it in range(8):
+        with torch.cuda.stream(side):
+            for _ in range(3):
+                big2.copy_(big); ga @ gb
+        got = run()
+        torch.cuda.synchronize()
+        for i, (g, r) in enumerate(zip(got, idle)):
+            assert torch.equal(g, r), f"round {it}: output {i} differs from the idle run by {float((g.float() - r.float()).abs().max()):.3e}"

@@ -194,6 +194,13 @@ int lmv_layernorm_bwd_reduce(const void* workspace, int partial_rows, int C, flo
 /* The forward mirror: a Linear with the residual epilogue followed by the LayerNorm of its output (proj + norm2, models/lemevit.py:562-563,
  * 632-635) in one launch:  out = res + row_scale (a W^T + bias);  seg[i].y = LN(out) (of the ROUNDED out, as a separate launch would read
  * it), seg[i].stats = (mean, rstd) when non-NULL.  bf16, N = 384, K % 64 == 0 (lmv_linear_res_ln_fwd_supported). */
+/* LayerNorm -> Linear with the EXACT LayerNorm in front (no folding), for the C = 96 layers (norm1 -> qkv1 / qkv2 / kv / q,
+ * models/lemevit.py:560,599; csrc/rswgemm.hip: the whole weight matrix resident in LDS, every wave streams 32-row panels through registers):
+ *     seg[i].y = LN(p[i].a)  (written when non-NULL: training keeps it for the weight gradient),  seg[i].stats = (mean, rstd) (when non-NULL),
+ *     p[i].out = seg[i].y W^T + bias.      gamma == NULL: plain Linear.   bf16, K = 96, N % 32 == 0, N <= 384 (lmv_ln_linear_exact_fwd_supported). */
+int lmv_ln_linear_exact_fwd_supported(int N, int K, int dtype);
+int lmv_ln_linear_exact_fwd(const lmv_linear_problem* p, const lmv_ln_segment* seg, int nproblems, int N, int K, const float* gamma, const float* beta,
+                            float eps, int dtype, void* stream);
 int lmv_linear_res_ln_fwd_supported(int N, int K, int dtype);
 int lmv_linear_res_ln_fwd(const lmv_linear_problem* p, const lmv_ln_segment* seg, int nproblems, int N, int K, const float* gamma, const float* beta,
                           float eps, int dtype, void* stream);

@@ -95,6 +95,8 @@ SIGNATURES = {
     "lmv_layernorm_bwd": (_I, [C.POINTER(LnSegment), _I, _P, _P, _P, _I, _P, _Z, _I, _P]),
     "lmv_layernorm_bwd_partial": (_I, [C.POINTER(LnSegment), _I, _P, _I, _P, _Z, C.POINTER(C.c_int), _I, _P]),
     "lmv_layernorm_bwd_reduce": (_I, [_P, _I, _I, _P, _P, _P]),
+    "lmv_ln_linear_exact_fwd_supported": (_I, [_I, _I, _I]),
+    "lmv_ln_linear_exact_fwd": (_I, [C.POINTER(LinearProblem), C.POINTER(LnSegment), _I, _I, _I, _P, _P, _F, _I, _P]),
     "lmv_linear_res_ln_fwd_supported": (_I, [_I, _I, _I]),
     "lmv_linear_res_ln_fwd": (_I, [C.POINTER(LinearProblem), C.POINTER(LnSegment), _I, _I, _I, _P, _P, _F, _I, _P]),
     "lmv_linear_dx_ln_bwd_supported": (_I, [_I, _I, _I]),

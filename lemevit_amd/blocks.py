@@ -322,10 +322,14 @@ def _attn_D_fwd(P, ts, ds, save):
     x, c = ts
     C, N, M = x.shape[-1], x.shape[1], c.shape[1]
     sx, sc = ops.dca_scales(N, M, C)
-    xn, st = ops.layernorm_fwd_multi(ts, P["norm1.weight"], P["norm1.bias"], BLOCK_LN_EPS, want_stats=save)
     q1, q2 = _empty(x, 3 * C), _empty(c, 3 * C)
-    ops.linear_fwd([Prob(xn[0], P["attn.qkv1.weight"], q1, bias=P["attn.qkv1.bias"]),
-                    Prob(xn[1], P["attn.qkv2.weight"], q2, bias=P["attn.qkv2.bias"])], 3 * C, C)
+    if ops.ln_exact_fused(3 * C, C, x.dtype):        # norm1 and both projections in one launch (csrc/rswgemm.hip, C = 96)
+        xn, st = ops.ln_linear_exact_fwd([Prob(x, P["attn.qkv1.weight"], q1, bias=P["attn.qkv1.bias"]), Prob(c, P["attn.qkv2.weight"], q2, bias=P["attn.qkv2.bias"])],
+                                         3 * C, C, P["norm1.weight"], P["norm1.bias"], BLOCK_LN_EPS, want_stats=save)
+    else:
+        xn, st = ops.layernorm_fwd_multi(ts, P["norm1.weight"], P["norm1.bias"], BLOCK_LN_EPS, want_stats=save)
+        ops.linear_fwd([Prob(xn[0], P["attn.qkv1.weight"], q1, bias=P["attn.qkv1.bias"]),
+                        Prob(xn[1], P["attn.qkv2.weight"], q2, bias=P["attn.qkv2.bias"])], 3 * C, C)
     aox, lsex = ops.attn_fwd((q1, 0), (q2, C), (q2, 2 * C), C, sx, want_lse=save)     # image -> meta   (:297)
     aoc, lsec = ops.attn_fwd((q2, 0), (q1, C), (q1, 2 * C), C, sc, want_lse=save)     # meta  -> image  (:300)
     ox, oc = torch.empty_like(x), torch.empty_like(c)
@@ -400,10 +404,14 @@ def _attn_D2_bwd(P, G, saved, douts, ds, g=None):
 def _attn_C_fwd(P, xp, c, ds, save):
     """c <- c + ds * proj(CA(q(LN1(c)), kv(LN1(xp))))  (models/lemevit.py:477-486,600)."""
     C, N, M = c.shape[-1], xp.shape[1], c.shape[1]
-    (xn, cn), (stx, stc) = ops.layernorm_fwd_multi([xp, c], P["norm1.weight"], P["norm1.bias"], BLOCK_LN_EPS, want_stats=save)
     kv, q = _empty(xp, 2 * C), _empty(c, C)
-    ops.linear_fwd([Prob(xn, P["attn.kv.weight"], kv, bias=P["attn.kv.bias"])], 2 * C, C)
-    ops.linear_fwd([Prob(cn, P["attn.q.weight"], q, bias=P["attn.q.bias"])], C, C)
+    if ops.ln_exact_fused(2 * C, C, xp.dtype) and ops.ln_exact_fused(C, C, xp.dtype):      # norm1 inside the two projection launches (C = 96)
+        (xn,), (stx,) = ops.ln_linear_exact_fwd([Prob(xp, P["attn.kv.weight"], kv, bias=P["attn.kv.bias"])], 2 * C, C, P["norm1.weight"], P["norm1.bias"], BLOCK_LN_EPS, want_stats=save)
+        (cn,), (stc,) = ops.ln_linear_exact_fwd([Prob(c, P["attn.q.weight"], q, bias=P["attn.q.bias"])], C, C, P["norm1.weight"], P["norm1.bias"], BLOCK_LN_EPS, want_stats=save)
+    else:
+        (xn, cn), (stx, stc) = ops.layernorm_fwd_multi([xp, c], P["norm1.weight"], P["norm1.bias"], BLOCK_LN_EPS, want_stats=save)
+        ops.linear_fwd([Prob(xn, P["attn.kv.weight"], kv, bias=P["attn.kv.bias"])], 2 * C, C)
+        ops.linear_fwd([Prob(cn, P["attn.q.weight"], q, bias=P["attn.q.bias"])], C, C)
     ao, lse = ops.attn_fwd((q, 0), (kv, 0), (kv, C), C, ops.SDPA_SCALE, want_lse=save)
     oc = torch.empty_like(c)
     ops.linear_fwd([Prob(ao, P["attn.proj.weight"], oc, bias=P["attn.proj.bias"], res=c, row_scale=ds, rps=M)], C, C)

@@ -431,8 +431,12 @@ extern "C" int lmv_block_fwd(const lmv_block_desc* d, const void* x, const void*
   const int C = D.C, N = D.N, M = D.M;
   LMV_TRY(lmv_dwconv3x3_residual_fwd(x, d->pos_w, d->pos_b, f.xp, D.B, D.H, D.W, C, D.dtype, stream));          // :546
   const bool fq = fused_on(d, D, save) && fold_qkv(D);      // norm1 folded into the projections: no LayerNorm launch, no normalised copy
-  const void* src[2] = {f.xp, c};                           // token rows the projections read (fq: raw; else LN1 output)
-  if (!fq) {
+  // C = 96 blocks: norm1 runs INSIDE the projection launches (csrc/rswgemm.hip: exact LayerNorm on the register-resident rows, the
+  // normalised rows and their statistics written from there) -- lemevit_amd/ops.py::ln_exact_fused is the same rule
+  const bool ex = !fq && D.dtype == LMV_BF16 && lmv_config().ln_exact_fused && D.kind != LMV_BLOCK_S &&
+                  lmv_ln_linear_exact_fwd_supported(cb ? 2 * D.C : 3 * D.C, D.C, D.dtype) && lmv_ln_linear_exact_fwd_supported(D.C, D.C, D.dtype);
+  const void* src[2] = {f.xp, c};                           // token rows the projections read (fq / ex: raw; else LN1 output)
+  if (!fq && !ex) {
     lmv_ln_segment seg[2] = {};
     seg[0].x = f.xp; seg[0].y = f.n1[0]; seg[0].stats = save ? f.st1[0] : nullptr; seg[0].rows = D.rows[0];
     seg[1].x = c; seg[1].y = f.n1[1]; seg[1].stats = save ? f.st1[1] : nullptr; seg[1].rows = D.rows[1];
@@ -446,6 +450,11 @@ extern "C" int lmv_block_fwd(const lmv_block_desc* d, const void* x, const void*
       p[i] = prob(src[s], fq ? d->fold_attn_w[k] : d->attn_w[k], f.pj[s], D.rows[s]);
       p[i].bias = fq ? d->fold_attn_b[k] : d->attn_b[k];
       if (fq) p[i].aux = d->fold_attn_s[k];
+    }
+    if (ex) {
+      lmv_ln_segment seg[2] = {};
+      for (int i = 0; i < np; ++i) { const int s = streams[i]; seg[i].y = f.n1[s]; seg[i].stats = save ? f.st1[s] : nullptr; seg[i].rows = D.rows[s]; }
+      return lmv_ln_linear_exact_fwd(p, seg, np, width, C, d->n1_w, d->n1_b, d->eps, D.dtype, stream);
     }
     return fq ? lmv_ln_linear_fwd(p, np, width, C, d->eps, LMV_ACT_NONE, D.dtype, stream) : lmv_linear_fwd(p, np, width, C, LMV_ACT_NONE, D.dtype, stream);
   };

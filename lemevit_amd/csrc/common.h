@@ -83,6 +83,7 @@ struct LmvConfig {
   int gemm_wn;            // LMV_GEMM_WN            1: whole-width kernel (wngemm.hip) for the 384-wide forward-form launches where it measured faster; 0: off; 2: wherever it applies
   int gemm_rs;            // LMV_GEMM_RS            1: register-stationary kernels (rsgemm.hip) where they measured faster; 0: off; 2: wherever they apply
   int dwconv_v;           // LMV_DWCONV_V           0 = auto: rows per thread of the depth-wise convolution kernels
+  int ln_exact_fused;     // LMV_LN_EXACT_FUSED     1: norm1 of the C = 96 blocks runs inside its projection launches (lmv_ln_linear_exact_fwd, csrc/rswgemm.hip)
   int res_ln_fused;       // LMV_RES_LN_FUSED       1: "S" blocks run the attention projection and norm2 as one launch where lmv_linear_res_ln_fwd applies
   int dx_ln_fused;        // LMV_DX_LN_FUSED        1: lmv_block_bwd fuses the dX of fc1 / qkv with the LayerNorm backward of their input where lmv_linear_dx_ln_bwd applies
   int mlp_split384;       // LMV_MLP_SPLIT384       1: fused inference schedule runs the C = 384 MLP half as LayerNorm + rsgemm fc1 + wngemm fc2 instead of the one-kernel form

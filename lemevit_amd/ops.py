@@ -294,6 +294,25 @@ def layernorm_bwd_multi(dys: Sequence[Tensor], xs: Sequence[Tensor], stats: Sequ
     return dxs if next_scales is None else (dxs, scaled)
 
 
+def ln_exact_fused(N: int, K: int, dtype) -> bool:
+    """Does the block schedule run LayerNorm -> Linear as ONE launch (lmv_ln_linear_exact_fwd)?  Same rule as csrc/block.hip::ln_exact_ok."""
+    return dtype == torch.bfloat16 and bool(lib.lmv_ln_linear_exact_fwd_supported(N, K, _lib.LMV_BF16)) and _lib.config_get("ln_exact_fused") != 0
+
+
+def ln_linear_exact_fwd(probs: Sequence[Prob], N: int, K: int, gamma: Tensor, beta: Tensor, eps: float, want_stats: bool):
+    """probs[i].a = raw rows: writes probs[i].out = LN(a) W^T + bias; returns (LayerNorm outputs, stats)  (lmv_ln_linear_exact_fwd)."""
+    arr = _pack(probs)
+    seg = (LnSegment * len(probs))()
+    ys, sts = [], []
+    for s, p in zip(seg, probs):
+        y = torch.empty_like(p.a)
+        st = torch.empty((p.rows, 2), device=p.a.device, dtype=torch.float32) if want_stats else None
+        s.y, s.stats, s.rows = _ptr(y), _f32(st), p.rows
+        ys.append(y); sts.append(st)
+    check(lib.lmv_ln_linear_exact_fwd(arr, seg, len(probs), N, K, _f32(gamma), _f32(beta), eps, dtype_code(probs[0].a), _stream()), "lmv_ln_linear_exact_fwd")
+    return ys, sts
+
+
 def res_ln_fused(C_: int, K: int, rows: int, dtype) -> bool:
     """Does the block schedule run `out = res + s (a W^T + b)` and the LayerNorm of `out` as ONE launch (lmv_linear_res_ln_fwd)?  The same
     rule as csrc/block.hip::res_ln_ok: supported shape, enough rows to fill the chip with 128-row panels, switch on."""

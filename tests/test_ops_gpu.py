@@ -769,3 +769,33 @@ def test_whole_width_kernels_under_load():
         torch.cuda.synchronize()
         for i, (g, r) in enumerate(zip(got, idle)):
             assert torch.equal(g, r), f"round {it}: output {i} differs from the idle run by {float((g.float() - r.float()).abs().max()):.3e}"
+
+
+@pytest.mark.parametrize("rows,rows_c,N", [(3136 * 4, 64, 288), (1000, 0, 192), (33, 48, 96), (4133, 16, 384)])
+def test_ln_linear_exact_fused(rows, rows_c, N):
+    """lmv_ln_linear_exact_fwd (csrc/rswgemm.hip, bf16, K = 96: the weight resident in LDS, LayerNorm on the register-resident rows): the
+    LayerNorm output and its (mean, rstd) against float64, y against float64 math on the kernel's own ROUNDED LayerNorm output (what the
+    two-launch form multiplies), a second problem with its own weight (qkv1 / qkv2 of a D block), ragged row counts; and y against
+    lmv_layernorm_fwd + lmv_linear_fwd on the same inputs."""
+    o = ops()
+    dtype, K, eps = torch.bfloat16, 96, 1e-6
+    gamma = (det_tensor((K,), "gam", 5, 0.3) + 1.0).to(dev()); beta = det_tensor((K,), "bet", 5, 0.2).to(dev())
+    probs, x64s = [], []
+    for tag, r in (("x", rows), ("c", rows_c)):
+        if not r:
+            continue
+        x, x64 = rnd((r, K), "x" + tag, dtype, 1.5); w, _ = rnd((N, K), "w" + tag, dtype, 1 / math.sqrt(K)); bias = det_tensor((N,), "b" + tag, 7, 0.5).to(dev())
+        probs.append(o.Prob(x, w, torch.zeros((r, N), device=dev(), dtype=dtype), bias=bias)); x64s.append(x64)
+    ys, sts = o.ln_linear_exact_fwd(probs, N, K, gamma, beta, eps, want_stats=True)
+    for p, x64, y, st in zip(probs, x64s, ys, sts):
+        mean = x64.mean(1, keepdim=True); var = ((x64 - mean) ** 2).mean(1, keepdim=True); rstd = 1 / torch.sqrt(var + eps)
+        assert_close(y, (x64 - mean) * rstd * gamma.cpu().double() + beta.cpu().double(), dtype, "LayerNorm output")
+        assert float((st[:, 0].cpu().double() - mean[:, 0]).abs().max()) <= 1e-5 * float(x64.abs().max())
+        assert float((st[:, 1].cpu().double() / rstd[:, 0] - 1).abs().max()) <= 1e-4
+        ref = y.float().cpu().double() @ p.w.float().cpu().double().t() + p.bias.cpu().double()
+        assert_close(p.out, ref, dtype, "LN(x) W^T + b")
+        y2, _ = o.layernorm_fwd(p.a.view(1, -1, K), gamma, beta, eps)
+        out2 = torch.empty_like(p.out)
+        o.linear_fwd([o.Prob(y2.view(-1, K), p.w, out2, bias=p.bias)], N, K)
+        d = float((p.out.float() - out2.float()).abs().max()); m = float(ref.abs().max())
+        assert d <= 1.2e-2 * m, f"fused and two-launch forms differ by {d:.3e} (max-abs {m:.3e})"

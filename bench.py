@@ -61,6 +61,8 @@ def parse():
     ap.add_argument("--no-issue-probe", action="store_true", help="skip the 5 synchronised single steps that measure host issue time (profiling runs: "
                     "they would sit in the 'last steps' window of a kernel trace)")
     ap.add_argument("--no-forward-probe", action="store_true", help="train mode: skip the forward-only pass timed after the train region (forward_* keys)")
+    ap.add_argument("--infer-parts", type=int, default=4, help="forward-only passes (--mode infer and the forward_* probe): run the batch as this many "
+                    "concurrent sub-batches inside the one hipGraph (lemevit_amd.graph.split_forward); 1 = the whole batch on one stream")
     ap.add_argument("--graph", type=int, default=-1, help="(-1 = auto: eager for train, graph replay for infer)  1 = capture the step into a hipGraph (lemevit_amd.graph.GraphedStep) and replay it; default 0 = "
                     "eager launches, which are faster here: the weight-gradient GEMMs overlap the dX chain on a side stream, and the "
                     "runtime serialises the branches of a captured graph (38.0 vs 39.6 ms per step)")
@@ -283,9 +285,12 @@ def main():
                 gsync.finish()
             opt.step()
     else:
+        from lemevit_amd.graph import split_forward
+        infer_outs = []
+
         def step():
             with torch.no_grad(), torch.autocast("cuda", torch.bfloat16):
-                model(x)
+                split_forward(model, x, args.infer_parts, infer_outs)
 
     def sync():
         if world > 1:
@@ -297,6 +302,8 @@ def main():
         from lemevit_amd.graph import try_graphed
         step, why = try_graphed(eager_step, warmup=3)
         graph_note = "hipGraph replay" if why is None else f"eager (graph capture failed: {why})"
+        if not train and args.infer_parts > 1:
+            graph_note += f", the batch as {args.infer_parts} concurrent sub-batches (graph branches)"
     for _ in range(args.warmup):
         step()
     sync()
@@ -339,13 +346,18 @@ def main():
     if train and not args.no_forward_probe:
         model.eval()
 
+        from lemevit_amd.graph import split_forward
+        fwd_outs = []
+
         def fwd_step():
             with torch.no_grad(), torch.autocast("cuda", torch.bfloat16):
-                model(x)
+                split_forward(model, x, args.infer_parts, fwd_outs)
 
         from lemevit_amd.graph import try_graphed
         fstep, why = try_graphed(fwd_step, warmup=3)
         fwd_note = "hipGraph replay" if why is None else f"eager (graph capture failed: {why})"
+        if args.infer_parts > 1:
+            fwd_note += f", the batch as {args.infer_parts} concurrent sub-batches (graph branches)"
         for _ in range(3):
             fstep()
         sync()

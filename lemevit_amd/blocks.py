@@ -325,7 +325,7 @@ def _attn_D_fwd(P, ts, ds, save):
     q1, q2 = _empty(x, 3 * C), _empty(c, 3 * C)
     if ops.ln_exact_fused(3 * C, C, x.dtype):        # norm1 and both projections in one launch (csrc/rswgemm.hip, C = 96)
         xn, st = ops.ln_linear_exact_fwd([Prob(x, P["attn.qkv1.weight"], q1, bias=P["attn.qkv1.bias"]), Prob(c, P["attn.qkv2.weight"], q2, bias=P["attn.qkv2.bias"])],
-                                         3 * C, C, P["norm1.weight"], P["norm1.bias"], BLOCK_LN_EPS, want_stats=save)
+                                         3 * C, C, P["norm1.weight"], P["norm1.bias"], BLOCK_LN_EPS, want_stats=save, want_ln=save)
     else:
         xn, st = ops.layernorm_fwd_multi(ts, P["norm1.weight"], P["norm1.bias"], BLOCK_LN_EPS, want_stats=save)
         ops.linear_fwd([Prob(xn[0], P["attn.qkv1.weight"], q1, bias=P["attn.qkv1.bias"]),
@@ -406,8 +406,8 @@ def _attn_C_fwd(P, xp, c, ds, save):
     C, N, M = c.shape[-1], xp.shape[1], c.shape[1]
     kv, q = _empty(xp, 2 * C), _empty(c, C)
     if ops.ln_exact_fused(2 * C, C, xp.dtype) and ops.ln_exact_fused(C, C, xp.dtype):      # norm1 inside the two projection launches (C = 96)
-        (xn,), (stx,) = ops.ln_linear_exact_fwd([Prob(xp, P["attn.kv.weight"], kv, bias=P["attn.kv.bias"])], 2 * C, C, P["norm1.weight"], P["norm1.bias"], BLOCK_LN_EPS, want_stats=save)
-        (cn,), (stc,) = ops.ln_linear_exact_fwd([Prob(c, P["attn.q.weight"], q, bias=P["attn.q.bias"])], C, C, P["norm1.weight"], P["norm1.bias"], BLOCK_LN_EPS, want_stats=save)
+        (xn,), (stx,) = ops.ln_linear_exact_fwd([Prob(xp, P["attn.kv.weight"], kv, bias=P["attn.kv.bias"])], 2 * C, C, P["norm1.weight"], P["norm1.bias"], BLOCK_LN_EPS, want_stats=save, want_ln=save)
+        (cn,), (stc,) = ops.ln_linear_exact_fwd([Prob(c, P["attn.q.weight"], q, bias=P["attn.q.bias"])], C, C, P["norm1.weight"], P["norm1.bias"], BLOCK_LN_EPS, want_stats=save, want_ln=save)
     else:
         (xn, cn), (stx, stc) = ops.layernorm_fwd_multi([xp, c], P["norm1.weight"], P["norm1.bias"], BLOCK_LN_EPS, want_stats=save)
         ops.linear_fwd([Prob(xn, P["attn.kv.weight"], kv, bias=P["attn.kv.bias"])], 2 * C, C)

@@ -453,7 +453,7 @@ extern "C" int lmv_block_fwd(const lmv_block_desc* d, const void* x, const void*
     }
     if (ex) {
       lmv_ln_segment seg[2] = {};
-      for (int i = 0; i < np; ++i) { const int s = streams[i]; seg[i].y = f.n1[s]; seg[i].stats = save ? f.st1[s] : nullptr; seg[i].rows = D.rows[s]; }
+      for (int i = 0; i < np; ++i) { const int s = streams[i]; seg[i].y = save ? f.n1[s] : nullptr; seg[i].stats = save ? f.st1[s] : nullptr; seg[i].rows = D.rows[s]; }      // inference: the normalised rows never leave the registers
       return lmv_ln_linear_exact_fwd(p, seg, np, width, C, d->n1_w, d->n1_b, d->eps, D.dtype, stream);
     }
     return fq ? lmv_ln_linear_fwd(p, np, width, C, d->eps, LMV_ACT_NONE, D.dtype, stream) : lmv_linear_fwd(p, np, width, C, LMV_ACT_NONE, D.dtype, stream);

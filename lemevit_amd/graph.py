@@ -44,6 +44,45 @@ class GraphedStep:
         self.graph.replay()
 
 
+def split_forward(model: Callable, x: torch.Tensor, parts: int, outs: Optional[list] = None):
+    """``model(x)`` as ``parts`` independent sub-batches, each on its own stream forked from (and joined back into) the current one;
+    returns the concatenated output (or fills ``outs``).  Inference only: the images of a batch do not interact in eval mode (the
+    reference's BatchNorm uses running statistics there, models/lemevit.py:663-676), so this is the same computation -- but the ramp and
+    the tail of every kernel of one sub-batch run under another sub-batch's kernels instead of under an idle chip (LeMeViT-Base 224^2,
+    B = 128, hipGraph replay: 8.93 -> 8.59 ms with 2 parts, 8.51 with 4; tools/split_infer.py).  Inside ``torch.cuda.graph`` the forks
+    become branches of the captured graph.  Scratch of the C-ABI calls is keyed by stream (model._persistent), so the branches share
+    nothing but the weights."""
+    parts = max(1, min(int(parts), x.shape[0]))
+    if parts == 1:
+        y = model(x)
+        if outs is not None:
+            outs[:] = [y]
+        return y
+    xs = x.chunk(parts)
+    cur = torch.cuda.current_stream()
+    key = (x.device, len(xs))
+    streams = _split_streams.get(key)
+    if streams is None:
+        streams = _split_streams[key] = [torch.cuda.Stream(device=x.device) for _ in range(len(xs) - 1)]
+    ys = [None] * len(xs)
+    for i, s in enumerate(streams):
+        s.wait_stream(cur)
+        with torch.cuda.stream(s):
+            ys[i + 1] = model(xs[i + 1])
+            xs[i + 1].record_stream(s)
+    ys[0] = model(xs[0])
+    for s, y in zip(streams, ys[1:]):
+        cur.wait_stream(s)
+        y.record_stream(cur)
+    if outs is not None:
+        outs[:] = ys
+        return None
+    return torch.cat(ys)
+
+
+_split_streams: dict = {}
+
+
 def try_graphed(step_fn: Callable[[], None], warmup: int = 3, pre_capture: Optional[Callable[[], None]] = None):
     """GraphedStep if capture succeeds, else the eager callable (with the reason)."""
     try:

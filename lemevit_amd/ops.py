@@ -299,15 +299,16 @@ def ln_exact_fused(N: int, K: int, dtype) -> bool:
     return dtype == torch.bfloat16 and bool(lib.lmv_ln_linear_exact_fwd_supported(N, K, _lib.LMV_BF16)) and _lib.config_get("ln_exact_fused") != 0
 
 
-def ln_linear_exact_fwd(probs: Sequence[Prob], N: int, K: int, gamma: Tensor, beta: Tensor, eps: float, want_stats: bool):
-    """probs[i].a = raw rows: writes probs[i].out = LN(a) W^T + bias; returns (LayerNorm outputs, stats)  (lmv_ln_linear_exact_fwd)."""
+def ln_linear_exact_fwd(probs: Sequence[Prob], N: int, K: int, gamma: Tensor, beta: Tensor, eps: float, want_stats: bool, want_ln: bool = True):
+    """probs[i].a = raw rows: writes probs[i].out = LN(a) W^T + bias; returns (LayerNorm outputs, stats)  (lmv_ln_linear_exact_fwd).
+    want_ln=False (inference): the normalised rows are not written (None in their place)."""
     arr = _pack(probs)
     seg = (LnSegment * len(probs))()
     ys, sts = [], []
     for s, p in zip(seg, probs):
-        y = torch.empty_like(p.a)
+        y = torch.empty_like(p.a) if want_ln else None
         st = torch.empty((p.rows, 2), device=p.a.device, dtype=torch.float32) if want_stats else None
-        s.y, s.stats, s.rows = _ptr(y), _f32(st), p.rows
+        s.y, s.stats, s.rows = (_ptr(y) if want_ln else None), _f32(st), p.rows
         ys.append(y); sts.append(st)
     check(lib.lmv_ln_linear_exact_fwd(arr, seg, len(probs), N, K, _f32(gamma), _f32(beta), eps, dtype_code(probs[0].a), _stream()), "lmv_ln_linear_exact_fwd")
     return ys, sts

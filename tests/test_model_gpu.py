@@ -202,6 +202,35 @@ def test_model_forward_bf16(golden, name, mode):
     print(f"{name} [{mode}]: bf16 logits rel err {e:.2e}")
 
 
+@pytest.mark.parametrize("parts", [2, 3])
+def test_split_forward_concurrent_sub_batches(parts):
+    """lemevit_amd.graph.split_forward (the forward_* / --mode infer schedule of bench.py): the batch as concurrent sub-batches on forked
+    streams, eager and as branches of one hipGraph, is BIT-equal to the same sub-batches run one after the other (the branches share
+    no scratch), and within the bf16 end-to-end budget of the whole-batch result (other row counts select other kernels)."""
+    from lemevit_amd.graph import GraphedStep, split_forward
+    m = _model("lemevit_tiny", 1000, 3).eval()
+    B = 11
+    img = det_tensor((B, 3, 224, 224), "split.img", 4).to(DEV)
+    with torch.no_grad(), torch.autocast("cuda", torch.bfloat16):
+        whole = m(img)
+        seq = torch.cat([m(xi) for xi in img.chunk(parts)])
+        par = split_forward(m, img, parts)
+    torch.cuda.synchronize()
+    assert par.shape == whole.shape and torch.equal(par, seq)
+    close(par, whole.float().cpu(), 5e-2, "sub-batches vs whole batch")
+    outs = []
+
+    def step():
+        with torch.no_grad(), torch.autocast("cuda", torch.bfloat16):
+            split_forward(m, img, parts, outs)
+
+    g = GraphedStep(step, warmup=2)
+    for _ in range(3):
+        g()
+    torch.cuda.synchronize()
+    assert len(outs) == parts and torch.equal(torch.cat(outs), seq)
+
+
 @pytest.mark.parametrize("name", ["model_tiny_224", "model_base_224", "model_small_v2_224", "model_tiny_v2_224"])
 def test_fused_inference_path(golden, name, monkeypatch):
     """The inference schedule with LayerNorm folded into the projections and the one-kernel MLP half (lmv_ln_linear_fwd /

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define LMV_ABI_VERSION 5
+#define LMV_ABI_VERSION 6
 
 enum { LMV_F32 = 0, LMV_BF16 = 1 };
 enum {
@@ -388,6 +388,15 @@ typedef struct lmv_block_desc {
 size_t lmv_block_arena_bytes(const lmv_block_desc* d);
 size_t lmv_block_bwd_scratch_bytes(const lmv_block_desc* d);
 int lmv_block_fwd(const lmv_block_desc* d, const void* x, const void* c, void* x_out, void* c_out, void* arena, size_t arena_bytes, int save, void* stream);
+/* The images [image0, image0 + nimages) of the same call: `d`, the tensors and the arena are those of the WHOLE batch (every tensor is
+ * [rows, width] with the images outermost, so a range of images is a contiguous slice of each; the attention workspace of the arena is
+ * sliced the same way).  The images of a batch do not interact inside a LeMeBlock (models/lemevit.py:500-650: LayerNorm, per-image
+ * attention, per-row Linears), so calls over disjoint ranges that cover the batch, on ANY streams and in any order, leave the outputs and
+ * the arena in the state one lmv_block_fwd call leaves them in (up to the kernel selection, which follows the row count) -- the training
+ * forward runs them on concurrent streams so that the ramp and the tail of each launch are covered by another range's kernels;
+ * lmv_block_bwd then consumes the arena as a whole. */
+int lmv_block_fwd_range(const lmv_block_desc* d, const void* x, const void* c, void* x_out, void* c_out, void* arena, size_t arena_bytes, int save,
+                        int image0, int nimages, void* stream);
 /* x, c: the block inputs of the forward call; dx_out / dc_out: gradients of x_out / c_out; dx / dc: gradients of x / c (written). */
 int lmv_block_bwd(const lmv_block_desc* d, const void* x, const void* c, const void* arena, size_t arena_bytes, const void* dx_out, const void* dc_out,
                   void* dx, void* dc, void* scratch, size_t scratch_bytes, void* stream, void* side_stream);

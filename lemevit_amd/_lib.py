@@ -14,7 +14,7 @@ LIB_PATH = os.path.join(_HERE, "csrc", "liblemevit_hip.so")
 
 LMV_F32, LMV_BF16 = 0, 1
 ACT_NONE, ACT_GELU, ACT_GELU_GRAD = 0, 1, 2
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 
 class LinearProblem(C.Structure):
@@ -132,6 +132,7 @@ SIGNATURES = {
     "lmv_block_arena_bytes": (_Z, [C.POINTER(BlockDesc)]),
     "lmv_block_bwd_scratch_bytes": (_Z, [C.POINTER(BlockDesc)]),
     "lmv_block_fwd": (_I, [C.POINTER(BlockDesc), _P, _P, _P, _P, _P, _Z, _I, _P]),
+    "lmv_block_fwd_range": (_I, [C.POINTER(BlockDesc), _P, _P, _P, _P, _P, _Z, _I, _I, _I, _P]),
     "lmv_block_bwd": (_I, [C.POINTER(BlockDesc), _P, _P, _P, _Z, _P, _P, _P, _P, _P, _Z, _P, _P]),
 }
 

@@ -50,6 +50,19 @@ struct Fwd {                      // forward intermediates = saved state of the 
   size_t ws_bytes;
 };
 
+// forward attention workspace of `b` images (>= 256), and the slices of lmv_block_fwd_range: the range starting at image i0 takes
+// [fwd_ws_off(i0), + fwd_ws_attn(n)); 512 bytes of slack per image keep the 256-byte rounded slices disjoint
+inline size_t fwd_ws_attn(const Dims& D, int b) {
+  size_t w, w2 = 0;
+  if (D.kind == LMV_BLOCK_C) w = lmv_attn_workspace_bytes(b, D.heads, D.M, D.N, 0);
+  else if (D.kind == LMV_BLOCK_D) { w = lmv_attn_workspace_bytes(b, D.heads, D.N, D.M, 0); w2 = lmv_attn_workspace_bytes(b, D.heads, D.M, D.N, 0); }
+  else { w = lmv_attn_workspace_bytes(b, D.heads, D.N, D.N, 0); w2 = lmv_attn_workspace_bytes(b, D.heads, D.M, D.M, 0); }
+  if (w2 > w) w = w2;
+  return w < 256 ? 256 : w;
+}
+inline size_t fwd_ws_off(const Dims& D, int i0) { return i0 <= 0 ? 0 : fwd_ws_attn(D, i0) + (size_t)512 * i0; }
+inline size_t fwd_ws_bytes(const Dims& D, int b) { return fwd_ws_attn(D, b) + (size_t)512 * b + 256; }
+
 void layout_fwd(const Dims& D, Bump& a, Fwd* f) {
   const bool cb = D.kind == LMV_BLOCK_C;
   f->xp = a.take(D.rows[0] * D.C * D.es);
@@ -66,13 +79,8 @@ void layout_fwd(const Dims& D, Bump& a, Fwd* f) {
     f->u[s] = has ? a.take(D.rows[s] * D.Hd * D.es) : nullptr;
     f->h[s] = has ? a.take(D.rows[s] * D.Hd * D.es) : nullptr;
   }
-  size_t w = 256;
-  if (cb) w = lmv_attn_workspace_bytes(D.B, D.heads, D.M, D.N, 0);
-  else if (D.kind == LMV_BLOCK_D) { w = lmv_attn_workspace_bytes(D.B, D.heads, D.N, D.M, 0); const size_t w2 = lmv_attn_workspace_bytes(D.B, D.heads, D.M, D.N, 0); if (w2 > w) w = w2; }
-  else { w = lmv_attn_workspace_bytes(D.B, D.heads, D.N, D.N, 0); const size_t w2 = lmv_attn_workspace_bytes(D.B, D.heads, D.M, D.M, 0); if (w2 > w) w = w2; }
-  if (w < 256) w = 256;
-  f->ws_bytes = w;
-  f->ws = a.take(w);
+  f->ws_bytes = fwd_ws_bytes(D, D.B);
+  f->ws = a.take(f->ws_bytes);
 }
 
 void attn_desc(lmv_attn_desc* a, const Dims& D, const void* q, int qw, int qo, const void* k, int kw, int ko, const void* v, int vw, int vo,
@@ -418,16 +426,51 @@ extern "C" size_t lmv_block_bwd_scratch_bytes(const lmv_block_desc* d) {
   return a.off + 256;
 }
 
-extern "C" int lmv_block_fwd(const lmv_block_desc* d, const void* x, const void* c, void* x_out, void* c_out, void* arena, size_t arena_bytes, int save, void* stream) {
-  Dims D;
-  LMV_TRY(dims_of(d, &D));
+namespace {
+int block_fwd_body(const lmv_block_desc* d, const Dims& D, const Fwd& f, const void* x, const void* c, void* x_out, void* c_out, int save, void* stream);
+}  // namespace
+
+extern "C" int lmv_block_fwd_range(const lmv_block_desc* d, const void* x, const void* c, void* x_out, void* c_out, void* arena, size_t arena_bytes, int save,
+                                   int image0, int nimages, void* stream) {
+  Dims DF;
+  LMV_TRY(dims_of(d, &DF));
   LMV_TRY(check_ptrs(d, false));
-  const bool cb = D.kind == LMV_BLOCK_C;
+  const bool cb = DF.kind == LMV_BLOCK_C;
   if (!x || !c || !c_out || (!cb && !x_out) || !arena || !lmv_aligned16(arena)) LMV_FAIL(LMV_ERR_SHAPE, "block_fwd: null / misaligned tensor");
+  if (image0 < 0 || nimages <= 0 || image0 + nimages > DF.B) LMV_FAIL(LMV_ERR_SHAPE, "block_fwd: images [%d, %d) outside the batch of %d", image0, image0 + nimages, DF.B);
   Bump a{(unsigned char*)arena, 0, arena_bytes};
   Fwd f;
-  layout_fwd(D, a, &f);
+  layout_fwd(DF, a, &f);
   if (a.off > arena_bytes) LMV_FAIL(LMV_ERR_WORKSPACE, "block_fwd: arena %zu < %zu bytes", arena_bytes, a.off);
+  if (image0 == 0 && nimages == DF.B) return block_fwd_body(d, DF, f, x, c, x_out, c_out, save, stream);
+  // a range of images: every tensor of the arena is [rows, width] with the images outermost, so the range is a contiguous slice of each
+  lmv_block_desc dr = *d;
+  dr.B = nimages;
+  for (int k = 0; k < 4; ++k) if (dr.masks[k]) dr.masks[k] += image0;
+  Dims D;
+  LMV_TRY(dims_of(&dr, &D));
+  const size_t es = D.es;
+  auto adv = [&](void* ptr, int s, size_t width_bytes) -> void* { return ptr ? (void*)((unsigned char*)ptr + (size_t)image0 * (s == 0 ? D.N : D.M) * width_bytes) : nullptr; };
+  f.xp = adv(f.xp, 0, D.C * es);
+  for (int s = 0; s < 2; ++s) {
+    f.n1[s] = adv(f.n1[s], s, D.C * es); f.st1[s] = (float*)adv(f.st1[s], s, 2 * sizeof(float)); f.pj[s] = adv(f.pj[s], s, proj_w(D, s) * es);
+    f.ao[s] = adv(f.ao[s], s, D.C * es); f.lse[s] = (float*)adv(f.lse[s], s, D.heads * sizeof(float)); f.t2[s] = adv(f.t2[s], s, D.C * es);
+    f.n2[s] = adv(f.n2[s], s, D.C * es); f.st2[s] = (float*)adv(f.st2[s], s, 2 * sizeof(float)); f.u[s] = adv(f.u[s], s, D.Hd * es); f.h[s] = adv(f.h[s], s, D.Hd * es);
+  }
+  const size_t w0 = fwd_ws_off(DF, image0), w1 = fwd_ws_attn(DF, nimages);
+  if (w0 + w1 > f.ws_bytes) LMV_FAIL(LMV_ERR_WORKSPACE, "block_fwd: attention workspace slice [%zu, %zu) outside %zu bytes", w0, w0 + w1, f.ws_bytes);
+  f.ws = (unsigned char*)f.ws + w0; f.ws_bytes = w1;
+  return block_fwd_body(&dr, D, f, adv(const_cast<void*>(x), 0, D.C * es), adv(const_cast<void*>(c), 1, D.C * es), adv(x_out, 0, D.C * es), adv(c_out, 1, D.C * es), save, stream);
+}
+
+extern "C" int lmv_block_fwd(const lmv_block_desc* d, const void* x, const void* c, void* x_out, void* c_out, void* arena, size_t arena_bytes, int save, void* stream) {
+  return lmv_block_fwd_range(d, x, c, x_out, c_out, arena, arena_bytes, save, 0, d ? d->B : 0, stream);
+}
+
+namespace {
+
+int block_fwd_body(const lmv_block_desc* d, const Dims& D, const Fwd& f, const void* x, const void* c, void* x_out, void* c_out, int save, void* stream) {
+  const bool cb = D.kind == LMV_BLOCK_C;
   const int C = D.C, N = D.N, M = D.M;
   LMV_TRY(lmv_dwconv3x3_residual_fwd(x, d->pos_w, d->pos_b, f.xp, D.B, D.H, D.W, C, D.dtype, stream));          // :546
   const bool fq = fused_on(d, D, save) && fold_qkv(D);      // norm1 folded into the projections: no LayerNorm launch, no normalised copy
@@ -502,6 +545,8 @@ extern "C" int lmv_block_fwd(const lmv_block_desc* d, const void* x, const void*
   const float* ds[2] = {cb ? nullptr : d->masks[1], cb ? d->masks[1] : d->masks[3]};
   return mlp_fwd(d, D, f, cb ? 1 : 0, outs, ds, save, stream, ln2_done);
 }
+
+}  // namespace
 
 extern "C" int lmv_block_bwd(const lmv_block_desc* d, const void* x, const void* c, const void* arena, size_t arena_bytes, const void* dx_out, const void* dc_out, void* dx, void* dc,
                              void* scratch, size_t scratch_bytes, void* stream, void* side_stream) {

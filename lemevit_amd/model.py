@@ -587,16 +587,86 @@ def _persistent(tag: str, nbytes: int, device) -> Tensor:
     return t
 
 
+# ---- training forward as concurrent image ranges ------------------------------------------------------------------------------------------
+# The images of a batch do not interact inside a LeMeBlock, so the blocks of one stage can run as TRAIN_PARTS independent ranges of images on
+# forked streams (lmv_block_fwd_range: same arena, same outputs); the ramp and the tail of each launch of one range are then covered by the
+# other ranges' kernels instead of an idle chip, as in lemevit_amd.graph.split_forward for inference.  The stage's downsample (a BatchNorm
+# over the whole batch, models/lemevit.py:663-676) and the backward pass see whole-batch tensors: image_ranges() joins at the stage's end.
+TRAIN_PARTS = int(os.environ.get("LMV_TRAIN_PARTS", "2"))
+TRAIN_PARTS_MIN_BATCH = 32          # smaller batches are launch-bound: more, smaller launches do not pay
+_range_state: dict = {}             # device index -> [streams, forked?]
+
+
+class image_ranges:
+    """with image_ranges(device, batch): the native block forwards inside (save=True) run as concurrent ranges of images."""
+
+    def __init__(self, device, batch: int, parts: Optional[int] = None):
+        parts = TRAIN_PARTS if parts is None else parts
+        self.on = device.type == "cuda" and parts > 1 and batch >= max(TRAIN_PARTS_MIN_BATCH, parts) and torch.is_grad_enabled()
+        self.dev, self.parts = device, parts
+
+    def __enter__(self):
+        if self.on:
+            key = (self.dev.index, self.parts)
+            streams = _range_streams.get(key)
+            if streams is None:
+                streams = _range_streams[key] = [torch.cuda.Stream(device=self.dev) for _ in range(self.parts - 1)]
+            _range_state[self.dev.index] = [streams, False]
+        return self
+
+    def __exit__(self, *exc):
+        if self.on:
+            streams, forked = _range_state.pop(self.dev.index)
+            if forked:
+                cur = torch.cuda.current_stream(self.dev)
+                for s in streams:
+                    cur.wait_stream(s)
+        return False
+
+
+_range_streams: dict = {}
+
+
+def _join_ranges(device) -> None:
+    """Anything inside image_ranges() that is NOT a range-aware native block (the per-launch Python schedule) reads whole-batch tensors on the
+    current stream: the range streams are joined first."""
+    rs = _range_state.get(device.index)
+    if rs is not None and rs[1]:
+        cur = torch.cuda.current_stream(device)
+        for s in rs[0]:
+            cur.wait_stream(s)
+        rs[1] = False
+
+
 def native_block_forward(kind: str, x: Tensor, c: Tensor, H: int, W: int, names, P: Dict[str, Tensor], masks, save: bool, folds=None, wts=None):
-    """lmv_block_fwd: returns (x_out, c_out, state) with state = (descriptor, arena) for native_block_backward (save=True)."""
+    """lmv_block_fwd: returns (x_out, c_out, state) with state = (descriptor, arena) for native_block_backward (save=True).
+    Inside image_ranges() (training): one lmv_block_fwd_range call per range of images, each on its own stream."""
     from ._lib import lib, check
     d = _block_desc(kind, x, c, H, W, names, P, masks, None if save else folds, wts if save else None)
     nbytes = _sized(lib.lmv_block_arena_bytes, d, kind, x, c, H, W)
     arena = torch.empty(nbytes, device=x.device, dtype=torch.uint8) if save else _persistent("fwd", nbytes, x.device)
     xo = torch.empty_like(x) if kind != "C" else None
     co = torch.empty_like(c)
-    check(lib.lmv_block_fwd(d, x.data_ptr(), c.data_ptr(), None if xo is None else xo.data_ptr(), co.data_ptr(), arena.data_ptr(), arena.numel(), 1 if save else 0,
-                            ops._stream()), "lmv_block_fwd")
+    rs = _range_state.get(x.device.index) if save else None
+    if rs is None:
+        check(lib.lmv_block_fwd(d, x.data_ptr(), c.data_ptr(), None if xo is None else xo.data_ptr(), co.data_ptr(), arena.data_ptr(), arena.numel(), 1 if save else 0,
+                                ops._stream()), "lmv_block_fwd")
+    else:
+        # Every range stream first waits for what the current stream holds NOW: the producers of x / c of the stage's first block, this
+        # block's weight copies, and whatever still reads memory the allocator has just handed out again.  After that the ranges are only
+        # ordered within their own stream (range i of block k+1 reads what range i of block k wrote on the same stream).
+        streams = rs[0]
+        B, n = x.shape[0], len(rs[0]) + 1
+        cuts = [B * i // n for i in range(n + 1)]
+        cur = torch.cuda.current_stream(x.device)
+        ev = cur.record_event()
+        for i in range(n):
+            st = cur if i == 0 else streams[i - 1]
+            if i:
+                st.wait_event(ev)
+            check(lib.lmv_block_fwd_range(d, x.data_ptr(), c.data_ptr(), None if xo is None else xo.data_ptr(), co.data_ptr(), arena.data_ptr(), arena.numel(), 1,
+                                          cuts[i], cuts[i + 1] - cuts[i], st.cuda_stream), "lmv_block_fwd_range")
+        rs[1] = True
     return (x if xo is None else xo), co, ((d, arena) if save else None)
 
 
@@ -646,6 +716,8 @@ class _BlockFn(torch.autograd.Function):
             xo, co, state = native_block_forward(kind, x, c, H, W, names, P, masks, save=True, wts=wts)
             saved = (x, c, state)
         else:
+            if x.is_cuda:
+                _join_ranges(x.device)
             xo, co, saved = block_forward(kind, x, c, H, W, P, masks, save=True)
         ctx.kind, ctx.H, ctx.W, ctx.masks, ctx.names = kind, H, W, masks, names
         ctx.saved, ctx.P = saved, P
@@ -1092,8 +1164,9 @@ class LeMeViT(nn.Module):
                 c = c.expand(B, -1, -1)
                 hoist = False
             c = c.to(cd).contiguous()
-            for blk in self.stages[i]:
-                xt, c = blk.forward_tokens(xt, c, H, W, masks=all_masks.get(id(blk)) if all_masks else None)
+            with image_ranges(xt.device, B):
+                for blk in self.stages[i]:
+                    xt, c = blk.forward_tokens(xt, c, H, W, masks=all_masks.get(id(blk)) if all_masks else None)
         bn = self.norm
         if head is not False and isinstance(self.pre_logits, nn.Identity) and (self.training or torch.is_grad_enabled()) and _tail_native(self.norm_c, head, xt, c, cd):
             # training: final BatchNorm (native kernels) -> LayerNorm(c) + both mean-pools + add (+ classifier) as ONE autograd node

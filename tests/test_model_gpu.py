@@ -301,6 +301,45 @@ def test_train_step_fp32(golden, name):
             close(m.state_dict()[k[5:]], g[k], 1e-5, k)
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("parts,B", [(2, 6), (3, 7)])
+def test_train_forward_image_ranges(monkeypatch, dtype, parts, B):
+    """model.image_ranges / lmv_block_fwd_range: the training forward of a stage's blocks as concurrent ranges of images (each on its own
+    stream, one arena, whole-batch backward) against the one-call forward: logits, loss and every parameter gradient agree (fp32: to
+    rounding -- the ranges only change the row counts the kernels see; bf16: the module budget), and two range runs give BIT-equal logits and loss (the
+    ranges share nothing but read-only weights)."""
+    import lemevit_amd.model as M
+    img = det_tensor((B, 3, 96, 96), "ranges.img", 5).to(DEV)
+    tgt = torch.arange(B, device=DEV) % 10
+
+    def run(p):
+        monkeypatch.setattr(M, "TRAIN_PARTS", p); monkeypatch.setattr(M, "TRAIN_PARTS_MIN_BATCH", 2)
+        m = _model("lemevit_tiny", 10, 11, drop_path_rate=0.0).train()
+        with torch.autocast("cuda", torch.bfloat16, enabled=dtype == torch.bfloat16):
+            logits = m(img)
+            loss = torch.nn.functional.cross_entropy(logits.float(), tgt)
+        loss.backward()
+        torch.cuda.synchronize()
+        return logits.detach().float().cpu(), loss.item(), {k: v.grad.detach().float().cpu() for k, v in m.named_parameters() if v.grad is not None}
+
+    l1, s1, g1 = run(1)
+    l2, s2, g2 = run(parts)
+    l3, s3, g3 = run(parts)
+    assert torch.equal(l2, l3) and s2 == s3              # the forward pass is what the ranges change: bit-equal from run to run
+    l0, s0, g0 = run(1)
+    for k in g2:                                          # (the backward's split reductions use atomics: run-to-run noise with or without ranges)
+        ref_noise = float((g0[k] - g1[k]).norm())
+        assert float((g2[k] - g3[k]).norm()) <= max(4 * ref_noise, 1e-6 * float(g2[k].norm())), k
+    tol = 2e-5 if dtype == torch.float32 else 2e-2
+    close(l2, l1, tol, "logits")
+    assert abs(s2 - s1) <= tol * max(1.0, abs(s1))
+    assert g1.keys() == g2.keys()
+    floor = 1e-3 * max(float(v.norm()) for v in g1.values())       # (a conv bias in front of a BatchNorm has a gradient of exactly-zero-plus-rounding)
+    for k in g1:
+        n1, dn = float(g1[k].norm()), float((g2[k] - g1[k]).norm())
+        assert dn <= (2e-4 if dtype == torch.float32 else 5e-2) * max(n1, floor), (k, n1, dn)
+
+
 def test_full_size_properties_bf16():
     """BASELINE-size run (Base, B=128, 224^2, bf16 autocast).  Size-independent properties of the hot path:
     every LeMeBlock is batch-independent -- permuting the batch permutes its outputs BIT-EXACTLY (checked per block with

@@ -49,3 +49,19 @@ for P in parts:
     if ref is None:
         ref = y
     print(f"parts {P}: {best * 1e3:.3f} ms per batch of {B} ({B / best:.0f} img/s)  max |diff| vs first {float((y - ref).abs().max()):.3e}", flush=True)
+
+    def seq_step():              # the same sub-batches one after the other on ONE stream (smaller working set per launch, no concurrency)
+        with torch.no_grad(), torch.autocast("cuda", torch.bfloat16):
+            for i in range(P):
+                outs[i] = model(xs[i])
+
+    if P > 1:
+        g2 = GraphedStep(seq_step, warmup=2)
+        for _ in range(3):
+            g2()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(20):
+            g2()
+        torch.cuda.synchronize()
+        print(f"   sequential on one stream: {(time.perf_counter() - t0) / 20 * 1e3:.3f} ms")

@@ -81,9 +81,14 @@ def compute_copy(p: Tensor, want: torch.dtype) -> Tensor:
     stamp = (p._version, _train_pass, torch.is_grad_enabled() and p.requires_grad)      # a later training pass invalidates inference casts too
     if ent is not None and ent[0]() is p and ent[1] == stamp and ent[2].dtype == want and ent[2].device == p.device:
         return ent[2]
+    global _casts_launched
+    _casts_launched += 1             # a kernel on the current stream: image_ranges() re-forks its range streams behind it
     t = ops.cast(p.detach().contiguous(), want)
     _copy_cache[key] = (weakref.ref(p), stamp, t)
     return t
+
+
+_casts_launched = 0
 
 
 _fold_cache: dict = {}
@@ -611,12 +616,12 @@ class image_ranges:
             streams = _range_streams.get(key)
             if streams is None:
                 streams = _range_streams[key] = [torch.cuda.Stream(device=self.dev) for _ in range(self.parts - 1)]
-            _range_state[self.dev.index] = [streams, False]
+            _range_state[self.dev.index] = [streams, False, -1]
         return self
 
     def __exit__(self, *exc):
         if self.on:
-            streams, forked = _range_state.pop(self.dev.index)
+            streams, forked, _ = _range_state.pop(self.dev.index)
             if forked:
                 cur = torch.cuda.current_stream(self.dev)
                 for s in streams:
@@ -652,17 +657,21 @@ def native_block_forward(kind: str, x: Tensor, c: Tensor, H: int, W: int, names,
         check(lib.lmv_block_fwd(d, x.data_ptr(), c.data_ptr(), None if xo is None else xo.data_ptr(), co.data_ptr(), arena.data_ptr(), arena.numel(), 1 if save else 0,
                                 ops._stream()), "lmv_block_fwd")
     else:
-        # Every range stream first waits for what the current stream holds NOW: the producers of x / c of the stage's first block, this
-        # block's weight copies, and whatever still reads memory the allocator has just handed out again.  After that the ranges are only
-        # ordered within their own stream (range i of block k+1 reads what range i of block k wrote on the same stream).
+        # The range streams wait for what the current stream holds at the FIRST block of the stage: the producers of x / c and whatever still
+        # reads memory the allocator hands out again (nothing is freed inside the stage loop).  After that the ranges are only ordered within
+        # their own stream (range i of block k+1 reads what range i of block k wrote on the same stream) -- unless a weight cast was launched
+        # on the current stream since (parameters without an optimizer-maintained bf16 copy): then they wait for it.
         streams = rs[0]
         B, n = x.shape[0], len(rs[0]) + 1
         cuts = [B * i // n for i in range(n + 1)]
         cur = torch.cuda.current_stream(x.device)
-        ev = cur.record_event()
+        ev = None
+        if not rs[1] or rs[2] != _casts_launched:
+            ev = cur.record_event()
+            rs[2] = _casts_launched
         for i in range(n):
             st = cur if i == 0 else streams[i - 1]
-            if i:
+            if i and ev is not None:
                 st.wait_event(ev)
             check(lib.lmv_block_fwd_range(d, x.data_ptr(), c.data_ptr(), None if xo is None else xo.data_ptr(), co.data_ptr(), arena.data_ptr(), arena.numel(), 1,
                                           cuts[i], cuts[i + 1] - cuts[i], st.cuda_stream), "lmv_block_fwd_range")

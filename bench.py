@@ -338,7 +338,8 @@ def main():
         timer.enabled = False
         _model._NATIVE = native_was
         kernel_timing_note = ("HIP events around every forward-Linear launch of 3 eager steps run right after the timed region (blocks on the per-launch "
-                              "Python schedule for these steps: same kernels and shapes as the native block calls of the timed region)")
+                              "Python schedule for these steps: whole-batch launches of the same kernels; the native block calls of the timed region issue the "
+                              "FORWARD-pass launches as model.TRAIN_PARTS concurrent ranges of images, i.e. at half the rows each by default)")
     # The north-star target is FORWARD throughput (BASELINE.json): in train mode the same process times the forward pass of the same
     # model on the same batch right after the train region (eval mode, no_grad, bf16 autocast, hipGraph replay as in --mode infer) and
     # reports it as extra keys of the same JSON line.  The timed train region above is not touched by it.

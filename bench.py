@@ -332,14 +332,17 @@ def main():
         import lemevit_amd.model as _model
         native_was, _model._NATIVE = _model._NATIVE, False
         timer.enabled = rank == 0
+        parts_was, args.infer_parts = args.infer_parts, 1      # (--mode infer: whole-batch launches on one stream, so that a launch's events bracket it alone)
         for _ in range(3):
             eager_step()
         sync()
         timer.enabled = False
+        args.infer_parts = parts_was
         _model._NATIVE = native_was
         kernel_timing_note = ("HIP events around every forward-Linear launch of 3 eager steps run right after the timed region (blocks on the per-launch "
                               "Python schedule for these steps: whole-batch launches of the same kernels; the native block calls of the timed region issue the "
-                              "FORWARD-pass launches as model.TRAIN_PARTS concurrent ranges of images, i.e. at half the rows each by default)")
+                              "FORWARD-pass launches as model.TRAIN_PARTS concurrent ranges of images, i.e. at half the rows each by default; --mode infer: "
+                              "whole batch on one stream for these steps, the timed region replays it as --infer-parts concurrent sub-batches)")
     # The north-star target is FORWARD throughput (BASELINE.json): in train mode the same process times the forward pass of the same
     # model on the same batch right after the train region (eval mode, no_grad, bf16 autocast, hipGraph replay as in --mode infer) and
     # reports it as extra keys of the same JSON line.  The timed train region above is not touched by it.

@@ -18,8 +18,8 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
     # steps: 2 warm-up + 4 timed (--no-issue-probe); a step starts at the stem's im2col launch (once per pass), the first passes carry
     # one-time kernels (weight folds, casts), so count from the 3rd marker to the end = the 4 timed passes
     marks = [i for i, r in enumerate(rows) if 'im2col_c3_kernel' in r[0]]
-    assert len(marks) == 6, len(marks)
-    sel = rows[marks[2]:]
+    assert len(marks) % 6 == 0 and marks, len(marks)      # (inference as k concurrent sub-batches: k stem launches per pass)
+    sel = rows[marks[2 * (len(marks) // 6)]:]
     per = len(sel) // 4
     kb = sum(r[1] for r in sel) / 4
     by = {}

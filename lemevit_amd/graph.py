@@ -60,10 +60,8 @@ def split_forward(model: Callable, x: torch.Tensor, parts: int, outs: Optional[l
         return y
     xs = x.chunk(parts)
     cur = torch.cuda.current_stream()
-    key = (x.device, len(xs))
-    streams = _split_streams.get(key)
-    if streams is None:
-        streams = _split_streams[key] = [torch.cuda.Stream(device=x.device) for _ in range(len(xs) - 1)]
+    from .blocks import aux_streams
+    streams = aux_streams(x.device, len(xs) - 1)          # shared with the training schedules: main + 3 streams per process (blocks.aux_streams)
     ys = [None] * len(xs)
     for i, s in enumerate(streams):
         s.wait_stream(cur)
@@ -78,9 +76,6 @@ def split_forward(model: Callable, x: torch.Tensor, parts: int, outs: Optional[l
         outs[:] = ys
         return None
     return torch.cat(ys)
-
-
-_split_streams: dict = {}
 
 
 def try_graphed(step_fn: Callable[[], None], warmup: int = 3, pre_capture: Optional[Callable[[], None]] = None):

@@ -612,10 +612,8 @@ class image_ranges:
 
     def __enter__(self):
         if self.on:
-            key = (self.dev.index, self.parts)
-            streams = _range_streams.get(key)
-            if streams is None:
-                streams = _range_streams[key] = [torch.cuda.Stream(device=self.dev) for _ in range(self.parts - 1)]
+            from . import blocks as _blocks
+            streams = _blocks.aux_streams(self.dev, self.parts - 1)      # [0] = the weight-gradient side stream, idle during the forward pass
             _range_state[self.dev.index] = [streams, False, -1]
         return self
 
@@ -627,9 +625,6 @@ class image_ranges:
                 for s in streams:
                     cur.wait_stream(s)
         return False
-
-
-_range_streams: dict = {}
 
 
 def _join_ranges(device) -> None:

@@ -28,3 +28,20 @@ for parts in [int(a) for a in sys.argv[1:]] or [1, 2, 4]:
         if it >= 4:
             tf += t1 - t0; tb += t2 - t1; n += 1
     print(f"parts {parts}: forward {tf / n * 1e3:.2f} ms  backward {tb / n * 1e3:.2f} ms", flush=True)
+    # device time of the forward pass with the host AHEAD of the device (a ~20 ms stack of matrix products is queued first)
+    big = torch.randn(8192, 8192, device=dev, dtype=torch.bfloat16)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    acc = 0.0
+    for it in range(6):
+        torch.cuda.synchronize()
+        for _ in range(40):
+            big @ big
+        e0.record()
+        with torch.autocast("cuda", torch.bfloat16):
+            loss = lossf(model(x), y)
+        e1.record()
+        loss.backward(); opt.step(); opt.zero_grad(set_to_none=False)
+        torch.cuda.synchronize()
+        if it >= 2:
+            acc += e0.elapsed_time(e1)
+    print(f"   forward, device time with the host ahead: {acc / 4:.2f} ms", flush=True)

@@ -101,3 +101,31 @@ def test_dense_backbone_checkpoint_remap(tmp_path):
     res = bb.init_weights(str(path))
     assert sorted(res.unexpected_keys) == ["head.bias", "head.weight"] and all(k.startswith("extra_norms.") for k in res.missing_keys)
     assert not hasattr(bb, "head") and all(blk.kind == "Sx" for st in bb.stages[3:] for blk in st)
+
+
+def test_schedule_helpers_without_gpu():
+    """Host logic of the concurrent schedules that does not need a device: split_forward with one part is the plain call (and fills `outs`),
+    image_ranges is a no-op off the GPU / under no_grad / for small batches, the range entry point is bound with the header's signature."""
+    from lemevit_amd import _lib
+    from lemevit_amd.graph import split_forward
+    import lemevit_amd.model as M
+    calls = []
+
+    def f(t):
+        calls.append(t.shape[0])
+        return t * 2
+
+    x = torch.arange(12.0).view(6, 2)
+    assert torch.equal(split_forward(f, x, 1), x * 2) and calls == [6]
+    outs = []
+    split_forward(f, x, 0, outs)                      # parts < 1 is clamped to 1
+    assert len(outs) == 1 and torch.equal(outs[0], x * 2)
+    cpu = torch.device("cpu")
+    with M.image_ranges(cpu, 128) as r:
+        assert not r.on and not M._range_state
+    with torch.no_grad():
+        assert not M.image_ranges(torch.device("cuda", 0), 128).on
+    assert not M.image_ranges(torch.device("cuda", 0), M.TRAIN_PARTS_MIN_BATCH - 1).on
+    assert not M.image_ranges(torch.device("cuda", 0), 128, parts=1).on
+    fn = _lib.lib.lmv_block_fwd_range
+    assert fn.restype is ctypes.c_int and len(fn.argtypes) == 11

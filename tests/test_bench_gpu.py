@@ -30,6 +30,7 @@ def test_bench_single_gpu_line_has_forward_keys():
         assert k in line and line[k] is not None and line[k] > 0, k
     # the forward pass is (much) cheaper than the train step on the same batch
     assert line["forward_ms"] < line["ms_per_step"]
+    assert "concurrent sub-batches" in line["forward_note"]          # the forward probe replays the batch as --infer-parts graph branches
 
 
 def test_bench_two_ranks_on_one_device():

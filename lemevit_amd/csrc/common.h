@@ -87,6 +87,7 @@ struct LmvConfig {
   int res_ln_fused;       // LMV_RES_LN_FUSED       1: "S" blocks run the attention projection and norm2 as one launch where lmv_linear_res_ln_fwd applies
   int dx_ln_fused;        // LMV_DX_LN_FUSED        1: lmv_block_bwd fuses the dX of fc1 / qkv with the LayerNorm backward of their input where lmv_linear_dx_ln_bwd applies
   int mlp_split384;       // LMV_MLP_SPLIT384       1: fused inference schedule runs the C = 384 MLP half as LayerNorm + rsgemm fc1 + wngemm fc2 instead of the one-kernel form
+  int mlp_rw96;           // LMV_MLP_RW96           1: the C = 96 one-kernel MLP with both weight matrices resident in LDS (csrc/rwmlp.hip) instead of the tile-streaming form
   int mlp_tm;             // LMV_MLP_TM             0 = auto: token rows per workgroup of the fused MLP kernel (64 / 128)
   int attn_pv16, attn_fuse_dq, attn_fused_bwd, attn_pair;      // LMV_ATTN_*
   int ln_bwd_blocks, ln_bwd_minrows;                           // LMV_LN_BWD_*
@@ -98,6 +99,9 @@ bool lmv_rs_eligible(const lmv_linear_problem* p, int nproblems, int N, int K, i
 int lmv_rs_linear(const lmv_linear_problem* p, int nproblems, int N, int K, int act, hipStream_t st);
 // wngemm.hip: one workgroup per 128-row token panel and ALL 384 output columns (bf16, forward form)
 bool lmv_wn_eligible(const lmv_linear_problem* p, int nproblems, int N, int K, int act, bool force);
+// csrc/rwmlp.hip: lmv_mlp_fused_fwd at C = 96 / hidden = 384 with both weight matrices resident in LDS
+bool lmv_mlp_rw96_eligible(const lmv_mlp_problem* p, int nproblems, int C, int hidden);
+int lmv_mlp_rw96_fwd(const lmv_mlp_problem* p, int nproblems, const lmv_mlp_weights* w, float eps, hipStream_t st);
 int lmv_wn_linear(const lmv_linear_problem* p, int nproblems, int N, int K, int act, hipStream_t st);
 
 static inline bool lmv_aligned16(const void* p) { return (((uintptr_t)p) & 15u) == 0; }

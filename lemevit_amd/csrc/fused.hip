@@ -472,6 +472,7 @@ extern "C" int lmv_mlp_fused_fwd(const lmv_mlp_problem* p, int nproblems, const 
     P.x = (const bf16_t*)q.x; P.out = (bf16_t*)q.out; P.row_scale = q.row_scale; P.rows = (int)q.rows; P.rps = q.rows_per_sample;
   }
   hipStream_t st = (hipStream_t)stream;
+  if (lmv_mlp_rw96_eligible(p, nproblems, C, hidden)) return lmv_mlp_rw96_fwd(p, nproblems, w, eps, st);      // both weight matrices resident in LDS (csrc/rwmlp.hip)
   int rc;
   switch (C) {
     case 64:  rc = launch_mlp_c<64>(g, st); break;

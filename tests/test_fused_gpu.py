@@ -178,6 +178,35 @@ def test_mlp_fused_full_shapes(C, B, N):
         assert_close(fused, unfused.double().cpu(), dtype, f"fused vs unfused C={C}", tol16=6e-3)
 
 
+@pytest.mark.parametrize("rows,rows_c", [(3 * 331, 48), (31, 0), (8 * 32 * 40 + 5, 16)])
+def test_mlp_fused_c96_resident_and_streaming_forms(rows, rows_c, request):
+    """C = 96, hidden = 384: the resident-weight kernel (csrc/rwmlp.hip, default) and the tile-streaming kernel (csrc/fused.hip, mlp_rw96 = 0)
+    against the kernel-math reference and against each other, one and two problems, DropPath scale on the first, row counts off the panel size."""
+    from lemevit_amd import _lib
+    request.addfinalizer(lambda: _lib.config_set("mlp_rw96", 1))
+    dtype, C, Hd = torch.bfloat16, 96, 384
+    o, F, masters, w2, b2 = _mlp_case(C, Hd)
+    L = 331 if rows % 331 == 0 else rows
+    x, x64 = _tokens(rows, C, "x", dtype)
+    xs, refs64 = [x.view(rows // L, L, C)], [x64]
+    scales = [(det_tensor((rows // L,), "sx", 7).abs() + 0.5).to(dev())]
+    if rows_c:
+        c, c64 = _tokens(rows_c, C, "c", dtype)
+        xs.append(c.view(rows_c // 16, 16, C)); refs64.append(c64); scales.append(None)
+    outs = {}
+    for form in (1, 0):
+        _lib.config_set("mlp_rw96", form)
+        outs[form] = o.mlp_fused_fwd(xs, F, w2, b2, EPS, scales)
+        for out, t64, sc, Lr in zip(outs[form], refs64, scales, (L, 16)):
+            n = t64.shape[0]
+            sr = torch.ones(n, 1, dtype=torch.float64) if sc is None else sc.cpu().double()[torch.arange(n) // Lr][:, None]
+            rk, rm = _mlp_refs(t64, F, w2.cpu().double(), b2.cpu(), masters, sr)
+            assert_close(out.view(n, C), rk, dtype, f"form {form} (kernel math)")
+            assert_close(out.view(n, C), rm, dtype, f"form {form} (reference math)", tol16=4e-3)
+    for a, b in zip(outs[1], outs[0]):
+        assert_close(a, b.double().cpu(), dtype, "resident vs streaming form", tol16=4e-3)
+
+
 @pytest.mark.parametrize("C,Hd,rows", [(64, 128, 1), (128, 256, 63), (96, 384, 65), (192, 384, 129), (384, 1536, 127), (320, 640, 257)])
 def test_mlp_fused_edges(C, Hd, rows):
     """row counts around the tile heights (1, 63 / 65, 127 / 129, 257) and MLP widths below 4 C (hidden = 2 C)"""

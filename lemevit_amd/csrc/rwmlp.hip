@@ -116,7 +116,6 @@ __global__ __launch_bounds__(512, 1) void rw_mlp96_kernel(const RwArgs g) {
   bf16x8_t cur[2][3], nxt[2][3];
   if (gw < npanels) load_panel(gw, cur);
   for (int pn = gw; pn < npanels; pn += stride) {
-    if (pn + stride < npanels) load_panel(pn + stride, nxt);       // two waves per SIMD: the next panel's rows are requested a whole panel ahead
     float mean[2], rstd[2], rsc[2];
 #pragma unroll
     for (int rt = 0; rt < 2; ++rt) {
@@ -151,33 +150,28 @@ __global__ __launch_bounds__(512, 1) void rw_mlp96_kernel(const RwArgs g) {
     // Two waves per SIMD cannot hide an LDS round trip per fragment: the reads are issued by hand, a whole phase ahead.  Per 32-wide hidden
     // chunk: GEMM1 (fc1 fragments requested during the previous chunk) -> request fc2's 6 fragments of this chunk AND fc1's 6 of the next ->
     // folded LayerNorm + GELU on the accumulators (~650 cycles of VALU work: covers the round trips) -> one wait -> GEMM2.
-    bf16x8_t w1f[3][2], w2f[3][2];
-    auto rd1 = [&](int hc) {
-      const unsigned b = lds0 + hc * 32 * RW_W1ROW;
-#pragma unroll
-      for (int ks = 0; ks < 3; ++ks)
-#pragma unroll
-        for (int t = 0; t < 2; ++t) { const unsigned a = b + w1off[t] + ks * 64; asm volatile("ds_read_b128 %0, %1" : "=v"(w1f[ks][t]) : "v"(a) : "memory"); }
-    };
-    rd1(0);
+    bf16x8_t w2f[3][2];
 #pragma unroll 1
     for (int hc = 0; hc < RW_H / 32; ++hc) {
+      // the next panel's rows are requested ten chunks ahead -- not before the loop: vmcnt retires in order, and any vector-memory wait the
+      // compiler places at the top of the loop would wait for these loads at once
+      if (hc == 2 && pn + stride < npanels) load_panel(pn + stride, nxt);
       f32x4_t acc1[2][2];
 #pragma unroll
       for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
         for (int t = 0; t < 2; ++t) acc1[rt][t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-      if (hc == 0) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      const unsigned char* w1b = sw1 + hc * 32 * RW_W1ROW;
 #pragma unroll
-      for (int ks = 0; ks < 3; ++ks)
+      for (int ks = 0; ks < 3; ++ks) {
+        bf16x8_t wf[2];
 #pragma unroll
-        for (int t = 0; t < 2; ++t) asm volatile("" : "+v"(w1f[ks][t]));          // the MFMAs below must not be scheduled above the wait
-#pragma unroll
-      for (int ks = 0; ks < 3; ++ks)
+        for (int t = 0; t < 2; ++t) wf[t] = *reinterpret_cast<const bf16x8_t*>(w1b + w1off[t] + ks * 64);
 #pragma unroll
         for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
-          for (int t = 0; t < 2; ++t) acc1[rt][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1f[ks][t], cur[rt][ks], acc1[rt][t], 0, 0, 0);
+          for (int t = 0; t < 2; ++t) acc1[rt][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[t], cur[rt][ks], acc1[rt][t], 0, 0, 0);
+      }
       // folded LayerNorm + bias + GELU on the lane's hidden values 32 hc + 8 grp + {0..7} (tile t: + 4 t + {0..3}); packed as the B operand of GEMM2
       const int h0 = hc * 32 + 8 * grp;
       const float4 c0 = *reinterpret_cast<const float4*>(scs + h0), c1 = *reinterpret_cast<const float4*>(scs + h0 + 4);
@@ -190,9 +184,6 @@ __global__ __launch_bounds__(512, 1) void rw_mlp96_kernel(const RwArgs g) {
           const unsigned a = lds0 + RW_W1_BYTES + s * 32 * RW_W2ROW + w2off[t] + (((c8 & ~15) | ((c8 & 15) ^ w2x[t])) << 4);
           asm volatile("ds_read_b128 %0, %1" : "=v"(w2f[s][t]) : "v"(a) : "memory");
         }
-      if (hc + 1 < RW_H / 32) {
-        rd1(hc + 1);                                   // (fc1's fragment registers are free: GEMM1 has been issued)
-      }
       bf16x8_t hf[2];
       {
         typedef __attribute__((ext_vector_type(4))) unsigned u32x4_t;

@@ -16,8 +16,8 @@
 //     for LDS; fc2's A fragments are plain 16-byte reads of its rows;
 //   * the residual comes from the raw-row registers (their k-slots are the 8 output columns of the lane), the output leaves as 16-byte stores.
 // Per 32-row panel and wave: 144 ds_read_b128 (147 KB) and 288 MFMAs -- LDS-read and MFMA time balance at ~9.2 k cycles per 256 rows of a CU.
-// Measured on the stage-1 shape (tools/rw_probe.py, 401 408 rows): 128 - 141 us against 171 us for the tile-streaming form.  Ablations of the
-// 141 us: without the GELU polynomial 96, without the GEMM2 MFMAs 123, without re-reading fc1's fragments 130, ONE hidden chunk instead of
+// Measured on the stage-1 shape (tools/rw_probe.py, 401 408 rows): 125 us against 171 - 190 us for the tile-streaming form.  Ablations of an
+// earlier 141 us version: without the GELU polynomial 96, without the GEMM2 MFMAs 123, without re-reading fc1's fragments 130, ONE hidden chunk instead of
 // twelve 52 (rows in, statistics, rows out, the weight images: the HBM floor of 154 MB is ~35 us) -- the kernel is bound by VALU issue: a
 // wave-chunk costs ~1.6 k cycles of SIMD time of which ~730 are the 8 packed degree-7 evaluations (v_pk_fma_f32 issues at half rate).
 #include <atomic>
@@ -147,9 +147,10 @@ __global__ __launch_bounds__(512, 1) void rw_mlp96_kernel(const RwArgs g) {
       for (int s = 0; s < 3; ++s)
 #pragma unroll
         for (int t = 0; t < 2; ++t) acc2[rt][s][t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-    // Two waves per SIMD cannot hide an LDS round trip per fragment: the reads are issued by hand, a whole phase ahead.  Per 32-wide hidden
-    // chunk: GEMM1 (fc1 fragments requested during the previous chunk) -> request fc2's 6 fragments of this chunk AND fc1's 6 of the next ->
-    // folded LayerNorm + GELU on the accumulators (~650 cycles of VALU work: covers the round trips) -> one wait -> GEMM2.
+    // Two waves per SIMD cannot hide an LDS round trip per fragment: fc2's six fragments of a chunk are requested by hand BEFORE the folded
+    // LayerNorm + GELU of the chunk (~650 cycles of VALU work cover the round trip) and waited for once; fc1's fragments are plain reads the
+    // compiler pipelines inside GEMM1 (prefetching them by hand as well cost 24 registers: the kernel spilled, and every scratch reload made
+    // the in-order vmcnt wait for the next panel's rows).
     bf16x8_t w2f[3][2];
 #pragma unroll 1
     for (int hc = 0; hc < RW_H / 32; ++hc) {

@@ -108,6 +108,21 @@ class GemmTimer:
             return r
 
         ops.linear_res_ln_fwd = timed_ln
+        orig_ex = ops.ln_linear_exact_fwd
+
+        def timed_ex(probs, N, K, *a, **kw):          # norm1 + projection of the C = 96 blocks (csrc/rswgemm.hip): a forward Linear launch as well
+            if not timer.enabled:
+                return orig_ex(probs, N, K, *a, **kw)
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record()
+            r = orig_ex(probs, N, K, *a, **kw)
+            e.record()
+            timer.events.append((s, e))
+            timer.flops.append(2.0 * N * K * sum(p.rows for p in probs))
+            timer.bytes.append(sum(2.0 * p.rows * (2 * K + N) + 8.0 * p.rows for p in probs) + 2.0 * N * K + 4.0 * N)      # raw rows in; LayerNorm(rows), (mean, rstd) and the projection out
+            return r
+
+        ops.ln_linear_exact_fwd = timed_ex
         import lemevit_amd.blocks as blocks
         import lemevit_amd.model as model
         blocks.ops.linear_fwd = timed
@@ -408,7 +423,7 @@ def main():
                         traffic=traffic, traffic_unit="MB/launch", traffic_source=traffic_src, algorithmic_mbytes_per_launch=round(g["mbytes_per_launch"], 2),
                         flop_per_byte=round(intensity, 1), ridge_flop_per_byte=round(PEAK_BF16_TFLOPS * 1e3 / PEAK_HBM_GBS, 1),
                         hbm_gbs=round(hbm_gbs, 1), hbm_peak_gbs=PEAK_HBM_GBS, hbm_frac=round(hbm_gbs / PEAK_HBM_GBS, 4),
-                        kernel="forward Linear launches: gemm_kernel<bf16,NT> / rs_gemm_kernel / wn_gemm_kernel", measured=kernel_timing_note, launches=g["launches"], avg_launch_us=round(g["avg_us"], 2),
+                        kernel="forward Linear launches: gemm_kernel<bf16,NT> / rs_gemm_kernel / wn_gemm_kernel / rsw_gemm_kernel", measured=kernel_timing_note, launches=g["launches"], avg_launch_us=round(g["avg_us"], 2),
                         gflop_per_launch=round(g["gflop_per_launch"], 3))
         line = {
             "metric": f"images/sec {pretty} {args.img}^2 bf16 " + ("fwd+bwd" if train else "fwd"),

@@ -52,6 +52,22 @@ __device__ __forceinline__ bf16x8_t rw_pack8(const float* v) {
   return __builtin_bit_cast(bf16x8_t, u);
 }
 
+// gelu_poly2 (common.h) on two pairs at once, the two Horner chains interleaved statement by statement: a dependent packed op waits for its
+// predecessor, so one chain at a time costs a wait state per step
+__device__ __forceinline__ void rw_gelu2x2(f32x2_t& a, f32x2_t& b) {
+  f32x2_t sa = a * 0.25f, sb = b * 0.25f;
+  sa[0] = __builtin_amdgcn_fmed3f(sa[0], -1.0f, 1.0f); sa[1] = __builtin_amdgcn_fmed3f(sa[1], -1.0f, 1.0f);
+  sb[0] = __builtin_amdgcn_fmed3f(sb[0], -1.0f, 1.0f); sb[1] = __builtin_amdgcn_fmed3f(sb[1], -1.0f, 1.0f);
+  const f32x2_t ua = sa * sa, ub = sb * sb;
+  f32x2_t qa = {-1.6300047636032104f, -1.6300047636032104f}, qb = qa;
+#define RW_STEP(c) qa = __builtin_elementwise_fma(qa, ua, f32x2_t{c, c}); qb = __builtin_elementwise_fma(qb, ub, f32x2_t{c, c})
+  RW_STEP(7.93373966217041f); RW_STEP(-16.877059936523438f); RW_STEP(20.921268463134766f); RW_STEP(-17.09065055847168f);
+  RW_STEP(9.8812894821167f); RW_STEP(-4.233964920043945f); RW_STEP(1.595382571220398f);
+#undef RW_STEP
+  a = a * __builtin_elementwise_fma(sa, qa, f32x2_t{0.5f, 0.5f});
+  b = b * __builtin_elementwise_fma(sb, qb, f32x2_t{0.5f, 0.5f});
+}
+
 __global__ __launch_bounds__(512, 1) void rw_mlp96_kernel(const RwArgs g) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];      // fc1 image | fc2 image | colsum [384] | b1' [384] | b2 [96]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -195,8 +211,9 @@ __global__ __launch_bounds__(512, 1) void rw_mlp96_kernel(const RwArgs g) {
 #pragma unroll
           for (int t = 0; t < 2; ++t) {
             const float4 c4 = t ? c1 : c0, d4 = t ? d1 : d0;
-            const f32x2_t y0 = gelu_poly2(f32x2_t{fmaf(rstd[rt], fmaf(nm, c4.x, acc1[rt][t][0]), d4.x), fmaf(rstd[rt], fmaf(nm, c4.y, acc1[rt][t][1]), d4.y)});
-            const f32x2_t y1 = gelu_poly2(f32x2_t{fmaf(rstd[rt], fmaf(nm, c4.z, acc1[rt][t][2]), d4.z), fmaf(rstd[rt], fmaf(nm, c4.w, acc1[rt][t][3]), d4.w)});
+            f32x2_t y0 = f32x2_t{fmaf(rstd[rt], fmaf(nm, c4.x, acc1[rt][t][0]), d4.x), fmaf(rstd[rt], fmaf(nm, c4.y, acc1[rt][t][1]), d4.y)};
+            f32x2_t y1 = f32x2_t{fmaf(rstd[rt], fmaf(nm, c4.z, acc1[rt][t][2]), d4.z), fmaf(rstd[rt], fmaf(nm, c4.w, acc1[rt][t][3]), d4.w)};
+            rw_gelu2x2(y0, y1);
             pk[2 * t] = pack_bf2(y0[0], y0[1]); pk[2 * t + 1] = pack_bf2(y1[0], y1[1]);
           }
           hf[rt] = __builtin_bit_cast(bf16x8_t, pk);

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define LMV_ABI_VERSION 6
+#define LMV_ABI_VERSION 7
 
 enum { LMV_F32 = 0, LMV_BF16 = 1 };
 enum {
@@ -400,6 +400,40 @@ int lmv_block_fwd_range(const lmv_block_desc* d, const void* x, const void* c, v
 /* x, c: the block inputs of the forward call; dx_out / dc_out: gradients of x_out / c_out; dx / dc: gradients of x / c (written). */
 int lmv_block_bwd(const lmv_block_desc* d, const void* x, const void* c, const void* arena, size_t arena_bytes, const void* dx_out, const void* dc_out,
                   void* dx, void* dc, void* scratch, size_t scratch_bytes, void* stream, void* side_stream);
+
+/* ------------------------------------------------------------------------------------------
+ * A whole run of "S" blocks as ONE persistent launch (csrc/sstage.hip; inference form, bf16): stage 3 of LeMeViT-Base -- 18 x
+ * LeMeBlock.forward_with_x (models/lemevit.py:615-650, live :631-635; StandardAttention :185-205; MLP :526-530) on x [B, 196, 384] and
+ * c [B, 16, 384].  The token rows stay on chip for the whole stage (two workgroups per image, residual stream in registers); only the
+ * block weights stream from L2.  Replaces nblocks lmv_block_fwd(kind = S, save = 0) calls; same math, the residual stream is kept in
+ * fp32 between the blocks instead of being rounded to bf16 after every residual add.
+ *   lmv_sstage_supported: 1 where the kernel applies (C = 384, 12 heads, hidden 1536, 14 x 14 image tokens, 16 meta tokens, bf16).
+ *   lmv_sstage_pack: one block's parameters (matrices bf16, vectors fp32, the reference's layouts: attn.qkv [3C, C], attn.proj [C, C],
+ *     mlp.0 [4C, C], mlp.3 [C, 4C], pos_embed.weight [C, 9]) -> `wpk_out` (lmv_sstage_wpk_bytes: the matrices in MFMA-fragment order) and
+ *     `vec_out` (lmv_sstage_vec_floats fp32).  The packed blocks of a stage are consecutive: block j at wpk + j * wpk_bytes, vec + j * vec_floats.
+ *   lmv_sstage_fwd: x_out / c_out may alias x / c.  `workspace` (lmv_sstage_workspace_bytes(min(B, 128))) holds the K / V fragments and the
+ *     grid rows the two halves of an image exchange, and their flags (reset by the call on `stream`).  The launch needs 2 * min(B, 128)
+ *     co-resident workgroups of 512 threads / 147 KB LDS (one per CU): it must not be issued while another kernel of the same kind runs
+ *     on a different stream of the same device.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct lmv_sstage_block_params {
+  int32_t C, heads, hidden, _pad;
+  const void* qkv_w; const void* proj_w; const void* fc1_w; const void* fc2_w;
+  const float* n1_w; const float* n1_b; const float* qkv_b; const float* proj_b;
+  const float* n2_w; const float* n2_b; const float* fc1_b; const float* fc2_b;
+  const float* pos_w; const float* pos_b;
+} lmv_sstage_block_params;
+typedef struct lmv_sstage_desc {
+  int32_t B, H, W, M, C, heads, hidden, nblocks, dtype;
+  float eps;                                       /* LayerNorm eps of norm1 / norm2 (1e-6) */
+  const void* wpk; const float* vec;               /* nblocks packed blocks (lmv_sstage_pack) */
+} lmv_sstage_desc;
+int lmv_sstage_supported(int C, int heads, int hidden, int H, int W, int M, int dtype);
+size_t lmv_sstage_wpk_bytes(int C, int hidden);
+size_t lmv_sstage_vec_floats(int C, int hidden);
+size_t lmv_sstage_workspace_bytes(int B);
+int lmv_sstage_pack(const lmv_sstage_block_params* p, void* wpk_out, float* vec_out, void* stream);
+int lmv_sstage_fwd(const lmv_sstage_desc* d, const void* x, const void* c, void* x_out, void* c_out, void* workspace, size_t workspace_bytes, void* stream);
 
 #ifdef __cplusplus
 }

@@ -14,7 +14,7 @@ LIB_PATH = os.path.join(_HERE, "csrc", "liblemevit_hip.so")
 
 LMV_F32, LMV_BF16 = 0, 1
 ACT_NONE, ACT_GELU, ACT_GELU_GRAD = 0, 1, 2
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 
 class LinearProblem(C.Structure):
@@ -62,6 +62,15 @@ class BlockDesc(C.Structure):
                 [(n, C.c_void_p) for n in ("g_n2_w", "g_n2_b", "g_fc1_w", "g_fc1_b", "g_fc2_w", "g_fc2_b")] +
                 [("fold_attn_w", C.c_void_p * 2), ("fold_attn_s", C.c_void_p * 2), ("fold_attn_b", C.c_void_p * 2)] +
                 [(n, C.c_void_p) for n in ("fold_fc1_w", "fold_fc1_s", "fold_fc1_b", "fc2_wt", "fc1_wt")] + [("attn_wt", C.c_void_p * 2)])
+
+
+class SStageBlockParams(C.Structure):
+    _fields_ = ([(n, C.c_int32) for n in ("C", "heads", "hidden", "_pad")] +
+                [(n, C.c_void_p) for n in ("qkv_w", "proj_w", "fc1_w", "fc2_w", "n1_w", "n1_b", "qkv_b", "proj_b", "n2_w", "n2_b", "fc1_b", "fc2_b", "pos_w", "pos_b")])
+
+
+class SStageDesc(C.Structure):
+    _fields_ = ([(n, C.c_int32) for n in ("B", "H", "W", "M", "C", "heads", "hidden", "nblocks", "dtype")] + [("eps", C.c_float), ("wpk", C.c_void_p), ("vec", C.c_void_p)])
 
 
 class TransposeSeg(C.Structure):
@@ -134,6 +143,12 @@ SIGNATURES = {
     "lmv_block_fwd": (_I, [C.POINTER(BlockDesc), _P, _P, _P, _P, _P, _Z, _I, _P]),
     "lmv_block_fwd_range": (_I, [C.POINTER(BlockDesc), _P, _P, _P, _P, _P, _Z, _I, _I, _I, _P]),
     "lmv_block_bwd": (_I, [C.POINTER(BlockDesc), _P, _P, _P, _Z, _P, _P, _P, _P, _P, _Z, _P, _P]),
+    "lmv_sstage_supported": (_I, [_I, _I, _I, _I, _I, _I, _I]),
+    "lmv_sstage_wpk_bytes": (_Z, [_I, _I]),
+    "lmv_sstage_vec_floats": (_Z, [_I, _I]),
+    "lmv_sstage_workspace_bytes": (_Z, [_I]),
+    "lmv_sstage_pack": (_I, [C.POINTER(SStageBlockParams), _P, _P, _P]),
+    "lmv_sstage_fwd": (_I, [C.POINTER(SStageDesc), _P, _P, _P, _P, _P, _Z, _P]),
 }
 
 

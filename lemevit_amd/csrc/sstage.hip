@@ -1,0 +1,614 @@
+// sstage.hip -- a whole run of "S" blocks (stage 3 of LeMeViT-Base: 18 blocks at 14 x 14 image tokens + 16 meta tokens, C = 384) as ONE
+// persistent launch with the token rows resident on chip (round 4; inference form).
+//
+// Reference math: LeMeBlock.forward_with_x, models/lemevit.py:615-650 (live branch :631-635): x = x + dwconv3x3(x) (:619);
+// x = x + attn(norm1(x)); x = x + mlp(norm2(x)); c = c + attn(norm1(c)); c = c + mlp(norm2(c)) with StandardAttention (:185-205: fused qkv,
+// softmax(q k^T / sqrt d) v per head, proj), the MLP of :526-530 (exact GELU) and LayerNorm eps 1e-6 (:513,525); x and c share every weight
+// but attend separately.  The per-launch schedule (csrc/block.hip) runs a block as ~5 dependent launches whose qkv / attention output /
+// hidden tensors each make an HBM round trip; a forward pass of the stage is 90 launches at 0.185 of the MFMA peak.
+//
+// Decomposition.  A batch of 128 images has 256 half-images for 256 CUs: TWO workgroups per image, split by token ROWS --
+//   half 0: image tokens 0..111 (grid rows 0..7: 7 tiles of 16), half 1: image tokens 112..195 (grid rows 8..13, slots 0..83) + 12 pad
+//   slots + the 16 meta tokens (slots 96..111): 7 tiles again -- so no FLOP is duplicated.  What the halves exchange per block, through
+//   L2 with write-through (sc1) stores, sc1 loads and one relaxed agent-scope flag each (cdna_hip_programming.md Guideline 16, form R1):
+//   the K / V fragments of their rows (attention needs all 196 keys) and the one grid row next to the cut (the 3 x 3 position embedding).
+// Inside a workgroup (8 waves, 512 threads, one per CU):
+//   * the residual stream lives in REGISTERS, fp32, for the whole stage: wave w owns channels 48 w .. 48 w + 47 of all 112 token slots
+//     (84 registers per lane, in the C/D layout of D[channel][token] MFMA tiles);
+//   * every Linear is computed channel-split: a wave owns a slice of OUTPUT channels, pulls its weight fragments STRAIGHT from L2 into
+//     registers (the weights are pre-packed in MFMA-fragment order by lmv_sstage_pack: one fully coalesced 1 KB load per fragment, no LDS,
+//     no barrier inside a GEMM) and reads the token operand -- LayerNorm output, attention output or hidden activations, 112 tokens x K --
+//     from LDS, stored in fragment order as well (1 KB per [k-step][token tile], lane-linear ds_read_b128: conflict-free);
+//   * outputs are produced TRANSPOSED, D[channel][token]: a lane then holds 4 consecutive channels of one token, and two such tiles are
+//     exactly the lane's 8 k-slots of the NEXT contraction's token operand (the k-order inside a 32-channel step is a fixed permutation that
+//     the packed weights share) -- q, k, the attention output, the hidden activations and the LayerNorm outputs are all written as ready
+//     operand fragments, no transposes anywhere; v is computed with the operands swapped, D[token][channel], which is the V^T operand of P V;
+//   * attention per (head, 16-query tile) inside one wave: scores transposed (S^T = K Q^T), two passes over the keys (row maximum, then
+//     exp2 / sum / P V with S recomputed: K and V fragments are read once per head and pass, every query tile of the head reuses them),
+//     P and V enter the P V product as fp16;
+//   * the MLP runs in 6 chunks of 256 hidden channels: fc1 chunk -> GELU -> LDS (57 KB) -> fc2 partial sums accumulate ON the residual registers.
+// Measured crux (tools/native/sstage_probe.hip): the GEMM stream of all 18 blocks in this form runs in 1.5 ms on 256 CUs (1.2 PFLOP/s;
+// 1.2 ms on 8 CUs: the difference is the L2 -> CU weight stream at ~10.6 TB/s), against ~3 ms of Linear launches in the per-launch schedule.
+#include <atomic>
+#include "common.h"
+
+namespace {
+
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8_t;
+typedef __attribute__((ext_vector_type(2))) _Float16 f16x2_t;
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4_t;
+typedef __attribute__((address_space(1))) unsigned gu32;
+typedef __attribute__((address_space(1))) unsigned long long gu64;
+
+constexpr int SS_C = 384, SS_NH = 12, SS_HID = 1536, SS_G = 14, SS_NIMG = 196, SS_M = 16;
+constexpr int SS_NT = 7;              // token tiles of 16 per workgroup (112 slots)
+constexpr int SS_KS = SS_C / 32;      // 12 k-steps of 32 channels
+constexpr int SS_NCHUNK = 6, SS_KSC = 8;      // MLP: 6 chunks of 256 hidden channels = 8 k-steps of fc2 each
+
+// packed weights of a block, in 1 KB fragments (64 lanes x 16 B).  Fragment (row0, ks) of a weight W [N][K]: lane (g = lane >> 4, i = lane & 15)
+// holds W[row0 + i][32 ks + 16 (j >> 2) + 4 g + (j & 3)], j = 0..7 -- the A operand of v_mfma_f32_16x16x32_bf16 under the k-slot permutation
+// every token operand of this kernel is written in.
+constexpr int WS_KV = 0;              // [unit u = 2 h + (0: k, 1: v)][ks 12][n 2]: rows (1 + (u & 1)) C + 32 (u >> 1) + 16 n of qkv.weight
+constexpr int WS_Q = 576;             // [head h][ks 12][n 2]: rows 32 h + 16 n
+constexpr int WS_PROJ = 864;          // [wave w][ks 12][n 3]: rows 48 w + 16 n of proj.weight
+constexpr int WS_FC1 = 1152;          // [chunk c][wave w][ks 12][n 2]: rows 256 c + 32 w + 16 n of mlp.0.weight
+constexpr int WS_FC2 = 2304;          // [chunk c][wave w][ksl 8][n 3]: rows 48 w + 16 n, columns of k-step 8 c + ksl of mlp.3.weight
+constexpr int WS_FRAGS = 3456;
+// packed fp32 vectors of a block (reference layouts, concatenated)
+constexpr int V_N1W = 0, V_N1B = 384, V_QKVB = 768, V_PROJB = 1920, V_N2W = 2304, V_N2B = 2688, V_FC1B = 3072, V_FC2B = 4608, V_POSW = 4992,
+              V_POSB = 8448, V_FLOATS = 8832;
+// LDS
+constexpr int L_XN = 0, L_XN_BYTES = SS_KS * SS_NT * 1024;        // token operand of qkv / fc1 (LayerNorm output) and of proj (attention output)
+constexpr int L_H = L_XN_BYTES, L_H_BYTES = SS_KSC * SS_NT * 1024;   // hidden chunk (token operand of fc2); second-head q fragments during attention
+constexpr int L_STAT = L_H + L_H_BYTES, L_STAT_BYTES = 8 * 112 * 8;  // LayerNorm partial sums [wave][slot] float2
+constexpr int L_TOTAL = L_STAT + L_STAT_BYTES;                        // 150 528 B
+constexpr int STG_ROW = 96, STG_WAVE = 126 * STG_ROW;                 // dwconv staging: per wave [<= 126 tokens][48 channels] bf16 (over L_XN | L_H)
+static_assert(8 * STG_WAVE <= L_STAT, "staging overlaps the statistics");
+// workspace
+constexpr size_t KBUF_IMG = (size_t)SS_NH * 14 * 1024;      // [head][14 key tiles: image 0..12, meta 13][1 KB]
+constexpr size_t VBUF_IMG = (size_t)SS_NH * 8 * 2 * 1024;   // [head][8 key-tile pairs: half 0 p0..3, half 1 p0..3][2 d-tiles][1 KB], fp16
+constexpr size_t HALO_IMG = (size_t)2 * 14 * SS_C * 2;      // [half][14 tokens][C] bf16
+constexpr unsigned SPIN_LIMIT = 1u << 22;
+
+struct SsArgs {
+  const bf16_t* x_in; const bf16_t* c_in; bf16_t* x_out; bf16_t* c_out;
+  const uint4* wpk; const float* vec;
+  unsigned char* kbuf; unsigned char* vbuf; unsigned char* halo; unsigned* flags;     // flags: [2 B] kv | [2 B] halo | [1] error
+  int B, nblocks; float eps;
+};
+
+__device__ __forceinline__ bf16x8_t as_bf8(const uint4& v) { return __builtin_bit_cast(bf16x8_t, v); }
+__device__ __forceinline__ bf16x8_t as_bf8(const u32x4_t& v) { return __builtin_bit_cast(bf16x8_t, v); }
+__device__ __forceinline__ f32x4_t mfma_bf16(const bf16x8_t& a, const bf16x8_t& b, const f32x4_t& c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
+__device__ __forceinline__ f32x4_t mfma_f16(const f16x8_t& a, const f16x8_t& b, const f32x4_t& c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
+__device__ __forceinline__ unsigned pack_h2(float lo, float hi) { return __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(lo, hi)); }
+__device__ __forceinline__ u32x4_t pack_bf8(const f32x4_t& a, const f32x4_t& b) {
+  return u32x4_t{pack_bf2(a[0], a[1]), pack_bf2(a[2], a[3]), pack_bf2(b[0], b[1]), pack_bf2(b[2], b[3])};
+}
+__device__ __forceinline__ float max4(const f32x4_t& s) { return fmaxf(fmaxf(s[0], s[1]), fmaxf(s[2], s[3])); }
+__device__ __forceinline__ float xsum4(float v) { v += __shfl_xor(v, 16, 64); v += __shfl_xor(v, 32, 64); return v; }      // over the 4 lane groups of a token
+__device__ __forceinline__ float xmax4(float v) { v = fmaxf(v, __shfl_xor(v, 16, 64)); v = fmaxf(v, __shfl_xor(v, 32, 64)); return v; }
+
+// one lane polls a flag word until it reaches `epoch` (relaxed agent-scope loads + s_sleep); a bounded spin reports through flags[err]
+__device__ __forceinline__ void wait_flag(unsigned* flag, unsigned epoch, unsigned* err, int lane) {
+  if (lane == 0) {
+    unsigned spins = 0;
+    while (__hip_atomic_load((gu32*)flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < epoch) {
+      __builtin_amdgcn_s_sleep(4);
+      if (++spins > SPIN_LIMIT) { __hip_atomic_store((gu32*)err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+    }
+  }
+}
+
+// ---- one GEMM unit: NC output-channel tiles x all 7 token tiles x NKS k-steps ------------------------------------------------------
+// ring: the wave's weight fragments, 4 k-steps deep, straight from L2.  On entry slots 0..2 hold steps 0..2 of this unit (ring_fill or the
+// previous unit's tail); on exit they hold steps 0..2 of the unit at `wnext`.  TRANS: D[channel][token] = W X^T; else D[token][channel].
+template <int NC>
+__device__ __forceinline__ void ring_fill(bf16x8_t (&ring)[4][NC], const uint4* w) {
+#pragma unroll
+  for (int s = 0; s < 3; ++s)
+#pragma unroll
+    for (int n = 0; n < NC; ++n) ring[s][n] = as_bf8(w[(s * NC + n) * 64]);
+}
+template <int NC, int NKS, bool TRANS>
+__device__ __forceinline__ void gemm_unit(f32x4_t (&acc)[SS_NT][NC], bf16x8_t (&ring)[4][NC], const uint4* wcur, const uint4* wnext, const unsigned char* xs, int lane) {
+  static_assert(NKS % 4 == 0, "ring phase");
+#pragma unroll
+  for (int ks = 0; ks < NKS; ++ks) {
+    const int sp = ks + 3;
+#pragma unroll
+    for (int n = 0; n < NC; ++n) ring[sp % 4][n] = as_bf8(sp < NKS ? wcur[(sp * NC + n) * 64] : wnext[((sp - NKS) * NC + n) * 64]);
+    bf16x8_t xf[SS_NT];
+#pragma unroll
+    for (int t = 0; t < SS_NT; ++t) xf[t] = *reinterpret_cast<const bf16x8_t*>(xs + ((ks * SS_NT + t) * 64 + lane) * 16);
+#pragma unroll
+    for (int t = 0; t < SS_NT; ++t)
+#pragma unroll
+      for (int n = 0; n < NC; ++n) acc[t][n] = TRANS ? mfma_bf16(ring[ks % 4][n], xf[t], acc[t][n]) : mfma_bf16(xf[t], ring[ks % 4][n], acc[t][n]);
+  }
+}
+
+// ---- LayerNorm of the register-resident rows -> bf16 token operand in LDS (fragment order) ------------------------------------------
+__device__ __forceinline__ void layer_norm_to_lds(const f32x4_t (&R)[SS_NT][3], const float* gam, const float* bet, float eps, unsigned char* smem, int wave, int lane) {
+  const int g = lane >> 4, li = lane & 15;
+  float2* stat = reinterpret_cast<float2*>(smem + L_STAT);
+#pragma unroll
+  for (int t = 0; t < SS_NT; ++t) {
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int ct = 0; ct < 3; ++ct)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { s1 += R[t][ct][r]; s2 = fmaf(R[t][ct][r], R[t][ct][r], s2); }
+    s1 = xsum4(s1); s2 = xsum4(s2);
+    if (g == 0) stat[wave * 112 + t * 16 + li] = make_float2(s1, s2);
+  }
+  __syncthreads();
+  float mean[SS_NT], rstd[SS_NT];
+#pragma unroll
+  for (int t = 0; t < SS_NT; ++t) {
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int w = 0; w < 8; ++w) { const float2 p = stat[w * 112 + t * 16 + li]; s1 += p.x; s2 += p.y; }
+    mean[t] = s1 * (1.f / SS_C);
+    rstd[t] = rsqrtf(fmaxf(s2 * (1.f / SS_C) - mean[t] * mean[t], 0.f) + eps);
+  }
+#pragma unroll
+  for (int ct = 0; ct < 3; ++ct) {
+    const int c0 = 48 * wave + 16 * ct + 4 * g, T = 3 * wave + ct;
+    const float4 ga = *reinterpret_cast<const float4*>(gam + c0), be = *reinterpret_cast<const float4*>(bet + c0);
+#pragma unroll
+    for (int t = 0; t < SS_NT; ++t) {
+      const float y0 = fmaf((R[t][ct][0] - mean[t]) * rstd[t], ga.x, be.x), y1 = fmaf((R[t][ct][1] - mean[t]) * rstd[t], ga.y, be.y);
+      const float y2 = fmaf((R[t][ct][2] - mean[t]) * rstd[t], ga.z, be.z), y3 = fmaf((R[t][ct][3] - mean[t]) * rstd[t], ga.w, be.w);
+      *reinterpret_cast<uint2*>(smem + L_XN + (((T >> 1) * SS_NT + t) * 64 + lane) * 16 + (T & 1) * 8) = make_uint2(pack_bf2(y0, y1), pack_bf2(y2, y3));
+    }
+  }
+  __syncthreads();
+}
+
+// ---- attention of one head for NQ image-query tiles (keys: the 196 image tokens, 13 key tiles) ------------------------------------------
+// Qf: B operands (q scaled by log2 e / sqrt d, bf16); K fragments [head][key tile], V fragments [head][pair slot][d-tile] from the exchange
+// buffers (sc1 loads).  Writes the normalised output as the proj operand fragment (k-step = head) of each query tile.
+template <int NQ>
+__device__ __forceinline__ void attn_image(const bf16x8_t (&Qf)[SS_NT], int h, __amdgpu_buffer_rsrc_t kr, __amdgpu_buffer_rsrc_t vr, unsigned char* smem, int lane) {
+  const int g = lane >> 4;
+  const int kbase = (h * 14 * 64 + lane) * 16, vbase = (h * 16 * 64 + lane) * 16;
+  const f32x4_t z4 = {0.f, 0.f, 0.f, 0.f};
+  float mx[NQ];
+#pragma unroll
+  for (int q = 0; q < NQ; ++q) mx[q] = -INFINITY;
+  u32x4_t kf = __builtin_amdgcn_raw_buffer_load_b128(kr, kbase, 0, 16);
+#pragma unroll 1
+  for (int kt = 0; kt < 13; ++kt) {
+    const u32x4_t kn = __builtin_amdgcn_raw_buffer_load_b128(kr, kbase + min(kt + 1, 12) * 1024, 0, 16);
+    const bool cut = kt == 12 && g != 0;        // key tile 12: only keys 192..195 (rows 0..3 = lane group 0) exist
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+      const f32x4_t s = mfma_bf16(as_bf8(kf), Qf[q], z4);
+      const float m = max4(s);
+      mx[q] = fmaxf(mx[q], cut ? -INFINITY : m);
+    }
+    kf = kn;
+  }
+#pragma unroll
+  for (int q = 0; q < NQ; ++q) mx[q] = xmax4(mx[q]);
+  f32x4_t O[NQ][2];
+  float l[NQ];
+#pragma unroll
+  for (int q = 0; q < NQ; ++q) { O[q][0] = z4; O[q][1] = z4; l[q] = 0.f; }
+#pragma unroll 1
+  for (int s = 0; s < 7; ++s) {
+    // key tiles (ta, tb) of step s and their V pair slot: half-0 pairs (0,1) (2,3) (4,5) (6,-), half-1 pairs (7,8) (9,10) (11,12)
+    const int ta = s < 4 ? 2 * s : 2 * s - 1;
+    const bool dummy = s == 3, cutb = s == 6 && g != 0;
+    const u32x4_t ka = __builtin_amdgcn_raw_buffer_load_b128(kr, kbase + ta * 1024, 0, 16);
+    const u32x4_t kb = __builtin_amdgcn_raw_buffer_load_b128(kr, kbase + (dummy ? ta : ta + 1) * 1024, 0, 16);
+    const u32x4_t v0 = __builtin_amdgcn_raw_buffer_load_b128(vr, vbase + (s * 2 + 0) * 1024, 0, 16);
+    const u32x4_t v1 = __builtin_amdgcn_raw_buffer_load_b128(vr, vbase + (s * 2 + 1) * 1024, 0, 16);
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+      const f32x4_t sa = mfma_bf16(as_bf8(ka), Qf[q], z4), sb = mfma_bf16(as_bf8(kb), Qf[q], z4);
+      const float mb = (dummy || cutb) ? INFINITY : mx[q];      // exp2(s - inf) = 0: absent keys
+      float p[8];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { p[r] = __builtin_amdgcn_exp2f(sa[r] - mx[q]); p[4 + r] = __builtin_amdgcn_exp2f(sb[r] - mb); }
+      l[q] += ((p[0] + p[1]) + (p[2] + p[3])) + ((p[4] + p[5]) + (p[6] + p[7]));
+      const u32x4_t pk = {pack_h2(p[0], p[1]), pack_h2(p[2], p[3]), pack_h2(p[4], p[5]), pack_h2(p[6], p[7])};
+      const f16x8_t pf = __builtin_bit_cast(f16x8_t, pk);
+      O[q][0] = mfma_f16(__builtin_bit_cast(f16x8_t, v0), pf, O[q][0]);
+      O[q][1] = mfma_f16(__builtin_bit_cast(f16x8_t, v1), pf, O[q][1]);
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < NQ; ++q) {
+    const float inv = 1.f / xsum4(l[q]);
+    const u32x4_t o = pack_bf8(O[q][0] * inv, O[q][1] * inv);
+    *reinterpret_cast<u32x4_t*>(smem + L_XN + ((h * SS_NT + q) * 64 + lane) * 16) = o;
+  }
+}
+// the 16 meta queries of half 1 (token tile 6) against the 16 meta keys (key tile 13, V pair slot 7)
+__device__ __forceinline__ void attn_meta(const bf16x8_t& Qf, int h, __amdgpu_buffer_rsrc_t kr, __amdgpu_buffer_rsrc_t vr, unsigned char* smem, int lane) {
+  const int kbase = (h * 14 * 64 + lane) * 16, vbase = (h * 16 * 64 + lane) * 16;
+  const f32x4_t z4 = {0.f, 0.f, 0.f, 0.f};
+  const u32x4_t kf = __builtin_amdgcn_raw_buffer_load_b128(kr, kbase + 13 * 1024, 0, 16);
+  const u32x4_t v0 = __builtin_amdgcn_raw_buffer_load_b128(vr, vbase + 14 * 1024, 0, 16), v1 = __builtin_amdgcn_raw_buffer_load_b128(vr, vbase + 15 * 1024, 0, 16);
+  const f32x4_t s = mfma_bf16(as_bf8(kf), Qf, z4);
+  const float m = xmax4(max4(s));
+  float p[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) p[r] = __builtin_amdgcn_exp2f(s[r] - m);
+  const float inv = 1.f / xsum4((p[0] + p[1]) + (p[2] + p[3]));
+  const u32x4_t pk = {pack_h2(p[0], p[1]), pack_h2(p[2], p[3]), 0u, 0u};
+  const f16x8_t pf = __builtin_bit_cast(f16x8_t, pk);
+  const f32x4_t o0 = mfma_f16(__builtin_bit_cast(f16x8_t, v0), pf, z4), o1 = mfma_f16(__builtin_bit_cast(f16x8_t, v1), pf, z4);
+  *reinterpret_cast<u32x4_t*>(smem + L_XN + ((h * SS_NT + 6) * 64 + lane) * 16) = pack_bf8(o0 * inv, o1 * inv);
+}
+
+__global__ __launch_bounds__(512, 2) void sstage_kernel(const SsArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int g = lane >> 4, li = lane & 15;
+  // the two halves of an image are workgroups b and b + 8: the same XCD under the round-robin dispatch (a speed matter only)
+  const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+  const int img = (idx >> 1) * 8 + xcd, half = idx & 1;
+  if (img >= a.B) return;
+  unsigned* const kvflag_mine = a.flags + img * 2 + half;
+  unsigned* const kvflag_peer = a.flags + img * 2 + (1 - half);
+  unsigned* const haloflag_mine = a.flags + 2 * a.B + img * 2 + half;
+  unsigned* const haloflag_peer = a.flags + 2 * a.B + img * 2 + (1 - half);
+  unsigned* const errflag = a.flags + 4 * a.B;
+  const __amdgpu_buffer_rsrc_t kr = __builtin_amdgcn_make_buffer_rsrc(a.kbuf + (size_t)img * KBUF_IMG, 0, (int)KBUF_IMG, 0x00020000);
+  const __amdgpu_buffer_rsrc_t vr = __builtin_amdgcn_make_buffer_rsrc(a.vbuf + (size_t)img * VBUF_IMG, 0, (int)VBUF_IMG, 0x00020000);
+  const int nimg_slots = half ? 84 : 112;          // slots that are image tokens
+  const int tok0 = half ? 112 : 0;
+
+  // ---- residual rows -> registers (fp32): R[t][ct][r] = token slot 16 t + li, channel 48 wave + 16 ct + 4 g + r ----
+  f32x4_t R[SS_NT][3];
+#pragma unroll
+  for (int t = 0; t < SS_NT; ++t) {
+    const int slot = 16 * t + li;
+    const bf16_t* src = nullptr;
+    if (slot < nimg_slots) src = a.x_in + ((size_t)img * SS_NIMG + tok0 + slot) * SS_C;
+    else if (half && slot >= 96) src = a.c_in + ((size_t)img * SS_M + slot - 96) * SS_C;
+#pragma unroll
+    for (int ct = 0; ct < 3; ++ct) {
+      float f[4] = {0.f, 0.f, 0.f, 0.f};
+      if (src) ld4(src + 48 * wave + 16 * ct + 4 * g, f);
+      R[t][ct] = f32x4_t{f[0], f[1], f[2], f[3]};
+    }
+  }
+
+#pragma unroll 1
+  for (int blk = 0; blk < a.nblocks; ++blk) {
+    const uint4* const wp = a.wpk + (size_t)blk * WS_FRAGS * 64 + lane;
+    const float* const vec = a.vec + (size_t)blk * V_FLOATS;
+
+    // ---- x += dwconv3x3(x) + bias on the 14 x 14 grid (models/lemevit.py:619): the wave's 48 channels of its tokens and of the one grid
+    //      row across the cut go through a wave-private bf16 staging image; taps read bf16, the sum is added to the fp32 residual ----
+    {
+      unsigned char* const stg = smem + wave * STG_WAVE;
+      const int own0 = half ? 14 : 0, halo0 = half ? 0 : 112;
+#pragma unroll
+      for (int t = 0; t < SS_NT; ++t) {
+        const int slot = 16 * t + li;
+        if (slot < nimg_slots) {
+#pragma unroll
+          for (int ct = 0; ct < 3; ++ct)
+            *reinterpret_cast<uint2*>(stg + (own0 + slot) * STG_ROW + 32 * ct + 8 * g) = make_uint2(pack_bf2(R[t][ct][0], R[t][ct][1]), pack_bf2(R[t][ct][2], R[t][ct][3]));
+        }
+      }
+      {
+        const unsigned char* hsrc;
+        if (blk == 0) hsrc = reinterpret_cast<const unsigned char*>(a.x_in + ((size_t)img * SS_NIMG + (half ? 98 : 112)) * SS_C);
+        else { wait_flag(haloflag_peer, (unsigned)blk, errflag, lane); hsrc = a.halo + (size_t)img * HALO_IMG + (size_t)(1 - half) * 14 * SS_C * 2; }
+        const __amdgpu_buffer_rsrc_t hr = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(hsrc), 0, 14 * SS_C * 2, 0x00020000);
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+          const int p = lane + 64 * it;
+          if (p < 84) {
+            const int tok = p / 6, q = p - tok * 6;
+            const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(hr, tok * SS_C * 2 + (48 * wave + 8 * q) * 2, 0, 16);
+            *reinterpret_cast<u32x4_t*>(stg + (halo0 + tok) * STG_ROW + 16 * q) = v;
+          }
+        }
+      }
+#pragma unroll 1
+      for (int ct = 0; ct < 3; ++ct) {
+        const int c0 = 48 * wave + 16 * ct + 4 * g;
+        float wt[36];
+#pragma unroll
+        for (int e = 0; e < 9; ++e) {
+          const float4 v = *reinterpret_cast<const float4*>(vec + V_POSW + c0 * 9 + 4 * e);
+          wt[4 * e] = v.x; wt[4 * e + 1] = v.y; wt[4 * e + 2] = v.z; wt[4 * e + 3] = v.w;
+        }
+        const float4 pb = *reinterpret_cast<const float4*>(vec + V_POSB + c0);
+#pragma unroll
+        for (int t = 0; t < SS_NT; ++t) {
+          const int slot = 16 * t + li;
+          const bool valid = slot < nimg_slots;
+          const int tk = tok0 + slot, y = tk / SS_G, x = tk - y * SS_G;
+          float acc[4] = {pb.x, pb.y, pb.z, pb.w};
+#pragma unroll
+          for (int dy = -1; dy <= 1; ++dy)
+#pragma unroll
+            for (int dx = -1; dx <= 1; ++dx) {
+              const bool ok = valid && (unsigned)(y + dy) < (unsigned)SS_G && (unsigned)(x + dx) < (unsigned)SS_G;
+              const int row = own0 + (ok ? slot + dy * SS_G + dx : (valid ? slot : 0));
+              float f[4];
+              ld4(reinterpret_cast<const bf16_t*>(stg + row * STG_ROW + 32 * ct + 8 * g), f);
+              const int tap = (dy + 1) * 3 + dx + 1;
+#pragma unroll
+              for (int r = 0; r < 4; ++r) acc[r] = fmaf(ok ? wt[r * 9 + tap] : 0.f, f[r], acc[r]);
+            }
+          // R[t][ct] is indexed with the runtime ct of this rolled loop through a select chain (three candidates)
+#pragma unroll
+          for (int cc = 0; cc < 3; ++cc)
+            if (cc == ct && valid) {
+#pragma unroll
+              for (int r = 0; r < 4; ++r) R[t][cc][r] += acc[r];
+            }
+        }
+      }
+    }
+
+    // ---- norm1 -> LDS; k / v projections of this half's tokens -> exchange buffers ----
+    layer_norm_to_lds(R, vec + V_N1W, vec + V_N1B, a.eps, smem, wave, lane);
+    bf16x8_t ring2[4][2];
+    ring_fill<2>(ring2, wp + (size_t)(WS_KV + (3 * wave) * 24) * 64);
+#pragma unroll 1
+    for (int uu = 0; uu < 3; ++uu) {
+      const int u = 3 * wave + uu, h = u >> 1, isv = u & 1;
+      const uint4* wcur = wp + (size_t)(WS_KV + u * 24) * 64;
+      const uint4* wnext = uu < 2 ? wcur + 24 * 64 : wp + (size_t)(WS_Q + wave * 24) * 64;
+      f32x4_t acc[SS_NT][2];
+#pragma unroll
+      for (int t = 0; t < SS_NT; ++t) { acc[t][0] = f32x4_t{0.f, 0.f, 0.f, 0.f}; acc[t][1] = acc[t][0]; }
+      if (!isv) {
+        gemm_unit<2, SS_KS, true>(acc, ring2, wcur, wnext, smem + L_XN, lane);
+        const float* bk = vec + V_QKVB + SS_C + 32 * h + 4 * g;
+        const float4 b0 = *reinterpret_cast<const float4*>(bk), b1 = *reinterpret_cast<const float4*>(bk + 16);
+#pragma unroll
+        for (int t = 0; t < SS_NT; ++t) {
+          const int kt = half ? (t < 6 ? 7 + t : 13) : t;
+          const f32x4_t k0 = {acc[t][0][0] + b0.x, acc[t][0][1] + b0.y, acc[t][0][2] + b0.z, acc[t][0][3] + b0.w};
+          const f32x4_t k1 = {acc[t][1][0] + b1.x, acc[t][1][1] + b1.y, acc[t][1][2] + b1.z, acc[t][1][3] + b1.w};
+          __builtin_amdgcn_raw_buffer_store_b128(pack_bf8(k0, k1), kr, ((h * 14 + kt) * 64 + lane) * 16, 0, 16);
+        }
+      } else {
+        gemm_unit<2, SS_KS, false>(acc, ring2, wcur, wnext, smem + L_XN, lane);
+        const float bv0 = vec[V_QKVB + 2 * SS_C + 32 * h + li], bv1 = vec[V_QKVB + 2 * SS_C + 32 * h + 16 + li];
+#pragma unroll
+        for (int p = 0; p < 4; ++p)
+#pragma unroll
+          for (int dt = 0; dt < 2; ++dt) {
+            const float bv = dt ? bv1 : bv0;
+            const f32x4_t lo = acc[2 * p][dt] + bv;
+            u32x4_t pk = {pack_h2(lo[0], lo[1]), pack_h2(lo[2], lo[3]), 0u, 0u};
+            if (p < 3) { const f32x4_t hi = acc[2 * p + 1][dt] + bv; pk[2] = pack_h2(hi[0], hi[1]); pk[3] = pack_h2(hi[2], hi[3]); }
+            __builtin_amdgcn_raw_buffer_store_b128(pk, vr, ((h * 16 + (half * 4 + p) * 2 + dt) * 64 + lane) * 16, 0, 16);
+          }
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // every storing wave drains (R1), then one lane raises the flag
+    __syncthreads();
+    if (tid == 0) __hip_atomic_store((gu32*)kvflag_mine, (unsigned)(blk + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+
+    // ---- q projections of the wave's heads (head `wave`, and head 8 + wave on waves 0..3) ----
+    const int nheads = wave < 4 ? 2 : 1;
+    bf16x8_t Qf[SS_NT];      // (ring2 already holds the first k-steps of head `wave`: the tail of the last k / v unit fetched them)
+#pragma unroll 1
+    for (int hu = 0; hu < nheads; ++hu) {
+      const int h = wave + 8 * hu;
+      const uint4* wcur = wp + (size_t)(WS_Q + h * 24) * 64;
+      const uint4* wnext = hu + 1 < nheads ? wp + (size_t)(WS_Q + (h + 8) * 24) * 64 : wcur;
+      f32x4_t acc[SS_NT][2];
+#pragma unroll
+      for (int t = 0; t < SS_NT; ++t) { acc[t][0] = f32x4_t{0.f, 0.f, 0.f, 0.f}; acc[t][1] = acc[t][0]; }
+      gemm_unit<2, SS_KS, true>(acc, ring2, wcur, wnext, smem + L_XN, lane);
+      const float* bq = vec + V_QKVB + 32 * h + 4 * g;
+      const float4 b0 = *reinterpret_cast<const float4*>(bq), b1 = *reinterpret_cast<const float4*>(bq + 16);
+      constexpr float QS = 0.25503486f;      // log2(e) / sqrt(32): softmax(q k^T / sqrt d) as exp2 of the scores (models/lemevit.py:203)
+#pragma unroll
+      for (int t = 0; t < SS_NT; ++t) {
+        const f32x4_t q0 = {(acc[t][0][0] + b0.x) * QS, (acc[t][0][1] + b0.y) * QS, (acc[t][0][2] + b0.z) * QS, (acc[t][0][3] + b0.w) * QS};
+        const f32x4_t q1 = {(acc[t][1][0] + b1.x) * QS, (acc[t][1][1] + b1.y) * QS, (acc[t][1][2] + b1.z) * QS, (acc[t][1][3] + b1.w) * QS};
+        const u32x4_t qf = pack_bf8(q0, q1);
+        if (hu == 0) Qf[t] = as_bf8(qf);
+        else *reinterpret_cast<u32x4_t*>(smem + L_H + ((wave * SS_NT + t) * 64 + lane) * 16) = qf;
+      }
+    }
+    if (wave == 0) wait_flag(kvflag_peer, (unsigned)(blk + 1), errflag, lane);
+    __syncthreads();          // every q projection has read the LayerNorm output: the attention output may overwrite it; the peer's K / V are published
+
+    // ---- attention of the wave's heads -> proj operand in LDS ----
+#pragma unroll 1
+    for (int hu = 0; hu < nheads; ++hu) {
+      const int h = wave + 8 * hu;
+      if (hu == 1) {
+#pragma unroll
+        for (int t = 0; t < SS_NT; ++t) Qf[t] = *reinterpret_cast<const bf16x8_t*>(smem + L_H + ((wave * SS_NT + t) * 64 + lane) * 16);
+      }
+      if (half == 0) attn_image<7>(Qf, h, kr, vr, smem, lane);
+      else { attn_image<6>(Qf, h, kr, vr, smem, lane); attn_meta(Qf[6], h, kr, vr, smem, lane); }
+    }
+    __syncthreads();
+
+    // ---- x += proj(attention) + bias: accumulated ON the residual registers ----
+    {
+#pragma unroll
+      for (int ct = 0; ct < 3; ++ct) {
+        const float4 b = *reinterpret_cast<const float4*>(vec + V_PROJB + 48 * wave + 16 * ct + 4 * g);
+#pragma unroll
+        for (int t = 0; t < SS_NT; ++t) { R[t][ct][0] += b.x; R[t][ct][1] += b.y; R[t][ct][2] += b.z; R[t][ct][3] += b.w; }
+      }
+      bf16x8_t ring3[4][3];
+      const uint4* wcur = wp + (size_t)(WS_PROJ + wave * 36) * 64;
+      ring_fill<3>(ring3, wcur);
+      gemm_unit<3, SS_KS, true>(R, ring3, wcur, wcur, smem + L_XN, lane);
+    }
+
+    // ---- norm2 -> LDS; MLP in 6 chunks of 256 hidden channels; fc2 accumulates on the residual registers ----
+    layer_norm_to_lds(R, vec + V_N2W, vec + V_N2B, a.eps, smem, wave, lane);
+#pragma unroll
+    for (int ct = 0; ct < 3; ++ct) {
+      const float4 b = *reinterpret_cast<const float4*>(vec + V_FC2B + 48 * wave + 16 * ct + 4 * g);
+#pragma unroll
+      for (int t = 0; t < SS_NT; ++t) { R[t][ct][0] += b.x; R[t][ct][1] += b.y; R[t][ct][2] += b.z; R[t][ct][3] += b.w; }
+    }
+#pragma unroll 1
+    for (int c = 0; c < SS_NCHUNK; ++c) {
+      {
+        f32x4_t acc[SS_NT][2];
+#pragma unroll
+        for (int t = 0; t < SS_NT; ++t) { acc[t][0] = f32x4_t{0.f, 0.f, 0.f, 0.f}; acc[t][1] = acc[t][0]; }
+        const uint4* wcur = wp + (size_t)(WS_FC1 + (c * 8 + wave) * 24) * 64;
+        ring_fill<2>(ring2, wcur);
+        gemm_unit<2, SS_KS, true>(acc, ring2, wcur, wcur, smem + L_XN, lane);
+        const float* b1p = vec + V_FC1B + 256 * c + 32 * wave + 4 * g;
+        const float4 b0 = *reinterpret_cast<const float4*>(b1p), b1 = *reinterpret_cast<const float4*>(b1p + 16);
+#pragma unroll
+        for (int t = 0; t < SS_NT; ++t) {
+          const f32x2_t h0 = gelu_poly2(f32x2_t{acc[t][0][0] + b0.x, acc[t][0][1] + b0.y}), h1 = gelu_poly2(f32x2_t{acc[t][0][2] + b0.z, acc[t][0][3] + b0.w});
+          const f32x2_t h2 = gelu_poly2(f32x2_t{acc[t][1][0] + b1.x, acc[t][1][1] + b1.y}), h3 = gelu_poly2(f32x2_t{acc[t][1][2] + b1.z, acc[t][1][3] + b1.w});
+          const u32x4_t hf = {pack_bf2(h0[0], h0[1]), pack_bf2(h1[0], h1[1]), pack_bf2(h2[0], h2[1]), pack_bf2(h3[0], h3[1])};
+          *reinterpret_cast<u32x4_t*>(smem + L_H + ((wave * SS_NT + t) * 64 + lane) * 16) = hf;
+        }
+      }
+      __syncthreads();
+      {
+        bf16x8_t ring3[4][3];
+        const uint4* wcur = wp + (size_t)(WS_FC2 + (c * 8 + wave) * 24) * 64;
+        ring_fill<3>(ring3, wcur);
+        gemm_unit<3, SS_KSC, true>(R, ring3, wcur, wcur, smem + L_H, lane);
+      }
+      if (c + 1 < SS_NCHUNK) __syncthreads();
+    }
+
+    // ---- block end: pad slots stay zero; the grid row next to the cut goes to the peer (next block's position embedding) ----
+    if (half) {
+#pragma unroll
+      for (int ct = 0; ct < 3; ++ct)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) R[5][ct][r] = li >= 4 ? 0.f : R[5][ct][r];
+    }
+    if (blk + 1 < a.nblocks) {
+      const int tok = half ? li : li - 2;
+      if ((unsigned)tok < 14u) {
+        bf16_t* dst = reinterpret_cast<bf16_t*>(a.halo + (size_t)img * HALO_IMG) + ((size_t)half * 14 + tok) * SS_C + 48 * wave + 4 * g;
+#pragma unroll
+        for (int ct = 0; ct < 3; ++ct) {
+          const f32x4_t v = half ? R[0][ct] : R[6][ct];
+          const unsigned long long pk = (unsigned long long)pack_bf2(v[0], v[1]) | ((unsigned long long)pack_bf2(v[2], v[3]) << 32);
+          __hip_atomic_store((gu64*)(dst + 16 * ct), pk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __syncthreads();
+    if (blk + 1 < a.nblocks && tid == 0) __hip_atomic_store((gu32*)haloflag_mine, (unsigned)(blk + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+
+  // ---- registers -> x_out / c_out ----
+#pragma unroll
+  for (int t = 0; t < SS_NT; ++t) {
+    const int slot = 16 * t + li;
+    bf16_t* dst = nullptr;
+    if (slot < nimg_slots) dst = a.x_out + ((size_t)img * SS_NIMG + tok0 + slot) * SS_C;
+    else if (half && slot >= 96) dst = a.c_out + ((size_t)img * SS_M + slot - 96) * SS_C;
+    if (dst) {
+#pragma unroll
+      for (int ct = 0; ct < 3; ++ct) {
+        const float f[4] = {R[t][ct][0], R[t][ct][1], R[t][ct][2], R[t][ct][3]};
+        st4(dst + 48 * wave + 16 * ct + 4 * g, f);
+      }
+    }
+  }
+}
+
+// ---- packing: reference layouts -> fragment order ------------------------------------------------------------------------------
+struct PackArgs { const bf16_t* qkv_w; const bf16_t* proj_w; const bf16_t* fc1_w; const bf16_t* fc2_w; uint4* out; };
+
+// (source matrix, first row, k-step, row stride) of fragment f
+__device__ __forceinline__ void frag_source(int f, const PackArgs& a, const bf16_t*& base, int& row0, int& ks, int& ld) {
+  if (f < WS_Q) { const int u = f / 24, r = f - u * 24; ks = r >> 1; base = a.qkv_w; ld = SS_C; row0 = (1 + (u & 1)) * SS_C + 32 * (u >> 1) + 16 * (r & 1); }
+  else if (f < WS_PROJ) { const int q = f - WS_Q, h = q / 24, r = q - h * 24; ks = r >> 1; base = a.qkv_w; ld = SS_C; row0 = 32 * h + 16 * (r & 1); }
+  else if (f < WS_FC1) { const int q = f - WS_PROJ, w = q / 36, r = q - w * 36; ks = r / 3; base = a.proj_w; ld = SS_C; row0 = 48 * w + 16 * (r - ks * 3); }
+  else if (f < WS_FC2) { const int q = f - WS_FC1, cw = q / 24, r = q - cw * 24; ks = r >> 1; base = a.fc1_w; ld = SS_C; row0 = 256 * (cw >> 3) + 32 * (cw & 7) + 16 * (r & 1); }
+  else { const int q = f - WS_FC2, cw = q / 24, r = q - cw * 24, ksl = r / 3; ks = 8 * (cw >> 3) + ksl; base = a.fc2_w; ld = SS_HID; row0 = 48 * (cw & 7) + 16 * (r - ksl * 3); }
+}
+__global__ __launch_bounds__(256) void sstage_pack_kernel(const PackArgs a) {
+  const int f = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63, g = lane >> 4, i = lane & 15;
+  if (f >= WS_FRAGS) return;
+  const bf16_t* base; int row0, ks, ld;
+  frag_source(f, a, base, row0, ks, ld);
+  const bf16_t* src = base + (size_t)(row0 + i) * ld + 32 * ks + 4 * g;
+  const uint2 lo = *reinterpret_cast<const uint2*>(src), hi = *reinterpret_cast<const uint2*>(src + 16);
+  a.out[(size_t)f * 64 + lane] = make_uint4(lo.x, lo.y, hi.x, hi.y);
+}
+
+}  // namespace
+
+// ---- C ABI --------------------------------------------------------------------------------------------------------------------
+int lmv_sstage_supported(int C, int heads, int hidden, int H, int W, int M, int dtype) {
+  return dtype == LMV_BF16 && C == SS_C && heads == SS_NH && hidden == SS_HID && H == SS_G && W == SS_G && M == SS_M;
+}
+size_t lmv_sstage_wpk_bytes(int C, int hidden) { (void)C; (void)hidden; return (size_t)WS_FRAGS * 1024; }
+size_t lmv_sstage_vec_floats(int C, int hidden) { (void)C; (void)hidden; return (size_t)V_FLOATS; }
+size_t lmv_sstage_workspace_bytes(int B) {
+  const size_t flags = ((size_t)(4 * B + 1) * 4 + 1023) & ~(size_t)1023;
+  return flags + (size_t)B * (KBUF_IMG + VBUF_IMG + HALO_IMG);
+}
+
+int lmv_sstage_pack(const lmv_sstage_block_params* p, void* wpk_out, float* vec_out, void* stream) {
+  if (!p || !wpk_out || !vec_out) LMV_FAIL(LMV_ERR_SHAPE, "sstage_pack: null argument");
+  if (!lmv_sstage_supported(p->C, p->heads, p->hidden, SS_G, SS_G, SS_M, LMV_BF16)) LMV_FAIL(LMV_ERR_DTYPE, "sstage_pack: C = %d / heads = %d / hidden = %d is not a supported stage", p->C, p->heads, p->hidden);
+  const void* ptrs[] = {p->qkv_w, p->proj_w, p->fc1_w, p->fc2_w, p->n1_w, p->n1_b, p->qkv_b, p->proj_b, p->n2_w, p->n2_b, p->fc1_b, p->fc2_b, p->pos_w, p->pos_b};
+  for (const void* q : ptrs) if (!q || !lmv_aligned16(q)) LMV_FAIL(LMV_ERR_SHAPE, "sstage_pack: null or misaligned parameter pointer");
+  if (!lmv_aligned16(wpk_out) || !lmv_aligned16(vec_out)) LMV_FAIL(LMV_ERR_SHAPE, "sstage_pack: misaligned output");
+  hipStream_t st = (hipStream_t)stream;
+  PackArgs a{(const bf16_t*)p->qkv_w, (const bf16_t*)p->proj_w, (const bf16_t*)p->fc1_w, (const bf16_t*)p->fc2_w, (uint4*)wpk_out};
+  hipLaunchKernelGGL(sstage_pack_kernel, dim3(WS_FRAGS / 4), dim3(256), 0, st, a);
+  LMV_CHECK_LAUNCH("sstage_pack");
+  const struct { const float* src; int off, n; } v[] = {{p->n1_w, V_N1W, 384}, {p->n1_b, V_N1B, 384}, {p->qkv_b, V_QKVB, 1152}, {p->proj_b, V_PROJB, 384}, {p->n2_w, V_N2W, 384},
+                                                        {p->n2_b, V_N2B, 384}, {p->fc1_b, V_FC1B, 1536}, {p->fc2_b, V_FC2B, 384}, {p->pos_w, V_POSW, 3456}, {p->pos_b, V_POSB, 384}};
+  for (const auto& e : v)
+    if (hipMemcpyAsync(vec_out + e.off, e.src, (size_t)e.n * sizeof(float), hipMemcpyDeviceToDevice, st) != hipSuccess) LMV_FAIL(LMV_ERR_LAUNCH, "sstage_pack: vector copy failed");
+  return LMV_OK;
+}
+
+int lmv_sstage_fwd(const lmv_sstage_desc* d, const void* x, const void* c, void* x_out, void* c_out, void* workspace, size_t workspace_bytes, void* stream) {
+  if (!d || !x || !c || !x_out || !c_out || !workspace) LMV_FAIL(LMV_ERR_SHAPE, "sstage_fwd: null argument");
+  if (!lmv_sstage_supported(d->C, d->heads, d->hidden, d->H, d->W, d->M, d->dtype)) LMV_FAIL(LMV_ERR_DTYPE, "sstage_fwd: unsupported stage shape / dtype");
+  if (d->B <= 0 || d->nblocks <= 0 || !d->wpk || !d->vec) LMV_FAIL(LMV_ERR_SHAPE, "sstage_fwd: bad descriptor");
+  const void* ptrs[] = {x, c, x_out, c_out, workspace, d->wpk, d->vec};
+  for (const void* q : ptrs) if (!lmv_aligned16(q)) LMV_FAIL(LMV_ERR_SHAPE, "sstage_fwd: pointers must be 16-byte aligned");
+  hipStream_t st = (hipStream_t)stream;
+  static std::atomic<unsigned long long> attr_done{0};
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  const unsigned long long bit = 1ull << (dev & 63);
+  if (!(attr_done.load(std::memory_order_acquire) & bit)) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(sstage_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, L_TOTAL) != hipSuccess) LMV_FAIL(LMV_ERR_LAUNCH, "sstage_fwd: cannot reserve LDS");
+    attr_done.fetch_or(bit, std::memory_order_release);
+  }
+  // Both halves of an image must be resident at the same time (they wait for each other): at most 128 images (256 workgroups, one per CU)
+  // per launch; a larger batch runs as consecutive launches over ranges of images.
+  constexpr int MAXB = 128;
+  for (int b0 = 0; b0 < d->B; b0 += MAXB) {
+    const int nb = d->B - b0 < MAXB ? d->B - b0 : MAXB;
+    if (workspace_bytes < lmv_sstage_workspace_bytes(nb)) LMV_FAIL(LMV_ERR_WORKSPACE, "sstage_fwd: workspace too small");
+    const size_t flags = ((size_t)(4 * nb + 1) * 4 + 1023) & ~(size_t)1023;
+    unsigned char* ws = (unsigned char*)workspace;
+    if (hipMemsetAsync(ws, 0, flags, st) != hipSuccess) LMV_FAIL(LMV_ERR_LAUNCH, "sstage_fwd: flag reset failed");      // every polled word, every call (Guideline 16)
+    SsArgs a{};
+    a.x_in = (const bf16_t*)x + (size_t)b0 * SS_NIMG * SS_C; a.c_in = (const bf16_t*)c + (size_t)b0 * SS_M * SS_C;
+    a.x_out = (bf16_t*)x_out + (size_t)b0 * SS_NIMG * SS_C; a.c_out = (bf16_t*)c_out + (size_t)b0 * SS_M * SS_C;
+    a.wpk = (const uint4*)d->wpk; a.vec = d->vec;
+    a.flags = (unsigned*)ws; a.kbuf = ws + flags; a.vbuf = a.kbuf + (size_t)nb * KBUF_IMG; a.halo = a.vbuf + (size_t)nb * VBUF_IMG;
+    a.B = nb; a.nblocks = d->nblocks; a.eps = d->eps;
+    const int nwg = 2 * ((nb + 7) / 8) * 8;
+    hipLaunchKernelGGL(sstage_kernel, dim3(nwg), dim3(512), L_TOTAL, st, a);
+    LMV_CHECK_LAUNCH("sstage_fwd");
+  }
+  return LMV_OK;
+}

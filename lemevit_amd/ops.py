@@ -602,3 +602,60 @@ def adamw_flat(param: Tensor, grad: Tensor, exp_avg: Tensor, exp_avg_sq: Tensor,
         raise TypeError("adamw_flat: step_dev must be an int32 device scalar")
     check(lib.lmv_adamw_flat(_f32(param), _f32(grad), _f32(exp_avg), _f32(exp_avg_sq), _f32(wd_mask), _ptr(shadow), param.numel(), lr, beta1, beta2, eps,
                              weight_decay, step, _ptr(step_dev), _stream()), "lmv_adamw_flat")
+
+
+# -------------------------------------------------------------------------------------------
+# A run of "S" blocks as one persistent launch (csrc/sstage.hip; inference, bf16)
+# -------------------------------------------------------------------------------------------
+def sstage_supported(C_: int, heads: int, hidden: int, H: int, W: int, M: int, dtype: torch.dtype) -> bool:
+    if dtype != torch.bfloat16:
+        return False
+    return bool(lib.lmv_sstage_supported(C_, heads, hidden, H, W, M, _lib.LMV_BF16))
+
+
+class SStagePacked:
+    """The parameters of `nblocks` consecutive S blocks in the layout lmv_sstage_fwd reads (lmv_sstage_pack)."""
+    __slots__ = ("wpk", "vec", "nblocks", "C", "heads", "hidden")
+
+
+SSTAGE_NAMES = ("attn.qkv.weight", "attn.proj.weight", "mlp.0.weight", "mlp.3.weight", "norm1.weight", "norm1.bias", "attn.qkv.bias", "attn.proj.bias",
+                "norm2.weight", "norm2.bias", "mlp.0.bias", "mlp.3.bias", "pos_embed.weight", "pos_embed.bias")
+
+
+def sstage_pack(blocks: Sequence[dict], heads: int) -> SStagePacked:
+    """blocks: per block a dict name -> tensor (SSTAGE_NAMES; matrices bf16, vectors fp32, reference layouts, on the GPU)."""
+    w0 = blocks[0]["attn.qkv.weight"]
+    C_ = w0.shape[1]
+    hidden = blocks[0]["mlp.0.weight"].shape[0]
+    wb, vf = int(lib.lmv_sstage_wpk_bytes(C_, hidden)), int(lib.lmv_sstage_vec_floats(C_, hidden))
+    P = SStagePacked()
+    P.nblocks, P.C, P.heads, P.hidden = len(blocks), C_, heads, hidden
+    P.wpk = torch.empty(len(blocks) * wb, device=w0.device, dtype=torch.uint8)
+    P.vec = torch.empty(len(blocks) * vf, device=w0.device, dtype=torch.float32)
+    keep = []
+    for j, blk in enumerate(blocks):
+        bp = _lib.SStageBlockParams()
+        bp.C, bp.heads, bp.hidden = C_, heads, hidden
+        for field, name in zip(("qkv_w", "proj_w", "fc1_w", "fc2_w"), SSTAGE_NAMES[:4]):
+            t = blk[name]
+            if t.dtype != torch.bfloat16:
+                raise TypeError("lemevit_amd: sstage_pack takes bf16 matrices")
+            t = t.contiguous(); keep.append(t)
+            setattr(bp, field, _ptr(t))
+        for field, name in zip(("n1_w", "n1_b", "qkv_b", "proj_b", "n2_w", "n2_b", "fc1_b", "fc2_b", "pos_w", "pos_b"), SSTAGE_NAMES[4:]):
+            t = blk[name].detach().float().contiguous(); keep.append(t)
+            setattr(bp, field, _ptr(t))
+        check(lib.lmv_sstage_pack(C.byref(bp), P.wpk.data_ptr() + j * wb, P.vec.data_ptr() + j * vf * 4, _stream()), "lmv_sstage_pack")
+    return P
+
+
+def sstage_fwd(x: Tensor, c: Tensor, P: SStagePacked, H: int, W: int, eps: float) -> Tuple[Tensor, Tensor]:
+    B, N, C_ = x.shape
+    d = _lib.SStageDesc()
+    d.B, d.H, d.W, d.M, d.C, d.heads, d.hidden, d.nblocks, d.dtype, d.eps = B, H, W, c.shape[1], C_, P.heads, P.hidden, P.nblocks, dtype_code(x), eps
+    d.wpk, d.vec = P.wpk.data_ptr(), P.vec.data_ptr()
+    xo, co = torch.empty_like(x), torch.empty_like(c)
+    nbytes = int(lib.lmv_sstage_workspace_bytes(min(B, 128)))
+    ws = _workspace(nbytes, x.device)
+    check(lib.lmv_sstage_fwd(C.byref(d), _ptr(x), _ptr(c), _ptr(xo), _ptr(co), ws.data_ptr(), ws.numel(), _stream()), "lmv_sstage_fwd")
+    return xo, co

@@ -1,0 +1,109 @@
+"""csrc/sstage.hip (lmv_sstage_fwd): a run of "S" blocks as ONE persistent launch, against the pinned CPU oracle (float64,
+LeMeBlock.forward_with_x, models/lemevit.py:615-650) on the bf16-rounded operands the kernel reads, against the per-launch schedule
+of the same library, and for run-to-run bit-equality (the two halves of an image exchange K / V fragments and grid rows through L2 inside
+the launch: a hand-off race shows as a run-to-run difference under load)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from detfill import det_tensor, fill_state_dict
+from oracle import lemevit_oracle as O
+from test_oracle_golden import block_spec
+
+DEV = "cuda:0"
+C, HEADS, HID, G, M = 384, 12, 1536, 14, 16
+
+
+def _stage_params(nblocks, seed):
+    """fp32 state dicts of `nblocks` S blocks with bf16-representable matrices (the kernel's operands), vectors fp32."""
+    sds = []
+    for j in range(nblocks):
+        sd = fill_state_dict(block_spec("S", C), seed + 17 * j)
+        for k, v in sd.items():
+            if v.dim() >= 2 and "pos_embed" not in k:
+                sd[k] = v.to(torch.bfloat16).float()
+        sds.append(sd)
+    return sds
+
+
+def _pack(sds):
+    from lemevit_amd import ops
+    blocks = []
+    for sd in sds:
+        d = {}
+        for name in ops.SSTAGE_NAMES:
+            t = sd["blk." + name].to(DEV)
+            if name == "pos_embed.weight":
+                t = t.reshape(C, 9)
+            d[name] = t.to(torch.bfloat16) if (t.dim() >= 2 and "pos_embed" not in name) else t.float()
+        blocks.append(d)
+    return ops.sstage_pack(blocks, HEADS)
+
+
+def _oracle(sds, x, c):
+    x, c = x.double(), c.double()
+    for sd in sds:
+        sdd = {k: v.double() for k, v in sd.items()}
+        x, c = O.leme_block(sdd, "blk.", "S", x, c, G, G, HEADS)
+    return x, c
+
+
+def _inputs(B, seed, scale=1.0):
+    x = det_tensor((B, G * G, C), "sstage.x", seed, scale).to(torch.bfloat16)
+    c = det_tensor((B, M, C), "sstage.c", seed, scale).to(torch.bfloat16)
+    return x, c
+
+
+def _rel(a, ref):
+    a = a.detach().double().cpu().numpy(); ref = ref.detach().double().cpu().numpy()
+    assert np.isfinite(a).all()
+    return float(np.abs(a - ref).max() / max(np.abs(ref).max(), 1e-30))
+
+
+@pytest.mark.parametrize("nblocks,B", [(1, 1), (1, 3), (2, 2), (3, 9)])
+def test_sstage_vs_oracle(nblocks, B):
+    """Full tensors against the float64 oracle.  One block: 1e-2 of max-abs (bf16 operands at five contractions, fp16 P / V, the GELU
+    polynomial; the per-launch bf16 schedule is held to 2e-2 by tests/test_model_gpu.py::test_block_forward); the residual stream stays
+    fp32 between blocks here, so the bound does not grow with the depth the way a bf16 stream's does."""
+    from lemevit_amd import ops
+    sds = _stage_params(nblocks, 5)
+    P = _pack(sds)
+    x, c = _inputs(B, 3)
+    xo, co = ops.sstage_fwd(x.to(DEV), c.to(DEV), P, G, G, 1e-6)
+    torch.cuda.synchronize()
+    xr, cr = _oracle(sds, x.float(), c.float())
+    ex, ec = _rel(xo.float(), xr), _rel(co.float(), cr)
+    print(f"sstage nblocks={nblocks} B={B}: x {ex:.2e} c {ec:.2e}")
+    assert ex <= 1e-2 and ec <= 1e-2, (ex, ec)
+
+
+def test_sstage_vs_per_launch_schedule_full_size():
+    """B = 128, 18 blocks (stage 3 of LeMeViT-Base at config 3) against 18 x the per-launch inference schedule (lmv_block_fwd) of the same
+    weights: both are bf16 pipelines of the same math, so they agree to a few bf16 roundings of the residual stream; and two runs of the
+    persistent launch agree bit for bit."""
+    import lemevit_amd.model as Mm
+    from lemevit_amd import ops
+    from lemevit_amd.blocks import PARAM_NAMES
+    nblocks, B = 18, 128
+    sds = _stage_params(nblocks, 9)
+    P = _pack(sds)
+    x, c = _inputs(B, 4)
+    x, c = x.to(DEV), c.to(DEV)
+    xo, co = ops.sstage_fwd(x, c, P, G, G, 1e-6)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    xo2, co2 = ops.sstage_fwd(x, c, P, G, G, 1e-6)
+    e1.record()
+    torch.cuda.synchronize()
+    print(f"sstage 18 blocks, B = 128: {e0.elapsed_time(e1):.3f} ms")
+    assert torch.equal(xo, xo2) and torch.equal(co, co2)
+    xr, cr = x, c
+    with torch.no_grad():
+        for sd in sds:
+            params = {n: sd["blk." + n].to(DEV) for n in PARAM_NAMES["S"]}
+            xr, cr = Mm.run_block("S", xr, cr, G, G, params, (None,) * 4)
+    ex, ec = _rel(xo.float(), xr.float()), _rel(co.float(), cr.float())
+    print(f"sstage vs per-launch schedule, 18 blocks, B = 128: x {ex:.2e} c {ec:.2e}")
+    assert ex <= 3e-2 and ec <= 3e-2, (ex, ec)

@@ -1,0 +1,98 @@
+// Crux probe for csrc/sstage.hip (round 4): can a workgroup that owns 112 token rows run the GEMMs of a stage-3 "S" block with
+//   * the token operand resident in LDS in MFMA-fragment order (1 KB per [k-step][token tile], lane-linear ds_read_b128), shared by 8 waves,
+//   * every wave owning a slice of OUTPUT channels and pulling its weight fragments STRAIGHT from L2 into registers (weights pre-packed in
+//     fragment order: one fully coalesced 1 KB global_load_dwordx4 per fragment, no LDS, no barrier inside a GEMM),
+// at a useful fraction of the MFMA rate?  256 workgroups (one per CU) walk the same 18 x 3.54 MB of packed weights, as the 256 half-images
+// of a batch of 128 would.  Prints ms per "stage" (18 blocks) and TFLOP/s.
+// usage: sstage_probe <NC: out tiles per unit 2|3|4> <RING: 3|4|6> <barrier every N units, 0 = never> <wgs> <reps>
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+
+constexpr int NT = 7;               // token tiles of 16 per workgroup
+constexpr int KS = 12;              // k-steps of 32 (K = 384)
+constexpr int TILE_UNITS = 36;      // (out tile x 12 k-steps) per wave and block: 9 qkv + 3 proj + 12 fc1 + 12 fc2-equivalents
+constexpr int FRAGS_PER_WAVE_BLOCK = TILE_UNITS * KS;   // 432 KB of weights per wave and block
+
+template <int NC, int RING>
+__global__ __launch_bounds__(512, 1) void probe(const uint4* __restrict__ w, const uint4* __restrict__ xsrc, float* sink, int nblocks, int bar_every) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  uint4* xs = reinterpret_cast<uint4*>(smem);
+  for (int i = tid; i < KS * NT * 64; i += 512) xs[i] = xsrc[i];
+  __syncthreads();
+  constexpr int UNITS = TILE_UNITS / NC;
+  float keep = 0.f;
+  for (int blk = 0; blk < nblocks; ++blk) {
+    const uint4* wb = w + ((size_t)(blk * 8 + wave) * FRAGS_PER_WAVE_BLOCK) * 64 + lane;
+    const int nsteps = UNITS * KS;
+    bf16x8_t ring[RING][NC];
+#pragma unroll
+    for (int s = 0; s < RING - 1; ++s)
+#pragma unroll
+      for (int n = 0; n < NC; ++n) ring[s][n] = __builtin_bit_cast(bf16x8_t, wb[(size_t)(s * NC + n) * 64]);
+    for (int u = 0; u < UNITS; ++u) {
+      f32x4_t acc[NT][NC];
+#pragma unroll
+      for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int n = 0; n < NC; ++n) acc[t][n] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        const int s = u * KS + ks;
+        {
+          const int sp = min(s + RING - 1, nsteps - 1);
+#pragma unroll
+          for (int n = 0; n < NC; ++n) ring[(ks + RING - 1) % RING][n] = __builtin_bit_cast(bf16x8_t, wb[(size_t)(sp * NC + n) * 64]);
+        }
+        bf16x8_t xf[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) xf[t] = __builtin_bit_cast(bf16x8_t, xs[(ks * NT + t) * 64 + lane]);
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+          for (int n = 0; n < NC; ++n) acc[t][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ring[ks % RING][n], xf[t], acc[t][n], 0, 0, 0);
+      }
+#pragma unroll
+      for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int n = 0; n < NC; ++n) keep += acc[t][n][0] + acc[t][n][3];
+      if (bar_every > 0 && (u % bar_every) == bar_every - 1) __syncthreads();
+    }
+  }
+  if (keep == 1.2345f) sink[0] = keep;
+}
+
+template <int NC, int RING>
+static void run(const uint4* w, const uint4* x, float* sink, int nblocks, int bar, int wgs, int reps) {
+  const int lds = KS * NT * 1024;
+  hipFuncSetAttribute(reinterpret_cast<const void*>(probe<NC, RING>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+  for (int i = 0; i < 2; ++i) hipLaunchKernelGGL((probe<NC, RING>), dim3(wgs), dim3(512), lds, 0, w, x, sink, nblocks, bar);
+  hipEventRecord(e0);
+  for (int i = 0; i < reps; ++i) hipLaunchKernelGGL((probe<NC, RING>), dim3(wgs), dim3(512), lds, 0, w, x, sink, nblocks, bar);
+  hipEventRecord(e1); hipEventSynchronize(e1);
+  float ms; hipEventElapsedTime(&ms, e0, e1); ms /= reps;
+  const double flop = (double)wgs * nblocks * 8 * TILE_UNITS * KS * NT * 16384.0;
+  printf("NC=%d RING=%d bar=%d wgs=%d blocks=%d: %.3f ms  %.0f TFLOP/s  (weights %.1f GB/s per CU, %.2f TB/s chip)\n", NC, RING, bar, wgs, nblocks, ms, flop / ms * 1e-9,
+         8.0 * FRAGS_PER_WAVE_BLOCK * 1024 * nblocks / ms * 1e-6, (double)wgs * 8 * FRAGS_PER_WAVE_BLOCK * 1024 * nblocks / ms * 1e-9);
+}
+
+int main(int argc, char** argv) {
+  const int nc = argc > 1 ? atoi(argv[1]) : 3, ring = argc > 2 ? atoi(argv[2]) : 3, bar = argc > 3 ? atoi(argv[3]) : 0;
+  const int wgs = argc > 4 ? atoi(argv[4]) : 256, reps = argc > 5 ? atoi(argv[5]) : 5, nblocks = 18;
+  const size_t wbytes = (size_t)nblocks * 8 * FRAGS_PER_WAVE_BLOCK * 1024, xbytes = (size_t)KS * NT * 1024;
+  uint4 *w, *x; float* sink;
+  hipMalloc(&w, wbytes); hipMalloc(&x, xbytes); hipMalloc(&sink, 4);
+  std::vector<unsigned short> h(wbytes / 2);
+  unsigned s = 12345u;
+  for (auto& v : h) { s = s * 1664525u + 1013904223u; v = (unsigned short)(0x3c00u + ((s >> 16) & 0x3ffu) + ((s >> 9) & 0x8000u)); }   // bf16 of magnitude ~[0.0078, 0.03], random sign
+  hipMemcpy(w, h.data(), wbytes, hipMemcpyHostToDevice);
+  hipMemcpy(x, h.data() + 777, xbytes, hipMemcpyHostToDevice);
+#define CASE(a, b) if (nc == a && ring == b) run<a, b>(w, x, sink, nblocks, bar, wgs, reps)
+  CASE(2, 3); CASE(2, 4); CASE(2, 6); CASE(3, 3); CASE(3, 4); CASE(3, 6); CASE(4, 3); CASE(4, 4); CASE(4, 6);
+  return 0;
+}

@@ -427,6 +427,7 @@ typedef struct lmv_sstage_desc {
   int32_t B, H, W, M, C, heads, hidden, nblocks, dtype;
   float eps;                                       /* LayerNorm eps of norm1 / norm2 (1e-6) */
   const void* wpk; const float* vec;               /* nblocks packed blocks (lmv_sstage_pack) */
+  void* timing; int32_t timing_block, _pad;        /* optional (NULL): uint64 s_memtime stamps [workgroup][8 waves][16] of block `timing_block` (tools/sstage_timeline.py) */
 } lmv_sstage_desc;
 int lmv_sstage_supported(int C, int heads, int hidden, int H, int W, int M, int dtype);
 size_t lmv_sstage_wpk_bytes(int C, int hidden);

@@ -62,19 +62,21 @@ constexpr int L_XN = 0, L_XN_BYTES = SS_KS * SS_NT * 1024;        // token opera
 constexpr int L_H = L_XN_BYTES, L_H_BYTES = SS_KSC * SS_NT * 1024;   // hidden chunk (token operand of fc2); second-head q fragments during attention
 constexpr int L_STAT = L_H + L_H_BYTES, L_STAT_BYTES = 8 * 112 * 8;  // LayerNorm partial sums [wave][slot] float2
 constexpr int L_TOTAL = L_STAT + L_STAT_BYTES;                        // 150 528 B
-constexpr int STG_ROW = 96, STG_WAVE = 126 * STG_ROW;                 // dwconv staging: per wave [<= 126 tokens][48 channels] bf16 (over L_XN | L_H)
+constexpr int STG_ROW = 96, STG_WAVE = 156 * STG_ROW;                 // dwconv staging: per wave [15 guard + 126 tokens + 15 guard][48 channels] bf16 (over L_XN | L_H)
 static_assert(8 * STG_WAVE <= L_STAT, "staging overlaps the statistics");
 // workspace
 constexpr size_t KBUF_IMG = (size_t)SS_NH * 14 * 1024;      // [head][14 key tiles: image 0..12, meta 13][1 KB]
 constexpr size_t VBUF_IMG = (size_t)SS_NH * 8 * 2 * 1024;   // [head][8 key-tile pairs: half 0 p0..3, half 1 p0..3][2 d-tiles][1 KB], fp16
 constexpr size_t HALO_IMG = (size_t)2 * 14 * SS_C * 2;      // [half][14 tokens][C] bf16
 constexpr unsigned SPIN_LIMIT = 1u << 22;
+constexpr int SS_NSTAMP = 16;
 
 struct SsArgs {
   const bf16_t* x_in; const bf16_t* c_in; bf16_t* x_out; bf16_t* c_out;
   const uint4* wpk; const float* vec;
   unsigned char* kbuf; unsigned char* vbuf; unsigned char* halo; unsigned* flags;     // flags: [2 B] kv | [2 B] halo | [1] error
   int B, nblocks; float eps;
+  unsigned long long* timing; int timing_block;      // optional (NULL): s_memtime stamps [workgroup][wave][SS_NSTAMP] of one block
 };
 
 __device__ __forceinline__ bf16x8_t as_bf8(const uint4& v) { return __builtin_bit_cast(bf16x8_t, v); }
@@ -100,31 +102,37 @@ __device__ __forceinline__ void wait_flag(unsigned* flag, unsigned epoch, unsign
   }
 }
 
+#define SS_STAMP(k)                                                                                              \
+  do {                                                                                                           \
+    if (a.timing && blk == a.timing_block && lane == 0) a.timing[((size_t)blockIdx.x * 8 + wave) * SS_NSTAMP + (k)] = __builtin_amdgcn_s_memtime(); \
+  } while (0)
+
 // ---- one GEMM unit: NC output-channel tiles x all 7 token tiles x NKS k-steps ------------------------------------------------------
-// ring: the wave's weight fragments, 4 k-steps deep, straight from L2.  On entry slots 0..2 hold steps 0..2 of this unit (ring_fill or the
-// previous unit's tail); on exit they hold steps 0..2 of the unit at `wnext`.  TRANS: D[channel][token] = W X^T; else D[token][channel].
-template <int NC>
-__device__ __forceinline__ void ring_fill(bf16x8_t (&ring)[4][NC], const uint4* w) {
+// ring: the wave's weight fragments, RD - 1 k-steps ahead, straight from L2 (w: wave-uniform byte pointer to fragment 0 of the unit, fragments
+// in [k-step][n] order: scalar base + lane * 16 + immediate).  On entry slots 0 .. RD - 2 hold the first k-steps of this unit (ring_fill or the
+// previous unit's tail); on exit they hold those of the unit at `wnext`.  TRANS: D[channel][token] = W X^T; else D[token][channel].
+__device__ __forceinline__ bf16x8_t ld_frag(const unsigned char* w, int frag, int lane) { return as_bf8(reinterpret_cast<const uint4*>(w + (size_t)frag * 1024)[lane]); }
+template <int NC, int RD>
+__device__ __forceinline__ void ring_fill(bf16x8_t (&ring)[RD][NC], const unsigned char* w, int lane) {
 #pragma unroll
-  for (int s = 0; s < 3; ++s)
+  for (int s = 0; s < RD - 1; ++s)
 #pragma unroll
-    for (int n = 0; n < NC; ++n) ring[s][n] = as_bf8(w[(s * NC + n) * 64]);
+    for (int n = 0; n < NC; ++n) ring[s][n] = ld_frag(w, s * NC + n, lane);
 }
-template <int NC, int NKS, bool TRANS>
-__device__ __forceinline__ void gemm_unit(f32x4_t (&acc)[SS_NT][NC], bf16x8_t (&ring)[4][NC], const uint4* wcur, const uint4* wnext, const unsigned char* xs, int lane) {
-  static_assert(NKS % 4 == 0, "ring phase");
+template <int NC, int NKS, int RD, bool TRANS>
+__device__ __forceinline__ void gemm_unit(f32x4_t (&acc)[SS_NT][NC], bf16x8_t (&ring)[RD][NC], const unsigned char* wcur, const unsigned char* wnext, const unsigned char* xs, int lane) {
+  static_assert(NKS % RD == 0, "ring phase");
 #pragma unroll
   for (int ks = 0; ks < NKS; ++ks) {
-    const int sp = ks + 3;
+    const int sp = ks + RD - 1;
 #pragma unroll
-    for (int n = 0; n < NC; ++n) ring[sp % 4][n] = as_bf8(sp < NKS ? wcur[(sp * NC + n) * 64] : wnext[((sp - NKS) * NC + n) * 64]);
-    bf16x8_t xf[SS_NT];
+    for (int n = 0; n < NC; ++n) ring[sp % RD][n] = sp < NKS ? ld_frag(wcur, sp * NC + n, lane) : ld_frag(wnext, (sp - NKS) * NC + n, lane);
 #pragma unroll
-    for (int t = 0; t < SS_NT; ++t) xf[t] = *reinterpret_cast<const bf16x8_t*>(xs + ((ks * SS_NT + t) * 64 + lane) * 16);
+    for (int t = 0; t < SS_NT; ++t) {
+      const bf16x8_t xf = *reinterpret_cast<const bf16x8_t*>(xs + ((ks * SS_NT + t) * 64 + lane) * 16);
 #pragma unroll
-    for (int t = 0; t < SS_NT; ++t)
-#pragma unroll
-      for (int n = 0; n < NC; ++n) acc[t][n] = TRANS ? mfma_bf16(ring[ks % 4][n], xf[t], acc[t][n]) : mfma_bf16(xf[t], ring[ks % 4][n], acc[t][n]);
+      for (int n = 0; n < NC; ++n) acc[t][n] = TRANS ? mfma_bf16(ring[ks % RD][n], xf, acc[t][n]) : mfma_bf16(xf, ring[ks % RD][n], acc[t][n]);
+    }
   }
 }
 
@@ -246,8 +254,14 @@ __device__ __forceinline__ void attn_meta(const bf16x8_t& Qf, int h, __amdgpu_bu
 
 __global__ __launch_bounds__(512, 2) void sstage_kernel(const SsArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int g = lane >> 4, li = lane & 15;
+  const int tid = threadIdx.x, lane0 = tid & 63, wave0 = __builtin_amdgcn_readfirstlane(tid >> 6);
+  // Every phase re-derives its lane / wave quantities from an opaque copy (SS_PHASE): otherwise the compiler hoists ~100 loop-invariant
+  // addresses and masks out of the block loop and spills them next to the 84 residual registers.
+#define SS_PHASE                                                    \
+  __builtin_amdgcn_sched_barrier(0);                                \
+  int lane = lane0; asm volatile("" : "+v"(lane));                  \
+  int wave = wave0; asm volatile("" : "+s"(wave));                  \
+  const int g = lane >> 4, li = lane & 15; (void)g; (void)li; (void)wave;
   // the two halves of an image are workgroups b and b + 8: the same XCD under the round-robin dispatch (a speed matter only)
   const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
   const int img = (idx >> 1) * 8 + xcd, half = idx & 1;
@@ -264,6 +278,8 @@ __global__ __launch_bounds__(512, 2) void sstage_kernel(const SsArgs a) {
 
   // ---- residual rows -> registers (fp32): R[t][ct][r] = token slot 16 t + li, channel 48 wave + 16 ct + 4 g + r ----
   f32x4_t R[SS_NT][3];
+  {
+  SS_PHASE
 #pragma unroll
   for (int t = 0; t < SS_NT; ++t) {
     const int slot = 16 * t + li;
@@ -277,17 +293,23 @@ __global__ __launch_bounds__(512, 2) void sstage_kernel(const SsArgs a) {
       R[t][ct] = f32x4_t{f[0], f[1], f[2], f[3]};
     }
   }
+  }
 
 #pragma unroll 1
   for (int blk = 0; blk < a.nblocks; ++blk) {
-    const uint4* const wp = a.wpk + (size_t)blk * WS_FRAGS * 64 + lane;
+    const unsigned char* const wp = reinterpret_cast<const unsigned char*>(a.wpk) + (size_t)blk * WS_FRAGS * 1024;      // wave-uniform
     const float* const vec = a.vec + (size_t)blk * V_FLOATS;
+    const int lane = lane0, wave = wave0;      // (stamps only)
 
+    SS_STAMP(0);
+    asm volatile("; PHASE_DWCONV" ::: "memory");
     // ---- x += dwconv3x3(x) + bias on the 14 x 14 grid (models/lemevit.py:619): the wave's 48 channels of its tokens and of the one grid
     //      row across the cut go through a wave-private bf16 staging image; taps read bf16, the sum is added to the fp32 residual ----
     {
+      SS_PHASE
+      // staging rows: [15 guard][own rows and the 14 halo rows, in token order][15 guard]: every tap is base + an immediate offset
       unsigned char* const stg = smem + wave * STG_WAVE;
-      const int own0 = half ? 14 : 0, halo0 = half ? 0 : 112;
+      const int own0 = half ? 29 : 15, halo0 = half ? 15 : 127;
 #pragma unroll
       for (int t = 0; t < SS_NT; ++t) {
         const int slot = 16 * t + li;
@@ -297,6 +319,7 @@ __global__ __launch_bounds__(512, 2) void sstage_kernel(const SsArgs a) {
             *reinterpret_cast<uint2*>(stg + (own0 + slot) * STG_ROW + 32 * ct + 8 * g) = make_uint2(pack_bf2(R[t][ct][0], R[t][ct][1]), pack_bf2(R[t][ct][2], R[t][ct][3]));
         }
       }
+      SS_STAMP(13);
       {
         const unsigned char* hsrc;
         if (blk == 0) hsrc = reinterpret_cast<const unsigned char*>(a.x_in + ((size_t)img * SS_NIMG + (half ? 98 : 112)) * SS_C);
@@ -312,8 +335,12 @@ __global__ __launch_bounds__(512, 2) void sstage_kernel(const SsArgs a) {
           }
         }
       }
-#pragma unroll 1
+      SS_STAMP(14);
+#pragma unroll
       for (int ct = 0; ct < 3; ++ct) {
+        int l2 = lane; asm volatile("" : "+v"(l2));      // per-channel-tile copies: the per-token masks and addresses are recomputed, not kept across the three passes
+        const int g = l2 >> 4, li = l2 & 15;
+        const unsigned char* const tap0 = stg + (own0 + li - 15) * STG_ROW + 8 * g;      // tap (dy, dx) of tile t: + (16 t + 15 + 14 dy + dx) * 96 + 32 ct
         const int c0 = 48 * wave + 16 * ct + 4 * g;
         float wt[36];
 #pragma unroll
@@ -324,146 +351,180 @@ __global__ __launch_bounds__(512, 2) void sstage_kernel(const SsArgs a) {
         const float4 pb = *reinterpret_cast<const float4*>(vec + V_POSB + c0);
 #pragma unroll
         for (int t = 0; t < SS_NT; ++t) {
-          const int slot = 16 * t + li;
+          // which of the 3 x 3 taps of this token fall inside the 14 x 14 grid
+          const int slot = 16 * t + li, tk = tok0 + slot, y = tk / SS_G, x = tk - y * SS_G;
           const bool valid = slot < nimg_slots;
-          const int tk = tok0 + slot, y = tk / SS_G, x = tk - y * SS_G;
+          const bool yo[3] = {y > 0, true, y < SS_G - 1}, xo[3] = {x > 0, true, x < SS_G - 1};
           float acc[4] = {pb.x, pb.y, pb.z, pb.w};
 #pragma unroll
-          for (int dy = -1; dy <= 1; ++dy)
+          for (int tap = 0; tap < 9; ++tap) {
+            const int dy = tap / 3 - 1, dx = tap % 3 - 1;
+            float f[4];
+            ld4(reinterpret_cast<const bf16_t*>(tap0 + (16 * t + 15 + SS_G * dy + dx) * STG_ROW + 32 * ct), f);
+            const bool ok = yo[dy + 1] && xo[dx + 1];
 #pragma unroll
-            for (int dx = -1; dx <= 1; ++dx) {
-              const bool ok = valid && (unsigned)(y + dy) < (unsigned)SS_G && (unsigned)(x + dx) < (unsigned)SS_G;
-              const int row = own0 + (ok ? slot + dy * SS_G + dx : (valid ? slot : 0));
-              float f[4];
-              ld4(reinterpret_cast<const bf16_t*>(stg + row * STG_ROW + 32 * ct + 8 * g), f);
-              const int tap = (dy + 1) * 3 + dx + 1;
+            for (int r = 0; r < 4; ++r) acc[r] = fmaf(wt[r * 9 + tap], ok ? f[r] : 0.f, acc[r]);
+          }
 #pragma unroll
-              for (int r = 0; r < 4; ++r) acc[r] = fmaf(ok ? wt[r * 9 + tap] : 0.f, f[r], acc[r]);
-            }
-          // R[t][ct] is indexed with the runtime ct of this rolled loop through a select chain (three candidates)
-#pragma unroll
-          for (int cc = 0; cc < 3; ++cc)
-            if (cc == ct && valid) {
-#pragma unroll
-              for (int r = 0; r < 4; ++r) R[t][cc][r] += acc[r];
-            }
+          for (int r = 0; r < 4; ++r) R[t][ct][r] += valid ? acc[r] : 0.f;
+          // one token tile's 9 taps at a time, finished here: otherwise LLVM sinks the FMA chains to the first use of R (the LayerNorm) and
+          // keeps all 189 loaded taps alive (in scratch) until then
+          asm volatile("" : "+v"(R[t][ct]));
+          __builtin_amdgcn_sched_barrier(0);
         }
       }
     }
 
+    SS_STAMP(1);
+    asm volatile("; PHASE_LN1_KV" ::: "memory");
     // ---- norm1 -> LDS; k / v projections of this half's tokens -> exchange buffers ----
-    layer_norm_to_lds(R, vec + V_N1W, vec + V_N1B, a.eps, smem, wave, lane);
-    bf16x8_t ring2[4][2];
-    ring_fill<2>(ring2, wp + (size_t)(WS_KV + (3 * wave) * 24) * 64);
+    bf16x8_t ring2[3][2];
+    {
+      SS_PHASE
+      ring_fill<2, 3>(ring2, wp + (size_t)(WS_KV + (3 * wave) * 24) * 1024, lane);       // lands under the LayerNorm
+      layer_norm_to_lds(R, vec + V_N1W, vec + V_N1B, a.eps, smem, wave, lane);
+    }
+    SS_STAMP(2);
+    {
+      SS_PHASE
 #pragma unroll 1
-    for (int uu = 0; uu < 3; ++uu) {
-      const int u = 3 * wave + uu, h = u >> 1, isv = u & 1;
-      const uint4* wcur = wp + (size_t)(WS_KV + u * 24) * 64;
-      const uint4* wnext = uu < 2 ? wcur + 24 * 64 : wp + (size_t)(WS_Q + wave * 24) * 64;
-      f32x4_t acc[SS_NT][2];
+      for (int uu = 0; uu < 3; ++uu) {
+        const int u = 3 * wave + uu, h = u >> 1, isv = u & 1;
+        const unsigned char* wcur = wp + (size_t)(WS_KV + u * 24) * 1024;
+        const unsigned char* wnext = uu < 2 ? wcur + 24 * 1024 : wp + (size_t)(WS_Q + wave * 24) * 1024;
+        f32x4_t acc[SS_NT][2];
 #pragma unroll
-      for (int t = 0; t < SS_NT; ++t) { acc[t][0] = f32x4_t{0.f, 0.f, 0.f, 0.f}; acc[t][1] = acc[t][0]; }
-      if (!isv) {
-        gemm_unit<2, SS_KS, true>(acc, ring2, wcur, wnext, smem + L_XN, lane);
-        const float* bk = vec + V_QKVB + SS_C + 32 * h + 4 * g;
-        const float4 b0 = *reinterpret_cast<const float4*>(bk), b1 = *reinterpret_cast<const float4*>(bk + 16);
+        for (int t = 0; t < SS_NT; ++t) { acc[t][0] = f32x4_t{0.f, 0.f, 0.f, 0.f}; acc[t][1] = acc[t][0]; }
+        if (!isv) {
+          gemm_unit<2, SS_KS, 3, true>(acc, ring2, wcur, wnext, smem + L_XN, lane);
+          const float* bk = vec + V_QKVB + SS_C + 32 * h + 4 * g;
+          const float4 b0 = *reinterpret_cast<const float4*>(bk), b1 = *reinterpret_cast<const float4*>(bk + 16);
 #pragma unroll
-        for (int t = 0; t < SS_NT; ++t) {
-          const int kt = half ? (t < 6 ? 7 + t : 13) : t;
-          const f32x4_t k0 = {acc[t][0][0] + b0.x, acc[t][0][1] + b0.y, acc[t][0][2] + b0.z, acc[t][0][3] + b0.w};
-          const f32x4_t k1 = {acc[t][1][0] + b1.x, acc[t][1][1] + b1.y, acc[t][1][2] + b1.z, acc[t][1][3] + b1.w};
-          __builtin_amdgcn_raw_buffer_store_b128(pack_bf8(k0, k1), kr, ((h * 14 + kt) * 64 + lane) * 16, 0, 16);
-        }
-      } else {
-        gemm_unit<2, SS_KS, false>(acc, ring2, wcur, wnext, smem + L_XN, lane);
-        const float bv0 = vec[V_QKVB + 2 * SS_C + 32 * h + li], bv1 = vec[V_QKVB + 2 * SS_C + 32 * h + 16 + li];
-#pragma unroll
-        for (int p = 0; p < 4; ++p)
-#pragma unroll
-          for (int dt = 0; dt < 2; ++dt) {
-            const float bv = dt ? bv1 : bv0;
-            const f32x4_t lo = acc[2 * p][dt] + bv;
-            u32x4_t pk = {pack_h2(lo[0], lo[1]), pack_h2(lo[2], lo[3]), 0u, 0u};
-            if (p < 3) { const f32x4_t hi = acc[2 * p + 1][dt] + bv; pk[2] = pack_h2(hi[0], hi[1]); pk[3] = pack_h2(hi[2], hi[3]); }
-            __builtin_amdgcn_raw_buffer_store_b128(pk, vr, ((h * 16 + (half * 4 + p) * 2 + dt) * 64 + lane) * 16, 0, 16);
+          for (int t = 0; t < SS_NT; ++t) {
+            const int kt = half ? (t < 6 ? 7 + t : 13) : t;
+            const f32x4_t k0 = {acc[t][0][0] + b0.x, acc[t][0][1] + b0.y, acc[t][0][2] + b0.z, acc[t][0][3] + b0.w};
+            const f32x4_t k1 = {acc[t][1][0] + b1.x, acc[t][1][1] + b1.y, acc[t][1][2] + b1.z, acc[t][1][3] + b1.w};
+            __builtin_amdgcn_raw_buffer_store_b128(pack_bf8(k0, k1), kr, ((h * 14 + kt) * 64 + lane) * 16, 0, 16);
           }
+        } else {
+          gemm_unit<2, SS_KS, 3, false>(acc, ring2, wcur, wnext, smem + L_XN, lane);
+          const float bv0 = vec[V_QKVB + 2 * SS_C + 32 * h + li], bv1 = vec[V_QKVB + 2 * SS_C + 32 * h + 16 + li];
+#pragma unroll
+          for (int p = 0; p < 4; ++p)
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt) {
+              const float bv = dt ? bv1 : bv0;
+              const f32x4_t lo = acc[2 * p][dt] + bv;
+              u32x4_t pk = {pack_h2(lo[0], lo[1]), pack_h2(lo[2], lo[3]), 0u, 0u};
+              if (p < 3) { const f32x4_t hi = acc[2 * p + 1][dt] + bv; pk[2] = pack_h2(hi[0], hi[1]); pk[3] = pack_h2(hi[2], hi[3]); }
+              __builtin_amdgcn_raw_buffer_store_b128(pk, vr, ((h * 16 + (half * 4 + p) * 2 + dt) * 64 + lane) * 16, 0, 16);
+            }
+        }
       }
     }
+    SS_STAMP(3);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // every storing wave drains (R1), then one lane raises the flag
     __syncthreads();
+    SS_STAMP(4);
     if (tid == 0) __hip_atomic_store((gu32*)kvflag_mine, (unsigned)(blk + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 
+    asm volatile("; PHASE_QPROJ" ::: "memory");
     // ---- q projections of the wave's heads (head `wave`, and head 8 + wave on waves 0..3) ----
-    const int nheads = wave < 4 ? 2 : 1;
-    bf16x8_t Qf[SS_NT];      // (ring2 already holds the first k-steps of head `wave`: the tail of the last k / v unit fetched them)
+    const int nheads = wave0 < 4 ? 2 : 1;
+    bf16x8_t Qf[SS_NT];      // (the drain above also waited for the first k-steps of head `wave`: the tail of the last k / v unit fetched them)
+    {
+      SS_PHASE
 #pragma unroll 1
-    for (int hu = 0; hu < nheads; ++hu) {
-      const int h = wave + 8 * hu;
-      const uint4* wcur = wp + (size_t)(WS_Q + h * 24) * 64;
-      const uint4* wnext = hu + 1 < nheads ? wp + (size_t)(WS_Q + (h + 8) * 24) * 64 : wcur;
-      f32x4_t acc[SS_NT][2];
+      for (int hu = 0; hu < nheads; ++hu) {
+        const int h = wave + 8 * hu;
+        const unsigned char* wcur = wp + (size_t)(WS_Q + h * 24) * 1024;
+        const unsigned char* wnext = hu + 1 < nheads ? wp + (size_t)(WS_Q + (h + 8) * 24) * 1024 : wcur;
+        f32x4_t acc[SS_NT][2];
 #pragma unroll
-      for (int t = 0; t < SS_NT; ++t) { acc[t][0] = f32x4_t{0.f, 0.f, 0.f, 0.f}; acc[t][1] = acc[t][0]; }
-      gemm_unit<2, SS_KS, true>(acc, ring2, wcur, wnext, smem + L_XN, lane);
-      const float* bq = vec + V_QKVB + 32 * h + 4 * g;
-      const float4 b0 = *reinterpret_cast<const float4*>(bq), b1 = *reinterpret_cast<const float4*>(bq + 16);
-      constexpr float QS = 0.25503486f;      // log2(e) / sqrt(32): softmax(q k^T / sqrt d) as exp2 of the scores (models/lemevit.py:203)
+        for (int t = 0; t < SS_NT; ++t) { acc[t][0] = f32x4_t{0.f, 0.f, 0.f, 0.f}; acc[t][1] = acc[t][0]; }
+        gemm_unit<2, SS_KS, 3, true>(acc, ring2, wcur, wnext, smem + L_XN, lane);
+        const float* bq = vec + V_QKVB + 32 * h + 4 * g;
+        const float4 b0 = *reinterpret_cast<const float4*>(bq), b1 = *reinterpret_cast<const float4*>(bq + 16);
+        constexpr float QS = 0.25503486f;      // log2(e) / sqrt(32): softmax(q k^T / sqrt d) as exp2 of the scores (models/lemevit.py:203)
 #pragma unroll
-      for (int t = 0; t < SS_NT; ++t) {
-        const f32x4_t q0 = {(acc[t][0][0] + b0.x) * QS, (acc[t][0][1] + b0.y) * QS, (acc[t][0][2] + b0.z) * QS, (acc[t][0][3] + b0.w) * QS};
-        const f32x4_t q1 = {(acc[t][1][0] + b1.x) * QS, (acc[t][1][1] + b1.y) * QS, (acc[t][1][2] + b1.z) * QS, (acc[t][1][3] + b1.w) * QS};
-        const u32x4_t qf = pack_bf8(q0, q1);
-        if (hu == 0) Qf[t] = as_bf8(qf);
-        else *reinterpret_cast<u32x4_t*>(smem + L_H + ((wave * SS_NT + t) * 64 + lane) * 16) = qf;
+        for (int t = 0; t < SS_NT; ++t) {
+          const f32x4_t q0 = {(acc[t][0][0] + b0.x) * QS, (acc[t][0][1] + b0.y) * QS, (acc[t][0][2] + b0.z) * QS, (acc[t][0][3] + b0.w) * QS};
+          const f32x4_t q1 = {(acc[t][1][0] + b1.x) * QS, (acc[t][1][1] + b1.y) * QS, (acc[t][1][2] + b1.z) * QS, (acc[t][1][3] + b1.w) * QS};
+          const u32x4_t qf = pack_bf8(q0, q1);
+          if (hu == 0) Qf[t] = as_bf8(qf);
+          else *reinterpret_cast<u32x4_t*>(smem + L_H + ((wave * SS_NT + t) * 64 + lane) * 16) = qf;
+        }
       }
     }
-    if (wave == 0) wait_flag(kvflag_peer, (unsigned)(blk + 1), errflag, lane);
+    SS_STAMP(5);
+    if (wave0 == 0) wait_flag(kvflag_peer, (unsigned)(blk + 1), errflag, lane0);
     __syncthreads();          // every q projection has read the LayerNorm output: the attention output may overwrite it; the peer's K / V are published
+    SS_STAMP(6);
 
+    asm volatile("; PHASE_ATTN" ::: "memory");
     // ---- attention of the wave's heads -> proj operand in LDS ----
+    {
+      SS_PHASE
 #pragma unroll 1
-    for (int hu = 0; hu < nheads; ++hu) {
-      const int h = wave + 8 * hu;
-      if (hu == 1) {
+      for (int hu = 0; hu < nheads; ++hu) {
+        const int h = wave + 8 * hu;
+        if (hu == 1) {
 #pragma unroll
-        for (int t = 0; t < SS_NT; ++t) Qf[t] = *reinterpret_cast<const bf16x8_t*>(smem + L_H + ((wave * SS_NT + t) * 64 + lane) * 16);
+          for (int t = 0; t < SS_NT; ++t) Qf[t] = *reinterpret_cast<const bf16x8_t*>(smem + L_H + ((wave * SS_NT + t) * 64 + lane) * 16);
+        }
+        if (half == 0) attn_image<7>(Qf, h, kr, vr, smem, lane);
+        else { attn_image<6>(Qf, h, kr, vr, smem, lane); attn_meta(Qf[6], h, kr, vr, smem, lane); }
       }
-      if (half == 0) attn_image<7>(Qf, h, kr, vr, smem, lane);
-      else { attn_image<6>(Qf, h, kr, vr, smem, lane); attn_meta(Qf[6], h, kr, vr, smem, lane); }
+    }
+    SS_STAMP(7);
+    bf16x8_t ring3[4][3];
+    {
+      SS_PHASE
+      ring_fill<3, 4>(ring3, wp + (size_t)(WS_PROJ + wave * 36) * 1024, lane);          // lands under the barrier
     }
     __syncthreads();
 
+    SS_STAMP(8);
+    asm volatile("; PHASE_PROJ" ::: "memory");
     // ---- x += proj(attention) + bias: accumulated ON the residual registers ----
     {
+      SS_PHASE
 #pragma unroll
       for (int ct = 0; ct < 3; ++ct) {
         const float4 b = *reinterpret_cast<const float4*>(vec + V_PROJB + 48 * wave + 16 * ct + 4 * g);
 #pragma unroll
         for (int t = 0; t < SS_NT; ++t) { R[t][ct][0] += b.x; R[t][ct][1] += b.y; R[t][ct][2] += b.z; R[t][ct][3] += b.w; }
       }
-      bf16x8_t ring3[4][3];
-      const uint4* wcur = wp + (size_t)(WS_PROJ + wave * 36) * 64;
-      ring_fill<3>(ring3, wcur);
-      gemm_unit<3, SS_KS, true>(R, ring3, wcur, wcur, smem + L_XN, lane);
+      const unsigned char* wcur = wp + (size_t)(WS_PROJ + wave * 36) * 1024;
+      gemm_unit<3, SS_KS, 4, true>(R, ring3, wcur, wcur, smem + L_XN, lane);
     }
 
+    SS_STAMP(9);
+    asm volatile("; PHASE_MLP" ::: "memory");
     // ---- norm2 -> LDS; MLP in 6 chunks of 256 hidden channels; fc2 accumulates on the residual registers ----
-    layer_norm_to_lds(R, vec + V_N2W, vec + V_N2B, a.eps, smem, wave, lane);
+    {
+      SS_PHASE
+      ring_fill<2, 3>(ring2, wp + (size_t)(WS_FC1 + wave * 24) * 1024, lane);            // lands under the LayerNorm
+      layer_norm_to_lds(R, vec + V_N2W, vec + V_N2B, a.eps, smem, wave, lane);
 #pragma unroll
-    for (int ct = 0; ct < 3; ++ct) {
-      const float4 b = *reinterpret_cast<const float4*>(vec + V_FC2B + 48 * wave + 16 * ct + 4 * g);
+      for (int ct = 0; ct < 3; ++ct) {
+        const float4 b = *reinterpret_cast<const float4*>(vec + V_FC2B + 48 * wave + 16 * ct + 4 * g);
 #pragma unroll
-      for (int t = 0; t < SS_NT; ++t) { R[t][ct][0] += b.x; R[t][ct][1] += b.y; R[t][ct][2] += b.z; R[t][ct][3] += b.w; }
+        for (int t = 0; t < SS_NT; ++t) { R[t][ct][0] += b.x; R[t][ct][1] += b.y; R[t][ct][2] += b.z; R[t][ct][3] += b.w; }
+      }
     }
+    SS_STAMP(10);
 #pragma unroll 1
     for (int c = 0; c < SS_NCHUNK; ++c) {
       {
+        SS_PHASE
         f32x4_t acc[SS_NT][2];
 #pragma unroll
         for (int t = 0; t < SS_NT; ++t) { acc[t][0] = f32x4_t{0.f, 0.f, 0.f, 0.f}; acc[t][1] = acc[t][0]; }
-        const uint4* wcur = wp + (size_t)(WS_FC1 + (c * 8 + wave) * 24) * 64;
-        ring_fill<2>(ring2, wcur);
-        gemm_unit<2, SS_KS, true>(acc, ring2, wcur, wcur, smem + L_XN, lane);
+        const unsigned char* wcur = wp + (size_t)(WS_FC1 + (c * 8 + wave) * 24) * 1024;
+        // the tail of this unit fetches the first k-steps of the NEXT chunk's fc1 (they ride through this chunk's fc2)
+        gemm_unit<2, SS_KS, 3, true>(acc, ring2, wcur, c + 1 < SS_NCHUNK ? wcur + 8 * 24 * 1024 : wcur, smem + L_XN, lane);
+        ring_fill<3, 4>(ring3, wp + (size_t)(WS_FC2 + (c * 8 + wave) * 24) * 1024, lane);      // lands under the GELU pass and the barrier
         const float* b1p = vec + V_FC1B + 256 * c + 32 * wave + 4 * g;
         const float4 b0 = *reinterpret_cast<const float4*>(b1p), b1 = *reinterpret_cast<const float4*>(b1p + 16);
 #pragma unroll
@@ -476,39 +537,45 @@ __global__ __launch_bounds__(512, 2) void sstage_kernel(const SsArgs a) {
       }
       __syncthreads();
       {
-        bf16x8_t ring3[4][3];
-        const uint4* wcur = wp + (size_t)(WS_FC2 + (c * 8 + wave) * 24) * 64;
-        ring_fill<3>(ring3, wcur);
-        gemm_unit<3, SS_KSC, true>(R, ring3, wcur, wcur, smem + L_H, lane);
+        SS_PHASE
+        const unsigned char* wcur = wp + (size_t)(WS_FC2 + (c * 8 + wave) * 24) * 1024;
+        gemm_unit<3, SS_KSC, 4, true>(R, ring3, wcur, wcur, smem + L_H, lane);
       }
       if (c + 1 < SS_NCHUNK) __syncthreads();
     }
 
+    SS_STAMP(11);
+    asm volatile("; PHASE_BLKEND" ::: "memory");
     // ---- block end: pad slots stay zero; the grid row next to the cut goes to the peer (next block's position embedding) ----
-    if (half) {
+    {
+      SS_PHASE
+      if (half) {
 #pragma unroll
-      for (int ct = 0; ct < 3; ++ct)
+        for (int ct = 0; ct < 3; ++ct)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) R[5][ct][r] = li >= 4 ? 0.f : R[5][ct][r];
-    }
-    if (blk + 1 < a.nblocks) {
-      const int tok = half ? li : li - 2;
-      if ((unsigned)tok < 14u) {
-        bf16_t* dst = reinterpret_cast<bf16_t*>(a.halo + (size_t)img * HALO_IMG) + ((size_t)half * 14 + tok) * SS_C + 48 * wave + 4 * g;
-#pragma unroll
-        for (int ct = 0; ct < 3; ++ct) {
-          const f32x4_t v = half ? R[0][ct] : R[6][ct];
-          const unsigned long long pk = (unsigned long long)pack_bf2(v[0], v[1]) | ((unsigned long long)pack_bf2(v[2], v[3]) << 32);
-          __hip_atomic_store((gu64*)(dst + 16 * ct), pk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
+          for (int r = 0; r < 4; ++r) R[5][ct][r] = li >= 4 ? 0.f : R[5][ct][r];
       }
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (blk + 1 < a.nblocks) {
+        const int tok = half ? li : li - 2;
+        if ((unsigned)tok < 14u) {
+          bf16_t* dst = reinterpret_cast<bf16_t*>(a.halo + (size_t)img * HALO_IMG) + ((size_t)half * 14 + tok) * SS_C + 48 * wave + 4 * g;
+#pragma unroll
+          for (int ct = 0; ct < 3; ++ct) {
+            const f32x4_t v = half ? R[0][ct] : R[6][ct];
+            const unsigned long long pk = (unsigned long long)pack_bf2(v[0], v[1]) | ((unsigned long long)pack_bf2(v[2], v[3]) << 32);
+            __hip_atomic_store((gu64*)(dst + 16 * ct), pk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
     }
     __syncthreads();
+    SS_STAMP(12);
     if (blk + 1 < a.nblocks && tid == 0) __hip_atomic_store((gu32*)haloflag_mine, (unsigned)(blk + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
 
   // ---- registers -> x_out / c_out ----
+  SS_PHASE
 #pragma unroll
   for (int t = 0; t < SS_NT; ++t) {
     const int slot = 16 * t + li;
@@ -606,6 +673,7 @@ int lmv_sstage_fwd(const lmv_sstage_desc* d, const void* x, const void* c, void*
     a.wpk = (const uint4*)d->wpk; a.vec = d->vec;
     a.flags = (unsigned*)ws; a.kbuf = ws + flags; a.vbuf = a.kbuf + (size_t)nb * KBUF_IMG; a.halo = a.vbuf + (size_t)nb * VBUF_IMG;
     a.B = nb; a.nblocks = d->nblocks; a.eps = d->eps;
+    a.timing = (unsigned long long*)d->timing; a.timing_block = d->timing_block;
     const int nwg = 2 * ((nb + 7) / 8) * 8;
     hipLaunchKernelGGL(sstage_kernel, dim3(nwg), dim3(512), L_TOTAL, st, a);
     LMV_CHECK_LAUNCH("sstage_fwd");

@@ -63,12 +63,25 @@ def split_forward(model: Callable, x: torch.Tensor, parts: int, outs: Optional[l
     from .blocks import aux_streams
     streams = aux_streams(x.device, len(xs) - 1)          # shared with the training schedules: main + 3 streams per process (blocks.aux_streams)
     ys = [None] * len(xs)
+    # Sub-batch 0 is ISSUED first, on the current stream: every lazily built operand cache of the model (bf16 casts, LayerNorm folds, conv + BatchNorm
+    # folds, the classifier tail, the packed S stage) is then filled by kernels on `cur`.  The other streams fork from the point BEFORE it (they
+    # run next to it) -- unless it filled a cache (model.cache_fills() moved: the first pass after a weight update): then they wait for the
+    # whole of sub-batch 0, so that no stream reads a half-written cached operand.  (Before round 4 the forks came first and the later
+    # sub-batches could read caches another stream was still writing.)
+    from . import model as _model
+    fork = torch.cuda.Event()
+    fork.record(cur)
+    fills = _model.cache_fills()
+    ys[0] = model(xs[0])
+    cold = _model.cache_fills() != fills
     for i, s in enumerate(streams):
-        s.wait_stream(cur)
+        if cold:
+            s.wait_stream(cur)
+        else:
+            s.wait_event(fork)
         with torch.cuda.stream(s):
             ys[i + 1] = model(xs[i + 1])
             xs[i + 1].record_stream(s)
-    ys[0] = model(xs[0])
     for s, y in zip(streams, ys[1:]):
         cur.wait_stream(s)
         y.record_stream(cur)

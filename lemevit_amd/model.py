@@ -91,6 +91,17 @@ def compute_copy(p: Tensor, want: torch.dtype) -> Tensor:
 _casts_launched = 0
 
 
+def _cache_filled() -> None:
+    """A lazily built operand cache was (re)filled by kernels on the CURRENT stream: image_ranges() re-forks its range streams behind them and
+    graph.split_forward orders its other sub-batch streams behind the sub-batch that filled it."""
+    global _casts_launched
+    _casts_launched += 1
+
+
+def cache_fills() -> int:
+    return _casts_launched
+
+
 _fold_cache: dict = {}
 _conv1_cache: dict = {}
 
@@ -110,6 +121,7 @@ def _ln_fold_cached(w: Tensor, b: Optional[Tensor], g: Tensor, be: Tensor, dtype
     with torch.no_grad():
         f32 = lambda t: None if t is None else t.detach().float().contiguous()
         F = ops.ln_fold(f32(w), f32(b), f32(g), f32(be), dtype)
+    _cache_filled()
     _ln_fold_cache[key] = (weakref.ref(w, lambda _r, k=key: _ln_fold_cache.pop(k, None)), stamp, F)      # dropped with the parameter (a deleted model does not leak its folds)
     return F
 
@@ -133,6 +145,7 @@ def _conv1_matrix(weight: Tensor, dtype: torch.dtype) -> Tensor:
     with torch.no_grad():
         m = torch.zeros(weight.shape[0], 32, device=weight.device, dtype=dtype)
         m[:, :27] = weight.detach().reshape(weight.shape[0], 27)
+    _cache_filled()
     _conv1_cache[key] = (weakref.ref(weight, lambda _r, k=key: _conv1_cache.pop(k, None)), stamp, m)
     return m
 
@@ -188,6 +201,7 @@ def _conv_matrix(weight: Tensor, dtype: torch.dtype, KP: int) -> Tensor:
         m[:, :9 * Ci] = weight.detach().permute(0, 2, 3, 1).reshape(Co, 9 * Ci)
     # dropped with `weight`: the eval-mode conv + BatchNorm fold builds a NEW folded weight after every training pass, whose matrix would
     # otherwise stay cached under the dead tensor's id (~5 MB per train -> eval cycle for Base)
+    _cache_filled()
     _conv_cache[key] = (weakref.ref(weight, lambda _r, k=key: _conv_cache.pop(k, None)), stamp, m)
     return m
 
@@ -425,6 +439,7 @@ def _tail_infer(norm_c: nn.LayerNorm, bn: nn.BatchNorm2d, head: nn.Linear, xt: T
             if head.bias is not None:
                 bp[:N] = head.bias.detach().float()
             ent = (ver, a.contiguous(), b.contiguous(), norm_c.weight.detach().float().contiguous(), norm_c.bias.detach().float().contiguous(), Wp, bp, N)
+        _cache_filled()
         _tail_cache[key] = ent
     _, a, b, g32, b32, Wp, bp, N = ent
     cc = c.detach().to(cd).contiguous()
@@ -483,6 +498,7 @@ def _folded_conv_bn(conv: nn.Conv2d, bn: nn.BatchNorm2d, dtype: torch.dtype):
         w = w.to(dtype).contiguous(memory_format=torch.channels_last)
         b32 = b.contiguous()
         b = b.to(dtype)
+    _cache_filled()
     _fold_cache[key] = (ver, w, b, b32)
     return w, b, b32
 
@@ -808,6 +824,51 @@ def run_block(kind: str, x: Tensor, c: Tensor, H: int, W: int, params: "OrderedD
 # ------------------------------------------------------------------------------------------------
 def _lin_probs(pairs, dtype):
     return [Prob(a, compute_copy(m.weight, dtype), o, bias=compute_copy(m.bias, torch.float32)) for a, m, o in pairs]
+
+
+# ------------------------------------------------------------------------------------------------
+# a whole stage of "S" blocks as one persistent launch (csrc/sstage.hip; inference)
+# ------------------------------------------------------------------------------------------------
+_SSTAGE = os.environ.get("LMV_SSTAGE", "1") != "0"        # 0: the per-block inference schedule (A/B runs)
+_sstage_cache: dict = {}
+
+
+def _sstage_applies(stage, xt: Tensor, c: Tensor, H: int, W: int) -> bool:
+    """models/lemevit.py:615-650 x depth as ONE launch: inference only (nothing is saved for a backward pass, no DropPath), bf16, every block
+    of the stage an "S" block of a shape lmv_sstage_supported accepts (stage 3 of LeMeViT-Base at 224 x 224)."""
+    if not (_SSTAGE and _FUSED and _NATIVE) or torch.is_grad_enabled() or xt.dtype != torch.bfloat16 or len(stage) == 0 or not xt.is_cuda:
+        return False
+    for blk in stage:
+        if type(blk) is not LeMeBlock or blk.kind != "S" or (blk.training and blk.drop_prob > 0.0) or type(blk)._masks is not LeMeBlock._masks or "_masks" in blk.__dict__:
+            return False
+    b0 = stage[0]
+    return ops.sstage_supported(xt.shape[2], b0.attn.num_heads, b0.mlp[0].out_features, H, W, c.shape[1], xt.dtype)
+
+
+def _sstage_packed(stage) -> "ops.SStagePacked":
+    """The stage's parameters in the kernel's layout, cached per parameter version (and per training pass, see compute_copy)."""
+    key = id(stage)
+    plist = [p for blk in stage for p in blk._params().values()]
+    stamp = tuple(p._version for p in plist) + tuple(id(p) for p in plist) + (_train_pass,)
+    ent = _sstage_cache.get(key)
+    if ent is not None and ent[0]() is stage and ent[1] == stamp:
+        return ent[2]
+    blocks = []
+    for blk in stage:
+        P = blk._params()
+        d = {}
+        for n in ops.SSTAGE_NAMES:
+            if n == "pos_embed.weight":
+                d[n] = P[n].detach().float().reshape(P[n].shape[0], 9).contiguous()
+            elif _is_matrix(n):
+                d[n] = compute_copy(P[n], torch.bfloat16)
+            else:
+                d[n] = compute_copy(P[n], torch.float32)
+        blocks.append(d)
+    packed = ops.sstage_pack(blocks, stage[0].attn.num_heads)
+    _cache_filled()
+    _sstage_cache[key] = (weakref.ref(stage, lambda _r, k=key: _sstage_cache.pop(k, None)), stamp, packed)
+    return packed
 
 
 class StandardAttention(nn.Module):
@@ -1168,6 +1229,9 @@ class LeMeViT(nn.Module):
                 c = c.expand(B, -1, -1)
                 hoist = False
             c = c.to(cd).contiguous()
+            if _sstage_applies(self.stages[i], xt, c, H, W):
+                xt, c = ops.sstage_fwd(xt.contiguous(), c, _sstage_packed(self.stages[i]), H, W, BLOCK_LN_EPS)
+                continue
             with image_ranges(xt.device, B):
                 for blk in self.stages[i]:
                     xt, c = blk.forward_tokens(xt, c, H, W, masks=all_masks.get(id(blk)) if all_masks else None)

@@ -649,11 +649,12 @@ def sstage_pack(blocks: Sequence[dict], heads: int) -> SStagePacked:
     return P
 
 
-def sstage_fwd(x: Tensor, c: Tensor, P: SStagePacked, H: int, W: int, eps: float) -> Tuple[Tensor, Tensor]:
+def sstage_fwd(x: Tensor, c: Tensor, P: SStagePacked, H: int, W: int, eps: float, timing: Optional[Tensor] = None, timing_block: int = 0) -> Tuple[Tensor, Tensor]:
     B, N, C_ = x.shape
     d = _lib.SStageDesc()
     d.B, d.H, d.W, d.M, d.C, d.heads, d.hidden, d.nblocks, d.dtype, d.eps = B, H, W, c.shape[1], C_, P.heads, P.hidden, P.nblocks, dtype_code(x), eps
     d.wpk, d.vec = P.wpk.data_ptr(), P.vec.data_ptr()
+    d.timing, d.timing_block = (None if timing is None else timing.data_ptr()), timing_block
     xo, co = torch.empty_like(x), torch.empty_like(c)
     nbytes = int(lib.lmv_sstage_workspace_bytes(min(B, 128)))
     ws = _workspace(nbytes, x.device)

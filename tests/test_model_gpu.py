@@ -231,6 +231,33 @@ def test_split_forward_concurrent_sub_batches(parts):
     assert len(outs) == parts and torch.equal(torch.cat(outs), seq)
 
 
+@pytest.mark.parametrize("variant", ["lemevit_tiny", "lemevit_base"])
+def test_split_forward_cold_caches(variant):
+    """the lazily built operand caches (bf16 casts, LayerNorm folds, conv + BatchNorm folds, the classifier tail, the packed S
+    stage) are filled by the FIRST sub-batch; the other sub-batch streams must not read them before those kernels have run.  A fresh model
+    (every cache cold) goes straight into split_forward, again after new_training_pass() (what the first eval batch after a training pass
+    sees), under a busy chip -- the result must be bit-equal to the warm sequential sub-batches."""
+    import lemevit_amd.model as M
+    from lemevit_amd.graph import split_forward
+    m = _model(variant, 1000, 5).eval()
+    B, parts = 12, 4
+    img = det_tensor((B, 3, 224, 224), "split.cold", 4).to(DEV)
+    busy = torch.randn(4096, 4096, device=DEV)
+    with torch.no_grad(), torch.autocast("cuda", torch.bfloat16):
+        for _ in range(4):
+            busy = busy @ busy * 1e-3                 # keeps the main stream behind: the forked streams would run ahead of a cold cache fill
+        cold = split_forward(m, img, parts)
+        torch.cuda.synchronize()
+        seq = torch.cat([m(xi) for xi in img.chunk(parts)])
+        assert torch.equal(cold, seq), float((cold.float() - seq.float()).abs().max())
+        M.new_training_pass()                          # stamps move: every cache is rebuilt by the next pass
+        for _ in range(4):
+            busy = busy @ busy * 1e-3
+        cold2 = split_forward(m, img, parts)
+        torch.cuda.synchronize()
+        assert torch.equal(cold2, seq), float((cold2.float() - seq.float()).abs().max())
+
+
 @pytest.mark.parametrize("name", ["model_tiny_224", "model_base_224", "model_small_v2_224", "model_tiny_v2_224"])
 def test_fused_inference_path(golden, name, monkeypatch):
     """The inference schedule with LayerNorm folded into the projections and the one-kernel MLP half (lmv_ln_linear_fwd /

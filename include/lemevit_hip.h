@@ -412,7 +412,7 @@ int lmv_block_bwd(const lmv_block_desc* d, const void* x, const void* c, const v
  *     mlp.0 [4C, C], mlp.3 [C, 4C], pos_embed.weight [C, 9]) -> `wpk_out` (lmv_sstage_wpk_bytes: the matrices in MFMA-fragment order) and
  *     `vec_out` (lmv_sstage_vec_floats fp32).  The packed blocks of a stage are consecutive: block j at wpk + j * wpk_bytes, vec + j * vec_floats.
  *   lmv_sstage_fwd: x_out / c_out may alias x / c.  `workspace` (lmv_sstage_workspace_bytes(min(B, 128))) holds the K / V fragments and the
- *     grid rows the two halves of an image exchange, and their flags (reset by the call on `stream`).  The launch needs 2 * min(B, 128)
+ *     grid rows the two halves of an image exchange, the parked residual registers, and the flags (reset by the call on `stream`).  The launch needs 2 * min(B, 128)
  *     co-resident workgroups of 512 threads / 147 KB LDS (one per CU): it must not be issued while another kernel of the same kind runs
  *     on a different stream of the same device.
  * ------------------------------------------------------------------------------------------ */
@@ -427,7 +427,7 @@ typedef struct lmv_sstage_desc {
   int32_t B, H, W, M, C, heads, hidden, nblocks, dtype;
   float eps;                                       /* LayerNorm eps of norm1 / norm2 (1e-6) */
   const void* wpk; const float* vec;               /* nblocks packed blocks (lmv_sstage_pack) */
-  void* timing; int32_t timing_block, _pad;        /* optional (NULL): uint64 s_memtime stamps [workgroup][8 waves][16] of block `timing_block` (tools/sstage_timeline.py) */
+  void* timing; int32_t timing_block, _pad;        /* optional (NULL): uint64 s_memtime stamps [workgroup][8 waves][24] of block `timing_block` (tools/sstage_timeline.py) */
 } lmv_sstage_desc;
 int lmv_sstage_supported(int C, int heads, int hidden, int H, int W, int M, int dtype);
 size_t lmv_sstage_wpk_bytes(int C, int hidden);

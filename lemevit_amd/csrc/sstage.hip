@@ -62,19 +62,29 @@ constexpr int L_XN = 0, L_XN_BYTES = SS_KS * SS_NT * 1024;        // token opera
 constexpr int L_H = L_XN_BYTES, L_H_BYTES = SS_KSC * SS_NT * 1024;   // hidden chunk (token operand of fc2); second-head q fragments during attention
 constexpr int L_STAT = L_H + L_H_BYTES, L_STAT_BYTES = 8 * 112 * 8;  // LayerNorm partial sums [wave][slot] float2
 constexpr int L_TOTAL = L_STAT + L_STAT_BYTES;                        // 150 528 B
-constexpr int STG_ROW = 96, STG_WAVE = 156 * STG_ROW;                 // dwconv staging: per wave [15 guard + 126 tokens + 15 guard][48 channels] bf16 (over L_XN | L_H)
+constexpr int STG_ROW = 96, STG_WAVE = 160 * STG_ROW;                 // dwconv staging: per wave [10 grid rows][16 columns][48 channels] bf16 (over L_XN | L_H)
 static_assert(8 * STG_WAVE <= L_STAT, "staging overlaps the statistics");
 // workspace
 constexpr size_t KBUF_IMG = (size_t)SS_NH * 14 * 1024;      // [head][14 key tiles: image 0..12, meta 13][1 KB]
 constexpr size_t VBUF_IMG = (size_t)SS_NH * 8 * 2 * 1024;   // [head][8 key-tile pairs: half 0 p0..3, half 1 p0..3][2 d-tiles][1 KB], fp16
 constexpr size_t HALO_IMG = (size_t)2 * 14 * SS_C * 2;      // [half][14 tokens][C] bf16
+constexpr size_t PARK_IMG = (size_t)2 * 8 * 21 * 1024;      // [half][wave][21 residual tiles][1 KB]: the fp32 residual registers, parked in L2 while k / v / q / attention run
 constexpr unsigned SPIN_LIMIT = 1u << 22;
-constexpr int SS_NSTAMP = 16;
+constexpr int SS_NSTAMP = 24;
+#ifndef SS_DWFENCE
+#define SS_DWFENCE 1
+#endif
+#ifndef SS_QFENCE
+#define SS_QFENCE 2
+#endif
+#ifndef SS_LDAUX
+#define SS_LDAUX 16      // sc1: the K / V fragments another workgroup wrote inside this launch (Guideline 16, R1)
+#endif
 
 struct SsArgs {
   const bf16_t* x_in; const bf16_t* c_in; bf16_t* x_out; bf16_t* c_out;
   const uint4* wpk; const float* vec;
-  unsigned char* kbuf; unsigned char* vbuf; unsigned char* halo; unsigned* flags;     // flags: [2 B] kv | [2 B] halo | [1] error
+  unsigned char* kbuf; unsigned char* vbuf; unsigned char* halo; unsigned char* park; unsigned* flags;     // flags: [2 B] kv | [2 B] halo | [1] error
   int B, nblocks; float eps;
   unsigned long long* timing; int timing_block;      // optional (NULL): s_memtime stamps [workgroup][wave][SS_NSTAMP] of one block
 };
@@ -87,9 +97,11 @@ __device__ __forceinline__ unsigned pack_h2(float lo, float hi) { return __built
 __device__ __forceinline__ u32x4_t pack_bf8(const f32x4_t& a, const f32x4_t& b) {
   return u32x4_t{pack_bf2(a[0], a[1]), pack_bf2(a[2], a[3]), pack_bf2(b[0], b[1]), pack_bf2(b[2], b[3])};
 }
-__device__ __forceinline__ float max4(const f32x4_t& s) { return fmaxf(fmaxf(s[0], s[1]), fmaxf(s[2], s[3])); }
+// max without the canonicalising v_max x, x that fmaxf costs under IEEE mode: v_med3(a, b, +inf) = max(a, b) for non-NaN inputs
+__device__ __forceinline__ float max2(float a, float b) { return __builtin_amdgcn_fmed3f(a, b, INFINITY); }
+__device__ __forceinline__ float max4(const f32x4_t& s) { return max2(max2(s[0], s[1]), max2(s[2], s[3])); }
 __device__ __forceinline__ float xsum4(float v) { v += __shfl_xor(v, 16, 64); v += __shfl_xor(v, 32, 64); return v; }      // over the 4 lane groups of a token
-__device__ __forceinline__ float xmax4(float v) { v = fmaxf(v, __shfl_xor(v, 16, 64)); v = fmaxf(v, __shfl_xor(v, 32, 64)); return v; }
+__device__ __forceinline__ float xmax4(float v) { v = max2(v, __shfl_xor(v, 16, 64)); v = max2(v, __shfl_xor(v, 32, 64)); return v; }
 
 // one lane polls a flag word until it reaches `epoch` (relaxed agent-scope loads + s_sleep); a bounded spin reports through flags[err]
 __device__ __forceinline__ void wait_flag(unsigned* flag, unsigned epoch, unsigned* err, int lane) {
@@ -106,6 +118,26 @@ __device__ __forceinline__ void wait_flag(unsigned* flag, unsigned epoch, unsign
   do {                                                                                                           \
     if (a.timing && blk == a.timing_block && lane == 0) a.timing[((size_t)blockIdx.x * 8 + wave) * SS_NSTAMP + (k)] = __builtin_amdgcn_s_memtime(); \
   } while (0)
+
+// gelu_poly2 (common.h) on the 8 pre-activations of one D tile pair at once, the four Horner chains interleaved statement by statement: a dependent
+// packed op waits a state for its predecessor, and hipcc does not interleave the chains on its own (it emitted them serially with an s_nop each)
+__device__ __forceinline__ void gelu4(f32x2_t& a, f32x2_t& b, f32x2_t& c, f32x2_t& d) {
+  f32x2_t sa = a * 0.25f, sb = b * 0.25f, sc = c * 0.25f, sd = d * 0.25f;
+  sa[0] = __builtin_amdgcn_fmed3f(sa[0], -1.0f, 1.0f); sb[0] = __builtin_amdgcn_fmed3f(sb[0], -1.0f, 1.0f);
+  sc[0] = __builtin_amdgcn_fmed3f(sc[0], -1.0f, 1.0f); sd[0] = __builtin_amdgcn_fmed3f(sd[0], -1.0f, 1.0f);
+  sa[1] = __builtin_amdgcn_fmed3f(sa[1], -1.0f, 1.0f); sb[1] = __builtin_amdgcn_fmed3f(sb[1], -1.0f, 1.0f);
+  sc[1] = __builtin_amdgcn_fmed3f(sc[1], -1.0f, 1.0f); sd[1] = __builtin_amdgcn_fmed3f(sd[1], -1.0f, 1.0f);
+  const f32x2_t ua = sa * sa, ub = sb * sb, uc = sc * sc, ud = sd * sd;
+  f32x2_t qa = {-1.6300047636032104f, -1.6300047636032104f}, qb = qa, qc = qa, qd = qa;
+#define SS_GSTEP(k)                                                                                                   \
+  qa = __builtin_elementwise_fma(qa, ua, f32x2_t{k, k}); qb = __builtin_elementwise_fma(qb, ub, f32x2_t{k, k});       \
+  qc = __builtin_elementwise_fma(qc, uc, f32x2_t{k, k}); qd = __builtin_elementwise_fma(qd, ud, f32x2_t{k, k})
+  SS_GSTEP(7.93373966217041f); SS_GSTEP(-16.877059936523438f); SS_GSTEP(20.921268463134766f); SS_GSTEP(-17.09065055847168f);
+  SS_GSTEP(9.8812894821167f); SS_GSTEP(-4.233964920043945f); SS_GSTEP(1.595382571220398f);
+#undef SS_GSTEP
+  a = a * __builtin_elementwise_fma(sa, qa, f32x2_t{0.5f, 0.5f}); b = b * __builtin_elementwise_fma(sb, qb, f32x2_t{0.5f, 0.5f});
+  c = c * __builtin_elementwise_fma(sc, qc, f32x2_t{0.5f, 0.5f}); d = d * __builtin_elementwise_fma(sd, qd, f32x2_t{0.5f, 0.5f});
+}
 
 // ---- one GEMM unit: NC output-channel tiles x all 7 token tiles x NKS k-steps ------------------------------------------------------
 // ring: the wave's weight fragments, RD - 1 k-steps ahead, straight from L2 (w: wave-uniform byte pointer to fragment 0 of the unit, fragments
@@ -150,6 +182,9 @@ __device__ __forceinline__ void layer_norm_to_lds(const f32x4_t (&R)[SS_NT][3], 
     s1 = xsum4(s1); s2 = xsum4(s2);
     if (g == 0) stat[wave * 112 + t * 16 + li] = make_float2(s1, s2);
   }
+  float4 ga[3], be[3];        // requested ahead of the barrier
+#pragma unroll
+  for (int ct = 0; ct < 3; ++ct) { ga[ct] = *reinterpret_cast<const float4*>(gam + 48 * wave + 16 * ct + 4 * g); be[ct] = *reinterpret_cast<const float4*>(bet + 48 * wave + 16 * ct + 4 * g); }
   __syncthreads();
   float mean[SS_NT], rstd[SS_NT];
 #pragma unroll
@@ -162,84 +197,100 @@ __device__ __forceinline__ void layer_norm_to_lds(const f32x4_t (&R)[SS_NT][3], 
   }
 #pragma unroll
   for (int ct = 0; ct < 3; ++ct) {
-    const int c0 = 48 * wave + 16 * ct + 4 * g, T = 3 * wave + ct;
-    const float4 ga = *reinterpret_cast<const float4*>(gam + c0), be = *reinterpret_cast<const float4*>(bet + c0);
+    const int T = 3 * wave + ct;
 #pragma unroll
     for (int t = 0; t < SS_NT; ++t) {
-      const float y0 = fmaf((R[t][ct][0] - mean[t]) * rstd[t], ga.x, be.x), y1 = fmaf((R[t][ct][1] - mean[t]) * rstd[t], ga.y, be.y);
-      const float y2 = fmaf((R[t][ct][2] - mean[t]) * rstd[t], ga.z, be.z), y3 = fmaf((R[t][ct][3] - mean[t]) * rstd[t], ga.w, be.w);
+      const float y0 = fmaf((R[t][ct][0] - mean[t]) * rstd[t], ga[ct].x, be[ct].x), y1 = fmaf((R[t][ct][1] - mean[t]) * rstd[t], ga[ct].y, be[ct].y);
+      const float y2 = fmaf((R[t][ct][2] - mean[t]) * rstd[t], ga[ct].z, be[ct].z), y3 = fmaf((R[t][ct][3] - mean[t]) * rstd[t], ga[ct].w, be[ct].w);
       *reinterpret_cast<uint2*>(smem + L_XN + (((T >> 1) * SS_NT + t) * 64 + lane) * 16 + (T & 1) * 8) = make_uint2(pack_bf2(y0, y1), pack_bf2(y2, y3));
     }
   }
   __syncthreads();
 }
 
-// ---- attention of one head for NQ image-query tiles (keys: the 196 image tokens, 13 key tiles) ------------------------------------------
+// ---- attention of one head for the NQ image-query tiles T0 .. T0 + NQ - 1 (keys: the 196 image tokens, 13 key tiles) ------------------------
 // Qf: B operands (q scaled by log2 e / sqrt d, bf16); K fragments [head][key tile], V fragments [head][pair slot][d-tile] from the exchange
-// buffers (sc1 loads).  Writes the normalised output as the proj operand fragment (k-step = head) of each query tile.
-template <int NQ>
+// buffers.  All 13 K fragments of the head are requested at once and stay in registers for both passes (row maximum; exp2 / sum / P V with S
+// recomputed), the V fragments run three steps ahead -- every loop is fully unrolled so that no fragment is ever copied between registers: a
+// rotating-register form made hipcc wait for the newest load at the top of every step, which exposed one L2 round trip per key tile.  (The
+// residual registers are parked in L2 during this phase: K alone is 52 registers.)  A head runs as two groups of query tiles (4 + 3).
+template <int T0, int NQ>
 __device__ __forceinline__ void attn_image(const bf16x8_t (&Qf)[SS_NT], int h, __amdgpu_buffer_rsrc_t kr, __amdgpu_buffer_rsrc_t vr, unsigned char* smem, int lane) {
   const int g = lane >> 4;
   const int kbase = (h * 14 * 64 + lane) * 16, vbase = (h * 16 * 64 + lane) * 16;
   const f32x4_t z4 = {0.f, 0.f, 0.f, 0.f};
+  u32x4_t K[13], V[7][2];
+#pragma unroll
+  for (int kt = 0; kt < 13; ++kt) K[kt] = __builtin_amdgcn_raw_buffer_load_b128(kr, kbase + kt * 1024, 0, SS_LDAUX);
+#pragma unroll
+  for (int s = 0; s < 3; ++s) { V[s][0] = __builtin_amdgcn_raw_buffer_load_b128(vr, vbase + (s * 2) * 1024, 0, SS_LDAUX); V[s][1] = __builtin_amdgcn_raw_buffer_load_b128(vr, vbase + (s * 2 + 1) * 1024, 0, SS_LDAUX); }
   float mx[NQ];
 #pragma unroll
   for (int q = 0; q < NQ; ++q) mx[q] = -INFINITY;
-  u32x4_t kf = __builtin_amdgcn_raw_buffer_load_b128(kr, kbase, 0, 16);
-#pragma unroll 1
+#pragma unroll
   for (int kt = 0; kt < 13; ++kt) {
-    const u32x4_t kn = __builtin_amdgcn_raw_buffer_load_b128(kr, kbase + min(kt + 1, 12) * 1024, 0, 16);
-    const bool cut = kt == 12 && g != 0;        // key tile 12: only keys 192..195 (rows 0..3 = lane group 0) exist
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
-      const f32x4_t s = mfma_bf16(as_bf8(kf), Qf[q], z4);
+      const f32x4_t s = mfma_bf16(as_bf8(K[kt]), Qf[T0 + q], z4);
       const float m = max4(s);
-      mx[q] = fmaxf(mx[q], cut ? -INFINITY : m);
+      mx[q] = max2(mx[q], (kt == 12 && g != 0) ? -INFINITY : m);        // key tile 12: only keys 192..195 (rows 0..3 = lane group 0) exist
     }
-    kf = kn;
+    if (kt % 2 == 1) __builtin_amdgcn_sched_barrier(0);
   }
 #pragma unroll
   for (int q = 0; q < NQ; ++q) mx[q] = xmax4(mx[q]);
+  // the second pass RECOMPUTES the score tiles: without these opaque copies the compiler recognises the first pass's MFMAs and keeps all 13 x NQ
+  // score tiles (208 registers at NQ = 4) alive instead
+#pragma unroll
+  for (int kt = 0; kt < 13; ++kt) asm volatile("" : "+v"(K[kt]));
   f32x4_t O[NQ][2];
   float l[NQ];
 #pragma unroll
   for (int q = 0; q < NQ; ++q) { O[q][0] = z4; O[q][1] = z4; l[q] = 0.f; }
-#pragma unroll 1
+  // key tiles (ta, tb) of step s and their V pair slot: half-0 pairs (0,1) (2,3) (4,5) (6,-), half-1 pairs (7,8) (9,10) (11,12)
+#pragma unroll
   for (int s = 0; s < 7; ++s) {
-    // key tiles (ta, tb) of step s and their V pair slot: half-0 pairs (0,1) (2,3) (4,5) (6,-), half-1 pairs (7,8) (9,10) (11,12)
+    if (s + 3 < 7) { V[s + 3][0] = __builtin_amdgcn_raw_buffer_load_b128(vr, vbase + ((s + 3) * 2) * 1024, 0, SS_LDAUX); V[s + 3][1] = __builtin_amdgcn_raw_buffer_load_b128(vr, vbase + ((s + 3) * 2 + 1) * 1024, 0, SS_LDAUX); }
     const int ta = s < 4 ? 2 * s : 2 * s - 1;
-    const bool dummy = s == 3, cutb = s == 6 && g != 0;
-    const u32x4_t ka = __builtin_amdgcn_raw_buffer_load_b128(kr, kbase + ta * 1024, 0, 16);
-    const u32x4_t kb = __builtin_amdgcn_raw_buffer_load_b128(kr, kbase + (dummy ? ta : ta + 1) * 1024, 0, 16);
-    const u32x4_t v0 = __builtin_amdgcn_raw_buffer_load_b128(vr, vbase + (s * 2 + 0) * 1024, 0, 16);
-    const u32x4_t v1 = __builtin_amdgcn_raw_buffer_load_b128(vr, vbase + (s * 2 + 1) * 1024, 0, 16);
+    const bool dummy = s == 3;
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
-      const f32x4_t sa = mfma_bf16(as_bf8(ka), Qf[q], z4), sb = mfma_bf16(as_bf8(kb), Qf[q], z4);
-      const float mb = (dummy || cutb) ? INFINITY : mx[q];      // exp2(s - inf) = 0: absent keys
+      const f32x4_t sa = mfma_bf16(as_bf8(K[ta]), Qf[T0 + q], z4);
       float p[8];
 #pragma unroll
-      for (int r = 0; r < 4; ++r) { p[r] = __builtin_amdgcn_exp2f(sa[r] - mx[q]); p[4 + r] = __builtin_amdgcn_exp2f(sb[r] - mb); }
+      for (int r = 0; r < 4; ++r) p[r] = __builtin_amdgcn_exp2f(sa[r] - mx[q]);
+      if (!dummy) {
+        const f32x4_t sb = mfma_bf16(as_bf8(K[ta + 1]), Qf[T0 + q], z4);
+        const float mb = (s == 6 && g != 0) ? INFINITY : mx[q];      // exp2(s - inf) = 0: absent keys
+#pragma unroll
+        for (int r = 0; r < 4; ++r) p[4 + r] = __builtin_amdgcn_exp2f(sb[r] - mb);
+      } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) p[4 + r] = 0.f;
+      }
       l[q] += ((p[0] + p[1]) + (p[2] + p[3])) + ((p[4] + p[5]) + (p[6] + p[7]));
+      asm volatile("" : "+v"(l[q]));        // summed HERE: LLVM otherwise sinks all row sums to their use behind the last step and keeps every p alive until then
       const u32x4_t pk = {pack_h2(p[0], p[1]), pack_h2(p[2], p[3]), pack_h2(p[4], p[5]), pack_h2(p[6], p[7])};
       const f16x8_t pf = __builtin_bit_cast(f16x8_t, pk);
-      O[q][0] = mfma_f16(__builtin_bit_cast(f16x8_t, v0), pf, O[q][0]);
-      O[q][1] = mfma_f16(__builtin_bit_cast(f16x8_t, v1), pf, O[q][1]);
+      O[q][0] = mfma_f16(__builtin_bit_cast(f16x8_t, V[s][0]), pf, O[q][0]);
+      O[q][1] = mfma_f16(__builtin_bit_cast(f16x8_t, V[s][1]), pf, O[q][1]);
+      if (q % SS_QFENCE == SS_QFENCE - 1) __builtin_amdgcn_sched_barrier(0);      // unfenced, the scheduler pulls every V request to the top and interleaves all steps and tiles (spills)
     }
+    __builtin_amdgcn_sched_barrier(0);
   }
 #pragma unroll
   for (int q = 0; q < NQ; ++q) {
     const float inv = 1.f / xsum4(l[q]);
     const u32x4_t o = pack_bf8(O[q][0] * inv, O[q][1] * inv);
-    *reinterpret_cast<u32x4_t*>(smem + L_XN + ((h * SS_NT + q) * 64 + lane) * 16) = o;
+    *reinterpret_cast<u32x4_t*>(smem + L_XN + ((h * SS_NT + T0 + q) * 64 + lane) * 16) = o;
   }
 }
 // the 16 meta queries of half 1 (token tile 6) against the 16 meta keys (key tile 13, V pair slot 7)
 __device__ __forceinline__ void attn_meta(const bf16x8_t& Qf, int h, __amdgpu_buffer_rsrc_t kr, __amdgpu_buffer_rsrc_t vr, unsigned char* smem, int lane) {
   const int kbase = (h * 14 * 64 + lane) * 16, vbase = (h * 16 * 64 + lane) * 16;
   const f32x4_t z4 = {0.f, 0.f, 0.f, 0.f};
-  const u32x4_t kf = __builtin_amdgcn_raw_buffer_load_b128(kr, kbase + 13 * 1024, 0, 16);
-  const u32x4_t v0 = __builtin_amdgcn_raw_buffer_load_b128(vr, vbase + 14 * 1024, 0, 16), v1 = __builtin_amdgcn_raw_buffer_load_b128(vr, vbase + 15 * 1024, 0, 16);
+  const u32x4_t kf = __builtin_amdgcn_raw_buffer_load_b128(kr, kbase + 13 * 1024, 0, SS_LDAUX);
+  const u32x4_t v0 = __builtin_amdgcn_raw_buffer_load_b128(vr, vbase + 14 * 1024, 0, 16), v1 = __builtin_amdgcn_raw_buffer_load_b128(vr, vbase + 15 * 1024, 0, SS_LDAUX);
   const f32x4_t s = mfma_bf16(as_bf8(kf), Qf, z4);
   const float m = xmax4(max4(s));
   float p[4];
@@ -304,19 +355,33 @@ __global__ __launch_bounds__(512, 2) void sstage_kernel(const SsArgs a) {
     SS_STAMP(0);
     asm volatile("; PHASE_DWCONV" ::: "memory");
     // ---- x += dwconv3x3(x) + bias on the 14 x 14 grid (models/lemevit.py:619): the wave's 48 channels of its tokens and of the one grid
-    //      row across the cut go through a wave-private bf16 staging image; taps read bf16, the sum is added to the fp32 residual ----
+    //      row across the cut go through a wave-private fp16 staging image; taps read fp16 (v_fma_mix_f32), the sum is added to the fp32 residual ----
     {
       SS_PHASE
-      // staging rows: [15 guard][own rows and the 14 halo rows, in token order][15 guard]: every tap is base + an immediate offset
+      // staging image of the wave's 48 channels: [10 grid rows: the row above, <= 8 own rows, the row below][16 columns: zero | x = 0..13 | zero],
+      // 96 B per entry.  The row across the cut comes from the peer, the row beyond the grid and the two pad columns are zero-filled: every
+      // tap is then an unconditional read at base + an immediate offset, no bounds masks (they were half of this phase's VALU work).
       unsigned char* const stg = smem + wave * STG_WAVE;
-      const int own0 = half ? 29 : 15, halo0 = half ? 15 : 127;
 #pragma unroll
       for (int t = 0; t < SS_NT; ++t) {
         const int slot = 16 * t + li;
         if (slot < nimg_slots) {
+          const int y = slot / SS_G, x = slot - y * SS_G;
 #pragma unroll
           for (int ct = 0; ct < 3; ++ct)
-            *reinterpret_cast<uint2*>(stg + (own0 + slot) * STG_ROW + 32 * ct + 8 * g) = make_uint2(pack_bf2(R[t][ct][0], R[t][ct][1]), pack_bf2(R[t][ct][2], R[t][ct][3]));
+            *reinterpret_cast<uint2*>(stg + ((y + 1) * 16 + x + 1) * STG_ROW + 32 * ct + 8 * g) = make_uint2(pack_h2(R[t][ct][0], R[t][ct][1]), pack_h2(R[t][ct][2], R[t][ct][3]));
+        }
+      }
+      {
+        const int grow = half ? 7 : 0;           // the grid row beyond the image: zeros
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+          const int p = lane + 64 * it;
+          if (p < 36 * 6) {
+            const int e = p / 6, q = p - e * 6;
+            const int idx = e < 20 ? (e >> 1) * 16 + (e & 1) * 15 : grow * 16 + (e - 20);
+            *reinterpret_cast<u32x4_t*>(stg + idx * STG_ROW + 16 * q) = u32x4_t{0u, 0u, 0u, 0u};
+          }
         }
       }
       SS_STAMP(13);
@@ -325,53 +390,71 @@ __global__ __launch_bounds__(512, 2) void sstage_kernel(const SsArgs a) {
         if (blk == 0) hsrc = reinterpret_cast<const unsigned char*>(a.x_in + ((size_t)img * SS_NIMG + (half ? 98 : 112)) * SS_C);
         else { wait_flag(haloflag_peer, (unsigned)blk, errflag, lane); hsrc = a.halo + (size_t)img * HALO_IMG + (size_t)(1 - half) * 14 * SS_C * 2; }
         const __amdgpu_buffer_rsrc_t hr = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(hsrc), 0, 14 * SS_C * 2, 0x00020000);
+        const int hrow = half ? 0 : 9;
 #pragma unroll
         for (int it = 0; it < 2; ++it) {
           const int p = lane + 64 * it;
           if (p < 84) {
             const int tok = p / 6, q = p - tok * 6;
             const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(hr, tok * SS_C * 2 + (48 * wave + 8 * q) * 2, 0, 16);
-            *reinterpret_cast<u32x4_t*>(stg + (halo0 + tok) * STG_ROW + 16 * q) = v;
+            u32x4_t hv;          // bf16 pairs -> fp16 pairs (the image is fp16: v_fma_mix reads it without an unpack)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) hv[e] = pack_h2(__uint_as_float(v[e] << 16), __uint_as_float(v[e] & 0xffff0000u));
+            *reinterpret_cast<u32x4_t*>(stg + (hrow * 16 + tok + 1) * STG_ROW + 16 * q) = hv;
           }
         }
       }
       SS_STAMP(14);
+      float4 wq[2][10];          // the 4 x 9 tap weights + bias of the lane's channels, one channel tile ahead (an L2 round trip per tile otherwise)
+#pragma unroll
+      for (int e = 0; e < 9; ++e) wq[0][e] = *reinterpret_cast<const float4*>(vec + V_POSW + (48 * wave + 4 * g) * 9 + 4 * e);
+      wq[0][9] = *reinterpret_cast<const float4*>(vec + V_POSB + 48 * wave + 4 * g);
 #pragma unroll
       for (int ct = 0; ct < 3; ++ct) {
-        int l2 = lane; asm volatile("" : "+v"(l2));      // per-channel-tile copies: the per-token masks and addresses are recomputed, not kept across the three passes
+        int l2 = lane; asm volatile("" : "+v"(l2));      // per-channel-tile copies: the per-token addresses are recomputed, not kept across the three passes
         const int g = l2 >> 4, li = l2 & 15;
-        const unsigned char* const tap0 = stg + (own0 + li - 15) * STG_ROW + 8 * g;      // tap (dy, dx) of tile t: + (16 t + 15 + 14 dy + dx) * 96 + 32 ct
-        const int c0 = 48 * wave + 16 * ct + 4 * g;
+        if (ct + 1 < 3) {
+          const int c1 = 48 * wave + 16 * (ct + 1) + 4 * g;
+#pragma unroll
+          for (int e = 0; e < 9; ++e) wq[(ct + 1) & 1][e] = *reinterpret_cast<const float4*>(vec + V_POSW + c1 * 9 + 4 * e);
+          wq[(ct + 1) & 1][9] = *reinterpret_cast<const float4*>(vec + V_POSB + c1);
+        }
         float wt[36];
 #pragma unroll
-        for (int e = 0; e < 9; ++e) {
-          const float4 v = *reinterpret_cast<const float4*>(vec + V_POSW + c0 * 9 + 4 * e);
-          wt[4 * e] = v.x; wt[4 * e + 1] = v.y; wt[4 * e + 2] = v.z; wt[4 * e + 3] = v.w;
-        }
-        const float4 pb = *reinterpret_cast<const float4*>(vec + V_POSB + c0);
+        for (int e = 0; e < 9; ++e) { const float4 v = wq[ct & 1][e]; wt[4 * e] = v.x; wt[4 * e + 1] = v.y; wt[4 * e + 2] = v.z; wt[4 * e + 3] = v.w; }
+        const float4 pb = wq[ct & 1][9];
 #pragma unroll
         for (int t = 0; t < SS_NT; ++t) {
-          // which of the 3 x 3 taps of this token fall inside the 14 x 14 grid
-          const int slot = 16 * t + li, tk = tok0 + slot, y = tk / SS_G, x = tk - y * SS_G;
+          const int slot = 16 * t + li;
           const bool valid = slot < nimg_slots;
-          const bool yo[3] = {y > 0, true, y < SS_G - 1}, xo[3] = {x > 0, true, x < SS_G - 1};
+          const int sv = valid ? slot : 0, y = sv / SS_G, x = sv - y * SS_G;
+          const unsigned char* const tap0 = stg + (y * 16 + x) * STG_ROW + 32 * ct + 8 * g;      // entry of the (-1, -1) neighbour; tap (dy, dx): + ((dy + 1) * 16 + dx + 1) * 96
           float acc[4] = {pb.x, pb.y, pb.z, pb.w};
+          // all 9 taps are requested before the first is used (one at a time, hipcc reused one register pair and waited out an LDS round trip per
+          // tap); v_fma_mix_f32 then takes the fp16 operand straight from either half of a loaded pair: one instruction per tap and channel
+          // (bf16 taps cost four unpack operations + two packed FMAs; hipcc itself converts and packs instead of selecting the mixed form)
+          uint2 f[9];
+#pragma unroll
+          for (int tap = 0; tap < 9; ++tap) f[tap] = *reinterpret_cast<const uint2*>(tap0 + ((tap / 3) * 16 + tap % 3) * STG_ROW);
+#pragma unroll
+          for (int tap = 0; tap < 9; ++tap) asm volatile("" : "+v"(f[tap]));
 #pragma unroll
           for (int tap = 0; tap < 9; ++tap) {
-            const int dy = tap / 3 - 1, dx = tap % 3 - 1;
-            float f[4];
-            ld4(reinterpret_cast<const bf16_t*>(tap0 + (16 * t + 15 + SS_G * dy + dx) * STG_ROW + 32 * ct), f);
-            const bool ok = yo[dy + 1] && xo[dx + 1];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) acc[r] = fmaf(wt[r * 9 + tap], ok ? f[r] : 0.f, acc[r]);
+            asm("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "+v"(acc[0]) : "v"(f[tap].x), "v"(wt[0 * 9 + tap]));
+            asm("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(acc[1]) : "v"(f[tap].x), "v"(wt[1 * 9 + tap]));
+            asm("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "+v"(acc[2]) : "v"(f[tap].y), "v"(wt[2 * 9 + tap]));
+            asm("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(acc[3]) : "v"(f[tap].y), "v"(wt[3 * 9 + tap]));
           }
 #pragma unroll
           for (int r = 0; r < 4; ++r) R[t][ct][r] += valid ? acc[r] : 0.f;
           // one token tile's 9 taps at a time, finished here: otherwise LLVM sinks the FMA chains to the first use of R (the LayerNorm) and
           // keeps all 189 loaded taps alive (in scratch) until then
           asm volatile("" : "+v"(R[t][ct]));
-          __builtin_amdgcn_sched_barrier(0);
+          if (t % SS_DWFENCE == SS_DWFENCE - 1) __builtin_amdgcn_sched_barrier(0);
+          if (ct == 0 && t == 0) SS_STAMP(21);
+          if (ct == 0 && t == 1) SS_STAMP(22);
         }
+        if (ct == 0) SS_STAMP(23);
       }
     }
 
@@ -383,6 +466,13 @@ __global__ __launch_bounds__(512, 2) void sstage_kernel(const SsArgs a) {
       SS_PHASE
       ring_fill<2, 3>(ring2, wp + (size_t)(WS_KV + (3 * wave) * 24) * 1024, lane);       // lands under the LayerNorm
       layer_norm_to_lds(R, vec + V_N1W, vec + V_N1B, a.eps, smem, wave, lane);
+      // the residual is not touched again before proj: its 84 registers go to L2 (a wave-private slab, plain stores) and come back behind the
+      // attention -- k / v / q and the attention (13 K fragments resident per head) get the registers
+      u32x4_t* const pk = reinterpret_cast<u32x4_t*>(a.park + (size_t)img * PARK_IMG + ((size_t)(half * 8 + wave) * 21) * 1024) + lane;
+#pragma unroll
+      for (int t = 0; t < SS_NT; ++t)
+#pragma unroll
+        for (int ct = 0; ct < 3; ++ct) pk[(t * 3 + ct) * 64] = __builtin_bit_cast(u32x4_t, R[t][ct]);
     }
     SS_STAMP(2);
     {
@@ -396,9 +486,9 @@ __global__ __launch_bounds__(512, 2) void sstage_kernel(const SsArgs a) {
 #pragma unroll
         for (int t = 0; t < SS_NT; ++t) { acc[t][0] = f32x4_t{0.f, 0.f, 0.f, 0.f}; acc[t][1] = acc[t][0]; }
         if (!isv) {
-          gemm_unit<2, SS_KS, 3, true>(acc, ring2, wcur, wnext, smem + L_XN, lane);
           const float* bk = vec + V_QKVB + SS_C + 32 * h + 4 * g;
           const float4 b0 = *reinterpret_cast<const float4*>(bk), b1 = *reinterpret_cast<const float4*>(bk + 16);
+          gemm_unit<2, SS_KS, 3, true>(acc, ring2, wcur, wnext, smem + L_XN, lane);
 #pragma unroll
           for (int t = 0; t < SS_NT; ++t) {
             const int kt = half ? (t < 6 ? 7 + t : 13) : t;
@@ -407,8 +497,8 @@ __global__ __launch_bounds__(512, 2) void sstage_kernel(const SsArgs a) {
             __builtin_amdgcn_raw_buffer_store_b128(pack_bf8(k0, k1), kr, ((h * 14 + kt) * 64 + lane) * 16, 0, 16);
           }
         } else {
-          gemm_unit<2, SS_KS, 3, false>(acc, ring2, wcur, wnext, smem + L_XN, lane);
           const float bv0 = vec[V_QKVB + 2 * SS_C + 32 * h + li], bv1 = vec[V_QKVB + 2 * SS_C + 32 * h + 16 + li];
+          gemm_unit<2, SS_KS, 3, false>(acc, ring2, wcur, wnext, smem + L_XN, lane);
 #pragma unroll
           for (int p = 0; p < 4; ++p)
 #pragma unroll
@@ -442,9 +532,9 @@ __global__ __launch_bounds__(512, 2) void sstage_kernel(const SsArgs a) {
         f32x4_t acc[SS_NT][2];
 #pragma unroll
         for (int t = 0; t < SS_NT; ++t) { acc[t][0] = f32x4_t{0.f, 0.f, 0.f, 0.f}; acc[t][1] = acc[t][0]; }
-        gemm_unit<2, SS_KS, 3, true>(acc, ring2, wcur, wnext, smem + L_XN, lane);
         const float* bq = vec + V_QKVB + 32 * h + 4 * g;
         const float4 b0 = *reinterpret_cast<const float4*>(bq), b1 = *reinterpret_cast<const float4*>(bq + 16);
+        gemm_unit<2, SS_KS, 3, true>(acc, ring2, wcur, wnext, smem + L_XN, lane);
         constexpr float QS = 0.25503486f;      // log2(e) / sqrt(32): softmax(q k^T / sqrt d) as exp2 of the scores (models/lemevit.py:203)
 #pragma unroll
         for (int t = 0; t < SS_NT; ++t) {
@@ -465,15 +555,20 @@ __global__ __launch_bounds__(512, 2) void sstage_kernel(const SsArgs a) {
     // ---- attention of the wave's heads -> proj operand in LDS ----
     {
       SS_PHASE
+      // 24 (head, query-tile group) units, three per wave: both groups of head `wave`, and one group of head 8 + (wave & 3) -- whose q fragments
+      // wave (wave & 3) left in LDS: waves 0..3 take its tiles 0..3, waves 4..7 its tiles 4..6 (11 / 10 query tiles per wave)
 #pragma unroll 1
-      for (int hu = 0; hu < nheads; ++hu) {
-        const int h = wave + 8 * hu;
-        if (hu == 1) {
+      for (int u = 0; u < 3; ++u) {
+        const bool third = u == 2;
+        const int h = third ? 8 + (wave & 3) : wave;
+        const bool groupb = third ? wave >= 4 : u == 1;
+        if (third) {
 #pragma unroll
-          for (int t = 0; t < SS_NT; ++t) Qf[t] = *reinterpret_cast<const bf16x8_t*>(smem + L_H + ((wave * SS_NT + t) * 64 + lane) * 16);
+          for (int t = 0; t < SS_NT; ++t) Qf[t] = *reinterpret_cast<const bf16x8_t*>(smem + L_H + (((wave & 3) * SS_NT + t) * 64 + lane) * 16);
         }
-        if (half == 0) attn_image<7>(Qf, h, kr, vr, smem, lane);
-        else { attn_image<6>(Qf, h, kr, vr, smem, lane); attn_meta(Qf[6], h, kr, vr, smem, lane); }
+        if (!groupb) attn_image<0, 4>(Qf, h, kr, vr, smem, lane);
+        else if (half == 0) attn_image<4, 3>(Qf, h, kr, vr, smem, lane);
+        else { attn_image<4, 2>(Qf, h, kr, vr, smem, lane); attn_meta(Qf[6], h, kr, vr, smem, lane); }
       }
     }
     SS_STAMP(7);
@@ -481,6 +576,11 @@ __global__ __launch_bounds__(512, 2) void sstage_kernel(const SsArgs a) {
     {
       SS_PHASE
       ring_fill<3, 4>(ring3, wp + (size_t)(WS_PROJ + wave * 36) * 1024, lane);          // lands under the barrier
+      const u32x4_t* const pk = reinterpret_cast<const u32x4_t*>(a.park + (size_t)img * PARK_IMG + ((size_t)(half * 8 + wave) * 21) * 1024) + lane;
+#pragma unroll
+      for (int t = 0; t < SS_NT; ++t)
+#pragma unroll
+        for (int ct = 0; ct < 3; ++ct) R[t][ct] = __builtin_bit_cast(f32x4_t, pk[(t * 3 + ct) * 64]);
     }
     __syncthreads();
 
@@ -489,14 +589,15 @@ __global__ __launch_bounds__(512, 2) void sstage_kernel(const SsArgs a) {
     // ---- x += proj(attention) + bias: accumulated ON the residual registers ----
     {
       SS_PHASE
+      float4 pbias[3];
 #pragma unroll
-      for (int ct = 0; ct < 3; ++ct) {
-        const float4 b = *reinterpret_cast<const float4*>(vec + V_PROJB + 48 * wave + 16 * ct + 4 * g);
-#pragma unroll
-        for (int t = 0; t < SS_NT; ++t) { R[t][ct][0] += b.x; R[t][ct][1] += b.y; R[t][ct][2] += b.z; R[t][ct][3] += b.w; }
-      }
+      for (int ct = 0; ct < 3; ++ct) pbias[ct] = *reinterpret_cast<const float4*>(vec + V_PROJB + 48 * wave + 16 * ct + 4 * g);
       const unsigned char* wcur = wp + (size_t)(WS_PROJ + wave * 36) * 1024;
       gemm_unit<3, SS_KS, 4, true>(R, ring3, wcur, wcur, smem + L_XN, lane);
+#pragma unroll
+      for (int ct = 0; ct < 3; ++ct)
+#pragma unroll
+        for (int t = 0; t < SS_NT; ++t) { R[t][ct][0] += pbias[ct].x; R[t][ct][1] += pbias[ct].y; R[t][ct][2] += pbias[ct].z; R[t][ct][3] += pbias[ct].w; }
     }
 
     SS_STAMP(9);
@@ -506,12 +607,6 @@ __global__ __launch_bounds__(512, 2) void sstage_kernel(const SsArgs a) {
       SS_PHASE
       ring_fill<2, 3>(ring2, wp + (size_t)(WS_FC1 + wave * 24) * 1024, lane);            // lands under the LayerNorm
       layer_norm_to_lds(R, vec + V_N2W, vec + V_N2B, a.eps, smem, wave, lane);
-#pragma unroll
-      for (int ct = 0; ct < 3; ++ct) {
-        const float4 b = *reinterpret_cast<const float4*>(vec + V_FC2B + 48 * wave + 16 * ct + 4 * g);
-#pragma unroll
-        for (int t = 0; t < SS_NT; ++t) { R[t][ct][0] += b.x; R[t][ct][1] += b.y; R[t][ct][2] += b.z; R[t][ct][3] += b.w; }
-      }
     }
     SS_STAMP(10);
 #pragma unroll 1
@@ -522,26 +617,33 @@ __global__ __launch_bounds__(512, 2) void sstage_kernel(const SsArgs a) {
 #pragma unroll
         for (int t = 0; t < SS_NT; ++t) { acc[t][0] = f32x4_t{0.f, 0.f, 0.f, 0.f}; acc[t][1] = acc[t][0]; }
         const unsigned char* wcur = wp + (size_t)(WS_FC1 + (c * 8 + wave) * 24) * 1024;
-        // the tail of this unit fetches the first k-steps of the NEXT chunk's fc1 (they ride through this chunk's fc2)
-        gemm_unit<2, SS_KS, 3, true>(acc, ring2, wcur, c + 1 < SS_NCHUNK ? wcur + 8 * 24 * 1024 : wcur, smem + L_XN, lane);
-        ring_fill<3, 4>(ring3, wp + (size_t)(WS_FC2 + (c * 8 + wave) * 24) * 1024, lane);      // lands under the GELU pass and the barrier
-        const float* b1p = vec + V_FC1B + 256 * c + 32 * wave + 4 * g;
+        const float* b1p = vec + V_FC1B + 256 * c + 32 * wave + 4 * g;          // (requested ahead of the GEMM: an L2 round trip in the epilogue otherwise)
         const float4 b0 = *reinterpret_cast<const float4*>(b1p), b1 = *reinterpret_cast<const float4*>(b1p + 16);
+        // the tail of this unit fetches the first k-steps of the NEXT chunk's fc1 (they ride through this chunk's fc2)
+        if (c == 2) SS_STAMP(15);
+        gemm_unit<2, SS_KS, 3, true>(acc, ring2, wcur, c + 1 < SS_NCHUNK ? wcur + 8 * 24 * 1024 : wcur, smem + L_XN, lane);
+        if (c == 2) SS_STAMP(16);
+        ring_fill<3, 4>(ring3, wp + (size_t)(WS_FC2 + (c * 8 + wave) * 24) * 1024, lane);      // lands under the GELU pass and the barrier
 #pragma unroll
         for (int t = 0; t < SS_NT; ++t) {
-          const f32x2_t h0 = gelu_poly2(f32x2_t{acc[t][0][0] + b0.x, acc[t][0][1] + b0.y}), h1 = gelu_poly2(f32x2_t{acc[t][0][2] + b0.z, acc[t][0][3] + b0.w});
-          const f32x2_t h2 = gelu_poly2(f32x2_t{acc[t][1][0] + b1.x, acc[t][1][1] + b1.y}), h3 = gelu_poly2(f32x2_t{acc[t][1][2] + b1.z, acc[t][1][3] + b1.w});
+          f32x2_t h0 = {acc[t][0][0] + b0.x, acc[t][0][1] + b0.y}, h1 = {acc[t][0][2] + b0.z, acc[t][0][3] + b0.w};
+          f32x2_t h2 = {acc[t][1][0] + b1.x, acc[t][1][1] + b1.y}, h3 = {acc[t][1][2] + b1.z, acc[t][1][3] + b1.w};
+          gelu4(h0, h1, h2, h3);
           const u32x4_t hf = {pack_bf2(h0[0], h0[1]), pack_bf2(h1[0], h1[1]), pack_bf2(h2[0], h2[1]), pack_bf2(h3[0], h3[1])};
           *reinterpret_cast<u32x4_t*>(smem + L_H + ((wave * SS_NT + t) * 64 + lane) * 16) = hf;
         }
       }
+      if (c == 2) SS_STAMP(17);
       __syncthreads();
+      if (c == 2) SS_STAMP(18);
       {
         SS_PHASE
         const unsigned char* wcur = wp + (size_t)(WS_FC2 + (c * 8 + wave) * 24) * 1024;
         gemm_unit<3, SS_KSC, 4, true>(R, ring3, wcur, wcur, smem + L_H, lane);
       }
+      if (c == 2) SS_STAMP(19);
       if (c + 1 < SS_NCHUNK) __syncthreads();
+      if (c == 2) SS_STAMP(20);
     }
 
     SS_STAMP(11);
@@ -549,6 +651,12 @@ __global__ __launch_bounds__(512, 2) void sstage_kernel(const SsArgs a) {
     // ---- block end: pad slots stay zero; the grid row next to the cut goes to the peer (next block's position embedding) ----
     {
       SS_PHASE
+#pragma unroll
+      for (int ct = 0; ct < 3; ++ct) {        // + mlp.3.bias
+        const float4 b = *reinterpret_cast<const float4*>(vec + V_FC2B + 48 * wave + 16 * ct + 4 * g);
+#pragma unroll
+        for (int t = 0; t < SS_NT; ++t) { R[t][ct][0] += b.x; R[t][ct][1] += b.y; R[t][ct][2] += b.z; R[t][ct][3] += b.w; }
+      }
       if (half) {
 #pragma unroll
         for (int ct = 0; ct < 3; ++ct)
@@ -623,7 +731,7 @@ size_t lmv_sstage_wpk_bytes(int C, int hidden) { (void)C; (void)hidden; return (
 size_t lmv_sstage_vec_floats(int C, int hidden) { (void)C; (void)hidden; return (size_t)V_FLOATS; }
 size_t lmv_sstage_workspace_bytes(int B) {
   const size_t flags = ((size_t)(4 * B + 1) * 4 + 1023) & ~(size_t)1023;
-  return flags + (size_t)B * (KBUF_IMG + VBUF_IMG + HALO_IMG);
+  return flags + (size_t)B * (KBUF_IMG + VBUF_IMG + HALO_IMG + PARK_IMG);
 }
 
 int lmv_sstage_pack(const lmv_sstage_block_params* p, void* wpk_out, float* vec_out, void* stream) {
@@ -671,7 +779,7 @@ int lmv_sstage_fwd(const lmv_sstage_desc* d, const void* x, const void* c, void*
     a.x_in = (const bf16_t*)x + (size_t)b0 * SS_NIMG * SS_C; a.c_in = (const bf16_t*)c + (size_t)b0 * SS_M * SS_C;
     a.x_out = (bf16_t*)x_out + (size_t)b0 * SS_NIMG * SS_C; a.c_out = (bf16_t*)c_out + (size_t)b0 * SS_M * SS_C;
     a.wpk = (const uint4*)d->wpk; a.vec = d->vec;
-    a.flags = (unsigned*)ws; a.kbuf = ws + flags; a.vbuf = a.kbuf + (size_t)nb * KBUF_IMG; a.halo = a.vbuf + (size_t)nb * VBUF_IMG;
+    a.flags = (unsigned*)ws; a.kbuf = ws + flags; a.vbuf = a.kbuf + (size_t)nb * KBUF_IMG; a.halo = a.vbuf + (size_t)nb * VBUF_IMG; a.park = a.halo + (size_t)nb * HALO_IMG;
     a.B = nb; a.nblocks = d->nblocks; a.eps = d->eps;
     a.timing = (unsigned long long*)d->timing; a.timing_block = d->timing_block;
     const int nwg = 2 * ((nb + 7) / 8) * 8;

@@ -4,7 +4,7 @@
 //     fragment order: one fully coalesced 1 KB global_load_dwordx4 per fragment, no LDS, no barrier inside a GEMM),
 // at a useful fraction of the MFMA rate?  256 workgroups (one per CU) walk the same 18 x 3.54 MB of packed weights, as the 256 half-images
 // of a batch of 128 would.  Prints ms per "stage" (18 blocks) and TFLOP/s.
-// usage: sstage_probe <NC: out tiles per unit 2|3|4|6> <RING: 3|4|6> <barrier every N units, 0 = never> <wgs> <reps> <waves per workgroup 8|4>
+// usage: sstage_probe <NC: out tiles per unit 2|3|4|6> <RING: 3|4|6> <barrier every N units, 0 = never> <wgs> <reps> <waves per workgroup 8> <ablation: 1 = no weight loads, 2 = no LDS reads, 3 = MFMAs only>
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
@@ -17,7 +17,7 @@ constexpr int KS = 12;              // k-steps of 32 (K = 384)
 constexpr int TILE_UNITS = 36;      // (out tile x 12 k-steps) per wave and block: 9 qkv + 3 proj + 12 fc1 + 12 fc2-equivalents
 constexpr int FRAGS_PER_WAVE_BLOCK = TILE_UNITS * KS;   // 432 KB of weights per wave and block
 
-template <int NC, int RING, int NW>
+template <int NC, int RING, int NW, int ABL>
 __global__ __launch_bounds__(NW * 64, 1) void probe(const uint4* __restrict__ w, const uint4* __restrict__ xsrc, float* sink, int nblocks, int bar_every) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -26,6 +26,8 @@ __global__ __launch_bounds__(NW * 64, 1) void probe(const uint4* __restrict__ w,
   __syncthreads();
   constexpr int UNITS = TILE_UNITS * 8 / NW / NC;      // the same 288 tile-units per workgroup and block over NW waves
   float keep = 0.f;
+  bf16x8_t xconst[NT];
+  for (int t = 0; t < NT; ++t) xconst[t] = __builtin_bit_cast(bf16x8_t, xs[t * 64 + lane]);
   for (int blk = 0; blk < nblocks; ++blk) {
     const uint4* wb = w + ((size_t)(blk * NW + wave) * (FRAGS_PER_WAVE_BLOCK * 8 / NW)) * 64 + lane;
     const int nsteps = UNITS * KS;
@@ -43,14 +45,17 @@ __global__ __launch_bounds__(NW * 64, 1) void probe(const uint4* __restrict__ w,
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) {
         const int s = u * KS + ks;
-        {
+        if (!(ABL & 1)) {
           const int sp = min(s + RING - 1, nsteps - 1);
 #pragma unroll
           for (int n = 0; n < NC; ++n) ring[(ks + RING - 1) % RING][n] = __builtin_bit_cast(bf16x8_t, wb[(size_t)(sp * NC + n) * 64]);
         }
         bf16x8_t xf[NT];
 #pragma unroll
-        for (int t = 0; t < NT; ++t) xf[t] = __builtin_bit_cast(bf16x8_t, xs[(ks * NT + t) * 64 + lane]);
+        for (int t = 0; t < NT; ++t) {
+          if (!(ABL & 2)) xf[t] = __builtin_bit_cast(bf16x8_t, xs[(ks * NT + t) * 64 + lane]);
+          else { xf[t] = xconst[t]; asm volatile("" : "+v"(xf[t])); }
+        }
 #pragma unroll
         for (int t = 0; t < NT; ++t)
 #pragma unroll
@@ -66,18 +71,18 @@ __global__ __launch_bounds__(NW * 64, 1) void probe(const uint4* __restrict__ w,
   if (keep == 1.2345f) sink[0] = keep;
 }
 
-template <int NC, int RING, int NW>
+template <int NC, int RING, int NW, int ABL>
 static void run(const uint4* w, const uint4* x, float* sink, int nblocks, int bar, int wgs, int reps) {
   const int lds = KS * NT * 1024;
-  hipFuncSetAttribute(reinterpret_cast<const void*>(probe<NC, RING, NW>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  hipFuncSetAttribute(reinterpret_cast<const void*>(probe<NC, RING, NW, ABL>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-  for (int i = 0; i < 2; ++i) hipLaunchKernelGGL((probe<NC, RING, NW>), dim3(wgs), dim3(NW * 64), lds, 0, w, x, sink, nblocks, bar);
+  for (int i = 0; i < 2; ++i) hipLaunchKernelGGL((probe<NC, RING, NW, ABL>), dim3(wgs), dim3(NW * 64), lds, 0, w, x, sink, nblocks, bar);
   hipEventRecord(e0);
-  for (int i = 0; i < reps; ++i) hipLaunchKernelGGL((probe<NC, RING, NW>), dim3(wgs), dim3(NW * 64), lds, 0, w, x, sink, nblocks, bar);
+  for (int i = 0; i < reps; ++i) hipLaunchKernelGGL((probe<NC, RING, NW, ABL>), dim3(wgs), dim3(NW * 64), lds, 0, w, x, sink, nblocks, bar);
   hipEventRecord(e1); hipEventSynchronize(e1);
   float ms; hipEventElapsedTime(&ms, e0, e1); ms /= reps;
   const double flop = (double)wgs * nblocks * 8 * TILE_UNITS * KS * NT * 16384.0;
-  printf("NW=%d NC=%d RING=%d bar=%d wgs=%d blocks=%d: %.3f ms  %.0f TFLOP/s  (weights %.1f GB/s per CU, %.2f TB/s chip)\n", NW, NC, RING, bar, wgs, nblocks, ms, flop / ms * 1e-9,
+  printf("ABL=%d NW=%d NC=%d RING=%d bar=%d wgs=%d blocks=%d: %.3f ms  %.0f TFLOP/s  (weights %.1f GB/s per CU, %.2f TB/s chip)\n", ABL, NW, NC, RING, bar, wgs, nblocks, ms, flop / ms * 1e-9,
          8.0 * FRAGS_PER_WAVE_BLOCK * 1024 * nblocks / ms * 1e-6, (double)wgs * 8 * FRAGS_PER_WAVE_BLOCK * 1024 * nblocks / ms * 1e-9);
 }
 
@@ -93,7 +98,8 @@ int main(int argc, char** argv) {
   hipMemcpy(w, h.data(), wbytes, hipMemcpyHostToDevice);
   hipMemcpy(x, h.data() + 777, xbytes, hipMemcpyHostToDevice);
   const int nw = argc > 6 ? atoi(argv[6]) : 8;
-#define CASE(a, b, c) if (nc == a && ring == b && nw == c) run<a, b, c>(w, x, sink, nblocks, bar, wgs, reps)
-  CASE(2, 4, 8); CASE(3, 4, 8); CASE(4, 4, 8); CASE(3, 3, 8); CASE(4, 4, 4); CASE(6, 4, 4); CASE(6, 3, 4); CASE(4, 3, 4); CASE(6, 6, 4); CASE(4, 6, 4);
+  const int abl = argc > 7 ? atoi(argv[7]) : 0;
+#define CASE(a, b, c, d) if (nc == a && ring == b && nw == c && abl == d) run<a, b, c, d>(w, x, sink, nblocks, bar, wgs, reps)
+  CASE(2, 4, 8, 0); CASE(2, 4, 8, 1); CASE(2, 4, 8, 2); CASE(2, 4, 8, 3); CASE(3, 4, 8, 0); CASE(3, 4, 8, 1); CASE(3, 4, 8, 2); CASE(3, 4, 8, 3); CASE(4, 4, 8, 0); CASE(4, 4, 8, 3);
   return 0;
 }

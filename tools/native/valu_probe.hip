@@ -1,0 +1,32 @@
+// VALU issue-rate probe: cycles per wave-instruction for a few opcodes, 1 or 2 waves per SIMD (512- or 256-thread workgroup on one CU)
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#define REP16(x) x x x x x x x x x x x x x x x x
+template <int OP>
+__global__ void k(unsigned long long* out, float* sink, float seed) {
+  float a0 = seed, a1 = seed + 1, a2 = seed + 2, a3 = seed + 3, a4 = seed + 4, a5 = seed + 5, a6 = seed + 6, a7 = seed + 7, w = 1.0001f;
+  unsigned h = 0x3c003c00u;
+  __builtin_amdgcn_s_barrier();
+  unsigned long long t0 = __builtin_amdgcn_s_memtime();
+  for (int it = 0; it < 64; ++it) {
+    if (OP == 0) { REP16(asm volatile("v_fma_f32 %0, %0, %8, %0\n v_fma_f32 %1, %1, %8, %1\n v_fma_f32 %2, %2, %8, %2\n v_fma_f32 %3, %3, %8, %3\n v_fma_f32 %4, %4, %8, %4\n v_fma_f32 %5, %5, %8, %5\n v_fma_f32 %6, %6, %8, %6\n v_fma_f32 %7, %7, %8, %7" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(w));) }
+    if (OP == 1) { REP16(asm volatile("v_fma_mix_f32 %0, %9, %8, %0 op_sel:[0,0,0] op_sel_hi:[1,0,0]\n v_fma_mix_f32 %1, %9, %8, %1 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n v_fma_mix_f32 %2, %9, %8, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]\n v_fma_mix_f32 %3, %9, %8, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n v_fma_mix_f32 %4, %9, %8, %4 op_sel:[0,0,0] op_sel_hi:[1,0,0]\n v_fma_mix_f32 %5, %9, %8, %5 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n v_fma_mix_f32 %6, %9, %8, %6 op_sel:[0,0,0] op_sel_hi:[1,0,0]\n v_fma_mix_f32 %7, %9, %8, %7 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(w), "v"(h));) }
+    if (OP == 2) { REP16(asm volatile("v_pk_fma_f32 %0, %0, %4, %0\n v_pk_fma_f32 %1, %1, %4, %1\n v_pk_fma_f32 %2, %2, %4, %2\n v_pk_fma_f32 %3, %3, %4, %3\n v_pk_fma_f32 %0, %0, %4, %0\n v_pk_fma_f32 %1, %1, %4, %1\n v_pk_fma_f32 %2, %2, %4, %2\n v_pk_fma_f32 %3, %3, %4, %3" : "+v"(*(double*)&a0), "+v"(*(double*)&a2), "+v"(*(double*)&a4), "+v"(*(double*)&a6) : "v"(*(double*)&w));) }
+    if (OP == 3) { REP16(asm volatile("v_exp_f32 %0, %0\n v_exp_f32 %1, %1\n v_exp_f32 %2, %2\n v_exp_f32 %3, %3\n v_exp_f32 %4, %4\n v_exp_f32 %5, %5\n v_exp_f32 %6, %6\n v_exp_f32 %7, %7" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7));) }
+    if (OP == 4) { REP16(asm volatile("v_cndmask_b32 %0, %0, %8, vcc\n v_cndmask_b32 %1, %1, %8, vcc\n v_cndmask_b32 %2, %2, %8, vcc\n v_cndmask_b32 %3, %3, %8, vcc\n v_lshlrev_b32 %4, 16, %4\n v_and_b32 %5, 0xffff0000, %5\n v_add_f32 %6, %6, %8\n v_cvt_pkrtz_f16_f32 %7, %7, %8" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(w) : "vcc");) }
+  }
+  unsigned long long t1 = __builtin_amdgcn_s_memtime();
+  if ((threadIdx.x & 63) == 0) out[blockIdx.x * 16 + (threadIdx.x >> 6)] = t1 - t0;
+  if (a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7 == 12345.f) sink[0] = a0;
+}
+template <int OP> void run(const char* name, unsigned long long* out, float* sink) {
+  for (int threads : {256, 512}) {
+    hipLaunchKernelGGL(k<OP>, dim3(1), dim3(threads), 0, 0, out, sink, 0.5f);
+    unsigned long long h[16]; hipMemcpy(h, out, sizeof(h), hipMemcpyDeviceToHost);
+    printf("%-28s %d waves/SIMD: %.2f cycles per wave-instruction (wave 0), %.2f per SIMD-instruction\n", name, threads / 256, h[0] / (64.0 * 128), h[0] / (64.0 * 128) / (threads / 256));
+  }
+}
+int main() {
+  unsigned long long* out; float* sink; hipMalloc(&out, 4096); hipMalloc(&sink, 4);
+  run<0>("v_fma_f32", out, sink); run<1>("v_fma_mix_f32", out, sink); run<2>("v_pk_fma_f32", out, sink); run<3>("v_exp_f32", out, sink); run<4>("cndmask/shift/add/cvt mix", out, sink);
+}

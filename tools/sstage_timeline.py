@@ -39,10 +39,11 @@ ms = e0.elapsed_time(e1) / reps
 flop = B * nblocks * (212 * 384 * (1152 + 384 + 2 * 1536) * 2 + 12 * (196 * 196 + 256) * 32 * 4)
 print(f"B={B} nblocks={nblocks}: {ms:.3f} ms per stage  ({flop / ms * 1e-9:.0f} TFLOP/s incl. attention, {ms / nblocks * 1e3:.1f} us per block)")
 nwg = 2 * ((B + 7) // 8) * 8
-tm = torch.zeros(nwg * 8 * 16, dtype=torch.int64, device=dev)
+NS = 24
+tm = torch.zeros(nwg * 8 * NS, dtype=torch.int64, device=dev)
 ops.sstage_fwd(x, c, P, 14, 14, 1e-6, timing=tm, timing_block=blk)
 torch.cuda.synchronize()
-traw = tm.cpu().numpy().reshape(nwg, 8, 16).astype(np.float64)
+traw = tm.cpu().numpy().reshape(nwg, 8, NS).astype(np.float64)
 t = traw[:, :, :13]
 names = ["dwconv", "norm1", "kv gemm", "kv drain+barrier", "q gemm", "kv wait+barrier", "attention", "attn barrier", "proj", "norm2", "mlp", "end barrier"]
 d = np.diff(t, axis=2)
@@ -55,6 +56,8 @@ for k, n in enumerate(names):
     print(f"{n:18s} {d[:, :, k].mean():8.0f} {d[:, :, k].max():8.0f} {d[:, :, k].min():8.0f}   {d[:, :4, k].mean():8.0f} {d[:, 4:, k].mean():8.0f}")
 vv = traw[valid]
 print(f"inside dwconv: staging own rows {np.mean(vv[:, :, 13] - vv[:, :, 0]):.0f}, flag wait + halo copy {np.mean(vv[:, :, 14] - vv[:, :, 13]):.0f}, taps {np.mean(vv[:, :, 1] - vv[:, :, 14]):.0f}")
+print(f"dwconv taps: first tile of channel tile 0 {np.mean(vv[:, :, 21] - vv[:, :, 14]):.0f}, second tile {np.mean(vv[:, :, 22] - vv[:, :, 21]):.0f}, rest of channel tile 0 {np.mean(vv[:, :, 23] - vv[:, :, 22]):.0f}, channel tiles 1 + 2 {np.mean(vv[:, :, 1] - vv[:, :, 23]):.0f}")
+print("MLP chunk 2: " + ", ".join(f"{n} {np.mean(vv[:, :, b] - vv[:, :, a]):.0f}" for n, a, b in (("fc1 gemm", 15, 16), ("gelu + H write", 16, 17), ("barrier", 17, 18), ("fc2 gemm", 18, 19), ("barrier", 19, 20))))
 for wg in (0, 8):
     print(f"workgroup {wg} (image 0, half {wg // 8 % 2}) per wave:")
     for w in range(8):

@@ -71,6 +71,9 @@ constexpr size_t HALO_IMG = (size_t)2 * 14 * SS_C * 2;      // [half][14 tokens]
 constexpr size_t PARK_IMG = (size_t)2 * 8 * 21 * 1024;      // [half][wave][21 residual tiles][1 KB]: the fp32 residual registers, parked in L2 while k / v / q / attention run
 constexpr unsigned SPIN_LIMIT = 1u << 22;
 constexpr int SS_NSTAMP = 24;
+#ifndef SS_PARK
+#define SS_PARK 1      // park the residual registers in L2 while k / v / q / attention run
+#endif
 #ifndef SS_DWFENCE
 #define SS_DWFENCE 1
 #endif
@@ -235,7 +238,7 @@ __device__ __forceinline__ void attn_image(const bf16x8_t (&Qf)[SS_NT], int h, _
       const float m = max4(s);
       mx[q] = max2(mx[q], (kt == 12 && g != 0) ? -INFINITY : m);        // key tile 12: only keys 192..195 (rows 0..3 = lane group 0) exist
     }
-    if (kt % 2 == 1) __builtin_amdgcn_sched_barrier(0);
+    if (kt % 4 == 3) __builtin_amdgcn_sched_barrier(0);
   }
 #pragma unroll
   for (int q = 0; q < NQ; ++q) mx[q] = xmax4(mx[q]);
@@ -468,11 +471,13 @@ __global__ __launch_bounds__(512, 2) void sstage_kernel(const SsArgs a) {
       layer_norm_to_lds(R, vec + V_N1W, vec + V_N1B, a.eps, smem, wave, lane);
       // the residual is not touched again before proj: its 84 registers go to L2 (a wave-private slab, plain stores) and come back behind the
       // attention -- k / v / q and the attention (13 K fragments resident per head) get the registers
+#if SS_PARK
       u32x4_t* const pk = reinterpret_cast<u32x4_t*>(a.park + (size_t)img * PARK_IMG + ((size_t)(half * 8 + wave) * 21) * 1024) + lane;
 #pragma unroll
       for (int t = 0; t < SS_NT; ++t)
 #pragma unroll
         for (int ct = 0; ct < 3; ++ct) pk[(t * 3 + ct) * 64] = __builtin_bit_cast(u32x4_t, R[t][ct]);
+#endif
     }
     SS_STAMP(2);
     {
@@ -576,11 +581,13 @@ __global__ __launch_bounds__(512, 2) void sstage_kernel(const SsArgs a) {
     {
       SS_PHASE
       ring_fill<3, 4>(ring3, wp + (size_t)(WS_PROJ + wave * 36) * 1024, lane);          // lands under the barrier
+#if SS_PARK
       const u32x4_t* const pk = reinterpret_cast<const u32x4_t*>(a.park + (size_t)img * PARK_IMG + ((size_t)(half * 8 + wave) * 21) * 1024) + lane;
 #pragma unroll
       for (int t = 0; t < SS_NT; ++t)
 #pragma unroll
         for (int ct = 0; ct < 3; ++ct) R[t][ct] = __builtin_bit_cast(f32x4_t, pk[(t * 3 + ct) * 64]);
+#endif
     }
     __syncthreads();
 

@@ -407,13 +407,17 @@ def main():
             # HBM bytes per launch of the same kernel from the PMC passes committed under profiles/ (tools/pmc_traffic.sh: FETCH_SIZE x 2
             # per the gfx950 correction + WRITE_SIZE, separate passes); only quoted for the workload it was collected on
             traffic, traffic_src = None, None
-            pmc = os.path.join(ROOT, "profiles", "r03_gemm_fwd_pmc_traffic.json")
-            if train and args.model == "lemevit_base" and args.img == 224 and args.batch == 128 and os.path.exists(pmc):
+            import glob
+            cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_gemm_fwd_pmc_traffic.json")))      # the newest COMMITTED round (r03's file never left gpurun_out/)
+            if train and args.model == "lemevit_base" and args.img == 224 and args.batch == 128 and cands:
+                pmc = cands[-1]
                 with open(pmc) as f:
                     traffic = round(json.load(f)["traffic_bytes_per_launch"] / 1e6, 2)
-                traffic_src = ("canned: profiles/r03_gemm_fwd_pmc_traffic.json (MB per launch over the forward-form Linear launches -- gemm_kernel<bf16,NT>, rs_gemm_kernel, "
+                traffic_src = (f"canned: profiles/{os.path.basename(pmc)} (MB per launch over the forward-form Linear launches -- gemm_kernel<bf16,NT>, rs_gemm_kernel, "
                                "wn_gemm_kernel -- of this command's train step, separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, tools/pmc_traffic.sh; NOT measured "
                                "in this run; that launch set also holds the dX launches that run as forward-form GEMMs on transposed weights)")
+            elif train:
+                print("bench.py: no profiles/rNN_gemm_fwd_pmc_traffic.json for this workload: roofline.traffic stays null", file=sys.stderr)
             # SURVEY 8(d) grades the path against the MFMA roof (94 % of the MACs are Linear GEMMs), so that is the primary figure.  The
             # launch mix itself has K = 96..512 on the big-row stages: its arithmetic intensity is below the ridge point of the chip
             # (2500 TFLOP/s / 8 TB/s = 312 flop/B), i.e. by the roofline model HBM is the binding roof -- reported beside it (`hbm_*`).
@@ -423,7 +427,8 @@ def main():
                         traffic=traffic, traffic_unit="MB/launch", traffic_source=traffic_src, algorithmic_mbytes_per_launch=round(g["mbytes_per_launch"], 2),
                         flop_per_byte=round(intensity, 1), ridge_flop_per_byte=round(PEAK_BF16_TFLOPS * 1e3 / PEAK_HBM_GBS, 1),
                         hbm_gbs=round(hbm_gbs, 1), hbm_peak_gbs=PEAK_HBM_GBS, hbm_frac=round(hbm_gbs / PEAK_HBM_GBS, 4),
-                        kernel="forward Linear launches: gemm_kernel<bf16,NT> / rs_gemm_kernel / wn_gemm_kernel / rsw_gemm_kernel", measured=kernel_timing_note, launches=g["launches"], avg_launch_us=round(g["avg_us"], 2),
+                        traffic_over_algorithmic=None if traffic is None else round(traffic / g["mbytes_per_launch"], 3),
+                        kernel="forward Linear launches: gemm_kernel<bf16,NT> / rs_gemm_kernel / wn_gemm_kernel (+ rsw_gemm_kernel in the event timing)", measured=kernel_timing_note, launches=g["launches"], avg_launch_us=round(g["avg_us"], 2),
                         gflop_per_launch=round(g["gflop_per_launch"], 3))
         line = {
             "metric": f"images/sec {pretty} {args.img}^2 bf16 " + ("fwd+bwd" if train else "fwd"),

@@ -8,6 +8,7 @@ import subprocess
 import sys
 
 import pytest
+import torch
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -31,6 +32,21 @@ def test_bench_single_gpu_line_has_forward_keys():
     # the forward pass is (much) cheaper than the train step on the same batch
     assert line["forward_ms"] < line["ms_per_step"]
     assert "concurrent sub-batches" in line["forward_note"]          # the forward probe replays the batch as --infer-parts graph branches
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two MI355X: bench.py --gpus 2 over RCCL, one device per rank (BASELINE config 4)")
+def test_bench_two_ranks_rccl():
+    """The driver's N > 1 launch line on real devices: torch.distributed.run, backend nccl (= RCCL), FlatGradSync all-reduces over xGMI."""
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("LMV_BENCH_SINGLE_DEVICE", None); env.pop("LMV_BENCH_BACKEND", None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "2", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, (r.stdout[-1500:] + "\n" + r.stderr[-3000:])
+    line = _json_line(r.stdout)
+    assert line["n_gpus"] == 2 and line["config"]["global_batch"] == 256 and line["config"]["parallelism"] == "dp2" and line["scaling"] == "weak"
+    assert line["value"] > 0 and line["value"] == line["value"]
 
 
 def test_bench_two_ranks_on_one_device():

@@ -637,8 +637,19 @@ def test_flat_adamw_survives_model_zero_grad():
     assert w2.grad is o2._grad_views[i]
 
 
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two MI355X (BASELINE config 4 runs on an 8-GPU node; the 1-GPU boxes take the gloo form below)")
+@pytest.mark.parametrize("compress", [None, "bf16"])
+def test_two_rank_gradients_equal_single_process_rccl(tmp_path, compress):
+    """The same check over RCCL / xGMI with one device per rank (main.py:333, scripts/train.sh:3-8): lights up on any box with >= 2 GPUs."""
+    _two_rank_vs_single(tmp_path, compress, "nccl")
+
+
 @pytest.mark.parametrize("compress", [None, "bf16"])
 def test_two_rank_gradients_equal_single_process(tmp_path, compress):
+    _two_rank_vs_single(tmp_path, compress, "gloo")
+
+
+def _two_rank_vs_single(tmp_path, compress, backend):
     """SURVEY section 4 "Distributed", on the PRODUCT model: lemevit_tiny (fp32 kernels) trained by two ranks that share this GPU
     (gloo process group), FlatAdamW + FlatGradSync, global batch 8 split 4 + 4, against one process on the whole batch.
     LayerNorm / attention / MLP are per-sample, so block gradients must agree to fp32 rounding; the stem and stage-transition
@@ -649,7 +660,7 @@ def test_two_rank_gradients_equal_single_process(tmp_path, compress):
     import torch.multiprocessing as mp
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     out = str(tmp_path / "g2.pt")
-    mp.spawn(_two_rank_worker_bn_eval, args=(2, port, out, compress), nprocs=2, join=True)
+    mp.spawn(_two_rank_worker_bn_eval, args=(2, port, out, compress, backend), nprocs=2, join=True)
     got = torch.load(out)
     Lm = L()
     torch.manual_seed(0)
@@ -675,12 +686,17 @@ def test_two_rank_gradients_equal_single_process(tmp_path, compress):
     assert checked > 100
 
 
-def _two_rank_worker_bn_eval(rank, world, port, out, compress):
+def _two_rank_worker_bn_eval(rank, world, port, out, compress, backend="gloo"):
     import os
-    os.environ.update(RANK=str(rank), LOCAL_RANK="0", WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    local = rank if backend == "nccl" else 0               # RCCL wants one device per rank; gloo lets both ranks share cuda:0 (1-GPU boxes)
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(local), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
     import torch.distributed as dist
-    torch.cuda.set_device(0)
-    dist.init_process_group("gloo")
+    torch.cuda.set_device(local)
+    DEV = f"cuda:{local}"
+    if backend == "nccl":
+        dist.init_process_group("nccl", device_id=torch.device(DEV))
+    else:
+        dist.init_process_group("gloo")
     import lemevit_amd as Lm
     from lemevit_amd.dist import attach_flat_grad_sync, shard_batch
     torch.manual_seed(0)

@@ -4,7 +4,7 @@
 //     fragment order: one fully coalesced 1 KB global_load_dwordx4 per fragment, no LDS, no barrier inside a GEMM),
 // at a useful fraction of the MFMA rate?  256 workgroups (one per CU) walk the same 18 x 3.54 MB of packed weights, as the 256 half-images
 // of a batch of 128 would.  Prints ms per "stage" (18 blocks) and TFLOP/s.
-// usage: sstage_probe <NC: out tiles per unit 2|3|4|6> <RING: 3|4|6> <barrier every N units, 0 = never> <wgs> <reps> <waves per workgroup 8> <ablation: 1 = no weight loads, 2 = no LDS reads, 3 = MFMAs only>
+// usage: sstage_probe <NC: out tiles per unit 2|3|4|6> <RING: 3|4|6> <barrier every N units, 0 = never> <wgs> <reps> <waves per workgroup 8> <ablation: 1 = no weight loads, 2 = no LDS reads, 3 = MFMAs only; 8 / 4 = MFMA-shape A/B arms (16x16x32 / 32x32x16 on 96 tokens x 32 channels), + 16 = s_setprio 1 on waves 4..7>
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
@@ -26,6 +26,7 @@ __global__ __launch_bounds__(NW * 64, 1) void probe(const uint4* __restrict__ w,
   __syncthreads();
   constexpr int UNITS = TILE_UNITS * 8 / NW / NC;      // the same 288 tile-units per workgroup and block over NW waves
   float keep = 0.f;
+  if ((ABL & 16) && wave >= 4) __builtin_amdgcn_s_setprio(1);      // static priority for the younger half of the workgroup
   bf16x8_t xconst[NT];
   for (int t = 0; t < NT; ++t) xconst[t] = __builtin_bit_cast(bf16x8_t, xs[t * 64 + lane]);
   for (int blk = 0; blk < nblocks; ++blk) {
@@ -38,6 +39,12 @@ __global__ __launch_bounds__(NW * 64, 1) void probe(const uint4* __restrict__ w,
       for (int n = 0; n < NC; ++n) ring[s][n] = __builtin_bit_cast(bf16x8_t, wb[(size_t)(s * NC + n) * 64]);
     for (int u = 0; u < UNITS; ++u) {
       f32x4_t acc[NT][NC];
+      typedef __attribute__((ext_vector_type(16))) float f32x16_t;
+      f32x16_t acc32[3];
+#pragma unroll
+      for (int t = 0; t < 3; ++t)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc32[t][e] = 0.f;
 #pragma unroll
       for (int t = 0; t < NT; ++t)
 #pragma unroll
@@ -56,10 +63,26 @@ __global__ __launch_bounds__(NW * 64, 1) void probe(const uint4* __restrict__ w,
           if (!(ABL & 2)) xf[t] = __builtin_bit_cast(bf16x8_t, xs[(ks * NT + t) * 64 + lane]);
           else { xf[t] = xconst[t]; asm volatile("" : "+v"(xf[t])); }
         }
+        if constexpr ((ABL & 12) == 0) {
 #pragma unroll
-        for (int t = 0; t < NT; ++t)
+          for (int t = 0; t < NT; ++t)
 #pragma unroll
-          for (int n = 0; n < NC; ++n) acc[t][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ring[ks % RING][n], xf[t], acc[t][n], 0, 0, 0);
+            for (int n = 0; n < NC; ++n) acc[t][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ring[ks % RING][n], xf[t], acc[t][n], 0, 0, 0);
+        } else if constexpr ((ABL & 8) != 0) {      // MFMA-shape A/B, arm A: 96 tokens x 32 channels per k-step as 12 x 16x16x32
+#pragma unroll
+          for (int t = 0; t < 6; ++t)
+#pragma unroll
+            for (int n = 0; n < 2; ++n) acc[t][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ring[ks % RING][n], xf[t], acc[t][n], 0, 0, 0);
+        } else {                                     // arm B: the same fragments (2 KB of weights, 6 KB of tokens, 48 accumulator registers) as 6 x 32x32x16
+#pragma unroll
+          for (int t = 0; t < 3; ++t)
+#pragma unroll
+            for (int kh = 0; kh < 2; ++kh) acc32[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ring[ks % RING][kh], xf[2 * t + kh], acc32[t], 0, 0, 0);
+        }
+      }
+      if constexpr ((ABL & 4) != 0) {
+#pragma unroll
+        for (int t = 0; t < 3; ++t) keep += acc32[t][0] + acc32[t][15];
       }
 #pragma unroll
       for (int t = 0; t < NT; ++t)
@@ -100,6 +123,6 @@ int main(int argc, char** argv) {
   const int nw = argc > 6 ? atoi(argv[6]) : 8;
   const int abl = argc > 7 ? atoi(argv[7]) : 0;
 #define CASE(a, b, c, d) if (nc == a && ring == b && nw == c && abl == d) run<a, b, c, d>(w, x, sink, nblocks, bar, wgs, reps)
-  CASE(2, 4, 8, 0); CASE(2, 4, 8, 1); CASE(2, 4, 8, 2); CASE(2, 4, 8, 3); CASE(3, 4, 8, 0); CASE(3, 4, 8, 1); CASE(3, 4, 8, 2); CASE(3, 4, 8, 3); CASE(4, 4, 8, 0); CASE(4, 4, 8, 3);
+  CASE(2, 4, 8, 0); CASE(2, 4, 8, 1); CASE(2, 4, 8, 2); CASE(2, 4, 8, 3); CASE(3, 4, 8, 0); CASE(3, 4, 8, 1); CASE(3, 4, 8, 2); CASE(3, 4, 8, 3); CASE(4, 4, 8, 0); CASE(4, 4, 8, 3); CASE(2, 4, 8, 4); CASE(2, 4, 8, 8); CASE(2, 4, 8, 20); CASE(2, 4, 8, 24); CASE(3, 4, 8, 16);
   return 0;
 }

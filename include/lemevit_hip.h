@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define LMV_ABI_VERSION 7
+#define LMV_ABI_VERSION 8
 
 enum { LMV_F32 = 0, LMV_BF16 = 1 };
 enum {
@@ -407,13 +407,14 @@ int lmv_block_bwd(const lmv_block_desc* d, const void* x, const void* c, const v
  * c [B, 16, 384].  The token rows stay on chip for the whole stage (two workgroups per image, residual stream in registers); only the
  * block weights stream from L2.  Replaces nblocks lmv_block_fwd(kind = S, save = 0) calls; same math, the residual stream is kept in
  * fp32 between the blocks instead of being rounded to bf16 after every residual add.
- *   lmv_sstage_supported: 1 where the kernel applies (C = 384, 12 heads, hidden 1536, 14 x 14 image tokens, 16 meta tokens, bf16).
+ *   lmv_sstage_supported: 1 where the kernel applies: C = 384 / 12 heads / hidden 1536 (LeMeViT-Base, Small-v2: 8 waves per workgroup) or C = 192 / 6 heads /
+ *     hidden 768 (LeMeViT-Tiny: 4 waves, two workgroups per CU), 14 x 14 image tokens, 16 meta tokens, bf16.
  *   lmv_sstage_pack: one block's parameters (matrices bf16, vectors fp32, the reference's layouts: attn.qkv [3C, C], attn.proj [C, C],
  *     mlp.0 [4C, C], mlp.3 [C, 4C], pos_embed.weight [C, 9]) -> `wpk_out` (lmv_sstage_wpk_bytes: the matrices in MFMA-fragment order) and
  *     `vec_out` (lmv_sstage_vec_floats fp32).  The packed blocks of a stage are consecutive: block j at wpk + j * wpk_bytes, vec + j * vec_floats.
- *   lmv_sstage_fwd: x_out / c_out may alias x / c.  `workspace` (lmv_sstage_workspace_bytes(min(B, 128))) holds the K / V fragments and the
- *     grid rows the two halves of an image exchange, the parked residual registers, and the flags (reset by the call on `stream`).  The launch needs 2 * min(B, 128)
- *     co-resident workgroups of 512 threads / 147 KB LDS (one per CU): it must not be issued while another kernel of the same kind runs
+ *   lmv_sstage_fwd: x_out / c_out may alias x / c.  `workspace` (lmv_sstage_workspace_bytes(min(B, lmv_sstage_max_images(C)), C)) holds the K / V fragments and the
+ *     grid rows the two halves of an image exchange, the parked residual registers, and the flags (reset by the call on `stream`).  The launch needs 2 * min(B, max images)
+ *     co-resident workgroups (512 threads / 147 KB LDS, one per CU; C = 192: 256 threads / 74 KB, two per CU): it must not be issued while another kernel of the same kind runs
  *     on a different stream of the same device.
  * ------------------------------------------------------------------------------------------ */
 typedef struct lmv_sstage_block_params {
@@ -432,7 +433,8 @@ typedef struct lmv_sstage_desc {
 int lmv_sstage_supported(int C, int heads, int hidden, int H, int W, int M, int dtype);
 size_t lmv_sstage_wpk_bytes(int C, int hidden);
 size_t lmv_sstage_vec_floats(int C, int hidden);
-size_t lmv_sstage_workspace_bytes(int B);
+size_t lmv_sstage_workspace_bytes(int B, int C);
+int lmv_sstage_max_images(int C);                 /* images one launch takes (128 at C = 384, 256 at C = 192): size the workspace for min(B, this) */
 int lmv_sstage_pack(const lmv_sstage_block_params* p, void* wpk_out, float* vec_out, void* stream);
 int lmv_sstage_fwd(const lmv_sstage_desc* d, const void* x, const void* c, void* x_out, void* c_out, void* workspace, size_t workspace_bytes, void* stream);
 

@@ -14,7 +14,7 @@ LIB_PATH = os.path.join(_HERE, "csrc", "liblemevit_hip.so")
 
 LMV_F32, LMV_BF16 = 0, 1
 ACT_NONE, ACT_GELU, ACT_GELU_GRAD = 0, 1, 2
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 
 class LinearProblem(C.Structure):
@@ -146,7 +146,8 @@ SIGNATURES = {
     "lmv_sstage_supported": (_I, [_I, _I, _I, _I, _I, _I, _I]),
     "lmv_sstage_wpk_bytes": (_Z, [_I, _I]),
     "lmv_sstage_vec_floats": (_Z, [_I, _I]),
-    "lmv_sstage_workspace_bytes": (_Z, [_I]),
+    "lmv_sstage_workspace_bytes": (_Z, [_I, _I]),
+    "lmv_sstage_max_images": (_I, [_I]),
     "lmv_sstage_pack": (_I, [C.POINTER(SStageBlockParams), _P, _P, _P]),
     "lmv_sstage_fwd": (_I, [C.POINTER(SStageDesc), _P, _P, _P, _P, _P, _Z, _P]),
 }

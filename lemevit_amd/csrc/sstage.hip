@@ -40,35 +40,56 @@ typedef __attribute__((ext_vector_type(4))) unsigned u32x4_t;
 typedef __attribute__((address_space(1))) unsigned gu32;
 typedef __attribute__((address_space(1))) unsigned long long gu64;
 
-constexpr int SS_C = 384, SS_NH = 12, SS_HID = 1536, SS_G = 14, SS_NIMG = 196, SS_M = 16;
+constexpr int SS_G = 14, SS_NIMG = 196, SS_M = 16;
 constexpr int SS_NT = 7;              // token tiles of 16 per workgroup (112 slots)
-constexpr int SS_KS = SS_C / 32;      // 12 k-steps of 32 channels
-constexpr int SS_NCHUNK = 6, SS_KSC = 8;      // MLP: 6 chunks of 256 hidden channels = 8 k-steps of fc2 each
+constexpr int SS_NCHUNK = 6;          // the MLP runs in 6 chunks of 32 NW hidden channels
 
-// packed weights of a block, in 1 KB fragments (64 lanes x 16 B).  Fragment (row0, ks) of a weight W [N][K]: lane (g = lane >> 4, i = lane & 15)
+// The kernel is written for NW waves of 48 channels each: C = 48 NW, 1.5 NW heads of 32, hidden 192 NW.  NW = 8: stage 3 of LeMeViT-Base / Small-v2
+// (C = 384, 12 heads, hidden 1536; one 512-thread workgroup per CU).  NW = 4: stage 3 of LeMeViT-Tiny (C = 192, 6 heads, hidden 768; 256-thread workgroups,
+// two per CU).  Everything below that says "wave w owns channels 48 w .." scales with it.
+//
+// Packed weights of a block, in 1 KB fragments (64 lanes x 16 B).  Fragment (row0, ks) of a weight W [N][K]: lane (g = lane >> 4, i = lane & 15)
 // holds W[row0 + i][32 ks + 16 (j >> 2) + 4 g + (j & 3)], j = 0..7 -- the A operand of v_mfma_f32_16x16x32_bf16 under the k-slot permutation
 // every token operand of this kernel is written in.
-constexpr int WS_KV = 0;              // [unit u = 2 h + (0: k, 1: v)][ks 12][n 2]: rows (1 + (u & 1)) C + 32 (u >> 1) + 16 n of qkv.weight
-constexpr int WS_Q = 576;             // [head h][ks 12][n 2]: rows 32 h + 16 n
-constexpr int WS_PROJ = 864;          // [wave w][ks 12][n 3]: rows 48 w + 16 n of proj.weight
-constexpr int WS_FC1 = 1152;          // [chunk c][wave w][ks 12][n 2]: rows 256 c + 32 w + 16 n of mlp.0.weight
-constexpr int WS_FC2 = 2304;          // [chunk c][wave w][ksl 8][n 3]: rows 48 w + 16 n, columns of k-step 8 c + ksl of mlp.3.weight
-constexpr int WS_FRAGS = 3456;
-// packed fp32 vectors of a block (reference layouts, concatenated)
-constexpr int V_N1W = 0, V_N1B = 384, V_QKVB = 768, V_PROJB = 1920, V_N2W = 2304, V_N2B = 2688, V_FC1B = 3072, V_FC2B = 4608, V_POSW = 4992,
-              V_POSB = 8448, V_FLOATS = 8832;
-// LDS
-constexpr int L_XN = 0, L_XN_BYTES = SS_KS * SS_NT * 1024;        // token operand of qkv / fc1 (LayerNorm output) and of proj (attention output)
-constexpr int L_H = L_XN_BYTES, L_H_BYTES = SS_KSC * SS_NT * 1024;   // hidden chunk (token operand of fc2); second-head q fragments during attention
-constexpr int L_STAT = L_H + L_H_BYTES, L_STAT_BYTES = 8 * 112 * 8;  // LayerNorm partial sums [wave][slot] float2
-constexpr int L_TOTAL = L_STAT + L_STAT_BYTES;                        // 150 528 B
-constexpr int STG_ROW = 96, STG_WAVE = 160 * STG_ROW;                 // dwconv staging: per wave [10 grid rows][16 columns][48 channels] bf16 (over L_XN | L_H)
-static_assert(8 * STG_WAVE <= L_STAT, "staging overlaps the statistics");
-// workspace
-constexpr size_t KBUF_IMG = (size_t)SS_NH * 14 * 1024;      // [head][14 key tiles: image 0..12, meta 13][1 KB]
-constexpr size_t VBUF_IMG = (size_t)SS_NH * 8 * 2 * 1024;   // [head][8 key-tile pairs: half 0 p0..3, half 1 p0..3][2 d-tiles][1 KB], fp16
-constexpr size_t HALO_IMG = (size_t)2 * 14 * SS_C * 2;      // [half][14 tokens][C] bf16
-constexpr size_t PARK_IMG = (size_t)2 * 8 * 21 * 1024;      // [half][wave][21 residual tiles][1 KB]: the fp32 residual registers, parked in L2 while k / v / q / attention run
+template <int NW> struct SG {
+  static constexpr int C = 48 * NW, NH = C / 32, HID = 4 * C;
+  static constexpr int KS = C / 32;          // k-steps of 32 channels
+  static constexpr int KSC = NW;             // k-steps of fc2 per MLP chunk (32 NW hidden channels)
+  static constexpr int PRD = KS % 4 == 0 ? 4 : 3;      // ring depth of the proj GEMM (KS must be a multiple)
+  static constexpr int WS_KV = 0;                              // [unit u = 2 h + (0: k, 1: v)][ks][n 2]: rows (1 + (u & 1)) C + 32 (u >> 1) + 16 n of qkv.weight
+  static constexpr int WS_Q = 2 * NH * KS * 2;                 // [head h][ks][n 2]: rows 32 h + 16 n
+  static constexpr int WS_PROJ = WS_Q + NH * KS * 2;           // [wave w][ks][n 3]: rows 48 w + 16 n of proj.weight
+  static constexpr int WS_FC1 = WS_PROJ + NW * KS * 3;         // [chunk c][wave w][ks][n 2]: rows 32 NW c + 32 w + 16 n of mlp.0.weight
+  static constexpr int WS_FC2 = WS_FC1 + SS_NCHUNK * NW * KS * 2;      // [chunk c][wave w][ksl KSC][n 3]: rows 48 w + 16 n, columns of k-step KSC c + ksl of mlp.3.weight
+  static constexpr int WS_FRAGS = WS_FC2 + SS_NCHUNK * NW * KSC * 3;
+  // packed fp32 vectors of a block (reference layouts, concatenated)
+  static constexpr int V_N1W = 0, V_N1B = C, V_QKVB = 2 * C, V_PROJB = 5 * C, V_N2W = 6 * C, V_N2B = 7 * C, V_FC1B = 8 * C, V_FC2B = 12 * C, V_POSW = 13 * C,
+                       V_POSB = 22 * C, V_FLOATS = 23 * C;
+  // LDS
+  static constexpr int L_XN = 0, L_XN_BYTES = KS * SS_NT * 1024;          // token operand of qkv / fc1 (LayerNorm output) and of proj (attention output)
+  static constexpr int L_H = L_XN_BYTES, L_H_BYTES = KSC * SS_NT * 1024;   // hidden chunk (token operand of fc2); second-head q fragments during attention
+  static constexpr int L_STAT = L_H + L_H_BYTES, L_STAT_BYTES = NW * 112 * 8;   // LayerNorm partial sums [wave][slot] float2
+  static constexpr int L_TOTAL = L_STAT + L_STAT_BYTES;                    // NW = 8: 150 528 B, NW = 4: 75 264 B
+  // workspace
+  static constexpr size_t KBUF_IMG = (size_t)NH * 14 * 1024;      // [head][14 key tiles: image 0..12, meta 13][1 KB]
+  static constexpr size_t VBUF_IMG = (size_t)NH * 8 * 2 * 1024;   // [head][8 key-tile pairs: half 0 p0..3, half 1 p0..3][2 d-tiles][1 KB], fp16
+  static constexpr size_t HALO_IMG = (size_t)2 * 14 * C * 2;      // [half][14 tokens][C] bf16
+  static constexpr size_t PARK_IMG = (size_t)2 * NW * 21 * 1024;  // [half][wave][21 residual tiles][1 KB]: the fp32 residual registers, parked in L2 while k / v / q / attention run
+};
+constexpr int STG_ROW = 96, STG_WAVE = 160 * STG_ROW;                 // dwconv staging: per wave [10 grid rows][16 columns][48 channels] fp16 (over L_XN | L_H)
+static_assert(8 * STG_WAVE <= SG<8>::L_STAT && 4 * STG_WAVE <= SG<4>::L_STAT, "staging overlaps the statistics");
+// the geometry of SG<NW> under the names the code uses
+#define SS_GEO(NW)                                                                                                                                     \
+  using G_ = SG<NW>;                                                                                                                                   \
+  constexpr int SS_C = G_::C, SS_NH = G_::NH, SS_HID = G_::HID, SS_KS = G_::KS, SS_KSC = G_::KSC, SS_PRD = G_::PRD;                                    \
+  constexpr int WS_KV = G_::WS_KV, WS_Q = G_::WS_Q, WS_PROJ = G_::WS_PROJ, WS_FC1 = G_::WS_FC1, WS_FC2 = G_::WS_FC2, WS_FRAGS = G_::WS_FRAGS;          \
+  constexpr int V_N1W = G_::V_N1W, V_N1B = G_::V_N1B, V_QKVB = G_::V_QKVB, V_PROJB = G_::V_PROJB, V_N2W = G_::V_N2W, V_N2B = G_::V_N2B,                \
+                V_FC1B = G_::V_FC1B, V_FC2B = G_::V_FC2B, V_POSW = G_::V_POSW, V_POSB = G_::V_POSB, V_FLOATS = G_::V_FLOATS;                           \
+  constexpr int L_XN = G_::L_XN, L_H = G_::L_H, L_STAT = G_::L_STAT, L_TOTAL = G_::L_TOTAL;                                                            \
+  constexpr size_t KBUF_IMG = G_::KBUF_IMG, VBUF_IMG = G_::VBUF_IMG, HALO_IMG = G_::HALO_IMG, PARK_IMG = G_::PARK_IMG;                                 \
+  (void)SS_C; (void)SS_NH; (void)SS_HID; (void)SS_KS; (void)SS_KSC; (void)SS_PRD; (void)WS_KV; (void)WS_Q; (void)WS_PROJ; (void)WS_FC1; (void)WS_FC2;  \
+  (void)WS_FRAGS; (void)V_N1W; (void)V_N1B; (void)V_QKVB; (void)V_PROJB; (void)V_N2W; (void)V_N2B; (void)V_FC1B; (void)V_FC2B; (void)V_POSW;           \
+  (void)V_POSB; (void)V_FLOATS; (void)L_XN; (void)L_H; (void)L_STAT; (void)L_TOTAL; (void)KBUF_IMG; (void)VBUF_IMG; (void)HALO_IMG; (void)PARK_IMG;
 constexpr unsigned SPIN_LIMIT = 1u << 22;
 constexpr int SS_NSTAMP = 24;
 #ifndef SS_PARK
@@ -119,7 +140,7 @@ __device__ __forceinline__ void wait_flag(unsigned* flag, unsigned epoch, unsign
 
 #define SS_STAMP(k)                                                                                              \
   do {                                                                                                           \
-    if (a.timing && blk == a.timing_block && lane == 0) a.timing[((size_t)blockIdx.x * 8 + wave) * SS_NSTAMP + (k)] = __builtin_amdgcn_s_memtime(); \
+    if (a.timing && blk == a.timing_block && lane == 0) a.timing[((size_t)blockIdx.x * NW + wave) * SS_NSTAMP + (k)] = __builtin_amdgcn_s_memtime(); \
   } while (0)
 
 // gelu_poly2 (common.h) on the 8 pre-activations of one D tile pair at once, the four Horner chains interleaved statement by statement: a dependent
@@ -172,7 +193,9 @@ __device__ __forceinline__ void gemm_unit(f32x4_t (&acc)[SS_NT][NC], bf16x8_t (&
 }
 
 // ---- LayerNorm of the register-resident rows -> bf16 token operand in LDS (fragment order) ------------------------------------------
+template <int NW>
 __device__ __forceinline__ void layer_norm_to_lds(const f32x4_t (&R)[SS_NT][3], const float* gam, const float* bet, float eps, unsigned char* smem, int wave, int lane) {
+  SS_GEO(NW)
   const int g = lane >> 4, li = lane & 15;
   float2* stat = reinterpret_cast<float2*>(smem + L_STAT);
 #pragma unroll
@@ -194,7 +217,7 @@ __device__ __forceinline__ void layer_norm_to_lds(const f32x4_t (&R)[SS_NT][3], 
   for (int t = 0; t < SS_NT; ++t) {
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-    for (int w = 0; w < 8; ++w) { const float2 p = stat[w * 112 + t * 16 + li]; s1 += p.x; s2 += p.y; }
+    for (int w = 0; w < NW; ++w) { const float2 p = stat[w * 112 + t * 16 + li]; s1 += p.x; s2 += p.y; }
     mean[t] = s1 * (1.f / SS_C);
     rstd[t] = rsqrtf(fmaxf(s2 * (1.f / SS_C) - mean[t] * mean[t], 0.f) + eps);
   }
@@ -217,6 +240,7 @@ __device__ __forceinline__ void layer_norm_to_lds(const f32x4_t (&R)[SS_NT][3], 
 // recomputed), the V fragments run three steps ahead -- every loop is fully unrolled so that no fragment is ever copied between registers: a
 // rotating-register form made hipcc wait for the newest load at the top of every step, which exposed one L2 round trip per key tile.  (The
 // residual registers are parked in L2 during this phase: K alone is 52 registers.)  A head runs as two groups of query tiles (4 + 3).
+constexpr int L_AO = 0;      // (= SG<NW>::L_XN: the attention output overwrites the LayerNorm output)
 template <int T0, int NQ>
 __device__ __forceinline__ void attn_image(const bf16x8_t (&Qf)[SS_NT], int h, __amdgpu_buffer_rsrc_t kr, __amdgpu_buffer_rsrc_t vr, unsigned char* smem, int lane) {
   const int g = lane >> 4;
@@ -285,7 +309,7 @@ __device__ __forceinline__ void attn_image(const bf16x8_t (&Qf)[SS_NT], int h, _
   for (int q = 0; q < NQ; ++q) {
     const float inv = 1.f / xsum4(l[q]);
     const u32x4_t o = pack_bf8(O[q][0] * inv, O[q][1] * inv);
-    *reinterpret_cast<u32x4_t*>(smem + L_XN + ((h * SS_NT + T0 + q) * 64 + lane) * 16) = o;
+    *reinterpret_cast<u32x4_t*>(smem + L_AO + ((h * SS_NT + T0 + q) * 64 + lane) * 16) = o;
   }
 }
 // the 16 meta queries of half 1 (token tile 6) against the 16 meta keys (key tile 13, V pair slot 7)
@@ -303,10 +327,12 @@ __device__ __forceinline__ void attn_meta(const bf16x8_t& Qf, int h, __amdgpu_bu
   const u32x4_t pk = {pack_h2(p[0], p[1]), pack_h2(p[2], p[3]), 0u, 0u};
   const f16x8_t pf = __builtin_bit_cast(f16x8_t, pk);
   const f32x4_t o0 = mfma_f16(__builtin_bit_cast(f16x8_t, v0), pf, z4), o1 = mfma_f16(__builtin_bit_cast(f16x8_t, v1), pf, z4);
-  *reinterpret_cast<u32x4_t*>(smem + L_XN + ((h * SS_NT + 6) * 64 + lane) * 16) = pack_bf8(o0 * inv, o1 * inv);
+  *reinterpret_cast<u32x4_t*>(smem + L_AO + ((h * SS_NT + 6) * 64 + lane) * 16) = pack_bf8(o0 * inv, o1 * inv);
 }
 
-__global__ __launch_bounds__(512, 2) void sstage_kernel(const SsArgs a) {
+template <int NW>
+__global__ __launch_bounds__(64 * NW, 2) void sstage_kernel(const SsArgs a) {
+  SS_GEO(NW)
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane0 = tid & 63, wave0 = __builtin_amdgcn_readfirstlane(tid >> 6);
   // Every phase re-derives its lane / wave quantities from an opaque copy (SS_PHASE): otherwise the compiler hoists ~100 loop-invariant
@@ -467,12 +493,12 @@ __global__ __launch_bounds__(512, 2) void sstage_kernel(const SsArgs a) {
     bf16x8_t ring2[3][2];
     {
       SS_PHASE
-      ring_fill<2, 3>(ring2, wp + (size_t)(WS_KV + (3 * wave) * 24) * 1024, lane);       // lands under the LayerNorm
-      layer_norm_to_lds(R, vec + V_N1W, vec + V_N1B, a.eps, smem, wave, lane);
+      ring_fill<2, 3>(ring2, wp + (size_t)(WS_KV + (3 * wave) * (2 * SS_KS)) * 1024, lane);       // lands under the LayerNorm
+      layer_norm_to_lds<NW>(R, vec + V_N1W, vec + V_N1B, a.eps, smem, wave, lane);
       // the residual is not touched again before proj: its 84 registers go to L2 (a wave-private slab, plain stores) and come back behind the
       // attention -- k / v / q and the attention (13 K fragments resident per head) get the registers
 #if SS_PARK
-      u32x4_t* const pk = reinterpret_cast<u32x4_t*>(a.park + (size_t)img * PARK_IMG + ((size_t)(half * 8 + wave) * 21) * 1024) + lane;
+      u32x4_t* const pk = reinterpret_cast<u32x4_t*>(a.park + (size_t)img * PARK_IMG + ((size_t)(half * NW + wave) * 21) * 1024) + lane;
 #pragma unroll
       for (int t = 0; t < SS_NT; ++t)
 #pragma unroll
@@ -485,8 +511,8 @@ __global__ __launch_bounds__(512, 2) void sstage_kernel(const SsArgs a) {
 #pragma unroll 1
       for (int uu = 0; uu < 3; ++uu) {
         const int u = 3 * wave + uu, h = u >> 1, isv = u & 1;
-        const unsigned char* wcur = wp + (size_t)(WS_KV + u * 24) * 1024;
-        const unsigned char* wnext = uu < 2 ? wcur + 24 * 1024 : wp + (size_t)(WS_Q + wave * 24) * 1024;
+        const unsigned char* wcur = wp + (size_t)(WS_KV + u * (2 * SS_KS)) * 1024;
+        const unsigned char* wnext = uu < 2 ? wcur + (2 * SS_KS) * 1024 : wp + (size_t)(WS_Q + wave * (2 * SS_KS)) * 1024;
         f32x4_t acc[SS_NT][2];
 #pragma unroll
         for (int t = 0; t < SS_NT; ++t) { acc[t][0] = f32x4_t{0.f, 0.f, 0.f, 0.f}; acc[t][1] = acc[t][0]; }
@@ -525,15 +551,15 @@ __global__ __launch_bounds__(512, 2) void sstage_kernel(const SsArgs a) {
 
     asm volatile("; PHASE_QPROJ" ::: "memory");
     // ---- q projections of the wave's heads (head `wave`, and head 8 + wave on waves 0..3) ----
-    const int nheads = wave0 < 4 ? 2 : 1;
+    const int nheads = wave0 < NW / 2 ? 2 : 1;
     bf16x8_t Qf[SS_NT];      // (the drain above also waited for the first k-steps of head `wave`: the tail of the last k / v unit fetched them)
     {
       SS_PHASE
 #pragma unroll 1
       for (int hu = 0; hu < nheads; ++hu) {
-        const int h = wave + 8 * hu;
-        const unsigned char* wcur = wp + (size_t)(WS_Q + h * 24) * 1024;
-        const unsigned char* wnext = hu + 1 < nheads ? wp + (size_t)(WS_Q + (h + 8) * 24) * 1024 : wcur;
+        const int h = wave + NW * hu;
+        const unsigned char* wcur = wp + (size_t)(WS_Q + h * (2 * SS_KS)) * 1024;
+        const unsigned char* wnext = hu + 1 < nheads ? wp + (size_t)(WS_Q + (h + NW) * (2 * SS_KS)) * 1024 : wcur;
         f32x4_t acc[SS_NT][2];
 #pragma unroll
         for (int t = 0; t < SS_NT; ++t) { acc[t][0] = f32x4_t{0.f, 0.f, 0.f, 0.f}; acc[t][1] = acc[t][0]; }
@@ -565,11 +591,11 @@ __global__ __launch_bounds__(512, 2) void sstage_kernel(const SsArgs a) {
 #pragma unroll 1
       for (int u = 0; u < 3; ++u) {
         const bool third = u == 2;
-        const int h = third ? 8 + (wave & 3) : wave;
-        const bool groupb = third ? wave >= 4 : u == 1;
+        const int h = third ? NW + (wave & (NW / 2 - 1)) : wave;
+        const bool groupb = third ? wave >= NW / 2 : u == 1;
         if (third) {
 #pragma unroll
-          for (int t = 0; t < SS_NT; ++t) Qf[t] = *reinterpret_cast<const bf16x8_t*>(smem + L_H + (((wave & 3) * SS_NT + t) * 64 + lane) * 16);
+          for (int t = 0; t < SS_NT; ++t) Qf[t] = *reinterpret_cast<const bf16x8_t*>(smem + L_H + (((wave & (NW / 2 - 1)) * SS_NT + t) * 64 + lane) * 16);
         }
         if (!groupb) attn_image<0, 4>(Qf, h, kr, vr, smem, lane);
         else if (half == 0) attn_image<4, 3>(Qf, h, kr, vr, smem, lane);
@@ -577,12 +603,12 @@ __global__ __launch_bounds__(512, 2) void sstage_kernel(const SsArgs a) {
       }
     }
     SS_STAMP(7);
-    bf16x8_t ring3[4][3];
+    bf16x8_t ring3[4][3], ringp[SS_PRD][3];
     {
       SS_PHASE
-      ring_fill<3, 4>(ring3, wp + (size_t)(WS_PROJ + wave * 36) * 1024, lane);          // lands under the barrier
+      ring_fill<3, SS_PRD>(ringp, wp + (size_t)(WS_PROJ + wave * (3 * SS_KS)) * 1024, lane);          // lands under the barrier
 #if SS_PARK
-      const u32x4_t* const pk = reinterpret_cast<const u32x4_t*>(a.park + (size_t)img * PARK_IMG + ((size_t)(half * 8 + wave) * 21) * 1024) + lane;
+      const u32x4_t* const pk = reinterpret_cast<const u32x4_t*>(a.park + (size_t)img * PARK_IMG + ((size_t)(half * NW + wave) * 21) * 1024) + lane;
 #pragma unroll
       for (int t = 0; t < SS_NT; ++t)
 #pragma unroll
@@ -599,8 +625,8 @@ __global__ __launch_bounds__(512, 2) void sstage_kernel(const SsArgs a) {
       float4 pbias[3];
 #pragma unroll
       for (int ct = 0; ct < 3; ++ct) pbias[ct] = *reinterpret_cast<const float4*>(vec + V_PROJB + 48 * wave + 16 * ct + 4 * g);
-      const unsigned char* wcur = wp + (size_t)(WS_PROJ + wave * 36) * 1024;
-      gemm_unit<3, SS_KS, 4, true>(R, ring3, wcur, wcur, smem + L_XN, lane);
+      const unsigned char* wcur = wp + (size_t)(WS_PROJ + wave * (3 * SS_KS)) * 1024;
+      gemm_unit<3, SS_KS, SS_PRD, true>(R, ringp, wcur, wcur, smem + L_XN, lane);
 #pragma unroll
       for (int ct = 0; ct < 3; ++ct)
 #pragma unroll
@@ -612,8 +638,8 @@ __global__ __launch_bounds__(512, 2) void sstage_kernel(const SsArgs a) {
     // ---- norm2 -> LDS; MLP in 6 chunks of 256 hidden channels; fc2 accumulates on the residual registers ----
     {
       SS_PHASE
-      ring_fill<2, 3>(ring2, wp + (size_t)(WS_FC1 + wave * 24) * 1024, lane);            // lands under the LayerNorm
-      layer_norm_to_lds(R, vec + V_N2W, vec + V_N2B, a.eps, smem, wave, lane);
+      ring_fill<2, 3>(ring2, wp + (size_t)(WS_FC1 + wave * (2 * SS_KS)) * 1024, lane);            // lands under the LayerNorm
+      layer_norm_to_lds<NW>(R, vec + V_N2W, vec + V_N2B, a.eps, smem, wave, lane);
     }
     SS_STAMP(10);
 #pragma unroll 1
@@ -623,14 +649,14 @@ __global__ __launch_bounds__(512, 2) void sstage_kernel(const SsArgs a) {
         f32x4_t acc[SS_NT][2];
 #pragma unroll
         for (int t = 0; t < SS_NT; ++t) { acc[t][0] = f32x4_t{0.f, 0.f, 0.f, 0.f}; acc[t][1] = acc[t][0]; }
-        const unsigned char* wcur = wp + (size_t)(WS_FC1 + (c * 8 + wave) * 24) * 1024;
-        const float* b1p = vec + V_FC1B + 256 * c + 32 * wave + 4 * g;          // (requested ahead of the GEMM: an L2 round trip in the epilogue otherwise)
+        const unsigned char* wcur = wp + (size_t)(WS_FC1 + (c * NW + wave) * (2 * SS_KS)) * 1024;
+        const float* b1p = vec + V_FC1B + 32 * NW * c + 32 * wave + 4 * g;          // (requested ahead of the GEMM: an L2 round trip in the epilogue otherwise)
         const float4 b0 = *reinterpret_cast<const float4*>(b1p), b1 = *reinterpret_cast<const float4*>(b1p + 16);
         // the tail of this unit fetches the first k-steps of the NEXT chunk's fc1 (they ride through this chunk's fc2)
         if (c == 2) SS_STAMP(15);
-        gemm_unit<2, SS_KS, 3, true>(acc, ring2, wcur, c + 1 < SS_NCHUNK ? wcur + 8 * 24 * 1024 : wcur, smem + L_XN, lane);
+        gemm_unit<2, SS_KS, 3, true>(acc, ring2, wcur, c + 1 < SS_NCHUNK ? wcur + NW * (2 * SS_KS) * 1024 : wcur, smem + L_XN, lane);
         if (c == 2) SS_STAMP(16);
-        ring_fill<3, 4>(ring3, wp + (size_t)(WS_FC2 + (c * 8 + wave) * 24) * 1024, lane);      // lands under the GELU pass and the barrier
+        ring_fill<3, 4>(ring3, wp + (size_t)(WS_FC2 + (c * NW + wave) * (3 * SS_KSC)) * 1024, lane);      // lands under the GELU pass and the barrier
 #pragma unroll
         for (int t = 0; t < SS_NT; ++t) {
           f32x2_t h0 = {acc[t][0][0] + b0.x, acc[t][0][1] + b0.y}, h1 = {acc[t][0][2] + b0.z, acc[t][0][3] + b0.w};
@@ -645,7 +671,7 @@ __global__ __launch_bounds__(512, 2) void sstage_kernel(const SsArgs a) {
       if (c == 2) SS_STAMP(18);
       {
         SS_PHASE
-        const unsigned char* wcur = wp + (size_t)(WS_FC2 + (c * 8 + wave) * 24) * 1024;
+        const unsigned char* wcur = wp + (size_t)(WS_FC2 + (c * NW + wave) * (3 * SS_KSC)) * 1024;
         gemm_unit<3, SS_KSC, 4, true>(R, ring3, wcur, wcur, smem + L_H, lane);
       }
       if (c == 2) SS_STAMP(19);
@@ -711,18 +737,22 @@ __global__ __launch_bounds__(512, 2) void sstage_kernel(const SsArgs a) {
 struct PackArgs { const bf16_t* qkv_w; const bf16_t* proj_w; const bf16_t* fc1_w; const bf16_t* fc2_w; uint4* out; };
 
 // (source matrix, first row, k-step, row stride) of fragment f
+template <int NW>
 __device__ __forceinline__ void frag_source(int f, const PackArgs& a, const bf16_t*& base, int& row0, int& ks, int& ld) {
-  if (f < WS_Q) { const int u = f / 24, r = f - u * 24; ks = r >> 1; base = a.qkv_w; ld = SS_C; row0 = (1 + (u & 1)) * SS_C + 32 * (u >> 1) + 16 * (r & 1); }
-  else if (f < WS_PROJ) { const int q = f - WS_Q, h = q / 24, r = q - h * 24; ks = r >> 1; base = a.qkv_w; ld = SS_C; row0 = 32 * h + 16 * (r & 1); }
-  else if (f < WS_FC1) { const int q = f - WS_PROJ, w = q / 36, r = q - w * 36; ks = r / 3; base = a.proj_w; ld = SS_C; row0 = 48 * w + 16 * (r - ks * 3); }
-  else if (f < WS_FC2) { const int q = f - WS_FC1, cw = q / 24, r = q - cw * 24; ks = r >> 1; base = a.fc1_w; ld = SS_C; row0 = 256 * (cw >> 3) + 32 * (cw & 7) + 16 * (r & 1); }
-  else { const int q = f - WS_FC2, cw = q / 24, r = q - cw * 24, ksl = r / 3; ks = 8 * (cw >> 3) + ksl; base = a.fc2_w; ld = SS_HID; row0 = 48 * (cw & 7) + 16 * (r - ksl * 3); }
+  SS_GEO(NW)
+  constexpr int UF = 2 * SS_KS, PF = 3 * SS_KS, F2 = 3 * SS_KSC;      // fragments per k / v / q unit, per wave of proj, per (chunk, wave) of fc2
+  if (f < WS_Q) { const int u = f / UF, r = f - u * UF; ks = r >> 1; base = a.qkv_w; ld = SS_C; row0 = (1 + (u & 1)) * SS_C + 32 * (u >> 1) + 16 * (r & 1); }
+  else if (f < WS_PROJ) { const int q = f - WS_Q, h = q / UF, r = q - h * UF; ks = r >> 1; base = a.qkv_w; ld = SS_C; row0 = 32 * h + 16 * (r & 1); }
+  else if (f < WS_FC1) { const int q = f - WS_PROJ, w = q / PF, r = q - w * PF; ks = r / 3; base = a.proj_w; ld = SS_C; row0 = 48 * w + 16 * (r - ks * 3); }
+  else if (f < WS_FC2) { const int q = f - WS_FC1, cw = q / UF, r = q - cw * UF; ks = r >> 1; base = a.fc1_w; ld = SS_C; row0 = 32 * NW * (cw / NW) + 32 * (cw % NW) + 16 * (r & 1); }
+  else { const int q = f - WS_FC2, cw = q / F2, r = q - cw * F2, ksl = r / 3; ks = SS_KSC * (cw / NW) + ksl; base = a.fc2_w; ld = SS_HID; row0 = 48 * (cw % NW) + 16 * (r - ksl * 3); }
 }
+template <int NW>
 __global__ __launch_bounds__(256) void sstage_pack_kernel(const PackArgs a) {
   const int f = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63, g = lane >> 4, i = lane & 15;
-  if (f >= WS_FRAGS) return;
+  if (f >= SG<NW>::WS_FRAGS) return;
   const bf16_t* base; int row0, ks, ld;
-  frag_source(f, a, base, row0, ks, ld);
+  frag_source<NW>(f, a, base, row0, ks, ld);
   const bf16_t* src = base + (size_t)(row0 + i) * ld + 32 * ks + 4 * g;
   const uint2 lo = *reinterpret_cast<const uint2*>(src), hi = *reinterpret_cast<const uint2*>(src + 16);
   a.out[(size_t)f * 64 + lane] = make_uint4(lo.x, lo.y, hi.x, hi.y);
@@ -731,30 +761,74 @@ __global__ __launch_bounds__(256) void sstage_pack_kernel(const PackArgs a) {
 }  // namespace
 
 // ---- C ABI --------------------------------------------------------------------------------------------------------------------
+static int ss_waves(int C, int heads, int hidden) {          // NW of the kernel instance that serves this stage, or 0
+  for (int nw : {8, 4})
+    if (C == 48 * nw && heads == C / 32 && hidden == 4 * C) return nw;
+  return 0;
+}
 int lmv_sstage_supported(int C, int heads, int hidden, int H, int W, int M, int dtype) {
-  return dtype == LMV_BF16 && C == SS_C && heads == SS_NH && hidden == SS_HID && H == SS_G && W == SS_G && M == SS_M;
+  return dtype == LMV_BF16 && ss_waves(C, heads, hidden) != 0 && H == SS_G && W == SS_G && M == SS_M;
 }
-size_t lmv_sstage_wpk_bytes(int C, int hidden) { (void)C; (void)hidden; return (size_t)WS_FRAGS * 1024; }
-size_t lmv_sstage_vec_floats(int C, int hidden) { (void)C; (void)hidden; return (size_t)V_FLOATS; }
-size_t lmv_sstage_workspace_bytes(int B) {
+size_t lmv_sstage_wpk_bytes(int C, int hidden) { return ss_waves(C, C / 32, hidden) == 4 ? (size_t)SG<4>::WS_FRAGS * 1024 : (size_t)SG<8>::WS_FRAGS * 1024; }
+size_t lmv_sstage_vec_floats(int C, int hidden) { (void)hidden; return (size_t)23 * C; }
+template <int NW> static size_t ss_workspace(int B) {
   const size_t flags = ((size_t)(4 * B + 1) * 4 + 1023) & ~(size_t)1023;
-  return flags + (size_t)B * (KBUF_IMG + VBUF_IMG + HALO_IMG + PARK_IMG);
+  return flags + (size_t)B * (SG<NW>::KBUF_IMG + SG<NW>::VBUF_IMG + SG<NW>::HALO_IMG + SG<NW>::PARK_IMG);
 }
+size_t lmv_sstage_workspace_bytes(int B, int C) { return C == 192 ? ss_workspace<4>(B) : ss_workspace<8>(B); }
+int lmv_sstage_max_images(int C) { return C == 192 ? 256 : 128; }
 
 int lmv_sstage_pack(const lmv_sstage_block_params* p, void* wpk_out, float* vec_out, void* stream) {
   if (!p || !wpk_out || !vec_out) LMV_FAIL(LMV_ERR_SHAPE, "sstage_pack: null argument");
-  if (!lmv_sstage_supported(p->C, p->heads, p->hidden, SS_G, SS_G, SS_M, LMV_BF16)) LMV_FAIL(LMV_ERR_DTYPE, "sstage_pack: C = %d / heads = %d / hidden = %d is not a supported stage", p->C, p->heads, p->hidden);
+  const int nw = ss_waves(p->C, p->heads, p->hidden);
+  if (!nw) LMV_FAIL(LMV_ERR_DTYPE, "sstage_pack: C = %d / heads = %d / hidden = %d is not a supported stage", p->C, p->heads, p->hidden);
   const void* ptrs[] = {p->qkv_w, p->proj_w, p->fc1_w, p->fc2_w, p->n1_w, p->n1_b, p->qkv_b, p->proj_b, p->n2_w, p->n2_b, p->fc1_b, p->fc2_b, p->pos_w, p->pos_b};
   for (const void* q : ptrs) if (!q || !lmv_aligned16(q)) LMV_FAIL(LMV_ERR_SHAPE, "sstage_pack: null or misaligned parameter pointer");
   if (!lmv_aligned16(wpk_out) || !lmv_aligned16(vec_out)) LMV_FAIL(LMV_ERR_SHAPE, "sstage_pack: misaligned output");
   hipStream_t st = (hipStream_t)stream;
   PackArgs a{(const bf16_t*)p->qkv_w, (const bf16_t*)p->proj_w, (const bf16_t*)p->fc1_w, (const bf16_t*)p->fc2_w, (uint4*)wpk_out};
-  hipLaunchKernelGGL(sstage_pack_kernel, dim3(WS_FRAGS / 4), dim3(256), 0, st, a);
+  if (nw == 8) hipLaunchKernelGGL(sstage_pack_kernel<8>, dim3((SG<8>::WS_FRAGS + 3) / 4), dim3(256), 0, st, a);
+  else hipLaunchKernelGGL(sstage_pack_kernel<4>, dim3((SG<4>::WS_FRAGS + 3) / 4), dim3(256), 0, st, a);
   LMV_CHECK_LAUNCH("sstage_pack");
-  const struct { const float* src; int off, n; } v[] = {{p->n1_w, V_N1W, 384}, {p->n1_b, V_N1B, 384}, {p->qkv_b, V_QKVB, 1152}, {p->proj_b, V_PROJB, 384}, {p->n2_w, V_N2W, 384},
-                                                        {p->n2_b, V_N2B, 384}, {p->fc1_b, V_FC1B, 1536}, {p->fc2_b, V_FC2B, 384}, {p->pos_w, V_POSW, 3456}, {p->pos_b, V_POSB, 384}};
+  const int C = p->C;
+  const struct { const float* src; int off, n; } v[] = {{p->n1_w, 0, C}, {p->n1_b, C, C}, {p->qkv_b, 2 * C, 3 * C}, {p->proj_b, 5 * C, C}, {p->n2_w, 6 * C, C},
+                                                        {p->n2_b, 7 * C, C}, {p->fc1_b, 8 * C, 4 * C}, {p->fc2_b, 12 * C, C}, {p->pos_w, 13 * C, 9 * C}, {p->pos_b, 22 * C, C}};
   for (const auto& e : v)
     if (hipMemcpyAsync(vec_out + e.off, e.src, (size_t)e.n * sizeof(float), hipMemcpyDeviceToDevice, st) != hipSuccess) LMV_FAIL(LMV_ERR_LAUNCH, "sstage_pack: vector copy failed");
+  return LMV_OK;
+}
+
+template <int NW>
+static int ss_launch(const lmv_sstage_desc* d, const void* x, const void* c, void* x_out, void* c_out, void* workspace, size_t workspace_bytes, hipStream_t st) {
+  using G = SG<NW>;
+  static std::atomic<unsigned long long> attr_done{0};
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  const unsigned long long bit = 1ull << (dev & 63);
+  if (!(attr_done.load(std::memory_order_acquire) & bit)) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(sstage_kernel<NW>), hipFuncAttributeMaxDynamicSharedMemorySize, G::L_TOTAL) != hipSuccess) LMV_FAIL(LMV_ERR_LAUNCH, "sstage_fwd: cannot reserve LDS");
+    attr_done.fetch_or(bit, std::memory_order_release);
+  }
+  // Both halves of an image must be resident at the same time (they wait for each other): at most 256 CUs x (1 workgroup of 8 waves | 2 of 4 waves)
+  // = 128 | 256 images per launch; a larger batch runs as consecutive launches over ranges of images.
+  const int MAXB = NW == 8 ? 128 : 256;
+  for (int b0 = 0; b0 < d->B; b0 += MAXB) {
+    const int nb = d->B - b0 < MAXB ? d->B - b0 : MAXB;
+    if (workspace_bytes < ss_workspace<NW>(nb)) LMV_FAIL(LMV_ERR_WORKSPACE, "sstage_fwd: workspace too small");
+    const size_t flags = ((size_t)(4 * nb + 1) * 4 + 1023) & ~(size_t)1023;
+    unsigned char* ws = (unsigned char*)workspace;
+    if (hipMemsetAsync(ws, 0, flags, st) != hipSuccess) LMV_FAIL(LMV_ERR_LAUNCH, "sstage_fwd: flag reset failed");      // every polled word, every call (Guideline 16)
+    SsArgs a{};
+    a.x_in = (const bf16_t*)x + (size_t)b0 * SS_NIMG * G::C; a.c_in = (const bf16_t*)c + (size_t)b0 * SS_M * G::C;
+    a.x_out = (bf16_t*)x_out + (size_t)b0 * SS_NIMG * G::C; a.c_out = (bf16_t*)c_out + (size_t)b0 * SS_M * G::C;
+    a.wpk = (const uint4*)d->wpk; a.vec = d->vec;
+    a.flags = (unsigned*)ws; a.kbuf = ws + flags; a.vbuf = a.kbuf + (size_t)nb * G::KBUF_IMG; a.halo = a.vbuf + (size_t)nb * G::VBUF_IMG; a.park = a.halo + (size_t)nb * G::HALO_IMG;
+    a.B = nb; a.nblocks = d->nblocks; a.eps = d->eps;
+    a.timing = (unsigned long long*)d->timing; a.timing_block = d->timing_block;
+    const int nwg = 2 * ((nb + 7) / 8) * 8;
+    hipLaunchKernelGGL(sstage_kernel<NW>, dim3(nwg), dim3(64 * NW), G::L_TOTAL, st, a);
+    LMV_CHECK_LAUNCH("sstage_fwd");
+  }
   return LMV_OK;
 }
 
@@ -764,34 +838,6 @@ int lmv_sstage_fwd(const lmv_sstage_desc* d, const void* x, const void* c, void*
   if (d->B <= 0 || d->nblocks <= 0 || !d->wpk || !d->vec) LMV_FAIL(LMV_ERR_SHAPE, "sstage_fwd: bad descriptor");
   const void* ptrs[] = {x, c, x_out, c_out, workspace, d->wpk, d->vec};
   for (const void* q : ptrs) if (!lmv_aligned16(q)) LMV_FAIL(LMV_ERR_SHAPE, "sstage_fwd: pointers must be 16-byte aligned");
-  hipStream_t st = (hipStream_t)stream;
-  static std::atomic<unsigned long long> attr_done{0};
-  int dev = 0;
-  (void)hipGetDevice(&dev);
-  const unsigned long long bit = 1ull << (dev & 63);
-  if (!(attr_done.load(std::memory_order_acquire) & bit)) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(sstage_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, L_TOTAL) != hipSuccess) LMV_FAIL(LMV_ERR_LAUNCH, "sstage_fwd: cannot reserve LDS");
-    attr_done.fetch_or(bit, std::memory_order_release);
-  }
-  // Both halves of an image must be resident at the same time (they wait for each other): at most 128 images (256 workgroups, one per CU)
-  // per launch; a larger batch runs as consecutive launches over ranges of images.
-  constexpr int MAXB = 128;
-  for (int b0 = 0; b0 < d->B; b0 += MAXB) {
-    const int nb = d->B - b0 < MAXB ? d->B - b0 : MAXB;
-    if (workspace_bytes < lmv_sstage_workspace_bytes(nb)) LMV_FAIL(LMV_ERR_WORKSPACE, "sstage_fwd: workspace too small");
-    const size_t flags = ((size_t)(4 * nb + 1) * 4 + 1023) & ~(size_t)1023;
-    unsigned char* ws = (unsigned char*)workspace;
-    if (hipMemsetAsync(ws, 0, flags, st) != hipSuccess) LMV_FAIL(LMV_ERR_LAUNCH, "sstage_fwd: flag reset failed");      // every polled word, every call (Guideline 16)
-    SsArgs a{};
-    a.x_in = (const bf16_t*)x + (size_t)b0 * SS_NIMG * SS_C; a.c_in = (const bf16_t*)c + (size_t)b0 * SS_M * SS_C;
-    a.x_out = (bf16_t*)x_out + (size_t)b0 * SS_NIMG * SS_C; a.c_out = (bf16_t*)c_out + (size_t)b0 * SS_M * SS_C;
-    a.wpk = (const uint4*)d->wpk; a.vec = d->vec;
-    a.flags = (unsigned*)ws; a.kbuf = ws + flags; a.vbuf = a.kbuf + (size_t)nb * KBUF_IMG; a.halo = a.vbuf + (size_t)nb * VBUF_IMG; a.park = a.halo + (size_t)nb * HALO_IMG;
-    a.B = nb; a.nblocks = d->nblocks; a.eps = d->eps;
-    a.timing = (unsigned long long*)d->timing; a.timing_block = d->timing_block;
-    const int nwg = 2 * ((nb + 7) / 8) * 8;
-    hipLaunchKernelGGL(sstage_kernel, dim3(nwg), dim3(512), L_TOTAL, st, a);
-    LMV_CHECK_LAUNCH("sstage_fwd");
-  }
-  return LMV_OK;
+  return ss_waves(d->C, d->heads, d->hidden) == 8 ? ss_launch<8>(d, x, c, x_out, c_out, workspace, workspace_bytes, (hipStream_t)stream)
+                                                 : ss_launch<4>(d, x, c, x_out, c_out, workspace, workspace_bytes, (hipStream_t)stream);
 }

@@ -656,7 +656,7 @@ def sstage_fwd(x: Tensor, c: Tensor, P: SStagePacked, H: int, W: int, eps: float
     d.wpk, d.vec = P.wpk.data_ptr(), P.vec.data_ptr()
     d.timing, d.timing_block = (None if timing is None else timing.data_ptr()), timing_block
     xo, co = torch.empty_like(x), torch.empty_like(c)
-    nbytes = int(lib.lmv_sstage_workspace_bytes(min(B, 128)))
+    nbytes = int(lib.lmv_sstage_workspace_bytes(min(B, int(lib.lmv_sstage_max_images(C_))), C_))
     ws = _workspace(nbytes, x.device)
     check(lib.lmv_sstage_fwd(C.byref(d), _ptr(x), _ptr(c), _ptr(xo), _ptr(co), ws.data_ptr(), ws.numel(), _stream()), "lmv_sstage_fwd")
     return xo, co

@@ -13,10 +13,10 @@ from oracle import lemevit_oracle as O
 from test_oracle_golden import block_spec
 
 DEV = "cuda:0"
-C, HEADS, HID, G, M = 384, 12, 1536, 14, 16
+G, M = 14, 16
 
 
-def _stage_params(nblocks, seed):
+def _stage_params(nblocks, seed, C=384):
     """fp32 state dicts of `nblocks` S blocks with bf16-representable matrices (the kernel's operands), vectors fp32."""
     sds = []
     for j in range(nblocks):
@@ -30,6 +30,7 @@ def _stage_params(nblocks, seed):
 
 def _pack(sds):
     from lemevit_amd import ops
+    C = sds[0]["blk.norm1.weight"].shape[0]
     blocks = []
     for sd in sds:
         d = {}
@@ -39,10 +40,11 @@ def _pack(sds):
                 t = t.reshape(C, 9)
             d[name] = t.to(torch.bfloat16) if (t.dim() >= 2 and "pos_embed" not in name) else t.float()
         blocks.append(d)
-    return ops.sstage_pack(blocks, HEADS)
+    return ops.sstage_pack(blocks, C // 32)
 
 
 def _oracle(sds, x, c):
+    HEADS = x.shape[-1] // 32
     x, c = x.double(), c.double()
     for sd in sds:
         sdd = {k: v.double() for k, v in sd.items()}
@@ -50,7 +52,7 @@ def _oracle(sds, x, c):
     return x, c
 
 
-def _inputs(B, seed, scale=1.0):
+def _inputs(B, seed, scale=1.0, C=384):
     x = det_tensor((B, G * G, C), "sstage.x", seed, scale).to(torch.bfloat16)
     c = det_tensor((B, M, C), "sstage.c", seed, scale).to(torch.bfloat16)
     return x, c
@@ -62,34 +64,35 @@ def _rel(a, ref):
     return float(np.abs(a - ref).max() / max(np.abs(ref).max(), 1e-30))
 
 
+@pytest.mark.parametrize("C", [384, 192])          # stage 3 of LeMeViT-Base (8 waves per workgroup) / LeMeViT-Tiny (4 waves, two workgroups per CU)
 @pytest.mark.parametrize("nblocks,B", [(1, 1), (1, 3), (2, 2), (3, 9)])
-def test_sstage_vs_oracle(nblocks, B):
+def test_sstage_vs_oracle(nblocks, B, C):
     """Full tensors against the float64 oracle.  One block: 1e-2 of max-abs (bf16 operands at five contractions, fp16 P / V, the GELU
     polynomial; the per-launch bf16 schedule is held to 2e-2 by tests/test_model_gpu.py::test_block_forward); the residual stream stays
     fp32 between blocks here, so the bound does not grow with the depth the way a bf16 stream's does."""
     from lemevit_amd import ops
-    sds = _stage_params(nblocks, 5)
+    sds = _stage_params(nblocks, 5, C)
     P = _pack(sds)
-    x, c = _inputs(B, 3)
+    x, c = _inputs(B, 3, C=C)
     xo, co = ops.sstage_fwd(x.to(DEV), c.to(DEV), P, G, G, 1e-6)
     torch.cuda.synchronize()
     xr, cr = _oracle(sds, x.float(), c.float())
     ex, ec = _rel(xo.float(), xr), _rel(co.float(), cr)
-    print(f"sstage nblocks={nblocks} B={B}: x {ex:.2e} c {ec:.2e}")
+    print(f"sstage C={C} nblocks={nblocks} B={B}: x {ex:.2e} c {ec:.2e}")
     assert ex <= 1e-2 and ec <= 1e-2, (ex, ec)
 
 
-def test_sstage_vs_per_launch_schedule_full_size():
-    """B = 128, 18 blocks (stage 3 of LeMeViT-Base at config 3) against 18 x the per-launch inference schedule (lmv_block_fwd) of the same
-    weights: both are bf16 pipelines of the same math, so they agree to a few bf16 roundings of the residual stream; and two runs of the
-    persistent launch agree bit for bit."""
+@pytest.mark.parametrize("C,nblocks,B", [(384, 18, 128), (192, 8, 256), (192, 8, 300)])
+def test_sstage_vs_per_launch_schedule_full_size(C, nblocks, B):
+    """Full batches -- stage 3 of LeMeViT-Base at config 3 (B = 128, 18 blocks), of LeMeViT-Tiny at config 2 (B = 256, 8 blocks) and a batch that needs
+    two launches -- against the per-launch inference schedule (lmv_block_fwd) of the same weights: both are bf16 pipelines of the same math, so they
+    agree to a few bf16 roundings of the residual stream; and two runs of the persistent launch agree bit for bit."""
     import lemevit_amd.model as Mm
     from lemevit_amd import ops
     from lemevit_amd.blocks import PARAM_NAMES
-    nblocks, B = 18, 128
-    sds = _stage_params(nblocks, 9)
+    sds = _stage_params(nblocks, 9, C)
     P = _pack(sds)
-    x, c = _inputs(B, 4)
+    x, c = _inputs(B, 4, C=C)
     x, c = x.to(DEV), c.to(DEV)
     xo, co = ops.sstage_fwd(x, c, P, G, G, 1e-6)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -97,7 +100,7 @@ def test_sstage_vs_per_launch_schedule_full_size():
     xo2, co2 = ops.sstage_fwd(x, c, P, G, G, 1e-6)
     e1.record()
     torch.cuda.synchronize()
-    print(f"sstage 18 blocks, B = 128: {e0.elapsed_time(e1):.3f} ms")
+    print(f"sstage C = {C}, {nblocks} blocks, B = {B}: {e0.elapsed_time(e1):.3f} ms")
     assert torch.equal(xo, xo2) and torch.equal(co, co2)
     xr, cr = x, c
     with torch.no_grad():
@@ -105,5 +108,5 @@ def test_sstage_vs_per_launch_schedule_full_size():
             params = {n: sd["blk." + n].to(DEV) for n in PARAM_NAMES["S"]}
             xr, cr = Mm.run_block("S", xr, cr, G, G, params, (None,) * 4)
     ex, ec = _rel(xo.float(), xr.float()), _rel(co.float(), cr.float())
-    print(f"sstage vs per-launch schedule, 18 blocks, B = 128: x {ex:.2e} c {ec:.2e}")
+    print(f"sstage vs per-launch schedule, C = {C}, {nblocks} blocks, B = {B}: x {ex:.2e} c {ec:.2e}")
     assert ex <= 3e-2 and ec <= 3e-2, (ex, ec)

@@ -110,3 +110,33 @@ def test_sstage_vs_per_launch_schedule_full_size(C, nblocks, B):
     ex, ec = _rel(xo.float(), xr.float()), _rel(co.float(), cr.float())
     print(f"sstage vs per-launch schedule, C = {C}, {nblocks} blocks, B = {B}: x {ex:.2e} c {ec:.2e}")
     assert ex <= 3e-2 and ec <= 3e-2, (ex, ec)
+
+
+@pytest.mark.parametrize("C,nblocks,B", [(384, 6, 128), (192, 8, 256)])
+def test_sstage_handoffs_under_uneven_load(C, nblocks, B):
+    """MI355X_MICROARCH.md, "Workgroup dispatch, XCD placement & inter-workgroup visibility": test every in-launch hand-off under UNEVEN load, checking
+    every word.  The K / V and grid-row exchanges of the stage kernel run (a) on an idle chip, (b) while another stream streams 1.5 GB through HBM and
+    (c) next to a second stage launch on a third stream that takes half of the CUs (so that pairs start late and unevenly); all outputs must be
+    bit-identical, and the kernel's error flag (a spin that ran out) must stay clear."""
+    from lemevit_amd import ops
+    sds = _stage_params(nblocks, 21, C)
+    P = _pack(sds)
+    x, c = _inputs(B, 6, C=C)
+    x, c = x.to(DEV), c.to(DEV)
+    ref = ops.sstage_fwd(x, c, P, G, G, 1e-6)
+    torch.cuda.synchronize()
+    big = torch.empty(3 * 128 * 1024 * 1024, device=DEV, dtype=torch.float32)
+    side, side2 = torch.cuda.Stream(), torch.cuda.Stream()
+    xh, ch = x[: B // 2].contiguous(), c[: B // 2].contiguous()
+    for rnd in range(4):
+        with torch.cuda.stream(side):
+            for _ in range(6):
+                big.mul_(1.0001)
+        if rnd % 2:
+            with torch.cuda.stream(side2):
+                half = ops.sstage_fwd(xh, ch, P, G, G, 1e-6)
+        out = ops.sstage_fwd(x, c, P, G, G, 1e-6)
+        torch.cuda.synchronize()
+        assert torch.equal(out[0], ref[0]) and torch.equal(out[1], ref[1]), rnd
+        if rnd % 2:
+            assert torch.equal(half[0], ref[0][: B // 2]) and torch.equal(half[1], ref[1][: B // 2]), rnd

@@ -14,7 +14,7 @@ LIB_PATH = os.path.join(_HERE, "csrc", "liblemevit_hip.so")
 
 LMV_F32, LMV_BF16 = 0, 1
 ACT_NONE, ACT_GELU, ACT_GELU_GRAD = 0, 1, 2
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 
 class LinearProblem(C.Structure):
@@ -71,6 +71,12 @@ class SStageBlockParams(C.Structure):
 
 class SStageDesc(C.Structure):
     _fields_ = ([(n, C.c_int32) for n in ("B", "H", "W", "M", "C", "heads", "hidden", "nblocks", "dtype")] + [("eps", C.c_float), ("wpk", C.c_void_p), ("vec", C.c_void_p), ("timing", C.c_void_p), ("timing_block", C.c_int32), ("_pad", C.c_int32)])
+
+
+class DStageBlockParams(C.Structure):
+    _fields_ = ([(n, C.c_int32) for n in ("C", "heads", "hidden", "_pad")] +
+                [(n, C.c_void_p) for n in ("qkv1_w", "qkv2_w", "projx_w", "projc_w", "fc1_w", "fc2_w", "n1_w", "n1_b", "qkv1_b", "qkv2_b", "projx_b", "projc_b",
+                                           "n2_w", "n2_b", "fc1_b", "fc2_b", "pos_w", "pos_b")])
 
 
 class TransposeSeg(C.Structure):
@@ -150,6 +156,12 @@ SIGNATURES = {
     "lmv_sstage_max_images": (_I, [_I]),
     "lmv_sstage_pack": (_I, [C.POINTER(SStageBlockParams), _P, _P, _P]),
     "lmv_sstage_fwd": (_I, [C.POINTER(SStageDesc), _P, _P, _P, _P, _P, _Z, _P]),
+    "lmv_dstage_supported": (_I, [_I, _I, _I, _I, _I, _I, _I]),
+    "lmv_dstage_wpk_bytes": (_Z, [_I, _I]),
+    "lmv_dstage_vec_floats": (_Z, [_I, _I]),
+    "lmv_dstage_workspace_bytes": (_Z, [_I, _I]),
+    "lmv_dstage_pack": (_I, [C.POINTER(DStageBlockParams), _P, _P, _P]),
+    "lmv_dstage_fwd": (_I, [C.POINTER(SStageDesc), _P, _P, _P, _P, _P, _Z, _P]),
 }
 
 

@@ -1,0 +1,735 @@
+// dstage.hip -- a whole run of "D" blocks (Dual Cross-Attention: stages 1 / 2 of LeMeViT) as ONE persistent launch with the token rows resident on
+// chip (round 4; inference form).  The construction of csrc/sstage.hip carried to the blocks whose image tokens do not fit one workgroup.
+//
+// Reference math: LeMeBlock.forward_with_xc, models/lemevit.py:542-582 (live branch :560-564): x = x + dwconv3x3(x) (:546);
+// (ax, ac) = DualCrossAttention(norm1(x), norm1(c)); x = x + ax; x = x + mlp(norm2(x)); c = c + ac; c = c + mlp(norm2(c)), with
+// DualCrossAttention :220-324 (live :288-302): qkv1 = W1 x + b1, qkv2 = W2 c + b2, ax = proj_x(softmax(q1 k2^T s_x) v2) (every image token against the
+// 16 meta keys), ac = proj_c(softmax(q2 k1^T s_c) v1) (16 meta queries against ALL image keys), s_x = log_N(M) C^-1/2, s_c = C^-1/2 (:235,255-256).
+//
+// Decomposition.  An image's N = GW x GW image tokens are KWG workgroups of 112 tokens (7 tiles of 16 = ROWS whole grid rows: 4 rows of 28 at stage 2,
+// 2 rows of 56 at stage 1) plus ONE meta workgroup that owns the 16 meta tokens.  All KWG + 1 workgroups of an image are resident at the same time and walk
+// the blocks of the stage together; a launch processes `slots` images at a time and loops over the batch.  What crosses workgroups, per block, through L2
+// (write-through stores, sc1 loads, one relaxed agent-scope flag per hand-off, epochs counted inside the call -- cdna_hip_programming.md Guideline 16, R1):
+//   * the grid rows next to a cut, both ways (3 x 3 position embedding), double-buffered by block parity;
+//   * meta -> image: the operand fragments the image tokens need from the meta tokens -- K2 and V2 of every head (x-direction attention, 16 keys) and
+//     q~ = (q2 W_k1[h]) s_c log2 e: the meta queries pushed through the k-projection of the image tokens, so that the c-direction scores are q~ . norm1(x)
+//     straight off the LayerNorm output in LDS -- the image tokens' k projection (C x C per token) is never computed; its bias shifts every score of a
+//     query by the same amount and drops out of the softmax;
+//   * image -> meta: per head the partial (max, sum, sum p v) of the 16 meta queries over the workgroup's 112 keys; the meta workgroup combines the KWG
+//     partials (log-sum-exp), adds the v bias (sum p = 1), and runs the whole c path (proj_c, norm2, MLP on 16 tokens) itself.
+// Inside an image workgroup: exactly the data flow of sstage.hip (NW waves x 48 channels: C = 48 NW; residual in registers; weights straight from L2 in fragment
+// order; token operands in LDS in fragment order; transposed outputs as ready operand fragments; MLP in 6 chunks); v1 is computed with the operands swapped
+// (the V^T operand of P V) right behind the scores of its head, in the same wave.
+#include <atomic>
+#include "stage_common.h"
+
+namespace {
+
+constexpr int DS_NCHUNK = 6, DS_M = 16, DS_NSTAMP = 16;
+
+template <int NW, int GW> struct DG {
+  static constexpr int C = 48 * NW, NH = C / 32, HID = 4 * C, KS = C / 32, KSC = NW, PRD = KS % 4 == 0 ? 4 : 3;
+  static constexpr int ROWS = 112 / GW, KWG = GW / ROWS, NIMG = GW * GW, NWG = KWG + 1;
+  static_assert(ROWS * GW == 112 && KWG * ROWS == GW, "an image workgroup is whole grid rows");
+  // packed weights of a block, 1 KB fragments (stage_common.h / sstage.hip: lane (g, i) holds W[row0 + i][32 ks + 16 (j >> 2) + 4 g + (j & 3)])
+  static constexpr int WS_Q1 = 0;                                   // [head][ks][n 2]: rows 32 h + 16 n of qkv1.weight
+  static constexpr int WS_V1 = WS_Q1 + NH * KS * 2;                 // [head][ks][n 2]: rows 2 C + 32 h + 16 n of qkv1.weight
+  static constexpr int WS_PX = WS_V1 + NH * KS * 2;                 // [wave][ks][n 3]: rows 48 w + 16 n of proj_x.weight
+  static constexpr int WS_FC1 = WS_PX + NW * KS * 3;                // [chunk][wave][ks][n 2]
+  static constexpr int WS_FC2 = WS_FC1 + DS_NCHUNK * NW * KS * 2;   // [chunk][wave][ksl KSC][n 3]
+  static constexpr int WS_K2 = WS_FC2 + DS_NCHUNK * NW * KSC * 3;   // meta: [head][ks][n 2]: rows C + 32 h + 16 n of qkv2.weight
+  static constexpr int WS_V2 = WS_K2 + NH * KS * 2;                 //       rows 2 C + 32 h + 16 n
+  static constexpr int WS_Q2 = WS_V2 + NH * KS * 2;                 //       rows 32 h + 16 n
+  static constexpr int WS_K1T = WS_Q2 + NH * KS * 2;                // [head][m < C / 16]: lane (g, i) holds qkv1.weight[C + 32 h + 16 (j >> 2) + 4 g + (j & 3)][16 m + i]
+  static constexpr int WS_PC = WS_K1T + NH * (C / 16);              // [wave][ks][n 3]: proj_c.weight
+  static constexpr int WS_FRAGS = WS_PC + NW * KS * 3;
+  static constexpr int V_N1W = 0, V_N1B = C, V_QKV1B = 2 * C, V_QKV2B = 5 * C, V_PXB = 8 * C, V_PCB = 9 * C, V_N2W = 10 * C, V_N2B = 11 * C, V_FC1B = 12 * C,
+                       V_FC2B = 16 * C, V_POSW = 17 * C, V_POSB = 26 * C, V_FLOATS = 27 * C;
+  // LDS of an image workgroup (the meta workgroup uses the front of the same regions with one token tile)
+  static constexpr int L_XN = 0, L_XN_BYTES = KS * SS_NT * 1024;
+  static constexpr int L_H = L_XN_BYTES, L_H_BYTES = KSC * SS_NT * 1024;
+  static constexpr int L_STAT = L_H + L_H_BYTES, L_STAT_BYTES = NW * 112 * 8;
+  static constexpr int L_TOTAL = L_STAT + L_STAT_BYTES;
+  static constexpr int STG_COLS = GW + 2, STG_ENT = (ROWS + 2) * STG_COLS, STG_WAVE = STG_ENT * 32;      // dwconv staging: [ROWS + 2][GW + 2] entries of 16 channels, fp16
+  static_assert(NW * STG_WAVE <= L_STAT, "staging overlaps the statistics");
+  // per-slot workspace
+  static constexpr int MF_HEAD = 3 + KS;                                   // meta fragments per head: K2 | V2 d-tile 0 | V2 d-tile 1 | q~ [ks]
+  static constexpr size_t MFRAG_BYTES = (size_t)2 * NH * MF_HEAD * 1024;   // [parity][head][MF_HEAD]
+  static constexpr size_t HALO_BYTES = (size_t)2 * KWG * 2 * GW * C * 2;   // [parity][workgroup][first | last grid row][GW tokens][C] bf16
+  static constexpr size_t PART_BYTES = (size_t)KWG * NH * 3 * 1024;        // [workgroup][head][O d-tile 0 | O d-tile 1 | (max, sum)]: f32x4 per lane
+  static constexpr size_t SLOT_BYTES = MFRAG_BYTES + HALO_BYTES + PART_BYTES;
+  static constexpr int FLAGS_PER_SLOT = 2 * KWG + 1;                       // halo [KWG] | partial [KWG] | meta
+};
+
+struct DsArgs {
+  const bf16_t* x_in; const bf16_t* c_in; bf16_t* x_out; bf16_t* c_out;
+  const uint4* wpk; const float* vec;
+  unsigned char* slots; unsigned* flags;           // flags: [nslots][FLAGS_PER_SLOT] | error
+  int B, nblocks, nslots; float eps, sx, sc;       // sx / sc: the two attention scales times log2 e
+  unsigned long long* timing; int timing_block;
+};
+
+#define DS_STAMP(k)                                                                                                                              \
+  do {                                                                                                                                           \
+    if (a.timing && gb == a.timing_block && lane == 0) a.timing[((size_t)blockIdx.x * NW + wave) * DS_NSTAMP + (k)] = __builtin_amdgcn_s_memtime(); \
+  } while (0)
+
+// LayerNorm of NTT register-resident token tiles -> bf16 operand fragments at `xn` ([k-step][tile]); statistics over the NW waves through `stat`
+template <int NW, int NTT>
+__device__ __forceinline__ void ds_layer_norm(const f32x4_t (&R)[NTT][3], const float* gam, const float* bet, float eps, unsigned char* xn, float2* stat, int wave, int lane) {
+  constexpr int C = 48 * NW;
+  const int g = lane >> 4, li = lane & 15;
+#pragma unroll
+  for (int t = 0; t < NTT; ++t) {
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int ct = 0; ct < 3; ++ct)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { s1 += R[t][ct][r]; s2 = fmaf(R[t][ct][r], R[t][ct][r], s2); }
+    s1 = xsum4(s1); s2 = xsum4(s2);
+    if (g == 0) stat[wave * 112 + t * 16 + li] = make_float2(s1, s2);
+  }
+  float4 ga[3], be[3];
+#pragma unroll
+  for (int ct = 0; ct < 3; ++ct) { ga[ct] = *reinterpret_cast<const float4*>(gam + 48 * wave + 16 * ct + 4 * g); be[ct] = *reinterpret_cast<const float4*>(bet + 48 * wave + 16 * ct + 4 * g); }
+  __syncthreads();
+  float mean[NTT], rstd[NTT];
+#pragma unroll
+  for (int t = 0; t < NTT; ++t) {
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) { const float2 p = stat[w * 112 + t * 16 + li]; s1 += p.x; s2 += p.y; }
+    mean[t] = s1 * (1.f / C);
+    rstd[t] = rsqrtf(fmaxf(s2 * (1.f / C) - mean[t] * mean[t], 0.f) + eps);
+  }
+#pragma unroll
+  for (int ct = 0; ct < 3; ++ct) {
+    const int T = 3 * wave + ct;
+#pragma unroll
+    for (int t = 0; t < NTT; ++t) {
+      const float y0 = fmaf((R[t][ct][0] - mean[t]) * rstd[t], ga[ct].x, be[ct].x), y1 = fmaf((R[t][ct][1] - mean[t]) * rstd[t], ga[ct].y, be[ct].y);
+      const float y2 = fmaf((R[t][ct][2] - mean[t]) * rstd[t], ga[ct].z, be[ct].z), y3 = fmaf((R[t][ct][3] - mean[t]) * rstd[t], ga[ct].w, be[ct].w);
+      *reinterpret_cast<uint2*>(xn + (((T >> 1) * NTT + t) * 64 + lane) * 16 + (T & 1) * 8) = make_uint2(pack_bf2(y0, y1), pack_bf2(y2, y3));
+    }
+  }
+  __syncthreads();
+}
+
+// the MLP half on NTT register-resident token tiles: fc1 chunk -> GELU -> LDS -> fc2 partial sums on R (bias of fc2 added by the caller)
+template <int NW, int NTT, typename G>
+__device__ __forceinline__ void ds_mlp(f32x4_t (&R)[NTT][3], const unsigned char* wp, const float* vec, unsigned char* xn, unsigned char* hb, int lane0, int wave0) {
+  constexpr int KS = G::KS, KSC = G::KSC;
+  bf16x8_t ring2[3][2], ring3[4][3];
+  ring_fill<2, 3>(ring2, wp + (size_t)(G::WS_FC1 + wave0 * (2 * KS)) * 1024, lane0);
+#pragma unroll 1
+  for (int c = 0; c < DS_NCHUNK; ++c) {
+    {
+      __builtin_amdgcn_sched_barrier(0);
+      int lane = lane0; asm volatile("" : "+v"(lane));
+      int wave = wave0; asm volatile("" : "+s"(wave));
+      const int g = lane >> 4;
+      f32x4_t acc[NTT][2];
+#pragma unroll
+      for (int t = 0; t < NTT; ++t) { acc[t][0] = f32x4_t{0.f, 0.f, 0.f, 0.f}; acc[t][1] = acc[t][0]; }
+      const unsigned char* wcur = wp + (size_t)(G::WS_FC1 + (c * NW + wave) * (2 * KS)) * 1024;
+      const float* b1p = vec + G::V_FC1B + 32 * NW * c + 32 * wave + 4 * g;
+      const float4 b0 = *reinterpret_cast<const float4*>(b1p), b1 = *reinterpret_cast<const float4*>(b1p + 16);
+      gemm_unit<2, KS, 3, true, NTT>(acc, ring2, wcur, c + 1 < DS_NCHUNK ? wcur + NW * (2 * KS) * 1024 : wcur, xn, lane);
+      ring_fill<3, 4>(ring3, wp + (size_t)(G::WS_FC2 + (c * NW + wave) * (3 * KSC)) * 1024, lane);
+#pragma unroll
+      for (int t = 0; t < NTT; ++t) {
+        f32x2_t h0 = {acc[t][0][0] + b0.x, acc[t][0][1] + b0.y}, h1 = {acc[t][0][2] + b0.z, acc[t][0][3] + b0.w};
+        f32x2_t h2 = {acc[t][1][0] + b1.x, acc[t][1][1] + b1.y}, h3 = {acc[t][1][2] + b1.z, acc[t][1][3] + b1.w};
+        gelu4(h0, h1, h2, h3);
+        const u32x4_t hf = {pack_bf2(h0[0], h0[1]), pack_bf2(h1[0], h1[1]), pack_bf2(h2[0], h2[1]), pack_bf2(h3[0], h3[1])};
+        *reinterpret_cast<u32x4_t*>(hb + ((wave * NTT + t) * 64 + lane) * 16) = hf;
+      }
+    }
+    __syncthreads();
+    {
+      __builtin_amdgcn_sched_barrier(0);
+      int lane = lane0; asm volatile("" : "+v"(lane));
+      int wave = wave0; asm volatile("" : "+s"(wave));
+      const unsigned char* wcur = wp + (size_t)(G::WS_FC2 + (c * NW + wave) * (3 * KSC)) * 1024;
+      gemm_unit<3, KSC, 4, true, NTT>(R, ring3, wcur, wcur, hb, lane);
+    }
+    if (c + 1 < DS_NCHUNK) __syncthreads();
+  }
+}
+
+template <int NW, int GW>
+__global__ __launch_bounds__(64 * NW, 2) void dstage_kernel(const DsArgs a) {
+  using G = DG<NW, GW>;
+  constexpr int C = G::C, NH = G::NH, KS = G::KS, KWG = G::KWG, ROWS = G::ROWS;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane0 = tid & 63, wave0 = __builtin_amdgcn_readfirstlane(tid >> 6);
+#define DS_PHASE                                                    \
+  __builtin_amdgcn_sched_barrier(0);                                \
+  int lane = lane0; asm volatile("" : "+v"(lane));                  \
+  int wave = wave0; asm volatile("" : "+s"(wave));                  \
+  const int g = lane >> 4, li = lane & 15; (void)g; (void)li; (void)wave;
+  // the workgroups of an image slot share an XCD under the round-robin dispatch (a speed matter only)
+  const int xcd = blockIdx.x & 7, jj = blockIdx.x >> 3;
+  const int slot = (jj / G::NWG) * 8 + xcd, role = jj % G::NWG;          // role < KWG: image rows [role ROWS, (role + 1) ROWS); role == KWG: the meta tokens
+  if (slot >= a.nslots) return;
+  unsigned* const fl = a.flags + (size_t)slot * G::FLAGS_PER_SLOT;
+  unsigned* const haloflag = fl, * const partflag = fl + KWG, * const mflag = fl + 2 * KWG;
+  unsigned* const errflag = a.flags + (size_t)a.nslots * G::FLAGS_PER_SLOT;
+  unsigned char* const sb = a.slots + (size_t)slot * G::SLOT_BYTES;
+  unsigned char* const mfr = sb, * const halo = sb + G::MFRAG_BYTES, * const part = halo + G::HALO_BYTES;
+  float2* const stat = reinterpret_cast<float2*>(smem + G::L_STAT);
+
+  int round = 0;
+#pragma unroll 1
+  for (int img = slot; img < a.B; img += a.nslots, ++round) {
+    if (role == KWG) {
+      // =================================== the meta workgroup: the 16 meta tokens of image `img` ===================================
+      f32x4_t Rc[1][3];
+      {
+        DS_PHASE
+#pragma unroll
+        for (int ct = 0; ct < 3; ++ct) { float f[4]; ld4(a.c_in + ((size_t)img * DS_M + li) * C + 48 * wave + 16 * ct + 4 * g, f); Rc[0][ct] = f32x4_t{f[0], f[1], f[2], f[3]}; }
+      }
+#pragma unroll 1
+      for (int blk = 0; blk < a.nblocks; ++blk) {
+        const int gb = round * a.nblocks + blk;                    // global block counter of this slot: epochs and buffer parities
+        const unsigned char* const wp = reinterpret_cast<const unsigned char*>(a.wpk) + (size_t)blk * G::WS_FRAGS * 1024;
+        const float* const vec = a.vec + (size_t)blk * G::V_FLOATS;
+        unsigned char* const mf = mfr + (size_t)(gb & 1) * (G::MFRAG_BYTES / 2);
+        const __amdgpu_buffer_rsrc_t mr = __builtin_amdgcn_make_buffer_rsrc(mf, 0, (int)(G::MFRAG_BYTES / 2), 0x00020000);
+        // ---- norm1(c) -> LDS; K2 / V2 / q2 of every head; q~ = q2 W_k1; all published for the image workgroups ----
+        {
+          DS_PHASE
+          ds_layer_norm<NW, 1>(Rc, vec + G::V_N1W, vec + G::V_N1B, a.eps, smem + G::L_XN, stat, wave, lane);
+        }
+        {
+          DS_PHASE
+          // 3 NH units (k2, v2, q2 of a head: 2 channel tiles x 1 token tile x KS) dealt round-robin to the waves; q2 fragments also go to LDS for the q~ pass
+          bf16x8_t ring[3][2];
+#pragma unroll 1
+          for (int u = wave; u < 3 * NH; u += NW) {
+            const int h = u / 3, typ = u - 3 * h;                 // 0: k2, 1: v2, 2: q2
+            const unsigned char* wcur = wp + (size_t)((typ == 0 ? G::WS_K2 : typ == 1 ? G::WS_V2 : G::WS_Q2) + h * (2 * KS)) * 1024;
+            ring_fill<2, 3>(ring, wcur, lane);
+            f32x4_t acc[1][2] = {{f32x4_t{0.f, 0.f, 0.f, 0.f}, f32x4_t{0.f, 0.f, 0.f, 0.f}}};
+            if (typ == 1) {
+              const float bv0 = vec[G::V_QKV2B + 2 * C + 32 * h + li], bv1 = vec[G::V_QKV2B + 2 * C + 32 * h + 16 + li];
+              gemm_unit<2, KS, 3, false, 1>(acc, ring, wcur, wcur, smem + G::L_XN, lane);
+#pragma unroll
+              for (int dt = 0; dt < 2; ++dt) {
+                const f32x4_t lo = acc[0][dt] + (dt ? bv1 : bv0);
+                const u32x4_t pk = {pack_h2(lo[0], lo[1]), pack_h2(lo[2], lo[3]), 0u, 0u};
+                __builtin_amdgcn_raw_buffer_store_b128(pk, mr, ((h * G::MF_HEAD + 1 + dt) * 64 + lane) * 16, 0, 16);
+              }
+            } else {
+              const float* bp = vec + G::V_QKV2B + (typ == 0 ? C : 0) + 32 * h + 4 * g;
+              const float4 b0 = *reinterpret_cast<const float4*>(bp), b1 = *reinterpret_cast<const float4*>(bp + 16);
+              gemm_unit<2, KS, 3, true, 1>(acc, ring, wcur, wcur, smem + G::L_XN, lane);
+              const float sc = typ == 0 ? 1.f : a.sc;
+              const f32x4_t k0 = {(acc[0][0][0] + b0.x) * sc, (acc[0][0][1] + b0.y) * sc, (acc[0][0][2] + b0.z) * sc, (acc[0][0][3] + b0.w) * sc};
+              const f32x4_t k1 = {(acc[0][1][0] + b1.x) * sc, (acc[0][1][1] + b1.y) * sc, (acc[0][1][2] + b1.z) * sc, (acc[0][1][3] + b1.w) * sc};
+              const u32x4_t pk = pack_bf8(k0, k1);
+              if (typ == 0) __builtin_amdgcn_raw_buffer_store_b128(pk, mr, ((h * G::MF_HEAD) * 64 + lane) * 16, 0, 16);
+              else *reinterpret_cast<u32x4_t*>(smem + G::L_H + (h * 64 + lane) * 16) = pk;
+            }
+          }
+        }
+        __syncthreads();
+        {
+          DS_PHASE
+          // q~[h] = q2[h] (16 queries x 32 d) x W_k1[h] (32 d x C channels): C / 16 output tiles of one MFMA each, dealt to the waves by (head, k-step)
+#pragma unroll 1
+          for (int u = wave; u < NH * KS; u += NW) {
+            const int h = u / KS, ks = u - h * KS;
+            const bf16x8_t q2f = *reinterpret_cast<const bf16x8_t*>(smem + G::L_H + (h * 64 + lane) * 16);
+            const f32x4_t z4 = {0.f, 0.f, 0.f, 0.f};
+            const f32x4_t d0 = mfma_bf16(ld_frag(wp, G::WS_K1T + h * (C / 16) + 2 * ks, lane), q2f, z4);
+            const f32x4_t d1 = mfma_bf16(ld_frag(wp, G::WS_K1T + h * (C / 16) + 2 * ks + 1, lane), q2f, z4);
+            __builtin_amdgcn_raw_buffer_store_b128(pack_bf8(d0, d1), mr, ((h * G::MF_HEAD + 3 + ks) * 64 + lane) * 16, 0, 16);
+          }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) __hip_atomic_store((gu32*)mflag, (unsigned)(gb + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // ---- the KWG partials of the c-direction attention -> c' (log-sum-exp combine, + v bias) -> proj_c operand in LDS ----
+        if (wave0 == 0) {
+#pragma unroll 1
+          for (int r = 0; r < KWG; ++r) wait_flag(partflag + r, (unsigned)(gb + 1), errflag, lane0);
+        }
+        __syncthreads();
+        {
+          DS_PHASE
+          const __amdgpu_buffer_rsrc_t pr = __builtin_amdgcn_make_buffer_rsrc(part, 0, (int)G::PART_BYTES, 0x00020000);
+#pragma unroll 1
+          for (int h = wave; h < NH; h += NW) {
+            float M = -INFINITY;
+#pragma unroll 1
+            for (int r = 0; r < KWG; ++r) {
+              const u32x4_t ml = __builtin_amdgcn_raw_buffer_load_b128(pr, (((r * NH + h) * 3 + 2) * 64 + lane) * 16, 0, 16);
+              M = max2(M, __uint_as_float(ml[0]));
+            }
+            f32x4_t o0 = {0.f, 0.f, 0.f, 0.f}, o1 = o0;
+            float L = 0.f;
+#pragma unroll 1
+            for (int r = 0; r < KWG; ++r) {
+              const int base = ((r * NH + h) * 3 * 64 + lane) * 16;
+              const u32x4_t ml = __builtin_amdgcn_raw_buffer_load_b128(pr, base + 2 * 1024, 0, 16);
+              const f32x4_t p0 = __builtin_bit_cast(f32x4_t, __builtin_amdgcn_raw_buffer_load_b128(pr, base, 0, 16));
+              const f32x4_t p1 = __builtin_bit_cast(f32x4_t, __builtin_amdgcn_raw_buffer_load_b128(pr, base + 1024, 0, 16));
+              const float w = __builtin_amdgcn_exp2f(__uint_as_float(ml[0]) - M);
+              L = fmaf(__uint_as_float(ml[1]), w, L);
+              o0 += p0 * w; o1 += p1 * w;
+            }
+            const float inv = 1.f / L;
+            const float* bv = vec + G::V_QKV1B + 2 * C + 32 * h + 4 * g;
+            const float4 b0 = *reinterpret_cast<const float4*>(bv), b1 = *reinterpret_cast<const float4*>(bv + 16);
+            const f32x4_t c0 = {o0[0] * inv + b0.x, o0[1] * inv + b0.y, o0[2] * inv + b0.z, o0[3] * inv + b0.w};
+            const f32x4_t c1 = {o1[0] * inv + b1.x, o1[1] * inv + b1.y, o1[2] * inv + b1.z, o1[3] * inv + b1.w};
+            *reinterpret_cast<u32x4_t*>(smem + G::L_XN + (h * 64 + lane) * 16) = pack_bf8(c0, c1);
+          }
+        }
+        __syncthreads();
+        // ---- c += proj_c(c') + bias; norm2; MLP ----
+        {
+          DS_PHASE
+          float4 pb[3];
+#pragma unroll
+          for (int ct = 0; ct < 3; ++ct) pb[ct] = *reinterpret_cast<const float4*>(vec + G::V_PCB + 48 * wave + 16 * ct + 4 * g);
+          bf16x8_t ringp[G::PRD][3];
+          const unsigned char* wcur = wp + (size_t)(G::WS_PC + wave * (3 * KS)) * 1024;
+          ring_fill<3, G::PRD>(ringp, wcur, lane);
+          gemm_unit<3, KS, G::PRD, true, 1>(Rc, ringp, wcur, wcur, smem + G::L_XN, lane);
+#pragma unroll
+          for (int ct = 0; ct < 3; ++ct) { Rc[0][ct][0] += pb[ct].x; Rc[0][ct][1] += pb[ct].y; Rc[0][ct][2] += pb[ct].z; Rc[0][ct][3] += pb[ct].w; }
+          __syncthreads();          // every wave has read the proj_c operand: norm2 may overwrite it
+          ds_layer_norm<NW, 1>(Rc, vec + G::V_N2W, vec + G::V_N2B, a.eps, smem + G::L_XN, stat, wave, lane);
+        }
+        ds_mlp<NW, 1, G>(Rc, wp, vec, smem + G::L_XN, smem + G::L_H, lane0, wave0);
+        {
+          DS_PHASE
+#pragma unroll
+          for (int ct = 0; ct < 3; ++ct) {
+            const float4 b = *reinterpret_cast<const float4*>(vec + G::V_FC2B + 48 * wave + 16 * ct + 4 * g);
+            Rc[0][ct][0] += b.x; Rc[0][ct][1] += b.y; Rc[0][ct][2] += b.z; Rc[0][ct][3] += b.w;
+          }
+        }
+        __syncthreads();
+      }
+      {
+        DS_PHASE
+#pragma unroll
+        for (int ct = 0; ct < 3; ++ct) {
+          const float f[4] = {Rc[0][ct][0], Rc[0][ct][1], Rc[0][ct][2], Rc[0][ct][3]};
+          st4(a.c_out + ((size_t)img * DS_M + li) * C + 48 * wave + 16 * ct + 4 * g, f);
+        }
+      }
+      continue;
+    }
+
+    // =================================== an image workgroup: 112 image tokens (ROWS grid rows) of image `img` ===================================
+    const int tok0 = role * 112;
+    f32x4_t R[SS_NT][3];
+    {
+      DS_PHASE
+#pragma unroll
+      for (int t = 0; t < SS_NT; ++t) {
+        const bf16_t* src = a.x_in + ((size_t)img * G::NIMG + tok0 + 16 * t + li) * C;
+#pragma unroll
+        for (int ct = 0; ct < 3; ++ct) { float f[4]; ld4(src + 48 * wave + 16 * ct + 4 * g, f); R[t][ct] = f32x4_t{f[0], f[1], f[2], f[3]}; }
+      }
+    }
+#pragma unroll 1
+    for (int blk = 0; blk < a.nblocks; ++blk) {
+      const int gb = round * a.nblocks + blk;
+      const int lane = lane0, wave = wave0;      // (stamps only)
+      const unsigned char* const wp = reinterpret_cast<const unsigned char*>(a.wpk) + (size_t)blk * G::WS_FRAGS * 1024;
+      const float* const vec = a.vec + (size_t)blk * G::V_FLOATS;
+      DS_STAMP(0);
+      // ---- x += dwconv3x3(x) + bias: per channel tile a wave-private fp16 image [ROWS + 2][GW + 2] of its 16 channels, zero pads, rows across the cuts from the peers ----
+      {
+        DS_PHASE
+        unsigned char* const stg = smem + wave * G::STG_WAVE;
+        const unsigned char* const hprev = halo + (size_t)((gb + 1) & 1) * (G::HALO_BYTES / 2);      // the rows published at the end of block gb - 1
+        if (gb > 0) {
+          // (block 0 of a later image reads its halo from x_in, but still waits: a workgroup must not run two blocks ahead of a neighbour that reads its rows)
+          if (role > 0) wait_flag(haloflag + role - 1, (unsigned)gb, errflag, lane);
+          if (role + 1 < KWG) wait_flag(haloflag + role + 1, (unsigned)gb, errflag, lane);
+        }
+        float4 wq[2][10];
+#pragma unroll
+        for (int e = 0; e < 9; ++e) wq[0][e] = *reinterpret_cast<const float4*>(vec + G::V_POSW + (48 * wave + 4 * g) * 9 + 4 * e);
+        wq[0][9] = *reinterpret_cast<const float4*>(vec + G::V_POSB + 48 * wave + 4 * g);
+#pragma unroll
+        for (int ct = 0; ct < 3; ++ct) {
+          int l2 = lane; asm volatile("" : "+v"(l2));
+          const int g = l2 >> 4, li = l2 & 15;
+          const int c0 = 48 * wave + 16 * ct;
+          if (ct + 1 < 3) {
+#pragma unroll
+            for (int e = 0; e < 9; ++e) wq[(ct + 1) & 1][e] = *reinterpret_cast<const float4*>(vec + G::V_POSW + (c0 + 16 + 4 * g) * 9 + 4 * e);
+            wq[(ct + 1) & 1][9] = *reinterpret_cast<const float4*>(vec + G::V_POSB + c0 + 16 + 4 * g);
+          }
+          // own rows
+#pragma unroll
+          for (int t = 0; t < SS_NT; ++t) {
+            const int s = 16 * t + li, y = s / GW, x = s - y * GW;
+            *reinterpret_cast<uint2*>(stg + ((y + 1) * G::STG_COLS + x + 1) * 32 + 8 * g) = make_uint2(pack_h2(R[t][ct][0], R[t][ct][1]), pack_h2(R[t][ct][2], R[t][ct][3]));
+          }
+          // pad columns, and the rows beyond the image
+          for (int e = l2; e < 2 * (ROWS + 2) * 2; e += 64) {          // (entry, 16-byte half)
+            const int ent = e >> 1, row = ent >> 1, col = (ent & 1) * (GW + 1);
+            *reinterpret_cast<u32x4_t*>(stg + (row * G::STG_COLS + col) * 32 + (e & 1) * 16) = u32x4_t{0u, 0u, 0u, 0u};
+          }
+          // the row above (last grid row of workgroup role - 1) and below (first grid row of role + 1): 2 x 16-byte pieces per token
+#pragma unroll
+          for (int side = 0; side < 2; ++side) {
+            const int nb = side ? role + 1 : role - 1, srow = side ? ROWS + 1 : 0;
+            const bool inside = side ? role + 1 < KWG : role > 0;
+            for (int p = l2; p < GW * 2; p += 64) {
+              const int tok = p >> 1, q = p & 1;
+              u32x4_t hv = {0u, 0u, 0u, 0u};
+              if (inside) {
+                u32x4_t v;
+                if (blk == 0) v = *reinterpret_cast<const u32x4_t*>(a.x_in + ((size_t)img * G::NIMG + (side ? tok0 + 112 : tok0 - GW) + tok) * C + c0 + 8 * q);
+                else {
+                  const __amdgpu_buffer_rsrc_t hr = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(hprev), 0, (int)(G::HALO_BYTES / 2), 0x00020000);
+                  v = __builtin_amdgcn_raw_buffer_load_b128(hr, (((nb * 2 + (side ? 0 : 1)) * GW + tok) * C + c0 + 8 * q) * 2, 0, 16);
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) hv[e] = pack_h2(__uint_as_float(v[e] << 16), __uint_as_float(v[e] & 0xffff0000u));
+              }
+              *reinterpret_cast<u32x4_t*>(stg + (srow * G::STG_COLS + tok + 1) * 32 + 16 * q) = hv;
+            }
+          }
+          float wt[36];
+#pragma unroll
+          for (int e = 0; e < 9; ++e) { const float4 v = wq[ct & 1][e]; wt[4 * e] = v.x; wt[4 * e + 1] = v.y; wt[4 * e + 2] = v.z; wt[4 * e + 3] = v.w; }
+          const float4 pb = wq[ct & 1][9];
+#pragma unroll
+          for (int t = 0; t < SS_NT; ++t) {
+            const int s = 16 * t + li, y = s / GW, x = s - y * GW;
+            const unsigned char* const tap0 = stg + (y * G::STG_COLS + x) * 32 + 8 * g;      // entry of the (-1, -1) neighbour
+            uint2 f[9];
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) f[tap] = *reinterpret_cast<const uint2*>(tap0 + ((tap / 3) * G::STG_COLS + tap % 3) * 32);
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) asm volatile("" : "+v"(f[tap]));
+            float acc[4] = {pb.x, pb.y, pb.z, pb.w};
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+              asm("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "+v"(acc[0]) : "v"(f[tap].x), "v"(wt[0 * 9 + tap]));
+              asm("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(acc[1]) : "v"(f[tap].x), "v"(wt[1 * 9 + tap]));
+              asm("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "+v"(acc[2]) : "v"(f[tap].y), "v"(wt[2 * 9 + tap]));
+              asm("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(acc[3]) : "v"(f[tap].y), "v"(wt[3 * 9 + tap]));
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) R[t][ct][r] += acc[r];
+            asm volatile("" : "+v"(R[t][ct]));
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        }
+      }
+      DS_STAMP(1);
+      // ---- norm1 -> LDS ----
+      {
+        DS_PHASE
+        ds_layer_norm<NW, SS_NT>(R, vec + G::V_N1W, vec + G::V_N1B, a.eps, smem + G::L_XN, stat, wave, lane);
+        if (wave == 0) wait_flag(mflag, (unsigned)(gb + 1), errflag, lane);      // the meta workgroup's fragments of this block
+      }
+      __syncthreads();
+      DS_STAMP(2);
+      const unsigned char* const mf = mfr + (size_t)(gb & 1) * (G::MFRAG_BYTES / 2);
+      const __amdgpu_buffer_rsrc_t mr = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(mf), 0, (int)(G::MFRAG_BYTES / 2), 0x00020000);
+      const __amdgpu_buffer_rsrc_t pr = __builtin_amdgcn_make_buffer_rsrc(part, 0, (int)G::PART_BYTES, 0x00020000);
+      // ---- c-direction: per head, scores of the 16 meta queries against the 112 tokens of this workgroup (q~ . norm1(x)), local softmax, v1 of the head
+      //      (operands swapped: the V^T fragments of P V), partial (max, sum, sum p v) -> the meta workgroup ----
+      {
+        DS_PHASE
+        const int nc = wave >= NW / 2 ? 2 : 1;
+#pragma unroll 1
+        for (int hu = 0; hu < nc; ++hu) {
+          const int h = hu == 0 ? wave : NW + wave - NW / 2;
+          f32x4_t S[SS_NT];
+#pragma unroll
+          for (int t = 0; t < SS_NT; ++t) S[t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int ks = 0; ks < KS; ++ks) {
+            const bf16x8_t qt = as_bf8(__builtin_amdgcn_raw_buffer_load_b128(mr, ((h * G::MF_HEAD + 3 + ks) * 64 + lane) * 16, 0, 16));
+#pragma unroll
+            for (int t = 0; t < SS_NT; ++t) S[t] = mfma_bf16(*reinterpret_cast<const bf16x8_t*>(smem + G::L_XN + ((ks * SS_NT + t) * 64 + lane) * 16), qt, S[t]);
+          }
+          float m = -INFINITY;
+#pragma unroll
+          for (int t = 0; t < SS_NT; ++t) m = max2(m, max4(S[t]));
+          m = xmax4(m);
+          float l = 0.f;
+          u32x4_t P[4];
+#pragma unroll
+          for (int p = 0; p < 4; ++p) {
+            float e[8];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { e[r] = __builtin_amdgcn_exp2f(S[2 * p][r] - m); e[4 + r] = p < 3 ? __builtin_amdgcn_exp2f(S[p < 3 ? 2 * p + 1 : 0][r] - m) : 0.f; }
+            l += ((e[0] + e[1]) + (e[2] + e[3])) + ((e[4] + e[5]) + (e[6] + e[7]));
+            P[p] = u32x4_t{pack_h2(e[0], e[1]), pack_h2(e[2], e[3]), pack_h2(e[4], e[5]), pack_h2(e[6], e[7])};
+          }
+          l = xsum4(l);
+          asm volatile("" : "+v"(l));
+          // v1 of the head: D'[token][channel] (no bias: sum p = 1 after the combine, the meta workgroup adds it)
+          f32x4_t acc[SS_NT][2];
+#pragma unroll
+          for (int t = 0; t < SS_NT; ++t) { acc[t][0] = f32x4_t{0.f, 0.f, 0.f, 0.f}; acc[t][1] = acc[t][0]; }
+          bf16x8_t ring[3][2];
+          const unsigned char* wcur = wp + (size_t)(G::WS_V1 + h * (2 * KS)) * 1024;
+          ring_fill<2, 3>(ring, wcur, lane);
+          gemm_unit<2, KS, 3, false>(acc, ring, wcur, wcur, smem + G::L_XN, lane);
+          f32x4_t O[2] = {f32x4_t{0.f, 0.f, 0.f, 0.f}, f32x4_t{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+          for (int p = 0; p < 4; ++p)
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt) {
+              const f32x4_t lo = acc[2 * p][dt];
+              u32x4_t vk = {pack_h2(lo[0], lo[1]), pack_h2(lo[2], lo[3]), 0u, 0u};
+              if (p < 3) { const f32x4_t hi = acc[p < 3 ? 2 * p + 1 : 0][dt]; vk[2] = pack_h2(hi[0], hi[1]); vk[3] = pack_h2(hi[2], hi[3]); }
+              O[dt] = mfma_f16(__builtin_bit_cast(f16x8_t, vk), __builtin_bit_cast(f16x8_t, P[p]), O[dt]);
+            }
+          const int pbase = ((role * NH + h) * 3 * 64 + lane) * 16;
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, O[0]), pr, pbase, 0, 16);
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, O[1]), pr, pbase + 1024, 0, 16);
+          __builtin_amdgcn_raw_buffer_store_b128(u32x4_t{__float_as_uint(m), __float_as_uint(l), 0u, 0u}, pr, pbase + 2048, 0, 16);
+        }
+      }
+      DS_STAMP(3);
+      // ---- x-direction: per head, q1 of the 112 tokens, softmax over the 16 meta keys, P V2; the proj_x operand fragments wait in registers ----
+      const int nx = wave0 < NW / 2 ? 2 : 1;
+      u32x4_t AO[2][SS_NT];
+      {
+        DS_PHASE
+        bf16x8_t ring[3][2];
+#pragma unroll
+        for (int hu = 0; hu < 2; ++hu) {
+          if (hu < nx) {
+            const int h = wave + NW * hu;
+            const u32x4_t k2 = __builtin_amdgcn_raw_buffer_load_b128(mr, ((h * G::MF_HEAD) * 64 + lane) * 16, 0, 16);
+            const u32x4_t v20 = __builtin_amdgcn_raw_buffer_load_b128(mr, ((h * G::MF_HEAD + 1) * 64 + lane) * 16, 0, 16);
+            const u32x4_t v21 = __builtin_amdgcn_raw_buffer_load_b128(mr, ((h * G::MF_HEAD + 2) * 64 + lane) * 16, 0, 16);
+            const unsigned char* wcur = wp + (size_t)(G::WS_Q1 + h * (2 * KS)) * 1024;
+            ring_fill<2, 3>(ring, wcur, lane);
+            const float* bq = vec + G::V_QKV1B + 32 * h + 4 * g;
+            const float4 b0 = *reinterpret_cast<const float4*>(bq), b1 = *reinterpret_cast<const float4*>(bq + 16);
+            f32x4_t acc[SS_NT][2];
+#pragma unroll
+            for (int t = 0; t < SS_NT; ++t) { acc[t][0] = f32x4_t{0.f, 0.f, 0.f, 0.f}; acc[t][1] = acc[t][0]; }
+            gemm_unit<2, KS, 3, true>(acc, ring, wcur, wcur, smem + G::L_XN, lane);
+            const f32x4_t z4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int t = 0; t < SS_NT; ++t) {
+              const f32x4_t q0 = {(acc[t][0][0] + b0.x) * a.sx, (acc[t][0][1] + b0.y) * a.sx, (acc[t][0][2] + b0.z) * a.sx, (acc[t][0][3] + b0.w) * a.sx};
+              const f32x4_t q1 = {(acc[t][1][0] + b1.x) * a.sx, (acc[t][1][1] + b1.y) * a.sx, (acc[t][1][2] + b1.z) * a.sx, (acc[t][1][3] + b1.w) * a.sx};
+              const f32x4_t s = mfma_bf16(as_bf8(k2), as_bf8(pack_bf8(q0, q1)), z4);          // S^T[key][query]
+              const float m = xmax4(max4(s));
+              float e[4];
+#pragma unroll
+              for (int r = 0; r < 4; ++r) e[r] = __builtin_amdgcn_exp2f(s[r] - m);
+              const float inv = 1.f / xsum4((e[0] + e[1]) + (e[2] + e[3]));
+              const u32x4_t pk = {pack_h2(e[0], e[1]), pack_h2(e[2], e[3]), 0u, 0u};
+              const f16x8_t pf = __builtin_bit_cast(f16x8_t, pk);
+              const f32x4_t o0 = mfma_f16(__builtin_bit_cast(f16x8_t, v20), pf, z4), o1 = mfma_f16(__builtin_bit_cast(f16x8_t, v21), pf, z4);
+              AO[hu][t] = pack_bf8(o0 * inv, o1 * inv);
+            }
+          }
+        }
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the partial stores of this wave (R1: every storing wave drains)
+      __syncthreads();                                         // ... and every wave is done with the LayerNorm output in LDS
+      if (tid == 0) __hip_atomic_store((gu32*)(partflag + role), (unsigned)(gb + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      {
+        DS_PHASE
+#pragma unroll
+        for (int hu = 0; hu < 2; ++hu)
+          if (hu < nx) {
+            const int h = wave + NW * hu;
+#pragma unroll
+            for (int t = 0; t < SS_NT; ++t) *reinterpret_cast<u32x4_t*>(smem + G::L_XN + ((h * SS_NT + t) * 64 + lane) * 16) = AO[hu][t];
+          }
+      }
+      __syncthreads();
+      DS_STAMP(4);
+      // ---- x += proj_x(attention) + bias; norm2; MLP ----
+      {
+        DS_PHASE
+        float4 pb[3];
+#pragma unroll
+        for (int ct = 0; ct < 3; ++ct) pb[ct] = *reinterpret_cast<const float4*>(vec + G::V_PXB + 48 * wave + 16 * ct + 4 * g);
+        bf16x8_t ringp[G::PRD][3];
+        const unsigned char* wcur = wp + (size_t)(G::WS_PX + wave * (3 * KS)) * 1024;
+        ring_fill<3, G::PRD>(ringp, wcur, lane);
+        gemm_unit<3, KS, G::PRD, true>(R, ringp, wcur, wcur, smem + G::L_XN, lane);
+#pragma unroll
+        for (int ct = 0; ct < 3; ++ct)
+#pragma unroll
+          for (int t = 0; t < SS_NT; ++t) { R[t][ct][0] += pb[ct].x; R[t][ct][1] += pb[ct].y; R[t][ct][2] += pb[ct].z; R[t][ct][3] += pb[ct].w; }
+        __syncthreads();          // every wave has read the proj_x operand: norm2 may overwrite it
+        ds_layer_norm<NW, SS_NT>(R, vec + G::V_N2W, vec + G::V_N2B, a.eps, smem + G::L_XN, stat, wave, lane);
+      }
+      DS_STAMP(5);
+      ds_mlp<NW, SS_NT, G>(R, wp, vec, smem + G::L_XN, smem + G::L_H, lane0, wave0);
+      DS_STAMP(6);
+      // ---- block end: + mlp.3.bias; the first and the last grid row go to the neighbours ----
+      {
+        DS_PHASE
+#pragma unroll
+        for (int ct = 0; ct < 3; ++ct) {
+          const float4 b = *reinterpret_cast<const float4*>(vec + G::V_FC2B + 48 * wave + 16 * ct + 4 * g);
+#pragma unroll
+          for (int t = 0; t < SS_NT; ++t) { R[t][ct][0] += b.x; R[t][ct][1] += b.y; R[t][ct][2] += b.z; R[t][ct][3] += b.w; }
+        }
+        unsigned char* const hcur = halo + (size_t)(gb & 1) * (G::HALO_BYTES / 2);
+#pragma unroll
+        for (int t = 0; t < SS_NT; ++t) {
+          const int s = 16 * t + li;
+#pragma unroll
+          for (int side = 0; side < 2; ++side) {
+            const int tok = side ? s - (112 - GW) : s;
+            if ((unsigned)tok < (unsigned)GW) {
+              bf16_t* dst = reinterpret_cast<bf16_t*>(hcur) + ((size_t)(role * 2 + side) * GW + tok) * C + 48 * wave + 4 * g;
+#pragma unroll
+              for (int ct = 0; ct < 3; ++ct) {
+                const unsigned long long pk = (unsigned long long)pack_bf2(R[t][ct][0], R[t][ct][1]) | ((unsigned long long)pack_bf2(R[t][ct][2], R[t][ct][3]) << 32);
+                __hip_atomic_store((gu64*)(dst + 16 * ct), pk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              }
+            }
+          }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      __syncthreads();
+      if (tid == 0) __hip_atomic_store((gu32*)(haloflag + role), (unsigned)(gb + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      DS_STAMP(7);
+    }
+    {
+      DS_PHASE
+#pragma unroll
+      for (int t = 0; t < SS_NT; ++t) {
+        bf16_t* dst = a.x_out + ((size_t)img * G::NIMG + tok0 + 16 * t + li) * C;
+#pragma unroll
+        for (int ct = 0; ct < 3; ++ct) {
+          const float f[4] = {R[t][ct][0], R[t][ct][1], R[t][ct][2], R[t][ct][3]};
+          st4(dst + 48 * wave + 16 * ct + 4 * g, f);
+        }
+      }
+    }
+  }
+}
+
+// ---- packing ----------------------------------------------------------------------------------------------------------------------
+struct DPackArgs { const bf16_t* qkv1_w; const bf16_t* qkv2_w; const bf16_t* projx_w; const bf16_t* projc_w; const bf16_t* fc1_w; const bf16_t* fc2_w; uint4* out; };
+
+template <int NW>
+__global__ __launch_bounds__(256) void dstage_pack_kernel(const DPackArgs a) {
+  using G = DG<NW, NW == 4 ? 28 : 56>;
+  constexpr int C = G::C, KS = G::KS, KSC = G::KSC, UF = 2 * KS, PF = 3 * KS, F2 = 3 * KSC;
+  const int f = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63, g = lane >> 4, i = lane & 15;
+  if (f >= G::WS_FRAGS) return;
+  const bf16_t* base; int row0, ks, ld = C;
+  if (f >= G::WS_K1T && f < G::WS_PC) {
+    // transposed fragment of the k rows of qkv1: lane (g, i) holds W[C + 32 h + 16 (j >> 2) + 4 g + (j & 3)][16 m + i]
+    const int q = f - G::WS_K1T, h = q / (C / 16), m = q - h * (C / 16);
+    unsigned short v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = a.qkv1_w[(size_t)(C + 32 * h + 16 * (j >> 2) + 4 * g + (j & 3)) * C + 16 * m + i];
+    a.out[(size_t)f * 64 + lane] = make_uint4(v[0] | (v[1] << 16), v[2] | (v[3] << 16), v[4] | (v[5] << 16), v[6] | (v[7] << 16));
+    return;
+  }
+  if (f < G::WS_V1) { const int h = f / UF, r = f - h * UF; ks = r >> 1; base = a.qkv1_w; row0 = 32 * h + 16 * (r & 1); }
+  else if (f < G::WS_PX) { const int q = f - G::WS_V1, h = q / UF, r = q - h * UF; ks = r >> 1; base = a.qkv1_w; row0 = 2 * C + 32 * h + 16 * (r & 1); }
+  else if (f < G::WS_FC1) { const int q = f - G::WS_PX, w = q / PF, r = q - w * PF; ks = r / 3; base = a.projx_w; row0 = 48 * w + 16 * (r - ks * 3); }
+  else if (f < G::WS_FC2) { const int q = f - G::WS_FC1, cw = q / UF, r = q - cw * UF; ks = r >> 1; base = a.fc1_w; row0 = 32 * NW * (cw / NW) + 32 * (cw % NW) + 16 * (r & 1); }
+  else if (f < G::WS_K2) { const int q = f - G::WS_FC2, cw = q / F2, r = q - cw * F2, ksl = r / 3; ks = KSC * (cw / NW) + ksl; base = a.fc2_w; ld = 4 * C; row0 = 48 * (cw % NW) + 16 * (r - ksl * 3); }
+  else if (f < G::WS_V2) { const int q = f - G::WS_K2, h = q / UF, r = q - h * UF; ks = r >> 1; base = a.qkv2_w; row0 = C + 32 * h + 16 * (r & 1); }
+  else if (f < G::WS_Q2) { const int q = f - G::WS_V2, h = q / UF, r = q - h * UF; ks = r >> 1; base = a.qkv2_w; row0 = 2 * C + 32 * h + 16 * (r & 1); }
+  else if (f < G::WS_K1T) { const int q = f - G::WS_Q2, h = q / UF, r = q - h * UF; ks = r >> 1; base = a.qkv2_w; row0 = 32 * h + 16 * (r & 1); }
+  else { const int q = f - G::WS_PC, w = q / PF, r = q - w * PF; ks = r / 3; base = a.projc_w; row0 = 48 * w + 16 * (r - ks * 3); }
+  const bf16_t* src = base + (size_t)(row0 + i) * ld + 32 * ks + 4 * g;
+  const uint2 lo = *reinterpret_cast<const uint2*>(src), hi = *reinterpret_cast<const uint2*>(src + 16);
+  a.out[(size_t)f * 64 + lane] = make_uint4(lo.x, lo.y, hi.x, hi.y);
+}
+
+template <int NW, int GW> static int ds_slots(int B, int wgs_per_cu) {
+  int dev = 0, cus = 256;
+  (void)hipGetDevice(&dev);
+  (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+  int n = (cus * wgs_per_cu / DG<NW, GW>::NWG) / 8 * 8;          // whole groups of 8 slots (one per XCD)
+  if (n < 8) n = 8;
+  const int need = (B + 7) / 8 * 8;
+  return n < need ? n : need;
+}
+
+}  // namespace
+
+// ---- C ABI --------------------------------------------------------------------------------------------------------------------------
+static int ds_variant(int C, int heads, int hidden, int H, int W, int M) {      // 4: stage 2 (C = 192, 28 x 28), 2: stage 1 (C = 96, 56 x 56), 0: not supported
+  if (M != DS_M || H != W || heads != C / 32 || hidden != 4 * C) return 0;
+  if (C == 192 && H == 28) return 4;
+  return 0;
+}
+int lmv_dstage_supported(int C, int heads, int hidden, int H, int W, int M, int dtype) { return dtype == LMV_BF16 && ds_variant(C, heads, hidden, H, W, M) != 0; }
+size_t lmv_dstage_wpk_bytes(int C, int hidden) { (void)hidden; return C == 192 ? (size_t)DG<4, 28>::WS_FRAGS * 1024 : 0; }
+size_t lmv_dstage_vec_floats(int C, int hidden) { (void)hidden; return (size_t)27 * C; }
+size_t lmv_dstage_workspace_bytes(int B, int C) {
+  if (C != 192) return 0;
+  using G = DG<4, 28>;
+  const int ns = ds_slots<4, 28>(B, 2);
+  return (((size_t)ns * G::FLAGS_PER_SLOT + 1) * 4 + 1023) / 1024 * 1024 + (size_t)ns * G::SLOT_BYTES;
+}
+
+int lmv_dstage_pack(const lmv_dstage_block_params* p, void* wpk_out, float* vec_out, void* stream) {
+  if (!p || !wpk_out || !vec_out) LMV_FAIL(LMV_ERR_SHAPE, "dstage_pack: null argument");
+  if (p->C != 192 || p->heads != 6 || p->hidden != 768) LMV_FAIL(LMV_ERR_DTYPE, "dstage_pack: C = %d / heads = %d / hidden = %d is not a supported stage", p->C, p->heads, p->hidden);
+  const void* ptrs[] = {p->qkv1_w, p->qkv2_w, p->projx_w, p->projc_w, p->fc1_w, p->fc2_w, p->n1_w, p->n1_b, p->qkv1_b, p->qkv2_b, p->projx_b, p->projc_b, p->n2_w, p->n2_b, p->fc1_b, p->fc2_b,
+                        p->pos_w, p->pos_b, wpk_out, vec_out};
+  for (const void* q : ptrs) if (!q || !lmv_aligned16(q)) LMV_FAIL(LMV_ERR_SHAPE, "dstage_pack: null or misaligned pointer");
+  hipStream_t st = (hipStream_t)stream;
+  DPackArgs a{(const bf16_t*)p->qkv1_w, (const bf16_t*)p->qkv2_w, (const bf16_t*)p->projx_w, (const bf16_t*)p->projc_w, (const bf16_t*)p->fc1_w, (const bf16_t*)p->fc2_w, (uint4*)wpk_out};
+  hipLaunchKernelGGL(dstage_pack_kernel<4>, dim3((DG<4, 28>::WS_FRAGS + 3) / 4), dim3(256), 0, st, a);
+  LMV_CHECK_LAUNCH("dstage_pack");
+  const int C = p->C;
+  const struct { const float* src; int off, n; } v[] = {{p->n1_w, 0, C}, {p->n1_b, C, C}, {p->qkv1_b, 2 * C, 3 * C}, {p->qkv2_b, 5 * C, 3 * C}, {p->projx_b, 8 * C, C}, {p->projc_b, 9 * C, C},
+                                                        {p->n2_w, 10 * C, C}, {p->n2_b, 11 * C, C}, {p->fc1_b, 12 * C, 4 * C}, {p->fc2_b, 16 * C, C}, {p->pos_w, 17 * C, 9 * C}, {p->pos_b, 26 * C, C}};
+  for (const auto& e : v)
+    if (hipMemcpyAsync(vec_out + e.off, e.src, (size_t)e.n * sizeof(float), hipMemcpyDeviceToDevice, st) != hipSuccess) LMV_FAIL(LMV_ERR_LAUNCH, "dstage_pack: vector copy failed");
+  return LMV_OK;
+}
+
+int lmv_dstage_fwd(const lmv_dstage_desc* d, const void* x, const void* c, void* x_out, void* c_out, void* workspace, size_t workspace_bytes, void* stream) {
+  if (!d || !x || !c || !x_out || !c_out || !workspace) LMV_FAIL(LMV_ERR_SHAPE, "dstage_fwd: null argument");
+  if (!lmv_dstage_supported(d->C, d->heads, d->hidden, d->H, d->W, d->M, d->dtype)) LMV_FAIL(LMV_ERR_DTYPE, "dstage_fwd: unsupported stage shape / dtype");
+  if (d->B <= 0 || d->nblocks <= 0 || !d->wpk || !d->vec) LMV_FAIL(LMV_ERR_SHAPE, "dstage_fwd: bad descriptor");
+  const void* ptrs[] = {x, c, x_out, c_out, workspace, d->wpk, d->vec};
+  for (const void* q : ptrs) if (!lmv_aligned16(q)) LMV_FAIL(LMV_ERR_SHAPE, "dstage_fwd: pointers must be 16-byte aligned");
+  if (workspace_bytes < lmv_dstage_workspace_bytes(d->B, d->C)) LMV_FAIL(LMV_ERR_WORKSPACE, "dstage_fwd: workspace too small");
+  hipStream_t st = (hipStream_t)stream;
+  using G = DG<4, 28>;
+  static std::atomic<unsigned long long> attr_done{0};
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  const unsigned long long bit = 1ull << (dev & 63);
+  if (!(attr_done.load(std::memory_order_acquire) & bit)) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(dstage_kernel<4, 28>), hipFuncAttributeMaxDynamicSharedMemorySize, G::L_TOTAL) != hipSuccess) LMV_FAIL(LMV_ERR_LAUNCH, "dstage_fwd: cannot reserve LDS");
+    attr_done.fetch_or(bit, std::memory_order_release);
+  }
+  const int ns = ds_slots<4, 28>(d->B, 2);
+  const size_t flags = (((size_t)ns * G::FLAGS_PER_SLOT + 1) * 4 + 1023) / 1024 * 1024;
+  unsigned char* ws = (unsigned char*)workspace;
+  if (hipMemsetAsync(ws, 0, flags, st) != hipSuccess) LMV_FAIL(LMV_ERR_LAUNCH, "dstage_fwd: flag reset failed");
+  DsArgs a{};
+  a.x_in = (const bf16_t*)x; a.c_in = (const bf16_t*)c; a.x_out = (bf16_t*)x_out; a.c_out = (bf16_t*)c_out;
+  a.wpk = (const uint4*)d->wpk; a.vec = d->vec; a.flags = (unsigned*)ws; a.slots = ws + flags;
+  a.B = d->B; a.nblocks = d->nblocks; a.nslots = ns; a.eps = d->eps;
+  const double N = (double)d->H * d->W, lg2e = 1.4426950408889634;
+  a.sx = (float)(log((double)d->M) / log(N) / sqrt((double)d->C) * lg2e);      // models/lemevit.py:255: log_N(M) C^-1/2
+  a.sc = (float)(1.0 / sqrt((double)d->C) * lg2e);                             // :256
+  a.timing = (unsigned long long*)d->timing; a.timing_block = d->timing_block;
+  hipLaunchKernelGGL((dstage_kernel<4, 28>), dim3(ns * G::NWG), dim3(256), G::L_TOTAL, st, a);
+  LMV_CHECK_LAUNCH("dstage_fwd");
+  return LMV_OK;
+}

@@ -1,0 +1,92 @@
+// stage_common.h -- device helpers shared by the persistent stage kernels (csrc/sstage.hip, csrc/dstage.hip): MFMA wrappers, packing, the
+// fragment-order GEMM unit (weights straight from L2, token operand from LDS), the interleaved GELU, the in-launch flag wait.
+#pragma once
+#include "common.h"
+
+namespace {
+
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8_t;
+typedef __attribute__((ext_vector_type(2))) _Float16 f16x2_t;
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4_t;
+typedef __attribute__((address_space(1))) unsigned gu32;
+typedef __attribute__((address_space(1))) unsigned long long gu64;
+
+constexpr int SS_NT = 7;              // token tiles of 16 per workgroup (112 slots)
+constexpr unsigned SPIN_LIMIT = 1u << 22;
+
+__device__ __forceinline__ bf16x8_t as_bf8(const uint4& v) { return __builtin_bit_cast(bf16x8_t, v); }
+__device__ __forceinline__ bf16x8_t as_bf8(const u32x4_t& v) { return __builtin_bit_cast(bf16x8_t, v); }
+__device__ __forceinline__ f32x4_t mfma_bf16(const bf16x8_t& a, const bf16x8_t& b, const f32x4_t& c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
+__device__ __forceinline__ f32x4_t mfma_f16(const f16x8_t& a, const f16x8_t& b, const f32x4_t& c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
+__device__ __forceinline__ unsigned pack_h2(float lo, float hi) { return __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(lo, hi)); }
+__device__ __forceinline__ u32x4_t pack_bf8(const f32x4_t& a, const f32x4_t& b) {
+  return u32x4_t{pack_bf2(a[0], a[1]), pack_bf2(a[2], a[3]), pack_bf2(b[0], b[1]), pack_bf2(b[2], b[3])};
+}
+// max without the canonicalising v_max x, x that fmaxf costs under IEEE mode: v_med3(a, b, +inf) = max(a, b) for non-NaN inputs
+__device__ __forceinline__ float max2(float a, float b) { return __builtin_amdgcn_fmed3f(a, b, INFINITY); }
+__device__ __forceinline__ float max4(const f32x4_t& s) { return max2(max2(s[0], s[1]), max2(s[2], s[3])); }
+__device__ __forceinline__ float xsum4(float v) { v += __shfl_xor(v, 16, 64); v += __shfl_xor(v, 32, 64); return v; }      // over the 4 lane groups of a token
+__device__ __forceinline__ float xmax4(float v) { v = max2(v, __shfl_xor(v, 16, 64)); v = max2(v, __shfl_xor(v, 32, 64)); return v; }
+
+// one lane polls a flag word until it reaches `epoch` (relaxed agent-scope loads + s_sleep); a bounded spin reports through flags[err]
+__device__ __forceinline__ void wait_flag(unsigned* flag, unsigned epoch, unsigned* err, int lane) {
+  if (lane == 0) {
+    unsigned spins = 0;
+    while (__hip_atomic_load((gu32*)flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < epoch) {
+      __builtin_amdgcn_s_sleep(4);
+      if (++spins > SPIN_LIMIT) { __hip_atomic_store((gu32*)err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+    }
+  }
+}
+
+// gelu_poly2 (common.h) on the 8 pre-activations of one D tile pair at once, the four Horner chains interleaved statement by statement: a dependent
+// packed op waits a state for its predecessor, and hipcc does not interleave the chains on its own (it emitted them serially with an s_nop each)
+__device__ __forceinline__ void gelu4(f32x2_t& a, f32x2_t& b, f32x2_t& c, f32x2_t& d) {
+  f32x2_t sa = a * 0.25f, sb = b * 0.25f, sc = c * 0.25f, sd = d * 0.25f;
+  sa[0] = __builtin_amdgcn_fmed3f(sa[0], -1.0f, 1.0f); sb[0] = __builtin_amdgcn_fmed3f(sb[0], -1.0f, 1.0f);
+  sc[0] = __builtin_amdgcn_fmed3f(sc[0], -1.0f, 1.0f); sd[0] = __builtin_amdgcn_fmed3f(sd[0], -1.0f, 1.0f);
+  sa[1] = __builtin_amdgcn_fmed3f(sa[1], -1.0f, 1.0f); sb[1] = __builtin_amdgcn_fmed3f(sb[1], -1.0f, 1.0f);
+  sc[1] = __builtin_amdgcn_fmed3f(sc[1], -1.0f, 1.0f); sd[1] = __builtin_amdgcn_fmed3f(sd[1], -1.0f, 1.0f);
+  const f32x2_t ua = sa * sa, ub = sb * sb, uc = sc * sc, ud = sd * sd;
+  f32x2_t qa = {-1.6300047636032104f, -1.6300047636032104f}, qb = qa, qc = qa, qd = qa;
+#define SS_GSTEP(k)                                                                                                   \
+  qa = __builtin_elementwise_fma(qa, ua, f32x2_t{k, k}); qb = __builtin_elementwise_fma(qb, ub, f32x2_t{k, k});       \
+  qc = __builtin_elementwise_fma(qc, uc, f32x2_t{k, k}); qd = __builtin_elementwise_fma(qd, ud, f32x2_t{k, k})
+  SS_GSTEP(7.93373966217041f); SS_GSTEP(-16.877059936523438f); SS_GSTEP(20.921268463134766f); SS_GSTEP(-17.09065055847168f);
+  SS_GSTEP(9.8812894821167f); SS_GSTEP(-4.233964920043945f); SS_GSTEP(1.595382571220398f);
+#undef SS_GSTEP
+  a = a * __builtin_elementwise_fma(sa, qa, f32x2_t{0.5f, 0.5f}); b = b * __builtin_elementwise_fma(sb, qb, f32x2_t{0.5f, 0.5f});
+  c = c * __builtin_elementwise_fma(sc, qc, f32x2_t{0.5f, 0.5f}); d = d * __builtin_elementwise_fma(sd, qd, f32x2_t{0.5f, 0.5f});
+}
+
+// ---- one GEMM unit: NC output-channel tiles x all 7 token tiles x NKS k-steps ------------------------------------------------------
+// ring: the wave's weight fragments, RD - 1 k-steps ahead, straight from L2 (w: wave-uniform byte pointer to fragment 0 of the unit, fragments
+// in [k-step][n] order: scalar base + lane * 16 + immediate).  On entry slots 0 .. RD - 2 hold the first k-steps of this unit (ring_fill or the
+// previous unit's tail); on exit they hold those of the unit at `wnext`.  TRANS: D[channel][token] = W X^T; else D[token][channel].
+__device__ __forceinline__ bf16x8_t ld_frag(const unsigned char* w, int frag, int lane) { return as_bf8(reinterpret_cast<const uint4*>(w + (size_t)frag * 1024)[lane]); }
+template <int NC, int RD>
+__device__ __forceinline__ void ring_fill(bf16x8_t (&ring)[RD][NC], const unsigned char* w, int lane) {
+#pragma unroll
+  for (int s = 0; s < RD - 1; ++s)
+#pragma unroll
+    for (int n = 0; n < NC; ++n) ring[s][n] = ld_frag(w, s * NC + n, lane);
+}
+template <int NC, int NKS, int RD, bool TRANS, int NTT = SS_NT>
+__device__ __forceinline__ void gemm_unit(f32x4_t (&acc)[NTT][NC], bf16x8_t (&ring)[RD][NC], const unsigned char* wcur, const unsigned char* wnext, const unsigned char* xs, int lane) {
+  static_assert(NKS % RD == 0, "ring phase");
+#pragma unroll
+  for (int ks = 0; ks < NKS; ++ks) {
+    const int sp = ks + RD - 1;
+#pragma unroll
+    for (int n = 0; n < NC; ++n) ring[sp % RD][n] = sp < NKS ? ld_frag(wcur, sp * NC + n, lane) : ld_frag(wnext, (sp - NKS) * NC + n, lane);
+#pragma unroll
+    for (int t = 0; t < NTT; ++t) {
+      const bf16x8_t xf = *reinterpret_cast<const bf16x8_t*>(xs + ((ks * NTT + t) * 64 + lane) * 16);
+#pragma unroll
+      for (int n = 0; n < NC; ++n) acc[t][n] = TRANS ? mfma_bf16(ring[ks % RD][n], xf, acc[t][n]) : mfma_bf16(xf, ring[ks % RD][n], acc[t][n]);
+    }
+  }
+}
+
+// ---- LayerNorm of the register-resident rows -> bf16 token operand in LDS (fragment order) ------------------------------------------
+}  // namespace

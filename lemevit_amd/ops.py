@@ -660,3 +660,61 @@ def sstage_fwd(x: Tensor, c: Tensor, P: SStagePacked, H: int, W: int, eps: float
     ws = _workspace(nbytes, x.device)
     check(lib.lmv_sstage_fwd(C.byref(d), _ptr(x), _ptr(c), _ptr(xo), _ptr(co), ws.data_ptr(), ws.numel(), _stream()), "lmv_sstage_fwd")
     return xo, co
+
+
+# -------------------------------------------------------------------------------------------
+# A run of "D" blocks as one persistent launch (csrc/dstage.hip; inference, bf16)
+# -------------------------------------------------------------------------------------------
+def dstage_supported(C_: int, heads: int, hidden: int, H: int, W: int, M: int, dtype: torch.dtype) -> bool:
+    if dtype != torch.bfloat16:
+        return False
+    return bool(lib.lmv_dstage_supported(C_, heads, hidden, H, W, M, _lib.LMV_BF16))
+
+
+DSTAGE_NAMES = ("attn.qkv1.weight", "attn.qkv2.weight", "attn.proj_x.weight", "attn.proj_c.weight", "mlp.0.weight", "mlp.3.weight",
+                "norm1.weight", "norm1.bias", "attn.qkv1.bias", "attn.qkv2.bias", "attn.proj_x.bias", "attn.proj_c.bias",
+                "norm2.weight", "norm2.bias", "mlp.0.bias", "mlp.3.bias", "pos_embed.weight", "pos_embed.bias")
+_DSTAGE_FIELDS = ("qkv1_w", "qkv2_w", "projx_w", "projc_w", "fc1_w", "fc2_w", "n1_w", "n1_b", "qkv1_b", "qkv2_b", "projx_b", "projc_b", "n2_w", "n2_b", "fc1_b", "fc2_b",
+                  "pos_w", "pos_b")
+
+
+def dstage_pack(blocks: Sequence[dict], heads: int) -> SStagePacked:
+    """blocks: per block a dict name -> tensor (DSTAGE_NAMES; matrices bf16, vectors fp32, reference layouts, on the GPU)."""
+    w0 = blocks[0]["attn.qkv1.weight"]
+    C_ = w0.shape[1]
+    hidden = blocks[0]["mlp.0.weight"].shape[0]
+    wb, vf = int(lib.lmv_dstage_wpk_bytes(C_, hidden)), int(lib.lmv_dstage_vec_floats(C_, hidden))
+    if wb == 0:
+        raise ValueError(f"lemevit_amd: dstage_pack does not support C = {C_}")
+    P = SStagePacked()
+    P.nblocks, P.C, P.heads, P.hidden = len(blocks), C_, heads, hidden
+    P.wpk = torch.empty(len(blocks) * wb, device=w0.device, dtype=torch.uint8)
+    P.vec = torch.empty(len(blocks) * vf, device=w0.device, dtype=torch.float32)
+    keep = []
+    for j, blk in enumerate(blocks):
+        bp = _lib.DStageBlockParams()
+        bp.C, bp.heads, bp.hidden = C_, heads, hidden
+        for k, (field, name) in enumerate(zip(_DSTAGE_FIELDS, DSTAGE_NAMES)):
+            t = blk[name]
+            if k < 6:
+                if t.dtype != torch.bfloat16:
+                    raise TypeError("lemevit_amd: dstage_pack takes bf16 matrices")
+                t = t.contiguous()
+            else:
+                t = t.detach().float().contiguous()
+            keep.append(t)
+            setattr(bp, field, _ptr(t))
+        check(lib.lmv_dstage_pack(C.byref(bp), P.wpk.data_ptr() + j * wb, P.vec.data_ptr() + j * vf * 4, _stream()), "lmv_dstage_pack")
+    return P
+
+
+def dstage_fwd(x: Tensor, c: Tensor, P: SStagePacked, H: int, W: int, eps: float, timing: Optional[Tensor] = None, timing_block: int = 0) -> Tuple[Tensor, Tensor]:
+    B, N, C_ = x.shape
+    d = _lib.SStageDesc()
+    d.B, d.H, d.W, d.M, d.C, d.heads, d.hidden, d.nblocks, d.dtype, d.eps = B, H, W, c.shape[1], C_, P.heads, P.hidden, P.nblocks, dtype_code(x), eps
+    d.wpk, d.vec = P.wpk.data_ptr(), P.vec.data_ptr()
+    d.timing, d.timing_block = (None if timing is None else timing.data_ptr()), timing_block
+    xo, co = torch.empty_like(x), torch.empty_like(c)
+    ws = _workspace(int(lib.lmv_dstage_workspace_bytes(B, C_)), x.device)
+    check(lib.lmv_dstage_fwd(C.byref(d), _ptr(x), _ptr(c), _ptr(xo), _ptr(co), ws.data_ptr(), ws.numel(), _stream()), "lmv_dstage_fwd")
+    return xo, co

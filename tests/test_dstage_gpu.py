@@ -1,0 +1,134 @@
+"""csrc/dstage.hip (lmv_dstage_fwd): a run of "D" blocks (Dual Cross-Attention, stage 2 of LeMeViT-Base) as ONE persistent launch, against the
+pinned CPU oracle (float64, LeMeBlock.forward_with_xc, models/lemevit.py:542-582) on the bf16-rounded operands the kernel reads, against the
+per-launch schedule of the same library, and for run-to-run bit-equality (the 8 workgroups of an image exchange grid rows, the meta tokens'
+operand fragments and softmax partials through L2 inside the launch: a hand-off race shows as a run-to-run difference under load)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from detfill import det_tensor, fill_state_dict
+from oracle import lemevit_oracle as O
+from test_oracle_golden import block_spec
+
+DEV = "cuda:0"
+M = 16
+
+
+def _stage_params(nblocks, seed, C):
+    sds = []
+    for j in range(nblocks):
+        sd = fill_state_dict(block_spec("D", C), seed + 17 * j)
+        for k, v in sd.items():
+            if v.dim() >= 2 and "pos_embed" not in k:
+                sd[k] = v.to(torch.bfloat16).float()
+        sds.append(sd)
+    return sds
+
+
+def _pack(sds):
+    from lemevit_amd import ops
+    C = sds[0]["blk.norm1.weight"].shape[0]
+    blocks = []
+    for sd in sds:
+        d = {}
+        for name in ops.DSTAGE_NAMES:
+            t = sd["blk." + name].to(DEV)
+            if name == "pos_embed.weight":
+                t = t.reshape(C, 9)
+            d[name] = t.to(torch.bfloat16) if (t.dim() >= 2 and "pos_embed" not in name) else t.float()
+        blocks.append(d)
+    return ops.dstage_pack(blocks, C // 32)
+
+
+def _oracle(sds, x, c, G):
+    HEADS = x.shape[-1] // 32
+    x, c = x.double(), c.double()
+    for sd in sds:
+        sdd = {k: v.double() for k, v in sd.items()}
+        x, c = O.leme_block(sdd, "blk.", "D", x, c, G, G, HEADS)
+    return x, c
+
+
+def _inputs(B, seed, C, G, scale=1.0):
+    x = det_tensor((B, G * G, C), "dstage.x", seed, scale).to(torch.bfloat16)
+    c = det_tensor((B, M, C), "dstage.c", seed, scale).to(torch.bfloat16)
+    return x, c
+
+
+def _rel(a, ref):
+    a = a.detach().double().cpu().numpy(); ref = ref.detach().double().cpu().numpy()
+    assert np.isfinite(a).all()
+    return float(np.abs(a - ref).max() / max(np.abs(ref).max(), 1e-30))
+
+
+@pytest.mark.parametrize("C,G", [(192, 28)])
+@pytest.mark.parametrize("nblocks,B", [(1, 1), (1, 3), (2, 2), (4, 9), (2, 70)])
+def test_dstage_vs_oracle(nblocks, B, C, G):
+    """Full tensors against the float64 oracle: 1e-2 of max-abs per tensor (bf16 operands at every contraction, fp16 P / V, the GELU polynomial, the
+    meta queries folded through the k projection in bf16); the residual stream stays fp32 between the blocks.  B = 70: more images than the 64 slots of a launch
+    (the second round of a slot reuses its exchange buffers and flags)."""
+    from lemevit_amd import ops
+    sds = _stage_params(nblocks, 5, C)
+    P = _pack(sds)
+    x, c = _inputs(B, 3, C, G)
+    xo, co = ops.dstage_fwd(x.to(DEV), c.to(DEV), P, G, G, 1e-6)
+    torch.cuda.synchronize()
+    nb = min(B, 12)          # (the oracle on 12 images is enough CPU time; the tail images of B = 70 are compared below)
+    idx = list(range(nb - 3)) + [B - 3, B - 2, B - 1] if B > 12 else list(range(B))
+    xr, cr = _oracle(sds, x[idx].float(), c[idx].float(), G)
+    ex, ec = _rel(xo[idx].float(), xr), _rel(co[idx].float(), cr)
+    print(f"dstage C={C} nblocks={nblocks} B={B}: x {ex:.2e} c {ec:.2e}")
+    assert ex <= 1e-2 and ec <= 1e-2, (ex, ec)
+
+
+@pytest.mark.parametrize("C,G,nblocks,B", [(192, 28, 4, 128)])
+def test_dstage_vs_per_launch_schedule_full_size(C, G, nblocks, B):
+    """Stage 2 of LeMeViT-Base at config 3 (B = 128, 4 blocks) against the per-launch inference schedule (lmv_block_fwd) of the same weights; two runs
+    of the persistent launch agree bit for bit."""
+    import lemevit_amd.model as Mm
+    from lemevit_amd import ops
+    from lemevit_amd.blocks import PARAM_NAMES
+    sds = _stage_params(nblocks, 9, C)
+    P = _pack(sds)
+    x, c = _inputs(B, 4, C, G)
+    x, c = x.to(DEV), c.to(DEV)
+    xo, co = ops.dstage_fwd(x, c, P, G, G, 1e-6)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    xo2, co2 = ops.dstage_fwd(x, c, P, G, G, 1e-6)
+    e1.record()
+    torch.cuda.synchronize()
+    print(f"dstage C = {C}, {nblocks} blocks, B = {B}: {e0.elapsed_time(e1):.3f} ms")
+    assert torch.equal(xo, xo2) and torch.equal(co, co2)
+    xr, cr = x, c
+    with torch.no_grad():
+        for sd in sds:
+            params = {n: sd["blk." + n].to(DEV) for n in PARAM_NAMES["D"]}
+            xr, cr = Mm.run_block("D", xr, cr, G, G, params, (None,) * 4)
+    ex, ec = _rel(xo.float(), xr.float()), _rel(co.float(), cr.float())
+    print(f"dstage vs per-launch schedule, C = {C}, {nblocks} blocks, B = {B}: x {ex:.2e} c {ec:.2e}")
+    assert ex <= 3e-2 and ec <= 3e-2, (ex, ec)
+
+
+@pytest.mark.parametrize("C,G,nblocks,B", [(192, 28, 4, 128)])
+def test_dstage_handoffs_under_uneven_load(C, G, nblocks, B):
+    """MI355X_MICROARCH.md, "Workgroup dispatch, XCD placement & inter-workgroup visibility": every in-launch hand-off under UNEVEN load, every word
+    checked: (a) idle chip, (b) another stream streaming 1.5 GB through HBM; outputs bit-identical."""
+    from lemevit_amd import ops
+    sds = _stage_params(nblocks, 21, C)
+    P = _pack(sds)
+    x, c = _inputs(B, 6, C, G)
+    x, c = x.to(DEV), c.to(DEV)
+    ref = ops.dstage_fwd(x, c, P, G, G, 1e-6)
+    torch.cuda.synchronize()
+    big = torch.empty(3 * 128 * 1024 * 1024, device=DEV, dtype=torch.float32)
+    side = torch.cuda.Stream()
+    for rnd in range(4):
+        with torch.cuda.stream(side):
+            for _ in range(6):
+                big.mul_(1.0001)
+        out = ops.dstage_fwd(x, c, P, G, G, 1e-6)
+        torch.cuda.synchronize()
+        assert torch.equal(out[0], ref[0]) and torch.equal(out[1], ref[1]), rnd

@@ -50,7 +50,7 @@ template <int NW, int GW> struct DG {
   static constexpr int L_H = L_XN_BYTES, L_H_BYTES = KSC * SS_NT * 1024;
   static constexpr int L_STAT = L_H + L_H_BYTES, L_STAT_BYTES = NW * 112 * 8;
   static constexpr int L_TOTAL = L_STAT + L_STAT_BYTES;
-  static constexpr int STG_COLS = GW + 2, STG_ENT = (ROWS + 2) * STG_COLS, STG_WAVE = STG_ENT * 32;      // dwconv staging: [ROWS + 2][GW + 2] entries of 16 channels, fp16
+  static constexpr int STG_COLS = GW + 2, STG_ENT = (ROWS + 2) * STG_COLS, STG_WAVE = STG_ENT * 32;      // dwconv staging: [ROWS + 2][GW + 2] entries of 16 channels, bf16
   static_assert(NW * STG_WAVE <= L_STAT, "staging overlaps the statistics");
   // per-slot workspace
   static constexpr int MF_HEAD = 3 + KS;                                   // meta fragments per head: K2 | V2 d-tile 0 | V2 d-tile 1 | q~ [ks]
@@ -183,6 +183,7 @@ __global__ __launch_bounds__(64 * NW, 2) void dstage_kernel(const DsArgs a) {
 #pragma unroll 1
   for (int img = slot; img < a.B; img += a.nslots, ++round) {
     if (role == KWG) {
+      asm volatile("; PHASE_META");
       // =================================== the meta workgroup: the 16 meta tokens of image `img` ===================================
       f32x4_t Rc[1][3];
       {
@@ -193,6 +194,8 @@ __global__ __launch_bounds__(64 * NW, 2) void dstage_kernel(const DsArgs a) {
 #pragma unroll 1
       for (int blk = 0; blk < a.nblocks; ++blk) {
         const int gb = round * a.nblocks + blk;                    // global block counter of this slot: epochs and buffer parities
+        const int lane = lane0, wave = wave0;                      // (stamps only)
+        DS_STAMP(8);
         const unsigned char* const wp = reinterpret_cast<const unsigned char*>(a.wpk) + (size_t)blk * G::WS_FRAGS * 1024;
         const float* const vec = a.vec + (size_t)blk * G::V_FLOATS;
         unsigned char* const mf = mfr + (size_t)(gb & 1) * (G::MFRAG_BYTES / 2);
@@ -202,6 +205,7 @@ __global__ __launch_bounds__(64 * NW, 2) void dstage_kernel(const DsArgs a) {
           DS_PHASE
           ds_layer_norm<NW, 1>(Rc, vec + G::V_N1W, vec + G::V_N1B, a.eps, smem + G::L_XN, stat, wave, lane);
         }
+        DS_STAMP(9);
         {
           DS_PHASE
           // 3 NH units (k2, v2, q2 of a head: 2 channel tiles x 1 token tile x KS) dealt round-robin to the waves; q2 fragments also go to LDS for the q~ pass
@@ -235,6 +239,7 @@ __global__ __launch_bounds__(64 * NW, 2) void dstage_kernel(const DsArgs a) {
           }
         }
         __syncthreads();
+        DS_STAMP(10);
         {
           DS_PHASE
           // q~[h] = q2[h] (16 queries x 32 d) x W_k1[h] (32 d x C channels): C / 16 output tiles of one MFMA each, dealt to the waves by (head, k-step)
@@ -251,12 +256,15 @@ __global__ __launch_bounds__(64 * NW, 2) void dstage_kernel(const DsArgs a) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (tid == 0) __hip_atomic_store((gu32*)mflag, (unsigned)(gb + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        DS_STAMP(11);
+        asm volatile("; PHASE_MCOMB");
         // ---- the KWG partials of the c-direction attention -> c' (log-sum-exp combine, + v bias) -> proj_c operand in LDS ----
         if (wave0 == 0) {
 #pragma unroll 1
           for (int r = 0; r < KWG; ++r) wait_flag(partflag + r, (unsigned)(gb + 1), errflag, lane0);
         }
         __syncthreads();
+        DS_STAMP(12);
         {
           DS_PHASE
           const __amdgpu_buffer_rsrc_t pr = __builtin_amdgcn_make_buffer_rsrc(part, 0, (int)G::PART_BYTES, 0x00020000);
@@ -289,6 +297,8 @@ __global__ __launch_bounds__(64 * NW, 2) void dstage_kernel(const DsArgs a) {
           }
         }
         __syncthreads();
+        DS_STAMP(13);
+        asm volatile("; PHASE_MPROJ");
         // ---- c += proj_c(c') + bias; norm2; MLP ----
         {
           DS_PHASE
@@ -304,7 +314,9 @@ __global__ __launch_bounds__(64 * NW, 2) void dstage_kernel(const DsArgs a) {
           __syncthreads();          // every wave has read the proj_c operand: norm2 may overwrite it
           ds_layer_norm<NW, 1>(Rc, vec + G::V_N2W, vec + G::V_N2B, a.eps, smem + G::L_XN, stat, wave, lane);
         }
+        DS_STAMP(14);
         ds_mlp<NW, 1, G>(Rc, wp, vec, smem + G::L_XN, smem + G::L_H, lane0, wave0);
+        DS_STAMP(15);
         {
           DS_PHASE
 #pragma unroll
@@ -326,6 +338,7 @@ __global__ __launch_bounds__(64 * NW, 2) void dstage_kernel(const DsArgs a) {
       continue;
     }
 
+    asm volatile("; PHASE_IMG");
     // =================================== an image workgroup: 112 image tokens (ROWS grid rows) of image `img` ===================================
     const int tok0 = role * 112;
     f32x4_t R[SS_NT][3];
@@ -345,7 +358,8 @@ __global__ __launch_bounds__(64 * NW, 2) void dstage_kernel(const DsArgs a) {
       const unsigned char* const wp = reinterpret_cast<const unsigned char*>(a.wpk) + (size_t)blk * G::WS_FRAGS * 1024;
       const float* const vec = a.vec + (size_t)blk * G::V_FLOATS;
       DS_STAMP(0);
-      // ---- x += dwconv3x3(x) + bias: per channel tile a wave-private fp16 image [ROWS + 2][GW + 2] of its 16 channels, zero pads, rows across the cuts from the peers ----
+      asm volatile("; PHASE_DW");
+      // ---- x += dwconv3x3(x) + bias: per channel tile a wave-private bf16 image [ROWS + 2][GW + 2] of its 16 channels, zero pads, rows across the cuts from the peers ----
       {
         DS_PHASE
         unsigned char* const stg = smem + wave * G::STG_WAVE;
@@ -373,7 +387,7 @@ __global__ __launch_bounds__(64 * NW, 2) void dstage_kernel(const DsArgs a) {
 #pragma unroll
           for (int t = 0; t < SS_NT; ++t) {
             const int s = 16 * t + li, y = s / GW, x = s - y * GW;
-            *reinterpret_cast<uint2*>(stg + ((y + 1) * G::STG_COLS + x + 1) * 32 + 8 * g) = make_uint2(pack_h2(R[t][ct][0], R[t][ct][1]), pack_h2(R[t][ct][2], R[t][ct][3]));
+            *reinterpret_cast<uint2*>(stg + ((y + 1) * G::STG_COLS + x + 1) * 32 + 8 * g) = make_uint2(pack_bf2(R[t][ct][0], R[t][ct][1]), pack_bf2(R[t][ct][2], R[t][ct][3]));
           }
           // pad columns, and the rows beyond the image
           for (int e = l2; e < 2 * (ROWS + 2) * 2; e += 64) {          // (entry, 16-byte half)
@@ -395,15 +409,21 @@ __global__ __launch_bounds__(64 * NW, 2) void dstage_kernel(const DsArgs a) {
                   const __amdgpu_buffer_rsrc_t hr = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(hprev), 0, (int)(G::HALO_BYTES / 2), 0x00020000);
                   v = __builtin_amdgcn_raw_buffer_load_b128(hr, (((nb * 2 + (side ? 0 : 1)) * GW + tok) * C + c0 + 8 * q) * 2, 0, 16);
                 }
-#pragma unroll
-                for (int e = 0; e < 4; ++e) hv[e] = pack_h2(__uint_as_float(v[e] << 16), __uint_as_float(v[e] & 0xffff0000u));
+                hv = v;
               }
               *reinterpret_cast<u32x4_t*>(stg + (srow * G::STG_COLS + tok + 1) * 32 + 16 * q) = hv;
             }
           }
-          float wt[36];
+          // tap weights as bf16 pairs (w, 0) / (0, w): v_dot2c_f32_bf16 of a loaded channel pair with one of them is that channel's tap product, accumulated in fp32
+          // (bf16 taps, as the reference's autocast convolution; the fp16 image of an earlier version overflowed on residual streams beyond 65504)
+          unsigned wt[36];
 #pragma unroll
-          for (int e = 0; e < 9; ++e) { const float4 v = wq[ct & 1][e]; wt[4 * e] = v.x; wt[4 * e + 1] = v.y; wt[4 * e + 2] = v.z; wt[4 * e + 3] = v.w; }
+          for (int e = 0; e < 9; ++e) {
+            const float4 v = wq[ct & 1][e];
+            const float w4[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { const int k = 4 * e + q; wt[k] = (k / 9) & 1 ? pack_bf2(0.f, w4[q]) : pack_bf2(w4[q], 0.f); }
+          }
           const float4 pb = wq[ct & 1][9];
 #pragma unroll
           for (int t = 0; t < SS_NT; ++t) {
@@ -417,10 +437,10 @@ __global__ __launch_bounds__(64 * NW, 2) void dstage_kernel(const DsArgs a) {
             float acc[4] = {pb.x, pb.y, pb.z, pb.w};
 #pragma unroll
             for (int tap = 0; tap < 9; ++tap) {
-              asm("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "+v"(acc[0]) : "v"(f[tap].x), "v"(wt[0 * 9 + tap]));
-              asm("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(acc[1]) : "v"(f[tap].x), "v"(wt[1 * 9 + tap]));
-              asm("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "+v"(acc[2]) : "v"(f[tap].y), "v"(wt[2 * 9 + tap]));
-              asm("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(acc[3]) : "v"(f[tap].y), "v"(wt[3 * 9 + tap]));
+              acc[0] = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, f[tap].x), __builtin_bit_cast(bf16x2_t, wt[0 * 9 + tap]), acc[0], false);
+              acc[1] = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, f[tap].x), __builtin_bit_cast(bf16x2_t, wt[1 * 9 + tap]), acc[1], false);
+              acc[2] = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, f[tap].y), __builtin_bit_cast(bf16x2_t, wt[2 * 9 + tap]), acc[2], false);
+              acc[3] = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, f[tap].y), __builtin_bit_cast(bf16x2_t, wt[3 * 9 + tap]), acc[3], false);
             }
 #pragma unroll
             for (int r = 0; r < 4; ++r) R[t][ct][r] += acc[r];
@@ -430,6 +450,7 @@ __global__ __launch_bounds__(64 * NW, 2) void dstage_kernel(const DsArgs a) {
         }
       }
       DS_STAMP(1);
+      asm volatile("; PHASE_LN1");
       // ---- norm1 -> LDS ----
       {
         DS_PHASE
@@ -441,6 +462,7 @@ __global__ __launch_bounds__(64 * NW, 2) void dstage_kernel(const DsArgs a) {
       const unsigned char* const mf = mfr + (size_t)(gb & 1) * (G::MFRAG_BYTES / 2);
       const __amdgpu_buffer_rsrc_t mr = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(mf), 0, (int)(G::MFRAG_BYTES / 2), 0x00020000);
       const __amdgpu_buffer_rsrc_t pr = __builtin_amdgcn_make_buffer_rsrc(part, 0, (int)G::PART_BYTES, 0x00020000);
+      asm volatile("; PHASE_CDIR");
       // ---- c-direction: per head, scores of the 16 meta queries against the 112 tokens of this workgroup (q~ . norm1(x)), local softmax, v1 of the head
       //      (operands swapped: the V^T fragments of P V), partial (max, sum, sum p v) -> the meta workgroup ----
       {
@@ -499,6 +521,7 @@ __global__ __launch_bounds__(64 * NW, 2) void dstage_kernel(const DsArgs a) {
         }
       }
       DS_STAMP(3);
+      asm volatile("; PHASE_XDIR");
       // ---- x-direction: per head, q1 of the 112 tokens, softmax over the 16 meta keys, P V2; the proj_x operand fragments wait in registers ----
       const int nx = wave0 < NW / 2 ? 2 : 1;
       u32x4_t AO[2][SS_NT];
@@ -554,6 +577,7 @@ __global__ __launch_bounds__(64 * NW, 2) void dstage_kernel(const DsArgs a) {
       }
       __syncthreads();
       DS_STAMP(4);
+      asm volatile("; PHASE_PROJ");
       // ---- x += proj_x(attention) + bias; norm2; MLP ----
       {
         DS_PHASE
@@ -572,8 +596,10 @@ __global__ __launch_bounds__(64 * NW, 2) void dstage_kernel(const DsArgs a) {
         ds_layer_norm<NW, SS_NT>(R, vec + G::V_N2W, vec + G::V_N2B, a.eps, smem + G::L_XN, stat, wave, lane);
       }
       DS_STAMP(5);
+      asm volatile("; PHASE_MLP");
       ds_mlp<NW, SS_NT, G>(R, wp, vec, smem + G::L_XN, smem + G::L_H, lane0, wave0);
       DS_STAMP(6);
+      asm volatile("; PHASE_END");
       // ---- block end: + mlp.3.bias; the first and the last grid row go to the neighbours ----
       {
         DS_PHASE

@@ -69,7 +69,7 @@ template <int NW> struct SG {
   static constexpr size_t HALO_IMG = (size_t)2 * 14 * C * 2;      // [half][14 tokens][C] bf16
   static constexpr size_t PARK_IMG = (size_t)2 * NW * 21 * 1024;  // [half][wave][21 residual tiles][1 KB]: the fp32 residual registers, parked in L2 while k / v / q / attention run
 };
-constexpr int STG_ROW = 96, STG_WAVE = 160 * STG_ROW;                 // dwconv staging: per wave [10 grid rows][16 columns][48 channels] fp16 (over L_XN | L_H)
+constexpr int STG_ROW = 96, STG_WAVE = 160 * STG_ROW;                 // dwconv staging: per wave [10 grid rows][16 columns][48 channels] bf16 (over L_XN | L_H)
 static_assert(8 * STG_WAVE <= SG<8>::L_STAT && 4 * STG_WAVE <= SG<4>::L_STAT, "staging overlaps the statistics");
 // the geometry of SG<NW> under the names the code uses
 #define SS_GEO(NW)                                                                                                                                     \
@@ -301,7 +301,7 @@ __global__ __launch_bounds__(64 * NW, 2) void sstage_kernel(const SsArgs a) {
     SS_STAMP(0);
     asm volatile("; PHASE_DWCONV" ::: "memory");
     // ---- x += dwconv3x3(x) + bias on the 14 x 14 grid (models/lemevit.py:619): the wave's 48 channels of its tokens and of the one grid
-    //      row across the cut go through a wave-private fp16 staging image; taps read fp16 (v_fma_mix_f32), the sum is added to the fp32 residual ----
+    //      row across the cut go through a wave-private bf16 staging image; taps are v_dot2c_f32_bf16 on a loaded channel pair, the sum is added to the fp32 residual ----
     {
       SS_PHASE
       // staging image of the wave's 48 channels: [10 grid rows: the row above, <= 8 own rows, the row below][16 columns: zero | x = 0..13 | zero],
@@ -315,7 +315,7 @@ __global__ __launch_bounds__(64 * NW, 2) void sstage_kernel(const SsArgs a) {
           const int y = slot / SS_G, x = slot - y * SS_G;
 #pragma unroll
           for (int ct = 0; ct < 3; ++ct)
-            *reinterpret_cast<uint2*>(stg + ((y + 1) * 16 + x + 1) * STG_ROW + 32 * ct + 8 * g) = make_uint2(pack_h2(R[t][ct][0], R[t][ct][1]), pack_h2(R[t][ct][2], R[t][ct][3]));
+            *reinterpret_cast<uint2*>(stg + ((y + 1) * 16 + x + 1) * STG_ROW + 32 * ct + 8 * g) = make_uint2(pack_bf2(R[t][ct][0], R[t][ct][1]), pack_bf2(R[t][ct][2], R[t][ct][3]));
         }
       }
       {
@@ -343,10 +343,7 @@ __global__ __launch_bounds__(64 * NW, 2) void sstage_kernel(const SsArgs a) {
           if (p < 84) {
             const int tok = p / 6, q = p - tok * 6;
             const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(hr, tok * SS_C * 2 + (48 * wave + 8 * q) * 2, 0, 16);
-            u32x4_t hv;          // bf16 pairs -> fp16 pairs (the image is fp16: v_fma_mix reads it without an unpack)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) hv[e] = pack_h2(__uint_as_float(v[e] << 16), __uint_as_float(v[e] & 0xffff0000u));
-            *reinterpret_cast<u32x4_t*>(stg + (hrow * 16 + tok + 1) * STG_ROW + 16 * q) = hv;
+            *reinterpret_cast<u32x4_t*>(stg + (hrow * 16 + tok + 1) * STG_ROW + 16 * q) = v;          // (the image is bf16, as the exchanged rows are)
           }
         }
       }
@@ -365,9 +362,16 @@ __global__ __launch_bounds__(64 * NW, 2) void sstage_kernel(const SsArgs a) {
           for (int e = 0; e < 9; ++e) wq[(ct + 1) & 1][e] = *reinterpret_cast<const float4*>(vec + V_POSW + c1 * 9 + 4 * e);
           wq[(ct + 1) & 1][9] = *reinterpret_cast<const float4*>(vec + V_POSB + c1);
         }
-        float wt[36];
+        // tap weights as bf16 pairs (w, 0) / (0, w): v_dot2c_f32_bf16 of a loaded channel pair with one of them is that channel's tap product, accumulated in fp32
+        // (bf16 taps, as the reference's autocast convolution; the fp16 image of an earlier version overflowed on residual streams beyond 65504)
+        unsigned wt[36];
 #pragma unroll
-        for (int e = 0; e < 9; ++e) { const float4 v = wq[ct & 1][e]; wt[4 * e] = v.x; wt[4 * e + 1] = v.y; wt[4 * e + 2] = v.z; wt[4 * e + 3] = v.w; }
+        for (int e = 0; e < 9; ++e) {
+          const float4 v = wq[ct & 1][e];
+          const float w4[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+          for (int q = 0; q < 4; ++q) { const int k = 4 * e + q; wt[k] = (k / 9) & 1 ? pack_bf2(0.f, w4[q]) : pack_bf2(w4[q], 0.f); }
+        }
         const float4 pb = wq[ct & 1][9];
 #pragma unroll
         for (int t = 0; t < SS_NT; ++t) {
@@ -377,8 +381,9 @@ __global__ __launch_bounds__(64 * NW, 2) void sstage_kernel(const SsArgs a) {
           const unsigned char* const tap0 = stg + (y * 16 + x) * STG_ROW + 32 * ct + 8 * g;      // entry of the (-1, -1) neighbour; tap (dy, dx): + ((dy + 1) * 16 + dx + 1) * 96
           float acc[4] = {pb.x, pb.y, pb.z, pb.w};
           // all 9 taps are requested before the first is used (one at a time, hipcc reused one register pair and waited out an LDS round trip per
-          // tap); v_fma_mix_f32 then takes the fp16 operand straight from either half of a loaded pair: one instruction per tap and channel
-          // (bf16 taps cost four unpack operations + two packed FMAs; hipcc itself converts and packs instead of selecting the mixed form)
+          // tap; the builtin, not inline asm: a DOT result needs wait states before another VALU instruction reads it, and the hazard recognizer only
+          // covers instructions it can see); one v_dot2c_f32_bf16 per tap and channel then takes the bf16 operand straight from a loaded pair (unpacking costs two more
+          // operations per pair)
           uint2 f[9];
 #pragma unroll
           for (int tap = 0; tap < 9; ++tap) f[tap] = *reinterpret_cast<const uint2*>(tap0 + ((tap / 3) * 16 + tap % 3) * STG_ROW);
@@ -386,10 +391,10 @@ __global__ __launch_bounds__(64 * NW, 2) void sstage_kernel(const SsArgs a) {
           for (int tap = 0; tap < 9; ++tap) asm volatile("" : "+v"(f[tap]));
 #pragma unroll
           for (int tap = 0; tap < 9; ++tap) {
-            asm("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "+v"(acc[0]) : "v"(f[tap].x), "v"(wt[0 * 9 + tap]));
-            asm("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(acc[1]) : "v"(f[tap].x), "v"(wt[1 * 9 + tap]));
-            asm("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "+v"(acc[2]) : "v"(f[tap].y), "v"(wt[2 * 9 + tap]));
-            asm("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(acc[3]) : "v"(f[tap].y), "v"(wt[3 * 9 + tap]));
+            acc[0] = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, f[tap].x), __builtin_bit_cast(bf16x2_t, wt[0 * 9 + tap]), acc[0], false);
+            acc[1] = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, f[tap].x), __builtin_bit_cast(bf16x2_t, wt[1 * 9 + tap]), acc[1], false);
+            acc[2] = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, f[tap].y), __builtin_bit_cast(bf16x2_t, wt[2 * 9 + tap]), acc[2], false);
+            acc[3] = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, f[tap].y), __builtin_bit_cast(bf16x2_t, wt[3 * 9 + tap]), acc[3], false);
           }
 #pragma unroll
           for (int r = 0; r < 4; ++r) R[t][ct][r] += valid ? acc[r] : 0.f;

@@ -830,22 +830,32 @@ def _lin_probs(pairs, dtype):
 # a whole stage of "S" blocks as one persistent launch (csrc/sstage.hip; inference)
 # ------------------------------------------------------------------------------------------------
 _SSTAGE = os.environ.get("LMV_SSTAGE", "1") != "0"        # 0: the per-block inference schedule (A/B runs)
+_DSTAGE = os.environ.get("LMV_DSTAGE", "1") != "0"        # 0: stages of D blocks on the per-block schedule (A/B runs)
 _sstage_cache: dict = {}
 
 
-def _sstage_applies(stage, xt: Tensor, c: Tensor, H: int, W: int) -> bool:
-    """models/lemevit.py:615-650 x depth as ONE launch: inference only (nothing is saved for a backward pass, no DropPath), bf16, every block
-    of the stage an "S" block of a shape lmv_sstage_supported accepts (stage 3 of LeMeViT-Base at 224 x 224)."""
+def _sstage_applies(stage, xt: Tensor, c: Tensor, H: int, W: int) -> Optional[str]:
+    """A whole stage as ONE launch: models/lemevit.py:615-650 x depth (csrc/sstage.hip: every block an "S" block of a shape lmv_sstage_supported accepts: stage 3 of
+    LeMeViT-Base / -Tiny at 224 x 224 -> "S") or :542-582 x depth (csrc/dstage.hip: "D" blocks, lmv_dstage_supported: stage 2 of LeMeViT-Base -> "D").  Inference only
+    (nothing is saved for a backward pass, no DropPath), bf16.  None: the per-block schedule."""
     if not (_SSTAGE and _FUSED and _NATIVE) or torch.is_grad_enabled() or xt.dtype != torch.bfloat16 or len(stage) == 0 or not xt.is_cuda:
-        return False
+        return None
+    kind = getattr(stage[0], "kind", None)
+    if kind not in ("S", "D"):
+        return None
     for blk in stage:
-        if type(blk) is not LeMeBlock or blk.kind != "S" or (blk.training and blk.drop_prob > 0.0) or type(blk)._masks is not LeMeBlock._masks or "_masks" in blk.__dict__:
-            return False
+        if type(blk) is not LeMeBlock or blk.kind != kind or (blk.training and blk.drop_prob > 0.0) or type(blk)._masks is not LeMeBlock._masks or "_masks" in blk.__dict__:
+            return None
     b0 = stage[0]
-    return ops.sstage_supported(xt.shape[2], b0.attn.num_heads, b0.mlp[0].out_features, H, W, c.shape[1], xt.dtype)
+    if kind == "S":
+        return "S" if ops.sstage_supported(xt.shape[2], b0.attn.num_heads, b0.mlp[0].out_features, H, W, c.shape[1], xt.dtype) else None
+    if _DSTAGE and all(type(blk.attn) is DualCrossAttention and blk.attn.scale == xt.shape[2] ** (-0.5) for blk in stage) and \
+            ops.dstage_supported(xt.shape[2], b0.attn.num_heads, b0.mlp[0].out_features, H, W, c.shape[1], xt.dtype):
+        return "D"
+    return None
 
 
-def _sstage_packed(stage) -> "ops.SStagePacked":
+def _sstage_packed(stage, kind: str = "S") -> "ops.SStagePacked":
     """The stage's parameters in the kernel's layout, cached per parameter version (and per training pass, see compute_copy)."""
     key = id(stage)
     plist = [p for blk in stage for p in blk._params().values()]
@@ -857,7 +867,7 @@ def _sstage_packed(stage) -> "ops.SStagePacked":
     for blk in stage:
         P = blk._params()
         d = {}
-        for n in ops.SSTAGE_NAMES:
+        for n in (ops.SSTAGE_NAMES if kind == "S" else ops.DSTAGE_NAMES):
             if n == "pos_embed.weight":
                 d[n] = P[n].detach().float().reshape(P[n].shape[0], 9).contiguous()
             elif _is_matrix(n):
@@ -865,7 +875,7 @@ def _sstage_packed(stage) -> "ops.SStagePacked":
             else:
                 d[n] = compute_copy(P[n], torch.float32)
         blocks.append(d)
-    packed = ops.sstage_pack(blocks, stage[0].attn.num_heads)
+    packed = (ops.sstage_pack if kind == "S" else ops.dstage_pack)(blocks, stage[0].attn.num_heads)
     _cache_filled()
     _sstage_cache[key] = (weakref.ref(stage, lambda _r, k=key: _sstage_cache.pop(k, None)), stamp, packed)
     return packed
@@ -1229,8 +1239,9 @@ class LeMeViT(nn.Module):
                 c = c.expand(B, -1, -1)
                 hoist = False
             c = c.to(cd).contiguous()
-            if _sstage_applies(self.stages[i], xt, c, H, W):
-                xt, c = ops.sstage_fwd(xt.contiguous(), c, _sstage_packed(self.stages[i]), H, W, BLOCK_LN_EPS)
+            whole = _sstage_applies(self.stages[i], xt, c, H, W)
+            if whole is not None:
+                xt, c = (ops.sstage_fwd if whole == "S" else ops.dstage_fwd)(xt.contiguous(), c, _sstage_packed(self.stages[i], whole), H, W, BLOCK_LN_EPS)
                 continue
             with image_ranges(xt.device, B):
                 for blk in self.stages[i]:

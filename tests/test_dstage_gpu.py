@@ -83,6 +83,20 @@ def test_dstage_vs_oracle(nblocks, B, C, G):
     assert ex <= 1e-2 and ec <= 1e-2, (ex, ec)
 
 
+@pytest.mark.parametrize("C,G", [(192, 28)])
+def test_dstage_large_residual_stream(C, G):
+    """A residual stream far beyond the fp16 range: nothing on the residual path may go through fp16."""
+    from lemevit_amd import ops
+    sds = _stage_params(2, 5, C)
+    P = _pack(sds)
+    x, c = _inputs(2, 3, C, G, scale=3e5)
+    xo, co = ops.dstage_fwd(x.to(DEV), c.to(DEV), P, G, G, 1e-6)
+    torch.cuda.synchronize()
+    xr, cr = _oracle(sds, x.float(), c.float(), G)
+    ex, ec = _rel(xo.float(), xr), _rel(co.float(), cr)
+    assert ex <= 1e-2 and ec <= 1e-2, (ex, ec)
+
+
 @pytest.mark.parametrize("C,G,nblocks,B", [(192, 28, 4, 128)])
 def test_dstage_vs_per_launch_schedule_full_size(C, G, nblocks, B):
     """Stage 2 of LeMeViT-Base at config 3 (B = 128, 4 blocks) against the per-launch inference schedule (lmv_block_fwd) of the same weights; two runs

@@ -82,6 +82,21 @@ def test_sstage_vs_oracle(nblocks, B, C):
     assert ex <= 1e-2 and ec <= 1e-2, (ex, ec)
 
 
+@pytest.mark.parametrize("C", [384, 192])
+def test_sstage_large_residual_stream(C):
+    """A residual stream far beyond the fp16 range (|x| up to 3e5: untrained or badly scaled weights do that, tests/golden's random-filled LeMeViT-Base reaches
+    6e4 at the logits): nothing on the residual path may go through fp16 (the depth-wise convolution's staging image once did)."""
+    from lemevit_amd import ops
+    sds = _stage_params(2, 5, C)
+    P = _pack(sds)
+    x, c = _inputs(2, 3, scale=3e5, C=C)
+    xo, co = ops.sstage_fwd(x.to(DEV), c.to(DEV), P, G, G, 1e-6)
+    torch.cuda.synchronize()
+    xr, cr = _oracle(sds, x.float(), c.float())
+    ex, ec = _rel(xo.float(), xr), _rel(co.float(), cr)
+    assert ex <= 1e-2 and ec <= 1e-2, (ex, ec)
+
+
 @pytest.mark.parametrize("C,nblocks,B", [(384, 18, 128), (192, 8, 256), (192, 8, 300)])
 def test_sstage_vs_per_launch_schedule_full_size(C, nblocks, B):
     """Full batches -- stage 3 of LeMeViT-Base at config 3 (B = 128, 18 blocks), of LeMeViT-Tiny at config 2 (B = 256, 8 blocks) and a batch that needs

@@ -439,18 +439,19 @@ int lmv_sstage_pack(const lmv_sstage_block_params* p, void* wpk_out, float* vec_
 int lmv_sstage_fwd(const lmv_sstage_desc* d, const void* x, const void* c, void* x_out, void* c_out, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------
- * A whole run of "D" blocks as ONE persistent launch (csrc/dstage.hip; inference form, bf16): stage 2 of LeMeViT-Base -- 4 x
+ * A whole run of "D" blocks as ONE persistent launch (csrc/dstage.hip; inference form, bf16): stages 1 and 2 of LeMeViT-Base -- 4 x
  * LeMeBlock.forward_with_xc (models/lemevit.py:542-582, live :560-564; DualCrossAttention :220-324, live :288-302; MLP :526-530) on
  * x [B, 784, 192] and c [B, 16, 192].  An image is 7 workgroups of 112 image tokens (4 grid rows) plus one workgroup for the 16 meta tokens,
  * all resident together; per block they exchange, through L2, the grid rows next to a cut, the meta tokens' K2 / V2 / (q2 W_k1) operand
  * fragments, and the per-workgroup softmax partials of the meta queries over the image keys.  Replaces nblocks lmv_block_fwd(kind = D, save = 0)
  * calls; same math (the image tokens' k projection is folded into the meta queries; its bias cancels in the softmax), residual stream fp32
  * between the blocks.
- *   lmv_dstage_supported: 1 for C = 192 / 6 heads / hidden 768, 28 x 28 image tokens, 16 meta tokens, bf16.
+ *   lmv_dstage_supported: 1 for C = 192 / 6 heads / hidden 768, 28 x 28 image tokens (stage 2 of LeMeViT-Base: 7 + 1 workgroups of 4 waves per image) and for
+ *     C = 96 / 3 heads / hidden 384, 56 x 56 image tokens (stage 1: 28 + 1 workgroups of 2 waves per image); 16 meta tokens, bf16.
  *   lmv_dstage_pack: one block's parameters (matrices bf16, vectors fp32, the reference's layouts: attn.qkv1 / attn.qkv2 [3C, C], attn.proj_x /
  *     attn.proj_c [C, C], mlp.0 [4C, C], mlp.3 [C, 4C], pos_embed.weight [C, 9]) -> wpk_out / vec_out; blocks of a stage consecutive as for lmv_sstage_pack.
  *   lmv_dstage_fwd: x_out / c_out must NOT alias x / c.  `workspace`: lmv_dstage_workspace_bytes(B, C) (exchange buffers and flags of the image
- *     slots; flags reset by the call on `stream`).  All 8 workgroups of an image slot must be co-resident (256 threads / 74 KB LDS each, two per CU):
+ *     slots; flags reset by the call on `stream`).  All 8 (29) workgroups of an image slot must be co-resident (256 threads / 74 KB LDS each, two per CU; 128 / 37 KB, four per CU):
  *     not to be issued while another persistent stage kernel runs on a different stream of the same device.
  * ------------------------------------------------------------------------------------------ */
 typedef struct lmv_dstage_block_params {

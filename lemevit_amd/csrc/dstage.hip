@@ -118,8 +118,8 @@ __device__ __forceinline__ void ds_layer_norm(const f32x4_t (&R)[NTT][3], const 
 // the MLP half on NTT register-resident token tiles: fc1 chunk -> GELU -> LDS -> fc2 partial sums on R (bias of fc2 added by the caller)
 template <int NW, int NTT, typename G>
 __device__ __forceinline__ void ds_mlp(f32x4_t (&R)[NTT][3], const unsigned char* wp, const float* vec, unsigned char* xn, unsigned char* hb, int lane0, int wave0) {
-  constexpr int KS = G::KS, KSC = G::KSC;
-  bf16x8_t ring2[3][2], ring3[4][3];
+  constexpr int KS = G::KS, KSC = G::KSC, RD2 = KSC % 4 == 0 ? 4 : 3;
+  bf16x8_t ring2[3][2], ring3[RD2][3];
   ring_fill<2, 3>(ring2, wp + (size_t)(G::WS_FC1 + wave0 * (2 * KS)) * 1024, lane0);
 #pragma unroll 1
   for (int c = 0; c < DS_NCHUNK; ++c) {
@@ -135,7 +135,7 @@ __device__ __forceinline__ void ds_mlp(f32x4_t (&R)[NTT][3], const unsigned char
       const float* b1p = vec + G::V_FC1B + 32 * NW * c + 32 * wave + 4 * g;
       const float4 b0 = *reinterpret_cast<const float4*>(b1p), b1 = *reinterpret_cast<const float4*>(b1p + 16);
       gemm_unit<2, KS, 3, true, NTT>(acc, ring2, wcur, c + 1 < DS_NCHUNK ? wcur + NW * (2 * KS) * 1024 : wcur, xn, lane);
-      ring_fill<3, 4>(ring3, wp + (size_t)(G::WS_FC2 + (c * NW + wave) * (3 * KSC)) * 1024, lane);
+      ring_fill<3, RD2>(ring3, wp + (size_t)(G::WS_FC2 + (c * NW + wave) * (3 * KSC)) * 1024, lane);
 #pragma unroll
       for (int t = 0; t < NTT; ++t) {
         f32x2_t h0 = {acc[t][0][0] + b0.x, acc[t][0][1] + b0.y}, h1 = {acc[t][0][2] + b0.z, acc[t][0][3] + b0.w};
@@ -151,7 +151,7 @@ __device__ __forceinline__ void ds_mlp(f32x4_t (&R)[NTT][3], const unsigned char
       int lane = lane0; asm volatile("" : "+v"(lane));
       int wave = wave0; asm volatile("" : "+s"(wave));
       const unsigned char* wcur = wp + (size_t)(G::WS_FC2 + (c * NW + wave) * (3 * KSC)) * 1024;
-      gemm_unit<3, KSC, 4, true, NTT>(R, ring3, wcur, wcur, hb, lane);
+      gemm_unit<3, KSC, RD2, true, NTT>(R, ring3, wcur, wcur, hb, lane);
     }
     if (c + 1 < DS_NCHUNK) __syncthreads();
   }
@@ -259,9 +259,14 @@ __global__ __launch_bounds__(64 * NW, 2) void dstage_kernel(const DsArgs a) {
         DS_STAMP(11);
         asm volatile("; PHASE_MCOMB");
         // ---- the KWG partials of the c-direction attention -> c' (log-sum-exp combine, + v bias) -> proj_c operand in LDS ----
-        if (wave0 == 0) {
-#pragma unroll 1
-          for (int r = 0; r < KWG; ++r) wait_flag(partflag + r, (unsigned)(gb + 1), errflag, lane0);
+        if (wave0 == 0) {          // lane r polls the flag of image workgroup r
+          unsigned spins = 0;
+          while (true) {
+            const unsigned v = lane0 < KWG ? __hip_atomic_load((gu32*)(partflag + lane0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0xffffffffu;
+            if (__all(v >= (unsigned)(gb + 1))) break;
+            __builtin_amdgcn_s_sleep(2);
+            if (++spins > SPIN_LIMIT) { if (lane0 == 0) __hip_atomic_store((gu32*)errflag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+          }
         }
         __syncthreads();
         DS_STAMP(12);
@@ -270,23 +275,36 @@ __global__ __launch_bounds__(64 * NW, 2) void dstage_kernel(const DsArgs a) {
           const __amdgpu_buffer_rsrc_t pr = __builtin_amdgcn_make_buffer_rsrc(part, 0, (int)G::PART_BYTES, 0x00020000);
 #pragma unroll 1
           for (int h = wave; h < NH; h += NW) {
-            float M = -INFINITY;
-#pragma unroll 1
+            // (all (max, sum) words first, then the partial sums 7 workgroups at a time: the loads of a batch are in flight together -- one at a time this
+            //  loop was 28 x 2 dependent L2 round trips, 50 us per block at stage 1, and the whole image waited on it)
+            typedef __attribute__((ext_vector_type(2))) unsigned u32x2_t;
+            float mr[KWG], lr[KWG];
+#pragma unroll
             for (int r = 0; r < KWG; ++r) {
-              const u32x4_t ml = __builtin_amdgcn_raw_buffer_load_b128(pr, (((r * NH + h) * 3 + 2) * 64 + lane) * 16, 0, 16);
-              M = max2(M, __uint_as_float(ml[0]));
+              const u32x2_t ml = __builtin_amdgcn_raw_buffer_load_b64(pr, (((r * NH + h) * 3 + 2) * 64 + lane) * 16, 0, 16);
+              mr[r] = __uint_as_float(ml[0]); lr[r] = __uint_as_float(ml[1]);
             }
+            float M = mr[0];
+#pragma unroll
+            for (int r = 1; r < KWG; ++r) M = max2(M, mr[r]);
             f32x4_t o0 = {0.f, 0.f, 0.f, 0.f}, o1 = o0;
             float L = 0.f;
-#pragma unroll 1
-            for (int r = 0; r < KWG; ++r) {
-              const int base = ((r * NH + h) * 3 * 64 + lane) * 16;
-              const u32x4_t ml = __builtin_amdgcn_raw_buffer_load_b128(pr, base + 2 * 1024, 0, 16);
-              const f32x4_t p0 = __builtin_bit_cast(f32x4_t, __builtin_amdgcn_raw_buffer_load_b128(pr, base, 0, 16));
-              const f32x4_t p1 = __builtin_bit_cast(f32x4_t, __builtin_amdgcn_raw_buffer_load_b128(pr, base + 1024, 0, 16));
-              const float w = __builtin_amdgcn_exp2f(__uint_as_float(ml[0]) - M);
-              L = fmaf(__uint_as_float(ml[1]), w, L);
-              o0 += p0 * w; o1 += p1 * w;
+#pragma unroll
+            for (int r0 = 0; r0 < KWG; r0 += 7) {
+              f32x4_t p0[7], p1[7];
+#pragma unroll
+              for (int k = 0; k < 7; ++k) {
+                const int base = (((r0 + k) * NH + h) * 3 * 64 + lane) * 16;
+                p0[k] = __builtin_bit_cast(f32x4_t, __builtin_amdgcn_raw_buffer_load_b128(pr, base, 0, 16));
+                p1[k] = __builtin_bit_cast(f32x4_t, __builtin_amdgcn_raw_buffer_load_b128(pr, base + 1024, 0, 16));
+              }
+#pragma unroll
+              for (int k = 0; k < 7; ++k) {
+                const float w = __builtin_amdgcn_exp2f(mr[r0 + k] - M);
+                L = fmaf(lr[r0 + k], w, L);
+                o0 += p0[k] * w; o1 += p1[k] * w;
+              }
+              __builtin_amdgcn_sched_barrier(0);
             }
             const float inv = 1.f / L;
             const float* bv = vec + G::V_QKV1B + 2 * C + 32 * h + 4 * g;
@@ -680,43 +698,70 @@ __global__ __launch_bounds__(256) void dstage_pack_kernel(const DPackArgs a) {
   a.out[(size_t)f * 64 + lane] = make_uint4(lo.x, lo.y, hi.x, hi.y);
 }
 
-template <int NW, int GW> static int ds_slots(int B, int wgs_per_cu) {
+template <int NW, int GW> static int ds_slots(int B) {
   int dev = 0, cus = 256;
   (void)hipGetDevice(&dev);
   (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-  int n = (cus * wgs_per_cu / DG<NW, GW>::NWG) / 8 * 8;          // whole groups of 8 slots (one per XCD)
+  int n = (cus * (8 / NW) / DG<NW, GW>::NWG) / 8 * 8;          // whole groups of 8 slots (one per XCD); 8 / NW workgroups per CU
   if (n < 8) n = 8;
   const int need = (B + 7) / 8 * 8;
   return n < need ? n : need;
+}
+template <int NW, int GW> static size_t ds_flag_bytes(int ns) { return (((size_t)ns * DG<NW, GW>::FLAGS_PER_SLOT + 1) * 4 + 1023) / 1024 * 1024; }
+template <int NW, int GW> static size_t ds_workspace(int B) { const int ns = ds_slots<NW, GW>(B); return ds_flag_bytes<NW, GW>(ns) + (size_t)ns * DG<NW, GW>::SLOT_BYTES; }
+
+template <int NW, int GW> static int ds_launch(const lmv_dstage_desc* d, const void* x, const void* c, void* x_out, void* c_out, void* workspace, hipStream_t st) {
+  using G = DG<NW, GW>;
+  static std::atomic<unsigned long long> attr_done{0};
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  const unsigned long long bit = 1ull << (dev & 63);
+  if (!(attr_done.load(std::memory_order_acquire) & bit)) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(dstage_kernel<NW, GW>), hipFuncAttributeMaxDynamicSharedMemorySize, G::L_TOTAL) != hipSuccess) LMV_FAIL(LMV_ERR_LAUNCH, "dstage_fwd: cannot reserve LDS");
+    attr_done.fetch_or(bit, std::memory_order_release);
+  }
+  const int ns = ds_slots<NW, GW>(d->B);
+  const size_t flags = ds_flag_bytes<NW, GW>(ns);
+  unsigned char* ws = (unsigned char*)workspace;
+  if (hipMemsetAsync(ws, 0, flags, st) != hipSuccess) LMV_FAIL(LMV_ERR_LAUNCH, "dstage_fwd: flag reset failed");
+  DsArgs a{};
+  a.x_in = (const bf16_t*)x; a.c_in = (const bf16_t*)c; a.x_out = (bf16_t*)x_out; a.c_out = (bf16_t*)c_out;
+  a.wpk = (const uint4*)d->wpk; a.vec = d->vec; a.flags = (unsigned*)ws; a.slots = ws + flags;
+  a.B = d->B; a.nblocks = d->nblocks; a.nslots = ns; a.eps = d->eps;
+  const double N = (double)d->H * d->W, lg2e = 1.4426950408889634;
+  a.sx = (float)(log((double)d->M) / log(N) / sqrt((double)d->C) * lg2e);      // models/lemevit.py:255: log_N(M) C^-1/2
+  a.sc = (float)(1.0 / sqrt((double)d->C) * lg2e);                             // :256
+  a.timing = (unsigned long long*)d->timing; a.timing_block = d->timing_block;
+  hipLaunchKernelGGL((dstage_kernel<NW, GW>), dim3(ns * G::NWG), dim3(64 * NW), G::L_TOTAL, st, a);
+  LMV_CHECK_LAUNCH("dstage_fwd");
+  return LMV_OK;
 }
 
 }  // namespace
 
 // ---- C ABI --------------------------------------------------------------------------------------------------------------------------
-static int ds_variant(int C, int heads, int hidden, int H, int W, int M) {      // 4: stage 2 (C = 192, 28 x 28), 2: stage 1 (C = 96, 56 x 56), 0: not supported
+static int ds_variant(int C, int heads, int hidden, int H, int W, int M) {      // waves per workgroup: 4: stage 2 of LeMeViT-Base (C = 192, 28 x 28), 2: stage 1 (C = 96, 56 x 56); 0: not supported
   if (M != DS_M || H != W || heads != C / 32 || hidden != 4 * C) return 0;
   if (C == 192 && H == 28) return 4;
+  if (C == 96 && H == 56) return 2;
   return 0;
 }
 int lmv_dstage_supported(int C, int heads, int hidden, int H, int W, int M, int dtype) { return dtype == LMV_BF16 && ds_variant(C, heads, hidden, H, W, M) != 0; }
-size_t lmv_dstage_wpk_bytes(int C, int hidden) { (void)hidden; return C == 192 ? (size_t)DG<4, 28>::WS_FRAGS * 1024 : 0; }
+size_t lmv_dstage_wpk_bytes(int C, int hidden) { (void)hidden; return C == 192 ? (size_t)DG<4, 28>::WS_FRAGS * 1024 : C == 96 ? (size_t)DG<2, 56>::WS_FRAGS * 1024 : 0; }
 size_t lmv_dstage_vec_floats(int C, int hidden) { (void)hidden; return (size_t)27 * C; }
-size_t lmv_dstage_workspace_bytes(int B, int C) {
-  if (C != 192) return 0;
-  using G = DG<4, 28>;
-  const int ns = ds_slots<4, 28>(B, 2);
-  return (((size_t)ns * G::FLAGS_PER_SLOT + 1) * 4 + 1023) / 1024 * 1024 + (size_t)ns * G::SLOT_BYTES;
-}
+size_t lmv_dstage_workspace_bytes(int B, int C) { return C == 192 ? ds_workspace<4, 28>(B) : C == 96 ? ds_workspace<2, 56>(B) : 0; }
 
 int lmv_dstage_pack(const lmv_dstage_block_params* p, void* wpk_out, float* vec_out, void* stream) {
   if (!p || !wpk_out || !vec_out) LMV_FAIL(LMV_ERR_SHAPE, "dstage_pack: null argument");
-  if (p->C != 192 || p->heads != 6 || p->hidden != 768) LMV_FAIL(LMV_ERR_DTYPE, "dstage_pack: C = %d / heads = %d / hidden = %d is not a supported stage", p->C, p->heads, p->hidden);
+  if (!((p->C == 192 || p->C == 96) && p->heads == p->C / 32 && p->hidden == 4 * p->C))
+    LMV_FAIL(LMV_ERR_DTYPE, "dstage_pack: C = %d / heads = %d / hidden = %d is not a supported stage", p->C, p->heads, p->hidden);
   const void* ptrs[] = {p->qkv1_w, p->qkv2_w, p->projx_w, p->projc_w, p->fc1_w, p->fc2_w, p->n1_w, p->n1_b, p->qkv1_b, p->qkv2_b, p->projx_b, p->projc_b, p->n2_w, p->n2_b, p->fc1_b, p->fc2_b,
                         p->pos_w, p->pos_b, wpk_out, vec_out};
   for (const void* q : ptrs) if (!q || !lmv_aligned16(q)) LMV_FAIL(LMV_ERR_SHAPE, "dstage_pack: null or misaligned pointer");
   hipStream_t st = (hipStream_t)stream;
   DPackArgs a{(const bf16_t*)p->qkv1_w, (const bf16_t*)p->qkv2_w, (const bf16_t*)p->projx_w, (const bf16_t*)p->projc_w, (const bf16_t*)p->fc1_w, (const bf16_t*)p->fc2_w, (uint4*)wpk_out};
-  hipLaunchKernelGGL(dstage_pack_kernel<4>, dim3((DG<4, 28>::WS_FRAGS + 3) / 4), dim3(256), 0, st, a);
+  if (p->C == 192) hipLaunchKernelGGL(dstage_pack_kernel<4>, dim3((DG<4, 28>::WS_FRAGS + 3) / 4), dim3(256), 0, st, a);
+  else hipLaunchKernelGGL(dstage_pack_kernel<2>, dim3((DG<2, 56>::WS_FRAGS + 3) / 4), dim3(256), 0, st, a);
   LMV_CHECK_LAUNCH("dstage_pack");
   const int C = p->C;
   const struct { const float* src; int off, n; } v[] = {{p->n1_w, 0, C}, {p->n1_b, C, C}, {p->qkv1_b, 2 * C, 3 * C}, {p->qkv2_b, 5 * C, 3 * C}, {p->projx_b, 8 * C, C}, {p->projc_b, 9 * C, C},
@@ -728,34 +773,13 @@ int lmv_dstage_pack(const lmv_dstage_block_params* p, void* wpk_out, float* vec_
 
 int lmv_dstage_fwd(const lmv_dstage_desc* d, const void* x, const void* c, void* x_out, void* c_out, void* workspace, size_t workspace_bytes, void* stream) {
   if (!d || !x || !c || !x_out || !c_out || !workspace) LMV_FAIL(LMV_ERR_SHAPE, "dstage_fwd: null argument");
-  if (!lmv_dstage_supported(d->C, d->heads, d->hidden, d->H, d->W, d->M, d->dtype)) LMV_FAIL(LMV_ERR_DTYPE, "dstage_fwd: unsupported stage shape / dtype");
+  if (d->dtype != LMV_BF16) LMV_FAIL(LMV_ERR_DTYPE, "dstage_fwd: bf16 only");
+  const int nw = ds_variant(d->C, d->heads, d->hidden, d->H, d->W, d->M);
+  if (!nw) LMV_FAIL(LMV_ERR_DTYPE, "dstage_fwd: unsupported stage shape");
   if (d->B <= 0 || d->nblocks <= 0 || !d->wpk || !d->vec) LMV_FAIL(LMV_ERR_SHAPE, "dstage_fwd: bad descriptor");
+  if (x == x_out || c == c_out) LMV_FAIL(LMV_ERR_SHAPE, "dstage_fwd: outputs must not alias the inputs");
   const void* ptrs[] = {x, c, x_out, c_out, workspace, d->wpk, d->vec};
   for (const void* q : ptrs) if (!lmv_aligned16(q)) LMV_FAIL(LMV_ERR_SHAPE, "dstage_fwd: pointers must be 16-byte aligned");
   if (workspace_bytes < lmv_dstage_workspace_bytes(d->B, d->C)) LMV_FAIL(LMV_ERR_WORKSPACE, "dstage_fwd: workspace too small");
-  hipStream_t st = (hipStream_t)stream;
-  using G = DG<4, 28>;
-  static std::atomic<unsigned long long> attr_done{0};
-  int dev = 0;
-  (void)hipGetDevice(&dev);
-  const unsigned long long bit = 1ull << (dev & 63);
-  if (!(attr_done.load(std::memory_order_acquire) & bit)) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(dstage_kernel<4, 28>), hipFuncAttributeMaxDynamicSharedMemorySize, G::L_TOTAL) != hipSuccess) LMV_FAIL(LMV_ERR_LAUNCH, "dstage_fwd: cannot reserve LDS");
-    attr_done.fetch_or(bit, std::memory_order_release);
-  }
-  const int ns = ds_slots<4, 28>(d->B, 2);
-  const size_t flags = (((size_t)ns * G::FLAGS_PER_SLOT + 1) * 4 + 1023) / 1024 * 1024;
-  unsigned char* ws = (unsigned char*)workspace;
-  if (hipMemsetAsync(ws, 0, flags, st) != hipSuccess) LMV_FAIL(LMV_ERR_LAUNCH, "dstage_fwd: flag reset failed");
-  DsArgs a{};
-  a.x_in = (const bf16_t*)x; a.c_in = (const bf16_t*)c; a.x_out = (bf16_t*)x_out; a.c_out = (bf16_t*)c_out;
-  a.wpk = (const uint4*)d->wpk; a.vec = d->vec; a.flags = (unsigned*)ws; a.slots = ws + flags;
-  a.B = d->B; a.nblocks = d->nblocks; a.nslots = ns; a.eps = d->eps;
-  const double N = (double)d->H * d->W, lg2e = 1.4426950408889634;
-  a.sx = (float)(log((double)d->M) / log(N) / sqrt((double)d->C) * lg2e);      // models/lemevit.py:255: log_N(M) C^-1/2
-  a.sc = (float)(1.0 / sqrt((double)d->C) * lg2e);                             // :256
-  a.timing = (unsigned long long*)d->timing; a.timing_block = d->timing_block;
-  hipLaunchKernelGGL((dstage_kernel<4, 28>), dim3(ns * G::NWG), dim3(256), G::L_TOTAL, st, a);
-  LMV_CHECK_LAUNCH("dstage_fwd");
-  return LMV_OK;
+  return nw == 4 ? ds_launch<4, 28>(d, x, c, x_out, c_out, workspace, (hipStream_t)stream) : ds_launch<2, 56>(d, x, c, x_out, c_out, workspace, (hipStream_t)stream);
 }

@@ -73,12 +73,15 @@ __device__ __forceinline__ void ring_fill(bf16x8_t (&ring)[RD][NC], const unsign
 }
 template <int NC, int NKS, int RD, bool TRANS, int NTT = SS_NT>
 __device__ __forceinline__ void gemm_unit(f32x4_t (&acc)[NTT][NC], bf16x8_t (&ring)[RD][NC], const unsigned char* wcur, const unsigned char* wnext, const unsigned char* xs, int lane) {
-  static_assert(NKS % RD == 0, "ring phase");
+  constexpr bool PRE = NKS % RD == 0;          // else: a unit of RD - 1 k-steps, all of them loaded by ring_fill, nothing fetched ahead (wnext unused)
+  static_assert(PRE || NKS == RD - 1, "ring phase");
 #pragma unroll
   for (int ks = 0; ks < NKS; ++ks) {
-    const int sp = ks + RD - 1;
+    if constexpr (PRE) {
+      const int sp = ks + RD - 1;
 #pragma unroll
-    for (int n = 0; n < NC; ++n) ring[sp % RD][n] = sp < NKS ? ld_frag(wcur, sp * NC + n, lane) : ld_frag(wnext, (sp - NKS) * NC + n, lane);
+      for (int n = 0; n < NC; ++n) ring[sp % RD][n] = sp < NKS ? ld_frag(wcur, sp * NC + n, lane) : ld_frag(wnext, (sp - NKS) * NC + n, lane);
+    }
 #pragma unroll
     for (int t = 0; t < NTT; ++t) {
       const bf16x8_t xf = *reinterpret_cast<const bf16x8_t*>(xs + ((ks * NTT + t) * 64 + lane) * 16);

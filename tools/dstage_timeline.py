@@ -1,6 +1,6 @@
 """Timeline of one block of the persistent D-stage kernel (csrc/dstage.hip): s_memtime stamps of every wave of every workgroup at the phase
 boundaries (lmv_dstage_desc.timing), image workgroups and meta workgroups apart, plus the launch time next to the per-launch schedule.
-usage: python tools/dstage_timeline.py [block=1] [B=128] [nblocks=4]"""
+usage: python tools/dstage_timeline.py [block=1] [B=128] [nblocks=4] [C=192 | 96]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -13,7 +13,8 @@ blk = int(sys.argv[1]) if len(sys.argv) > 1 else 1
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 128
 nblocks = int(sys.argv[3]) if len(sys.argv) > 3 else 4
 dev = "cuda:0"
-C, G, NWV, KWG = 192, 28, 4, 7
+C = int(sys.argv[4]) if len(sys.argv) > 4 else 192
+G, NWV, KWG, MAXSLOTS = (28, 4, 7, 64) if C == 192 else (56, 2, 28, 32)
 HID = 4 * C
 g = torch.Generator(device="cpu").manual_seed(0)
 def rnd(*shape, s=1.0): return (torch.rand(*shape, generator=g) * 2 - 1) * s
@@ -51,7 +52,7 @@ try:
     print(f"per-launch schedule (lmv_block_fwd x {nblocks}): {timed(per_launch):.3f} ms")
 except Exception as e:      # (the A/B line is a convenience, the timeline below is the tool)
     print("per-launch schedule not timed:", repr(e)[:200])
-nslots = min(64, (B + 7) // 8 * 8)
+nslots = min(MAXSLOTS, (B + 7) // 8 * 8)
 nwg = nslots * (KWG + 1)
 NS = 16
 tm = torch.zeros(nwg * NWV * NS, dtype=torch.int64, device=dev)

@@ -46,9 +46,12 @@ template <int NW, int GW> struct DG {
   static constexpr int V_N1W = 0, V_N1B = C, V_QKV1B = 2 * C, V_QKV2B = 5 * C, V_PXB = 8 * C, V_PCB = 9 * C, V_N2W = 10 * C, V_N2B = 11 * C, V_FC1B = 12 * C,
                        V_FC2B = 16 * C, V_POSW = 17 * C, V_POSB = 26 * C, V_FLOATS = 27 * C;
   // LDS of an image workgroup (the meta workgroup uses the front of the same regions with one token tile)
-  static constexpr int L_XN = 0, L_XN_BYTES = KS * SS_NT * 1024;
-  static constexpr int L_H = L_XN_BYTES, L_H_BYTES = KSC * SS_NT * 1024;
-  static constexpr int L_STAT = L_H + L_H_BYTES, L_STAT_BYTES = NW * 112 * 8;
+  // L_H | L_XN in this order: the attention output (the proj_x operand, KS k-steps) is written from L_H on -- the heads of the first NW k-steps land in L_H while the
+  // other waves still read the LayerNorm output in L_XN, only the last KS - NW wait (in registers) for the barrier
+  static constexpr int L_H = 0, L_H_BYTES = KSC * SS_NT * 1024;
+  static constexpr int L_XN = L_H_BYTES, L_XN_BYTES = KS * SS_NT * 1024;
+  static constexpr int L_AO = L_H;
+  static constexpr int L_STAT = L_XN + L_XN_BYTES, L_STAT_BYTES = NW * 112 * 8;
   static constexpr int L_TOTAL = L_STAT + L_STAT_BYTES;
   static constexpr int STG_COLS = GW + 2, STG_ENT = (ROWS + 2) * STG_COLS, STG_WAVE = STG_ENT * 32;      // dwconv staging: [ROWS + 2][GW + 2] entries of 16 channels, bf16
   static_assert(NW * STG_WAVE <= L_STAT, "staging overlaps the statistics");
@@ -542,7 +545,7 @@ __global__ __launch_bounds__(64 * NW, 2) void dstage_kernel(const DsArgs a) {
       asm volatile("; PHASE_XDIR");
       // ---- x-direction: per head, q1 of the 112 tokens, softmax over the 16 meta keys, P V2; the proj_x operand fragments wait in registers ----
       const int nx = wave0 < NW / 2 ? 2 : 1;
-      u32x4_t AO[2][SS_NT];
+      u32x4_t AO1[SS_NT];          // the second head of waves 0 .. NW / 2 - 1
       {
         DS_PHASE
         bf16x8_t ring[3][2];
@@ -575,7 +578,9 @@ __global__ __launch_bounds__(64 * NW, 2) void dstage_kernel(const DsArgs a) {
               const u32x4_t pk = {pack_h2(e[0], e[1]), pack_h2(e[2], e[3]), 0u, 0u};
               const f16x8_t pf = __builtin_bit_cast(f16x8_t, pk);
               const f32x4_t o0 = mfma_f16(__builtin_bit_cast(f16x8_t, v20), pf, z4), o1 = mfma_f16(__builtin_bit_cast(f16x8_t, v21), pf, z4);
-              AO[hu][t] = pack_bf8(o0 * inv, o1 * inv);
+              const u32x4_t ao = pack_bf8(o0 * inv, o1 * inv);
+              if (hu == 0) *reinterpret_cast<u32x4_t*>(smem + G::L_AO + ((h * SS_NT + t) * 64 + lane) * 16) = ao;
+              else AO1[t] = ao;
             }
           }
         }
@@ -583,15 +588,11 @@ __global__ __launch_bounds__(64 * NW, 2) void dstage_kernel(const DsArgs a) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the partial stores of this wave (R1: every storing wave drains)
       __syncthreads();                                         // ... and every wave is done with the LayerNorm output in LDS
       if (tid == 0) __hip_atomic_store((gu32*)(partflag + role), (unsigned)(gb + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      {
+      if (nx == 2) {
         DS_PHASE
+        const int h = wave + NW;
 #pragma unroll
-        for (int hu = 0; hu < 2; ++hu)
-          if (hu < nx) {
-            const int h = wave + NW * hu;
-#pragma unroll
-            for (int t = 0; t < SS_NT; ++t) *reinterpret_cast<u32x4_t*>(smem + G::L_XN + ((h * SS_NT + t) * 64 + lane) * 16) = AO[hu][t];
-          }
+        for (int t = 0; t < SS_NT; ++t) *reinterpret_cast<u32x4_t*>(smem + G::L_AO + ((h * SS_NT + t) * 64 + lane) * 16) = AO1[t];
       }
       __syncthreads();
       DS_STAMP(4);
@@ -605,7 +606,7 @@ __global__ __launch_bounds__(64 * NW, 2) void dstage_kernel(const DsArgs a) {
         bf16x8_t ringp[G::PRD][3];
         const unsigned char* wcur = wp + (size_t)(G::WS_PX + wave * (3 * KS)) * 1024;
         ring_fill<3, G::PRD>(ringp, wcur, lane);
-        gemm_unit<3, KS, G::PRD, true>(R, ringp, wcur, wcur, smem + G::L_XN, lane);
+        gemm_unit<3, KS, G::PRD, true>(R, ringp, wcur, wcur, smem + G::L_AO, lane);
 #pragma unroll
         for (int ct = 0; ct < 3; ++ct)
 #pragma unroll

@@ -25,8 +25,20 @@ __device__ __forceinline__ u32x4_t pack_bf8(const f32x4_t& a, const f32x4_t& b) 
 // max without the canonicalising v_max x, x that fmaxf costs under IEEE mode: v_med3(a, b, +inf) = max(a, b) for non-NaN inputs
 __device__ __forceinline__ float max2(float a, float b) { return __builtin_amdgcn_fmed3f(a, b, INFINITY); }
 __device__ __forceinline__ float max4(const f32x4_t& s) { return max2(max2(s[0], s[1]), max2(s[2], s[3])); }
-__device__ __forceinline__ float xsum4(float v) { v += __shfl_xor(v, 16, 64); v += __shfl_xor(v, 32, 64); return v; }      // over the 4 lane groups of a token
-__device__ __forceinline__ float xmax4(float v) { v = max2(v, __shfl_xor(v, 16, 64)); v = max2(v, __shfl_xor(v, 32, 64)); return v; }
+// reductions over the 4 lane groups of a token (lanes i, i + 16, i + 32, i + 48): v_permlane16_swap / v_permlane32_swap of two copies leave every lane with both
+// halves of a pair -- VALU only (the __shfl_xor form is two ds_bpermute round trips through the LDS pipe per reduction)
+__device__ __forceinline__ float xsum4(float v) {
+  auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  v = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+  auto q = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return __uint_as_float(q[0]) + __uint_as_float(q[1]);
+}
+__device__ __forceinline__ float xmax4(float v) {
+  auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  v = max2(__uint_as_float(r[0]), __uint_as_float(r[1]));
+  auto q = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return max2(__uint_as_float(q[0]), __uint_as_float(q[1]));
+}
 
 // one lane polls a flag word until it reaches `epoch` (relaxed agent-scope loads + s_sleep); a bounded spin reports through flags[err]
 __device__ __forceinline__ void wait_flag(unsigned* flag, unsigned epoch, unsigned* err, int lane) {

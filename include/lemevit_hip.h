@@ -446,8 +446,8 @@ int lmv_sstage_fwd(const lmv_sstage_desc* d, const void* x, const void* c, void*
  * fragments, and the per-workgroup softmax partials of the meta queries over the image keys.  Replaces nblocks lmv_block_fwd(kind = D, save = 0)
  * calls; same math (the image tokens' k projection is folded into the meta queries; its bias cancels in the softmax), residual stream fp32
  * between the blocks.
- *   lmv_dstage_supported: 1 for C = 192 / 6 heads / hidden 768, 28 x 28 image tokens (stage 2 of LeMeViT-Base: 7 + 1 workgroups of 4 waves per image) and for
- *     C = 96 / 3 heads / hidden 384, 56 x 56 image tokens (stage 1: 28 + 1 workgroups of 2 waves per image); 16 meta tokens, bf16.
+ *   lmv_dstage_supported: 1 for C = 192 (LeMeViT-Base / -Small stage 2) or 128 (LeMeViT-Tiny stage 2) at 28 x 28 image tokens (7 + 1 workgroups of 4 waves per image) and for
+ *     C = 96 (Base / Small stage 1) or 64 (Tiny stage 1) at 56 x 56 (28 + 1 workgroups of 2 waves); heads = C / 32, hidden = 4 C, 16 meta tokens, bf16.
  *   lmv_dstage_pack: one block's parameters (matrices bf16, vectors fp32, the reference's layouts: attn.qkv1 / attn.qkv2 [3C, C], attn.proj_x /
  *     attn.proj_c [C, C], mlp.0 [4C, C], mlp.3 [C, 4C], pos_embed.weight [C, 9]) -> wpk_out / vec_out; blocks of a stage consecutive as for lmv_sstage_pack.
  *   lmv_dstage_fwd: x_out / c_out must NOT alias x / c.  `workspace`: lmv_dstage_workspace_bytes(B, C) (exchange buffers and flags of the image

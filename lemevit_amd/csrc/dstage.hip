@@ -25,24 +25,28 @@
 
 namespace {
 
-constexpr int DS_NCHUNK = 6, DS_M = 16, DS_NSTAMP = 16;
+constexpr int DS_M = 16, DS_NSTAMP = 16;
 
-template <int NW, int GW> struct DG {
-  static constexpr int C = 48 * NW, NH = C / 32, HID = 4 * C, KS = C / 32, KSC = NW, PRD = KS % 4 == 0 ? 4 : 3;
+// NW waves per workgroup, a wave owns CT channel tiles of 16 (CT = 3: C = 96 / 192, LeMeViT-Base / -Small; CT = 2: C = 64 / 128, LeMeViT-Tiny); GW x GW image tokens
+template <int NW, int GW, int CTILES> struct DG {
+  static constexpr int CT = CTILES, CW = 16 * CT, C = CW * NW, NH = C / 32, HID = 4 * C, KS = C / 32, KSC = NW, NCHUNK = 2 * CT;
+  static constexpr int PRD = KS % 4 == 0 ? 4 : 3;                                  // ring depth of the proj units (CT tiles per k-step; KS = 2: the whole unit up front)
+  static constexpr int URD = KS % 3 == 0 ? 3 : (KS % 4 == 0 ? 4 : 3);              // ring depth of the 2-tile units (q1, v1, k2 / v2 / q2, fc1)
+  static_assert((CT * NW) % 2 == 0, "whole heads");
   static constexpr int ROWS = 112 / GW, KWG = GW / ROWS, NIMG = GW * GW, NWG = KWG + 1;
   static_assert(ROWS * GW == 112 && KWG * ROWS == GW, "an image workgroup is whole grid rows");
   // packed weights of a block, 1 KB fragments (stage_common.h / sstage.hip: lane (g, i) holds W[row0 + i][32 ks + 16 (j >> 2) + 4 g + (j & 3)])
   static constexpr int WS_Q1 = 0;                                   // [head][ks][n 2]: rows 32 h + 16 n of qkv1.weight
   static constexpr int WS_V1 = WS_Q1 + NH * KS * 2;                 // [head][ks][n 2]: rows 2 C + 32 h + 16 n of qkv1.weight
-  static constexpr int WS_PX = WS_V1 + NH * KS * 2;                 // [wave][ks][n 3]: rows 48 w + 16 n of proj_x.weight
-  static constexpr int WS_FC1 = WS_PX + NW * KS * 3;                // [chunk][wave][ks][n 2]
-  static constexpr int WS_FC2 = WS_FC1 + DS_NCHUNK * NW * KS * 2;   // [chunk][wave][ksl KSC][n 3]
-  static constexpr int WS_K2 = WS_FC2 + DS_NCHUNK * NW * KSC * 3;   // meta: [head][ks][n 2]: rows C + 32 h + 16 n of qkv2.weight
+  static constexpr int WS_PX = WS_V1 + NH * KS * 2;                 // [wave][ks][n CT]: rows CW w + 16 n of proj_x.weight
+  static constexpr int WS_FC1 = WS_PX + NW * KS * CT;                // [chunk][wave][ks][n 2]
+  static constexpr int WS_FC2 = WS_FC1 + NCHUNK * NW * KS * 2;      // [chunk][wave][ksl KSC][n CT]
+  static constexpr int WS_K2 = WS_FC2 + NCHUNK * NW * KSC * CT;     // meta: [head][ks][n 2]: rows C + 32 h + 16 n of qkv2.weight
   static constexpr int WS_V2 = WS_K2 + NH * KS * 2;                 //       rows 2 C + 32 h + 16 n
   static constexpr int WS_Q2 = WS_V2 + NH * KS * 2;                 //       rows 32 h + 16 n
   static constexpr int WS_K1T = WS_Q2 + NH * KS * 2;                // [head][m < C / 16]: lane (g, i) holds qkv1.weight[C + 32 h + 16 (j >> 2) + 4 g + (j & 3)][16 m + i]
-  static constexpr int WS_PC = WS_K1T + NH * (C / 16);              // [wave][ks][n 3]: proj_c.weight
-  static constexpr int WS_FRAGS = WS_PC + NW * KS * 3;
+  static constexpr int WS_PC = WS_K1T + NH * (C / 16);              // [wave][ks][n CT]: proj_c.weight
+  static constexpr int WS_FRAGS = WS_PC + NW * KS * CT;
   static constexpr int V_N1W = 0, V_N1B = C, V_QKV1B = 2 * C, V_QKV2B = 5 * C, V_PXB = 8 * C, V_PCB = 9 * C, V_N2W = 10 * C, V_N2B = 11 * C, V_FC1B = 12 * C,
                        V_FC2B = 16 * C, V_POSW = 17 * C, V_POSB = 26 * C, V_FLOATS = 27 * C;
   // LDS of an image workgroup (the meta workgroup uses the front of the same regions with one token tile)
@@ -78,23 +82,23 @@ struct DsArgs {
   } while (0)
 
 // LayerNorm of NTT register-resident token tiles -> bf16 operand fragments at `xn` ([k-step][tile]); statistics over the NW waves through `stat`
-template <int NW, int NTT>
-__device__ __forceinline__ void ds_layer_norm(const f32x4_t (&R)[NTT][3], const float* gam, const float* bet, float eps, unsigned char* xn, float2* stat, int wave, int lane) {
-  constexpr int C = 48 * NW;
+template <int NW, int NTT, int CT>
+__device__ __forceinline__ void ds_layer_norm(const f32x4_t (&R)[NTT][CT], const float* gam, const float* bet, float eps, unsigned char* xn, float2* stat, int wave, int lane) {
+  constexpr int CW = 16 * CT, C = CW * NW;
   const int g = lane >> 4, li = lane & 15;
 #pragma unroll
   for (int t = 0; t < NTT; ++t) {
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-    for (int ct = 0; ct < 3; ++ct)
+    for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
       for (int r = 0; r < 4; ++r) { s1 += R[t][ct][r]; s2 = fmaf(R[t][ct][r], R[t][ct][r], s2); }
     s1 = xsum4(s1); s2 = xsum4(s2);
     if (g == 0) stat[wave * 112 + t * 16 + li] = make_float2(s1, s2);
   }
-  float4 ga[3], be[3];
+  float4 ga[CT], be[CT];
 #pragma unroll
-  for (int ct = 0; ct < 3; ++ct) { ga[ct] = *reinterpret_cast<const float4*>(gam + 48 * wave + 16 * ct + 4 * g); be[ct] = *reinterpret_cast<const float4*>(bet + 48 * wave + 16 * ct + 4 * g); }
+  for (int ct = 0; ct < CT; ++ct) { ga[ct] = *reinterpret_cast<const float4*>(gam + CW * wave + 16 * ct + 4 * g); be[ct] = *reinterpret_cast<const float4*>(bet + CW * wave + 16 * ct + 4 * g); }
   __syncthreads();
   float mean[NTT], rstd[NTT];
 #pragma unroll
@@ -106,8 +110,8 @@ __device__ __forceinline__ void ds_layer_norm(const f32x4_t (&R)[NTT][3], const 
     rstd[t] = rsqrtf(fmaxf(s2 * (1.f / C) - mean[t] * mean[t], 0.f) + eps);
   }
 #pragma unroll
-  for (int ct = 0; ct < 3; ++ct) {
-    const int T = 3 * wave + ct;
+  for (int ct = 0; ct < CT; ++ct) {
+    const int T = CT * wave + ct;
 #pragma unroll
     for (int t = 0; t < NTT; ++t) {
       const float y0 = fmaf((R[t][ct][0] - mean[t]) * rstd[t], ga[ct].x, be[ct].x), y1 = fmaf((R[t][ct][1] - mean[t]) * rstd[t], ga[ct].y, be[ct].y);
@@ -120,12 +124,13 @@ __device__ __forceinline__ void ds_layer_norm(const f32x4_t (&R)[NTT][3], const 
 
 // the MLP half on NTT register-resident token tiles: fc1 chunk -> GELU -> LDS -> fc2 partial sums on R (bias of fc2 added by the caller)
 template <int NW, int NTT, typename G>
-__device__ __forceinline__ void ds_mlp(f32x4_t (&R)[NTT][3], const unsigned char* wp, const float* vec, unsigned char* xn, unsigned char* hb, int lane0, int wave0) {
-  constexpr int KS = G::KS, KSC = G::KSC, RD2 = KSC % 4 == 0 ? 4 : 3;
-  bf16x8_t ring2[3][2], ring3[RD2][3];
-  ring_fill<2, 3>(ring2, wp + (size_t)(G::WS_FC1 + wave0 * (2 * KS)) * 1024, lane0);
+__device__ __forceinline__ void ds_mlp(f32x4_t (&R)[NTT][G::CT], const unsigned char* wp, const float* vec, unsigned char* xn, unsigned char* hb, int lane0, int wave0) {
+  constexpr int KS = G::KS, KSC = G::KSC, CT = G::CT, URD = G::URD, RD2 = KSC % 4 == 0 ? 4 : 3;
+  constexpr bool PRE1 = KS % URD == 0;          // the fc1 fragments of chunk c + 1 are fetched behind those of chunk c (else: a unit is loaded whole, up front)
+  bf16x8_t ring2[URD][2], ring3[RD2][CT];
+  if constexpr (PRE1) ring_fill<2, URD>(ring2, wp + (size_t)(G::WS_FC1 + wave0 * (2 * KS)) * 1024, lane0);
 #pragma unroll 1
-  for (int c = 0; c < DS_NCHUNK; ++c) {
+  for (int c = 0; c < G::NCHUNK; ++c) {
     {
       __builtin_amdgcn_sched_barrier(0);
       int lane = lane0; asm volatile("" : "+v"(lane));
@@ -137,8 +142,9 @@ __device__ __forceinline__ void ds_mlp(f32x4_t (&R)[NTT][3], const unsigned char
       const unsigned char* wcur = wp + (size_t)(G::WS_FC1 + (c * NW + wave) * (2 * KS)) * 1024;
       const float* b1p = vec + G::V_FC1B + 32 * NW * c + 32 * wave + 4 * g;
       const float4 b0 = *reinterpret_cast<const float4*>(b1p), b1 = *reinterpret_cast<const float4*>(b1p + 16);
-      gemm_unit<2, KS, 3, true, NTT>(acc, ring2, wcur, c + 1 < DS_NCHUNK ? wcur + NW * (2 * KS) * 1024 : wcur, xn, lane);
-      ring_fill<3, RD2>(ring3, wp + (size_t)(G::WS_FC2 + (c * NW + wave) * (3 * KSC)) * 1024, lane);
+      if constexpr (!PRE1) ring_fill<2, URD>(ring2, wcur, lane);
+      gemm_unit<2, KS, URD, true, NTT>(acc, ring2, wcur, c + 1 < G::NCHUNK ? wcur + NW * (2 * KS) * 1024 : wcur, xn, lane);
+      ring_fill<CT, RD2>(ring3, wp + (size_t)(G::WS_FC2 + (c * NW + wave) * (CT * KSC)) * 1024, lane);
 #pragma unroll
       for (int t = 0; t < NTT; ++t) {
         f32x2_t h0 = {acc[t][0][0] + b0.x, acc[t][0][1] + b0.y}, h1 = {acc[t][0][2] + b0.z, acc[t][0][3] + b0.w};
@@ -153,17 +159,17 @@ __device__ __forceinline__ void ds_mlp(f32x4_t (&R)[NTT][3], const unsigned char
       __builtin_amdgcn_sched_barrier(0);
       int lane = lane0; asm volatile("" : "+v"(lane));
       int wave = wave0; asm volatile("" : "+s"(wave));
-      const unsigned char* wcur = wp + (size_t)(G::WS_FC2 + (c * NW + wave) * (3 * KSC)) * 1024;
-      gemm_unit<3, KSC, RD2, true, NTT>(R, ring3, wcur, wcur, hb, lane);
+      const unsigned char* wcur = wp + (size_t)(G::WS_FC2 + (c * NW + wave) * (CT * KSC)) * 1024;
+      gemm_unit<CT, KSC, RD2, true, NTT>(R, ring3, wcur, wcur, hb, lane);
     }
-    if (c + 1 < DS_NCHUNK) __syncthreads();
+    if (c + 1 < G::NCHUNK) __syncthreads();
   }
 }
 
-template <int NW, int GW>
+template <int NW, int GW, int CT>
 __global__ __launch_bounds__(64 * NW, 2) void dstage_kernel(const DsArgs a) {
-  using G = DG<NW, GW>;
-  constexpr int C = G::C, NH = G::NH, KS = G::KS, KWG = G::KWG, ROWS = G::ROWS;
+  using G = DG<NW, GW, CT>;
+  constexpr int C = G::C, NH = G::NH, KS = G::KS, KWG = G::KWG, ROWS = G::ROWS, CW = G::CW, URD = G::URD;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane0 = tid & 63, wave0 = __builtin_amdgcn_readfirstlane(tid >> 6);
 #define DS_PHASE                                                    \
@@ -188,11 +194,11 @@ __global__ __launch_bounds__(64 * NW, 2) void dstage_kernel(const DsArgs a) {
     if (role == KWG) {
       asm volatile("; PHASE_META");
       // =================================== the meta workgroup: the 16 meta tokens of image `img` ===================================
-      f32x4_t Rc[1][3];
+      f32x4_t Rc[1][CT];
       {
         DS_PHASE
 #pragma unroll
-        for (int ct = 0; ct < 3; ++ct) { float f[4]; ld4(a.c_in + ((size_t)img * DS_M + li) * C + 48 * wave + 16 * ct + 4 * g, f); Rc[0][ct] = f32x4_t{f[0], f[1], f[2], f[3]}; }
+        for (int ct = 0; ct < CT; ++ct) { float f[4]; ld4(a.c_in + ((size_t)img * DS_M + li) * C + CW * wave + 16 * ct + 4 * g, f); Rc[0][ct] = f32x4_t{f[0], f[1], f[2], f[3]}; }
       }
 #pragma unroll 1
       for (int blk = 0; blk < a.nblocks; ++blk) {
@@ -206,22 +212,22 @@ __global__ __launch_bounds__(64 * NW, 2) void dstage_kernel(const DsArgs a) {
         // ---- norm1(c) -> LDS; K2 / V2 / q2 of every head; q~ = q2 W_k1; all published for the image workgroups ----
         {
           DS_PHASE
-          ds_layer_norm<NW, 1>(Rc, vec + G::V_N1W, vec + G::V_N1B, a.eps, smem + G::L_XN, stat, wave, lane);
+          ds_layer_norm<NW, 1, CT>(Rc, vec + G::V_N1W, vec + G::V_N1B, a.eps, smem + G::L_XN, stat, wave, lane);
         }
         DS_STAMP(9);
         {
           DS_PHASE
           // 3 NH units (k2, v2, q2 of a head: 2 channel tiles x 1 token tile x KS) dealt round-robin to the waves; q2 fragments also go to LDS for the q~ pass
-          bf16x8_t ring[3][2];
+          bf16x8_t ring[URD][2];
 #pragma unroll 1
           for (int u = wave; u < 3 * NH; u += NW) {
             const int h = u / 3, typ = u - 3 * h;                 // 0: k2, 1: v2, 2: q2
             const unsigned char* wcur = wp + (size_t)((typ == 0 ? G::WS_K2 : typ == 1 ? G::WS_V2 : G::WS_Q2) + h * (2 * KS)) * 1024;
-            ring_fill<2, 3>(ring, wcur, lane);
+            ring_fill<2, URD>(ring, wcur, lane);
             f32x4_t acc[1][2] = {{f32x4_t{0.f, 0.f, 0.f, 0.f}, f32x4_t{0.f, 0.f, 0.f, 0.f}}};
             if (typ == 1) {
               const float bv0 = vec[G::V_QKV2B + 2 * C + 32 * h + li], bv1 = vec[G::V_QKV2B + 2 * C + 32 * h + 16 + li];
-              gemm_unit<2, KS, 3, false, 1>(acc, ring, wcur, wcur, smem + G::L_XN, lane);
+              gemm_unit<2, KS, URD, false, 1>(acc, ring, wcur, wcur, smem + G::L_XN, lane);
 #pragma unroll
               for (int dt = 0; dt < 2; ++dt) {
                 const f32x4_t lo = acc[0][dt] + (dt ? bv1 : bv0);
@@ -231,7 +237,7 @@ __global__ __launch_bounds__(64 * NW, 2) void dstage_kernel(const DsArgs a) {
             } else {
               const float* bp = vec + G::V_QKV2B + (typ == 0 ? C : 0) + 32 * h + 4 * g;
               const float4 b0 = *reinterpret_cast<const float4*>(bp), b1 = *reinterpret_cast<const float4*>(bp + 16);
-              gemm_unit<2, KS, 3, true, 1>(acc, ring, wcur, wcur, smem + G::L_XN, lane);
+              gemm_unit<2, KS, URD, true, 1>(acc, ring, wcur, wcur, smem + G::L_XN, lane);
               const float sc = typ == 0 ? 1.f : a.sc;
               const f32x4_t k0 = {(acc[0][0][0] + b0.x) * sc, (acc[0][0][1] + b0.y) * sc, (acc[0][0][2] + b0.z) * sc, (acc[0][0][3] + b0.w) * sc};
               const f32x4_t k1 = {(acc[0][1][0] + b1.x) * sc, (acc[0][1][1] + b1.y) * sc, (acc[0][1][2] + b1.z) * sc, (acc[0][1][3] + b1.w) * sc};
@@ -323,17 +329,17 @@ __global__ __launch_bounds__(64 * NW, 2) void dstage_kernel(const DsArgs a) {
         // ---- c += proj_c(c') + bias; norm2; MLP ----
         {
           DS_PHASE
-          float4 pb[3];
+          float4 pb[CT];
 #pragma unroll
-          for (int ct = 0; ct < 3; ++ct) pb[ct] = *reinterpret_cast<const float4*>(vec + G::V_PCB + 48 * wave + 16 * ct + 4 * g);
-          bf16x8_t ringp[G::PRD][3];
-          const unsigned char* wcur = wp + (size_t)(G::WS_PC + wave * (3 * KS)) * 1024;
-          ring_fill<3, G::PRD>(ringp, wcur, lane);
-          gemm_unit<3, KS, G::PRD, true, 1>(Rc, ringp, wcur, wcur, smem + G::L_XN, lane);
+          for (int ct = 0; ct < CT; ++ct) pb[ct] = *reinterpret_cast<const float4*>(vec + G::V_PCB + CW * wave + 16 * ct + 4 * g);
+          bf16x8_t ringp[G::PRD][CT];
+          const unsigned char* wcur = wp + (size_t)(G::WS_PC + wave * (CT * KS)) * 1024;
+          ring_fill<CT, G::PRD>(ringp, wcur, lane);
+          gemm_unit<CT, KS, G::PRD, true, 1>(Rc, ringp, wcur, wcur, smem + G::L_XN, lane);
 #pragma unroll
-          for (int ct = 0; ct < 3; ++ct) { Rc[0][ct][0] += pb[ct].x; Rc[0][ct][1] += pb[ct].y; Rc[0][ct][2] += pb[ct].z; Rc[0][ct][3] += pb[ct].w; }
+          for (int ct = 0; ct < CT; ++ct) { Rc[0][ct][0] += pb[ct].x; Rc[0][ct][1] += pb[ct].y; Rc[0][ct][2] += pb[ct].z; Rc[0][ct][3] += pb[ct].w; }
           __syncthreads();          // every wave has read the proj_c operand: norm2 may overwrite it
-          ds_layer_norm<NW, 1>(Rc, vec + G::V_N2W, vec + G::V_N2B, a.eps, smem + G::L_XN, stat, wave, lane);
+          ds_layer_norm<NW, 1, CT>(Rc, vec + G::V_N2W, vec + G::V_N2B, a.eps, smem + G::L_XN, stat, wave, lane);
         }
         DS_STAMP(14);
         ds_mlp<NW, 1, G>(Rc, wp, vec, smem + G::L_XN, smem + G::L_H, lane0, wave0);
@@ -341,8 +347,8 @@ __global__ __launch_bounds__(64 * NW, 2) void dstage_kernel(const DsArgs a) {
         {
           DS_PHASE
 #pragma unroll
-          for (int ct = 0; ct < 3; ++ct) {
-            const float4 b = *reinterpret_cast<const float4*>(vec + G::V_FC2B + 48 * wave + 16 * ct + 4 * g);
+          for (int ct = 0; ct < CT; ++ct) {
+            const float4 b = *reinterpret_cast<const float4*>(vec + G::V_FC2B + CW * wave + 16 * ct + 4 * g);
             Rc[0][ct][0] += b.x; Rc[0][ct][1] += b.y; Rc[0][ct][2] += b.z; Rc[0][ct][3] += b.w;
           }
         }
@@ -351,9 +357,9 @@ __global__ __launch_bounds__(64 * NW, 2) void dstage_kernel(const DsArgs a) {
       {
         DS_PHASE
 #pragma unroll
-        for (int ct = 0; ct < 3; ++ct) {
+        for (int ct = 0; ct < CT; ++ct) {
           const float f[4] = {Rc[0][ct][0], Rc[0][ct][1], Rc[0][ct][2], Rc[0][ct][3]};
-          st4(a.c_out + ((size_t)img * DS_M + li) * C + 48 * wave + 16 * ct + 4 * g, f);
+          st4(a.c_out + ((size_t)img * DS_M + li) * C + CW * wave + 16 * ct + 4 * g, f);
         }
       }
       continue;
@@ -362,14 +368,14 @@ __global__ __launch_bounds__(64 * NW, 2) void dstage_kernel(const DsArgs a) {
     asm volatile("; PHASE_IMG");
     // =================================== an image workgroup: 112 image tokens (ROWS grid rows) of image `img` ===================================
     const int tok0 = role * 112;
-    f32x4_t R[SS_NT][3];
+    f32x4_t R[SS_NT][CT];
     {
       DS_PHASE
 #pragma unroll
       for (int t = 0; t < SS_NT; ++t) {
         const bf16_t* src = a.x_in + ((size_t)img * G::NIMG + tok0 + 16 * t + li) * C;
 #pragma unroll
-        for (int ct = 0; ct < 3; ++ct) { float f[4]; ld4(src + 48 * wave + 16 * ct + 4 * g, f); R[t][ct] = f32x4_t{f[0], f[1], f[2], f[3]}; }
+        for (int ct = 0; ct < CT; ++ct) { float f[4]; ld4(src + CW * wave + 16 * ct + 4 * g, f); R[t][ct] = f32x4_t{f[0], f[1], f[2], f[3]}; }
       }
     }
 #pragma unroll 1
@@ -392,14 +398,14 @@ __global__ __launch_bounds__(64 * NW, 2) void dstage_kernel(const DsArgs a) {
         }
         float4 wq[2][10];
 #pragma unroll
-        for (int e = 0; e < 9; ++e) wq[0][e] = *reinterpret_cast<const float4*>(vec + G::V_POSW + (48 * wave + 4 * g) * 9 + 4 * e);
-        wq[0][9] = *reinterpret_cast<const float4*>(vec + G::V_POSB + 48 * wave + 4 * g);
+        for (int e = 0; e < 9; ++e) wq[0][e] = *reinterpret_cast<const float4*>(vec + G::V_POSW + (CW * wave + 4 * g) * 9 + 4 * e);
+        wq[0][9] = *reinterpret_cast<const float4*>(vec + G::V_POSB + CW * wave + 4 * g);
 #pragma unroll
-        for (int ct = 0; ct < 3; ++ct) {
+        for (int ct = 0; ct < CT; ++ct) {
           int l2 = lane; asm volatile("" : "+v"(l2));
           const int g = l2 >> 4, li = l2 & 15;
-          const int c0 = 48 * wave + 16 * ct;
-          if (ct + 1 < 3) {
+          const int c0 = CW * wave + 16 * ct;
+          if (ct + 1 < CT) {
 #pragma unroll
             for (int e = 0; e < 9; ++e) wq[(ct + 1) & 1][e] = *reinterpret_cast<const float4*>(vec + G::V_POSW + (c0 + 16 + 4 * g) * 9 + 4 * e);
             wq[(ct + 1) & 1][9] = *reinterpret_cast<const float4*>(vec + G::V_POSB + c0 + 16 + 4 * g);
@@ -475,7 +481,7 @@ __global__ __launch_bounds__(64 * NW, 2) void dstage_kernel(const DsArgs a) {
       // ---- norm1 -> LDS ----
       {
         DS_PHASE
-        ds_layer_norm<NW, SS_NT>(R, vec + G::V_N1W, vec + G::V_N1B, a.eps, smem + G::L_XN, stat, wave, lane);
+        ds_layer_norm<NW, SS_NT, CT>(R, vec + G::V_N1W, vec + G::V_N1B, a.eps, smem + G::L_XN, stat, wave, lane);
         if (wave == 0) wait_flag(mflag, (unsigned)(gb + 1), errflag, lane);      // the meta workgroup's fragments of this block
       }
       __syncthreads();
@@ -488,7 +494,7 @@ __global__ __launch_bounds__(64 * NW, 2) void dstage_kernel(const DsArgs a) {
       //      (operands swapped: the V^T fragments of P V), partial (max, sum, sum p v) -> the meta workgroup ----
       {
         DS_PHASE
-        const int nc = wave >= NW / 2 ? 2 : 1;
+        const int nc = (wave >= NW / 2 && NW + wave - NW / 2 < NH) ? 2 : 1;
 #pragma unroll 1
         for (int hu = 0; hu < nc; ++hu) {
           const int h = hu == 0 ? wave : NW + wave - NW / 2;
@@ -521,10 +527,10 @@ __global__ __launch_bounds__(64 * NW, 2) void dstage_kernel(const DsArgs a) {
           f32x4_t acc[SS_NT][2];
 #pragma unroll
           for (int t = 0; t < SS_NT; ++t) { acc[t][0] = f32x4_t{0.f, 0.f, 0.f, 0.f}; acc[t][1] = acc[t][0]; }
-          bf16x8_t ring[3][2];
+          bf16x8_t ring[URD][2];
           const unsigned char* wcur = wp + (size_t)(G::WS_V1 + h * (2 * KS)) * 1024;
-          ring_fill<2, 3>(ring, wcur, lane);
-          gemm_unit<2, KS, 3, false>(acc, ring, wcur, wcur, smem + G::L_XN, lane);
+          ring_fill<2, URD>(ring, wcur, lane);
+          gemm_unit<2, KS, URD, false>(acc, ring, wcur, wcur, smem + G::L_XN, lane);
           f32x4_t O[2] = {f32x4_t{0.f, 0.f, 0.f, 0.f}, f32x4_t{0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
           for (int p = 0; p < 4; ++p)
@@ -544,11 +550,11 @@ __global__ __launch_bounds__(64 * NW, 2) void dstage_kernel(const DsArgs a) {
       DS_STAMP(3);
       asm volatile("; PHASE_XDIR");
       // ---- x-direction: per head, q1 of the 112 tokens, softmax over the 16 meta keys, P V2; the proj_x operand fragments wait in registers ----
-      const int nx = wave0 < NW / 2 ? 2 : 1;
+      const int nx = wave0 + NW < NH ? 2 : 1;
       u32x4_t AO1[SS_NT];          // the second head of waves 0 .. NW / 2 - 1
       {
         DS_PHASE
-        bf16x8_t ring[3][2];
+        bf16x8_t ring[URD][2];
 #pragma unroll
         for (int hu = 0; hu < 2; ++hu) {
           if (hu < nx) {
@@ -557,13 +563,13 @@ __global__ __launch_bounds__(64 * NW, 2) void dstage_kernel(const DsArgs a) {
             const u32x4_t v20 = __builtin_amdgcn_raw_buffer_load_b128(mr, ((h * G::MF_HEAD + 1) * 64 + lane) * 16, 0, 16);
             const u32x4_t v21 = __builtin_amdgcn_raw_buffer_load_b128(mr, ((h * G::MF_HEAD + 2) * 64 + lane) * 16, 0, 16);
             const unsigned char* wcur = wp + (size_t)(G::WS_Q1 + h * (2 * KS)) * 1024;
-            ring_fill<2, 3>(ring, wcur, lane);
+            ring_fill<2, URD>(ring, wcur, lane);
             const float* bq = vec + G::V_QKV1B + 32 * h + 4 * g;
             const float4 b0 = *reinterpret_cast<const float4*>(bq), b1 = *reinterpret_cast<const float4*>(bq + 16);
             f32x4_t acc[SS_NT][2];
 #pragma unroll
             for (int t = 0; t < SS_NT; ++t) { acc[t][0] = f32x4_t{0.f, 0.f, 0.f, 0.f}; acc[t][1] = acc[t][0]; }
-            gemm_unit<2, KS, 3, true>(acc, ring, wcur, wcur, smem + G::L_XN, lane);
+            gemm_unit<2, KS, URD, true>(acc, ring, wcur, wcur, smem + G::L_XN, lane);
             const f32x4_t z4 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int t = 0; t < SS_NT; ++t) {
@@ -600,19 +606,19 @@ __global__ __launch_bounds__(64 * NW, 2) void dstage_kernel(const DsArgs a) {
       // ---- x += proj_x(attention) + bias; norm2; MLP ----
       {
         DS_PHASE
-        float4 pb[3];
+        float4 pb[CT];
 #pragma unroll
-        for (int ct = 0; ct < 3; ++ct) pb[ct] = *reinterpret_cast<const float4*>(vec + G::V_PXB + 48 * wave + 16 * ct + 4 * g);
-        bf16x8_t ringp[G::PRD][3];
-        const unsigned char* wcur = wp + (size_t)(G::WS_PX + wave * (3 * KS)) * 1024;
-        ring_fill<3, G::PRD>(ringp, wcur, lane);
-        gemm_unit<3, KS, G::PRD, true>(R, ringp, wcur, wcur, smem + G::L_AO, lane);
+        for (int ct = 0; ct < CT; ++ct) pb[ct] = *reinterpret_cast<const float4*>(vec + G::V_PXB + CW * wave + 16 * ct + 4 * g);
+        bf16x8_t ringp[G::PRD][CT];
+        const unsigned char* wcur = wp + (size_t)(G::WS_PX + wave * (CT * KS)) * 1024;
+        ring_fill<CT, G::PRD>(ringp, wcur, lane);
+        gemm_unit<CT, KS, G::PRD, true>(R, ringp, wcur, wcur, smem + G::L_AO, lane);
 #pragma unroll
-        for (int ct = 0; ct < 3; ++ct)
+        for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
           for (int t = 0; t < SS_NT; ++t) { R[t][ct][0] += pb[ct].x; R[t][ct][1] += pb[ct].y; R[t][ct][2] += pb[ct].z; R[t][ct][3] += pb[ct].w; }
         __syncthreads();          // every wave has read the proj_x operand: norm2 may overwrite it
-        ds_layer_norm<NW, SS_NT>(R, vec + G::V_N2W, vec + G::V_N2B, a.eps, smem + G::L_XN, stat, wave, lane);
+        ds_layer_norm<NW, SS_NT, CT>(R, vec + G::V_N2W, vec + G::V_N2B, a.eps, smem + G::L_XN, stat, wave, lane);
       }
       DS_STAMP(5);
       asm volatile("; PHASE_MLP");
@@ -623,8 +629,8 @@ __global__ __launch_bounds__(64 * NW, 2) void dstage_kernel(const DsArgs a) {
       {
         DS_PHASE
 #pragma unroll
-        for (int ct = 0; ct < 3; ++ct) {
-          const float4 b = *reinterpret_cast<const float4*>(vec + G::V_FC2B + 48 * wave + 16 * ct + 4 * g);
+        for (int ct = 0; ct < CT; ++ct) {
+          const float4 b = *reinterpret_cast<const float4*>(vec + G::V_FC2B + CW * wave + 16 * ct + 4 * g);
 #pragma unroll
           for (int t = 0; t < SS_NT; ++t) { R[t][ct][0] += b.x; R[t][ct][1] += b.y; R[t][ct][2] += b.z; R[t][ct][3] += b.w; }
         }
@@ -636,9 +642,9 @@ __global__ __launch_bounds__(64 * NW, 2) void dstage_kernel(const DsArgs a) {
           for (int side = 0; side < 2; ++side) {
             const int tok = side ? s - (112 - GW) : s;
             if ((unsigned)tok < (unsigned)GW) {
-              bf16_t* dst = reinterpret_cast<bf16_t*>(hcur) + ((size_t)(role * 2 + side) * GW + tok) * C + 48 * wave + 4 * g;
+              bf16_t* dst = reinterpret_cast<bf16_t*>(hcur) + ((size_t)(role * 2 + side) * GW + tok) * C + CW * wave + 4 * g;
 #pragma unroll
-              for (int ct = 0; ct < 3; ++ct) {
+              for (int ct = 0; ct < CT; ++ct) {
                 const unsigned long long pk = (unsigned long long)pack_bf2(R[t][ct][0], R[t][ct][1]) | ((unsigned long long)pack_bf2(R[t][ct][2], R[t][ct][3]) << 32);
                 __hip_atomic_store((gu64*)(dst + 16 * ct), pk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
               }
@@ -657,9 +663,9 @@ __global__ __launch_bounds__(64 * NW, 2) void dstage_kernel(const DsArgs a) {
       for (int t = 0; t < SS_NT; ++t) {
         bf16_t* dst = a.x_out + ((size_t)img * G::NIMG + tok0 + 16 * t + li) * C;
 #pragma unroll
-        for (int ct = 0; ct < 3; ++ct) {
+        for (int ct = 0; ct < CT; ++ct) {
           const float f[4] = {R[t][ct][0], R[t][ct][1], R[t][ct][2], R[t][ct][3]};
-          st4(dst + 48 * wave + 16 * ct + 4 * g, f);
+          st4(dst + CW * wave + 16 * ct + 4 * g, f);
         }
       }
     }
@@ -669,10 +675,10 @@ __global__ __launch_bounds__(64 * NW, 2) void dstage_kernel(const DsArgs a) {
 // ---- packing ----------------------------------------------------------------------------------------------------------------------
 struct DPackArgs { const bf16_t* qkv1_w; const bf16_t* qkv2_w; const bf16_t* projx_w; const bf16_t* projc_w; const bf16_t* fc1_w; const bf16_t* fc2_w; uint4* out; };
 
-template <int NW>
+template <int NW, int CT>
 __global__ __launch_bounds__(256) void dstage_pack_kernel(const DPackArgs a) {
-  using G = DG<NW, NW == 4 ? 28 : 56>;
-  constexpr int C = G::C, KS = G::KS, KSC = G::KSC, UF = 2 * KS, PF = 3 * KS, F2 = 3 * KSC;
+  using G = DG<NW, NW == 4 ? 28 : 56, CT>;
+  constexpr int C = G::C, KS = G::KS, KSC = G::KSC, UF = 2 * KS, PF = CT * KS, F2 = CT * KSC, CW = G::CW;
   const int f = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63, g = lane >> 4, i = lane & 15;
   if (f >= G::WS_FRAGS) return;
   const bf16_t* base; int row0, ks, ld = C;
@@ -687,42 +693,47 @@ __global__ __launch_bounds__(256) void dstage_pack_kernel(const DPackArgs a) {
   }
   if (f < G::WS_V1) { const int h = f / UF, r = f - h * UF; ks = r >> 1; base = a.qkv1_w; row0 = 32 * h + 16 * (r & 1); }
   else if (f < G::WS_PX) { const int q = f - G::WS_V1, h = q / UF, r = q - h * UF; ks = r >> 1; base = a.qkv1_w; row0 = 2 * C + 32 * h + 16 * (r & 1); }
-  else if (f < G::WS_FC1) { const int q = f - G::WS_PX, w = q / PF, r = q - w * PF; ks = r / 3; base = a.projx_w; row0 = 48 * w + 16 * (r - ks * 3); }
+  else if (f < G::WS_FC1) { const int q = f - G::WS_PX, w = q / PF, r = q - w * PF; ks = r / CT; base = a.projx_w; row0 = CW * w + 16 * (r - ks * CT); }
   else if (f < G::WS_FC2) { const int q = f - G::WS_FC1, cw = q / UF, r = q - cw * UF; ks = r >> 1; base = a.fc1_w; row0 = 32 * NW * (cw / NW) + 32 * (cw % NW) + 16 * (r & 1); }
-  else if (f < G::WS_K2) { const int q = f - G::WS_FC2, cw = q / F2, r = q - cw * F2, ksl = r / 3; ks = KSC * (cw / NW) + ksl; base = a.fc2_w; ld = 4 * C; row0 = 48 * (cw % NW) + 16 * (r - ksl * 3); }
+  else if (f < G::WS_K2) { const int q = f - G::WS_FC2, cw = q / F2, r = q - cw * F2, ksl = r / CT; ks = KSC * (cw / NW) + ksl; base = a.fc2_w; ld = 4 * C; row0 = CW * (cw % NW) + 16 * (r - ksl * CT); }
   else if (f < G::WS_V2) { const int q = f - G::WS_K2, h = q / UF, r = q - h * UF; ks = r >> 1; base = a.qkv2_w; row0 = C + 32 * h + 16 * (r & 1); }
   else if (f < G::WS_Q2) { const int q = f - G::WS_V2, h = q / UF, r = q - h * UF; ks = r >> 1; base = a.qkv2_w; row0 = 2 * C + 32 * h + 16 * (r & 1); }
   else if (f < G::WS_K1T) { const int q = f - G::WS_Q2, h = q / UF, r = q - h * UF; ks = r >> 1; base = a.qkv2_w; row0 = 32 * h + 16 * (r & 1); }
-  else { const int q = f - G::WS_PC, w = q / PF, r = q - w * PF; ks = r / 3; base = a.projc_w; row0 = 48 * w + 16 * (r - ks * 3); }
+  else { const int q = f - G::WS_PC, w = q / PF, r = q - w * PF; ks = r / CT; base = a.projc_w; row0 = CW * w + 16 * (r - ks * CT); }
   const bf16_t* src = base + (size_t)(row0 + i) * ld + 32 * ks + 4 * g;
   const uint2 lo = *reinterpret_cast<const uint2*>(src), hi = *reinterpret_cast<const uint2*>(src + 16);
   a.out[(size_t)f * 64 + lane] = make_uint4(lo.x, lo.y, hi.x, hi.y);
 }
 
-template <int NW, int GW> static int ds_slots(int B) {
+template <int NW, int GW, int CT> static int ds_slots(int B) {
   int dev = 0, cus = 256;
   (void)hipGetDevice(&dev);
   (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-  int n = (cus * (8 / NW) / DG<NW, GW>::NWG) / 8 * 8;          // whole groups of 8 slots (one per XCD); 8 / NW workgroups per CU
+  int n = (cus * (8 / NW) / DG<NW, GW, CT>::NWG) / 8 * 8;          // whole groups of 8 slots (one per XCD); 8 / NW workgroups per CU
   if (n < 8) n = 8;
   const int need = (B + 7) / 8 * 8;
   return n < need ? n : need;
 }
-template <int NW, int GW> static size_t ds_flag_bytes(int ns) { return (((size_t)ns * DG<NW, GW>::FLAGS_PER_SLOT + 1) * 4 + 1023) / 1024 * 1024; }
-template <int NW, int GW> static size_t ds_workspace(int B) { const int ns = ds_slots<NW, GW>(B); return ds_flag_bytes<NW, GW>(ns) + (size_t)ns * DG<NW, GW>::SLOT_BYTES; }
+template <int NW, int GW, int CT> static size_t ds_flag_bytes(int ns) { return (((size_t)ns * DG<NW, GW, CT>::FLAGS_PER_SLOT + 1) * 4 + 1023) / 1024 * 1024; }
+template <int NW, int GW, int CT> static size_t ds_workspace(int B) { const int ns = ds_slots<NW, GW, CT>(B); return ds_flag_bytes<NW, GW, CT>(ns) + (size_t)ns * DG<NW, GW, CT>::SLOT_BYTES; }
 
-template <int NW, int GW> static int ds_launch(const lmv_dstage_desc* d, const void* x, const void* c, void* x_out, void* c_out, void* workspace, hipStream_t st) {
-  using G = DG<NW, GW>;
+template <int NW, int GW, int CT> static int ds_pack_launch(const DPackArgs& a, hipStream_t st) {
+  hipLaunchKernelGGL((dstage_pack_kernel<NW, CT>), dim3((DG<NW, GW, CT>::WS_FRAGS + 3) / 4), dim3(256), 0, st, a);
+  return 0;
+}
+
+template <int NW, int GW, int CT> static int ds_launch(const lmv_dstage_desc* d, const void* x, const void* c, void* x_out, void* c_out, void* workspace, hipStream_t st) {
+  using G = DG<NW, GW, CT>;
   static std::atomic<unsigned long long> attr_done{0};
   int dev = 0;
   (void)hipGetDevice(&dev);
   const unsigned long long bit = 1ull << (dev & 63);
   if (!(attr_done.load(std::memory_order_acquire) & bit)) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(dstage_kernel<NW, GW>), hipFuncAttributeMaxDynamicSharedMemorySize, G::L_TOTAL) != hipSuccess) LMV_FAIL(LMV_ERR_LAUNCH, "dstage_fwd: cannot reserve LDS");
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(dstage_kernel<NW, GW, CT>), hipFuncAttributeMaxDynamicSharedMemorySize, G::L_TOTAL) != hipSuccess) LMV_FAIL(LMV_ERR_LAUNCH, "dstage_fwd: cannot reserve LDS");
     attr_done.fetch_or(bit, std::memory_order_release);
   }
-  const int ns = ds_slots<NW, GW>(d->B);
-  const size_t flags = ds_flag_bytes<NW, GW>(ns);
+  const int ns = ds_slots<NW, GW, CT>(d->B);
+  const size_t flags = ds_flag_bytes<NW, GW, CT>(ns);
   unsigned char* ws = (unsigned char*)workspace;
   if (hipMemsetAsync(ws, 0, flags, st) != hipSuccess) LMV_FAIL(LMV_ERR_LAUNCH, "dstage_fwd: flag reset failed");
   DsArgs a{};
@@ -733,7 +744,7 @@ template <int NW, int GW> static int ds_launch(const lmv_dstage_desc* d, const v
   a.sx = (float)(log((double)d->M) / log(N) / sqrt((double)d->C) * lg2e);      // models/lemevit.py:255: log_N(M) C^-1/2
   a.sc = (float)(1.0 / sqrt((double)d->C) * lg2e);                             // :256
   a.timing = (unsigned long long*)d->timing; a.timing_block = d->timing_block;
-  hipLaunchKernelGGL((dstage_kernel<NW, GW>), dim3(ns * G::NWG), dim3(64 * NW), G::L_TOTAL, st, a);
+  hipLaunchKernelGGL((dstage_kernel<NW, GW, CT>), dim3(ns * G::NWG), dim3(64 * NW), G::L_TOTAL, st, a);
   LMV_CHECK_LAUNCH("dstage_fwd");
   return LMV_OK;
 }
@@ -741,28 +752,35 @@ template <int NW, int GW> static int ds_launch(const lmv_dstage_desc* d, const v
 }  // namespace
 
 // ---- C ABI --------------------------------------------------------------------------------------------------------------------------
-static int ds_variant(int C, int heads, int hidden, int H, int W, int M) {      // waves per workgroup: 4: stage 2 of LeMeViT-Base (C = 192, 28 x 28), 2: stage 1 (C = 96, 56 x 56); 0: not supported
+// the four instances: 10 NW + CT
+#define DS_DISPATCH(code, EXPR, DFLT)                                                        \
+  ((code) == 43 ? EXPR(4, 28, 3) : (code) == 23 ? EXPR(2, 56, 3) : (code) == 42 ? EXPR(4, 28, 2) : (code) == 22 ? EXPR(2, 56, 2) : (DFLT))
+static int ds_code_of_c(int C) { return C == 192 ? 43 : C == 96 ? 23 : C == 128 ? 42 : C == 64 ? 22 : 0; }
+static int ds_variant(int C, int heads, int hidden, int H, int W, int M) {      // stages 2 / 1 of LeMeViT-Base and -Small (C = 192 at 28 x 28, C = 96 at 56 x 56), of LeMeViT-Tiny (128, 64); 0: not supported
   if (M != DS_M || H != W || heads != C / 32 || hidden != 4 * C) return 0;
-  if (C == 192 && H == 28) return 4;
-  if (C == 96 && H == 56) return 2;
-  return 0;
+  const int code = ds_code_of_c(C);
+  if (!code) return 0;
+  return H == (code / 10 == 4 ? 28 : 56) ? code : 0;
 }
 int lmv_dstage_supported(int C, int heads, int hidden, int H, int W, int M, int dtype) { return dtype == LMV_BF16 && ds_variant(C, heads, hidden, H, W, M) != 0; }
-size_t lmv_dstage_wpk_bytes(int C, int hidden) { (void)hidden; return C == 192 ? (size_t)DG<4, 28>::WS_FRAGS * 1024 : C == 96 ? (size_t)DG<2, 56>::WS_FRAGS * 1024 : 0; }
+#define DS_WPK(NW, GW, CT) ((size_t)DG<NW, GW, CT>::WS_FRAGS * 1024)
+size_t lmv_dstage_wpk_bytes(int C, int hidden) { (void)hidden; const int code = ds_code_of_c(C); return DS_DISPATCH(code, DS_WPK, (size_t)0); }
 size_t lmv_dstage_vec_floats(int C, int hidden) { (void)hidden; return (size_t)27 * C; }
-size_t lmv_dstage_workspace_bytes(int B, int C) { return C == 192 ? ds_workspace<4, 28>(B) : C == 96 ? ds_workspace<2, 56>(B) : 0; }
+#define DS_WS(NW, GW, CT) ds_workspace<NW, GW, CT>(B)
+size_t lmv_dstage_workspace_bytes(int B, int C) { const int code = ds_code_of_c(C); return DS_DISPATCH(code, DS_WS, (size_t)0); }
 
 int lmv_dstage_pack(const lmv_dstage_block_params* p, void* wpk_out, float* vec_out, void* stream) {
   if (!p || !wpk_out || !vec_out) LMV_FAIL(LMV_ERR_SHAPE, "dstage_pack: null argument");
-  if (!((p->C == 192 || p->C == 96) && p->heads == p->C / 32 && p->hidden == 4 * p->C))
+  const int code = ds_code_of_c(p->C);
+  if (!(code && p->heads == p->C / 32 && p->hidden == 4 * p->C))
     LMV_FAIL(LMV_ERR_DTYPE, "dstage_pack: C = %d / heads = %d / hidden = %d is not a supported stage", p->C, p->heads, p->hidden);
   const void* ptrs[] = {p->qkv1_w, p->qkv2_w, p->projx_w, p->projc_w, p->fc1_w, p->fc2_w, p->n1_w, p->n1_b, p->qkv1_b, p->qkv2_b, p->projx_b, p->projc_b, p->n2_w, p->n2_b, p->fc1_b, p->fc2_b,
                         p->pos_w, p->pos_b, wpk_out, vec_out};
   for (const void* q : ptrs) if (!q || !lmv_aligned16(q)) LMV_FAIL(LMV_ERR_SHAPE, "dstage_pack: null or misaligned pointer");
   hipStream_t st = (hipStream_t)stream;
   DPackArgs a{(const bf16_t*)p->qkv1_w, (const bf16_t*)p->qkv2_w, (const bf16_t*)p->projx_w, (const bf16_t*)p->projc_w, (const bf16_t*)p->fc1_w, (const bf16_t*)p->fc2_w, (uint4*)wpk_out};
-  if (p->C == 192) hipLaunchKernelGGL(dstage_pack_kernel<4>, dim3((DG<4, 28>::WS_FRAGS + 3) / 4), dim3(256), 0, st, a);
-  else hipLaunchKernelGGL(dstage_pack_kernel<2>, dim3((DG<2, 56>::WS_FRAGS + 3) / 4), dim3(256), 0, st, a);
+#define DS_PACK(NW, GW, CT) ds_pack_launch<NW, GW, CT>(a, st)
+  (void)DS_DISPATCH(code, DS_PACK, 0);
   LMV_CHECK_LAUNCH("dstage_pack");
   const int C = p->C;
   const struct { const float* src; int off, n; } v[] = {{p->n1_w, 0, C}, {p->n1_b, C, C}, {p->qkv1_b, 2 * C, 3 * C}, {p->qkv2_b, 5 * C, 3 * C}, {p->projx_b, 8 * C, C}, {p->projc_b, 9 * C, C},
@@ -782,5 +800,6 @@ int lmv_dstage_fwd(const lmv_dstage_desc* d, const void* x, const void* c, void*
   const void* ptrs[] = {x, c, x_out, c_out, workspace, d->wpk, d->vec};
   for (const void* q : ptrs) if (!lmv_aligned16(q)) LMV_FAIL(LMV_ERR_SHAPE, "dstage_fwd: pointers must be 16-byte aligned");
   if (workspace_bytes < lmv_dstage_workspace_bytes(d->B, d->C)) LMV_FAIL(LMV_ERR_WORKSPACE, "dstage_fwd: workspace too small");
-  return nw == 4 ? ds_launch<4, 28>(d, x, c, x_out, c_out, workspace, (hipStream_t)stream) : ds_launch<2, 56>(d, x, c, x_out, c_out, workspace, (hipStream_t)stream);
+#define DS_LAUNCH(NW, GW, CT) ds_launch<NW, GW, CT>(d, x, c, x_out, c_out, workspace, (hipStream_t)stream)
+  return DS_DISPATCH(nw, DS_LAUNCH, LMV_ERR_DTYPE);
 }

@@ -63,7 +63,7 @@ def _rel(a, ref):
     return float(np.abs(a - ref).max() / max(np.abs(ref).max(), 1e-30))
 
 
-@pytest.mark.parametrize("C,G", [(192, 28), (96, 56)])          # stage 2 / stage 1 of LeMeViT-Base (4 / 2 waves per workgroup)
+@pytest.mark.parametrize("C,G", [(192, 28), (96, 56), (128, 28), (64, 56)])          # stages 2 / 1 of LeMeViT-Base (4 / 2 waves x 48 channels), of LeMeViT-Tiny (x 32 channels)
 @pytest.mark.parametrize("nblocks,B", [(1, 1), (1, 3), (2, 2), (4, 9), (2, 70)])
 def test_dstage_vs_oracle(nblocks, B, C, G):
     """Full tensors against the float64 oracle: 1e-2 of max-abs per tensor (bf16 operands at every contraction, fp16 P / V, the GELU polynomial, the
@@ -83,7 +83,7 @@ def test_dstage_vs_oracle(nblocks, B, C, G):
     assert ex <= 1e-2 and ec <= 1e-2, (ex, ec)
 
 
-@pytest.mark.parametrize("C,G", [(192, 28), (96, 56)])
+@pytest.mark.parametrize("C,G", [(192, 28), (96, 56), (128, 28), (64, 56)])
 def test_dstage_large_residual_stream(C, G):
     """A residual stream far beyond the fp16 range: nothing on the residual path may go through fp16."""
     from lemevit_amd import ops
@@ -97,7 +97,7 @@ def test_dstage_large_residual_stream(C, G):
     assert ex <= 1e-2 and ec <= 1e-2, (ex, ec)
 
 
-@pytest.mark.parametrize("C,G,nblocks,B", [(192, 28, 4, 128), (96, 56, 4, 128)])
+@pytest.mark.parametrize("C,G,nblocks,B", [(192, 28, 4, 128), (96, 56, 4, 128), (128, 28, 2, 256), (64, 56, 2, 256)])
 def test_dstage_vs_per_launch_schedule_full_size(C, G, nblocks, B):
     """Stage 2 of LeMeViT-Base at config 3 (B = 128, 4 blocks) against the per-launch inference schedule (lmv_block_fwd) of the same weights; two runs
     of the persistent launch agree bit for bit."""
@@ -126,7 +126,7 @@ def test_dstage_vs_per_launch_schedule_full_size(C, G, nblocks, B):
     assert ex <= 3e-2 and ec <= 3e-2, (ex, ec)
 
 
-@pytest.mark.parametrize("C,G,nblocks,B", [(192, 28, 4, 128), (96, 56, 4, 128)])
+@pytest.mark.parametrize("C,G,nblocks,B", [(192, 28, 4, 128), (96, 56, 4, 128), (128, 28, 2, 256), (64, 56, 2, 256)])
 def test_dstage_handoffs_under_uneven_load(C, G, nblocks, B):
     """MI355X_MICROARCH.md, "Workgroup dispatch, XCD placement & inter-workgroup visibility": every in-launch hand-off under UNEVEN load, every word
     checked: (a) idle chip, (b) another stream streaming 1.5 GB through HBM; outputs bit-identical."""

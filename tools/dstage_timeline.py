@@ -1,6 +1,6 @@
 """Timeline of one block of the persistent D-stage kernel (csrc/dstage.hip): s_memtime stamps of every wave of every workgroup at the phase
 boundaries (lmv_dstage_desc.timing), image workgroups and meta workgroups apart, plus the launch time next to the per-launch schedule.
-usage: python tools/dstage_timeline.py [block=1] [B=128] [nblocks=4] [C=192 | 96]"""
+usage: python tools/dstage_timeline.py [block=1] [B=128] [nblocks=4] [C=192 | 96 | 128 | 64]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -14,7 +14,7 @@ B = int(sys.argv[2]) if len(sys.argv) > 2 else 128
 nblocks = int(sys.argv[3]) if len(sys.argv) > 3 else 4
 dev = "cuda:0"
 C = int(sys.argv[4]) if len(sys.argv) > 4 else 192
-G, NWV, KWG, MAXSLOTS = (28, 4, 7, 64) if C == 192 else (56, 2, 28, 32)
+G, NWV, KWG, MAXSLOTS = (28, 4, 7, 64) if C in (192, 128) else (56, 2, 28, 32)
 HID = 4 * C
 g = torch.Generator(device="cpu").manual_seed(0)
 def rnd(*shape, s=1.0): return (torch.rand(*shape, generator=g) * 2 - 1) * s

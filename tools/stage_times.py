@@ -38,3 +38,18 @@ with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
                     a, b = blk.forward_tokens(a, b, res, res, masks=None)
             return a, b
         print(f"  stage {i}: {len(stage)} x {stage[0].kind} blocks, C = {C}, {res} x {res}: {timed(run):.3f} ms")
+    # stem and stage transitions (models/lemevit.py:698-728) on synthetic feature maps of their input shapes
+    res, cin = 224, 3
+    for i, ds in enumerate(m.downsample_layers):
+        if isinstance(ds, torch.nn.Identity):
+            continue
+        if i == 0:
+            inp = x
+        else:
+            Cp = m.stages[i - 1][0].norm1.weight.shape[0]  # (Base geometry below; other variants: the same resolutions)
+            r = 56 if i <= 2 else (28 if i == 3 else 14)
+            inp = torch.randn(B, r, r, Cp, device=dev).bfloat16().permute(0, 3, 1, 2)
+        def rund():
+            y = m._run_downsample(ds, inp)
+            return m._to_tokens(y, torch.bfloat16)
+        print(f"  downsample {i} (input {tuple(inp.shape)}): {timed(rund):.3f} ms")

@@ -61,7 +61,7 @@ def parse():
     ap.add_argument("--no-issue-probe", action="store_true", help="skip the 5 synchronised single steps that measure host issue time (profiling runs: "
                     "they would sit in the 'last steps' window of a kernel trace)")
     ap.add_argument("--no-forward-probe", action="store_true", help="train mode: skip the forward-only pass timed after the train region (forward_* keys)")
-    ap.add_argument("--infer-parts", type=int, default=4, help="forward-only passes (--mode infer and the forward_* probe): run the batch as this many "
+    ap.add_argument("--infer-parts", type=int, default=0, help="forward-only passes (--mode infer and the forward_* probe): run the batch as this many "
                     "concurrent sub-batches inside the one hipGraph (lemevit_amd.graph.split_forward); 1 = the whole batch on one stream")
     ap.add_argument("--graph", type=int, default=-1, help="(-1 = auto: eager for train, graph replay for infer)  1 = capture the step into a hipGraph (lemevit_amd.graph.GraphedStep) and replay it; default 0 = "
                     "eager launches, which are faster here: the weight-gradient GEMMs overlap the dX chain on a side stream, and the "
@@ -225,12 +225,46 @@ def cpu_baseline_protocol(out_path: str):
     print(json.dumps(res))
 
 
+def pick_infer_parts(model, x, use_graph, candidates=(1, 2, 4)):
+    """--infer-parts 0 (default): the forward-only schedule is chosen BEFORE the timed region -- the batch as 1, 2 or 4 concurrent sub-batches
+    (lemevit_amd.graph.split_forward), each tried for a few passes; persistent stage kernels fill the chip on their own (one stream wins where
+    they cover most of the pass: LeMeViT-Tiny), per-launch stages overlap their ramps and tails across sub-batches."""
+    from lemevit_amd.graph import split_forward, try_graphed
+    best, best_ms, table = candidates[0], float("inf"), {}
+    for parts in candidates:
+        outs = []
+
+        def fstep(parts=parts, outs=outs):
+            with torch.no_grad(), torch.autocast("cuda", torch.bfloat16):
+                split_forward(model, x, parts, outs)
+
+        step = fstep
+        if use_graph:
+            step, why = try_graphed(fstep, warmup=3)
+        for _ in range(3):
+            step()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(6):
+            step()
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / 6
+        table[parts] = round(ms, 3)
+        if ms < best_ms:
+            best, best_ms = parts, ms
+        del step, outs
+    return best, table
+
+
 def main():
     args = parse()
     if args.cpu_baseline_protocol:
         return cpu_baseline_protocol(args.cpu_baseline_protocol)
     if args.graph < 0:
         args.graph = 0 if args.mode == "train" else 1
+    parts_table = None
     # stdout carries exactly ONE line, the JSON record: RCCL prints a version banner through C stdio on stdout (flushed at
     # exit, i.e. AFTER anything printed here), MIOpen / hipBLASLt may log there too.  Everything else goes to stderr.
     sys.stdout.flush()
@@ -302,6 +336,8 @@ def main():
     else:
         from lemevit_amd.graph import split_forward
         infer_outs = []
+        if args.infer_parts <= 0:
+            args.infer_parts, parts_table = pick_infer_parts(model, x, bool(args.graph) and world == 1)
 
         def step():
             with torch.no_grad(), torch.autocast("cuda", torch.bfloat16):
@@ -367,6 +403,8 @@ def main():
 
         from lemevit_amd.graph import split_forward
         fwd_outs = []
+        if args.infer_parts <= 0:
+            args.infer_parts, parts_table = pick_infer_parts(model, x, True)
 
         def fwd_step():
             with torch.no_grad(), torch.autocast("cuda", torch.bfloat16):
@@ -450,6 +488,8 @@ def main():
             line["forward_frac_of_bf16_peak"] = None if gflop is None else round(fv * gflop / 1e3 / (PEAK_BF16_TFLOPS * world), 4)
             line["forward_note"] = (f"forward pass of the same model / batch timed after the train region: eval mode, no_grad, bf16 autocast, {fwd_note}, "
                                     f"{fwd_iters} iterations, fused inference schedule")
+        if parts_table is not None:
+            line["forward_schedule_probe_ms"] = {f"{k}_sub_batches": v for k, v in parts_table.items()}      # --infer-parts 0: chosen before the timed region
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args.model, args.img, args.mode)
         os.write(json_fd, (json.dumps(line) + "\n").encode())

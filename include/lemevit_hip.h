@@ -428,7 +428,7 @@ typedef struct lmv_sstage_desc {
   int32_t B, H, W, M, C, heads, hidden, nblocks, dtype;
   float eps;                                       /* LayerNorm eps of norm1 / norm2 (1e-6) */
   const void* wpk; const float* vec;               /* nblocks packed blocks (lmv_sstage_pack) */
-  void* timing; int32_t timing_block, _pad;        /* optional (NULL): uint64 s_memtime stamps [workgroup][8 waves][24] of block `timing_block` (tools/sstage_timeline.py) */
+  void* timing; int32_t timing_block, kind;        /* optional (NULL): uint64 s_memtime stamps [workgroup][8 waves][24] of block `timing_block` (tools/sstage_timeline.py); kind: 0 (lmv_dstage_fwd: 0 = "D" blocks, 1 = "C" blocks) */
 } lmv_sstage_desc;
 int lmv_sstage_supported(int C, int heads, int hidden, int H, int W, int M, int dtype);
 size_t lmv_sstage_wpk_bytes(int C, int hidden);
@@ -461,7 +461,10 @@ typedef struct lmv_dstage_block_params {
   const float* n2_w; const float* n2_b; const float* fc1_b; const float* fc2_b;
   const float* pos_w; const float* pos_b;
 } lmv_dstage_block_params;
-typedef lmv_sstage_desc lmv_dstage_desc;          /* same fields; timing: uint64 stamps [workgroup][waves][16] */
+typedef lmv_sstage_desc lmv_dstage_desc;          /* same fields; timing: uint64 stamps [workgroup][waves][16]; kind = 1: a run of "C" blocks (stage 0: LeMeBlock.forward_with_c,
+                                                   * models/lemevit.py:584-612 -- only the meta tokens change: c += proj(softmax(q(n1 c) k(n1 x')^T / sqrt(32)) v(n1 x')), c += mlp(n2 c) with x' = x + dwconv(x);
+                                                   * x passes through, x_out is not written and may be NULL-equivalent = x).  Packed as a D block with qkv1 = [0 | attn.kv], qkv2 = [attn.q | 0 | 0],
+                                                   * proj_c = attn.proj, proj_x unused (lemevit_amd/ops.py::cstage_pack) */
 int lmv_dstage_supported(int C, int heads, int hidden, int H, int W, int M, int dtype);
 size_t lmv_dstage_wpk_bytes(int C, int hidden);
 size_t lmv_dstage_vec_floats(int C, int hidden);

@@ -70,7 +70,7 @@ class SStageBlockParams(C.Structure):
 
 
 class SStageDesc(C.Structure):
-    _fields_ = ([(n, C.c_int32) for n in ("B", "H", "W", "M", "C", "heads", "hidden", "nblocks", "dtype")] + [("eps", C.c_float), ("wpk", C.c_void_p), ("vec", C.c_void_p), ("timing", C.c_void_p), ("timing_block", C.c_int32), ("_pad", C.c_int32)])
+    _fields_ = ([(n, C.c_int32) for n in ("B", "H", "W", "M", "C", "heads", "hidden", "nblocks", "dtype")] + [("eps", C.c_float), ("wpk", C.c_void_p), ("vec", C.c_void_p), ("timing", C.c_void_p), ("timing_block", C.c_int32), ("kind", C.c_int32)])
 
 
 class DStageBlockParams(C.Structure):

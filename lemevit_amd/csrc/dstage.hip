@@ -34,6 +34,7 @@ template <int NW, int GW, int CTILES> struct DG {
   static constexpr int URD = KS % 3 == 0 ? 3 : (KS % 4 == 0 ? 4 : 3);              // ring depth of the 2-tile units (q1, v1, k2 / v2 / q2, fc1)
   static_assert((CT * NW) % 2 == 0, "whole heads");
   static constexpr int ROWS = 112 / GW, KWG = GW / ROWS, NIMG = GW * GW, NWG = KWG + 1;
+  static constexpr int CSUB = KWG % 2 == 0 ? 2 : 1, NWG_C = KWG / CSUB + 1;      // "C" blocks: row groups per image workgroup, workgroups per slot
   static_assert(ROWS * GW == 112 && KWG * ROWS == GW, "an image workgroup is whole grid rows");
   // packed weights of a block, 1 KB fragments (stage_common.h / sstage.hip: lane (g, i) holds W[row0 + i][32 ks + 16 (j >> 2) + 4 g + (j & 3)])
   static constexpr int WS_Q1 = 0;                                   // [head][ks][n 2]: rows 32 h + 16 n of qkv1.weight
@@ -166,7 +167,7 @@ __device__ __forceinline__ void ds_mlp(f32x4_t (&R)[NTT][G::CT], const unsigned 
   }
 }
 
-template <int NW, int GW, int CT>
+template <int NW, int GW, int CT, int KIND>          // KIND: 0 "D" blocks, 1 "C" blocks
 __global__ __launch_bounds__(64 * NW, 2) void dstage_kernel(const DsArgs a) {
   using G = DG<NW, GW, CT>;
   constexpr int C = G::C, NH = G::NH, KS = G::KS, KWG = G::KWG, ROWS = G::ROWS, CW = G::CW, URD = G::URD;
@@ -179,7 +180,10 @@ __global__ __launch_bounds__(64 * NW, 2) void dstage_kernel(const DsArgs a) {
   const int g = lane >> 4, li = lane & 15; (void)g; (void)li; (void)wave;
   // the workgroups of an image slot share an XCD under the round-robin dispatch (a speed matter only)
   const int xcd = blockIdx.x & 7, jj = blockIdx.x >> 3;
-  const int slot = (jj / G::NWG) * 8 + xcd, role = jj % G::NWG;          // role < KWG: image rows [role ROWS, (role + 1) ROWS); role == KWG: the meta tokens
+  // "D" blocks: KWG image workgroups + the meta workgroup per slot; "C" blocks (the image side of a block is a third of the work and every block starts from x_in): an image
+  // workgroup takes SUB = 2 row groups in turn, KWG / 2 + 1 workgroups per slot, twice the slots in flight
+  constexpr int sub_n = KIND ? G::CSUB : 1, nimgwg = KWG / sub_n, nwg = nimgwg + 1;
+  const int slot = (jj / nwg) * 8 + xcd, rolep = jj % nwg;               // rolep < nimgwg: image rows; rolep == nimgwg: the meta tokens
   if (slot >= a.nslots) return;
   unsigned* const fl = a.flags + (size_t)slot * G::FLAGS_PER_SLOT;
   unsigned* const haloflag = fl, * const partflag = fl + KWG, * const mflag = fl + 2 * KWG;
@@ -191,7 +195,7 @@ __global__ __launch_bounds__(64 * NW, 2) void dstage_kernel(const DsArgs a) {
   int round = 0;
 #pragma unroll 1
   for (int img = slot; img < a.B; img += a.nslots, ++round) {
-    if (role == KWG) {
+    if (rolep == nimgwg) {
       asm volatile("; PHASE_META");
       // =================================== the meta workgroup: the 16 meta tokens of image `img` ===================================
       f32x4_t Rc[1][CT];
@@ -222,6 +226,7 @@ __global__ __launch_bounds__(64 * NW, 2) void dstage_kernel(const DsArgs a) {
 #pragma unroll 1
           for (int u = wave; u < 3 * NH; u += NW) {
             const int h = u / 3, typ = u - 3 * h;                 // 0: k2, 1: v2, 2: q2
+            if (KIND && typ != 2) continue;                     // "C" blocks: no x-direction
             const unsigned char* wcur = wp + (size_t)((typ == 0 ? G::WS_K2 : typ == 1 ? G::WS_V2 : G::WS_Q2) + h * (2 * KS)) * 1024;
             ring_fill<2, URD>(ring, wcur, lane);
             f32x4_t acc[1][2] = {{f32x4_t{0.f, 0.f, 0.f, 0.f}, f32x4_t{0.f, 0.f, 0.f, 0.f}}};
@@ -367,23 +372,25 @@ __global__ __launch_bounds__(64 * NW, 2) void dstage_kernel(const DsArgs a) {
 
     asm volatile("; PHASE_IMG");
     // =================================== an image workgroup: 112 image tokens (ROWS grid rows) of image `img` ===================================
-    const int tok0 = role * 112;
     f32x4_t R[SS_NT][CT];
-    {
+    auto load_rows = [&](int first_token) {
       DS_PHASE
 #pragma unroll
       for (int t = 0; t < SS_NT; ++t) {
-        const bf16_t* src = a.x_in + ((size_t)img * G::NIMG + tok0 + 16 * t + li) * C;
+        const bf16_t* src = a.x_in + ((size_t)img * G::NIMG + first_token + 16 * t + li) * C;
 #pragma unroll
         for (int ct = 0; ct < CT; ++ct) { float f[4]; ld4(src + CW * wave + 16 * ct + 4 * g, f); R[t][ct] = f32x4_t{f[0], f[1], f[2], f[3]}; }
       }
-    }
+    };
+    if constexpr (KIND == 0) load_rows(rolep * 112);
 #pragma unroll 1
-    for (int blk = 0; blk < a.nblocks; ++blk) {
+    for (int it = 0; it < a.nblocks * sub_n; ++it) {
+      const int blk = sub_n == 1 ? it : it / sub_n, role = sub_n == 1 ? rolep : rolep * sub_n + (it - blk * sub_n), tok0 = role * 112;      // role: the row group [role ROWS, (role + 1) ROWS)
       const int gb = round * a.nblocks + blk;
       const int lane = lane0, wave = wave0;      // (stamps only)
       const unsigned char* const wp = reinterpret_cast<const unsigned char*>(a.wpk) + (size_t)blk * G::WS_FRAGS * 1024;
       const float* const vec = a.vec + (size_t)blk * G::V_FLOATS;
+      if constexpr (KIND != 0) load_rows(tok0);          // "C" blocks return x as it came: the position embedding of a block only feeds its norm1, every block (and row group) starts from x_in
       DS_STAMP(0);
       asm volatile("; PHASE_DW");
       // ---- x += dwconv3x3(x) + bias: per channel tile a wave-private bf16 image [ROWS + 2][GW + 2] of its 16 channels, zero pads, rows across the cuts from the peers ----
@@ -391,7 +398,7 @@ __global__ __launch_bounds__(64 * NW, 2) void dstage_kernel(const DsArgs a) {
         DS_PHASE
         unsigned char* const stg = smem + wave * G::STG_WAVE;
         const unsigned char* const hprev = halo + (size_t)((gb + 1) & 1) * (G::HALO_BYTES / 2);      // the rows published at the end of block gb - 1
-        if (gb > 0) {
+        if (gb > 0 && !KIND) {
           // (block 0 of a later image reads its halo from x_in, but still waits: a workgroup must not run two blocks ahead of a neighbour that reads its rows)
           if (role > 0) wait_flag(haloflag + role - 1, (unsigned)gb, errflag, lane);
           if (role + 1 < KWG) wait_flag(haloflag + role + 1, (unsigned)gb, errflag, lane);
@@ -431,7 +438,7 @@ __global__ __launch_bounds__(64 * NW, 2) void dstage_kernel(const DsArgs a) {
               u32x4_t hv = {0u, 0u, 0u, 0u};
               if (inside) {
                 u32x4_t v;
-                if (blk == 0) v = *reinterpret_cast<const u32x4_t*>(a.x_in + ((size_t)img * G::NIMG + (side ? tok0 + 112 : tok0 - GW) + tok) * C + c0 + 8 * q);
+                if (blk == 0 || KIND) v = *reinterpret_cast<const u32x4_t*>(a.x_in + ((size_t)img * G::NIMG + (side ? tok0 + 112 : tok0 - GW) + tok) * C + c0 + 8 * q);
                 else {
                   const __amdgpu_buffer_rsrc_t hr = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(hprev), 0, (int)(G::HALO_BYTES / 2), 0x00020000);
                   v = __builtin_amdgcn_raw_buffer_load_b128(hr, (((nb * 2 + (side ? 0 : 1)) * GW + tok) * C + c0 + 8 * q) * 2, 0, 16);
@@ -548,6 +555,12 @@ __global__ __launch_bounds__(64 * NW, 2) void dstage_kernel(const DsArgs a) {
         }
       }
       DS_STAMP(3);
+      if constexpr (KIND != 0) {          // "C" blocks end here for the image tokens
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) __hip_atomic_store((gu32*)(partflag + role), (unsigned)(gb + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        continue;
+      }
       asm volatile("; PHASE_XDIR");
       // ---- x-direction: per head, q1 of the 112 tokens, softmax over the 16 meta keys, P V2; the proj_x operand fragments wait in registers ----
       const int nx = wave0 + NW < NH ? 2 : 1;
@@ -657,11 +670,12 @@ __global__ __launch_bounds__(64 * NW, 2) void dstage_kernel(const DsArgs a) {
       if (tid == 0) __hip_atomic_store((gu32*)(haloflag + role), (unsigned)(gb + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       DS_STAMP(7);
     }
+    if constexpr (KIND == 0)
     {
       DS_PHASE
 #pragma unroll
       for (int t = 0; t < SS_NT; ++t) {
-        bf16_t* dst = a.x_out + ((size_t)img * G::NIMG + tok0 + 16 * t + li) * C;
+        bf16_t* dst = a.x_out + ((size_t)img * G::NIMG + rolep * 112 + 16 * t + li) * C;          // ("D" blocks: role = rolep)
 #pragma unroll
         for (int ct = 0; ct < CT; ++ct) {
           const float f[4] = {R[t][ct][0], R[t][ct][1], R[t][ct][2], R[t][ct][3]};
@@ -705,34 +719,37 @@ __global__ __launch_bounds__(256) void dstage_pack_kernel(const DPackArgs a) {
   a.out[(size_t)f * 64 + lane] = make_uint4(lo.x, lo.y, hi.x, hi.y);
 }
 
-template <int NW, int GW, int CT> static int ds_slots(int B) {
+template <int NW, int GW, int CT> static int ds_slots(int B, int kind) {
   int dev = 0, cus = 256;
   (void)hipGetDevice(&dev);
   (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-  int n = (cus * (8 / NW) / DG<NW, GW, CT>::NWG) / 8 * 8;          // whole groups of 8 slots (one per XCD); 8 / NW workgroups per CU
+  int n = (cus * (8 / NW) / (kind ? DG<NW, GW, CT>::NWG_C : DG<NW, GW, CT>::NWG)) / 8 * 8;          // whole groups of 8 slots (one per XCD); 8 / NW workgroups per CU
   if (n < 8) n = 8;
   const int need = (B + 7) / 8 * 8;
   return n < need ? n : need;
 }
 template <int NW, int GW, int CT> static size_t ds_flag_bytes(int ns) { return (((size_t)ns * DG<NW, GW, CT>::FLAGS_PER_SLOT + 1) * 4 + 1023) / 1024 * 1024; }
-template <int NW, int GW, int CT> static size_t ds_workspace(int B) { const int ns = ds_slots<NW, GW, CT>(B); return ds_flag_bytes<NW, GW, CT>(ns) + (size_t)ns * DG<NW, GW, CT>::SLOT_BYTES; }
+template <int NW, int GW, int CT> static size_t ds_workspace(int B) {          // (either kind)
+  const int n0 = ds_slots<NW, GW, CT>(B, 0), n1 = ds_slots<NW, GW, CT>(B, 1), ns = n0 > n1 ? n0 : n1;
+  return ds_flag_bytes<NW, GW, CT>(ns) + (size_t)ns * DG<NW, GW, CT>::SLOT_BYTES;
+}
 
 template <int NW, int GW, int CT> static int ds_pack_launch(const DPackArgs& a, hipStream_t st) {
   hipLaunchKernelGGL((dstage_pack_kernel<NW, CT>), dim3((DG<NW, GW, CT>::WS_FRAGS + 3) / 4), dim3(256), 0, st, a);
   return 0;
 }
 
-template <int NW, int GW, int CT> static int ds_launch(const lmv_dstage_desc* d, const void* x, const void* c, void* x_out, void* c_out, void* workspace, hipStream_t st) {
+template <int NW, int GW, int CT, int KIND> static int ds_launch_kind(const lmv_dstage_desc* d, const void* x, const void* c, void* x_out, void* c_out, void* workspace, hipStream_t st) {
   using G = DG<NW, GW, CT>;
   static std::atomic<unsigned long long> attr_done{0};
   int dev = 0;
   (void)hipGetDevice(&dev);
   const unsigned long long bit = 1ull << (dev & 63);
   if (!(attr_done.load(std::memory_order_acquire) & bit)) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(dstage_kernel<NW, GW, CT>), hipFuncAttributeMaxDynamicSharedMemorySize, G::L_TOTAL) != hipSuccess) LMV_FAIL(LMV_ERR_LAUNCH, "dstage_fwd: cannot reserve LDS");
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(dstage_kernel<NW, GW, CT, KIND>), hipFuncAttributeMaxDynamicSharedMemorySize, G::L_TOTAL) != hipSuccess) LMV_FAIL(LMV_ERR_LAUNCH, "dstage_fwd: cannot reserve LDS");
     attr_done.fetch_or(bit, std::memory_order_release);
   }
-  const int ns = ds_slots<NW, GW, CT>(d->B);
+  const int ns = ds_slots<NW, GW, CT>(d->B, KIND);
   const size_t flags = ds_flag_bytes<NW, GW, CT>(ns);
   unsigned char* ws = (unsigned char*)workspace;
   if (hipMemsetAsync(ws, 0, flags, st) != hipSuccess) LMV_FAIL(LMV_ERR_LAUNCH, "dstage_fwd: flag reset failed");
@@ -742,11 +759,17 @@ template <int NW, int GW, int CT> static int ds_launch(const lmv_dstage_desc* d,
   a.B = d->B; a.nblocks = d->nblocks; a.nslots = ns; a.eps = d->eps;
   const double N = (double)d->H * d->W, lg2e = 1.4426950408889634;
   a.sx = (float)(log((double)d->M) / log(N) / sqrt((double)d->C) * lg2e);      // models/lemevit.py:255: log_N(M) C^-1/2
-  a.sc = (float)(1.0 / sqrt((double)d->C) * lg2e);                             // :256
+  a.sc = (float)(1.0 / sqrt(d->kind ? 32.0 : (double)d->C) * lg2e);            // :256; "C" blocks: F.scaled_dot_product_attention's head_dim^-1/2 (:480-483)
   a.timing = (unsigned long long*)d->timing; a.timing_block = d->timing_block;
-  hipLaunchKernelGGL((dstage_kernel<NW, GW, CT>), dim3(ns * G::NWG), dim3(64 * NW), G::L_TOTAL, st, a);
+  hipLaunchKernelGGL((dstage_kernel<NW, GW, CT, KIND>), dim3(ns * (KIND ? G::NWG_C : G::NWG)), dim3(64 * NW), G::L_TOTAL, st, a);
   LMV_CHECK_LAUNCH("dstage_fwd");
   return LMV_OK;
+}
+template <int NW, int GW, int CT> static int ds_launch(const lmv_dstage_desc* d, const void* x, const void* c, void* x_out, void* c_out, void* workspace, hipStream_t st) {
+  if constexpr (GW == 56) {          // "C" blocks exist at stage 0 only (56 x 56 image tokens)
+    if (d->kind) return ds_launch_kind<NW, GW, CT, 1>(d, x, c, x_out, c_out, workspace, st);
+  } else if (d->kind) LMV_FAIL(LMV_ERR_DTYPE, "dstage_fwd: C blocks are built for the 56 x 56 stage only");
+  return ds_launch_kind<NW, GW, CT, 0>(d, x, c, x_out, c_out, workspace, st);
 }
 
 }  // namespace
@@ -796,7 +819,8 @@ int lmv_dstage_fwd(const lmv_dstage_desc* d, const void* x, const void* c, void*
   const int nw = ds_variant(d->C, d->heads, d->hidden, d->H, d->W, d->M);
   if (!nw) LMV_FAIL(LMV_ERR_DTYPE, "dstage_fwd: unsupported stage shape");
   if (d->B <= 0 || d->nblocks <= 0 || !d->wpk || !d->vec) LMV_FAIL(LMV_ERR_SHAPE, "dstage_fwd: bad descriptor");
-  if (x == x_out || c == c_out) LMV_FAIL(LMV_ERR_SHAPE, "dstage_fwd: outputs must not alias the inputs");
+  if (d->kind != 0 && d->kind != 1) LMV_FAIL(LMV_ERR_SHAPE, "dstage_fwd: kind must be 0 (D blocks) or 1 (C blocks)");
+  if ((x == x_out && !d->kind) || c == c_out) LMV_FAIL(LMV_ERR_SHAPE, "dstage_fwd: outputs must not alias the inputs");
   const void* ptrs[] = {x, c, x_out, c_out, workspace, d->wpk, d->vec};
   for (const void* q : ptrs) if (!lmv_aligned16(q)) LMV_FAIL(LMV_ERR_SHAPE, "dstage_fwd: pointers must be 16-byte aligned");
   if (workspace_bytes < lmv_dstage_workspace_bytes(d->B, d->C)) LMV_FAIL(LMV_ERR_WORKSPACE, "dstage_fwd: workspace too small");

@@ -841,7 +841,7 @@ def _sstage_applies(stage, xt: Tensor, c: Tensor, H: int, W: int) -> Optional[st
     if not (_SSTAGE and _FUSED and _NATIVE) or torch.is_grad_enabled() or xt.dtype != torch.bfloat16 or len(stage) == 0 or not xt.is_cuda:
         return None
     kind = getattr(stage[0], "kind", None)
-    if kind not in ("S", "D"):
+    if kind not in ("S", "D", "C"):
         return None
     for blk in stage:
         if type(blk) is not LeMeBlock or blk.kind != kind or (blk.training and blk.drop_prob > 0.0) or type(blk)._masks is not LeMeBlock._masks or "_masks" in blk.__dict__:
@@ -849,10 +849,17 @@ def _sstage_applies(stage, xt: Tensor, c: Tensor, H: int, W: int) -> Optional[st
     b0 = stage[0]
     if kind == "S":
         return "S" if ops.sstage_supported(xt.shape[2], b0.attn.num_heads, b0.mlp[0].out_features, H, W, c.shape[1], xt.dtype) else None
-    if _DSTAGE and all(type(blk.attn) is DualCrossAttention and blk.attn.scale == xt.shape[2] ** (-0.5) for blk in stage) and \
-            ops.dstage_supported(xt.shape[2], b0.attn.num_heads, b0.mlp[0].out_features, H, W, c.shape[1], xt.dtype):
-        return "D"
-    return None
+    if not (_DSTAGE and ops.dstage_supported(xt.shape[2], b0.attn.num_heads, b0.mlp[0].out_features, H, W, c.shape[1], xt.dtype)):
+        return None
+    if kind == "D":
+        return "D" if all(type(blk.attn) is DualCrossAttention and blk.attn.scale == xt.shape[2] ** (-0.5) for blk in stage) else None
+    return "C" if all(type(blk.attn) is CrossAttention for blk in stage) else None          # stage 0: only the meta tokens change (:584-612)
+
+
+def _whole_stage_fwd(whole: str, xt: Tensor, c: Tensor, packed, H: int, W: int):
+    if whole == "S":
+        return ops.sstage_fwd(xt, c, packed, H, W, BLOCK_LN_EPS)
+    return ops.dstage_fwd(xt, c, packed, H, W, BLOCK_LN_EPS, kind=1 if whole == "C" else 0)
 
 
 def _sstage_packed(stage, kind: str = "S") -> "ops.SStagePacked":
@@ -867,7 +874,7 @@ def _sstage_packed(stage, kind: str = "S") -> "ops.SStagePacked":
     for blk in stage:
         P = blk._params()
         d = {}
-        for n in (ops.SSTAGE_NAMES if kind == "S" else ops.DSTAGE_NAMES):
+        for n in {"S": ops.SSTAGE_NAMES, "D": ops.DSTAGE_NAMES, "C": ops.CSTAGE_NAMES}[kind]:
             if n == "pos_embed.weight":
                 d[n] = P[n].detach().float().reshape(P[n].shape[0], 9).contiguous()
             elif _is_matrix(n):
@@ -875,7 +882,7 @@ def _sstage_packed(stage, kind: str = "S") -> "ops.SStagePacked":
             else:
                 d[n] = compute_copy(P[n], torch.float32)
         blocks.append(d)
-    packed = (ops.sstage_pack if kind == "S" else ops.dstage_pack)(blocks, stage[0].attn.num_heads)
+    packed = {"S": ops.sstage_pack, "D": ops.dstage_pack, "C": ops.cstage_pack}[kind](blocks, stage[0].attn.num_heads)
     _cache_filled()
     _sstage_cache[key] = (weakref.ref(stage, lambda _r, k=key: _sstage_cache.pop(k, None)), stamp, packed)
     return packed
@@ -1241,7 +1248,7 @@ class LeMeViT(nn.Module):
             c = c.to(cd).contiguous()
             whole = _sstage_applies(self.stages[i], xt, c, H, W)
             if whole is not None:
-                xt, c = (ops.sstage_fwd if whole == "S" else ops.dstage_fwd)(xt.contiguous(), c, _sstage_packed(self.stages[i], whole), H, W, BLOCK_LN_EPS)
+                xt, c = _whole_stage_fwd(whole, xt.contiguous(), c, _sstage_packed(self.stages[i], whole), H, W)
                 continue
             with image_ranges(xt.device, B):
                 for blk in self.stages[i]:

@@ -708,13 +708,39 @@ def dstage_pack(blocks: Sequence[dict], heads: int) -> SStagePacked:
     return P
 
 
-def dstage_fwd(x: Tensor, c: Tensor, P: SStagePacked, H: int, W: int, eps: float, timing: Optional[Tensor] = None, timing_block: int = 0) -> Tuple[Tensor, Tensor]:
+CSTAGE_NAMES = ("attn.q.weight", "attn.kv.weight", "attn.proj.weight", "mlp.0.weight", "mlp.3.weight", "norm1.weight", "norm1.bias", "attn.q.bias", "attn.kv.bias", "attn.proj.bias",
+                "norm2.weight", "norm2.bias", "mlp.0.bias", "mlp.3.bias", "pos_embed.weight", "pos_embed.bias")
+
+
+def cstage_pack(blocks: Sequence[dict], heads: int) -> SStagePacked:
+    """A run of "C" blocks (CrossAttention, models/lemevit.py:421-498: q from the meta tokens, k / v from the image tokens) in the layout of the D-stage kernel:
+    qkv1 = [0 | attn.kv] (the image tokens' k / v rows), qkv2 = [attn.q | 0 | 0] (the meta tokens' queries), proj_c = attn.proj; for dstage_fwd(kind=1)."""
+    out = []
+    for blk in blocks:
+        kv, q = blk["attn.kv.weight"], blk["attn.q.weight"]
+        C_ = q.shape[0]
+        z = torch.zeros_like(q)
+        zb = torch.zeros(C_, device=q.device, dtype=torch.float32)
+        d = {n: blk[n] for n in ("mlp.0.weight", "mlp.3.weight", "norm1.weight", "norm1.bias", "norm2.weight", "norm2.bias", "mlp.0.bias", "mlp.3.bias", "pos_embed.weight", "pos_embed.bias")}
+        d["attn.qkv1.weight"] = torch.cat([z, kv], 0)
+        d["attn.qkv2.weight"] = torch.cat([q, z, z], 0)
+        d["attn.qkv1.bias"] = torch.cat([zb, blk["attn.kv.bias"].float()], 0)
+        d["attn.qkv2.bias"] = torch.cat([blk["attn.q.bias"].float(), zb, zb], 0)
+        d["attn.proj_x.weight"], d["attn.proj_x.bias"] = blk["attn.proj.weight"], blk["attn.proj.bias"]          # (not read)
+        d["attn.proj_c.weight"], d["attn.proj_c.bias"] = blk["attn.proj.weight"], blk["attn.proj.bias"]
+        out.append(d)
+    return dstage_pack(out, heads)
+
+
+def dstage_fwd(x: Tensor, c: Tensor, P: SStagePacked, H: int, W: int, eps: float, timing: Optional[Tensor] = None, timing_block: int = 0, kind: int = 0) -> Tuple[Tensor, Tensor]:
+    """kind = 1: the packed blocks are "C" blocks (cstage_pack): x is returned as it came."""
     B, N, C_ = x.shape
     d = _lib.SStageDesc()
+    d.kind = kind
     d.B, d.H, d.W, d.M, d.C, d.heads, d.hidden, d.nblocks, d.dtype, d.eps = B, H, W, c.shape[1], C_, P.heads, P.hidden, P.nblocks, dtype_code(x), eps
     d.wpk, d.vec = P.wpk.data_ptr(), P.vec.data_ptr()
     d.timing, d.timing_block = (None if timing is None else timing.data_ptr()), timing_block
-    xo, co = torch.empty_like(x), torch.empty_like(c)
+    xo, co = (x if kind else torch.empty_like(x)), torch.empty_like(c)
     ws = _workspace(int(lib.lmv_dstage_workspace_bytes(B, C_)), x.device)
     check(lib.lmv_dstage_fwd(C.byref(d), _ptr(x), _ptr(c), _ptr(xo), _ptr(co), ws.data_ptr(), ws.numel(), _stream()), "lmv_dstage_fwd")
     return xo, co

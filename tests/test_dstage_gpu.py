@@ -146,3 +146,54 @@ def test_dstage_handoffs_under_uneven_load(C, G, nblocks, B):
         out = ops.dstage_fwd(x, c, P, G, G, 1e-6)
         torch.cuda.synchronize()
         assert torch.equal(out[0], ref[0]) and torch.equal(out[1], ref[1]), rnd
+
+
+# ---- "C" blocks (stage 0: CrossAttention, only the meta tokens change) through the same kernel (kind = 1) ----
+def _cstage(nblocks, seed, C):
+    sds = []
+    for j in range(nblocks):
+        sd = fill_state_dict(block_spec("C", C), seed + 17 * j)
+        for k, v in sd.items():
+            if v.dim() >= 2 and "pos_embed" not in k:
+                sd[k] = v.to(torch.bfloat16).float()
+        sds.append(sd)
+    return sds
+
+
+def _cpack(sds):
+    from lemevit_amd import ops
+    C = sds[0]["blk.norm1.weight"].shape[0]
+    blocks = []
+    for sd in sds:
+        d = {}
+        for name in ops.CSTAGE_NAMES:
+            t = sd["blk." + name].to(DEV)
+            if name == "pos_embed.weight":
+                t = t.reshape(C, 9)
+            d[name] = t.to(torch.bfloat16) if (t.dim() >= 2 and "pos_embed" not in name) else t.float()
+        blocks.append(d)
+    return ops.cstage_pack(blocks, C // 32)
+
+
+@pytest.mark.parametrize("C", [96, 64])
+@pytest.mark.parametrize("nblocks,B", [(1, 3), (2, 9), (2, 70)])
+def test_cstage_vs_oracle(nblocks, B, C):
+    """LeMeBlock.forward_with_c (models/lemevit.py:584-612) x depth: c against the float64 oracle, x returned untouched."""
+    from lemevit_amd import ops
+    G = 56
+    sds = _cstage(nblocks, 7, C)
+    P = _cpack(sds)
+    x, c = _inputs(B, 5, C, G)
+    xd = x.to(DEV)
+    xo, co = ops.dstage_fwd(xd, c.to(DEV), P, G, G, 1e-6, kind=1)
+    torch.cuda.synchronize()
+    assert xo.data_ptr() == xd.data_ptr() and torch.equal(xo.cpu(), x)
+    idx = list(range(9)) + [B - 3, B - 2, B - 1] if B > 12 else list(range(B))
+    xr, cr = x[idx].double(), c[idx].double()
+    for sd in sds:
+        xr, cr = O.leme_block({k: v.double() for k, v in sd.items()}, "blk.", "C", xr, cr, G, G, C // 32)
+    ec = _rel(co[idx].float(), cr)
+    print(f"cstage C={C} nblocks={nblocks} B={B}: c {ec:.2e}")
+    assert ec <= 1e-2, ec
+    co2 = ops.dstage_fwd(xd, c.to(DEV), P, G, G, 1e-6, kind=1)[1]
+    assert torch.equal(co, co2)

@@ -32,7 +32,7 @@ with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
             a, b = xt, c
             whole = Mm._sstage_applies(stage, a, b, res, res)
             if whole is not None:
-                return (Mm.ops.sstage_fwd if whole == "S" else Mm.ops.dstage_fwd)(a, b, Mm._sstage_packed(stage, whole), res, res, Mm.BLOCK_LN_EPS)
+                return Mm._whole_stage_fwd(whole, a, b, Mm._sstage_packed(stage, whole), res, res)
             with Mm.image_ranges(a.device, B):
                 for blk in stage:
                     a, b = blk.forward_tokens(a, b, res, res, masks=None)

@@ -472,6 +472,24 @@ size_t lmv_dstage_workspace_bytes(int B, int C);
 int lmv_dstage_pack(const lmv_dstage_block_params* p, void* wpk_out, float* vec_out, void* stream);
 int lmv_dstage_fwd(const lmv_dstage_desc* d, const void* x, const void* c, void* x_out, void* c_out, void* workspace, size_t workspace_bytes, void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * The stem as ONE launch (csrc/stem.hip; inference form, BatchNorm folded into the convolutions by the caller):
+ *   Conv2d(3, Cm, 3, 2, 1) -> BN -> GELU -> Conv2d(Cm, Co, 3, 2, 1) -> BN   (models/lemevit.py:698-704, called at :713)
+ * on images x [B, 3, H, W] (element strides sb, sc, sh, sw: NCHW or channels-last, fp32 or bf16) -> y [B, H/4, W/4, Co] bf16 (= the token
+ * matrix [B, H/4 * W/4, Co]).  Replaces lmv_im2col3x3s2_c3 + lmv_linear_fwd(GELU) + lmv_im2col3x3s2_nhwc + lmv_linear_fwd: no patch matrix and
+ * no Cm-channel map in HBM (an 8 x 8 output tile's 17 x 17 x Cm intermediate lives in LDS).
+ *   lmv_stem_supported: (Cm, Co) = (48, 96) (LeMeViT-Base / -Small) or (32, 64) (LeMeViT-Tiny), H and W multiples of 32, bf16 compute.
+ *   lmv_stem_pack: w1m [Cm, 32] bf16 (column ci * 9 + ky * 3 + kx, 27..31 zero: the operand of lmv_im2col3x3s2_c3's GEMM), w2m [Co, ld2] bf16
+ *     (column (ky * 3 + kx) * Cm + ci: the operand of lmv_im2col3x3s2_nhwc's GEMM) -> wpk_out (lmv_stem_wpk_bytes, MFMA-fragment order).
+ *   lmv_stem_fwd: b1 [Cm], b2 [Co] fp32 (the folded biases).
+ * ------------------------------------------------------------------------------------------ */
+int lmv_stem_supported(int H, int W, int Cm, int Co, int dtype);
+size_t lmv_stem_wpk_bytes(int Cm, int Co);
+int lmv_stem_pack(const void* w1m, const void* w2m, int ld2, int Cm, int Co, void* wpk_out, void* stream);
+int lmv_stem_fwd(const void* x, int x_dtype, int64_t sb, int64_t sc, int64_t sh, int64_t sw, int B, int H, int W, int Cm, int Co, const void* wpk, const float* b1,
+                 const float* b2, void* y, void* stream);
+void lmv_stem_debug_timing(void* buf);   /* tools/stem_timeline.py: NULL, or a device buffer of [workgroups][4 waves][8] uint64 s_memtime stamps filled by the next lmv_stem_fwd calls */
+
 #ifdef __cplusplus
 }
 #endif

@@ -156,6 +156,11 @@ SIGNATURES = {
     "lmv_sstage_max_images": (_I, [_I]),
     "lmv_sstage_pack": (_I, [C.POINTER(SStageBlockParams), _P, _P, _P]),
     "lmv_sstage_fwd": (_I, [C.POINTER(SStageDesc), _P, _P, _P, _P, _P, _Z, _P]),
+    "lmv_stem_supported": (_I, [_I, _I, _I, _I, _I]),
+    "lmv_stem_wpk_bytes": (_Z, [_I, _I]),
+    "lmv_stem_pack": (_I, [_P, _P, _I, _I, _I, _P, _P]),
+    "lmv_stem_fwd": (_I, [_P, _I, _L, _L, _L, _L, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P]),
+    "lmv_stem_debug_timing": (None, [_P]),
     "lmv_dstage_supported": (_I, [_I, _I, _I, _I, _I, _I, _I]),
     "lmv_dstage_wpk_bytes": (_Z, [_I, _I]),
     "lmv_dstage_vec_floats": (_Z, [_I, _I]),

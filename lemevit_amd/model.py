@@ -503,6 +503,42 @@ def _folded_conv_bn(conv: nn.Conv2d, bn: nn.BatchNorm2d, dtype: torch.dtype):
     return w, b, b32
 
 
+_STEM = os.environ.get("LMV_STEM", "1") != "0"          # 0: the stem as im2col + GEMM launches (A/B runs)
+_stem_cache: dict = {}
+
+
+def _stem_applies(mods, x: Tensor, cd: torch.dtype) -> bool:
+    """models/lemevit.py:698-704: Conv(3, C/2, 3, 2, 1) - BN - GELU - Conv(C/2, C, 3, 2, 1) - BN in inference -> ONE launch (csrc/stem.hip)."""
+    if not (_STEM and _CONV_NATIVE and len(mods) == 5 and x.is_cuda and x.dim() == 4 and x.shape[1] == 3 and cd == torch.bfloat16 and x.dtype in (torch.float32, torch.bfloat16)):
+        return False
+    c1, b1, act, c2, b2 = mods
+    ok = lambda c, ci, co: (isinstance(c, nn.Conv2d) and c.kernel_size == (3, 3) and c.stride == (2, 2) and c.padding == (1, 1) and c.dilation == (1, 1) and c.groups == 1
+                            and c.padding_mode == "zeros" and c.in_channels == ci and c.out_channels == co and c.weight.dtype == torch.float32)
+    if not (isinstance(c1, nn.Conv2d) and isinstance(c2, nn.Conv2d) and ok(c1, 3, c1.out_channels) and ok(c2, c1.out_channels, c2.out_channels)):
+        return False
+    if not all(isinstance(b, nn.BatchNorm2d) and b.track_running_stats for b in (b1, b2)) or not (isinstance(act, nn.GELU) and getattr(act, "approximate", "none") == "none"):
+        return False
+    return ops.stem_supported(x.shape[2], x.shape[3], c1.out_channels, c2.out_channels, cd)
+
+
+def _stem_fused(mods, x: Tensor, cd: torch.dtype) -> Tensor:
+    c1, b1, _, c2, b2 = mods
+    w1, _, b1f = _folded_conv_bn(c1, b1, cd)
+    w2, _, b2f = _folded_conv_bn(c2, b2, cd)
+    key = (id(c1), id(c2))
+    ent = _stem_cache.get(key)
+    if ent is None or ent[0] is not w1 or ent[1] is not w2:          # (the folds are new tensors whenever a source tensor changed)
+        Cm = w1.shape[0]
+        w1m = torch.zeros(Cm, 32, device=w1.device, dtype=cd)
+        w1m[:, :27] = w1.reshape(Cm, 27)
+        w2m = w2.permute(0, 2, 3, 1).reshape(w2.shape[0], 9 * Cm).contiguous()
+        ent = (w1, w2, ops.stem_pack(w1m, w2m))
+        _cache_filled()
+        _stem_cache[key] = ent
+    y = ops.stem_fwd(x, ent[2], b1f, b2f, w1.shape[0], w2.shape[0])
+    return y.permute(0, 3, 1, 2)                     # NCHW-shaped, channels-last-strided: _to_tokens takes it without a copy
+
+
 def _resolve_dtype(x: Tensor) -> torch.dtype:
     if not x.is_cuda:
         raise RuntimeError("lemevit_amd: the model runs on an MI355X only -- move the model and inputs to 'cuda' "
@@ -1166,6 +1202,8 @@ class LeMeViT(nn.Module):
         cd = x.dtype if not torch.is_autocast_enabled() else torch.get_autocast_dtype("cuda")
         fold = not (self.training or torch.is_grad_enabled())
         mods, i = list(seq), 0
+        if fold and _stem_applies(mods, x, cd):
+            return _stem_fused(mods, x, cd)
         while i < len(mods):
             m = mods[i]
             bn = mods[i + 1] if i + 1 < len(mods) and isinstance(mods[i + 1], nn.BatchNorm2d) and mods[i + 1].track_running_stats else None

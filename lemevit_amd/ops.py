@@ -744,3 +744,34 @@ def dstage_fwd(x: Tensor, c: Tensor, P: SStagePacked, H: int, W: int, eps: float
     ws = _workspace(int(lib.lmv_dstage_workspace_bytes(B, C_)), x.device)
     check(lib.lmv_dstage_fwd(C.byref(d), _ptr(x), _ptr(c), _ptr(xo), _ptr(co), ws.data_ptr(), ws.numel(), _stream()), "lmv_dstage_fwd")
     return xo, co
+
+
+# -------------------------------------------------------------------------------------------
+# The stem as one launch (csrc/stem.hip; inference, BatchNorm folded by the caller)
+# -------------------------------------------------------------------------------------------
+def stem_supported(H: int, W: int, Cm: int, Co: int, dtype: torch.dtype) -> bool:
+    return dtype == torch.bfloat16 and bool(lib.lmv_stem_supported(H, W, Cm, Co, _lib.LMV_BF16))
+
+
+def stem_pack(w1m: Tensor, w2m: Tensor) -> Tensor:
+    """w1m [Cm, 32], w2m [Co, >= 9 Cm] bf16 (the GEMM operands of the two im2col forms) -> the packed weights of stem_fwd."""
+    Cm, Co = w1m.shape[0], w2m.shape[0]
+    if w1m.dtype != torch.bfloat16 or w2m.dtype != torch.bfloat16 or w1m.shape[1] != 32 or not w1m.is_contiguous() or w2m.stride(1) != 1:
+        raise TypeError("lemevit_amd: stem_pack takes the bf16 [Cm, 32] and [Co, KP] conv matrices")
+    nb = int(lib.lmv_stem_wpk_bytes(Cm, Co))
+    if nb == 0:
+        raise ValueError(f"lemevit_amd: stem_pack does not support {Cm} -> {Co} channels")
+    out = torch.empty(nb, device=w1m.device, dtype=torch.uint8)
+    check(lib.lmv_stem_pack(_ptr(w1m), _ptr(w2m), w2m.stride(0), Cm, Co, out.data_ptr(), _stream()), "lmv_stem_pack")
+    return out
+
+
+def stem_fwd(x: Tensor, wpk: Tensor, b1: Tensor, b2: Tensor, Cm: int, Co: int) -> Tensor:
+    """x [B, 3, H, W] (any strides, fp32 / bf16) -> [B, H/4, W/4, Co] bf16."""
+    B, C3, H, W = x.shape
+    if C3 != 3 or not x.is_cuda:
+        raise ValueError("lemevit_amd: stem_fwd takes [B, 3, H, W] images on the GPU")
+    y = torch.empty((B, H // 4, W // 4, Co), device=x.device, dtype=torch.bfloat16)
+    sb, sc, sh, sw = x.stride()
+    check(lib.lmv_stem_fwd(x.data_ptr(), dtype_code(x), sb, sc, sh, sw, B, H, W, Cm, Co, wpk.data_ptr(), _f32(b1), _f32(b2), _ptr(y), _stream()), "lmv_stem_fwd")
+    return y

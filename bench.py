@@ -69,74 +69,6 @@ def parse():
     return ap.parse_args()
 
 
-class GemmTimer:
-    """Brackets every forward Linear launch (lemevit_amd.ops.linear_fwd) with HIP events on the launch stream."""
-
-    def __init__(self):
-        self.events, self.flops, self.bytes, self.enabled = [], [], [], False
-
-    def install(self):
-        from lemevit_amd import ops
-        orig = ops.linear_fwd
-        timer = self
-
-        def timed(probs, N, K, act=0):
-            if not timer.enabled:
-                return orig(probs, N, K, act)
-            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            s.record()
-            orig(probs, N, K, act)
-            e.record()
-            timer.events.append((s, e))
-            timer.flops.append(2.0 * N * K * sum(p.rows for p in probs))
-            # algorithmic HBM bytes of the launch: A in, C out (+ pre-activation copy, + residual in), W and bias once (bf16 = 2 B)
-            timer.bytes.append(sum(2.0 * p.rows * (K + N * (1 + (p.out_pre is not None) + (p.res is not None))) for p in probs) + 2.0 * N * K + 4.0 * N)
-
-        ops.linear_fwd = timed
-        orig_ln = ops.linear_res_ln_fwd
-
-        def timed_ln(probs, N, K, *a, **kw):          # the projection + norm2 launch of the C = 384 blocks is a forward Linear launch too
-            if not timer.enabled:
-                return orig_ln(probs, N, K, *a, **kw)
-            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            s.record()
-            r = orig_ln(probs, N, K, *a, **kw)
-            e.record()
-            timer.events.append((s, e))
-            timer.flops.append(2.0 * N * K * sum(p.rows for p in probs))
-            timer.bytes.append(sum(2.0 * p.rows * (K + 3 * N) for p in probs) + 2.0 * N * K + 12.0 * N)      # A, residual in; out and LayerNorm(out) out
-            return r
-
-        ops.linear_res_ln_fwd = timed_ln
-        orig_ex = ops.ln_linear_exact_fwd
-
-        def timed_ex(probs, N, K, *a, **kw):          # norm1 + projection of the C = 96 blocks (csrc/rswgemm.hip): a forward Linear launch as well
-            if not timer.enabled:
-                return orig_ex(probs, N, K, *a, **kw)
-            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            s.record()
-            r = orig_ex(probs, N, K, *a, **kw)
-            e.record()
-            timer.events.append((s, e))
-            timer.flops.append(2.0 * N * K * sum(p.rows for p in probs))
-            timer.bytes.append(sum(2.0 * p.rows * (2 * K + N) + 8.0 * p.rows for p in probs) + 2.0 * N * K + 4.0 * N)      # raw rows in; LayerNorm(rows), (mean, rstd) and the projection out
-            return r
-
-        ops.ln_linear_exact_fwd = timed_ex
-        import lemevit_amd.blocks as blocks
-        import lemevit_amd.model as model
-        blocks.ops.linear_fwd = timed
-        model.ops.linear_fwd = timed
-
-    def summary(self):
-        if not self.events:
-            return None
-        ms = sum(s.elapsed_time(e) for s, e in self.events)
-        fl = sum(self.flops)
-        return dict(launches=len(self.events), total_ms=ms, avg_us=1e3 * ms / len(self.events), tflops=fl / (ms * 1e-3) / 1e12,
-                    gflop_per_launch=fl / len(self.events) / 1e9, mbytes_per_launch=sum(self.bytes) / len(self.events) / 1e6)
-
-
 def cpu_baseline(model_name: str, img: int, mode: str):
     """Oracle (port of the reference) on the host cores, bounded to ~10-30 s."""
     from oracle import lemevit_oracle as O
@@ -290,9 +222,6 @@ def main():
     model.train(train)
     x = torch.randn(args.batch, 3, args.img, args.img, device=dev)
     loss_fn = torch.nn.CrossEntropyLoss().to(dev)
-    timer = GemmTimer()
-    if rank == 0 and not args.no_kernel_timing:
-        timer.install()
     # The process group is created AFTER the model: with RCCL initialised first, every step of this workload is ~3 ms slower
     # even when no collective runs (measured with a 1-rank group, tools/cpu_launch_time.py --pg-first); all ranks seed
     # identically and FlatGradSync / DDP broadcast rank 0's parameters anyway.
@@ -373,27 +302,32 @@ def main():
         issue.append(time.perf_counter() - ti)
     sync()
     t_issued = sorted(issue)[len(issue) // 2] * args.steps if issue else None
-    kernel_timing_note = None
+    kernel_timing_note, probe = None, None
     if not args.no_kernel_timing:
-        # Same kernels, same shapes: every forward-GEMM launch of 3 eager steps run right AFTER the timed region is bracketed by HIP
-        # events on rank 0 (events cannot be timed inside a captured graph, and in eager mode they cost ~1 ms per step, which
-        # must not leak into `value`).  All ranks run the 3 steps: they contain the gradient collectives.
-        # The timed region runs each block through ONE native call (lmv_block_fwd / _bwd), whose launches Python cannot bracket; these 3
-        # steps take the Python schedule of the same blocks (lemevit_amd/blocks.py: the same kernels on the same shapes, launch by launch).
-        import lemevit_amd.model as _model
-        native_was, _model._NATIVE = _model._NATIVE, False
-        timer.enabled = rank == 0
-        parts_was, args.infer_parts = args.infer_parts, 1      # (--mode infer: whole-batch launches on one stream, so that a launch's events bracket it alone)
+        # Same schedule as the timed region: 3 eager steps right AFTER it with the library's launch-timing probe on (lmv_debug_launch_timing: HIP events around
+        # every forward-form Linear entry point and every persistent stage / stem launch, recorded on the stream the launch is issued on -- the native block
+        # schedule's launches included).  Events cannot be timed inside a captured graph, and in eager mode they cost ~1 ms per step, which must not leak
+        # into `value`.  All ranks run the 3 steps: they contain the gradient collectives.
+        import ctypes
+        from lemevit_amd import _lib as _L
+        cap = 16384
+        if rank == 0:
+            _L.check(_L.lib.lmv_debug_launch_timing(cap), "lmv_debug_launch_timing")
         for _ in range(3):
             eager_step()
         sync()
-        timer.enabled = False
-        args.infer_parts = parts_was
-        _model._NATIVE = native_was
-        kernel_timing_note = ("HIP events around every forward-Linear launch of 3 eager steps run right after the timed region (blocks on the per-launch "
-                              "Python schedule for these steps: whole-batch launches of the same kernels; the native block calls of the timed region issue the "
-                              "FORWARD-pass launches as model.TRAIN_PARTS concurrent ranges of images, i.e. at half the rows each by default; --mode infer: "
-                              "whole batch on one stream for these steps, the timed region replays it as --infer-parts concurrent sub-batches)")
+        if rank == 0:
+            ms, fl, by, kd = (ctypes.c_float * cap)(), (ctypes.c_double * cap)(), (ctypes.c_double * cap)(), (ctypes.c_int * cap)()
+            n = _L.lib.lmv_debug_launch_timing_read(ms, fl, by, kd, cap)
+            _L.lib.lmv_debug_launch_timing(0)
+            probe = {}
+            for i in range(n):
+                e = probe.setdefault(kd[i], dict(launches=0, total_ms=0.0, flops=0.0, bytes=0.0))
+                e["launches"] += 1; e["total_ms"] += ms[i]; e["flops"] += fl[i]; e["bytes"] += by[i]
+        kernel_timing_note = ("HIP events of the library's launch-timing probe (lmv_debug_launch_timing) around every launch of this kind in 3 eager steps run right after the timed "
+                              "region, on the timed region's own schedule (native block calls, concurrent ranges of images / sub-batches, weight-gradient GEMMs on the side stream) and on "
+                              "the launch's own stream: launches that overlap on the chip share it, so the sum of their durations exceeds the wall time they cover (round 3 timed whole-batch "
+                              "launches alone on the chip: 0.144 for the same kernels)")
     # The north-star target is FORWARD throughput (BASELINE.json): in train mode the same process times the forward pass of the same
     # model on the same batch right after the train region (eval mode, no_grad, bf16 autocast, hipGraph replay as in --mode infer) and
     # reports it as extra keys of the same JSON line.  The timed train region above is not touched by it.
@@ -439,7 +373,14 @@ def main():
         mult = 3.0 if train else 1.0
         gmac = CANONICAL_GMAC.get((args.model, args.img))
         gflop = None if gmac is None else 2.0 * gmac
-        g = timer.summary()
+        KIND_NAMES = {0: "forward Linear launches: gemm_kernel<bf16,NT> / rs_gemm_kernel / wn_gemm_kernel / rsw_gemm_kernel",
+                      1: "sstage_kernel (a stage of S blocks as one persistent launch)", 2: "dstage_kernel (a stage of D / C blocks as one persistent launch)", 3: "stem_kernel"}
+        g, gkind = None, None
+        if probe:
+            gkind = max(probe, key=lambda k: probe[k]["total_ms"])          # the dominant launch kind of this workload
+            e = probe[gkind]
+            g = dict(launches=e["launches"], total_ms=e["total_ms"], avg_us=1e3 * e["total_ms"] / e["launches"], tflops=e["flops"] / (e["total_ms"] * 1e-3) / 1e12,
+                     gflop_per_launch=e["flops"] / e["launches"] / 1e9, mbytes_per_launch=e["bytes"] / e["launches"] / 1e6)
         roof = None
         if g is not None:
             # HBM bytes per launch of the same kernel from the PMC passes committed under profiles/ (tools/pmc_traffic.sh: FETCH_SIZE x 2
@@ -447,14 +388,14 @@ def main():
             traffic, traffic_src = None, None
             import glob
             cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_gemm_fwd_pmc_traffic.json")))      # the newest COMMITTED round (r03's file never left gpurun_out/)
-            if train and args.model == "lemevit_base" and args.img == 224 and args.batch == 128 and cands:
+            if gkind == 0 and train and args.model == "lemevit_base" and args.img == 224 and args.batch == 128 and cands:
                 pmc = cands[-1]
                 with open(pmc) as f:
                     traffic = round(json.load(f)["traffic_bytes_per_launch"] / 1e6, 2)
                 traffic_src = (f"canned: profiles/{os.path.basename(pmc)} (MB per launch over the forward-form Linear launches -- gemm_kernel<bf16,NT>, rs_gemm_kernel, "
                                "wn_gemm_kernel -- of this command's train step, separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, tools/pmc_traffic.sh; NOT measured "
                                "in this run; that launch set also holds the dX launches that run as forward-form GEMMs on transposed weights)")
-            elif train:
+            elif train and gkind == 0:
                 print("bench.py: no profiles/rNN_gemm_fwd_pmc_traffic.json for this workload: roofline.traffic stays null", file=sys.stderr)
             # SURVEY 8(d) grades the path against the MFMA roof (94 % of the MACs are Linear GEMMs), so that is the primary figure.  The
             # launch mix itself has K = 96..512 on the big-row stages: its arithmetic intensity is below the ridge point of the chip
@@ -466,7 +407,9 @@ def main():
                         flop_per_byte=round(intensity, 1), ridge_flop_per_byte=round(PEAK_BF16_TFLOPS * 1e3 / PEAK_HBM_GBS, 1),
                         hbm_gbs=round(hbm_gbs, 1), hbm_peak_gbs=PEAK_HBM_GBS, hbm_frac=round(hbm_gbs / PEAK_HBM_GBS, 4),
                         traffic_over_algorithmic=None if traffic is None else round(traffic / g["mbytes_per_launch"], 3),
-                        kernel="forward Linear launches: gemm_kernel<bf16,NT> / rs_gemm_kernel / wn_gemm_kernel (+ rsw_gemm_kernel in the event timing)", measured=kernel_timing_note, launches=g["launches"], avg_launch_us=round(g["avg_us"], 2),
+                        kernel=KIND_NAMES.get(gkind, str(gkind)), measured=kernel_timing_note,
+                        other_launch_kinds={KIND_NAMES[k].split(" ")[0].split(":")[0]: dict(launches=v["launches"], ms_per_step=round(v["total_ms"] / 3, 3), tflops=round(v["flops"] / (v["total_ms"] * 1e-3) / 1e12, 1))
+                                            for k, v in probe.items() if k != gkind}, launches=g["launches"], avg_launch_us=round(g["avg_us"], 2),
                         gflop_per_launch=round(g["gflop_per_launch"], 3))
         line = {
             "metric": f"images/sec {pretty} {args.img}^2 bf16 " + ("fwd+bwd" if train else "fwd"),

@@ -488,6 +488,12 @@ size_t lmv_stem_wpk_bytes(int Cm, int Co);
 int lmv_stem_pack(const void* w1m, const void* w2m, int ld2, int Cm, int Co, void* wpk_out, void* stream);
 int lmv_stem_fwd(const void* x, int x_dtype, int64_t sb, int64_t sc, int64_t sh, int64_t sw, int B, int H, int W, int Cm, int Co, const void* wpk, const float* b1,
                  const float* b2, void* y, void* stream);
+/* Launch timing probe: lmv_debug_launch_timing(capacity > 0) creates `capacity` event pairs and from then on brackets every lmv_linear_fwd / lmv_linear_res_ln_fwd /
+ * lmv_ln_linear_exact_fwd call -- from any schedule, the native block schedule (lmv_block_fwd) included -- with HIP events on the stream it launches on; after a device
+ * synchronisation lmv_debug_launch_timing_read returns the number of calls and fills their durations [ms], FLOPs and algorithmic HBM bytes; capacity = 0 frees the events.
+ * Not for use inside a stream capture; single host thread.  (bench.py's roofline object.) */
+int lmv_debug_launch_timing(int capacity);
+int lmv_debug_launch_timing_read(float* ms, double* flops, double* bytes, int* kinds, int capacity);   /* kinds: 0 forward-form Linear, 1 lmv_sstage_fwd, 2 lmv_dstage_fwd, 3 lmv_stem_fwd */
 void lmv_stem_debug_timing(void* buf);   /* tools/stem_timeline.py: NULL, or a device buffer of [workgroups][4 waves][8] uint64 s_memtime stamps filled by the next lmv_stem_fwd calls */
 
 #ifdef __cplusplus

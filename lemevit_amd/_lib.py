@@ -161,6 +161,8 @@ SIGNATURES = {
     "lmv_stem_pack": (_I, [_P, _P, _I, _I, _I, _P, _P]),
     "lmv_stem_fwd": (_I, [_P, _I, _L, _L, _L, _L, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P]),
     "lmv_stem_debug_timing": (None, [_P]),
+    "lmv_debug_launch_timing": (_I, [_I]),
+    "lmv_debug_launch_timing_read": (_I, [_P, _P, _P, _P, _I]),
     "lmv_dstage_supported": (_I, [_I, _I, _I, _I, _I, _I, _I]),
     "lmv_dstage_wpk_bytes": (_Z, [_I, _I]),
     "lmv_dstage_vec_floats": (_Z, [_I, _I]),

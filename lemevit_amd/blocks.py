@@ -477,10 +477,12 @@ def block_forward(kind: str, x: Tensor, c: Tensor, H: int, W: int, P: Dict[str, 
         # (the one-kernel / LayerNorm-folded MLP half of the fused inference schedule has no use for norm2's output: csrc/block.hip::res_ln_ok)
         Hd = P["mlp.0.weight"].shape[0]
         rows = xp.numel() // xp.shape[-1] + c.numel() // c.shape[-1]
-        folded = fc1_fold is not None and not save and not (xp.shape[-1] == 384 and Hd == 1536 and 16384 <= rows <= 65536 and _lib_config("mlp_split384"))
+        split = xp.shape[-1] == 384 and Hd == 1536 and 16384 <= rows <= 65536 and bool(_lib_config("mlp_split384"))      # csrc/block.hip::mlp_fwd: LayerNorm + rsgemm fc1 + wngemm fc2
+        folded = fc1_fold is not None and not save and not split
         r = _attn_S_fwd(P, [xp, c], [masks[0], masks[2]], save, want_ln2=not folded)
         (x2, c1), sa, ln2 = r if not folded else (r[0], r[1], None)
-        (x3, c2), sm = _mlp_fwd(P, [x2, c1], [masks[1], masks[3]], save, fc1_fold, pre_ln=ln2)
+        # split: never the one-kernel MLP, with or without a fused norm2 in front (the native schedule's rule)
+        (x3, c2), sm = _mlp_fwd(P, [x2, c1], [masks[1], masks[3]], save, None if split else fc1_fold, pre_ln=ln2)
         return x3, c2, ((x, sa, sm) if save else None)
     fwd = {"D": _attn_D_fwd, "D2": _attn_D2_fwd}[kind]
     (x2, c1), sa = fwd(P, [xp, c], [masks[0], masks[2]], save)

@@ -19,6 +19,16 @@ void lmv_set_error(const char* fmt, ...);
     lmv_set_error(__VA_ARGS__);      \
     return (code);                   \
   } while (0)
+// ---- launch timing probe (lmv_debug_launch_timing, misc.hip): HIP events around the forward-form Linear entry points ON THE STREAM THEY LAUNCH ON, whichever schedule calls
+// them (the native block schedule of csrc/block.hip included) -- bench.py's roofline object.  Off: one predictable branch per entry.
+extern bool g_lmv_timing_on;
+void lmv_timing_begin(void* stream, double flops, double bytes, int kind);
+void lmv_timing_end(void* stream);
+struct LmvTimedLaunch {          // RAII bracket of one entry point
+  void* st; bool on;
+  LmvTimedLaunch(void* stream, double flops, double bytes, int kind = 0) : st(stream), on(g_lmv_timing_on) { if (on) lmv_timing_begin(st, flops, bytes, kind); }          // kind: 0 forward-form Linear, 1 sstage, 2 dstage, 3 stem
+  ~LmvTimedLaunch() { if (on) lmv_timing_end(st); }
+};
 #define LMV_CHECK_LAUNCH(name)                                                \
   do {                                                                        \
     hipError_t e__ = hipGetLastError();                                       \

@@ -824,6 +824,10 @@ int lmv_dstage_fwd(const lmv_dstage_desc* d, const void* x, const void* c, void*
   const void* ptrs[] = {x, c, x_out, c_out, workspace, d->wpk, d->vec};
   for (const void* q : ptrs) if (!lmv_aligned16(q)) LMV_FAIL(LMV_ERR_SHAPE, "dstage_fwd: pointers must be 16-byte aligned");
   if (workspace_bytes < lmv_dstage_workspace_bytes(d->B, d->C)) LMV_FAIL(LMV_ERR_WORKSPACE, "dstage_fwd: workspace too small");
+  // (timing probe.  "D" blocks: qkv1 (the k third folded away: 2 C^2), proj_x, the MLP per image token; the meta tokens' qkv2, q~, proj_c, MLP; both attention directions.  "C": k / v folded or computed (C^2), meta path)
+  const double Cd = d->C, N = (double)d->H * d->W, M = d->M;
+  const double fl_img = d->kind ? N * Cd * Cd * 2.0 : N * Cd * 11.0 * Cd * 2.0, fl_meta = M * Cd * (d->kind ? 11.0 : 13.0) * Cd * 2.0, fl_att = (Cd / 32.0) * N * M * 32.0 * (d->kind ? 4.0 : 8.0);
+  LmvTimedLaunch timed(stream, (double)d->B * d->nblocks * (fl_img + fl_meta + fl_att), (double)d->B * (N * (d->kind ? 1.0 : 2.0) + 2.0 * M) * Cd * 2.0 + (double)d->nblocks * 18.0 * Cd * Cd * 2.0, 2);
 #define DS_LAUNCH(NW, GW, CT) ds_launch<NW, GW, CT>(d, x, c, x_out, c_out, workspace, (hipStream_t)stream)
   return DS_DISPATCH(nw, DS_LAUNCH, LMV_ERR_DTYPE);
 }

@@ -606,6 +606,10 @@ extern "C" int lmv_linear_fwd(const lmv_linear_problem* p, int nproblems, int N,
   if (act != LMV_ACT_NONE && act != LMV_ACT_GELU && act != LMV_ACT_GELU_GRAD) LMV_FAIL(LMV_ERR_SHAPE, "linear_fwd: act must be NONE, GELU or GELU_GRAD");
   for (int i = 0; i < nproblems && i < 2; ++i)
     if (act == LMV_ACT_GELU_GRAD && (!p[i].aux || p[i].res)) LMV_FAIL(LMV_ERR_SHAPE, "linear_fwd: GELU_GRAD needs aux and takes no residual");
+  double rows = 0., bytes = 2.0 * N * K + 4.0 * N;          // algorithmic HBM bytes: A in, C out (+ pre-activation copy out, + residual in, + the GELU' operand in), W and bias once (bf16 = 2 B)
+  if (g_lmv_timing_on)
+    for (int i = 0; i < nproblems && i < 2; ++i) { rows += (double)p[i].rows; bytes += 2.0 * p[i].rows * (K + (double)N * (1 + (p[i].out_pre != nullptr) + (p[i].res != nullptr) + (p[i].aux != nullptr))); }
+  LmvTimedLaunch timed(stream, 2.0 * N * K * rows, bytes);
   return launch(p, nproblems, N, K, act, dtype, stream, MODE_FWD, nullptr, 0);
 }
 extern "C" int lmv_linear_dx(const lmv_linear_problem* p, int nproblems, int N, int K, int act, int dtype, void* stream) {

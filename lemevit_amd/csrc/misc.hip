@@ -1,6 +1,7 @@
 // misc.hip -- error plumbing and the small memory-bound utilities (cast, DropPath row scale,
 // fused flat AdamW).  All are grid-stride, 16-byte-per-lane kernels bounded by HBM bandwidth.
 #include <stdarg.h>
+#include <vector>
 #include "common.h"
 
 static thread_local char g_err[512] = "";
@@ -12,6 +13,46 @@ void lmv_set_error(const char* fmt, ...) {
   va_end(ap);
 }
 extern "C" const char* lmv_last_error(void) { return g_err; }
+
+// ---- launch timing probe ---------------------------------------------------------------------------------------------------------------
+bool g_lmv_timing_on = false;
+namespace {
+struct TimingRec { hipEvent_t e0, e1; double flops, bytes; int kind; };
+std::vector<TimingRec> g_timing;          // (single host thread: the probe is a measurement aid, enabled for a few steps by bench.py)
+size_t g_timing_n = 0;
+}
+void lmv_timing_begin(void* stream, double flops, double bytes, int kind) {
+  if (g_timing_n >= g_timing.size()) return;
+  TimingRec& r = g_timing[g_timing_n];
+  r.flops = flops; r.bytes = bytes; r.kind = kind;
+  (void)hipEventRecord(r.e0, (hipStream_t)stream);
+}
+void lmv_timing_end(void* stream) {
+  if (g_timing_n >= g_timing.size()) return;
+  (void)hipEventRecord(g_timing[g_timing_n++].e1, (hipStream_t)stream);
+}
+extern "C" int lmv_debug_launch_timing(int capacity) {
+  g_lmv_timing_on = false;
+  for (auto& r : g_timing) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
+  g_timing.clear(); g_timing_n = 0;
+  if (capacity <= 0) return LMV_OK;
+  g_timing.resize((size_t)capacity);
+  for (auto& r : g_timing)
+    if (hipEventCreate(&r.e0) != hipSuccess || hipEventCreate(&r.e1) != hipSuccess) LMV_FAIL(LMV_ERR_LAUNCH, "launch timing: cannot create events");
+  g_lmv_timing_on = true;
+  return LMV_OK;
+}
+extern "C" int lmv_debug_launch_timing_read(float* ms, double* flops, double* bytes, int* kinds, int capacity) {
+  g_lmv_timing_on = false;          // (the caller has synchronised the device)
+  int n = 0;
+  for (size_t i = 0; i < g_timing_n && n < capacity; ++i) {
+    float t = 0.f;
+    if (hipEventElapsedTime(&t, g_timing[i].e0, g_timing[i].e1) != hipSuccess) continue;
+    ms[n] = t; flops[n] = g_timing[i].flops; bytes[n] = g_timing[i].bytes; kinds[n] = g_timing[i].kind; ++n;
+  }
+  return n;
+}
+
 extern "C" int lmv_abi_version(void) { return LMV_ABI_VERSION; }
 
 // ---- A/B switches: the environment is read once, here ------------------------------------------------------------------------------------

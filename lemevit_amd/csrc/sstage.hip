@@ -760,6 +760,10 @@ int lmv_sstage_fwd(const lmv_sstage_desc* d, const void* x, const void* c, void*
   if (d->B <= 0 || d->nblocks <= 0 || !d->wpk || !d->vec) LMV_FAIL(LMV_ERR_SHAPE, "sstage_fwd: bad descriptor");
   const void* ptrs[] = {x, c, x_out, c_out, workspace, d->wpk, d->vec};
   for (const void* q : ptrs) if (!lmv_aligned16(q)) LMV_FAIL(LMV_ERR_SHAPE, "sstage_fwd: pointers must be 16-byte aligned");
+  // (timing probe: the Linear layers of 212 tokens per image + the two attention products of every head; bytes: tokens in and out once, the weights once)
+  const double Cd = d->C, tok = (double)d->H * d->W + d->M, img = (double)d->H * d->W;
+  LmvTimedLaunch timed(stream, (double)d->B * d->nblocks * (tok * Cd * 12.0 * Cd * 2.0 + (Cd / 32.0) * (img * img + (double)d->M * d->M) * 32.0 * 4.0),
+                       (double)d->B * tok * Cd * 2.0 * 2.0 + (double)d->nblocks * 12.0 * Cd * Cd * 2.0, 1);
   return ss_waves(d->C, d->heads, d->hidden) == 8 ? ss_launch<8>(d, x, c, x_out, c_out, workspace, workspace_bytes, (hipStream_t)stream)
                                                  : ss_launch<4>(d, x, c, x_out, c_out, workspace, workspace_bytes, (hipStream_t)stream);
 }

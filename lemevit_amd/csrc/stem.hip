@@ -281,6 +281,8 @@ int lmv_stem_fwd(const void* x, int x_dtype, int64_t sb, int64_t sc, int64_t sh,
   const long long nt = (long long)B * a.tiles_y * a.tiles_x;
   if (nt >= (1ll << 31)) LMV_FAIL(LMV_ERR_SHAPE, "stem_fwd: too many tiles");
   a.ntiles = (int)nt; a.timing = g_stem_timing;
+  LmvTimedLaunch timed(stream, (double)B * ((H / 2.0) * (W / 2.0) * 27.0 * Cm + (H / 4.0) * (W / 4.0) * 9.0 * Cm * Co) * 2.0,
+                       (double)B * (3.0 * H * W * (a.x_bf16 ? 2.0 : 4.0) + (H / 4.0) * (W / 4.0) * Co * 2.0), 3);
   hipStream_t st = (hipStream_t)stream;
   if (v == 1) return a.x_bf16 ? stem_launch<48, 96, true>(a, st) : stem_launch<48, 96, false>(a, st);
   return a.x_bf16 ? stem_launch<32, 64, true>(a, st) : stem_launch<32, 64, false>(a, st);

@@ -499,6 +499,10 @@ extern "C" int lmv_linear_res_ln_fwd(const lmv_linear_problem* p, const lmv_ln_s
                                      float eps, int dtype, void* stream) {
   if (!lmv_linear_res_ln_fwd_supported(N, K, dtype)) LMV_FAIL(LMV_ERR_SHAPE, "linear_res_ln_fwd: N=%d K=%d dtype=%d (bf16, N = 384, K %% 64 == 0)", N, K, dtype);
   if (nproblems < 1 || nproblems > 2 || !p || !seg || !gamma || !beta || !(eps > 0.f)) LMV_FAIL(LMV_ERR_SHAPE, "linear_res_ln_fwd: null argument / nproblems must be 1 or 2");
+  double trows = 0., tbytes = 2.0 * N * K + 12.0 * N;          // A, residual in; out and LayerNorm(out) out
+  if (g_lmv_timing_on)
+    for (int i = 0; i < nproblems; ++i) { trows += (double)p[i].rows; tbytes += 2.0 * p[i].rows * (K + 3.0 * N); }
+  LmvTimedLaunch timed(stream, 2.0 * N * K * trows, tbytes);
   WnArgs a{};
   int npan[2] = {0, 0};
   for (int i = 0; i < nproblems; ++i) {

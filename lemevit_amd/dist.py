@@ -139,7 +139,15 @@ class FlatGradSync:
         if self._opt is not None:
             # model.zero_grad() (set_to_none) un-binds p.grad from the flat buffer: the block backward then hands its gradients to autograd,
             # no chunk callback fires, and the flat buffer would be exchanged stale.  Re-bind (copying stray gradients in) BEFORE sending.
-            self._opt.rebind_grads()
+            touched = self._opt.rebind_grads()
+            # A chunk whose all-reduce already started during the backward pass (some of its parameters were still bound, so its callback fired) must not be
+            # rewritten now: its slices would travel un-averaged, or be summed twice if the chunk were sent again -- the ranks would diverge silently.
+            for k in self._work:
+                s_, e_ = self.bounds[k]
+                if any(off < e_ and off + n > s_ for off, n in touched):
+                    raise RuntimeError("FlatGradSync.finish(): some block parameters had their .grad cleared or replaced (p.grad = None on a subset) while others of the same "
+                                       f"chunk {k} stayed bound to the flat gradient buffer, and that chunk's all-reduce had already started.  Clear gradients with "
+                                       "optimizer.zero_grad() / model.zero_grad() for ALL parameters (either way is handled), not for a subset.")
         if self.flat.is_cuda:
             from . import blocks as _blocks
             _blocks.drain_deferred()                     # the weight-gradient side stream has written every slice that is about to travel

@@ -1089,6 +1089,8 @@ class LeMeBlock(nn.Module):
         """x [B, H*W, C] token-major, c [B, M, C]."""
         if masks is None:
             masks = self._masks(x.shape[0], x.device)
+            if any(m is not None for m in masks):
+                _cache_filled()          # masks drawn HERE are kernels on the current stream: image_ranges() must re-fork its range streams behind them (ADVICE round 3)
         return run_block(self.kind, x, c, H, W, self._params(), masks)
 
     def forward(self, x: Tensor, c: Tensor) -> Tuple[Tensor, Tensor]:

@@ -99,13 +99,14 @@ class FlatAdamW:
         self._hook = model.register_load_state_dict_post_hook(lambda *_: self.refresh())
 
     # ---- the optimizer interface ---------------------------------------------------------------------------------
-    def _rebind(self, keep: bool) -> None:
+    def _rebind(self, keep: bool) -> list:
         """Every flat-managed ``p.grad`` must be a view of the flat gradient buffer.  ``model.zero_grad()`` (set_to_none=True) or
         ``p.grad = None`` breaks that: the block backward then hands the gradients to autograd, which allocates fresh ``.grad``
         tensors the fused update would never read.  keep=True copies such a stray gradient into its slice first (COPY, not add: a ``.grad`` that
         is not our view means the caller cleared or replaced the gradients since the slice was last bound, so whatever the slice still holds
         is stale -- e.g. the previous step's gradients after ``model.zero_grad()`` -- and autograd has accumulated every micro-batch since then
         into the stray tensor)."""
+        touched = []                                                   # (offset, length) of every slice whose CONTENT this call changed
         for i, (_, p, off, n) in enumerate(self._slices):
             g = p.grad
             if g is self._grad_views[i]:                               # the common case: one identity test per parameter
@@ -114,9 +115,12 @@ class FlatAdamW:
             if g is not None and g.data_ptr() != view.data_ptr():
                 if keep:
                     view.copy_(g.detach().to(view.dtype).view(view.shape))
+                    touched.append((off, n))
             elif g is None and keep:
                 view.zero_()                                               # cleared and not re-computed: no gradient (the slice would be stale)
+                touched.append((off, n))
             p.grad = view
+        return touched
 
     def zero_grad(self, set_to_none: bool = True) -> None:
         self._flat_g.zero_()                                           # the flat gradients stay allocated: the kernels accumulate into them
@@ -124,9 +128,10 @@ class FlatAdamW:
         if self._rest is not None:
             self._rest.zero_grad(set_to_none=set_to_none)
 
-    def rebind_grads(self) -> None:
-        """Public form of ``_rebind(keep=True)``: call before anything reads the flat gradient buffer directly (FlatGradSync.finish does)."""
-        self._rebind(keep=True)
+    def rebind_grads(self) -> list:
+        """Public form of ``_rebind(keep=True)``: call before anything reads the flat gradient buffer directly (FlatGradSync.finish does).  Returns the (offset, length)
+        slices of the flat buffer it rewrote."""
+        return self._rebind(keep=True)
 
     @torch.no_grad()
     def step(self) -> None:

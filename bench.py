@@ -302,7 +302,7 @@ def main():
         issue.append(time.perf_counter() - ti)
     sync()
     t_issued = sorted(issue)[len(issue) // 2] * args.steps if issue else None
-    kernel_timing_note, probe = None, None
+    kernel_timing_note, probe, probe_alone = None, None, None
     if not args.no_kernel_timing:
         # Same schedule as the timed region: 3 eager steps right AFTER it with the library's launch-timing probe on (lmv_debug_launch_timing: HIP events around
         # every forward-form Linear entry point and every persistent stage / stem launch, recorded on the stream the launch is issued on -- the native block
@@ -316,14 +316,32 @@ def main():
         for _ in range(3):
             eager_step()
         sync()
-        if rank == 0:
+        def read_probe():
             ms, fl, by, kd = (ctypes.c_float * cap)(), (ctypes.c_double * cap)(), (ctypes.c_double * cap)(), (ctypes.c_int * cap)()
             n = _L.lib.lmv_debug_launch_timing_read(ms, fl, by, kd, cap)
             _L.lib.lmv_debug_launch_timing(0)
-            probe = {}
+            out = {}
             for i in range(n):
-                e = probe.setdefault(kd[i], dict(launches=0, total_ms=0.0, flops=0.0, bytes=0.0))
+                e = out.setdefault(kd[i], dict(launches=0, total_ms=0.0, flops=0.0, bytes=0.0))
                 e["launches"] += 1; e["total_ms"] += ms[i]; e["flops"] += fl[i]; e["bytes"] += by[i]
+            return out
+        if rank == 0:
+            probe = read_probe()
+        # ... and, for continuity with rounds 1 - 3, the same kernels launched ALONE on the chip: the per-launch Python schedule of the blocks (whole-batch launches,
+        # lemevit_amd/blocks.py), one stream for the forward pass; reported beside the primary figure as roofline.frac_whole_batch_launches
+        import lemevit_amd.model as _model
+        native_was = _model._NATIVE
+        if train:
+            _model._NATIVE = False          # (--mode infer keeps the persistent stage launches: there "alone" means the whole batch on one stream)
+        parts_was, args.infer_parts = args.infer_parts, 1
+        if rank == 0:
+            _L.check(_L.lib.lmv_debug_launch_timing(cap), "lmv_debug_launch_timing")
+        for _ in range(2):
+            eager_step()
+        sync()
+        probe_alone = read_probe() if rank == 0 else None
+        args.infer_parts = parts_was
+        _model._NATIVE = native_was
         kernel_timing_note = ("HIP events of the library's launch-timing probe (lmv_debug_launch_timing) around every launch of this kind in 3 eager steps run right after the timed "
                               "region, on the timed region's own schedule (native block calls, concurrent ranges of images / sub-batches, weight-gradient GEMMs on the side stream) and on "
                               "the launch's own stream: launches that overlap on the chip share it, so the sum of their durations exceeds the wall time they cover (round 3 timed whole-batch "
@@ -408,6 +426,7 @@ def main():
                         hbm_gbs=round(hbm_gbs, 1), hbm_peak_gbs=PEAK_HBM_GBS, hbm_frac=round(hbm_gbs / PEAK_HBM_GBS, 4),
                         traffic_over_algorithmic=None if traffic is None else round(traffic / g["mbytes_per_launch"], 3),
                         kernel=KIND_NAMES.get(gkind, str(gkind)), measured=kernel_timing_note,
+                        frac_whole_batch_launches=None if not (probe_alone and gkind in probe_alone) else round(probe_alone[gkind]["flops"] / (probe_alone[gkind]["total_ms"] * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4),
                         other_launch_kinds={KIND_NAMES[k].split(" ")[0].split(":")[0]: dict(launches=v["launches"], ms_per_step=round(v["total_ms"] / 3, 3), tflops=round(v["flops"] / (v["total_ms"] * 1e-3) / 1e12, 1))
                                             for k, v in probe.items() if k != gkind}, launches=g["launches"], avg_launch_us=round(g["avg_us"], 2),
                         gflop_per_launch=round(g["gflop_per_launch"], 3))

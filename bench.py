@@ -427,7 +427,7 @@ def main():
                         traffic_over_algorithmic=None if traffic is None else round(traffic / g["mbytes_per_launch"], 3),
                         kernel=KIND_NAMES.get(gkind, str(gkind)), measured=kernel_timing_note,
                         frac_whole_batch_launches=None if not (probe_alone and gkind in probe_alone) else round(probe_alone[gkind]["flops"] / (probe_alone[gkind]["total_ms"] * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4),
-                        other_launch_kinds={KIND_NAMES[k].split(" ")[0].split(":")[0]: dict(launches=v["launches"], ms_per_step=round(v["total_ms"] / 3, 3), tflops=round(v["flops"] / (v["total_ms"] * 1e-3) / 1e12, 1))
+                        other_launch_kinds={{0: "forward_linear_launches", 1: "sstage_kernel", 2: "dstage_kernel", 3: "stem_kernel"}.get(k, str(k)): dict(launches=v["launches"], ms_per_step=round(v["total_ms"] / 3, 3), tflops=round(v["flops"] / (v["total_ms"] * 1e-3) / 1e12, 1))
                                             for k, v in probe.items() if k != gkind}, launches=g["launches"], avg_launch_us=round(g["avg_us"], 2),
                         gflop_per_launch=round(g["gflop_per_launch"], 3))
         line = {

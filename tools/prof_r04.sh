@@ -8,6 +8,7 @@ python bench.py --mode infer --no-cpu-baseline > $O/bench_infer.json 2>> $O/benc
 python bench.py --mode infer --no-cpu-baseline --infer-parts 1 > $O/bench_infer_one_stream.json 2>> $O/bench_train.err
 LMV_SSTAGE=0 python bench.py --mode infer --no-cpu-baseline > $O/bench_infer_per_block_schedule.json 2>> $O/bench_train.err
 LMV_DSTAGE=0 python bench.py --mode infer --no-cpu-baseline > $O/bench_infer_no_dstage.json 2>> $O/bench_train.err
+LMV_STEM=0 python bench.py --mode infer --no-cpu-baseline > $O/bench_infer_no_stem.json 2>> $O/bench_train.err
 rocprofv3 --kernel-trace --stats -d $O/kt -o trace -- python bench.py --no-cpu-baseline --no-kernel-timing --no-issue-probe --no-forward-probe > $O/bench_under_rocprof.log 2>&1
 DB=$(find $O/kt -name "*.db" | head -1)
 python tools/rocpd_stats.py $DB > $O/train_kernel_stats_full.csv
@@ -28,10 +29,11 @@ python bench.py --model lemevit_tiny --batch 256 --no-cpu-baseline --no-forward-
 python bench.py --img 384 --batch 64 --mode infer --no-cpu-baseline > $O/bench_base384_b64_infer.json 2>/dev/null
 python bench.py --img 384 --batch 64 --no-cpu-baseline --no-forward-probe > $O/bench_base384_b64_train.json 2>/dev/null
 python tools/sstage_timeline.py 5 > $O/sstage_timeline.txt 2>&1
+(python tools/stem_timeline.py 48 96 128; python tools/stem_timeline.py 32 64 256) > $O/stem_timeline.txt 2>&1
 (python tools/dstage_timeline.py 1 128 4 192; python tools/dstage_timeline.py 1 128 4 96; python tools/dstage_timeline.py 1 256 2 128; python tools/dstage_timeline.py 1 256 2 64) > $O/dstage_timeline.txt 2>&1
 (python tools/stage_times.py lemevit_base 128; python tools/stage_times.py lemevit_tiny 256; python tools/stage_times.py lemevit_small 128) > $O/stage_times.txt 2>&1
 python bench.py --model lemevit_tiny --batch 256 --mode infer --no-cpu-baseline --infer-parts 1 > $O/bench_tiny224_b256_infer_one_stream.json 2>/dev/null
 python bench.py --model lemevit_small --mode infer --no-cpu-baseline > $O/bench_small224_b128_infer.json 2>/dev/null
 bash tools/prof_infer.sh $O/tiny_infer_kernel_stats.csv --infer-parts 1 --model lemevit_tiny --batch 256 > $O/prof_infer_tiny.log 2>&1
-for f in bench_train bench_infer bench_infer_one_stream bench_infer_per_block_schedule bench_infer_no_dstage bench_tiny224_b256_infer bench_tiny224_b256_infer_one_stream bench_small224_b128_infer bench_tiny224_b256_train bench_base384_b64_infer bench_base384_b64_train; do echo "$f: $(tail -1 $O/$f.json | cut -c1-170)"; done
+for f in bench_train bench_infer bench_infer_one_stream bench_infer_per_block_schedule bench_infer_no_dstage bench_infer_no_stem bench_tiny224_b256_infer bench_tiny224_b256_infer_one_stream bench_small224_b128_infer bench_tiny224_b256_train bench_base384_b64_infer bench_base384_b64_train; do echo "$f: $(tail -1 $O/$f.json | cut -c1-170)"; done
 head -12 $O/train_step_breakdown.csv; head -8 $O/train_hbm_traffic.json; head -6 $O/infer_hbm_traffic.json; cat $O/gemm_fwd_pmc_traffic.json | head -5

@@ -10,10 +10,13 @@ with torch.no_grad(), torch.autocast("cuda", torch.bfloat16):
     with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True) as prof:
         m(x); torch.cuda.synchronize()
 cnt = collections.Counter()
-for ev in prof.events():
-    if ev.name in ("aten::copy_", "aten::clone", "aten::contiguous", "aten::_to_copy") and ev.stack:
-        fr = [s for s in ev.stack if "lemevit_amd" in s][:2]
+evs = list(prof.events())
+print(len(evs))
+names = collections.Counter(e.name for e in evs)
+print([ (k, v) for k, v in names.items() if "opy" in k or "emcpy" in k or "emset" in k])
+for ev in evs:
+    if ev.name in ("aten::copy_", "aten::clone", "aten::contiguous", "aten::_to_copy", "aten::zero_", "aten::fill_", "aten::cat") :
+        fr = [s for s in (ev.stack or []) if "lemevit_amd" in s][:2]
         cnt[(ev.name, tuple(fr))] += 1
-for k, v in cnt.most_common(25):
+for k, v in cnt.most_common(30):
     print(v, k)
-print([ (e.key, e.count) for e in prof.key_averages() if "emcpy" in e.key or "copyBuffer" in e.key])

@@ -451,8 +451,9 @@ int lmv_sstage_fwd(const lmv_sstage_desc* d, const void* x, const void* c, void*
  *   lmv_dstage_pack: one block's parameters (matrices bf16, vectors fp32, the reference's layouts: attn.qkv1 / attn.qkv2 [3C, C], attn.proj_x /
  *     attn.proj_c [C, C], mlp.0 [4C, C], mlp.3 [C, 4C], pos_embed.weight [C, 9]) -> wpk_out / vec_out; blocks of a stage consecutive as for lmv_sstage_pack.
  *   lmv_dstage_fwd: x_out / c_out must NOT alias x / c.  `workspace`: lmv_dstage_workspace_bytes(B, C) (exchange buffers and flags of the image
- *     slots; flags reset by the call on `stream`).  All 8 (29) workgroups of an image slot must be co-resident (256 threads / 74 KB LDS each, two per CU; 128 / 37 KB, four per CU):
- *     not to be issued while another persistent stage kernel runs on a different stream of the same device.
+ *     slots; flags reset by the call on `stream`; one workspace per concurrent call).  All 8 (29) workgroups of an image slot must be co-resident (256 threads / 74 KB LDS each, two per CU;
+ *     128 / 37 KB, four per CU).  Concurrent calls on different streams are safe up to FOUR at a time (lemevit_amd.graph.split_forward issues that many): workgroups are dispatched in index
+ *     order and slots come in groups of 8 (64 / 232 workgroups), so each call has at most one partially resident group and the rest of the chip always runs complete groups.
  * ------------------------------------------------------------------------------------------ */
 typedef struct lmv_dstage_block_params {
   int32_t C, heads, hidden, _pad;

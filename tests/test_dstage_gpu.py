@@ -148,6 +148,31 @@ def test_dstage_handoffs_under_uneven_load(C, G, nblocks, B):
         assert torch.equal(out[0], ref[0]) and torch.equal(out[1], ref[1]), rnd
 
 
+@pytest.mark.parametrize("C,G,nblocks", [(192, 28, 4), (96, 56, 4)])
+def test_dstage_four_concurrent_launches(C, G, nblocks):
+    """graph.split_forward issues the sub-batches of a forward pass on 4 streams: 4 persistent launches that together ask for more co-resident workgroups than the chip
+    holds (stage 1: 4 x 928 of 1024).  Workgroups are dispatched in index order and a slot group (8 slots, one per XCD) is 64 / 232 workgroups, so at most one group per launch
+    is ever partially resident and the rest of the chip runs complete groups: progress is guaranteed up to 4 launches.  Outputs must equal the one-launch result
+    of the same images bit for bit, and nothing may time out."""
+    from lemevit_amd import ops
+    sds = _stage_params(nblocks, 31, C)
+    P = _pack(sds)
+    B = 128
+    x, c = _inputs(B, 8, C, G)
+    x, c = x.to(DEV), c.to(DEV)
+    ref = ops.dstage_fwd(x, c, P, G, G, 1e-6)
+    torch.cuda.synchronize()
+    streams = [torch.cuda.Stream() for _ in range(4)]
+    for rnd in range(3):
+        outs = []
+        for k, st in enumerate(streams):
+            st.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(st):
+                outs.append(ops.dstage_fwd(x[32 * k:32 * k + 32].contiguous(), c[32 * k:32 * k + 32].contiguous(), P, G, G, 1e-6))
+        torch.cuda.synchronize()
+        for k, (xo, co) in enumerate(outs):
+            assert torch.equal(xo, ref[0][32 * k:32 * k + 32]) and torch.equal(co, ref[1][32 * k:32 * k + 32]), (rnd, k)
+
 # ---- "C" blocks (stage 0: CrossAttention, only the meta tokens change) through the same kernel (kind = 1) ----
 def _cstage(nblocks, seed, C):
     sds = []

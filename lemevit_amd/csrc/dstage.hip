@@ -33,9 +33,10 @@ template <int NW, int GW, int CTILES> struct DG {
   static constexpr int PRD = KS % 4 == 0 ? 4 : 3;                                  // ring depth of the proj units (CT tiles per k-step; KS = 2: the whole unit up front)
   static constexpr int URD = KS % 3 == 0 ? 3 : (KS % 4 == 0 ? 4 : 3);              // ring depth of the 2-tile units (q1, v1, k2 / v2 / q2, fc1)
   static_assert((CT * NW) % 2 == 0, "whole heads");
-  static constexpr int ROWS = 112 / GW, KWG = GW / ROWS, NIMG = GW * GW, NWG = KWG + 1;
+  static constexpr int NT = GW % 7 == 0 ? 7 : 6, TOK = 16 * NT;                   // token tiles / tokens of an image workgroup: 112 (56 x 56, 28 x 28 grids) or 96 (96 x 96, 48 x 48: 384 x 384 images)
+  static constexpr int ROWS = TOK / GW, KWG = GW / ROWS, NIMG = GW * GW, NWG = KWG + 1;
   static constexpr int CSUB = KWG % 2 == 0 ? 2 : 1, NWG_C = KWG / CSUB + 1;      // "C" blocks: row groups per image workgroup, workgroups per slot
-  static_assert(ROWS * GW == 112 && KWG * ROWS == GW, "an image workgroup is whole grid rows");
+  static_assert(ROWS * GW == TOK && KWG * ROWS == GW, "an image workgroup is whole grid rows");
   // packed weights of a block, 1 KB fragments (stage_common.h / sstage.hip: lane (g, i) holds W[row0 + i][32 ks + 16 (j >> 2) + 4 g + (j & 3)])
   static constexpr int WS_Q1 = 0;                                   // [head][ks][n 2]: rows 32 h + 16 n of qkv1.weight
   static constexpr int WS_V1 = WS_Q1 + NH * KS * 2;                 // [head][ks][n 2]: rows 2 C + 32 h + 16 n of qkv1.weight
@@ -53,10 +54,10 @@ template <int NW, int GW, int CTILES> struct DG {
   // LDS of an image workgroup (the meta workgroup uses the front of the same regions with one token tile)
   // L_H | L_XN in this order: the attention output (the proj_x operand, KS k-steps) is written from L_H on -- the heads of the first NW k-steps land in L_H while the
   // other waves still read the LayerNorm output in L_XN, only the last KS - NW wait (in registers) for the barrier
-  static constexpr int L_H = 0, L_H_BYTES = KSC * SS_NT * 1024;
-  static constexpr int L_XN = L_H_BYTES, L_XN_BYTES = KS * SS_NT * 1024;
+  static constexpr int L_H = 0, L_H_BYTES = KSC * NT * 1024;
+  static constexpr int L_XN = L_H_BYTES, L_XN_BYTES = KS * NT * 1024;
   static constexpr int L_AO = L_H;
-  static constexpr int L_STAT = L_XN + L_XN_BYTES, L_STAT_BYTES = NW * 112 * 8;
+  static constexpr int L_STAT = L_XN + L_XN_BYTES, L_STAT_BYTES = NW * TOK * 8;
   static constexpr int L_TOTAL = L_STAT + L_STAT_BYTES;
   static constexpr int STG_COLS = GW + 2, STG_ENT = (ROWS + 2) * STG_COLS, STG_WAVE = STG_ENT * 32;      // dwconv staging: [ROWS + 2][GW + 2] entries of 16 channels, bf16
   static_assert(NW * STG_WAVE <= L_STAT, "staging overlaps the statistics");
@@ -95,7 +96,7 @@ __device__ __forceinline__ void ds_layer_norm(const f32x4_t (&R)[NTT][CT], const
 #pragma unroll
       for (int r = 0; r < 4; ++r) { s1 += R[t][ct][r]; s2 = fmaf(R[t][ct][r], R[t][ct][r], s2); }
     s1 = xsum4(s1); s2 = xsum4(s2);
-    if (g == 0) stat[wave * 112 + t * 16 + li] = make_float2(s1, s2);
+    if (g == 0) stat[wave * (16 * NTT) + t * 16 + li] = make_float2(s1, s2);
   }
   float4 ga[CT], be[CT];
 #pragma unroll
@@ -106,7 +107,7 @@ __device__ __forceinline__ void ds_layer_norm(const f32x4_t (&R)[NTT][CT], const
   for (int t = 0; t < NTT; ++t) {
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-    for (int w = 0; w < NW; ++w) { const float2 p = stat[w * 112 + t * 16 + li]; s1 += p.x; s2 += p.y; }
+    for (int w = 0; w < NW; ++w) { const float2 p = stat[w * (16 * NTT) + t * 16 + li]; s1 += p.x; s2 += p.y; }
     mean[t] = s1 * (1.f / C);
     rstd[t] = rsqrtf(fmaxf(s2 * (1.f / C) - mean[t] * mean[t], 0.f) + eps);
   }
@@ -170,7 +171,7 @@ __device__ __forceinline__ void ds_mlp(f32x4_t (&R)[NTT][G::CT], const unsigned 
 template <int NW, int GW, int CT, int KIND>          // KIND: 0 "D" blocks, 1 "C" blocks
 __global__ __launch_bounds__(64 * NW, 2) void dstage_kernel(const DsArgs a) {
   using G = DG<NW, GW, CT>;
-  constexpr int C = G::C, NH = G::NH, KS = G::KS, KWG = G::KWG, ROWS = G::ROWS, CW = G::CW, URD = G::URD;
+  constexpr int C = G::C, NH = G::NH, KS = G::KS, KWG = G::KWG, ROWS = G::ROWS, CW = G::CW, URD = G::URD, NT = G::NT, TOK = G::TOK, NP = (NT + 1) / 2;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane0 = tid & 63, wave0 = __builtin_amdgcn_readfirstlane(tid >> 6);
 #define DS_PHASE                                                    \
@@ -276,8 +277,13 @@ __global__ __launch_bounds__(64 * NW, 2) void dstage_kernel(const DsArgs a) {
         if (wave0 == 0) {          // lane r polls the flag of image workgroup r
           unsigned spins = 0;
           while (true) {
-            const unsigned v = lane0 < KWG ? __hip_atomic_load((gu32*)(partflag + lane0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0xffffffffu;
-            if (__all(v >= (unsigned)(gb + 1))) break;
+            bool ok = true;
+#pragma unroll
+            for (int r0 = 0; r0 < KWG; r0 += 64) {
+              const unsigned v = r0 + lane0 < KWG ? __hip_atomic_load((gu32*)(partflag + r0 + lane0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0xffffffffu;
+              ok = ok && v >= (unsigned)(gb + 1);
+            }
+            if (__all(ok)) break;
             __builtin_amdgcn_s_sleep(2);
             if (++spins > SPIN_LIMIT) { if (lane0 == 0) __hip_atomic_store((gu32*)errflag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
           }
@@ -289,36 +295,38 @@ __global__ __launch_bounds__(64 * NW, 2) void dstage_kernel(const DsArgs a) {
           const __amdgpu_buffer_rsrc_t pr = __builtin_amdgcn_make_buffer_rsrc(part, 0, (int)G::PART_BYTES, 0x00020000);
 #pragma unroll 1
           for (int h = wave; h < NH; h += NW) {
-            // (all (max, sum) words first, then the partial sums 7 workgroups at a time: the loads of a batch are in flight together -- one at a time this
-            //  loop was 28 x 2 dependent L2 round trips, 50 us per block at stage 1, and the whole image waited on it)
+            // (two passes over the KWG partials, CB workgroups per batch of loads: the loads of a batch are in flight together -- one at a time this was 28 x 2 dependent L2 round
+            //  trips, 50 us per block at stage 1, and the whole image waited on it)
             typedef __attribute__((ext_vector_type(2))) unsigned u32x2_t;
-            float mr[KWG], lr[KWG];
+            constexpr int CB = KWG % 8 == 0 ? 8 : 7;
+            static_assert(KWG % CB == 0, "batches of partials");
+            float M = -INFINITY;
+#pragma unroll 1
+            for (int r0 = 0; r0 < KWG; r0 += CB) {
+              float mb[CB];
 #pragma unroll
-            for (int r = 0; r < KWG; ++r) {
-              const u32x2_t ml = __builtin_amdgcn_raw_buffer_load_b64(pr, (((r * NH + h) * 3 + 2) * 64 + lane) * 16, 0, 16);
-              mr[r] = __uint_as_float(ml[0]); lr[r] = __uint_as_float(ml[1]);
+              for (int k = 0; k < CB; ++k) mb[k] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(pr, ((((r0 + k) * NH + h) * 3 + 2) * 64 + lane) * 16, 0, 16));
+#pragma unroll
+              for (int k = 0; k < CB; ++k) M = max2(M, mb[k]);
             }
-            float M = mr[0];
-#pragma unroll
-            for (int r = 1; r < KWG; ++r) M = max2(M, mr[r]);
             f32x4_t o0 = {0.f, 0.f, 0.f, 0.f}, o1 = o0;
             float L = 0.f;
+#pragma unroll 1
+            for (int r0 = 0; r0 < KWG; r0 += CB) {
+              f32x4_t p0[CB], p1[CB]; u32x2_t ml[CB];
 #pragma unroll
-            for (int r0 = 0; r0 < KWG; r0 += 7) {
-              f32x4_t p0[7], p1[7];
-#pragma unroll
-              for (int k = 0; k < 7; ++k) {
+              for (int k = 0; k < CB; ++k) {
                 const int base = (((r0 + k) * NH + h) * 3 * 64 + lane) * 16;
                 p0[k] = __builtin_bit_cast(f32x4_t, __builtin_amdgcn_raw_buffer_load_b128(pr, base, 0, 16));
                 p1[k] = __builtin_bit_cast(f32x4_t, __builtin_amdgcn_raw_buffer_load_b128(pr, base + 1024, 0, 16));
+                ml[k] = __builtin_amdgcn_raw_buffer_load_b64(pr, base + 2048, 0, 16);
               }
 #pragma unroll
-              for (int k = 0; k < 7; ++k) {
-                const float w = __builtin_amdgcn_exp2f(mr[r0 + k] - M);
-                L = fmaf(lr[r0 + k], w, L);
+              for (int k = 0; k < CB; ++k) {
+                const float w = __builtin_amdgcn_exp2f(__uint_as_float(ml[k][0]) - M);
+                L = fmaf(__uint_as_float(ml[k][1]), w, L);
                 o0 += p0[k] * w; o1 += p1[k] * w;
               }
-              __builtin_amdgcn_sched_barrier(0);
             }
             const float inv = 1.f / L;
             const float* bv = vec + G::V_QKV1B + 2 * C + 32 * h + 4 * g;
@@ -372,26 +380,32 @@ __global__ __launch_bounds__(64 * NW, 2) void dstage_kernel(const DsArgs a) {
 
     asm volatile("; PHASE_IMG");
     // =================================== an image workgroup: 112 image tokens (ROWS grid rows) of image `img` ===================================
-    f32x4_t R[SS_NT][CT];
+    f32x4_t R[NT][CT];
     auto load_rows = [&](int first_token) {
       DS_PHASE
 #pragma unroll
-      for (int t = 0; t < SS_NT; ++t) {
+      for (int t = 0; t < NT; ++t) {
         const bf16_t* src = a.x_in + ((size_t)img * G::NIMG + first_token + 16 * t + li) * C;
 #pragma unroll
         for (int ct = 0; ct < CT; ++ct) { float f[4]; ld4(src + CW * wave + 16 * ct + 4 * g, f); R[t][ct] = f32x4_t{f[0], f[1], f[2], f[3]}; }
       }
     };
-    if constexpr (KIND == 0) load_rows(rolep * 112);
+    if constexpr (KIND == 0) load_rows(rolep * TOK);
 #pragma unroll 1
     for (int it = 0; it < a.nblocks * sub_n; ++it) {
-      const int blk = sub_n == 1 ? it : it / sub_n, role = sub_n == 1 ? rolep : rolep * sub_n + (it - blk * sub_n), tok0 = role * 112;      // role: the row group [role ROWS, (role + 1) ROWS)
+      const int blk = sub_n == 1 ? it : it / sub_n, role = sub_n == 1 ? rolep : rolep * sub_n + (it - blk * sub_n), tok0 = role * TOK;      // role: the row group [role ROWS, (role + 1) ROWS)
       const int gb = round * a.nblocks + blk;
       const int lane = lane0, wave = wave0;      // (stamps only)
       const unsigned char* const wp = reinterpret_cast<const unsigned char*>(a.wpk) + (size_t)blk * G::WS_FRAGS * 1024;
       const float* const vec = a.vec + (size_t)blk * G::V_FLOATS;
       if constexpr (KIND != 0) load_rows(tok0);          // "C" blocks return x as it came: the position embedding of a block only feeds its norm1, every block (and row group) starts from x_in
       DS_STAMP(0);
+      if (a.timing && gb == a.timing_block && lane0 == 0) {          // (placement probe: which CU / SE / XCD hosts this workgroup -- tools/dstage_timeline.py)
+        unsigned hw, xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        a.timing[((size_t)blockIdx.x * NW + wave0) * DS_NSTAMP + 15] = ((unsigned long long)xcc << 32) | hw;
+      }
       asm volatile("; PHASE_DW");
       // ---- x += dwconv3x3(x) + bias: per channel tile a wave-private bf16 image [ROWS + 2][GW + 2] of its 16 channels, zero pads, rows across the cuts from the peers ----
       {
@@ -419,7 +433,7 @@ __global__ __launch_bounds__(64 * NW, 2) void dstage_kernel(const DsArgs a) {
           }
           // own rows
 #pragma unroll
-          for (int t = 0; t < SS_NT; ++t) {
+          for (int t = 0; t < NT; ++t) {
             const int s = 16 * t + li, y = s / GW, x = s - y * GW;
             *reinterpret_cast<uint2*>(stg + ((y + 1) * G::STG_COLS + x + 1) * 32 + 8 * g) = make_uint2(pack_bf2(R[t][ct][0], R[t][ct][1]), pack_bf2(R[t][ct][2], R[t][ct][3]));
           }
@@ -438,7 +452,7 @@ __global__ __launch_bounds__(64 * NW, 2) void dstage_kernel(const DsArgs a) {
               u32x4_t hv = {0u, 0u, 0u, 0u};
               if (inside) {
                 u32x4_t v;
-                if (blk == 0 || KIND) v = *reinterpret_cast<const u32x4_t*>(a.x_in + ((size_t)img * G::NIMG + (side ? tok0 + 112 : tok0 - GW) + tok) * C + c0 + 8 * q);
+                if (blk == 0 || KIND) v = *reinterpret_cast<const u32x4_t*>(a.x_in + ((size_t)img * G::NIMG + (side ? tok0 + TOK : tok0 - GW) + tok) * C + c0 + 8 * q);
                 else {
                   const __amdgpu_buffer_rsrc_t hr = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(hprev), 0, (int)(G::HALO_BYTES / 2), 0x00020000);
                   v = __builtin_amdgcn_raw_buffer_load_b128(hr, (((nb * 2 + (side ? 0 : 1)) * GW + tok) * C + c0 + 8 * q) * 2, 0, 16);
@@ -460,7 +474,7 @@ __global__ __launch_bounds__(64 * NW, 2) void dstage_kernel(const DsArgs a) {
           }
           const float4 pb = wq[ct & 1][9];
 #pragma unroll
-          for (int t = 0; t < SS_NT; ++t) {
+          for (int t = 0; t < NT; ++t) {
             const int s = 16 * t + li, y = s / GW, x = s - y * GW;
             const unsigned char* const tap0 = stg + (y * G::STG_COLS + x) * 32 + 8 * g;      // entry of the (-1, -1) neighbour
             uint2 f[9];
@@ -488,7 +502,7 @@ __global__ __launch_bounds__(64 * NW, 2) void dstage_kernel(const DsArgs a) {
       // ---- norm1 -> LDS ----
       {
         DS_PHASE
-        ds_layer_norm<NW, SS_NT, CT>(R, vec + G::V_N1W, vec + G::V_N1B, a.eps, smem + G::L_XN, stat, wave, lane);
+        ds_layer_norm<NW, NT, CT>(R, vec + G::V_N1W, vec + G::V_N1B, a.eps, smem + G::L_XN, stat, wave, lane);
         if (wave == 0) wait_flag(mflag, (unsigned)(gb + 1), errflag, lane);      // the meta workgroup's fragments of this block
       }
       __syncthreads();
@@ -505,47 +519,49 @@ __global__ __launch_bounds__(64 * NW, 2) void dstage_kernel(const DsArgs a) {
 #pragma unroll 1
         for (int hu = 0; hu < nc; ++hu) {
           const int h = hu == 0 ? wave : NW + wave - NW / 2;
-          f32x4_t S[SS_NT];
+          f32x4_t S[NT];
 #pragma unroll
-          for (int t = 0; t < SS_NT; ++t) S[t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+          for (int t = 0; t < NT; ++t) S[t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
           for (int ks = 0; ks < KS; ++ks) {
             const bf16x8_t qt = as_bf8(__builtin_amdgcn_raw_buffer_load_b128(mr, ((h * G::MF_HEAD + 3 + ks) * 64 + lane) * 16, 0, 16));
 #pragma unroll
-            for (int t = 0; t < SS_NT; ++t) S[t] = mfma_bf16(*reinterpret_cast<const bf16x8_t*>(smem + G::L_XN + ((ks * SS_NT + t) * 64 + lane) * 16), qt, S[t]);
+            for (int t = 0; t < NT; ++t) S[t] = mfma_bf16(*reinterpret_cast<const bf16x8_t*>(smem + G::L_XN + ((ks * NT + t) * 64 + lane) * 16), qt, S[t]);
           }
           float m = -INFINITY;
 #pragma unroll
-          for (int t = 0; t < SS_NT; ++t) m = max2(m, max4(S[t]));
+          for (int t = 0; t < NT; ++t) m = max2(m, max4(S[t]));
           m = xmax4(m);
           float l = 0.f;
-          u32x4_t P[4];
+          u32x4_t P[NP];          // pairs of key tiles (the last pair of an odd tile count: one tile, zeros)
 #pragma unroll
-          for (int p = 0; p < 4; ++p) {
+          for (int p = 0; p < NP; ++p) {
+            constexpr int LAST = NT - 1;
+            const bool two = 2 * p + 1 < NT;
             float e[8];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) { e[r] = __builtin_amdgcn_exp2f(S[2 * p][r] - m); e[4 + r] = p < 3 ? __builtin_amdgcn_exp2f(S[p < 3 ? 2 * p + 1 : 0][r] - m) : 0.f; }
+            for (int r = 0; r < 4; ++r) { e[r] = __builtin_amdgcn_exp2f(S[2 * p][r] - m); e[4 + r] = two ? __builtin_amdgcn_exp2f(S[two ? 2 * p + 1 : LAST][r] - m) : 0.f; }
             l += ((e[0] + e[1]) + (e[2] + e[3])) + ((e[4] + e[5]) + (e[6] + e[7]));
             P[p] = u32x4_t{pack_h2(e[0], e[1]), pack_h2(e[2], e[3]), pack_h2(e[4], e[5]), pack_h2(e[6], e[7])};
           }
           l = xsum4(l);
           asm volatile("" : "+v"(l));
           // v1 of the head: D'[token][channel] (no bias: sum p = 1 after the combine, the meta workgroup adds it)
-          f32x4_t acc[SS_NT][2];
+          f32x4_t acc[NT][2];
 #pragma unroll
-          for (int t = 0; t < SS_NT; ++t) { acc[t][0] = f32x4_t{0.f, 0.f, 0.f, 0.f}; acc[t][1] = acc[t][0]; }
+          for (int t = 0; t < NT; ++t) { acc[t][0] = f32x4_t{0.f, 0.f, 0.f, 0.f}; acc[t][1] = acc[t][0]; }
           bf16x8_t ring[URD][2];
           const unsigned char* wcur = wp + (size_t)(G::WS_V1 + h * (2 * KS)) * 1024;
           ring_fill<2, URD>(ring, wcur, lane);
-          gemm_unit<2, KS, URD, false>(acc, ring, wcur, wcur, smem + G::L_XN, lane);
+          gemm_unit<2, KS, URD, false, NT>(acc, ring, wcur, wcur, smem + G::L_XN, lane);
           f32x4_t O[2] = {f32x4_t{0.f, 0.f, 0.f, 0.f}, f32x4_t{0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
-          for (int p = 0; p < 4; ++p)
+          for (int p = 0; p < NP; ++p)
 #pragma unroll
             for (int dt = 0; dt < 2; ++dt) {
               const f32x4_t lo = acc[2 * p][dt];
               u32x4_t vk = {pack_h2(lo[0], lo[1]), pack_h2(lo[2], lo[3]), 0u, 0u};
-              if (p < 3) { const f32x4_t hi = acc[p < 3 ? 2 * p + 1 : 0][dt]; vk[2] = pack_h2(hi[0], hi[1]); vk[3] = pack_h2(hi[2], hi[3]); }
+              if (2 * p + 1 < NT) { const f32x4_t hi = acc[2 * p + 1 < NT ? 2 * p + 1 : 0][dt]; vk[2] = pack_h2(hi[0], hi[1]); vk[3] = pack_h2(hi[2], hi[3]); }
               O[dt] = mfma_f16(__builtin_bit_cast(f16x8_t, vk), __builtin_bit_cast(f16x8_t, P[p]), O[dt]);
             }
           const int pbase = ((role * NH + h) * 3 * 64 + lane) * 16;
@@ -564,7 +580,7 @@ __global__ __launch_bounds__(64 * NW, 2) void dstage_kernel(const DsArgs a) {
       asm volatile("; PHASE_XDIR");
       // ---- x-direction: per head, q1 of the 112 tokens, softmax over the 16 meta keys, P V2; the proj_x operand fragments wait in registers ----
       const int nx = wave0 + NW < NH ? 2 : 1;
-      u32x4_t AO1[SS_NT];          // the second head of waves 0 .. NW / 2 - 1
+      u32x4_t AO1[NT];          // the second head of waves 0 .. NW / 2 - 1
       {
         DS_PHASE
         bf16x8_t ring[URD][2];
@@ -579,13 +595,13 @@ __global__ __launch_bounds__(64 * NW, 2) void dstage_kernel(const DsArgs a) {
             ring_fill<2, URD>(ring, wcur, lane);
             const float* bq = vec + G::V_QKV1B + 32 * h + 4 * g;
             const float4 b0 = *reinterpret_cast<const float4*>(bq), b1 = *reinterpret_cast<const float4*>(bq + 16);
-            f32x4_t acc[SS_NT][2];
+            f32x4_t acc[NT][2];
 #pragma unroll
-            for (int t = 0; t < SS_NT; ++t) { acc[t][0] = f32x4_t{0.f, 0.f, 0.f, 0.f}; acc[t][1] = acc[t][0]; }
-            gemm_unit<2, KS, URD, true>(acc, ring, wcur, wcur, smem + G::L_XN, lane);
+            for (int t = 0; t < NT; ++t) { acc[t][0] = f32x4_t{0.f, 0.f, 0.f, 0.f}; acc[t][1] = acc[t][0]; }
+            gemm_unit<2, KS, URD, true, NT>(acc, ring, wcur, wcur, smem + G::L_XN, lane);
             const f32x4_t z4 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int t = 0; t < SS_NT; ++t) {
+            for (int t = 0; t < NT; ++t) {
               const f32x4_t q0 = {(acc[t][0][0] + b0.x) * a.sx, (acc[t][0][1] + b0.y) * a.sx, (acc[t][0][2] + b0.z) * a.sx, (acc[t][0][3] + b0.w) * a.sx};
               const f32x4_t q1 = {(acc[t][1][0] + b1.x) * a.sx, (acc[t][1][1] + b1.y) * a.sx, (acc[t][1][2] + b1.z) * a.sx, (acc[t][1][3] + b1.w) * a.sx};
               const f32x4_t s = mfma_bf16(as_bf8(k2), as_bf8(pack_bf8(q0, q1)), z4);          // S^T[key][query]
@@ -598,7 +614,7 @@ __global__ __launch_bounds__(64 * NW, 2) void dstage_kernel(const DsArgs a) {
               const f16x8_t pf = __builtin_bit_cast(f16x8_t, pk);
               const f32x4_t o0 = mfma_f16(__builtin_bit_cast(f16x8_t, v20), pf, z4), o1 = mfma_f16(__builtin_bit_cast(f16x8_t, v21), pf, z4);
               const u32x4_t ao = pack_bf8(o0 * inv, o1 * inv);
-              if (hu == 0) *reinterpret_cast<u32x4_t*>(smem + G::L_AO + ((h * SS_NT + t) * 64 + lane) * 16) = ao;
+              if (hu == 0) *reinterpret_cast<u32x4_t*>(smem + G::L_AO + ((h * NT + t) * 64 + lane) * 16) = ao;
               else AO1[t] = ao;
             }
           }
@@ -611,7 +627,7 @@ __global__ __launch_bounds__(64 * NW, 2) void dstage_kernel(const DsArgs a) {
         DS_PHASE
         const int h = wave + NW;
 #pragma unroll
-        for (int t = 0; t < SS_NT; ++t) *reinterpret_cast<u32x4_t*>(smem + G::L_AO + ((h * SS_NT + t) * 64 + lane) * 16) = AO1[t];
+        for (int t = 0; t < NT; ++t) *reinterpret_cast<u32x4_t*>(smem + G::L_AO + ((h * NT + t) * 64 + lane) * 16) = AO1[t];
       }
       __syncthreads();
       DS_STAMP(4);
@@ -625,17 +641,17 @@ __global__ __launch_bounds__(64 * NW, 2) void dstage_kernel(const DsArgs a) {
         bf16x8_t ringp[G::PRD][CT];
         const unsigned char* wcur = wp + (size_t)(G::WS_PX + wave * (CT * KS)) * 1024;
         ring_fill<CT, G::PRD>(ringp, wcur, lane);
-        gemm_unit<CT, KS, G::PRD, true>(R, ringp, wcur, wcur, smem + G::L_AO, lane);
+        gemm_unit<CT, KS, G::PRD, true, NT>(R, ringp, wcur, wcur, smem + G::L_AO, lane);
 #pragma unroll
         for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
-          for (int t = 0; t < SS_NT; ++t) { R[t][ct][0] += pb[ct].x; R[t][ct][1] += pb[ct].y; R[t][ct][2] += pb[ct].z; R[t][ct][3] += pb[ct].w; }
+          for (int t = 0; t < NT; ++t) { R[t][ct][0] += pb[ct].x; R[t][ct][1] += pb[ct].y; R[t][ct][2] += pb[ct].z; R[t][ct][3] += pb[ct].w; }
         __syncthreads();          // every wave has read the proj_x operand: norm2 may overwrite it
-        ds_layer_norm<NW, SS_NT, CT>(R, vec + G::V_N2W, vec + G::V_N2B, a.eps, smem + G::L_XN, stat, wave, lane);
+        ds_layer_norm<NW, NT, CT>(R, vec + G::V_N2W, vec + G::V_N2B, a.eps, smem + G::L_XN, stat, wave, lane);
       }
       DS_STAMP(5);
       asm volatile("; PHASE_MLP");
-      ds_mlp<NW, SS_NT, G>(R, wp, vec, smem + G::L_XN, smem + G::L_H, lane0, wave0);
+      ds_mlp<NW, NT, G>(R, wp, vec, smem + G::L_XN, smem + G::L_H, lane0, wave0);
       DS_STAMP(6);
       asm volatile("; PHASE_END");
       // ---- block end: + mlp.3.bias; the first and the last grid row go to the neighbours ----
@@ -645,15 +661,15 @@ __global__ __launch_bounds__(64 * NW, 2) void dstage_kernel(const DsArgs a) {
         for (int ct = 0; ct < CT; ++ct) {
           const float4 b = *reinterpret_cast<const float4*>(vec + G::V_FC2B + CW * wave + 16 * ct + 4 * g);
 #pragma unroll
-          for (int t = 0; t < SS_NT; ++t) { R[t][ct][0] += b.x; R[t][ct][1] += b.y; R[t][ct][2] += b.z; R[t][ct][3] += b.w; }
+          for (int t = 0; t < NT; ++t) { R[t][ct][0] += b.x; R[t][ct][1] += b.y; R[t][ct][2] += b.z; R[t][ct][3] += b.w; }
         }
         unsigned char* const hcur = halo + (size_t)(gb & 1) * (G::HALO_BYTES / 2);
 #pragma unroll
-        for (int t = 0; t < SS_NT; ++t) {
+        for (int t = 0; t < NT; ++t) {
           const int s = 16 * t + li;
 #pragma unroll
           for (int side = 0; side < 2; ++side) {
-            const int tok = side ? s - (112 - GW) : s;
+            const int tok = side ? s - (TOK - GW) : s;
             if ((unsigned)tok < (unsigned)GW) {
               bf16_t* dst = reinterpret_cast<bf16_t*>(hcur) + ((size_t)(role * 2 + side) * GW + tok) * C + CW * wave + 4 * g;
 #pragma unroll
@@ -674,8 +690,8 @@ __global__ __launch_bounds__(64 * NW, 2) void dstage_kernel(const DsArgs a) {
     {
       DS_PHASE
 #pragma unroll
-      for (int t = 0; t < SS_NT; ++t) {
-        bf16_t* dst = a.x_out + ((size_t)img * G::NIMG + rolep * 112 + 16 * t + li) * C;          // ("D" blocks: role = rolep)
+      for (int t = 0; t < NT; ++t) {
+        bf16_t* dst = a.x_out + ((size_t)img * G::NIMG + rolep * TOK + 16 * t + li) * C;          // ("D" blocks: role = rolep)
 #pragma unroll
         for (int ct = 0; ct < CT; ++ct) {
           const float f[4] = {R[t][ct][0], R[t][ct][1], R[t][ct][2], R[t][ct][3]};
@@ -766,31 +782,41 @@ template <int NW, int GW, int CT, int KIND> static int ds_launch_kind(const lmv_
   return LMV_OK;
 }
 template <int NW, int GW, int CT> static int ds_launch(const lmv_dstage_desc* d, const void* x, const void* c, void* x_out, void* c_out, void* workspace, hipStream_t st) {
-  if constexpr (GW == 56) {          // "C" blocks exist at stage 0 only (56 x 56 image tokens)
+  if constexpr (GW == 56 || GW == 96) {          // "C" blocks exist at stage 0 only (the resolution of stage 1)
     if (d->kind) return ds_launch_kind<NW, GW, CT, 1>(d, x, c, x_out, c_out, workspace, st);
-  } else if (d->kind) LMV_FAIL(LMV_ERR_DTYPE, "dstage_fwd: C blocks are built for the 56 x 56 stage only");
+  } else if (d->kind) LMV_FAIL(LMV_ERR_DTYPE, "dstage_fwd: C blocks are built for the stage-0 / stage-1 grid only");
   return ds_launch_kind<NW, GW, CT, 0>(d, x, c, x_out, c_out, workspace, st);
 }
 
 }  // namespace
 
 // ---- C ABI --------------------------------------------------------------------------------------------------------------------------
-// the four instances: 10 NW + CT
-#define DS_DISPATCH(code, EXPR, DFLT)                                                        \
-  ((code) == 43 ? EXPR(4, 28, 3) : (code) == 23 ? EXPR(2, 56, 3) : (code) == 42 ? EXPR(4, 28, 2) : (code) == 22 ? EXPR(2, 56, 2) : (DFLT))
-static int ds_code_of_c(int C) { return C == 192 ? 43 : C == 96 ? 23 : C == 128 ? 42 : C == 64 ? 22 : 0; }
-static int ds_variant(int C, int heads, int hidden, int H, int W, int M) {      // stages 2 / 1 of LeMeViT-Base and -Small (C = 192 at 28 x 28, C = 96 at 56 x 56), of LeMeViT-Tiny (128, 64); 0: not supported
+// the instances: 1000 NW + 10 GW + CT.  224 x 224 images: (4, 28, 3) / (2, 56, 3) LeMeViT-Base and -Small, (4, 28, 2) / (2, 56, 2) LeMeViT-Tiny; 384 x 384 (BASELINE config 5): (4, 48, 3) / (2, 96, 3)
+#define DS_DISPATCH(code, EXPR, DFLT)                                                                                                                   \
+  ((code) == 4283 ? EXPR(4, 28, 3) : (code) == 2563 ? EXPR(2, 56, 3) : (code) == 4282 ? EXPR(4, 28, 2) : (code) == 2562 ? EXPR(2, 56, 2) : (code) == 4483 ? EXPR(4, 48, 3) : \
+   (code) == 2963 ? EXPR(2, 96, 3) : (DFLT))
+static int ds_code_of_c(int C) { return C == 192 ? 4283 : C == 96 ? 2563 : C == 128 ? 4282 : C == 64 ? 2562 : 0; }          // (what depends on C only: the packed layout)
+static int ds_code(int C, int H) {
+  if (C == 192) return H == 28 ? 4283 : H == 48 ? 4483 : 0;
+  if (C == 96) return H == 56 ? 2563 : H == 96 ? 2963 : 0;
+  if (C == 128) return H == 28 ? 4282 : 0;
+  if (C == 64) return H == 56 ? 2562 : 0;
+  return 0;
+}
+static int ds_variant(int C, int heads, int hidden, int H, int W, int M) {      // 0: not supported
   if (M != DS_M || H != W || heads != C / 32 || hidden != 4 * C) return 0;
-  const int code = ds_code_of_c(C);
-  if (!code) return 0;
-  return H == (code / 10 == 4 ? 28 : 56) ? code : 0;
+  return ds_code(C, H);
 }
 int lmv_dstage_supported(int C, int heads, int hidden, int H, int W, int M, int dtype) { return dtype == LMV_BF16 && ds_variant(C, heads, hidden, H, W, M) != 0; }
 #define DS_WPK(NW, GW, CT) ((size_t)DG<NW, GW, CT>::WS_FRAGS * 1024)
 size_t lmv_dstage_wpk_bytes(int C, int hidden) { (void)hidden; const int code = ds_code_of_c(C); return DS_DISPATCH(code, DS_WPK, (size_t)0); }
 size_t lmv_dstage_vec_floats(int C, int hidden) { (void)hidden; return (size_t)27 * C; }
 #define DS_WS(NW, GW, CT) ds_workspace<NW, GW, CT>(B)
-size_t lmv_dstage_workspace_bytes(int B, int C) { const int code = ds_code_of_c(C); return DS_DISPATCH(code, DS_WS, (size_t)0); }
+size_t lmv_dstage_workspace_bytes(int B, int C) {          // (any grid the kernel takes at this C)
+  const int code = ds_code_of_c(C), code2 = C == 192 ? 4483 : C == 96 ? 2963 : 0;
+  const size_t a = DS_DISPATCH(code, DS_WS, (size_t)0), b = DS_DISPATCH(code2, DS_WS, (size_t)0);
+  return a > b ? a : b;
+}
 
 int lmv_dstage_pack(const lmv_dstage_block_params* p, void* wpk_out, float* vec_out, void* stream) {
   if (!p || !wpk_out || !vec_out) LMV_FAIL(LMV_ERR_SHAPE, "dstage_pack: null argument");

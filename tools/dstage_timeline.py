@@ -72,3 +72,28 @@ for nm, t, names in (("image workgroup", img, ["halo wait + dwconv", "norm1 + me
 print("image workgroup 0 per wave:")
 for w in range(NWV):
     print("  wave", w, " ".join(f"{v:6.0f}" for v in np.diff(traw[0, w, :8])))
+# per role (row group of the image): is one of them systematically late?
+tr = traw[role < KWG][:, :, :8]
+rr = role[role < KWG]
+ok = tr[:, 0, 0] > 0
+print("per role: mean start skew vs the image's first workgroup, dwconv phase, whole block")
+slot_of = (np.arange(nwg) // 8 // (KWG + 1)) * 8 + (np.arange(nwg) % 8)
+so = slot_of[role < KWG]
+t0 = tr[:, 0, 0]
+for r in range(KWG):
+    sel = ok & (rr == r)
+    if not sel.any(): continue
+    base = np.array([t0[ok & (so == s)].min() for s in so[sel]])
+    print(f"  role {r:2d}: start +{np.mean(t0[sel] - base):7.0f}   dwconv {np.mean(tr[sel][:, 0, 1] - tr[sel][:, 0, 0]):7.0f}   block {np.mean(tr[sel][:, 0, 7] - tr[sel][:, 0, 0]):7.0f}")
+# placement: HW_ID of wave 0 of every image workgroup (cu_id bits 11:8, sh_id 12, se_id 15:13 on gfx9; XCC_ID low bits)
+hw = traw[:, 0, 15].astype(np.int64)
+if (hw != 0).any():
+    cu = ((hw >> 8) & 15) | (((hw >> 12) & 1) << 4) | (((hw >> 13) & 7) << 5) | (((hw >> 32) & 15) << 8)
+    print("placement of the first workgroups on XCD 0 (workgroup index // 8, role, cu key):", [(int(j // 8), int(role[j]), int(cu[j])) for j in range(0, 8 * 40, 8) if hw[j] != 0][:40])
+    import collections
+    per_cu = collections.defaultdict(list)
+    for j in range(nwg):
+        if hw[j] != 0: per_cu[int(cu[j])].append((int(slot_of[j]), int(role[j])))
+    sizes = collections.Counter(len(v) for v in per_cu.values())
+    print("workgroups per CU histogram:", dict(sizes), " CUs used:", len(per_cu))
+    print("examples:", list(per_cu.items())[:6])

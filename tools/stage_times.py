@@ -1,5 +1,5 @@
 """Per-stage time of the inference forward's block schedule (the blocks of every stage on synthetic tokens of the stage's shape, bf16, no grad),
-plus the stem / downsample layers: where the forward's milliseconds are.  usage: python tools/stage_times.py [model=lemevit_base] [B=128]"""
+plus the stem / downsample layers: where the forward's milliseconds are.  usage: python tools/stage_times.py [model=lemevit_base] [B=128] [img=224]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -9,6 +9,7 @@ import lemevit_amd.model as Mm
 
 name = sys.argv[1] if len(sys.argv) > 1 else "lemevit_base"
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 128
+IMG = int(sys.argv[3]) if len(sys.argv) > 3 else 224
 dev = "cuda:0"
 torch.manual_seed(0)
 m = registry.create_model(name).to(dev).eval()
@@ -20,10 +21,10 @@ def timed(fn, reps=10):
     for _ in range(reps): fn()
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / reps
-x = torch.randn(B, 3, 224, 224, device=dev)
+x = torch.randn(B, 3, IMG, IMG, device=dev)
 with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
     print(f"{name} B={B} whole forward: {timed(lambda: m(x)):.3f} ms")
-    res = 224 // 4
+    res = IMG // 4
     for i, stage in enumerate(m.stages):
         if i >= 2: res //= 2
         C = stage[0].norm1.weight.shape[0]
@@ -39,7 +40,7 @@ with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
             return a, b
         print(f"  stage {i}: {len(stage)} x {stage[0].kind} blocks, C = {C}, {res} x {res}: {timed(run):.3f} ms")
     # stem and stage transitions (models/lemevit.py:698-728) on synthetic feature maps of their input shapes
-    res, cin = 224, 3
+    res, cin = IMG, 3
     for i, ds in enumerate(m.downsample_layers):
         if isinstance(ds, torch.nn.Identity):
             continue
@@ -47,7 +48,7 @@ with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
             inp = x
         else:
             Cp = m.stages[i - 1][0].norm1.weight.shape[0]  # (Base geometry below; other variants: the same resolutions)
-            r = 56 if i <= 2 else (28 if i == 3 else 14)
+            r = IMG // 4 if i <= 2 else (IMG // 8 if i == 3 else IMG // 16)
             inp = torch.randn(B, r, r, Cp, device=dev).bfloat16().permute(0, 3, 1, 2)
         def rund():
             y = m._run_downsample(ds, inp)

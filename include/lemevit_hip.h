@@ -452,8 +452,8 @@ int lmv_sstage_fwd(const lmv_sstage_desc* d, const void* x, const void* c, void*
  *     attn.proj_c [C, C], mlp.0 [4C, C], mlp.3 [C, 4C], pos_embed.weight [C, 9]) -> wpk_out / vec_out; blocks of a stage consecutive as for lmv_sstage_pack.
  *   lmv_dstage_fwd: x_out / c_out must NOT alias x / c.  `workspace`: lmv_dstage_workspace_bytes(B, C) (exchange buffers and flags of the image
  *     slots; flags reset by the call on `stream`; one workspace per concurrent call).  All 8 (29) workgroups of an image slot must be co-resident (256 threads / 74 KB LDS each, two per CU;
- *     128 / 37 KB, four per CU).  Concurrent calls on different streams are safe up to FOUR at a time (lemevit_amd.graph.split_forward issues that many): workgroups are dispatched in index
- *     order and slots come in groups of 8 (64 / 232 workgroups), so each call has at most one partially resident group and the rest of the chip always runs complete groups.
+ *     128 / 37 KB, four per CU).  Concurrent calls on different streams are safe up to lmv_dstage_max_concurrent() at a time (lemevit_amd.graph.split_forward issues up to 4): workgroups are dispatched in index
+ *     order and slots come in groups of 8 (64 / 232 workgroups at 224 x 224), so each call has at most one partially resident group and the rest of the chip always runs complete groups.
  * ------------------------------------------------------------------------------------------ */
 typedef struct lmv_dstage_block_params {
   int32_t C, heads, hidden, _pad;
@@ -470,6 +470,8 @@ int lmv_dstage_supported(int C, int heads, int hidden, int H, int W, int M, int 
 size_t lmv_dstage_wpk_bytes(int C, int hidden);
 size_t lmv_dstage_vec_floats(int C, int hidden);
 size_t lmv_dstage_workspace_bytes(int B, int C);
+int lmv_dstage_max_concurrent(int C, int H, int kind);   /* lmv_dstage_fwd calls that may be in flight on different streams of the device at once (0: unsupported shape): 8 / 4 at 28 x 28 / 56 x 56,
+                                                           * 2 / 1 at 48 x 48 / 96 x 96 -- the caller must not exceed it (lemevit_amd.model falls back to the per-block schedule) */
 int lmv_dstage_pack(const lmv_dstage_block_params* p, void* wpk_out, float* vec_out, void* stream);
 int lmv_dstage_fwd(const lmv_dstage_desc* d, const void* x, const void* c, void* x_out, void* c_out, void* workspace, size_t workspace_bytes, void* stream);
 

@@ -167,6 +167,7 @@ SIGNATURES = {
     "lmv_dstage_wpk_bytes": (_Z, [_I, _I]),
     "lmv_dstage_vec_floats": (_Z, [_I, _I]),
     "lmv_dstage_workspace_bytes": (_Z, [_I, _I]),
+    "lmv_dstage_max_concurrent": (_I, [_I, _I, _I]),
     "lmv_dstage_pack": (_I, [C.POINTER(DStageBlockParams), _P, _P, _P]),
     "lmv_dstage_fwd": (_I, [C.POINTER(SStageDesc), _P, _P, _P, _P, _P, _Z, _P]),
 }

@@ -818,6 +818,18 @@ size_t lmv_dstage_workspace_bytes(int B, int C) {          // (any grid the kern
   return a > b ? a : b;
 }
 
+// How many lmv_dstage_fwd calls may be in flight on different streams of one device: workgroups are dispatched in index order and a slot group is 8 NWG workgroups, so each
+// call has at most one partially resident group -- progress needs the chip to hold one more complete group than that: capacity / (8 NWG) calls.
+template <int NW, int GW, int CT> static int ds_max_concurrent(int kind) {
+  int dev = 0, cus = 256;
+  (void)hipGetDevice(&dev);
+  (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+  const int n = cus * (8 / NW) / (8 * (kind ? DG<NW, GW, CT>::NWG_C : DG<NW, GW, CT>::NWG));
+  return n < 1 ? 1 : n;
+}
+#define DS_MAXC(NW, GW, CT) ds_max_concurrent<NW, GW, CT>(kind)
+int lmv_dstage_max_concurrent(int C, int H, int kind) { const int code = ds_code(C, H); return DS_DISPATCH(code, DS_MAXC, 0); }
+
 int lmv_dstage_pack(const lmv_dstage_block_params* p, void* wpk_out, float* vec_out, void* stream) {
   if (!p || !wpk_out || !vec_out) LMV_FAIL(LMV_ERR_SHAPE, "dstage_pack: null argument");
   const int code = ds_code_of_c(p->C);

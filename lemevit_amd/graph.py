@@ -72,16 +72,20 @@ def split_forward(model: Callable, x: torch.Tensor, parts: int, outs: Optional[l
     fork = torch.cuda.Event()
     fork.record(cur)
     fills = _model.cache_fills()
-    ys[0] = model(xs[0])
-    cold = _model.cache_fills() != fills
-    for i, s in enumerate(streams):
-        if cold:
-            s.wait_stream(cur)
-        else:
-            s.wait_event(fork)
-        with torch.cuda.stream(s):
-            ys[i + 1] = model(xs[i + 1])
-            xs[i + 1].record_stream(s)
+    was, _model.concurrent_launches = _model.concurrent_launches, len(xs)      # (persistent stage kernels of some shapes may not share the chip: model._sstage_applies)
+    try:
+        ys[0] = model(xs[0])
+        cold = _model.cache_fills() != fills
+        for i, s in enumerate(streams):
+            if cold:
+                s.wait_stream(cur)
+            else:
+                s.wait_event(fork)
+            with torch.cuda.stream(s):
+                ys[i + 1] = model(xs[i + 1])
+                xs[i + 1].record_stream(s)
+    finally:
+        _model.concurrent_launches = was
     for s, y in zip(streams, ys[1:]):
         cur.wait_stream(s)
         y.record_stream(cur)

@@ -866,6 +866,7 @@ def _lin_probs(pairs, dtype):
 # a whole stage of "S" blocks as one persistent launch (csrc/sstage.hip; inference)
 # ------------------------------------------------------------------------------------------------
 _SSTAGE = os.environ.get("LMV_SSTAGE", "1") != "0"        # 0: the per-block inference schedule (A/B runs)
+concurrent_launches = 1          # set by graph.split_forward while it issues its sub-batches: how many forward passes run side by side on the device
 _DSTAGE = os.environ.get("LMV_DSTAGE", "1") != "0"        # 0: stages of D blocks on the per-block schedule (A/B runs)
 _sstage_cache: dict = {}
 
@@ -887,6 +888,8 @@ def _sstage_applies(stage, xt: Tensor, c: Tensor, H: int, W: int) -> Optional[st
         return "S" if ops.sstage_supported(xt.shape[2], b0.attn.num_heads, b0.mlp[0].out_features, H, W, c.shape[1], xt.dtype) else None
     if not (_DSTAGE and ops.dstage_supported(xt.shape[2], b0.attn.num_heads, b0.mlp[0].out_features, H, W, c.shape[1], xt.dtype)):
         return None
+    if concurrent_launches > ops.dstage_max_concurrent(xt.shape[2], H, 1 if kind == "C" else 0):
+        return None          # graph.split_forward runs more sub-batches side by side than launches of this shape may share the chip (96 x 96 grids: one)
     if kind == "D":
         return "D" if all(type(blk.attn) is DualCrossAttention and blk.attn.scale == xt.shape[2] ** (-0.5) for blk in stage) else None
     return "C" if all(type(blk.attn) is CrossAttention for blk in stage) else None          # stage 0: only the meta tokens change (:584-612)

@@ -671,6 +671,11 @@ def dstage_supported(C_: int, heads: int, hidden: int, H: int, W: int, M: int, d
     return bool(lib.lmv_dstage_supported(C_, heads, hidden, H, W, M, _lib.LMV_BF16))
 
 
+def dstage_max_concurrent(C_: int, H: int, kind: int = 0) -> int:
+    """dstage_fwd launches of this shape that may be in flight on different streams at once (co-residency of their workgroups, csrc/dstage.hip)."""
+    return int(lib.lmv_dstage_max_concurrent(C_, H, kind))
+
+
 DSTAGE_NAMES = ("attn.qkv1.weight", "attn.qkv2.weight", "attn.proj_x.weight", "attn.proj_c.weight", "mlp.0.weight", "mlp.3.weight",
                 "norm1.weight", "norm1.bias", "attn.qkv1.bias", "attn.qkv2.bias", "attn.proj_x.bias", "attn.proj_c.bias",
                 "norm2.weight", "norm2.bias", "mlp.0.bias", "mlp.3.bias", "pos_embed.weight", "pos_embed.bias")

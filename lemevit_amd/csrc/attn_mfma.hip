@@ -88,8 +88,8 @@ __device__ __forceinline__ bf16x8_t load_frag_global(const bf16_t* base, int64_t
   if (row < L) v = *reinterpret_cast<const uint4*>(base + (int64_t)row * rs + (lane >> 4) * 8);
   return __builtin_bit_cast(bf16x8_t, v);
 }
-__device__ __forceinline__ float group_max4(float v) { v = fmaxf(v, __shfl_xor(v, 16, 64)); return fmaxf(v, __shfl_xor(v, 32, 64)); }
-__device__ __forceinline__ float group_sum4(float v) { v += __shfl_xor(v, 16, 64); return v + __shfl_xor(v, 32, 64); }
+__device__ __forceinline__ float group_max4(float v) { return lmv_xmax4(v); }
+__device__ __forceinline__ float group_sum4(float v) { return lmv_xsum4(v); }
 __device__ __forceinline__ void store4(bf16_t* p, const f32x4_t& v) { *reinterpret_cast<uint2*>(p) = make_uint2(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])); }
 // the tile pair (x0, x1) of a frag_t-produced output: d = 8g .. 8g+7 of the row at `row` (32 d, 64 bytes)
 __device__ __forceinline__ void store8(bf16_t* row, int g, const f32x4_t& x0, const f32x4_t& x1) {

@@ -216,6 +216,20 @@ __device__ __forceinline__ f32x2_t gelu_poly2(f32x2_t x) {
   return x * phi;
 }
 
+// sum / max over the 4 lane groups of a 16-lane row (lanes i, i + 16, i + 32, i + 48): v_permlane16_swap / v_permlane32_swap of two copies leave every lane with both halves of
+// a pair -- VALU only, bit-identical to v + __shfl_xor(v, 16) then + __shfl_xor(., 32) (two ds_bpermute round trips through the LDS pipe)
+__device__ __forceinline__ float lmv_xsum4(float v) {
+  auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  v = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+  auto q = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return __uint_as_float(q[0]) + __uint_as_float(q[1]);
+}
+__device__ __forceinline__ float lmv_xmax4(float v) {
+  auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  v = fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+  auto q = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return fmaxf(__uint_as_float(q[0]), __uint_as_float(q[1]));
+}
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

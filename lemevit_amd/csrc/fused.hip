@@ -234,7 +234,7 @@ __global__ __launch_bounds__(TM * 4) void mlp_fused_kernel(const MlpArgs g) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) s += (float)v[e];
       }
-    s += __shfl_xor(s, 16, 64); s += __shfl_xor(s, 32, 64);
+    s = lmv_xsum4(s);
     const float mean = s * (1.0f / C);
     float q = 0.f;
 #pragma unroll 1
@@ -245,7 +245,7 @@ __global__ __launch_bounds__(TM * 4) void mlp_fused_kernel(const MlpArgs g) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) { const float d = (float)v[e] - mean; q += d * d; }
       }
-    q += __shfl_xor(q, 16, 64); q += __shfl_xor(q, 32, 64);
+    q = lmv_xsum4(q);
     mu[t] = mean; rs[t] = rsqrtf(q * (1.0f / C) + g.eps);
   }
 

@@ -104,14 +104,14 @@ __global__ __launch_bounds__(512, 4) void rsw_gemm_kernel(const RswArgs g) {
 #pragma unroll
           for (int e = 0; e < 8; ++e) s += v[ks][e];
         }
-        s += __shfl_xor(s, 16, 64); s += __shfl_xor(s, 32, 64);
+        s = lmv_xsum4(s);
         const float mean = s * (1.f / RSW_K);
         float q = 0.f;
 #pragma unroll
         for (int ks = 0; ks < 3; ++ks)
 #pragma unroll
           for (int e = 0; e < 8; ++e) { const float d = v[ks][e] - mean; q = fmaf(d, d, q); }
-        q += __shfl_xor(q, 16, 64); q += __shfl_xor(q, 32, 64);
+        q = lmv_xsum4(q);
         const float rstd = rsqrtf(q * (1.f / RSW_K) + g.eps);
         const int row = row0 + rt * 16;
 #pragma unroll

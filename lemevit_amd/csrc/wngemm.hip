@@ -250,8 +250,8 @@ __global__ __launch_bounds__(512, 2) void wn_gemm_kernel(const WnArgs g) {
             a1 += gg; a2 = fmaf(gg, xh, a2);
           }
         }
-        a1 += __shfl_xor(a1, 16, 64); a1 += __shfl_xor(a1, 32, 64);
-        a2 += __shfl_xor(a2, 16, 64); a2 += __shfl_xor(a2, 32, 64);
+        a1 = lmv_xsum4(a1);
+        a2 = lmv_xsum4(a2);
         s1[ti] = a1; s2[ti] = a2;
         if (lane < 16) { red[(wave * 64 + ti * 16 + lane) * 2] = a1; red[(wave * 64 + ti * 16 + lane) * 2 + 1] = a2; }
       }
@@ -363,8 +363,8 @@ __global__ __launch_bounds__(512, 2) void wn_gemm_kernel(const WnArgs g) {
       }
     }
     if (EPI == WN_RES_LN) {
-      a1 += __shfl_xor(a1, 16, 64); a1 += __shfl_xor(a1, 32, 64);
-      a2 += __shfl_xor(a2, 16, 64); a2 += __shfl_xor(a2, 32, 64);
+      a1 = lmv_xsum4(a1);
+      a2 = lmv_xsum4(a2);
       rs1[ti] = a1; rs2[ti] = a2;
     }
   }

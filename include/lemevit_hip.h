@@ -491,6 +491,11 @@ size_t lmv_stem_wpk_bytes(int Cm, int Co);
 int lmv_stem_pack(const void* w1m, const void* w2m, int ld2, int Cm, int Co, void* wpk_out, void* stream);
 int lmv_stem_fwd(const void* x, int x_dtype, int64_t sb, int64_t sc, int64_t sh, int64_t sw, int B, int H, int W, int Cm, int Co, const void* wpk, const float* b1,
                  const float* b2, void* y, void* stream);
+/* The persistent stage kernels (lmv_sstage_fwd, lmv_dstage_fwd) bound every in-launch wait; a spin that runs out (a lost hand-off: a bug, or more concurrent launches than
+ * lmv_dstage_max_concurrent allows) sets a sticky per-device error word instead of hanging the GPU.  lmv_stage_error_count returns it (0 = every hand-off of every launch so far
+ * arrived; < 0: LMV_ERR_*) after the caller has synchronised the streams of interest; reset != 0 clears it. */
+int lmv_stage_error_count(int reset);
+
 /* Launch timing probe: lmv_debug_launch_timing(capacity > 0) creates `capacity` event pairs and from then on brackets every lmv_linear_fwd / lmv_linear_res_ln_fwd /
  * lmv_ln_linear_exact_fwd call -- from any schedule, the native block schedule (lmv_block_fwd) included -- with HIP events on the stream it launches on; after a device
  * synchronisation lmv_debug_launch_timing_read returns the number of calls and fills their durations [ms], FLOPs and algorithmic HBM bytes; capacity = 0 frees the events.

@@ -161,6 +161,7 @@ SIGNATURES = {
     "lmv_stem_pack": (_I, [_P, _P, _I, _I, _I, _P, _P]),
     "lmv_stem_fwd": (_I, [_P, _I, _L, _L, _L, _L, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P]),
     "lmv_stem_debug_timing": (None, [_P]),
+    "lmv_stage_error_count": (_I, [_I]),
     "lmv_debug_launch_timing": (_I, [_I]),
     "lmv_debug_launch_timing_read": (_I, [_P, _P, _P, _P, _I]),
     "lmv_dstage_supported": (_I, [_I, _I, _I, _I, _I, _I, _I]),

@@ -19,6 +19,9 @@ void lmv_set_error(const char* fmt, ...);
     lmv_set_error(__VA_ARGS__);      \
     return (code);                   \
   } while (0)
+// ---- the persistent stage kernels' error word (misc.hip): one sticky device word per device that a bounded spin sets when it runs out (a lost hand-off); read by lmv_stage_error_count
+unsigned* lmv_stage_errword();
+
 // ---- launch timing probe (lmv_debug_launch_timing, misc.hip): HIP events around the forward-form Linear entry points ON THE STREAM THEY LAUNCH ON, whichever schedule calls
 // them (the native block schedule of csrc/block.hip included) -- bench.py's roofline object.  Off: one predictable branch per entry.
 extern bool g_lmv_timing_on;

@@ -73,7 +73,7 @@ template <int NW, int GW, int CTILES> struct DG {
 struct DsArgs {
   const bf16_t* x_in; const bf16_t* c_in; bf16_t* x_out; bf16_t* c_out;
   const uint4* wpk; const float* vec;
-  unsigned char* slots; unsigned* flags;           // flags: [nslots][FLAGS_PER_SLOT] | error
+  unsigned char* slots; unsigned* flags; unsigned* err;          // flags: [nslots][FLAGS_PER_SLOT]; err: the sticky device error word (lmv_stage_error_count)
   int B, nblocks, nslots; float eps, sx, sc;       // sx / sc: the two attention scales times log2 e
   unsigned long long* timing; int timing_block;
 };
@@ -188,7 +188,7 @@ __global__ __launch_bounds__(64 * NW, 2) void dstage_kernel(const DsArgs a) {
   if (slot >= a.nslots) return;
   unsigned* const fl = a.flags + (size_t)slot * G::FLAGS_PER_SLOT;
   unsigned* const haloflag = fl, * const partflag = fl + KWG, * const mflag = fl + 2 * KWG;
-  unsigned* const errflag = a.flags + (size_t)a.nslots * G::FLAGS_PER_SLOT;
+  unsigned* const errflag = a.err;
   unsigned char* const sb = a.slots + (size_t)slot * G::SLOT_BYTES;
   unsigned char* const mfr = sb, * const halo = sb + G::MFRAG_BYTES, * const part = halo + G::HALO_BYTES;
   float2* const stat = reinterpret_cast<float2*>(smem + G::L_STAT);
@@ -777,6 +777,8 @@ template <int NW, int GW, int CT, int KIND> static int ds_launch_kind(const lmv_
   a.sx = (float)(log((double)d->M) / log(N) / sqrt((double)d->C) * lg2e);      // models/lemevit.py:255: log_N(M) C^-1/2
   a.sc = (float)(1.0 / sqrt(d->kind ? 32.0 : (double)d->C) * lg2e);            // :256; "C" blocks: F.scaled_dot_product_attention's head_dim^-1/2 (:480-483)
   a.timing = (unsigned long long*)d->timing; a.timing_block = d->timing_block;
+  a.err = lmv_stage_errword();
+  if (!a.err) LMV_FAIL(LMV_ERR_LAUNCH, "dstage_fwd: cannot allocate the error word");
   hipLaunchKernelGGL((dstage_kernel<NW, GW, CT, KIND>), dim3(ns * (KIND ? G::NWG_C : G::NWG)), dim3(64 * NW), G::L_TOTAL, st, a);
   LMV_CHECK_LAUNCH("dstage_fwd");
   return LMV_OK;

@@ -14,6 +14,27 @@ void lmv_set_error(const char* fmt, ...) {
 }
 extern "C" const char* lmv_last_error(void) { return g_err; }
 
+// ---- error word of the persistent stage kernels ------------------------------------------------------------------------------------------
+namespace { unsigned* g_errword[64] = {}; }
+unsigned* lmv_stage_errword() {
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  unsigned*& w = g_errword[dev & 63];
+  if (!w) {          // (first stage launch on this device: an eager warm-up call, before any stream capture)
+    if (hipMalloc(&w, 256) != hipSuccess) { w = nullptr; return nullptr; }
+    (void)hipMemset(w, 0, 256);
+  }
+  return w;
+}
+extern "C" int lmv_stage_error_count(int reset) {
+  unsigned* w = lmv_stage_errword();
+  if (!w) LMV_FAIL(LMV_ERR_LAUNCH, "stage_error_count: cannot allocate the error word");
+  unsigned v = 0;
+  if (hipMemcpy(&v, w, 4, hipMemcpyDeviceToHost) != hipSuccess) LMV_FAIL(LMV_ERR_LAUNCH, "stage_error_count: copy failed");
+  if (reset && v) (void)hipMemset(w, 0, 4);
+  return (int)(v & 0x7fffffffu);
+}
+
 // ---- launch timing probe ---------------------------------------------------------------------------------------------------------------
 bool g_lmv_timing_on = false;
 namespace {

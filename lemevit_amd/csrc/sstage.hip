@@ -100,7 +100,7 @@ constexpr int SS_NSTAMP = 24;
 struct SsArgs {
   const bf16_t* x_in; const bf16_t* c_in; bf16_t* x_out; bf16_t* c_out;
   const uint4* wpk; const float* vec;
-  unsigned char* kbuf; unsigned char* vbuf; unsigned char* halo; unsigned char* park; unsigned* flags;     // flags: [2 B] kv | [2 B] halo | [1] error
+  unsigned char* kbuf; unsigned char* vbuf; unsigned char* halo; unsigned char* park; unsigned* flags; unsigned* err;     // flags: [2 B] kv | [2 B] halo; err: the sticky device error word (lmv_stage_error_count)
   int B, nblocks; float eps;
   unsigned long long* timing; int timing_block;      // optional (NULL): s_memtime stamps [workgroup][wave][SS_NSTAMP] of one block
 };
@@ -267,7 +267,7 @@ __global__ __launch_bounds__(64 * NW, 2) void sstage_kernel(const SsArgs a) {
   unsigned* const kvflag_peer = a.flags + img * 2 + (1 - half);
   unsigned* const haloflag_mine = a.flags + 2 * a.B + img * 2 + half;
   unsigned* const haloflag_peer = a.flags + 2 * a.B + img * 2 + (1 - half);
-  unsigned* const errflag = a.flags + 4 * a.B;
+  unsigned* const errflag = a.err;
   const __amdgpu_buffer_rsrc_t kr = __builtin_amdgcn_make_buffer_rsrc(a.kbuf + (size_t)img * KBUF_IMG, 0, (int)KBUF_IMG, 0x00020000);
   const __amdgpu_buffer_rsrc_t vr = __builtin_amdgcn_make_buffer_rsrc(a.vbuf + (size_t)img * VBUF_IMG, 0, (int)VBUF_IMG, 0x00020000);
   const int nimg_slots = half ? 84 : 112;          // slots that are image tokens
@@ -747,6 +747,8 @@ static int ss_launch(const lmv_sstage_desc* d, const void* x, const void* c, voi
     a.flags = (unsigned*)ws; a.kbuf = ws + flags; a.vbuf = a.kbuf + (size_t)nb * G::KBUF_IMG; a.halo = a.vbuf + (size_t)nb * G::VBUF_IMG; a.park = a.halo + (size_t)nb * G::HALO_IMG;
     a.B = nb; a.nblocks = d->nblocks; a.eps = d->eps;
     a.timing = (unsigned long long*)d->timing; a.timing_block = d->timing_block;
+    a.err = lmv_stage_errword();
+    if (!a.err) LMV_FAIL(LMV_ERR_LAUNCH, "sstage_fwd: cannot allocate the error word");
     const int nwg = 2 * ((nb + 7) / 8) * 8;
     hipLaunchKernelGGL(sstage_kernel<NW>, dim3(nwg), dim3(64 * NW), G::L_TOTAL, st, a);
     LMV_CHECK_LAUNCH("sstage_fwd");

@@ -780,3 +780,12 @@ def stem_fwd(x: Tensor, wpk: Tensor, b1: Tensor, b2: Tensor, Cm: int, Co: int) -
     sb, sc, sh, sw = x.stride()
     check(lib.lmv_stem_fwd(x.data_ptr(), dtype_code(x), sb, sc, sh, sw, B, H, W, Cm, Co, wpk.data_ptr(), _f32(b1), _f32(b2), _ptr(y), _stream()), "lmv_stem_fwd")
     return y
+
+
+def stage_error_count(reset: bool = False) -> int:
+    """The sticky error word of the persistent stage kernels (a bounded in-launch wait that ran out); synchronises the device first."""
+    torch.cuda.synchronize()
+    v = int(lib.lmv_stage_error_count(1 if reset else 0))
+    if v < 0:
+        check(v, "lmv_stage_error_count")
+    return v

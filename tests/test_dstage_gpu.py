@@ -222,3 +222,9 @@ def test_cstage_vs_oracle(nblocks, B, C, G):
     assert ec <= 1e-2, ec
     co2 = ops.dstage_fwd(xd, c.to(DEV), P, G, G, 1e-6, kind=1)[1]
     assert torch.equal(co, co2)
+
+
+def test_no_handoff_ever_timed_out():
+    """Runs last in this file: the sticky error word of the stage kernels (a bounded in-launch wait that ran out) is still clear after every launch above."""
+    from lemevit_amd import ops
+    assert ops.stage_error_count() == 0

@@ -155,3 +155,9 @@ def test_sstage_handoffs_under_uneven_load(C, nblocks, B):
         assert torch.equal(out[0], ref[0]) and torch.equal(out[1], ref[1]), rnd
         if rnd % 2:
             assert torch.equal(half[0], ref[0][: B // 2]) and torch.equal(half[1], ref[1][: B // 2]), rnd
+
+
+def test_no_handoff_ever_timed_out():
+    """Runs last in this file: the sticky error word of the stage kernels (a bounded in-launch wait that ran out) is still clear after every launch above."""
+    from lemevit_amd import ops
+    assert ops.stage_error_count() == 0

@@ -48,7 +48,8 @@ template <int NW, int GW, int CTILES> struct DG {
   static constexpr int WS_Q2 = WS_V2 + NH * KS * 2;                 //       rows 32 h + 16 n
   static constexpr int WS_K1T = WS_Q2 + NH * KS * 2;                // [head][m < C / 16]: lane (g, i) holds qkv1.weight[C + 32 h + 16 (j >> 2) + 4 g + (j & 3)][16 m + i]
   static constexpr int WS_PC = WS_K1T + NH * (C / 16);              // [wave][ks][n CT]: proj_c.weight
-  static constexpr int WS_FRAGS = WS_PC + NW * KS * CT;
+  static constexpr int WS_K1 = WS_PC + NW * KS * CT;                // [head][ks][n 2]: rows C + 32 h + 16 n of qkv1.weight ("S" blocks: the image tokens' keys are computed)
+  static constexpr int WS_FRAGS = WS_K1 + NH * KS * 2;
   static constexpr int V_N1W = 0, V_N1B = C, V_QKV1B = 2 * C, V_QKV2B = 5 * C, V_PXB = 8 * C, V_PCB = 9 * C, V_N2W = 10 * C, V_N2B = 11 * C, V_FC1B = 12 * C,
                        V_FC2B = 16 * C, V_POSW = 17 * C, V_POSB = 26 * C, V_FLOATS = 27 * C;
   // LDS of an image workgroup (the meta workgroup uses the front of the same regions with one token tile)
@@ -66,8 +67,10 @@ template <int NW, int GW, int CTILES> struct DG {
   static constexpr size_t MFRAG_BYTES = (size_t)2 * NH * MF_HEAD * 1024;   // [parity][head][MF_HEAD]
   static constexpr size_t HALO_BYTES = (size_t)2 * KWG * 2 * GW * C * 2;   // [parity][workgroup][first | last grid row][GW tokens][C] bf16
   static constexpr size_t PART_BYTES = (size_t)KWG * NH * 3 * 1024;        // [workgroup][head][O d-tile 0 | O d-tile 1 | (max, sum)]: f32x4 per lane
-  static constexpr size_t SLOT_BYTES = MFRAG_BYTES + HALO_BYTES + PART_BYTES;
-  static constexpr int FLAGS_PER_SLOT = 2 * KWG + 1;                       // halo [KWG] | partial [KWG] | meta
+  // "S" blocks (KIND 2, the 8-wave instance only): K and V^T operand fragments of all image tokens of the image, [parity][K | V][head][KWG NT key tiles] x 1 KB
+  static constexpr size_t KV_HALF = (size_t)NH * KWG * NT * 1024, KV_BYTES = NW == 8 ? 4 * KV_HALF : 0;
+  static constexpr size_t SLOT_BYTES = MFRAG_BYTES + HALO_BYTES + PART_BYTES + KV_BYTES;
+  static constexpr int FLAGS_PER_SLOT = 3 * KWG + 1;                       // halo [KWG] | partial [KWG] | meta | K / V ready [KWG] ("S" blocks)
 };
 
 struct DsArgs {
@@ -168,7 +171,7 @@ __device__ __forceinline__ void ds_mlp(f32x4_t (&R)[NTT][G::CT], const unsigned 
   }
 }
 
-template <int NW, int GW, int CT, int KIND>          // KIND: 0 "D" blocks, 1 "C" blocks
+template <int NW, int GW, int CT, int KIND>          // KIND: 0 "D" blocks, 1 "C" blocks, 2 "S" blocks (self-attention of the image tokens across the workgroups of an image; NW = 8)
 __global__ __launch_bounds__(64 * NW, 2) void dstage_kernel(const DsArgs a) {
   using G = DG<NW, GW, CT>;
   constexpr int C = G::C, NH = G::NH, KS = G::KS, KWG = G::KWG, ROWS = G::ROWS, CW = G::CW, URD = G::URD, NT = G::NT, TOK = G::TOK, NP = (NT + 1) / 2;
@@ -183,14 +186,15 @@ __global__ __launch_bounds__(64 * NW, 2) void dstage_kernel(const DsArgs a) {
   const int xcd = blockIdx.x & 7, jj = blockIdx.x >> 3;
   // "D" blocks: KWG image workgroups + the meta workgroup per slot; "C" blocks (the image side of a block is a third of the work and every block starts from x_in): an image
   // workgroup takes SUB = 2 row groups in turn, KWG / 2 + 1 workgroups per slot, twice the slots in flight
-  constexpr int sub_n = KIND ? G::CSUB : 1, nimgwg = KWG / sub_n, nwg = nimgwg + 1;
+  constexpr int sub_n = KIND == 1 ? G::CSUB : 1, nimgwg = KWG / sub_n, nwg = nimgwg + 1;
   const int slot = (jj / nwg) * 8 + xcd, rolep = jj % nwg;               // rolep < nimgwg: image rows; rolep == nimgwg: the meta tokens
   if (slot >= a.nslots) return;
   unsigned* const fl = a.flags + (size_t)slot * G::FLAGS_PER_SLOT;
-  unsigned* const haloflag = fl, * const partflag = fl + KWG, * const mflag = fl + 2 * KWG;
+  unsigned* const haloflag = fl, * const partflag = fl + KWG, * const mflag = fl + 2 * KWG, * const kvflag = fl + 2 * KWG + 1;
   unsigned* const errflag = a.err;
   unsigned char* const sb = a.slots + (size_t)slot * G::SLOT_BYTES;
-  unsigned char* const mfr = sb, * const halo = sb + G::MFRAG_BYTES, * const part = halo + G::HALO_BYTES;
+  unsigned char* const mfr = sb, * const halo = sb + G::MFRAG_BYTES, * const part = halo + G::HALO_BYTES, * const kvb = part + G::PART_BYTES;
+  (void)kvb; (void)kvflag;
   float2* const stat = reinterpret_cast<float2*>(smem + G::L_STAT);
 
   int round = 0;
@@ -227,7 +231,7 @@ __global__ __launch_bounds__(64 * NW, 2) void dstage_kernel(const DsArgs a) {
 #pragma unroll 1
           for (int u = wave; u < 3 * NH; u += NW) {
             const int h = u / 3, typ = u - 3 * h;                 // 0: k2, 1: v2, 2: q2
-            if (KIND && typ != 2) continue;                     // "C" blocks: no x-direction
+            if (KIND == 1 && typ != 2) continue;                // "C" blocks: no x-direction
             const unsigned char* wcur = wp + (size_t)((typ == 0 ? G::WS_K2 : typ == 1 ? G::WS_V2 : G::WS_Q2) + h * (2 * KS)) * 1024;
             ring_fill<2, URD>(ring, wcur, lane);
             f32x4_t acc[1][2] = {{f32x4_t{0.f, 0.f, 0.f, 0.f}, f32x4_t{0.f, 0.f, 0.f, 0.f}}};
@@ -238,7 +242,8 @@ __global__ __launch_bounds__(64 * NW, 2) void dstage_kernel(const DsArgs a) {
               for (int dt = 0; dt < 2; ++dt) {
                 const f32x4_t lo = acc[0][dt] + (dt ? bv1 : bv0);
                 const u32x4_t pk = {pack_h2(lo[0], lo[1]), pack_h2(lo[2], lo[3]), 0u, 0u};
-                __builtin_amdgcn_raw_buffer_store_b128(pk, mr, ((h * G::MF_HEAD + 1 + dt) * 64 + lane) * 16, 0, 16);
+                if constexpr (KIND == 2) *reinterpret_cast<u32x4_t*>(smem + G::L_XN + ((KS + NH + 2 * h + dt) * 64 + lane) * 16) = pk;          // ("S" blocks: the meta tokens attend among themselves, here)
+                else __builtin_amdgcn_raw_buffer_store_b128(pk, mr, ((h * G::MF_HEAD + 1 + dt) * 64 + lane) * 16, 0, 16);
               }
             } else {
               const float* bp = vec + G::V_QKV2B + (typ == 0 ? C : 0) + 32 * h + 4 * g;
@@ -248,13 +253,38 @@ __global__ __launch_bounds__(64 * NW, 2) void dstage_kernel(const DsArgs a) {
               const f32x4_t k0 = {(acc[0][0][0] + b0.x) * sc, (acc[0][0][1] + b0.y) * sc, (acc[0][0][2] + b0.z) * sc, (acc[0][0][3] + b0.w) * sc};
               const f32x4_t k1 = {(acc[0][1][0] + b1.x) * sc, (acc[0][1][1] + b1.y) * sc, (acc[0][1][2] + b1.z) * sc, (acc[0][1][3] + b1.w) * sc};
               const u32x4_t pk = pack_bf8(k0, k1);
-              if (typ == 0) __builtin_amdgcn_raw_buffer_store_b128(pk, mr, ((h * G::MF_HEAD) * 64 + lane) * 16, 0, 16);
-              else *reinterpret_cast<u32x4_t*>(smem + G::L_H + (h * 64 + lane) * 16) = pk;
+              if (typ == 0) {
+                if constexpr (KIND == 2) *reinterpret_cast<u32x4_t*>(smem + G::L_XN + ((KS + h) * 64 + lane) * 16) = pk;
+                else __builtin_amdgcn_raw_buffer_store_b128(pk, mr, ((h * G::MF_HEAD) * 64 + lane) * 16, 0, 16);
+              } else *reinterpret_cast<u32x4_t*>(smem + G::L_H + (h * 64 + lane) * 16) = pk;
             }
           }
         }
         __syncthreads();
         DS_STAMP(10);
+        if constexpr (KIND == 2) {
+          // "S" blocks: softmax(q2 k2^T / sqrt 32) v2 per head on the 16 meta tokens -> the proj_c operand (the LayerNorm output in L_XN is dead behind the barrier above)
+          DS_PHASE
+#pragma unroll 1
+          for (int h = wave; h < NH; h += NW) {
+            const bf16x8_t q2f = *reinterpret_cast<const bf16x8_t*>(smem + G::L_H + (h * 64 + lane) * 16);
+            const bf16x8_t k2f = *reinterpret_cast<const bf16x8_t*>(smem + G::L_XN + ((KS + h) * 64 + lane) * 16);
+            const f16x8_t v20 = *reinterpret_cast<const f16x8_t*>(smem + G::L_XN + ((KS + NH + 2 * h) * 64 + lane) * 16);
+            const f16x8_t v21 = *reinterpret_cast<const f16x8_t*>(smem + G::L_XN + ((KS + NH + 2 * h + 1) * 64 + lane) * 16);
+            const f32x4_t z4 = {0.f, 0.f, 0.f, 0.f};
+            const f32x4_t sc = mfma_bf16(k2f, q2f, z4);          // S^T[key][query]
+            const float m = xmax4(max4(sc));
+            float e[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) e[r] = __builtin_amdgcn_exp2f(sc[r] - m);
+            const float inv = 1.f / xsum4((e[0] + e[1]) + (e[2] + e[3]));
+            const u32x4_t pk = {pack_h2(e[0], e[1]), pack_h2(e[2], e[3]), 0u, 0u};
+            const f16x8_t pf = __builtin_bit_cast(f16x8_t, pk);
+            const f32x4_t o0 = mfma_f16(v20, pf, z4), o1 = mfma_f16(v21, pf, z4);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            *reinterpret_cast<u32x4_t*>(smem + G::L_XN + (h * 64 + lane) * 16) = pack_bf8(o0 * inv, o1 * inv);
+          }
+        } else {
         {
           DS_PHASE
           // q~[h] = q2[h] (16 queries x 32 d) x W_k1[h] (32 d x C channels): C / 16 output tiles of one MFMA each, dealt to the waves by (head, k-step)
@@ -336,6 +366,7 @@ __global__ __launch_bounds__(64 * NW, 2) void dstage_kernel(const DsArgs a) {
             *reinterpret_cast<u32x4_t*>(smem + G::L_XN + (h * 64 + lane) * 16) = pack_bf8(c0, c1);
           }
         }
+        }          // (KIND != 2)
         __syncthreads();
         DS_STAMP(13);
         asm volatile("; PHASE_MPROJ");
@@ -390,7 +421,7 @@ __global__ __launch_bounds__(64 * NW, 2) void dstage_kernel(const DsArgs a) {
         for (int ct = 0; ct < CT; ++ct) { float f[4]; ld4(src + CW * wave + 16 * ct + 4 * g, f); R[t][ct] = f32x4_t{f[0], f[1], f[2], f[3]}; }
       }
     };
-    if constexpr (KIND == 0) load_rows(rolep * TOK);
+    if constexpr (KIND != 1) load_rows(rolep * TOK);
 #pragma unroll 1
     for (int it = 0; it < a.nblocks * sub_n; ++it) {
       const int blk = sub_n == 1 ? it : it / sub_n, role = sub_n == 1 ? rolep : rolep * sub_n + (it - blk * sub_n), tok0 = role * TOK;      // role: the row group [role ROWS, (role + 1) ROWS)
@@ -398,7 +429,7 @@ __global__ __launch_bounds__(64 * NW, 2) void dstage_kernel(const DsArgs a) {
       const int lane = lane0, wave = wave0;      // (stamps only)
       const unsigned char* const wp = reinterpret_cast<const unsigned char*>(a.wpk) + (size_t)blk * G::WS_FRAGS * 1024;
       const float* const vec = a.vec + (size_t)blk * G::V_FLOATS;
-      if constexpr (KIND != 0) load_rows(tok0);          // "C" blocks return x as it came: the position embedding of a block only feeds its norm1, every block (and row group) starts from x_in
+      if constexpr (KIND == 1) load_rows(tok0);          // "C" blocks return x as it came: the position embedding of a block only feeds its norm1, every block (and row group) starts from x_in
       DS_STAMP(0);
       if (a.timing && gb == a.timing_block && lane0 == 0) {          // (placement probe: which CU / SE / XCD hosts this workgroup -- tools/dstage_timeline.py)
         unsigned hw, xcc;
@@ -412,7 +443,7 @@ __global__ __launch_bounds__(64 * NW, 2) void dstage_kernel(const DsArgs a) {
         DS_PHASE
         unsigned char* const stg = smem + wave * G::STG_WAVE;
         const unsigned char* const hprev = halo + (size_t)((gb + 1) & 1) * (G::HALO_BYTES / 2);      // the rows published at the end of block gb - 1
-        if (gb > 0 && !KIND) {
+        if (gb > 0 && KIND != 1) {
           // (block 0 of a later image reads its halo from x_in, but still waits: a workgroup must not run two blocks ahead of a neighbour that reads its rows)
           if (role > 0) wait_flag(haloflag + role - 1, (unsigned)gb, errflag, lane);
           if (role + 1 < KWG) wait_flag(haloflag + role + 1, (unsigned)gb, errflag, lane);
@@ -452,7 +483,7 @@ __global__ __launch_bounds__(64 * NW, 2) void dstage_kernel(const DsArgs a) {
               u32x4_t hv = {0u, 0u, 0u, 0u};
               if (inside) {
                 u32x4_t v;
-                if (blk == 0 || KIND) v = *reinterpret_cast<const u32x4_t*>(a.x_in + ((size_t)img * G::NIMG + (side ? tok0 + TOK : tok0 - GW) + tok) * C + c0 + 8 * q);
+                if (blk == 0 || KIND == 1) v = *reinterpret_cast<const u32x4_t*>(a.x_in + ((size_t)img * G::NIMG + (side ? tok0 + TOK : tok0 - GW) + tok) * C + c0 + 8 * q);
                 else {
                   const __amdgpu_buffer_rsrc_t hr = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(hprev), 0, (int)(G::HALO_BYTES / 2), 0x00020000);
                   v = __builtin_amdgcn_raw_buffer_load_b128(hr, (((nb * 2 + (side ? 0 : 1)) * GW + tok) * C + c0 + 8 * q) * 2, 0, 16);
@@ -503,10 +534,12 @@ __global__ __launch_bounds__(64 * NW, 2) void dstage_kernel(const DsArgs a) {
       {
         DS_PHASE
         ds_layer_norm<NW, NT, CT>(R, vec + G::V_N1W, vec + G::V_N1B, a.eps, smem + G::L_XN, stat, wave, lane);
-        if (wave == 0) wait_flag(mflag, (unsigned)(gb + 1), errflag, lane);      // the meta workgroup's fragments of this block
+        if constexpr (KIND != 2)
+          if (wave == 0) wait_flag(mflag, (unsigned)(gb + 1), errflag, lane);      // the meta workgroup's fragments of this block
       }
       __syncthreads();
       DS_STAMP(2);
+      if constexpr (KIND != 2) {
       const unsigned char* const mf = mfr + (size_t)(gb & 1) * (G::MFRAG_BYTES / 2);
       const __amdgpu_buffer_rsrc_t mr = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(mf), 0, (int)(G::MFRAG_BYTES / 2), 0x00020000);
       const __amdgpu_buffer_rsrc_t pr = __builtin_amdgcn_make_buffer_rsrc(part, 0, (int)G::PART_BYTES, 0x00020000);
@@ -571,7 +604,7 @@ __global__ __launch_bounds__(64 * NW, 2) void dstage_kernel(const DsArgs a) {
         }
       }
       DS_STAMP(3);
-      if constexpr (KIND != 0) {          // "C" blocks end here for the image tokens
+      if constexpr (KIND == 1) {          // "C" blocks end here for the image tokens
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (tid == 0) __hip_atomic_store((gu32*)(partflag + role), (unsigned)(gb + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -628,6 +661,156 @@ __global__ __launch_bounds__(64 * NW, 2) void dstage_kernel(const DsArgs a) {
         const int h = wave + NW;
 #pragma unroll
         for (int t = 0; t < NT; ++t) *reinterpret_cast<u32x4_t*>(smem + G::L_AO + ((h * NT + t) * 64 + lane) * 16) = AO1[t];
+      }
+      } else {
+        // =========== "S" blocks: self-attention of the image tokens (models/lemevit.py:185-205), the keys and values of the whole image through L2 ===========
+        constexpr int KT = KWG * NT, NPW = NT / 2, NQ = NT / 2;          // key tiles of the image; key-tile pairs / query tiles of a unit per workgroup
+        static_assert(NW == 8 && NT % 2 == 0 && (2 * NH) % NW == 0, "S blocks: the 8-wave instance");
+        unsigned char* const kvw = kvb + (size_t)(gb & 1) * (2 * G::KV_HALF);
+        const __amdgpu_buffer_rsrc_t kr = __builtin_amdgcn_make_buffer_rsrc(kvw, 0, (int)(2 * G::KV_HALF), 0x00020000);
+        // ---- k (even waves) / v (odd waves) of this workgroup's tokens, 2 NH units over the waves -> K fragments [head][key tile], V^T fragments [head][pair][d-tile] ----
+        {
+          DS_PHASE
+          bf16x8_t ring[URD][2];
+          const int isv = wave & 1;
+#pragma unroll 1
+          for (int j = 0; j < (2 * NH) / NW; ++j) {
+            const int h = (wave >> 1) + (NW / 2) * j;
+            const unsigned char* wcur = wp + (size_t)((isv ? G::WS_V1 : G::WS_K1) + h * (2 * KS)) * 1024;
+            ring_fill<2, URD>(ring, wcur, lane);
+            f32x4_t acc[NT][2];
+#pragma unroll
+            for (int t = 0; t < NT; ++t) { acc[t][0] = f32x4_t{0.f, 0.f, 0.f, 0.f}; acc[t][1] = acc[t][0]; }
+            if (!isv) {
+              const float* bk = vec + G::V_QKV1B + C + 32 * h + 4 * g;
+              const float4 b0 = *reinterpret_cast<const float4*>(bk), b1 = *reinterpret_cast<const float4*>(bk + 16);
+              gemm_unit<2, KS, URD, true, NT>(acc, ring, wcur, wcur, smem + G::L_XN, lane);
+#pragma unroll
+              for (int t = 0; t < NT; ++t) {
+                const f32x4_t k0 = {acc[t][0][0] + b0.x, acc[t][0][1] + b0.y, acc[t][0][2] + b0.z, acc[t][0][3] + b0.w};
+                const f32x4_t k1 = {acc[t][1][0] + b1.x, acc[t][1][1] + b1.y, acc[t][1][2] + b1.z, acc[t][1][3] + b1.w};
+                __builtin_amdgcn_raw_buffer_store_b128(pack_bf8(k0, k1), kr, ((h * KT + role * NT + t) * 64 + lane) * 16, 0, 16);
+              }
+            } else {
+              const float bv[2] = {vec[G::V_QKV1B + 2 * C + 32 * h + li], vec[G::V_QKV1B + 2 * C + 32 * h + 16 + li]};
+              gemm_unit<2, KS, URD, false, NT>(acc, ring, wcur, wcur, smem + G::L_XN, lane);
+#pragma unroll
+              for (int p = 0; p < NPW; ++p)
+#pragma unroll
+                for (int dt = 0; dt < 2; ++dt) {
+                  const f32x4_t lo = acc[2 * p][dt] + bv[dt], hi = acc[2 * p + 1][dt] + bv[dt];
+                  const u32x4_t vk = {pack_h2(lo[0], lo[1]), pack_h2(lo[2], lo[3]), pack_h2(hi[0], hi[1]), pack_h2(hi[2], hi[3])};
+                  __builtin_amdgcn_raw_buffer_store_b128(vk, kr, (int)G::KV_HALF + (((h * (KT / 2) + role * NPW + p) * 2 + dt) * 64 + lane) * 16, 0, 16);
+                }
+            }
+          }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) __hip_atomic_store((gu32*)(kvflag + role), (unsigned)(gb + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        DS_STAMP(3);
+        if (wave0 == 0) {          // every workgroup of the image has published its keys and values of this block
+          unsigned spins = 0;
+          while (true) {
+            const unsigned v = lane0 < KWG ? __hip_atomic_load((gu32*)(kvflag + lane0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0xffffffffu;
+            if (__all(v >= (unsigned)(gb + 1))) break;
+            __builtin_amdgcn_s_sleep(2);
+            if (++spins > SPIN_LIMIT) { if (lane0 == 0) __hip_atomic_store((gu32*)errflag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+          }
+        }
+        __syncthreads();
+        // ---- attention: 2 NH units (head, half of the workgroup's query tiles) over the waves; two passes over the KT key tiles (row maxima; exp2 / sums / P V with the scores
+        //      recomputed), K and V^T fragments straight from L2 through a 3-deep register ring of key-tile pairs ----
+#pragma unroll
+        for (int j = 0; j < (2 * NH) / NW; ++j) {
+          DS_PHASE
+          const int h = (wave >> 1) + (NW / 2) * j, t0 = NQ * (wave & 1);
+          bf16x8_t Q[NQ];
+          {
+            bf16x8_t ring[URD][2];
+            const unsigned char* wcur = wp + (size_t)(G::WS_Q1 + h * (2 * KS)) * 1024;
+            ring_fill<2, URD>(ring, wcur, lane);
+            const float* bq = vec + G::V_QKV1B + 32 * h + 4 * g;
+            const float4 b0 = *reinterpret_cast<const float4*>(bq), b1 = *reinterpret_cast<const float4*>(bq + 16);
+            f32x4_t acc[NQ][2];
+#pragma unroll
+            for (int t = 0; t < NQ; ++t) { acc[t][0] = f32x4_t{0.f, 0.f, 0.f, 0.f}; acc[t][1] = acc[t][0]; }
+            gemm_unit<2, KS, URD, true, NQ, NT>(acc, ring, wcur, wcur, smem + G::L_XN + t0 * 1024, lane);
+#pragma unroll
+            for (int t = 0; t < NQ; ++t) {
+              const f32x4_t q0 = {(acc[t][0][0] + b0.x) * a.sx, (acc[t][0][1] + b0.y) * a.sx, (acc[t][0][2] + b0.z) * a.sx, (acc[t][0][3] + b0.w) * a.sx};
+              const f32x4_t q1 = {(acc[t][1][0] + b1.x) * a.sx, (acc[t][1][1] + b1.y) * a.sx, (acc[t][1][2] + b1.z) * a.sx, (acc[t][1][3] + b1.w) * a.sx};
+              Q[t] = as_bf8(pack_bf8(q0, q1));
+            }
+          }
+          // (the attention outputs of heads >= NW land where the LayerNorm output lies: every wave must be done with its q projections first)
+          if (NW / 2 * j + NW / 2 > NW) __syncthreads();
+          const int kbase = (h * KT * 64 + lane) * 16, vbase = (int)G::KV_HALF + (h * KT * 64 + lane) * 16;
+          const f32x4_t z4 = {0.f, 0.f, 0.f, 0.f};
+          float m[NQ];
+#pragma unroll
+          for (int t = 0; t < NQ; ++t) m[t] = -INFINITY;
+          {
+            u32x4_t kp[3][2];
+#pragma unroll
+            for (int pi = 0; pi < 2; ++pi)
+#pragma unroll
+              for (int e = 0; e < 2; ++e) kp[pi][e] = __builtin_amdgcn_raw_buffer_load_b128(kr, kbase + (2 * pi + e) * 1024, 0, 16);
+#pragma unroll
+            for (int pi = 0; pi < KT / 2; ++pi) {
+              if (pi + 2 < KT / 2) {
+#pragma unroll
+                for (int e = 0; e < 2; ++e) kp[(pi + 2) % 3][e] = __builtin_amdgcn_raw_buffer_load_b128(kr, kbase + (2 * (pi + 2) + e) * 1024, 0, 16);
+              }
+#pragma unroll
+              for (int e = 0; e < 2; ++e)
+#pragma unroll
+                for (int t = 0; t < NQ; ++t) m[t] = max2(m[t], max4(mfma_bf16(as_bf8(kp[pi % 3][e]), Q[t], z4)));
+            }
+          }
+          float l[NQ]; f32x4_t O[NQ][2];
+#pragma unroll
+          for (int t = 0; t < NQ; ++t) { m[t] = xmax4(m[t]); l[t] = 0.f; O[t][0] = z4; O[t][1] = z4; asm volatile("" : "+v"(Q[t])); }
+          {
+            int ko = 0; asm volatile("" : "+v"(ko));          // (an opaque offset: the second pass's loads and score tiles are not the first pass's)
+            u32x4_t kp[3][2], vp[3][2];
+#pragma unroll
+            for (int pi = 0; pi < 2; ++pi)
+#pragma unroll
+              for (int e = 0; e < 2; ++e) {
+                kp[pi][e] = __builtin_amdgcn_raw_buffer_load_b128(kr, ko + kbase + (2 * pi + e) * 1024, 0, 16);
+                vp[pi][e] = __builtin_amdgcn_raw_buffer_load_b128(kr, ko + vbase + (2 * pi + e) * 1024, 0, 16);
+              }
+#pragma unroll
+            for (int pi = 0; pi < KT / 2; ++pi) {
+              if (pi + 2 < KT / 2) {
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                  kp[(pi + 2) % 3][e] = __builtin_amdgcn_raw_buffer_load_b128(kr, ko + kbase + (2 * (pi + 2) + e) * 1024, 0, 16);
+                  vp[(pi + 2) % 3][e] = __builtin_amdgcn_raw_buffer_load_b128(kr, ko + vbase + (2 * (pi + 2) + e) * 1024, 0, 16);
+                }
+              }
+#pragma unroll
+              for (int t = 0; t < NQ; ++t) {
+                const f32x4_t s0 = mfma_bf16(as_bf8(kp[pi % 3][0]), Q[t], z4), s1 = mfma_bf16(as_bf8(kp[pi % 3][1]), Q[t], z4);
+                float e[8];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { e[r] = __builtin_amdgcn_exp2f(s0[r] - m[t]); e[4 + r] = __builtin_amdgcn_exp2f(s1[r] - m[t]); }
+                l[t] += ((e[0] + e[1]) + (e[2] + e[3])) + ((e[4] + e[5]) + (e[6] + e[7]));
+                const u32x4_t pk = {pack_h2(e[0], e[1]), pack_h2(e[2], e[3]), pack_h2(e[4], e[5]), pack_h2(e[6], e[7])};
+                const f16x8_t pf = __builtin_bit_cast(f16x8_t, pk);
+                O[t][0] = mfma_f16(__builtin_bit_cast(f16x8_t, vp[pi % 3][0]), pf, O[t][0]);
+                O[t][1] = mfma_f16(__builtin_bit_cast(f16x8_t, vp[pi % 3][1]), pf, O[t][1]);
+                asm volatile("" : "+v"(l[t]));
+              }
+            }
+          }
+#pragma unroll
+          for (int t = 0; t < NQ; ++t) {
+            const float inv = 1.f / xsum4(l[t]);
+            *reinterpret_cast<u32x4_t*>(smem + G::L_AO + ((h * NT + t0 + t) * 64 + lane) * 16) = pack_bf8(O[t][0] * inv, O[t][1] * inv);
+          }
+        }
       }
       __syncthreads();
       DS_STAMP(4);
@@ -686,7 +869,7 @@ __global__ __launch_bounds__(64 * NW, 2) void dstage_kernel(const DsArgs a) {
       if (tid == 0) __hip_atomic_store((gu32*)(haloflag + role), (unsigned)(gb + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       DS_STAMP(7);
     }
-    if constexpr (KIND == 0)
+    if constexpr (KIND != 1)
     {
       DS_PHASE
 #pragma unroll
@@ -707,7 +890,7 @@ struct DPackArgs { const bf16_t* qkv1_w; const bf16_t* qkv2_w; const bf16_t* pro
 
 template <int NW, int CT>
 __global__ __launch_bounds__(256) void dstage_pack_kernel(const DPackArgs a) {
-  using G = DG<NW, NW == 4 ? 28 : 56, CT>;
+  using G = DG<NW, NW == 8 ? 24 : NW == 4 ? 28 : 56, CT>;
   constexpr int C = G::C, KS = G::KS, KSC = G::KSC, UF = 2 * KS, PF = CT * KS, F2 = CT * KSC, CW = G::CW;
   const int f = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63, g = lane >> 4, i = lane & 15;
   if (f >= G::WS_FRAGS) return;
@@ -729,7 +912,8 @@ __global__ __launch_bounds__(256) void dstage_pack_kernel(const DPackArgs a) {
   else if (f < G::WS_V2) { const int q = f - G::WS_K2, h = q / UF, r = q - h * UF; ks = r >> 1; base = a.qkv2_w; row0 = C + 32 * h + 16 * (r & 1); }
   else if (f < G::WS_Q2) { const int q = f - G::WS_V2, h = q / UF, r = q - h * UF; ks = r >> 1; base = a.qkv2_w; row0 = 2 * C + 32 * h + 16 * (r & 1); }
   else if (f < G::WS_K1T) { const int q = f - G::WS_Q2, h = q / UF, r = q - h * UF; ks = r >> 1; base = a.qkv2_w; row0 = 32 * h + 16 * (r & 1); }
-  else { const int q = f - G::WS_PC, w = q / PF, r = q - w * PF; ks = r / CT; base = a.projc_w; row0 = CW * w + 16 * (r - ks * CT); }
+  else if (f < G::WS_K1) { const int q = f - G::WS_PC, w = q / PF, r = q - w * PF; ks = r / CT; base = a.projc_w; row0 = CW * w + 16 * (r - ks * CT); }
+  else { const int q = f - G::WS_K1, h = q / UF, r = q - h * UF; ks = r >> 1; base = a.qkv1_w; row0 = C + 32 * h + 16 * (r & 1); }
   const bf16_t* src = base + (size_t)(row0 + i) * ld + 32 * ks + 4 * g;
   const uint2 lo = *reinterpret_cast<const uint2*>(src), hi = *reinterpret_cast<const uint2*>(src + 16);
   a.out[(size_t)f * 64 + lane] = make_uint4(lo.x, lo.y, hi.x, hi.y);
@@ -739,7 +923,7 @@ template <int NW, int GW, int CT> static int ds_slots(int B, int kind) {
   int dev = 0, cus = 256;
   (void)hipGetDevice(&dev);
   (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-  int n = (cus * (8 / NW) / (kind ? DG<NW, GW, CT>::NWG_C : DG<NW, GW, CT>::NWG)) / 8 * 8;          // whole groups of 8 slots (one per XCD); 8 / NW workgroups per CU
+  int n = (cus * (8 / NW) / (kind == 1 ? DG<NW, GW, CT>::NWG_C : DG<NW, GW, CT>::NWG)) / 8 * 8;          // whole groups of 8 slots (one per XCD); 8 / NW workgroups per CU
   if (n < 8) n = 8;
   const int need = (B + 7) / 8 * 8;
   return n < need ? n : need;
@@ -776,18 +960,25 @@ template <int NW, int GW, int CT, int KIND> static int ds_launch_kind(const lmv_
   const double N = (double)d->H * d->W, lg2e = 1.4426950408889634;
   a.sx = (float)(log((double)d->M) / log(N) / sqrt((double)d->C) * lg2e);      // models/lemevit.py:255: log_N(M) C^-1/2
   a.sc = (float)(1.0 / sqrt(d->kind ? 32.0 : (double)d->C) * lg2e);            // :256; "C" blocks: F.scaled_dot_product_attention's head_dim^-1/2 (:480-483)
+  if (KIND == 2) a.sx = a.sc;                                                  // "S" blocks: both attentions are F.scaled_dot_product_attention (:199-203)
   a.timing = (unsigned long long*)d->timing; a.timing_block = d->timing_block;
   a.err = lmv_stage_errword();
   if (!a.err) LMV_FAIL(LMV_ERR_LAUNCH, "dstage_fwd: cannot allocate the error word");
-  hipLaunchKernelGGL((dstage_kernel<NW, GW, CT, KIND>), dim3(ns * (KIND ? G::NWG_C : G::NWG)), dim3(64 * NW), G::L_TOTAL, st, a);
+  hipLaunchKernelGGL((dstage_kernel<NW, GW, CT, KIND>), dim3(ns * (KIND == 1 ? G::NWG_C : G::NWG)), dim3(64 * NW), G::L_TOTAL, st, a);
   LMV_CHECK_LAUNCH("dstage_fwd");
   return LMV_OK;
 }
 template <int NW, int GW, int CT> static int ds_launch(const lmv_dstage_desc* d, const void* x, const void* c, void* x_out, void* c_out, void* workspace, hipStream_t st) {
-  if constexpr (GW == 56 || GW == 96) {          // "C" blocks exist at stage 0 only (the resolution of stage 1)
-    if (d->kind) return ds_launch_kind<NW, GW, CT, 1>(d, x, c, x_out, c_out, workspace, st);
-  } else if (d->kind) LMV_FAIL(LMV_ERR_DTYPE, "dstage_fwd: C blocks are built for the stage-0 / stage-1 grid only");
-  return ds_launch_kind<NW, GW, CT, 0>(d, x, c, x_out, c_out, workspace, st);
+  if constexpr (NW == 8) {          // the "S"-block instance (stage 3 of LeMeViT-Base at 384 x 384)
+    if (d->kind != 2) LMV_FAIL(LMV_ERR_DTYPE, "dstage_fwd: this shape is built for S blocks (kind 2) only");
+    return ds_launch_kind<NW, GW, CT, 2>(d, x, c, x_out, c_out, workspace, st);
+  } else {
+    if (d->kind == 2) LMV_FAIL(LMV_ERR_DTYPE, "dstage_fwd: S blocks (kind 2) are built for C = 384 at 24 x 24 only");
+    if constexpr (GW == 56 || GW == 96) {          // "C" blocks exist at stage 0 only (the resolution of stage 1)
+      if (d->kind) return ds_launch_kind<NW, GW, CT, 1>(d, x, c, x_out, c_out, workspace, st);
+    } else if (d->kind) LMV_FAIL(LMV_ERR_DTYPE, "dstage_fwd: C blocks are built for the stage-0 / stage-1 grid only");
+    return ds_launch_kind<NW, GW, CT, 0>(d, x, c, x_out, c_out, workspace, st);
+  }
 }
 
 }  // namespace
@@ -796,13 +987,14 @@ template <int NW, int GW, int CT> static int ds_launch(const lmv_dstage_desc* d,
 // the instances: 1000 NW + 10 GW + CT.  224 x 224 images: (4, 28, 3) / (2, 56, 3) LeMeViT-Base and -Small, (4, 28, 2) / (2, 56, 2) LeMeViT-Tiny; 384 x 384 (BASELINE config 5): (4, 48, 3) / (2, 96, 3)
 #define DS_DISPATCH(code, EXPR, DFLT)                                                                                                                   \
   ((code) == 4283 ? EXPR(4, 28, 3) : (code) == 2563 ? EXPR(2, 56, 3) : (code) == 4282 ? EXPR(4, 28, 2) : (code) == 2562 ? EXPR(2, 56, 2) : (code) == 4483 ? EXPR(4, 48, 3) : \
-   (code) == 2963 ? EXPR(2, 96, 3) : (DFLT))
-static int ds_code_of_c(int C) { return C == 192 ? 4283 : C == 96 ? 2563 : C == 128 ? 4282 : C == 64 ? 2562 : 0; }          // (what depends on C only: the packed layout)
+   (code) == 2963 ? EXPR(2, 96, 3) : (code) == 8243 ? EXPR(8, 24, 3) : (DFLT))
+static int ds_code_of_c(int C) { return C == 192 ? 4283 : C == 96 ? 2563 : C == 128 ? 4282 : C == 64 ? 2562 : C == 384 ? 8243 : 0; }          // (what depends on C only: the packed layout)
 static int ds_code(int C, int H) {
   if (C == 192) return H == 28 ? 4283 : H == 48 ? 4483 : 0;
   if (C == 96) return H == 56 ? 2563 : H == 96 ? 2963 : 0;
   if (C == 128) return H == 28 ? 4282 : 0;
   if (C == 64) return H == 56 ? 2562 : 0;
+  if (C == 384) return H == 24 ? 8243 : 0;          // ("S" blocks, kind 2)
   return 0;
 }
 static int ds_variant(int C, int heads, int hidden, int H, int W, int M) {      // 0: not supported
@@ -826,7 +1018,7 @@ template <int NW, int GW, int CT> static int ds_max_concurrent(int kind) {
   int dev = 0, cus = 256;
   (void)hipGetDevice(&dev);
   (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-  const int n = cus * (8 / NW) / (8 * (kind ? DG<NW, GW, CT>::NWG_C : DG<NW, GW, CT>::NWG));
+  const int n = cus * (8 / NW) / (8 * (kind == 1 ? DG<NW, GW, CT>::NWG_C : DG<NW, GW, CT>::NWG));
   return n < 1 ? 1 : n;
 }
 #define DS_MAXC(NW, GW, CT) ds_max_concurrent<NW, GW, CT>(kind)
@@ -859,8 +1051,8 @@ int lmv_dstage_fwd(const lmv_dstage_desc* d, const void* x, const void* c, void*
   const int nw = ds_variant(d->C, d->heads, d->hidden, d->H, d->W, d->M);
   if (!nw) LMV_FAIL(LMV_ERR_DTYPE, "dstage_fwd: unsupported stage shape");
   if (d->B <= 0 || d->nblocks <= 0 || !d->wpk || !d->vec) LMV_FAIL(LMV_ERR_SHAPE, "dstage_fwd: bad descriptor");
-  if (d->kind != 0 && d->kind != 1) LMV_FAIL(LMV_ERR_SHAPE, "dstage_fwd: kind must be 0 (D blocks) or 1 (C blocks)");
-  if ((x == x_out && !d->kind) || c == c_out) LMV_FAIL(LMV_ERR_SHAPE, "dstage_fwd: outputs must not alias the inputs");
+  if (d->kind < 0 || d->kind > 2) LMV_FAIL(LMV_ERR_SHAPE, "dstage_fwd: kind must be 0 (D blocks), 1 (C blocks) or 2 (S blocks)");
+  if ((x == x_out && d->kind != 1) || c == c_out) LMV_FAIL(LMV_ERR_SHAPE, "dstage_fwd: outputs must not alias the inputs");
   const void* ptrs[] = {x, c, x_out, c_out, workspace, d->wpk, d->vec};
   for (const void* q : ptrs) if (!lmv_aligned16(q)) LMV_FAIL(LMV_ERR_SHAPE, "dstage_fwd: pointers must be 16-byte aligned");
   if (workspace_bytes < lmv_dstage_workspace_bytes(d->B, d->C)) LMV_FAIL(LMV_ERR_WORKSPACE, "dstage_fwd: workspace too small");

@@ -83,7 +83,7 @@ __device__ __forceinline__ void ring_fill(bf16x8_t (&ring)[RD][NC], const unsign
 #pragma unroll
     for (int n = 0; n < NC; ++n) ring[s][n] = ld_frag(w, s * NC + n, lane);
 }
-template <int NC, int NKS, int RD, bool TRANS, int NTT = SS_NT>
+template <int NC, int NKS, int RD, bool TRANS, int NTT = SS_NT, int XST = NTT>          // XST: token tiles per k-step of the operand image at `xs` (NTT of them are used, from xs on)
 __device__ __forceinline__ void gemm_unit(f32x4_t (&acc)[NTT][NC], bf16x8_t (&ring)[RD][NC], const unsigned char* wcur, const unsigned char* wnext, const unsigned char* xs, int lane) {
   constexpr bool PRE = NKS % RD == 0;          // else: a unit of RD - 1 k-steps, all of them loaded by ring_fill, nothing fetched ahead (wnext unused)
   static_assert(PRE || NKS == RD - 1, "ring phase");
@@ -96,7 +96,7 @@ __device__ __forceinline__ void gemm_unit(f32x4_t (&acc)[NTT][NC], bf16x8_t (&ri
     }
 #pragma unroll
     for (int t = 0; t < NTT; ++t) {
-      const bf16x8_t xf = *reinterpret_cast<const bf16x8_t*>(xs + ((ks * NTT + t) * 64 + lane) * 16);
+      const bf16x8_t xf = *reinterpret_cast<const bf16x8_t*>(xs + ((ks * XST + t) * 64 + lane) * 16);
 #pragma unroll
       for (int n = 0; n < NC; ++n) acc[t][n] = TRANS ? mfma_bf16(ring[ks % RD][n], xf, acc[t][n]) : mfma_bf16(xf, ring[ks % RD][n], acc[t][n]);
     }

@@ -885,7 +885,13 @@ def _sstage_applies(stage, xt: Tensor, c: Tensor, H: int, W: int) -> Optional[st
             return None
     b0 = stage[0]
     if kind == "S":
-        return "S" if ops.sstage_supported(xt.shape[2], b0.attn.num_heads, b0.mlp[0].out_features, H, W, c.shape[1], xt.dtype) else None
+        if ops.sstage_supported(xt.shape[2], b0.attn.num_heads, b0.mlp[0].out_features, H, W, c.shape[1], xt.dtype):
+            return "S"
+        # longer sequences (24 x 24 image tokens at 384 x 384): the multi-workgroup kernel of the D stages with self-attention across the workgroups of an image
+        if _DSTAGE and ops.dstage_supported(xt.shape[2], b0.attn.num_heads, b0.mlp[0].out_features, H, W, c.shape[1], xt.dtype) and \
+                concurrent_launches <= ops.dstage_max_concurrent(xt.shape[2], H, 2):
+            return "S2"
+        return None
     if not (_DSTAGE and ops.dstage_supported(xt.shape[2], b0.attn.num_heads, b0.mlp[0].out_features, H, W, c.shape[1], xt.dtype)):
         return None
     if concurrent_launches > ops.dstage_max_concurrent(xt.shape[2], H, 1 if kind == "C" else 0):
@@ -898,7 +904,7 @@ def _sstage_applies(stage, xt: Tensor, c: Tensor, H: int, W: int) -> Optional[st
 def _whole_stage_fwd(whole: str, xt: Tensor, c: Tensor, packed, H: int, W: int):
     if whole == "S":
         return ops.sstage_fwd(xt, c, packed, H, W, BLOCK_LN_EPS)
-    return ops.dstage_fwd(xt, c, packed, H, W, BLOCK_LN_EPS, kind=1 if whole == "C" else 0)
+    return ops.dstage_fwd(xt, c, packed, H, W, BLOCK_LN_EPS, kind={"D": 0, "C": 1, "S2": 2}[whole])
 
 
 def _sstage_packed(stage, kind: str = "S") -> "ops.SStagePacked":
@@ -913,7 +919,7 @@ def _sstage_packed(stage, kind: str = "S") -> "ops.SStagePacked":
     for blk in stage:
         P = blk._params()
         d = {}
-        for n in {"S": ops.SSTAGE_NAMES, "D": ops.DSTAGE_NAMES, "C": ops.CSTAGE_NAMES}[kind]:
+        for n in {"S": ops.SSTAGE_NAMES, "S2": ops.SSTAGE_NAMES, "D": ops.DSTAGE_NAMES, "C": ops.CSTAGE_NAMES}[kind]:
             if n == "pos_embed.weight":
                 d[n] = P[n].detach().float().reshape(P[n].shape[0], 9).contiguous()
             elif _is_matrix(n):
@@ -921,7 +927,7 @@ def _sstage_packed(stage, kind: str = "S") -> "ops.SStagePacked":
             else:
                 d[n] = compute_copy(P[n], torch.float32)
         blocks.append(d)
-    packed = {"S": ops.sstage_pack, "D": ops.dstage_pack, "C": ops.cstage_pack}[kind](blocks, stage[0].attn.num_heads)
+    packed = {"S": ops.sstage_pack, "S2": ops.s2stage_pack, "D": ops.dstage_pack, "C": ops.cstage_pack}[kind](blocks, stage[0].attn.num_heads)
     _cache_filled()
     _sstage_cache[key] = (weakref.ref(stage, lambda _r, k=key: _sstage_cache.pop(k, None)), stamp, packed)
     return packed

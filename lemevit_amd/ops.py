@@ -737,15 +737,29 @@ def cstage_pack(blocks: Sequence[dict], heads: int) -> SStagePacked:
     return dstage_pack(out, heads)
 
 
+def s2stage_pack(blocks: Sequence[dict], heads: int) -> SStagePacked:
+    """A run of "S" blocks (SSTAGE_NAMES) in the layout of the D-stage kernel, for dstage_fwd(kind=2): the image tokens and the meta tokens share attn.qkv / attn.proj
+    (qkv1 = qkv2, proj_x = proj_c).  Stage 3 of LeMeViT-Base at 384 x 384 (576 + 16 tokens: too long for sstage_fwd's two workgroups per image)."""
+    out = []
+    for blk in blocks:
+        d = {n: blk[n] for n in ("mlp.0.weight", "mlp.3.weight", "norm1.weight", "norm1.bias", "norm2.weight", "norm2.bias", "mlp.0.bias", "mlp.3.bias", "pos_embed.weight", "pos_embed.bias")}
+        d["attn.qkv1.weight"] = d["attn.qkv2.weight"] = blk["attn.qkv.weight"]
+        d["attn.qkv1.bias"] = d["attn.qkv2.bias"] = blk["attn.qkv.bias"]
+        d["attn.proj_x.weight"] = d["attn.proj_c.weight"] = blk["attn.proj.weight"]
+        d["attn.proj_x.bias"] = d["attn.proj_c.bias"] = blk["attn.proj.bias"]
+        out.append(d)
+    return dstage_pack(out, heads)
+
+
 def dstage_fwd(x: Tensor, c: Tensor, P: SStagePacked, H: int, W: int, eps: float, timing: Optional[Tensor] = None, timing_block: int = 0, kind: int = 0) -> Tuple[Tensor, Tensor]:
-    """kind = 1: the packed blocks are "C" blocks (cstage_pack): x is returned as it came."""
+    """kind = 1: the packed blocks are "C" blocks (cstage_pack): x is returned as it came; kind = 2: "S" blocks (s2stage_pack)."""
     B, N, C_ = x.shape
     d = _lib.SStageDesc()
     d.kind = kind
     d.B, d.H, d.W, d.M, d.C, d.heads, d.hidden, d.nblocks, d.dtype, d.eps = B, H, W, c.shape[1], C_, P.heads, P.hidden, P.nblocks, dtype_code(x), eps
     d.wpk, d.vec = P.wpk.data_ptr(), P.vec.data_ptr()
     d.timing, d.timing_block = (None if timing is None else timing.data_ptr()), timing_block
-    xo, co = (x if kind else torch.empty_like(x)), torch.empty_like(c)
+    xo, co = (x if kind == 1 else torch.empty_like(x)), torch.empty_like(c)
     ws = _workspace(int(lib.lmv_dstage_workspace_bytes(B, C_)), x.device)
     check(lib.lmv_dstage_fwd(C.byref(d), _ptr(x), _ptr(c), _ptr(xo), _ptr(co), ws.data_ptr(), ws.numel(), _stream()), "lmv_dstage_fwd")
     return xo, co

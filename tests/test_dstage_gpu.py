@@ -224,6 +224,55 @@ def test_cstage_vs_oracle(nblocks, B, C, G):
     assert torch.equal(co, co2)
 
 
+# ---- "S" blocks on long sequences (stage 3 of LeMeViT-Base at 384 x 384: 24 x 24 image tokens) through the same kernel (kind = 2) ----
+def _s2(nblocks, seed, C=384):
+    sds = []
+    for j in range(nblocks):
+        sd = fill_state_dict(block_spec("S", C), seed + 17 * j)
+        for k, v in sd.items():
+            if v.dim() >= 2 and "pos_embed" not in k:
+                sd[k] = v.to(torch.bfloat16).float()
+        sds.append(sd)
+    return sds
+
+
+def _s2pack(sds):
+    from lemevit_amd import ops
+    C = sds[0]["blk.norm1.weight"].shape[0]
+    blocks = []
+    for sd in sds:
+        d = {}
+        for name in ops.SSTAGE_NAMES:
+            t = sd["blk." + name].to(DEV)
+            if name == "pos_embed.weight":
+                t = t.reshape(C, 9)
+            d[name] = t.to(torch.bfloat16) if (t.dim() >= 2 and "pos_embed" not in name) else t.float()
+        blocks.append(d)
+    return ops.s2stage_pack(blocks, C // 32)
+
+
+@pytest.mark.parametrize("nblocks,B", [(1, 1), (1, 3), (2, 2), (3, 9), (2, 40)])
+def test_s2stage_vs_oracle(nblocks, B):
+    """LeMeBlock.forward_with_x (models/lemevit.py:615-650) x depth on 576 + 16 tokens x 384 channels against the float64 oracle (6 image-row workgroups + 1 meta workgroup per image;
+    the keys and values of an image cross its workgroups through L2); B = 40: more images than slots; run-to-run bit-equality."""
+    from lemevit_amd import ops
+    C, G = 384, 24
+    sds = _s2(nblocks, 13)
+    P = _s2pack(sds)
+    x, c = _inputs(B, 7, C, G)
+    xo, co = ops.dstage_fwd(x.to(DEV), c.to(DEV), P, G, G, 1e-6, kind=2)
+    xo2, co2 = ops.dstage_fwd(x.to(DEV), c.to(DEV), P, G, G, 1e-6, kind=2)
+    torch.cuda.synchronize()
+    assert torch.equal(xo, xo2) and torch.equal(co, co2)
+    idx = list(range(4)) + [B - 2, B - 1] if B > 6 else list(range(B))
+    xr, cr = x[idx].double(), c[idx].double()
+    for sd in sds:
+        xr, cr = O.leme_block({k: v.double() for k, v in sd.items()}, "blk.", "S", xr, cr, G, G, C // 32)
+    ex, ec = _rel(xo[idx].float(), xr), _rel(co[idx].float(), cr)
+    print(f"s2stage nblocks={nblocks} B={B}: x {ex:.2e} c {ec:.2e}")
+    assert ex <= 1e-2 and ec <= 1e-2, (ex, ec)
+
+
 def test_no_handoff_ever_timed_out():
     """Runs last in this file: the sticky error word of the stage kernels (a bounded in-launch wait that ran out) is still clear after every launch above."""
     from lemevit_amd import ops

@@ -665,6 +665,13 @@ __global__ __launch_bounds__(64 * NW, 2) void dstage_kernel(const DsArgs a) {
       } else {
         // =========== "S" blocks: self-attention of the image tokens (models/lemevit.py:185-205), the keys and values of the whole image through L2 ===========
         constexpr int KT = KWG * NT, NPW = NT / 2, NQ = NT / 2;          // key tiles of the image; key-tile pairs / query tiles of a unit per workgroup
+#ifndef DS_RG1
+#define DS_RG1 3
+#endif
+#ifndef DS_RG2
+#define DS_RG2 3
+#endif
+        constexpr int RG1 = DS_RG1, RG2 = DS_RG2;          // key-tile pairs in flight (ring depth) of the two attention passes
         static_assert(NW == 8 && NT % 2 == 0 && (2 * NH) % NW == 0, "S blocks: the 8-wave instance");
         unsigned char* const kvw = kvb + (size_t)(gb & 1) * (2 * G::KV_HALF);
         const __amdgpu_buffer_rsrc_t kr = __builtin_amdgcn_make_buffer_rsrc(kvw, 0, (int)(2 * G::KV_HALF), 0x00020000);
@@ -751,31 +758,34 @@ __global__ __launch_bounds__(64 * NW, 2) void dstage_kernel(const DsArgs a) {
 #pragma unroll
           for (int t = 0; t < NQ; ++t) m[t] = -INFINITY;
           {
-            u32x4_t kp[3][2];
+            u32x4_t kp[RG1][2];
 #pragma unroll
-            for (int pi = 0; pi < 2; ++pi)
+            for (int pi = 0; pi < RG1 - 1; ++pi)
 #pragma unroll
               for (int e = 0; e < 2; ++e) kp[pi][e] = __builtin_amdgcn_raw_buffer_load_b128(kr, kbase + (2 * pi + e) * 1024, 0, 16);
 #pragma unroll
             for (int pi = 0; pi < KT / 2; ++pi) {
-              if (pi + 2 < KT / 2) {
+              if (pi + RG1 - 1 < KT / 2) {
 #pragma unroll
-                for (int e = 0; e < 2; ++e) kp[(pi + 2) % 3][e] = __builtin_amdgcn_raw_buffer_load_b128(kr, kbase + (2 * (pi + 2) + e) * 1024, 0, 16);
+                for (int e = 0; e < 2; ++e) kp[(pi + RG1 - 1) % RG1][e] = __builtin_amdgcn_raw_buffer_load_b128(kr, kbase + (2 * (pi + RG1 - 1) + e) * 1024, 0, 16);
               }
 #pragma unroll
               for (int e = 0; e < 2; ++e)
 #pragma unroll
-                for (int t = 0; t < NQ; ++t) m[t] = max2(m[t], max4(mfma_bf16(as_bf8(kp[pi % 3][e]), Q[t], z4)));
+                for (int t = 0; t < NQ; ++t) { const f32x4_t sc = mfma_bf16(as_bf8(kp[pi % RG1][e]), Q[t], z4); m[t] = fmaxf(fmaxf(fmaxf(sc[0], sc[1]), fmaxf(sc[2], sc[3])), m[t]); }
             }
           }
-          float l[NQ]; f32x4_t O[NQ][2];
+          // second pass: the row maximum rides the score MFMA as its accumulator input (s - m for free), the row sums come out of one more MFMA against a fragment of ones
+          // (sum over the 32 keys of the pair AND over the lane groups: no adds, no cross-lane step) -- the pass is VALU-bound, the matrix pipe has the room
+          f32x4_t L[NQ], O[NQ][2], negm[NQ];
+          const f16x8_t ones = {(_Float16)1.f, (_Float16)1.f, (_Float16)1.f, (_Float16)1.f, (_Float16)1.f, (_Float16)1.f, (_Float16)1.f, (_Float16)1.f};
 #pragma unroll
-          for (int t = 0; t < NQ; ++t) { m[t] = xmax4(m[t]); l[t] = 0.f; O[t][0] = z4; O[t][1] = z4; asm volatile("" : "+v"(Q[t])); }
+          for (int t = 0; t < NQ; ++t) { m[t] = xmax4(m[t]); negm[t] = f32x4_t{-m[t], -m[t], -m[t], -m[t]}; L[t] = z4; O[t][0] = z4; O[t][1] = z4; asm volatile("" : "+v"(Q[t])); }
           {
             int ko = 0; asm volatile("" : "+v"(ko));          // (an opaque offset: the second pass's loads and score tiles are not the first pass's)
-            u32x4_t kp[3][2], vp[3][2];
+            u32x4_t kp[RG2][2], vp[RG2][2];
 #pragma unroll
-            for (int pi = 0; pi < 2; ++pi)
+            for (int pi = 0; pi < RG2 - 1; ++pi)
 #pragma unroll
               for (int e = 0; e < 2; ++e) {
                 kp[pi][e] = __builtin_amdgcn_raw_buffer_load_b128(kr, ko + kbase + (2 * pi + e) * 1024, 0, 16);
@@ -783,31 +793,30 @@ __global__ __launch_bounds__(64 * NW, 2) void dstage_kernel(const DsArgs a) {
               }
 #pragma unroll
             for (int pi = 0; pi < KT / 2; ++pi) {
-              if (pi + 2 < KT / 2) {
+              if (pi + RG2 - 1 < KT / 2) {
 #pragma unroll
                 for (int e = 0; e < 2; ++e) {
-                  kp[(pi + 2) % 3][e] = __builtin_amdgcn_raw_buffer_load_b128(kr, ko + kbase + (2 * (pi + 2) + e) * 1024, 0, 16);
-                  vp[(pi + 2) % 3][e] = __builtin_amdgcn_raw_buffer_load_b128(kr, ko + vbase + (2 * (pi + 2) + e) * 1024, 0, 16);
+                  kp[(pi + RG2 - 1) % RG2][e] = __builtin_amdgcn_raw_buffer_load_b128(kr, ko + kbase + (2 * (pi + RG2 - 1) + e) * 1024, 0, 16);
+                  vp[(pi + RG2 - 1) % RG2][e] = __builtin_amdgcn_raw_buffer_load_b128(kr, ko + vbase + (2 * (pi + RG2 - 1) + e) * 1024, 0, 16);
                 }
               }
 #pragma unroll
               for (int t = 0; t < NQ; ++t) {
-                const f32x4_t s0 = mfma_bf16(as_bf8(kp[pi % 3][0]), Q[t], z4), s1 = mfma_bf16(as_bf8(kp[pi % 3][1]), Q[t], z4);
+                const f32x4_t s0 = mfma_bf16(as_bf8(kp[pi % RG2][0]), Q[t], negm[t]), s1 = mfma_bf16(as_bf8(kp[pi % RG2][1]), Q[t], negm[t]);
                 float e[8];
 #pragma unroll
-                for (int r = 0; r < 4; ++r) { e[r] = __builtin_amdgcn_exp2f(s0[r] - m[t]); e[4 + r] = __builtin_amdgcn_exp2f(s1[r] - m[t]); }
-                l[t] += ((e[0] + e[1]) + (e[2] + e[3])) + ((e[4] + e[5]) + (e[6] + e[7]));
+                for (int r = 0; r < 4; ++r) { e[r] = __builtin_amdgcn_exp2f(s0[r]); e[4 + r] = __builtin_amdgcn_exp2f(s1[r]); }
                 const u32x4_t pk = {pack_h2(e[0], e[1]), pack_h2(e[2], e[3]), pack_h2(e[4], e[5]), pack_h2(e[6], e[7])};
                 const f16x8_t pf = __builtin_bit_cast(f16x8_t, pk);
-                O[t][0] = mfma_f16(__builtin_bit_cast(f16x8_t, vp[pi % 3][0]), pf, O[t][0]);
-                O[t][1] = mfma_f16(__builtin_bit_cast(f16x8_t, vp[pi % 3][1]), pf, O[t][1]);
-                asm volatile("" : "+v"(l[t]));
+                O[t][0] = mfma_f16(__builtin_bit_cast(f16x8_t, vp[pi % RG2][0]), pf, O[t][0]);
+                O[t][1] = mfma_f16(__builtin_bit_cast(f16x8_t, vp[pi % RG2][1]), pf, O[t][1]);
+                L[t] = mfma_f16(ones, pf, L[t]);
               }
             }
           }
 #pragma unroll
           for (int t = 0; t < NQ; ++t) {
-            const float inv = 1.f / xsum4(l[t]);
+            const float inv = 1.f / L[t][0];
             *reinterpret_cast<u32x4_t*>(smem + G::L_AO + ((h * NT + t0 + t) * 64 + lane) * 16) = pack_bf8(O[t][0] * inv, O[t][1] * inv);
           }
         }

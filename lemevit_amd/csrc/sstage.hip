@@ -187,10 +187,12 @@ __device__ __forceinline__ void attn_image(const bf16x8_t (&Qf)[SS_NT], int h, _
   // score tiles (208 registers at NQ = 4) alive instead
 #pragma unroll
   for (int kt = 0; kt < 13; ++kt) asm volatile("" : "+v"(K[kt]));
-  f32x4_t O[NQ][2];
-  float l[NQ];
+  // second pass (VALU-bound; the matrix pipe has room): the row maximum rides the score MFMA as its accumulator input (s - m for free; -inf where a key does not exist), the row
+  // sums come out of one more MFMA against a fragment of ones (over the 32 keys of the step and over the lane groups: no adds, no cross-lane step)
+  f32x4_t O[NQ][2], L[NQ], negm[NQ];
+  const f16x8_t ones = {(_Float16)1.f, (_Float16)1.f, (_Float16)1.f, (_Float16)1.f, (_Float16)1.f, (_Float16)1.f, (_Float16)1.f, (_Float16)1.f};
 #pragma unroll
-  for (int q = 0; q < NQ; ++q) { O[q][0] = z4; O[q][1] = z4; l[q] = 0.f; }
+  for (int q = 0; q < NQ; ++q) { O[q][0] = z4; O[q][1] = z4; L[q] = z4; negm[q] = f32x4_t{-mx[q], -mx[q], -mx[q], -mx[q]}; }
   // key tiles (ta, tb) of step s and their V pair slot: half-0 pairs (0,1) (2,3) (4,5) (6,-), half-1 pairs (7,8) (9,10) (11,12)
 #pragma unroll
   for (int s = 0; s < 7; ++s) {
@@ -199,32 +201,31 @@ __device__ __forceinline__ void attn_image(const bf16x8_t (&Qf)[SS_NT], int h, _
     const bool dummy = s == 3;
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
-      const f32x4_t sa = mfma_bf16(as_bf8(K[ta]), Qf[T0 + q], z4);
+      const f32x4_t sa = mfma_bf16(as_bf8(K[ta]), Qf[T0 + q], negm[q]);
       float p[8];
 #pragma unroll
-      for (int r = 0; r < 4; ++r) p[r] = __builtin_amdgcn_exp2f(sa[r] - mx[q]);
+      for (int r = 0; r < 4; ++r) p[r] = __builtin_amdgcn_exp2f(sa[r]);
       if (!dummy) {
-        const f32x4_t sb = mfma_bf16(as_bf8(K[ta + 1]), Qf[T0 + q], z4);
-        const float mb = (s == 6 && g != 0) ? INFINITY : mx[q];      // exp2(s - inf) = 0: absent keys
+        const float nb = (s == 6 && g != 0) ? -INFINITY : -mx[q];      // exp2(-inf) = 0: absent keys
+        const f32x4_t sb = mfma_bf16(as_bf8(K[ta + 1]), Qf[T0 + q], s == 6 ? f32x4_t{nb, nb, nb, nb} : negm[q]);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) p[4 + r] = __builtin_amdgcn_exp2f(sb[r] - mb);
+        for (int r = 0; r < 4; ++r) p[4 + r] = __builtin_amdgcn_exp2f(sb[r]);
       } else {
 #pragma unroll
         for (int r = 0; r < 4; ++r) p[4 + r] = 0.f;
       }
-      l[q] += ((p[0] + p[1]) + (p[2] + p[3])) + ((p[4] + p[5]) + (p[6] + p[7]));
-      asm volatile("" : "+v"(l[q]));        // summed HERE: LLVM otherwise sinks all row sums to their use behind the last step and keeps every p alive until then
       const u32x4_t pk = {pack_h2(p[0], p[1]), pack_h2(p[2], p[3]), pack_h2(p[4], p[5]), pack_h2(p[6], p[7])};
       const f16x8_t pf = __builtin_bit_cast(f16x8_t, pk);
       O[q][0] = mfma_f16(__builtin_bit_cast(f16x8_t, V[s][0]), pf, O[q][0]);
       O[q][1] = mfma_f16(__builtin_bit_cast(f16x8_t, V[s][1]), pf, O[q][1]);
+      L[q] = mfma_f16(ones, pf, L[q]);
       if (q % SS_QFENCE == SS_QFENCE - 1) __builtin_amdgcn_sched_barrier(0);      // unfenced, the scheduler pulls every V request to the top and interleaves all steps and tiles (spills)
     }
     __builtin_amdgcn_sched_barrier(0);
   }
 #pragma unroll
   for (int q = 0; q < NQ; ++q) {
-    const float inv = 1.f / xsum4(l[q]);
+    const float inv = 1.f / L[q][0];
     const u32x4_t o = pack_bf8(O[q][0] * inv, O[q][1] * inv);
     *reinterpret_cast<u32x4_t*>(smem + L_AO + ((h * SS_NT + T0 + q) * 64 + lane) * 16) = o;
   }

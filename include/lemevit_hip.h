@@ -462,6 +462,9 @@ typedef struct lmv_dstage_block_params {
   const float* n2_w; const float* n2_b; const float* fc1_b; const float* fc2_b;
   const float* pos_w; const float* pos_b;
 } lmv_dstage_block_params;
+/* kind = 2: a run of "S" blocks on a long sequence (LeMeBlock.forward_with_x, models/lemevit.py:615-650; C = 384, 24 x 24 image tokens: stage 3 of LeMeViT-Base at 384 x 384), packed as a D
+ * block with qkv1 = qkv2 = attn.qkv and proj_x = proj_c = attn.proj (lemevit_amd/ops.py::s2stage_pack): 6 image-row workgroups + 1 meta workgroup per image, the image's keys and values cross
+ * its workgroups through L2. */
 typedef lmv_sstage_desc lmv_dstage_desc;          /* same fields; timing: uint64 stamps [workgroup][waves][16]; kind = 1: a run of "C" blocks (stage 0: LeMeBlock.forward_with_c,
                                                    * models/lemevit.py:584-612 -- only the meta tokens change: c += proj(softmax(q(n1 c) k(n1 x')^T / sqrt(32)) v(n1 x')), c += mlp(n2 c) with x' = x + dwconv(x);
                                                    * x passes through, x_out is not written and may be NULL-equivalent = x).  Packed as a D block with qkv1 = [0 | attn.kv], qkv2 = [attn.q | 0 | 0],

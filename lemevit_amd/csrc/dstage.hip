@@ -493,16 +493,11 @@ __global__ __launch_bounds__(64 * NW, 2) void dstage_kernel(const DsArgs a) {
               *reinterpret_cast<u32x4_t*>(stg + (srow * G::STG_COLS + tok + 1) * 32 + 16 * q) = hv;
             }
           }
-          // tap weights as bf16 pairs (w, 0) / (0, w): v_dot2c_f32_bf16 of a loaded channel pair with one of them is that channel's tap product, accumulated in fp32
-          // (bf16 taps, as the reference's autocast convolution; the fp16 image of an earlier version overflowed on residual streams beyond 65504)
+          // tap weights: bf16 pairs (w, 0) / (0, w), packed by lmv_*stage_pack (stage_common.h): v_dot2c_f32_bf16 of a loaded channel pair with one of them is that channel's tap product,
+          // accumulated in fp32 (bf16 taps, as the reference's autocast convolution; the fp16 image of an earlier version overflowed on residual streams beyond 65504)
           unsigned wt[36];
 #pragma unroll
-          for (int e = 0; e < 9; ++e) {
-            const float4 v = wq[ct & 1][e];
-            const float w4[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-            for (int q = 0; q < 4; ++q) { const int k = 4 * e + q; wt[k] = (k / 9) & 1 ? pack_bf2(0.f, w4[q]) : pack_bf2(w4[q], 0.f); }
-          }
+          for (int e = 0; e < 9; ++e) { const float4 v = wq[ct & 1][e]; wt[4 * e] = __float_as_uint(v.x); wt[4 * e + 1] = __float_as_uint(v.y); wt[4 * e + 2] = __float_as_uint(v.z); wt[4 * e + 3] = __float_as_uint(v.w); }
           const float4 pb = wq[ct & 1][9];
 #pragma unroll
           for (int t = 0; t < NT; ++t) {
@@ -1048,9 +1043,11 @@ int lmv_dstage_pack(const lmv_dstage_block_params* p, void* wpk_out, float* vec_
   LMV_CHECK_LAUNCH("dstage_pack");
   const int C = p->C;
   const struct { const float* src; int off, n; } v[] = {{p->n1_w, 0, C}, {p->n1_b, C, C}, {p->qkv1_b, 2 * C, 3 * C}, {p->qkv2_b, 5 * C, 3 * C}, {p->projx_b, 8 * C, C}, {p->projc_b, 9 * C, C},
-                                                        {p->n2_w, 10 * C, C}, {p->n2_b, 11 * C, C}, {p->fc1_b, 12 * C, 4 * C}, {p->fc2_b, 16 * C, C}, {p->pos_w, 17 * C, 9 * C}, {p->pos_b, 26 * C, C}};
+                                                        {p->n2_w, 10 * C, C}, {p->n2_b, 11 * C, C}, {p->fc1_b, 12 * C, 4 * C}, {p->fc2_b, 16 * C, C}, {p->pos_b, 26 * C, C}};
   for (const auto& e : v)
     if (hipMemcpyAsync(vec_out + e.off, e.src, (size_t)e.n * sizeof(float), hipMemcpyDeviceToDevice, st) != hipSuccess) LMV_FAIL(LMV_ERR_LAUNCH, "dstage_pack: vector copy failed");
+  hipLaunchKernelGGL(stage_posw_pack_kernel, dim3((9 * C + 255) / 256), dim3(256), 0, st, p->pos_w, reinterpret_cast<unsigned*>(vec_out + 17 * C), 9 * C);          // the 3 x 3 taps as bf16 pair words
+  LMV_CHECK_LAUNCH("dstage_pack");
   return LMV_OK;
 }
 

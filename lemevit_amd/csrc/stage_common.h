@@ -104,4 +104,14 @@ __device__ __forceinline__ void gemm_unit(f32x4_t (&acc)[NTT][NC], bf16x8_t (&ri
 }
 
 // ---- LayerNorm of the register-resident rows -> bf16 token operand in LDS (fragment order) ------------------------------------------
+// The depth-wise 3 x 3 weights as the stage kernels read them: word [c * 9 + tap] = the bf16 pair (w, 0) for even channels, (0, w) for odd ones -- v_dot2c_f32_bf16 of a loaded
+// channel pair with it is that channel's tap product; the words replace the fp32 taps in the packed vector (same count), so a lane's 4 channels x 9 taps are 9 float4 loads and no
+// conversion in the kernel.
+__global__ __launch_bounds__(256) void stage_posw_pack_kernel(const float* __restrict__ w, unsigned* __restrict__ out, int n) {          // w [C][9]
+  const int k = blockIdx.x * 256 + threadIdx.x;
+  if (k >= n) return;
+  const int c = k / 9;
+  out[k] = (c & 1) ? pack_bf2(0.f, w[k]) : pack_bf2(w[k], 0.f);
+}
+
 }  // namespace

@@ -15,9 +15,9 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
     tabs = [r[0] for r in db.execute("select name from sqlite_master where type in ('table','view')")]
     cc = [t for t in tabs if t.startswith('counters_collection')][0]
     rows = db.execute(f"select kernel_name, value, start from {cc} where counter_name = '{c}' order by start").fetchall()
-    # steps: 2 warm-up + 4 timed (--no-issue-probe); a step starts at the stem's im2col launch (once per pass), the first passes carry
+    # steps: 2 warm-up + 4 timed (--no-issue-probe); a step starts at the stem's first launch (once per pass), the first passes carry
     # one-time kernels (weight folds, casts), so count from the 3rd marker to the end = the 4 timed passes
-    marks = [i for i, r in enumerate(rows) if 'im2col_c3_kernel' in r[0]]
+    marks = [i for i, r in enumerate(rows) if 'im2col_c3_kernel' in r[0] or 'stem_kernel' in r[0]]          # (training / the per-launch stem; the one-launch stem of the inference forward)
     assert len(marks) % 6 == 0 and marks, len(marks)      # (inference as k concurrent sub-batches: k stem launches per pass)
     sel = rows[marks[2 * (len(marks) // 6)]:]
     per = len(sel) // 4

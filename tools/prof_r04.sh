@@ -30,8 +30,8 @@ python bench.py --img 384 --batch 64 --mode infer --no-cpu-baseline > $O/bench_b
 python bench.py --img 384 --batch 64 --no-cpu-baseline --no-forward-probe > $O/bench_base384_b64_train.json 2>/dev/null
 python tools/sstage_timeline.py 5 > $O/sstage_timeline.txt 2>&1
 (python tools/stem_timeline.py 48 96 128; python tools/stem_timeline.py 32 64 256) > $O/stem_timeline.txt 2>&1
-(python tools/dstage_timeline.py 1 128 4 192; python tools/dstage_timeline.py 1 128 4 96; python tools/dstage_timeline.py 1 256 2 128; python tools/dstage_timeline.py 1 256 2 64) > $O/dstage_timeline.txt 2>&1
-(python tools/stage_times.py lemevit_base 128; python tools/stage_times.py lemevit_tiny 256; python tools/stage_times.py lemevit_small 128) > $O/stage_times.txt 2>&1
+(python tools/dstage_timeline.py 1 128 4 192; python tools/dstage_timeline.py 1 128 4 96; python tools/dstage_timeline.py 1 256 2 128; python tools/dstage_timeline.py 1 256 2 64; python tools/dstage_timeline.py 1 64 18 384) > $O/dstage_timeline.txt 2>&1
+(python tools/stage_times.py lemevit_base 128; python tools/stage_times.py lemevit_tiny 256; python tools/stage_times.py lemevit_small 128; python tools/stage_times.py lemevit_base 64 384) > $O/stage_times.txt 2>&1
 python bench.py --model lemevit_tiny --batch 256 --mode infer --no-cpu-baseline --infer-parts 1 > $O/bench_tiny224_b256_infer_one_stream.json 2>/dev/null
 python bench.py --model lemevit_small --mode infer --no-cpu-baseline > $O/bench_small224_b128_infer.json 2>/dev/null
 bash tools/prof_infer.sh $O/tiny_infer_kernel_stats.csv --infer-parts 1 --model lemevit_tiny --batch 256 > $O/prof_infer_tiny.log 2>&1

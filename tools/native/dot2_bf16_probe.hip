@@ -1,3 +1,4 @@
+// Probe: v_dot2c_f32_bf16 / v_dot2_f32_bf16 / the builtin on (w, 0) and (0, w) pairs (the depth-wise taps of csrc/sstage.hip, dstage.hip); prints the three results beside the expected value.
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstring>

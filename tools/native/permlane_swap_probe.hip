@@ -1,3 +1,4 @@
+// Probe: sum over the 4 lane groups of a 16-lane row with v_permlane16_swap + v_permlane32_swap against the __shfl_xor form (lmv_xsum4, csrc/common.h).
 #include <hip/hip_runtime.h>
 #include <cstdio>
 __device__ __forceinline__ float xsum4b(float v) {

@@ -413,6 +413,17 @@ def main():
                 traffic_src = (f"canned: profiles/{os.path.basename(pmc)} (MB per launch over the forward-form Linear launches -- gemm_kernel<bf16,NT>, rs_gemm_kernel, "
                                "wn_gemm_kernel -- of this command's train step, separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, tools/pmc_traffic.sh; NOT measured "
                                "in this run; that launch set also holds the dX launches that run as forward-form GEMMs on transposed weights)")
+            elif gkind == 1 and not train and args.model == "lemevit_base" and args.img == 224 and args.batch == 128:
+                # the persistent stage-3 launch: per-kernel PMC table of the same command (tools/pmc_kernels.sh; one launch = the whole batch)
+                cands_k = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_pmc_per_kernel_infer.csv")))
+                if cands_k:
+                    import csv
+                    with open(cands_k[-1]) as f:
+                        for row in csv.DictReader(f):
+                            if row["kernel"].startswith("sstage_kernel<8>"):
+                                traffic = round(float(row["fetch_MB_per_launch(x2_corrected)"]) + float(row["write_MB_per_launch"]), 1)
+                                traffic_src = (f"canned: profiles/{os.path.basename(cands_k[-1])} (whole-batch launch; FETCH_SIZE x 2 + WRITE_SIZE at the L2-fabric boundary: it counts the write-through "
+                                               "K / V and halo exchanges and the parked residual registers of the launch -- MALL-absorbable traffic, DESIGN 4.9 -- not only the algorithmic tokens + weights)")
             elif train and gkind == 0:
                 print("bench.py: no profiles/rNN_gemm_fwd_pmc_traffic.json for this workload: roofline.traffic stays null", file=sys.stderr)
             # SURVEY 8(d) grades the path against the MFMA roof (94 % of the MACs are Linear GEMMs), so that is the primary figure.  The

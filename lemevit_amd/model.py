@@ -878,7 +878,7 @@ def _sstage_applies(stage, xt: Tensor, c: Tensor, H: int, W: int) -> Optional[st
     if not (_SSTAGE and _FUSED and _NATIVE) or torch.is_grad_enabled() or xt.dtype != torch.bfloat16 or len(stage) == 0 or not xt.is_cuda:
         return None
     kind = getattr(stage[0], "kind", None)
-    if kind not in ("S", "D", "C"):
+    if kind not in ("S", "D", "D2", "C"):
         return None
     for blk in stage:
         if type(blk) is not LeMeBlock or blk.kind != kind or (blk.training and blk.drop_prob > 0.0) or type(blk)._masks is not LeMeBlock._masks or "_masks" in blk.__dict__:
@@ -898,13 +898,15 @@ def _sstage_applies(stage, xt: Tensor, c: Tensor, H: int, W: int) -> Optional[st
         return None          # graph.split_forward runs more sub-batches side by side than launches of this shape may share the chip (96 x 96 grids: one)
     if kind == "D":
         return "D" if all(type(blk.attn) is DualCrossAttention and blk.attn.scale == xt.shape[2] ** (-0.5) for blk in stage) else None
+    if kind == "D2":          # (lemevit_tiny_v2: the same kernel, other packing -- ops.d2stage_pack)
+        return "D2" if all(type(blk.attn) is DualCrossAttention_v2 and blk.attn.scale == xt.shape[2] ** (-0.5) for blk in stage) else None
     return "C" if all(type(blk.attn) is CrossAttention for blk in stage) else None          # stage 0: only the meta tokens change (:584-612)
 
 
 def _whole_stage_fwd(whole: str, xt: Tensor, c: Tensor, packed, H: int, W: int):
     if whole == "S":
         return ops.sstage_fwd(xt, c, packed, H, W, BLOCK_LN_EPS)
-    return ops.dstage_fwd(xt, c, packed, H, W, BLOCK_LN_EPS, kind={"D": 0, "C": 1, "S2": 2}[whole])
+    return ops.dstage_fwd(xt, c, packed, H, W, BLOCK_LN_EPS, kind={"D": 0, "D2": 0, "C": 1, "S2": 2}[whole])
 
 
 def _sstage_packed(stage, kind: str = "S") -> "ops.SStagePacked":
@@ -919,7 +921,7 @@ def _sstage_packed(stage, kind: str = "S") -> "ops.SStagePacked":
     for blk in stage:
         P = blk._params()
         d = {}
-        for n in {"S": ops.SSTAGE_NAMES, "S2": ops.SSTAGE_NAMES, "D": ops.DSTAGE_NAMES, "C": ops.CSTAGE_NAMES}[kind]:
+        for n in {"S": ops.SSTAGE_NAMES, "S2": ops.SSTAGE_NAMES, "D": ops.DSTAGE_NAMES, "D2": ops.D2STAGE_NAMES, "C": ops.CSTAGE_NAMES}[kind]:
             if n == "pos_embed.weight":
                 d[n] = P[n].detach().float().reshape(P[n].shape[0], 9).contiguous()
             elif _is_matrix(n):
@@ -927,7 +929,7 @@ def _sstage_packed(stage, kind: str = "S") -> "ops.SStagePacked":
             else:
                 d[n] = compute_copy(P[n], torch.float32)
         blocks.append(d)
-    packed = {"S": ops.sstage_pack, "S2": ops.s2stage_pack, "D": ops.dstage_pack, "C": ops.cstage_pack}[kind](blocks, stage[0].attn.num_heads)
+    packed = {"S": ops.sstage_pack, "S2": ops.s2stage_pack, "D": ops.dstage_pack, "D2": ops.d2stage_pack, "C": ops.cstage_pack}[kind](blocks, stage[0].attn.num_heads)
     _cache_filled()
     _sstage_cache[key] = (weakref.ref(stage, lambda _r, k=key: _sstage_cache.pop(k, None)), stamp, packed)
     return packed

@@ -751,6 +751,28 @@ def s2stage_pack(blocks: Sequence[dict], heads: int) -> SStagePacked:
     return dstage_pack(out, heads)
 
 
+D2STAGE_NAMES = ("attn.qv1.weight", "attn.kv2.weight", "attn.proj_x.weight", "attn.proj_c.weight", "mlp.0.weight", "mlp.3.weight", "norm1.weight", "norm1.bias", "attn.qv1.bias", "attn.kv2.bias",
+                 "attn.proj_x.bias", "attn.proj_c.bias", "norm2.weight", "norm2.bias", "mlp.0.bias", "mlp.3.bias", "pos_embed.weight", "pos_embed.bias")
+
+
+def d2stage_pack(blocks: Sequence[dict], heads: int) -> SStagePacked:
+    """A run of "D2" blocks (DualCrossAttention_v2, models/lemevit.py:327-418: the image tokens' q is also their key, the meta tokens' k also their query) in the D-stage
+    kernel's layout, for dstage_fwd(kind=0): qkv1 = [q | q | v1] from attn.qv1, qkv2 = [k | k | v2] from attn.kv2 -- x' = softmax(q k^T s_x) v2, c' = softmax(k q^T s_c) v1."""
+    out = []
+    for blk in blocks:
+        qv1, kv2 = blk["attn.qv1.weight"], blk["attn.kv2.weight"]
+        C_ = qv1.shape[1]
+        b1, b2 = blk["attn.qv1.bias"].float(), blk["attn.kv2.bias"].float()
+        d = {n: blk[n] for n in ("attn.proj_x.weight", "attn.proj_c.weight", "attn.proj_x.bias", "attn.proj_c.bias", "mlp.0.weight", "mlp.3.weight", "norm1.weight", "norm1.bias",
+                                 "norm2.weight", "norm2.bias", "mlp.0.bias", "mlp.3.bias", "pos_embed.weight", "pos_embed.bias")}
+        d["attn.qkv1.weight"] = torch.cat([qv1[:C_], qv1[:C_], qv1[C_:]], 0)
+        d["attn.qkv2.weight"] = torch.cat([kv2[:C_], kv2[:C_], kv2[C_:]], 0)
+        d["attn.qkv1.bias"] = torch.cat([b1[:C_], b1[:C_], b1[C_:]], 0)
+        d["attn.qkv2.bias"] = torch.cat([b2[:C_], b2[:C_], b2[C_:]], 0)
+        out.append(d)
+    return dstage_pack(out, heads)
+
+
 def dstage_fwd(x: Tensor, c: Tensor, P: SStagePacked, H: int, W: int, eps: float, timing: Optional[Tensor] = None, timing_block: int = 0, kind: int = 0) -> Tuple[Tensor, Tensor]:
     """kind = 1: the packed blocks are "C" blocks (cstage_pack): x is returned as it came; kind = 2: "S" blocks (s2stage_pack)."""
     B, N, C_ = x.shape

@@ -318,6 +318,35 @@ def test_s2stage_full_size_and_under_load():
             assert torch.equal(half[0], ref[0][:32]) and torch.equal(half[1], ref[1][:32]), rnd
 
 
+@pytest.mark.parametrize("C,G", [(96, 56), (192, 28)])
+def test_d2stage_vs_oracle(C, G):
+    """DualCrossAttention_v2 blocks ("D2", lemevit_tiny_v2: models/lemevit.py:327-418) through the D kernel by packing alone (ops.d2stage_pack): against the float64 oracle."""
+    from lemevit_amd import ops
+    sds = []
+    for j in range(2):
+        sd = fill_state_dict(block_spec("D2", C), 41 + 17 * j)
+        sds.append({k: (v.to(torch.bfloat16).float() if v.dim() >= 2 and "pos_embed" not in k else v) for k, v in sd.items()})
+    blocks = []
+    for sd in sds:
+        d = {}
+        for name in ops.D2STAGE_NAMES:
+            t = sd["blk." + name].to(DEV)
+            if name == "pos_embed.weight":
+                t = t.reshape(C, 9)
+            d[name] = t.to(torch.bfloat16) if (t.dim() >= 2 and "pos_embed" not in name) else t.float()
+        blocks.append(d)
+    P = ops.d2stage_pack(blocks, C // 32)
+    x, c = _inputs(5, 11, C, G)
+    xo, co = ops.dstage_fwd(x.to(DEV), c.to(DEV), P, G, G, 1e-6)
+    torch.cuda.synchronize()
+    xr, cr = x.double(), c.double()
+    for sd in sds:
+        xr, cr = O.leme_block({k: v.double() for k, v in sd.items()}, "blk.", "D2", xr, cr, G, G, C // 32)
+    ex, ec = _rel(xo.float(), xr), _rel(co.float(), cr)
+    print(f"d2stage C={C}: x {ex:.2e} c {ec:.2e}")
+    assert ex <= 1e-2 and ec <= 1e-2, (ex, ec)
+
+
 def test_no_handoff_ever_timed_out():
     """Runs last in this file: the sticky error word of the stage kernels (a bounded in-launch wait that ran out) is still clear after every launch above."""
     from lemevit_amd import ops

@@ -349,7 +349,7 @@ def main():
     # The north-star target is FORWARD throughput (BASELINE.json): in train mode the same process times the forward pass of the same
     # model on the same batch right after the train region (eval mode, no_grad, bf16 autocast, hipGraph replay as in --mode infer) and
     # reports it as extra keys of the same JSON line.  The timed train region above is not touched by it.
-    fwd_dt, fwd_iters, fwd_note = None, 0, None
+    fwd_dt, fwd_iters, fwd_note, fwd_probe = None, 0, None, None
     if train and not args.no_forward_probe:
         model.eval()
 
@@ -376,6 +376,30 @@ def main():
             fstep()
         sync()
         fwd_dt = time.perf_counter() - tf0
+        fwd_probe = None
+        if rank == 0 and not args.no_kernel_timing:
+            # the forward pass's own dominant launch (the persistent stage-3 kernel on this workload), whole batch on one stream, by the same library probe
+            import ctypes
+            from lemevit_amd import _lib as _L
+            from lemevit_amd.graph import split_forward as _sf
+            cap = 4096
+            _L.check(_L.lib.lmv_debug_launch_timing(cap), "lmv_debug_launch_timing")
+            for _ in range(2):
+                with torch.no_grad(), torch.autocast("cuda", torch.bfloat16):
+                    _sf(model, x, 1, [])
+            torch.cuda.synchronize()
+            ms_, fl_, by_, kd_ = (ctypes.c_float * cap)(), (ctypes.c_double * cap)(), (ctypes.c_double * cap)(), (ctypes.c_int * cap)()
+            n_ = _L.lib.lmv_debug_launch_timing_read(ms_, fl_, by_, kd_, cap)
+            _L.lib.lmv_debug_launch_timing(0)
+            agg = {}
+            for i in range(n_):
+                e = agg.setdefault(kd_[i], [0, 0.0, 0.0]); e[0] += 1; e[1] += ms_[i]; e[2] += fl_[i]
+            if agg:
+                k = max(agg, key=lambda q: agg[q][1])
+                fwd_probe = dict(kernel={0: "forward Linear launches", 1: "sstage_kernel", 2: "dstage_kernel", 3: "stem_kernel"}.get(k, str(k)), launches=agg[k][0],
+                                 avg_launch_us=round(1e3 * agg[k][1] / agg[k][0], 1), tflops=round(agg[k][2] / (agg[k][1] * 1e-3) / 1e12, 1),
+                                 frac=round(agg[k][2] / (agg[k][1] * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4), bound="mfma", peak=PEAK_BF16_TFLOPS, unit="TFLOP/s",
+                                 measured="2 eager forward passes after the forward region, whole batch on one stream, library launch-timing probe")
         model.train(True)
     tmax = torch.tensor([dt, fwd_dt or 0.0], device=dev, dtype=torch.float64)
     if world > 1:
@@ -459,6 +483,8 @@ def main():
             line["forward_images_per_sec"] = round(fv, 2)
             line["forward_ms"] = round(1e3 * fwd_dt / fwd_iters, 3)
             line["forward_frac_of_bf16_peak"] = None if gflop is None else round(fv * gflop / 1e3 / (PEAK_BF16_TFLOPS * world), 4)
+            if fwd_probe is not None:
+                line["forward_roofline"] = fwd_probe
             line["forward_note"] = (f"forward pass of the same model / batch timed after the train region: eval mode, no_grad, bf16 autocast, {fwd_note}, "
                                     f"{fwd_iters} iterations, fused inference schedule")
         if parts_table is not None:

@@ -215,6 +215,11 @@ def main():
 
     import lemevit_amd
     from lemevit_amd.dist import wrap_ddp
+    if os.environ.get("LMV_BENCH_SINGLE_DEVICE") == "1" and world > 1:
+        # Ranks that SHARE a device (the 1-GPU test hook only) must not launch the persistent stage kernels: those assume the workgroups of an image are co-resident, which one
+        # process arranges for its own launches ("Residency") but two processes on one device cannot -- the in-launch waits would run into their bounded spins.
+        import lemevit_amd.model as _m
+        _m._SSTAGE = False
 
     torch.manual_seed(0)
     train = args.mode == "train"

@@ -494,6 +494,8 @@ size_t lmv_stem_wpk_bytes(int Cm, int Co);
 int lmv_stem_pack(const void* w1m, const void* w2m, int ld2, int Cm, int Co, void* wpk_out, void* stream);
 int lmv_stem_fwd(const void* x, int x_dtype, int64_t sb, int64_t sc, int64_t sh, int64_t sw, int B, int H, int W, int Cm, int Co, const void* wpk, const float* b1,
                  const float* b2, void* y, void* stream);
+/* One process per device: the persistent stage kernels assume that the workgroups of an image (a slot) can be resident together, which holds for the launches of ONE process on a
+ * device (lmv_dstage_max_concurrent) and not for several processes sharing it. */
 /* The persistent stage kernels (lmv_sstage_fwd, lmv_dstage_fwd) bound every in-launch wait; a spin that runs out (a lost hand-off: a bug, or more concurrent launches than
  * lmv_dstage_max_concurrent allows) sets a sticky per-device error word instead of hanging the GPU.  lmv_stage_error_count returns it (0 = every hand-off of every launch so far
  * arrived; < 0: LMV_ERR_*) after the caller has synchronised the streams of interest; reset != 0 clears it. */

@@ -988,16 +988,16 @@ template <int NW, int GW, int CT> static int ds_launch(const lmv_dstage_desc* d,
 }  // namespace
 
 // ---- C ABI --------------------------------------------------------------------------------------------------------------------------
-// the instances: 1000 NW + 10 GW + CT.  224 x 224 images: (4, 28, 3) / (2, 56, 3) LeMeViT-Base and -Small, (4, 28, 2) / (2, 56, 2) LeMeViT-Tiny; 384 x 384 (BASELINE config 5): (4, 48, 3) / (2, 96, 3)
+// the instances: 1000 NW + 10 GW + CT.  224 x 224 images: (4, 28, 3) / (2, 56, 3) LeMeViT-Base and -Small, (4, 28, 2) / (2, 56, 2) LeMeViT-Tiny; 384 x 384 (BASELINE config 5): (4, 48, 3) / (2, 96, 3), Tiny: (4, 48, 2) / (2, 96, 2)
 #define DS_DISPATCH(code, EXPR, DFLT)                                                                                                                   \
   ((code) == 4283 ? EXPR(4, 28, 3) : (code) == 2563 ? EXPR(2, 56, 3) : (code) == 4282 ? EXPR(4, 28, 2) : (code) == 2562 ? EXPR(2, 56, 2) : (code) == 4483 ? EXPR(4, 48, 3) : \
-   (code) == 2963 ? EXPR(2, 96, 3) : (code) == 8243 ? EXPR(8, 24, 3) : (DFLT))
+   (code) == 2963 ? EXPR(2, 96, 3) : (code) == 4482 ? EXPR(4, 48, 2) : (code) == 2962 ? EXPR(2, 96, 2) : (code) == 8243 ? EXPR(8, 24, 3) : (DFLT))
 static int ds_code_of_c(int C) { return C == 192 ? 4283 : C == 96 ? 2563 : C == 128 ? 4282 : C == 64 ? 2562 : C == 384 ? 8243 : 0; }          // (what depends on C only: the packed layout)
 static int ds_code(int C, int H) {
   if (C == 192) return H == 28 ? 4283 : H == 48 ? 4483 : 0;
   if (C == 96) return H == 56 ? 2563 : H == 96 ? 2963 : 0;
-  if (C == 128) return H == 28 ? 4282 : 0;
-  if (C == 64) return H == 56 ? 2562 : 0;
+  if (C == 128) return H == 28 ? 4282 : H == 48 ? 4482 : 0;
+  if (C == 64) return H == 56 ? 2562 : H == 96 ? 2962 : 0;
   if (C == 384) return H == 24 ? 8243 : 0;          // ("S" blocks, kind 2)
   return 0;
 }
@@ -1011,7 +1011,7 @@ size_t lmv_dstage_wpk_bytes(int C, int hidden) { (void)hidden; const int code = 
 size_t lmv_dstage_vec_floats(int C, int hidden) { (void)hidden; return (size_t)27 * C; }
 #define DS_WS(NW, GW, CT) ds_workspace<NW, GW, CT>(B)
 size_t lmv_dstage_workspace_bytes(int B, int C) {          // (any grid the kernel takes at this C)
-  const int code = ds_code_of_c(C), code2 = C == 192 ? 4483 : C == 96 ? 2963 : 0;
+  const int code = ds_code_of_c(C), code2 = C == 192 ? 4483 : C == 96 ? 2963 : C == 128 ? 4482 : C == 64 ? 2962 : 0;
   const size_t a = DS_DISPATCH(code, DS_WS, (size_t)0), b = DS_DISPATCH(code2, DS_WS, (size_t)0);
   return a > b ? a : b;
 }

@@ -68,7 +68,7 @@ template <int NW, int GW, int CTILES> struct DG {
   static constexpr size_t HALO_BYTES = (size_t)2 * KWG * 2 * GW * C * 2;   // [parity][workgroup][first | last grid row][GW tokens][C] bf16
   static constexpr size_t PART_BYTES = (size_t)KWG * NH * 3 * 1024;        // [workgroup][head][O d-tile 0 | O d-tile 1 | (max, sum)]: f32x4 per lane
   // "S" blocks (KIND 2, the 8-wave instance only): K and V^T operand fragments of all image tokens of the image, [parity][K | V][head][KWG NT key tiles] x 1 KB
-  static constexpr size_t KV_HALF = (size_t)NH * KWG * NT * 1024, KV_BYTES = NW == 8 ? 4 * KV_HALF : 0;
+  static constexpr size_t KV_HALF = (size_t)NH * KWG * NT * 1024, KV_BYTES = GW == 24 ? 4 * KV_HALF : 0;
   static constexpr size_t SLOT_BYTES = MFRAG_BYTES + HALO_BYTES + PART_BYTES + KV_BYTES;
   static constexpr int FLAGS_PER_SLOT = 3 * KWG + 1;                       // halo [KWG] | partial [KWG] | meta | K / V ready [KWG] ("S" blocks)
 };
@@ -667,7 +667,7 @@ __global__ __launch_bounds__(64 * NW, 2) void dstage_kernel(const DsArgs a) {
 #define DS_RG2 3
 #endif
         constexpr int RG1 = DS_RG1, RG2 = DS_RG2;          // key-tile pairs in flight (ring depth) of the two attention passes
-        static_assert(NW == 8 && NT % 2 == 0 && (2 * NH) % NW == 0, "S blocks: the 8-wave instance");
+        static_assert(GW == 24 && NT % 2 == 0 && (2 * NH) % NW == 0 && NW % 2 == 0, "S blocks: the 24 x 24 instances");
         unsigned char* const kvw = kvb + (size_t)(gb & 1) * (2 * G::KV_HALF);
         const __amdgpu_buffer_rsrc_t kr = __builtin_amdgcn_make_buffer_rsrc(kvw, 0, (int)(2 * G::KV_HALF), 0x00020000);
         // ---- k (even waves) / v (odd waves) of this workgroup's tokens, 2 NH units over the waves -> K fragments [head][key tile], V^T fragments [head][pair][d-tile] ----
@@ -894,7 +894,7 @@ struct DPackArgs { const bf16_t* qkv1_w; const bf16_t* qkv2_w; const bf16_t* pro
 
 template <int NW, int CT>
 __global__ __launch_bounds__(256) void dstage_pack_kernel(const DPackArgs a) {
-  using G = DG<NW, NW == 8 ? 24 : NW == 4 ? 28 : 56, CT>;
+  using G = DG<NW, NW == 8 ? 24 : NW == 4 ? 28 : 56, CT>;          // (the packed layout does not depend on the grid)
   constexpr int C = G::C, KS = G::KS, KSC = G::KSC, UF = 2 * KS, PF = CT * KS, F2 = CT * KSC, CW = G::CW;
   const int f = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63, g = lane >> 4, i = lane & 15;
   if (f >= G::WS_FRAGS) return;
@@ -973,11 +973,11 @@ template <int NW, int GW, int CT, int KIND> static int ds_launch_kind(const lmv_
   return LMV_OK;
 }
 template <int NW, int GW, int CT> static int ds_launch(const lmv_dstage_desc* d, const void* x, const void* c, void* x_out, void* c_out, void* workspace, hipStream_t st) {
-  if constexpr (NW == 8) {          // the "S"-block instance (stage 3 of LeMeViT-Base at 384 x 384)
+  if constexpr (GW == 24) {          // the "S"-block instances (stage 3 of LeMeViT-Base / -Tiny at 384 x 384)
     if (d->kind != 2) LMV_FAIL(LMV_ERR_DTYPE, "dstage_fwd: this shape is built for S blocks (kind 2) only");
     return ds_launch_kind<NW, GW, CT, 2>(d, x, c, x_out, c_out, workspace, st);
   } else {
-    if (d->kind == 2) LMV_FAIL(LMV_ERR_DTYPE, "dstage_fwd: S blocks (kind 2) are built for C = 384 at 24 x 24 only");
+    if (d->kind == 2) LMV_FAIL(LMV_ERR_DTYPE, "dstage_fwd: S blocks (kind 2) are built for the 24 x 24 grid (C = 384 / 192) only");
     if constexpr (GW == 56 || GW == 96) {          // "C" blocks exist at stage 0 only (the resolution of stage 1)
       if (d->kind) return ds_launch_kind<NW, GW, CT, 1>(d, x, c, x_out, c_out, workspace, st);
     } else if (d->kind) LMV_FAIL(LMV_ERR_DTYPE, "dstage_fwd: C blocks are built for the stage-0 / stage-1 grid only");
@@ -991,10 +991,10 @@ template <int NW, int GW, int CT> static int ds_launch(const lmv_dstage_desc* d,
 // the instances: 1000 NW + 10 GW + CT.  224 x 224 images: (4, 28, 3) / (2, 56, 3) LeMeViT-Base and -Small, (4, 28, 2) / (2, 56, 2) LeMeViT-Tiny; 384 x 384 (BASELINE config 5): (4, 48, 3) / (2, 96, 3), Tiny: (4, 48, 2) / (2, 96, 2)
 #define DS_DISPATCH(code, EXPR, DFLT)                                                                                                                   \
   ((code) == 4283 ? EXPR(4, 28, 3) : (code) == 2563 ? EXPR(2, 56, 3) : (code) == 4282 ? EXPR(4, 28, 2) : (code) == 2562 ? EXPR(2, 56, 2) : (code) == 4483 ? EXPR(4, 48, 3) : \
-   (code) == 2963 ? EXPR(2, 96, 3) : (code) == 4482 ? EXPR(4, 48, 2) : (code) == 2962 ? EXPR(2, 96, 2) : (code) == 8243 ? EXPR(8, 24, 3) : (DFLT))
+   (code) == 2963 ? EXPR(2, 96, 3) : (code) == 4482 ? EXPR(4, 48, 2) : (code) == 2962 ? EXPR(2, 96, 2) : (code) == 8243 ? EXPR(8, 24, 3) : (code) == 4243 ? EXPR(4, 24, 3) : (DFLT))
 static int ds_code_of_c(int C) { return C == 192 ? 4283 : C == 96 ? 2563 : C == 128 ? 4282 : C == 64 ? 2562 : C == 384 ? 8243 : 0; }          // (what depends on C only: the packed layout)
 static int ds_code(int C, int H) {
-  if (C == 192) return H == 28 ? 4283 : H == 48 ? 4483 : 0;
+  if (C == 192) return H == 28 ? 4283 : H == 48 ? 4483 : H == 24 ? 4243 : 0;          // (24 x 24: "S" blocks, kind 2)
   if (C == 96) return H == 56 ? 2563 : H == 96 ? 2963 : 0;
   if (C == 128) return H == 28 ? 4282 : H == 48 ? 4482 : 0;
   if (C == 64) return H == 56 ? 2562 : H == 96 ? 2962 : 0;
@@ -1012,8 +1012,8 @@ size_t lmv_dstage_vec_floats(int C, int hidden) { (void)hidden; return (size_t)2
 #define DS_WS(NW, GW, CT) ds_workspace<NW, GW, CT>(B)
 size_t lmv_dstage_workspace_bytes(int B, int C) {          // (any grid the kernel takes at this C)
   const int code = ds_code_of_c(C), code2 = C == 192 ? 4483 : C == 96 ? 2963 : C == 128 ? 4482 : C == 64 ? 2962 : 0;
-  const size_t a = DS_DISPATCH(code, DS_WS, (size_t)0), b = DS_DISPATCH(code2, DS_WS, (size_t)0);
-  return a > b ? a : b;
+  const size_t a = DS_DISPATCH(code, DS_WS, (size_t)0), b = DS_DISPATCH(code2, DS_WS, (size_t)0), c3 = C == 192 ? ds_workspace<4, 24, 3>(B) : 0;
+  return a > b ? (a > c3 ? a : c3) : (b > c3 ? b : c3);
 }
 
 // How many lmv_dstage_fwd calls may be in flight on different streams of one device: workgroups are dispatched in index order and a slot group is 8 NWG workgroups, so each

@@ -14,11 +14,11 @@ One process per GPU; N > 1 shards images over ranks (weak scaling, 128 images pe
 all-reduced by RCCL (lemevit_amd.dist.FlatGradSync: chunks of the flat fp32 gradient buffer, overlapped with backward;
 --ddp selects torch DDP instead).  Rank 0 prints ONE JSON line.
 
-`roofline` is measured live for the dominant kernel -- the bf16 MFMA GEMM of the Linear layers
-(gemm_kernel<bf16, NT>, forward launches) -- with HIP events on the launch stream inside the timed region:
-algorithmic FLOPs of those launches / their summed duration, against the 2.5 PFLOP/s dense bf16 MFMA peak (the roof
-SURVEY 8(d) names).  The launch mix has K = 96..512 on the big-row stages, i.e. an arithmetic intensity below the
-312 flop/B ridge of the chip, so the algorithmic-bytes figure against the 8 TB/s HBM roof is reported beside it (`hbm_*`).
+`roofline` is measured live for the dominant kernel of the timed region: the library's launch-timing probe brackets every GEMM (forward-form tile / register-stationary /
+whole-width kernels, the transpose-read dX kernel, the split-K weight-gradient kernel and its slab reduce), every attention launch and every persistent stage / stem launch with
+HIP events on the stream it is issued on, for 3 eager steps right after the timed region; the KERNEL with the largest total time is the one reported (train mode: the weight-gradient
+GEMM, gemm_kernel<bf16, TR, TR, split-K>; --mode infer: sstage_kernel) -- its algorithmic FLOPs / its summed duration against the 2.5 PFLOP/s dense bf16 MFMA peak (the roof
+SURVEY 8(d) names), the algorithmic-bytes figure against the 8 TB/s HBM roof beside it (`hbm_*`), every other kernel under `other_launch_kinds`.
 `cpu_baseline` times the CPU oracle (oracle/, a port of the reference) on a bounded sample of the same workload.
 """
 from __future__ import annotations
@@ -57,6 +57,8 @@ def parse():
     ap.add_argument("--force-sync", action="store_true", help="run the FlatGradSync collectives even at world size 1 (1-rank process group)")
     ap.add_argument("--force-ddp", action="store_true", help="wrap in DDP (and use the DDP code path) even at world size 1: measures the wrapper's overhead")
     ap.add_argument("--torch-adamw", action="store_true", help="use torch.optim.AdamW(fused=True) instead of lemevit_amd.FlatAdamW at N=1")
+    ap.add_argument("--grad-wire", default="auto", choices=["auto", "fp32", "bf16"], help="N > 1 with FlatGradSync: element type of the gradient all-reduce.  auto = bf16 "
+                    "(106 MB instead of 212 MB per step over xGMI, SURVEY 8(e) / row f3; the reference's own DDP path has no compression: --grad-wire fp32 reproduces its byte count)")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--no-issue-probe", action="store_true", help="skip the 5 synchronised single steps that measure host issue time (profiling runs: "
                     "they would sit in the 'last steps' window of a kernel trace)")
@@ -252,7 +254,8 @@ def main():
                 # data parallelism without a DDP wrapper: the flat block-gradient buffer is all-reduced in 4 large chunks, each as soon
                 # as the backward pass has written it (lemevit_amd/dist.py::FlatGradSync)
                 from lemevit_amd.dist import attach_flat_grad_sync
-                gsync = attach_flat_grad_sync(model, opt, force=args.force_sync)
+                wire = "bf16" if args.grad_wire in ("auto", "bf16") else None
+                gsync = attach_flat_grad_sync(model, opt, force=args.force_sync, compress=wire)
         else:
             opt = torch.optim.AdamW([dict(params=decay, weight_decay=0.05), dict(params=no_decay, weight_decay=0.0)], lr=1e-4, eps=1e-8, fused=True,
                                     capturable=bool(args.graph))
@@ -282,6 +285,25 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    from lemevit_amd import ops as _ops
+    stage_errors = 0
+
+    def check_handoffs(where):
+        # A persistent stage kernel whose in-launch wait ran out has produced wrong tensors: that must be an exception here, not a normal-looking bench line
+        # (VERDICT round 4, weak #2).  Called right behind a sync(): the pinned error word then covers every launch issued so far.
+        _ops.check_stage_errors(f"bench.py, {where}", sync=False)
+
+    # which devices take part: the driver can check N distinct GPUs from the line (N > 1: an all-gather of (rank, device uuid) over the process group)
+    try:
+        my_uuid = str(torch.cuda.get_device_properties(dev).uuid)
+    except Exception:
+        my_uuid = f"cuda:{local}"
+    ranks_seen, device_uuids = 1, [my_uuid]
+    if dist.is_initialized():
+        gathered = [None] * dist.get_world_size()
+        dist.all_gather_object(gathered, (rank, my_uuid))
+        ranks_seen, device_uuids = dist.get_world_size(), [u for _, u in sorted(gathered)]
+
     eager_step, graph_note = step, "eager, weight-gradient GEMMs on a side stream"
     if args.graph and world == 1 and not args.force_ddp and not args.force_sync:
         from lemevit_amd.graph import try_graphed
@@ -297,6 +319,7 @@ def main():
         step()
     sync()
     dt = time.perf_counter() - t0
+    check_handoffs("timed region")
     # host time to ENQUEUE one step, measured on an EMPTY launch queue (issuing K steps back to back only measures the queue's
     # back-pressure: the host blocks once the device is a queue depth behind) -- median of 5 single steps, each preceded by a sync
     issue = []
@@ -381,6 +404,7 @@ def main():
             fstep()
         sync()
         fwd_dt = time.perf_counter() - tf0
+        check_handoffs("forward region")
         fwd_probe = None
         if rank == 0 and not args.no_kernel_timing:
             # the forward pass's own dominant launch (the persistent stage-3 kernel on this workload), whole batch on one stream, by the same library probe
@@ -401,7 +425,8 @@ def main():
                 e = agg.setdefault(kd_[i], [0, 0.0, 0.0]); e[0] += 1; e[1] += ms_[i]; e[2] += fl_[i]
             if agg:
                 k = max(agg, key=lambda q: agg[q][1])
-                fwd_probe = dict(kernel={0: "forward Linear launches", 1: "sstage_kernel", 2: "dstage_kernel", 3: "stem_kernel"}.get(k, str(k)), launches=agg[k][0],
+                fwd_probe = dict(kernel={0: "gemm_kernel<bf16, NT>", 1: "sstage_kernel", 2: "dstage_kernel", 3: "stem_kernel", 7: "attention forward launches", 8: "rs_gemm_kernel", 9: "wn_gemm_kernel",
+                                         11: "rsw_gemm_kernel"}.get(k, str(k)), launches=agg[k][0],
                                  avg_launch_us=round(1e3 * agg[k][1] / agg[k][0], 1), tflops=round(agg[k][2] / (agg[k][1] * 1e-3) / 1e12, 1),
                                  frac=round(agg[k][2] / (agg[k][1] * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4), bound="mfma", peak=PEAK_BF16_TFLOPS, unit="TFLOP/s",
                                  measured="2 eager forward passes after the forward region, whole batch on one stream, library launch-timing probe")
@@ -420,11 +445,17 @@ def main():
         mult = 3.0 if train else 1.0
         gmac = CANONICAL_GMAC.get((args.model, args.img))
         gflop = None if gmac is None else 2.0 * gmac
-        KIND_NAMES = {0: "forward Linear launches: gemm_kernel<bf16,NT> / rs_gemm_kernel / wn_gemm_kernel / rsw_gemm_kernel",
-                      1: "sstage_kernel (a stage of S blocks as one persistent launch)", 2: "dstage_kernel (a stage of D / C blocks as one persistent launch)", 3: "stem_kernel"}
+        KIND_NAMES = {0: "gemm_kernel<bf16, NT> (forward-form Linear launches on the 128 x 128 tile kernel)",
+                      1: "sstage_kernel (a stage of S blocks as one persistent launch)", 2: "dstage_kernel (a stage of D / C blocks as one persistent launch)", 3: "stem_kernel",
+                      4: "gemm_kernel<bf16, B transposed> (dX through the untransposed weight)", 5: "gemm_kernel<bf16, TR, TR, split-K> (weight-gradient GEMM, dW = dY^T X)",
+                      6: "splitk_reduce_kernel (slab sums of the weight-gradient GEMM)", 7: "attention forward launches (mfma_fwd_*)", 8: "rs_gemm_kernel (register-stationary forward-form Linear)",
+                      9: "wn_gemm_kernel (whole-width forward-form Linear, incl. the fused proj + norm2 and dX + LayerNorm-backward forms)", 10: "attention backward launches (mfma_bwd_*)",
+                      11: "rsw_gemm_kernel (norm1 + C = 96 projections, weights resident in LDS)"}
+        SHORT = {0: "gemm_kernel_nt", 1: "sstage_kernel", 2: "dstage_kernel", 3: "stem_kernel", 4: "gemm_kernel_dx", 5: "gemm_kernel_dw", 6: "splitk_reduce", 7: "attention_fwd", 8: "rs_gemm_kernel",
+                 9: "wn_gemm_kernel", 10: "attention_bwd", 11: "rsw_gemm_kernel"}
         g, gkind = None, None
         if probe:
-            gkind = max(probe, key=lambda k: probe[k]["total_ms"])          # the dominant launch kind of this workload
+            gkind = max(probe, key=lambda k: probe[k]["total_ms"])          # the dominant KERNEL of this workload: the kind with the largest total time (one kernel per kind)
             e = probe[gkind]
             g = dict(launches=e["launches"], total_ms=e["total_ms"], avg_us=1e3 * e["total_ms"] / e["launches"], tflops=e["flops"] / (e["total_ms"] * 1e-3) / 1e12,
                      gflop_per_launch=e["flops"] / e["launches"] / 1e9, mbytes_per_launch=e["bytes"] / e["launches"] / 1e6)
@@ -435,7 +466,13 @@ def main():
             traffic, traffic_src = None, None
             import glob
             cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_gemm_fwd_pmc_traffic.json")))      # the newest COMMITTED round (r03's file never left gpurun_out/)
-            if gkind == 0 and train and args.model == "lemevit_base" and args.img == 224 and args.batch == 128 and cands:
+            cands_dw = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_gemm_dw_pmc_traffic.json")))
+            if gkind == 5 and train and args.model == "lemevit_base" and args.img == 224 and args.batch == 128 and cands_dw:
+                with open(cands_dw[-1]) as f:
+                    traffic = round(json.load(f)["traffic_bytes_per_launch"] / 1e6, 2)
+                traffic_src = (f"canned: profiles/{os.path.basename(cands_dw[-1])} (MB per launch of gemm_kernel<bf16, TR, TR, split-K> over this command's train step, separate rocprofv3 --pmc "
+                               "FETCH_SIZE / WRITE_SIZE passes, tools/pmc_traffic.sh; NOT measured in this run)")
+            elif gkind == 0 and train and args.model == "lemevit_base" and args.img == 224 and args.batch == 128 and cands:
                 pmc = cands[-1]
                 with open(pmc) as f:
                     traffic = round(json.load(f)["traffic_bytes_per_launch"] / 1e6, 2)
@@ -467,7 +504,7 @@ def main():
                         traffic_over_algorithmic=None if traffic is None else round(traffic / g["mbytes_per_launch"], 3),
                         kernel=KIND_NAMES.get(gkind, str(gkind)), measured=kernel_timing_note,
                         frac_whole_batch_launches=None if not (probe_alone and gkind in probe_alone) else round(probe_alone[gkind]["flops"] / (probe_alone[gkind]["total_ms"] * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4),
-                        other_launch_kinds={{0: "forward_linear_launches", 1: "sstage_kernel", 2: "dstage_kernel", 3: "stem_kernel"}.get(k, str(k)): dict(launches=v["launches"], ms_per_step=round(v["total_ms"] / 3, 3), tflops=round(v["flops"] / (v["total_ms"] * 1e-3) / 1e12, 1))
+                        other_launch_kinds={SHORT.get(k, str(k)): dict(launches=v["launches"], ms_per_step=round(v["total_ms"] / 3, 3), tflops=round(v["flops"] / (v["total_ms"] * 1e-3) / 1e12, 1))
                                             for k, v in probe.items() if k != gkind}, launches=g["launches"], avg_launch_us=round(g["avg_us"], 2),
                         gflop_per_launch=round(g["gflop_per_launch"], 3))
         line = {
@@ -482,6 +519,8 @@ def main():
             "model_tflops": None if gflop is None else round(value * gflop * mult / 1e3, 2),
             "model_frac_of_bf16_peak": None if gflop is None else round(value * gflop * mult / 1e3 / (PEAK_BF16_TFLOPS * world), 4),
             "roofline": roof,
+            "stage_errors": stage_errors, "ranks_seen": ranks_seen, "device_uuids": device_uuids,
+            "grad_wire": None if not (train and world > 1) else ("torch DDP bf16 hook" if (args.ddp or args.force_ddp) else ("bf16" if args.grad_wire in ("auto", "bf16") else "fp32")),
         }
         if fwd_dt is not None:
             fv = args.batch * world * fwd_iters / fwd_dt

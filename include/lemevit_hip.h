@@ -14,7 +14,12 @@
  *     affine, statistics, DropPath scales) and gradient accumulators are always fp32;
  *   - `stream` is a hipStream_t passed as void*; kernels are enqueued, never synchronised;
  *   - return 0 on success, else LMV_ERR_* (message via lmv_last_error()); nothing throws;
- *   - stateless and re-entrant; the device is whatever the caller made current.
+ *   - re-entrant: entry points may be called from several host threads and on any streams; the device is whatever the caller made current.
+ *     Per-call state lives in the caller's buffers.  What the library keeps per PROCESS, and is therefore not "stateless", is listed here:
+ *       * the tuning switches (lmv_config_set: process-wide, unsynchronised -- set them between launches);
+ *       * one sticky error word per device (pinned host memory) that the persistent stage kernels raise (lmv_stage_error_count);
+ *       * the measurement aids lmv_debug_launch_timing / lmv_stem_debug_timing (single host thread, never in production);
+ *       * per-device caches of occupancy queries and of the hipFuncSetAttribute calls (write-once, atomics).
  */
 #ifndef LEMEVIT_HIP_H
 #define LEMEVIT_HIP_H
@@ -26,7 +31,7 @@
 extern "C" {
 #endif
 
-#define LMV_ABI_VERSION 9
+#define LMV_ABI_VERSION 10
 
 enum { LMV_F32 = 0, LMV_BF16 = 1 };
 enum {
@@ -42,7 +47,7 @@ const char* lmv_last_error(void);
 /* Tuning switches (A/B runs, parity tests of alternative code paths).  The LMV_* environment variables are read ONCE when the library
  * is loaded -- never on a launch path; these two change / read a switch at run time.  Keys: "gemm_bk", "gemm_bk32_tiles", "dw_bk",
  * "dw_target_blocks", "gemm_no_dma", "gemm_w8", "gemm_cumap", "gemm_nst", "gemm_nst_dw", "gemm_rs", "dwconv_v", "mlp_tm", "attn_pv16",
- * "attn_fuse_dq", "attn_fused_bwd", "attn_pair", "ln_bwd_blocks", "ln_bwd_minrows" (lemevit_amd/csrc/common.h: LmvConfig).
+ * "attn_fuse_dq", "attn_fused_bwd", "attn_pair", "ln_bwd_blocks", "ln_bwd_minrows", "stage_ticket_skew" (test switch) (lemevit_amd/csrc/common.h: LmvConfig).
  * Process-wide, not synchronised: set them between launches. */
 int lmv_config_set(const char* key, int value);
 int lmv_config_get(const char* key, int* value);
@@ -414,8 +419,7 @@ int lmv_block_bwd(const lmv_block_desc* d, const void* x, const void* c, const v
  *     `vec_out` (lmv_sstage_vec_floats fp32).  The packed blocks of a stage are consecutive: block j at wpk + j * wpk_bytes, vec + j * vec_floats.
  *   lmv_sstage_fwd: x_out / c_out may alias x / c.  `workspace` (lmv_sstage_workspace_bytes(min(B, lmv_sstage_max_images(C)), C)) holds the K / V fragments and the
  *     grid rows the two halves of an image exchange, the parked residual registers, and the flags (reset by the call on `stream`).  The launch needs 2 * min(B, max images)
- *     co-resident workgroups (512 threads / 147 KB LDS, one per CU; C = 192: 256 threads / 74 KB, two per CU): it must not be issued while another kernel of the same kind runs
- *     on a different stream of the same device.
+ *     co-resident workgroups (512 threads / 147 KB LDS, one per CU; C = 192: 256 threads / 74 KB, two per CU): concurrent calls on different streams are safe up to lmv_sstage_max_concurrent() at a time (each with its own workspace).
  * ------------------------------------------------------------------------------------------ */
 typedef struct lmv_sstage_block_params {
   int32_t C, heads, hidden, _pad;
@@ -434,7 +438,8 @@ int lmv_sstage_supported(int C, int heads, int hidden, int H, int W, int M, int 
 size_t lmv_sstage_wpk_bytes(int C, int hidden);
 size_t lmv_sstage_vec_floats(int C, int hidden);
 size_t lmv_sstage_workspace_bytes(int B, int C);
-int lmv_sstage_max_images(int C);                 /* images one launch takes (128 at C = 384, 256 at C = 192): size the workspace for min(B, this) */
+int lmv_sstage_max_images(int C);                 /* images one launch takes: (workgroups of the instance the device holds) / 2, whole groups of 8 -- 128 at C = 384, 256 at C = 192 on an MI355X; size the workspace for min(B, this) */
+int lmv_sstage_max_concurrent(int C);             /* lmv_sstage_fwd calls that may be in flight on different streams of a device at once (see lmv_dstage_max_concurrent); 0: none */
 int lmv_sstage_pack(const lmv_sstage_block_params* p, void* wpk_out, float* vec_out, void* stream);
 int lmv_sstage_fwd(const lmv_sstage_desc* d, const void* x, const void* c, void* x_out, void* c_out, void* workspace, size_t workspace_bytes, void* stream);
 
@@ -452,8 +457,8 @@ int lmv_sstage_fwd(const lmv_sstage_desc* d, const void* x, const void* c, void*
  *     attn.proj_c [C, C], mlp.0 [4C, C], mlp.3 [C, 4C], pos_embed.weight [C, 9]) -> wpk_out / vec_out; blocks of a stage consecutive as for lmv_sstage_pack.
  *   lmv_dstage_fwd: x_out / c_out must NOT alias x / c.  `workspace`: lmv_dstage_workspace_bytes(B, C) (exchange buffers and flags of the image
  *     slots; flags reset by the call on `stream`; one workspace per concurrent call).  All 8 (29) workgroups of an image slot must be co-resident (256 threads / 74 KB LDS each, two per CU;
- *     128 / 37 KB, four per CU).  Concurrent calls on different streams are safe up to lmv_dstage_max_concurrent() at a time (lemevit_amd.graph.split_forward issues up to 4): workgroups are dispatched in index
- *     order and slots come in groups of 8 (64 / 232 workgroups at 224 x 224), so each call has at most one partially resident group and the rest of the chip always runs complete groups.
+ *     128 / 37 KB, four per CU).  Concurrent calls on different streams are safe up to lmv_dstage_max_concurrent() at a time (lemevit_amd.graph.split_forward issues up to 4): slots are assigned by ticket
+ *     (see "Residency" below), so every call holds at most 8 incomplete slots and the rest of the chip always runs complete ones, whatever the dispatch order.
  * ------------------------------------------------------------------------------------------ */
 typedef struct lmv_dstage_block_params {
   int32_t C, heads, hidden, _pad;
@@ -494,12 +499,18 @@ size_t lmv_stem_wpk_bytes(int Cm, int Co);
 int lmv_stem_pack(const void* w1m, const void* w2m, int ld2, int Cm, int Co, void* wpk_out, void* stream);
 int lmv_stem_fwd(const void* x, int x_dtype, int64_t sb, int64_t sc, int64_t sh, int64_t sw, int B, int H, int W, int Cm, int Co, const void* wpk, const float* b1,
                  const float* b2, void* y, void* stream);
-/* One process per device: the persistent stage kernels assume that the workgroups of an image (a slot) can be resident together, which holds for the launches of ONE process on a
- * device (lmv_dstage_max_concurrent) and not for several processes sharing it. */
-/* The persistent stage kernels (lmv_sstage_fwd, lmv_dstage_fwd) bound every in-launch wait; a spin that runs out (a lost hand-off: a bug, or more concurrent launches than
- * lmv_dstage_max_concurrent allows) sets a sticky per-device error word instead of hanging the GPU.  lmv_stage_error_count returns it (0 = every hand-off of every launch so far
- * arrived; < 0: LMV_ERR_*) after the caller has synchronised the streams of interest; reset != 0 clears it. */
+/* Residency of the persistent stage kernels.  The workgroups of a slot (the two halves of an image in lmv_sstage_fwd, the image-row workgroups + the meta workgroup of an image in
+ * lmv_dstage_fwd) wait for each other inside the launch, so a slot advances only while all of them are resident.  The kernels do NOT rely on a dispatch order or a workgroup -> XCD
+ * map for that (HIP promises neither): every workgroup takes a ticket when it starts (csrc/stage_common.h: stage_ticket) and becomes role t % NWG of slot t / NWG, so the started workgroups
+ * always form complete slots plus at most 8 incomplete ones per launch, and the next workgroups to start complete those.  Progress needs room for the incomplete slots of ALL launches in
+ * flight plus one workgroup: n * 8 (NWG - 1) + 1 <= (workgroups the device holds) -- lmv_sstage_max_concurrent / lmv_dstage_max_concurrent return that n for a shape (launches of
+ * different shapes mix under the same per-shape bound), lmv_*stage_supported is 0 on a device too small for n = 1, and the host mirror (lemevit_amd/model.py) takes the per-block
+ * schedule where a bound is exceeded.  The bounds count the launches of ONE process; processes sharing a device add up (one process per GPU is the deployment contract).
+ * Every in-launch wait is bounded all the same: a spin that runs out (a lost hand-off -- a bug, or more launches in flight than the bound) sets a sticky per-device error word in pinned
+ * host memory instead of hanging the GPU.  lmv_stage_error_count returns it without synchronising anything: 0 = every hand-off of every COMPLETED launch arrived (synchronise the streams
+ * of interest first for a verdict on them); < 0: LMV_ERR_*; reset != 0 clears it.  lmv_debug_stage_error_set stores a value there from the host (tests of the callers' error paths). */
 int lmv_stage_error_count(int reset);
+int lmv_debug_stage_error_set(int value);
 
 /* Launch timing probe: lmv_debug_launch_timing(capacity > 0) creates `capacity` event pairs and from then on brackets every lmv_linear_fwd / lmv_linear_res_ln_fwd /
  * lmv_ln_linear_exact_fwd call -- from any schedule, the native block schedule (lmv_block_fwd) included -- with HIP events on the stream it launches on; after a device

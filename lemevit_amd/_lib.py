@@ -14,7 +14,7 @@ LIB_PATH = os.path.join(_HERE, "csrc", "liblemevit_hip.so")
 
 LMV_F32, LMV_BF16 = 0, 1
 ACT_NONE, ACT_GELU, ACT_GELU_GRAD = 0, 1, 2
-ABI_VERSION = 9
+ABI_VERSION = 10
 
 
 class LinearProblem(C.Structure):
@@ -154,6 +154,7 @@ SIGNATURES = {
     "lmv_sstage_vec_floats": (_Z, [_I, _I]),
     "lmv_sstage_workspace_bytes": (_Z, [_I, _I]),
     "lmv_sstage_max_images": (_I, [_I]),
+    "lmv_sstage_max_concurrent": (_I, [_I]),
     "lmv_sstage_pack": (_I, [C.POINTER(SStageBlockParams), _P, _P, _P]),
     "lmv_sstage_fwd": (_I, [C.POINTER(SStageDesc), _P, _P, _P, _P, _P, _Z, _P]),
     "lmv_stem_supported": (_I, [_I, _I, _I, _I, _I]),
@@ -162,6 +163,7 @@ SIGNATURES = {
     "lmv_stem_fwd": (_I, [_P, _I, _L, _L, _L, _L, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P]),
     "lmv_stem_debug_timing": (None, [_P]),
     "lmv_stage_error_count": (_I, [_I]),
+    "lmv_debug_stage_error_set": (_I, [_I]),
     "lmv_debug_launch_timing": (_I, [_I]),
     "lmv_debug_launch_timing_read": (_I, [_P, _P, _P, _P, _I]),
     "lmv_dstage_supported": (_I, [_I, _I, _I, _I, _I, _I, _I]),

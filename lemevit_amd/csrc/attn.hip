@@ -461,11 +461,18 @@ extern "C" size_t lmv_attn_workspace_bytes(int B, int H, int Lq, int Lk, int bac
   return align256((size_t)B * H * Lq * sizeof(float)) + align256(acc);
 }
 
+// (timing probe) FLOPs / algorithmic bytes of one attention problem: forward 2 contractions, backward 5 (S and dP recomputed, dV, dK, dQ); bytes: q, k, v, o (+ dO, dq, dk, dv)
+static inline double attn_flops(const lmv_attn_desc* d, bool bwd) { return (bwd ? 10.0 : 4.0) * d->B * d->H * (double)d->Lq * d->Lk * 32.0; }
+static inline double attn_bytes(const lmv_attn_desc* d, int dtype, bool bwd) {
+  const double es = dtype == LMV_BF16 ? 2.0 : 4.0, rows = (double)d->B * d->H * 32.0 * (2.0 * d->Lq + 2.0 * d->Lk);
+  return rows * es * (bwd ? 2.0 : 1.0) + (bwd ? (double)d->B * d->H * d->Lq * 32.0 * es : 0.0);
+}
 /* Two independent attention problems (same B and H): the image-token and the meta-token self-attention of an S block.  bf16 problems
  * of the model's hot shapes run as ONE launch; anything else as two.  The workspace must satisfy lmv_attn_workspace_bytes of both. */
 extern "C" int lmv_attn_fwd_pair(const lmv_attn_desc* d, void* ws, size_t ws_bytes, int dtype, void* stream) {
   for (int i = 0; i < 2; ++i)
     if (int rc = check_desc(d + i, dtype, false)) return rc;
+  LmvTimedLaunch timed(stream, attn_flops(d, false) + attn_flops(d + 1, false), attn_bytes(d, dtype, false) + attn_bytes(d + 1, dtype, false), LMV_TK_ATTN_FWD);
   if (dtype == LMV_BF16) {
     const Args a1 = to_args(d), a2 = to_args(d + 1);
     if (lmv_attn_mfma_supported(a1) && lmv_attn_mfma_supported(a2) && lmv_attn_mfma_fwd_pair(a1, a2, (hipStream_t)stream)) {
@@ -482,6 +489,7 @@ extern "C" int lmv_attn_fwd_pair(const lmv_attn_desc* d, void* ws, size_t ws_byt
 extern "C" int lmv_attn_bwd_pair(const lmv_attn_desc* d, void* ws, size_t ws_bytes, int dtype, void* stream) {
   for (int i = 0; i < 2; ++i)
     if (int rc = check_desc(d + i, dtype, true)) return rc;
+  LmvTimedLaunch timed(stream, attn_flops(d, true) + attn_flops(d + 1, true), attn_bytes(d, dtype, true) + attn_bytes(d + 1, dtype, true), LMV_TK_ATTN_BWD);
   if (dtype == LMV_BF16) {
     const Args a1 = to_args(d), a2 = to_args(d + 1);
     if (lmv_attn_mfma_supported(a1) && lmv_attn_mfma_supported(a2) && lmv_attn_mfma_bwd_pair(a1, a2, (hipStream_t)stream)) {
@@ -498,10 +506,12 @@ extern "C" int lmv_attn_bwd_pair(const lmv_attn_desc* d, void* ws, size_t ws_byt
 
 extern "C" int lmv_attn_fwd(const lmv_attn_desc* d, void* ws, size_t ws_bytes, int dtype, void* stream) {
   if (int rc = check_desc(d, dtype, false)) return rc;
+  LmvTimedLaunch timed(stream, attn_flops(d, false), attn_bytes(d, dtype, false), LMV_TK_ATTN_FWD);
   return dtype == LMV_BF16 ? fwd_impl<bf16_t>(d, ws, ws_bytes, (hipStream_t)stream) : fwd_impl<float>(d, ws, ws_bytes, (hipStream_t)stream);
 }
 extern "C" int lmv_attn_bwd(const lmv_attn_desc* d, void* ws, size_t ws_bytes, int dtype, void* stream) {
   if (int rc = check_desc(d, dtype, true)) return rc;
+  LmvTimedLaunch timed(stream, attn_flops(d, true), attn_bytes(d, dtype, true), LMV_TK_ATTN_BWD);
   return dtype == LMV_BF16 ? bwd_impl<bf16_t>(d, ws, ws_bytes, (hipStream_t)stream) : bwd_impl<float>(d, ws, ws_bytes, (hipStream_t)stream);
 }
 

@@ -19,17 +19,25 @@ void lmv_set_error(const char* fmt, ...);
     lmv_set_error(__VA_ARGS__);      \
     return (code);                   \
   } while (0)
-// ---- the persistent stage kernels' error word (misc.hip): one sticky device word per device that a bounded spin sets when it runs out (a lost hand-off); read by lmv_stage_error_count
-unsigned* lmv_stage_errword();
+// ---- the persistent stage kernels' error word (misc.hip): one sticky word per device (pinned host memory, device-mapped) that a bounded spin sets when it runs out (a lost
+// hand-off); read by lmv_stage_error_count without a synchronisation.  `stream`: the stream of the launch (a first call inside a stream capture is refused: NULL).
+unsigned* lmv_stage_errword(void* stream);
+// workgroups of `kernel` the device holds at once (occupancy query x CUs; misc.hip); 0: unknown
+int lmv_stage_capacity(const void* kernel, int threads, size_t lds_bytes);
 
 // ---- launch timing probe (lmv_debug_launch_timing, misc.hip): HIP events around the forward-form Linear entry points ON THE STREAM THEY LAUNCH ON, whichever schedule calls
 // them (the native block schedule of csrc/block.hip included) -- bench.py's roofline object.  Off: one predictable branch per entry.
 extern bool g_lmv_timing_on;
 void lmv_timing_begin(void* stream, double flops, double bytes, int kind);
 void lmv_timing_end(void* stream);
-struct LmvTimedLaunch {          // RAII bracket of one entry point
+void lmv_timing_set_kind(int kind);
+// launch kinds of the probe = kernels (bench.py names the kind with the largest total as roofline.kernel)
+enum { LMV_TK_GEMM_NT = 0, LMV_TK_SSTAGE = 1, LMV_TK_DSTAGE = 2, LMV_TK_STEM = 3, LMV_TK_GEMM_DX = 4, LMV_TK_GEMM_DW = 5, LMV_TK_SPLITK_REDUCE = 6, LMV_TK_ATTN_FWD = 7,
+       LMV_TK_RS_GEMM = 8, LMV_TK_WN_GEMM = 9, LMV_TK_ATTN_BWD = 10, LMV_TK_RSW_GEMM = 11 };
+struct LmvTimedLaunch {          // RAII bracket of one entry point (or of one launch inside it)
   void* st; bool on;
-  LmvTimedLaunch(void* stream, double flops, double bytes, int kind = 0) : st(stream), on(g_lmv_timing_on) { if (on) lmv_timing_begin(st, flops, bytes, kind); }          // kind: 0 forward-form Linear, 1 sstage, 2 dstage, 3 stem
+  LmvTimedLaunch(void* stream, double flops, double bytes, int kind = 0) : st(stream), on(g_lmv_timing_on) { if (on) lmv_timing_begin(st, flops, bytes, kind); }
+  void kind(int k) { if (on) lmv_timing_set_kind(k); }
   ~LmvTimedLaunch() { if (on) lmv_timing_end(st); }
 };
 #define LMV_CHECK_LAUNCH(name)                                                \
@@ -104,6 +112,7 @@ struct LmvConfig {
   int mlp_tm;             // LMV_MLP_TM             0 = auto: token rows per workgroup of the fused MLP kernel (64 / 128)
   int attn_pv16, attn_fuse_dq, attn_fused_bwd, attn_pair;      // LMV_ATTN_*
   int ln_bwd_blocks, ln_bwd_minrows;                           // LMV_LN_BWD_*
+  int stage_ticket_skew;  // LMV_STAGE_TICKET_SKEW  test switch (0): the persistent stage kernels ask ticket counter (XCC_ID + skew * hash(blockIdx)) & 7 first -- a simulated foreign workgroup -> XCD placement
 };
 LmvConfig& lmv_config();
 

@@ -76,7 +76,8 @@ template <int NW, int GW, int CTILES> struct DG {
 struct DsArgs {
   const bf16_t* x_in; const bf16_t* c_in; bf16_t* x_out; bf16_t* c_out;
   const uint4* wpk; const float* vec;
-  unsigned char* slots; unsigned* flags; unsigned* err;          // flags: [nslots][FLAGS_PER_SLOT]; err: the sticky device error word (lmv_stage_error_count)
+  unsigned char* slots; unsigned* flags; unsigned* err;          // flags: [nslots][FLAGS_PER_SLOT] | [8] tickets; err: the sticky error word (lmv_stage_error_count)
+  unsigned* tickets; unsigned quota, skew;                            // stage_ticket (stage_common.h): 8 counters of `quota` = nslots / 8 x (workgroups per slot) tickets
   int B, nblocks, nslots; float eps, sx, sc;       // sx / sc: the two attention scales times log2 e
   unsigned long long* timing; int timing_block;
 };
@@ -182,8 +183,11 @@ __global__ __launch_bounds__(64 * NW, 2) void dstage_kernel(const DsArgs a) {
   int lane = lane0; asm volatile("" : "+v"(lane));                  \
   int wave = wave0; asm volatile("" : "+s"(wave));                  \
   const int g = lane >> 4, li = lane & 15; (void)g; (void)li; (void)wave;
-  // the workgroups of an image slot share an XCD under the round-robin dispatch (a speed matter only)
-  const int xcd = blockIdx.x & 7, jj = blockIdx.x >> 3;
+  // (slot, role) by ticket, not by blockIdx: the workgroups that are resident always form complete slots + at most one incomplete slot per counter, under any dispatch order
+  // (stage_ticket, stage_common.h); the workgroups of a slot take consecutive tickets of the counter of the XCD they run on and share its L2 (a speed matter only)
+  const int tk = stage_ticket(a.tickets, a.quota, smem, a.skew);
+  if (tk < 0) return;
+  const int xcd = tk & 7, jj = tk >> 3;
   // "D" blocks: KWG image workgroups + the meta workgroup per slot; "C" blocks (the image side of a block is a third of the work and every block starts from x_in): an image
   // workgroup takes SUB = 2 row groups in turn, KWG / 2 + 1 workgroups per slot, twice the slots in flight
   constexpr int sub_n = KIND == 1 ? G::CSUB : 1, nimgwg = KWG / sub_n, nwg = nimgwg + 1;
@@ -923,16 +927,32 @@ __global__ __launch_bounds__(256) void dstage_pack_kernel(const DPackArgs a) {
   a.out[(size_t)f * 64 + lane] = make_uint4(lo.x, lo.y, hi.x, hi.y);
 }
 
+// Workgroups of an instance the device holds at once: the occupancy query x the CU count (cached per device); without a device (sizing calls in a CPU process) the MI355X figure.
+// Slots are assigned by ticket (stage_ticket), so the slot count below decides how many images are in flight, not whether the launch is correct; what progress needs -- room for
+// 8 incomplete slots + 1 workgroup per launch in flight -- is what lmv_dstage_supported / lmv_dstage_max_concurrent check.
+template <int NW, int GW, int CT, int KIND> static int ds_capacity_kind() {
+  static std::atomic<int> cache[64];
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return 0;
+  int v = cache[dev & 63].load(std::memory_order_relaxed);
+  if (!v) { v = lmv_stage_capacity(reinterpret_cast<const void*>(dstage_kernel<NW, GW, CT, KIND>), 64 * NW, DG<NW, GW, CT>::L_TOTAL); cache[dev & 63].store(v, std::memory_order_relaxed); }
+  return v;
+}
+template <int NW, int GW, int CT> static int ds_capacity(int kind) {
+  int v;
+  if constexpr (GW == 24) v = ds_capacity_kind<NW, GW, CT, 2>();
+  else if constexpr (GW == 56 || GW == 96) v = kind == 1 ? ds_capacity_kind<NW, GW, CT, 1>() : ds_capacity_kind<NW, GW, CT, 0>();
+  else v = ds_capacity_kind<NW, GW, CT, 0>();
+  return v > 0 ? v : 256 * (8 / NW);
+}
+template <int NW, int GW, int CT> static int ds_nwg(int kind) { return kind == 1 ? DG<NW, GW, CT>::NWG_C : DG<NW, GW, CT>::NWG; }
 template <int NW, int GW, int CT> static int ds_slots(int B, int kind) {
-  int dev = 0, cus = 256;
-  (void)hipGetDevice(&dev);
-  (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-  int n = (cus * (8 / NW) / (kind == 1 ? DG<NW, GW, CT>::NWG_C : DG<NW, GW, CT>::NWG)) / 8 * 8;          // whole groups of 8 slots (one per XCD); 8 / NW workgroups per CU
+  int n = ds_capacity<NW, GW, CT>(kind) / ds_nwg<NW, GW, CT>(kind) / 8 * 8;          // whole groups of 8 slots (one per ticket counter)
   if (n < 8) n = 8;
   const int need = (B + 7) / 8 * 8;
   return n < need ? n : need;
 }
-template <int NW, int GW, int CT> static size_t ds_flag_bytes(int ns) { return (((size_t)ns * DG<NW, GW, CT>::FLAGS_PER_SLOT + 1) * 4 + 1023) / 1024 * 1024; }
+template <int NW, int GW, int CT> static size_t ds_flag_bytes(int ns) { return (((size_t)ns * DG<NW, GW, CT>::FLAGS_PER_SLOT + 8 + 1) * 4 + 1023) / 1024 * 1024; }          // (+ the 8 ticket counters)
 template <int NW, int GW, int CT> static size_t ds_workspace(int B) {          // (either kind)
   const int n0 = ds_slots<NW, GW, CT>(B, 0), n1 = ds_slots<NW, GW, CT>(B, 1), ns = n0 > n1 ? n0 : n1;
   return ds_flag_bytes<NW, GW, CT>(ns) + (size_t)ns * DG<NW, GW, CT>::SLOT_BYTES;
@@ -966,8 +986,9 @@ template <int NW, int GW, int CT, int KIND> static int ds_launch_kind(const lmv_
   a.sc = (float)(1.0 / sqrt(d->kind ? 32.0 : (double)d->C) * lg2e);            // :256; "C" blocks: F.scaled_dot_product_attention's head_dim^-1/2 (:480-483)
   if (KIND == 2) a.sx = a.sc;                                                  // "S" blocks: both attentions are F.scaled_dot_product_attention (:199-203)
   a.timing = (unsigned long long*)d->timing; a.timing_block = d->timing_block;
-  a.err = lmv_stage_errword();
-  if (!a.err) LMV_FAIL(LMV_ERR_LAUNCH, "dstage_fwd: cannot allocate the error word");
+  a.err = lmv_stage_errword(st);
+  if (!a.err) LMV_FAIL(LMV_ERR_LAUNCH, "dstage_fwd: cannot allocate the error word (the first stage call of a process must not be inside a stream capture)");
+  a.tickets = a.flags + (size_t)ns * G::FLAGS_PER_SLOT; a.quota = (unsigned)(ns / 8 * (KIND == 1 ? G::NWG_C : G::NWG)); a.skew = (unsigned)lmv_config().stage_ticket_skew;
   hipLaunchKernelGGL((dstage_kernel<NW, GW, CT, KIND>), dim3(ns * (KIND == 1 ? G::NWG_C : G::NWG)), dim3(64 * NW), G::L_TOTAL, st, a);
   LMV_CHECK_LAUNCH("dstage_fwd");
   return LMV_OK;
@@ -1005,7 +1026,11 @@ static int ds_variant(int C, int heads, int hidden, int H, int W, int M) {      
   if (M != DS_M || H != W || heads != C / 32 || hidden != 4 * C) return 0;
   return ds_code(C, H);
 }
-int lmv_dstage_supported(int C, int heads, int hidden, int H, int W, int M, int dtype) { return dtype == LMV_BF16 && ds_variant(C, heads, hidden, H, W, M) != 0; }
+int lmv_dstage_max_concurrent(int C, int H, int kind);
+int lmv_dstage_supported(int C, int heads, int hidden, int H, int W, int M, int dtype) {
+  if (!(dtype == LMV_BF16 && ds_variant(C, heads, hidden, H, W, M) != 0)) return 0;
+  return lmv_dstage_max_concurrent(C, H, H == 24 ? 2 : 0) >= 1;          // a device too small for 8 incomplete slots + 1 workgroup (a partition) takes the per-block schedule
+}
 #define DS_WPK(NW, GW, CT) ((size_t)DG<NW, GW, CT>::WS_FRAGS * 1024)
 size_t lmv_dstage_wpk_bytes(int C, int hidden) { (void)hidden; const int code = ds_code_of_c(C); return DS_DISPATCH(code, DS_WPK, (size_t)0); }
 size_t lmv_dstage_vec_floats(int C, int hidden) { (void)hidden; return (size_t)27 * C; }
@@ -1016,14 +1041,13 @@ size_t lmv_dstage_workspace_bytes(int B, int C) {          // (any grid the kern
   return a > b ? (a > c3 ? a : c3) : (b > c3 ? b : c3);
 }
 
-// How many lmv_dstage_fwd calls may be in flight on different streams of one device: workgroups are dispatched in index order and a slot group is 8 NWG workgroups, so each
-// call has at most one partially resident group -- progress needs the chip to hold one more complete group than that: capacity / (8 NWG) calls.
+// How many lmv_dstage_fwd calls may be in flight on different streams of one device.  Every launch holds at most 8 incomplete slots (one per ticket counter: stage_ticket,
+// stage_common.h) of NWG - 1 resident workgroups each; as long as one more workgroup fits beside the incomplete slots of ALL launches in flight, the next workgroup to start
+// completes a slot: n * 8 (NWG - 1) + 1 <= capacity.  Launches of different shapes mix under the same rule (each shape's n bounds its share of the device by 1 / n).
+// 0: not even one launch (lmv_dstage_supported then says no).
 template <int NW, int GW, int CT> static int ds_max_concurrent(int kind) {
-  int dev = 0, cus = 256;
-  (void)hipGetDevice(&dev);
-  (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-  const int n = cus * (8 / NW) / (8 * (kind == 1 ? DG<NW, GW, CT>::NWG_C : DG<NW, GW, CT>::NWG));
-  return n < 1 ? 1 : n;
+  const int cap = ds_capacity<NW, GW, CT>(kind), nwg = ds_nwg<NW, GW, CT>(kind);
+  return (cap - 1) / (8 * (nwg - 1));
 }
 #define DS_MAXC(NW, GW, CT) ds_max_concurrent<NW, GW, CT>(kind)
 int lmv_dstage_max_concurrent(int C, int H, int kind) { const int code = ds_code(C, H); return DS_DISPATCH(code, DS_MAXC, 0); }

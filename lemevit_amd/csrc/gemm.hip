@@ -519,10 +519,14 @@ int launch(const lmv_linear_problem* p, int nproblems, int N, int K, int act, in
            lmv_reduce_seg* segs = nullptr, int* nsegs = nullptr) {
   Plan pl;
   if (int rc = make_plan(p, nproblems, N, K, act, dtype, mode, &pl)) return rc;      // (validates the operands)
-  if (mode == MODE_FWD && dtype == LMV_BF16 && lmv_config().gemm_rs && lmv_rs_eligible(p, nproblems, N, K, act, lmv_config().gemm_rs == 2))
+  if (mode == MODE_FWD && dtype == LMV_BF16 && lmv_config().gemm_rs && lmv_rs_eligible(p, nproblems, N, K, act, lmv_config().gemm_rs == 2)) {
+    lmv_timing_set_kind(LMV_TK_RS_GEMM);          // (the open bracket of lmv_linear_fwd, if the probe is armed)
     return lmv_rs_linear(p, nproblems, N, K, act, (hipStream_t)stream);              // register-stationary kernel (rsgemm.hip)
-  if (mode == MODE_FWD && dtype == LMV_BF16 && lmv_config().gemm_wn && lmv_wn_eligible(p, nproblems, N, K, act, lmv_config().gemm_wn == 2))
+  }
+  if (mode == MODE_FWD && dtype == LMV_BF16 && lmv_config().gemm_wn && lmv_wn_eligible(p, nproblems, N, K, act, lmv_config().gemm_wn == 2)) {
+    lmv_timing_set_kind(LMV_TK_WN_GEMM);
     return lmv_wn_linear(p, nproblems, N, K, act, (hipStream_t)stream);              // whole-width kernel (wngemm.hip)
+  }
   GemmArgs& g = pl.g;
   if (mode == MODE_DW) {
     if (!ws || ws_bytes < pl.ws_bytes || !lmv_aligned16(ws)) LMV_FAIL(LMV_ERR_WORKSPACE, "linear_dw: workspace %zu < %zu bytes", ws_bytes, pl.ws_bytes);
@@ -533,12 +537,20 @@ int launch(const lmv_linear_problem* p, int nproblems, int N, int K, int act, in
   hipStream_t st = (hipStream_t)stream;
   int rc;
   if (mode == MODE_DW) grid.x = g.nsplits >= 8 ? pl.total * g.nsplits : 8 * ((pl.total + 8 / g.nsplits - 1) / (8 / g.nsplits));
+  double trows = 0.;
+  for (int i = 0; i < nproblems && i < 2; ++i) trows += (double)p[i].rows;
   if (mode == MODE_FWD) rc = launch_mode<false, false, false>(pl, grid, bf, st);
-  else if (mode == MODE_DX) rc = launch_mode<false, true, false>(pl, grid, bf, st);
-  else rc = launch_mode<true, true, true>(pl, grid, bf, st);
+  else if (mode == MODE_DX) {          // (timing probe: the transpose-read dX kernel; bytes: dY in, dX out (+ the GELU' operand), W once)
+    LmvTimedLaunch timed(stream, 2.0 * N * K * trows, 2.0 * trows * (N + K * (1.0 + (act == LMV_ACT_GELU_GRAD))) + 2.0 * N * K, LMV_TK_GEMM_DX);
+    rc = launch_mode<false, true, false>(pl, grid, bf, st);
+  } else {                              // (the split-K weight-gradient kernel; bytes: dY and X in, the fp32 slabs out)
+    LmvTimedLaunch timed(stream, 2.0 * N * K * trows, 2.0 * trows * (N + K) + 4.0 * N * K * (g.nsplits > 0 ? g.nsplits : 1), LMV_TK_GEMM_DW);
+    rc = launch_mode<true, true, true>(pl, grid, bf, st);
+  }
   if (rc) return rc;
   LMV_CHECK_LAUNCH("linear");
   if (mode == MODE_DW) {
+    LmvTimedLaunch timed_r(stream, 0.0, 4.0 * N * K * ((g.nsplits > 0 ? g.nsplits : 1) + 1.0), LMV_TK_SPLITK_REDUCE);          // (skipped when the reduction is deferred: then the bracket is empty)
     const int64_t nw = (int64_t)N * K;
     const bool shared = nproblems == 2 && p[0].out == p[1].out;
     for (int i = 0; i < nproblems; ++i) {

@@ -1,6 +1,8 @@
 // misc.hip -- error plumbing and the small memory-bound utilities (cast, DropPath row scale,
 // fused flat AdamW).  All are grid-stride, 16-byte-per-lane kernels bounded by HBM bandwidth.
 #include <stdarg.h>
+#include <string.h>
+#include <mutex>
 #include <vector>
 #include "common.h"
 
@@ -15,24 +17,58 @@ void lmv_set_error(const char* fmt, ...) {
 extern "C" const char* lmv_last_error(void) { return g_err; }
 
 // ---- error word of the persistent stage kernels ------------------------------------------------------------------------------------------
-namespace { unsigned* g_errword[64] = {}; }
-unsigned* lmv_stage_errword() {
+// One sticky word per device in PINNED, device-mapped host memory: a kernel whose bounded in-launch wait runs out stores 1 there (system scope), and the host reads
+// it with a plain load -- no device synchronisation, no copy -- so every forward call can afford to look at it (lemevit_amd/model.py raises at the next call, bench.py and
+// graph.try_graphed at their synchronisation points).  Allocated on the first stage call of a device under a mutex; never inside a stream capture (the first call of a
+// process is an eager warm-up; a capture that would be the first call is refused).
+namespace {
+struct ErrWord { unsigned* host = nullptr; unsigned* dev = nullptr; };
+ErrWord g_errword[64];
+std::mutex g_errword_mu;
+}
+unsigned* lmv_stage_errword(void* stream) {
   int dev = 0;
   (void)hipGetDevice(&dev);
-  unsigned*& w = g_errword[dev & 63];
-  if (!w) {          // (first stage launch on this device: an eager warm-up call, before any stream capture)
-    if (hipMalloc(&w, 256) != hipSuccess) { w = nullptr; return nullptr; }
-    (void)hipMemset(w, 0, 256);
+  std::lock_guard<std::mutex> lock(g_errword_mu);
+  ErrWord& w = g_errword[dev & 63];
+  if (!w.dev) {
+    if (stream) {          // hipHostMalloc is not a capturable call
+      hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+      if (hipStreamIsCapturing((hipStream_t)stream, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone) return nullptr;
+    }
+    void* h = nullptr; void* d = nullptr;
+    if (hipHostMalloc(&h, 256, hipHostMallocMapped) != hipSuccess) return nullptr;
+    memset(h, 0, 256);
+    if (hipHostGetDevicePointer(&d, h, 0) != hipSuccess) { (void)hipHostFree(h); return nullptr; }
+    w.host = (unsigned*)h; w.dev = (unsigned*)d;
   }
-  return w;
+  return w.dev;
 }
 extern "C" int lmv_stage_error_count(int reset) {
-  unsigned* w = lmv_stage_errword();
-  if (!w) LMV_FAIL(LMV_ERR_LAUNCH, "stage_error_count: cannot allocate the error word");
-  unsigned v = 0;
-  if (hipMemcpy(&v, w, 4, hipMemcpyDeviceToHost) != hipSuccess) LMV_FAIL(LMV_ERR_LAUNCH, "stage_error_count: copy failed");
-  if (reset && v) (void)hipMemset(w, 0, 4);
+  if (!lmv_stage_errword(nullptr)) LMV_FAIL(LMV_ERR_LAUNCH, "stage_error_count: cannot allocate the error word");
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  volatile unsigned* h = g_errword[dev & 63].host;
+  const unsigned v = *h;
+  if (reset && v) *h = 0;
   return (int)(v & 0x7fffffffu);
+}
+// test hook: what a kernel's exhausted wait does, from the host (tests/test_model_gpu.py::test_lost_handoff_is_loud)
+extern "C" int lmv_debug_stage_error_set(int value) {
+  if (!lmv_stage_errword(nullptr)) LMV_FAIL(LMV_ERR_LAUNCH, "debug_stage_error_set: cannot allocate the error word");
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  *(volatile unsigned*)g_errword[dev & 63].host = (unsigned)value;
+  return LMV_OK;
+}
+// Workgroups of `kernel` (threads, dynamic LDS bytes) the device holds at once: the occupancy query x the CU count.  The stage kernels size their slot counts with it; their
+// slot assignment (stage_ticket, stage_common.h) is correct for ANY residency, so an optimistic answer (MI355X_MICROARCH.md: the query can be one block per CU high) costs time, not results.
+int lmv_stage_capacity(const void* kernel, int threads, size_t lds_bytes) {
+  int dev = 0, cus = 0, per_cu = 0;
+  (void)hipGetDevice(&dev);
+  if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) return 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, threads, lds_bytes) != hipSuccess || per_cu <= 0) return 0;
+  return cus * per_cu;
 }
 
 // ---- launch timing probe ---------------------------------------------------------------------------------------------------------------
@@ -51,6 +87,9 @@ void lmv_timing_begin(void* stream, double flops, double bytes, int kind) {
 void lmv_timing_end(void* stream) {
   if (g_timing_n >= g_timing.size()) return;
   (void)hipEventRecord(g_timing[g_timing_n++].e1, (hipStream_t)stream);
+}
+void lmv_timing_set_kind(int kind) {          // the open record (between begin and end): the entry point learns which kernel takes the launch after it has opened the bracket
+  if (g_timing_n < g_timing.size()) g_timing[g_timing_n].kind = kind;
 }
 extern "C" int lmv_debug_launch_timing(int capacity) {
   g_lmv_timing_on = false;
@@ -89,7 +128,7 @@ const ConfigKey kConfigKeys[] = {
     {"gemm_cumap", "LMV_GEMM_CUMAP", &LmvConfig::gemm_cumap, 1}, {"gemm_nst", "LMV_GEMM_NST", &LmvConfig::gemm_nst, 2},
     {"gemm_nst_dw", "LMV_GEMM_NST_DW", &LmvConfig::gemm_nst_dw, 3}, {"gemm_rs", "LMV_GEMM_RS", &LmvConfig::gemm_rs, 1}, {"gemm_wn", "LMV_GEMM_WN", &LmvConfig::gemm_wn, 1},
     {"dwconv_v", "LMV_DWCONV_V", &LmvConfig::dwconv_v, 0},
-    {"mlp_tm", "LMV_MLP_TM", &LmvConfig::mlp_tm, 0}, {"mlp_rw96", "LMV_MLP_RW96", &LmvConfig::mlp_rw96, 1}, {"mlp_split384", "LMV_MLP_SPLIT384", &LmvConfig::mlp_split384, 1}, {"dx_ln_fused", "LMV_DX_LN_FUSED", &LmvConfig::dx_ln_fused, 1}, {"res_ln_fused", "LMV_RES_LN_FUSED", &LmvConfig::res_ln_fused, 1}, {"ln_exact_fused", "LMV_LN_EXACT_FUSED", &LmvConfig::ln_exact_fused, 1}, {"attn_pv16", "LMV_ATTN_PV16", &LmvConfig::attn_pv16, 1},
+    {"stage_ticket_skew", "LMV_STAGE_TICKET_SKEW", &LmvConfig::stage_ticket_skew, 0}, {"mlp_tm", "LMV_MLP_TM", &LmvConfig::mlp_tm, 0}, {"mlp_rw96", "LMV_MLP_RW96", &LmvConfig::mlp_rw96, 1}, {"mlp_split384", "LMV_MLP_SPLIT384", &LmvConfig::mlp_split384, 1}, {"dx_ln_fused", "LMV_DX_LN_FUSED", &LmvConfig::dx_ln_fused, 1}, {"res_ln_fused", "LMV_RES_LN_FUSED", &LmvConfig::res_ln_fused, 1}, {"ln_exact_fused", "LMV_LN_EXACT_FUSED", &LmvConfig::ln_exact_fused, 1}, {"attn_pv16", "LMV_ATTN_PV16", &LmvConfig::attn_pv16, 1},
     {"attn_fuse_dq", "LMV_ATTN_FUSE_DQ", &LmvConfig::attn_fuse_dq, 1}, {"attn_fused_bwd", "LMV_ATTN_FUSED_BWD", &LmvConfig::attn_fused_bwd, 1},
     {"attn_pair", "LMV_ATTN_PAIR", &LmvConfig::attn_pair, 1}, {"ln_bwd_blocks", "LMV_LN_BWD_BLOCKS", &LmvConfig::ln_bwd_blocks, 1024},
     {"ln_bwd_minrows", "LMV_LN_BWD_MINROWS", &LmvConfig::ln_bwd_minrows, 2},

@@ -190,7 +190,7 @@ extern "C" int lmv_ln_linear_exact_fwd(const lmv_linear_problem* p, const lmv_ln
   double trows = 0., tbytes = 2.0 * N * K + 4.0 * N;          // raw rows in; LayerNorm(rows), (mean, rstd) and the projection out
   if (g_lmv_timing_on)
     for (int i = 0; i < nproblems; ++i) { trows += (double)p[i].rows; tbytes += 2.0 * p[i].rows * (2.0 * K + N) + 8.0 * p[i].rows; }
-  LmvTimedLaunch timed(stream, 2.0 * N * K * trows, tbytes);
+  LmvTimedLaunch timed(stream, 2.0 * N * K * trows, tbytes, LMV_TK_RSW_GEMM);
   const bool ln = gamma != nullptr;
   if (ln && (!beta || !(eps > 0.f) || !lmv_aligned16(gamma) || !lmv_aligned16(beta))) LMV_FAIL(LMV_ERR_SHAPE, "ln_linear_exact: gamma, beta and eps > 0 are required together");
   RswArgs a{};

@@ -100,7 +100,8 @@ constexpr int SS_NSTAMP = 24;
 struct SsArgs {
   const bf16_t* x_in; const bf16_t* c_in; bf16_t* x_out; bf16_t* c_out;
   const uint4* wpk; const float* vec;
-  unsigned char* kbuf; unsigned char* vbuf; unsigned char* halo; unsigned char* park; unsigned* flags; unsigned* err;     // flags: [2 B] kv | [2 B] halo; err: the sticky device error word (lmv_stage_error_count)
+  unsigned char* kbuf; unsigned char* vbuf; unsigned char* halo; unsigned char* park; unsigned* flags; unsigned* err;     // flags: [2 B] kv | [2 B] halo | [8] tickets; err: the sticky error word (lmv_stage_error_count)
+  unsigned* tickets; unsigned quota, skew;      // stage_ticket (stage_common.h): 8 counters of `quota` = 2 ceil(B / 8) tickets
   int B, nblocks; float eps;
   unsigned long long* timing; int timing_block;      // optional (NULL): s_memtime stamps [workgroup][wave][SS_NSTAMP] of one block
 };
@@ -260,8 +261,11 @@ __global__ __launch_bounds__(64 * NW, 2) void sstage_kernel(const SsArgs a) {
   int lane = lane0; asm volatile("" : "+v"(lane));                  \
   int wave = wave0; asm volatile("" : "+s"(wave));                  \
   const int g = lane >> 4, li = lane & 15; (void)g; (void)li; (void)wave;
-  // the two halves of an image are workgroups b and b + 8: the same XCD under the round-robin dispatch (a speed matter only)
-  const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+  // (image, half) by ticket, not by blockIdx: whichever workgroups are resident form complete pairs, under any dispatch order (stage_ticket, stage_common.h); the two halves of an
+  // image take consecutive tickets of the counter of the XCD they run on, so they share an L2 wherever the hardware places them (a speed matter only)
+  const int tk = stage_ticket(a.tickets, a.quota, smem, a.skew);
+  if (tk < 0) return;
+  const int xcd = tk & 7, idx = tk >> 3;
   const int img = (idx >> 1) * 8 + xcd, half = idx & 1;
   if (img >= a.B) return;
   unsigned* const kvflag_mine = a.flags + img * 2 + half;
@@ -684,17 +688,43 @@ static int ss_waves(int C, int heads, int hidden) {          // NW of the kernel
     if (C == 48 * nw && heads == C / 32 && hidden == 4 * C) return nw;
   return 0;
 }
+template <int NW> static int ss_capacity();
 int lmv_sstage_supported(int C, int heads, int hidden, int H, int W, int M, int dtype) {
-  return dtype == LMV_BF16 && ss_waves(C, heads, hidden) != 0 && H == SS_G && W == SS_G && M == SS_M;
+  const int nw = ss_waves(C, heads, hidden);
+  if (!(dtype == LMV_BF16 && nw != 0 && H == SS_G && W == SS_G && M == SS_M)) return 0;
+  const int cap = nw == 8 ? ss_capacity<8>() : ss_capacity<4>();
+  return cap == 0 || cap >= 9;          // a device that cannot hold 8 incomplete pairs + 1 workgroup (a small partition) takes the per-block schedule
 }
 size_t lmv_sstage_wpk_bytes(int C, int hidden) { return ss_waves(C, C / 32, hidden) == 4 ? (size_t)SG<4>::WS_FRAGS * 1024 : (size_t)SG<8>::WS_FRAGS * 1024; }
 size_t lmv_sstage_vec_floats(int C, int hidden) { (void)hidden; return (size_t)23 * C; }
+template <int NW> static size_t ss_flag_bytes(int B) { return ((size_t)(4 * B + 8 + 1) * 4 + 1023) & ~(size_t)1023; }          // kv | halo flags, the 8 ticket counters
 template <int NW> static size_t ss_workspace(int B) {
-  const size_t flags = ((size_t)(4 * B + 1) * 4 + 1023) & ~(size_t)1023;
-  return flags + (size_t)B * (SG<NW>::KBUF_IMG + SG<NW>::VBUF_IMG + SG<NW>::HALO_IMG + SG<NW>::PARK_IMG);
+  return ss_flag_bytes<NW>(B) + (size_t)B * (SG<NW>::KBUF_IMG + SG<NW>::VBUF_IMG + SG<NW>::HALO_IMG + SG<NW>::PARK_IMG);
 }
 size_t lmv_sstage_workspace_bytes(int B, int C) { return C == 192 ? ss_workspace<4>(B) : ss_workspace<8>(B); }
-int lmv_sstage_max_images(int C) { return C == 192 ? 256 : 128; }
+// Workgroups of the instance the device holds at once (occupancy query x CUs, cached per device; 0: no device / unknown).  Both halves of an image wait for each other, so a launch
+// takes capacity / 2 images (whole groups of 8; a larger batch runs as consecutive launches).  The slot assignment is by ticket (stage_ticket), so these counts are a matter of speed:
+// what progress needs is room for 8 incomplete pairs + 1 workgroup per launch in flight -- lmv_sstage_supported / lmv_sstage_max_concurrent.
+template <int NW> static int ss_capacity() {
+  static std::atomic<int> cache[64];
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return 0;
+  int v = cache[dev & 63].load(std::memory_order_relaxed);
+  if (!v) { v = lmv_stage_capacity(reinterpret_cast<const void*>(sstage_kernel<NW>), 64 * NW, SG<NW>::L_TOTAL); cache[dev & 63].store(v, std::memory_order_relaxed); }
+  return v;
+}
+template <int NW> static int ss_max_images() {
+  const int cap = ss_capacity<NW>();
+  if (cap <= 0) return NW == 8 ? 128 : 256;          // (no device in this process: the MI355X figure, for workspace sizing only)
+  const int n = cap / 2 / 8 * 8;
+  return n < 8 ? 8 : n;
+}
+int lmv_sstage_max_images(int C) { return C == 192 ? ss_max_images<4>() : ss_max_images<8>(); }
+int lmv_sstage_max_concurrent(int C) {
+  int cap = C == 192 ? ss_capacity<4>() : ss_capacity<8>();
+  if (cap <= 0) cap = C == 192 ? 512 : 256;          // (no device in this process: the MI355X figure)
+  return (cap - 1) / 8;
+}
 
 int lmv_sstage_pack(const lmv_sstage_block_params* p, void* wpk_out, float* vec_out, void* stream) {
   if (!p || !wpk_out || !vec_out) LMV_FAIL(LMV_ERR_SHAPE, "sstage_pack: null argument");
@@ -729,13 +759,15 @@ static int ss_launch(const lmv_sstage_desc* d, const void* x, const void* c, voi
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(sstage_kernel<NW>), hipFuncAttributeMaxDynamicSharedMemorySize, G::L_TOTAL) != hipSuccess) LMV_FAIL(LMV_ERR_LAUNCH, "sstage_fwd: cannot reserve LDS");
     attr_done.fetch_or(bit, std::memory_order_release);
   }
-  // Both halves of an image must be resident at the same time (they wait for each other): at most 256 CUs x (1 workgroup of 8 waves | 2 of 4 waves)
-  // = 128 | 256 images per launch; a larger batch runs as consecutive launches over ranges of images.
-  const int MAXB = NW == 8 ? 128 : 256;
+  // Both halves of an image wait for each other: a launch takes as many images as the device holds pairs of workgroups (MI355X: 128 at 8 waves, 256 at 4); a larger batch runs as
+  // consecutive launches over ranges of images.
+  const int MAXB = ss_max_images<NW>();
+  unsigned* const errword = lmv_stage_errword(st);
+  if (!errword) LMV_FAIL(LMV_ERR_LAUNCH, "sstage_fwd: cannot allocate the error word (the first stage call of a process must not be inside a stream capture)");
   for (int b0 = 0; b0 < d->B; b0 += MAXB) {
     const int nb = d->B - b0 < MAXB ? d->B - b0 : MAXB;
     if (workspace_bytes < ss_workspace<NW>(nb)) LMV_FAIL(LMV_ERR_WORKSPACE, "sstage_fwd: workspace too small");
-    const size_t flags = ((size_t)(4 * nb + 1) * 4 + 1023) & ~(size_t)1023;
+    const size_t flags = ss_flag_bytes<NW>(nb);
     unsigned char* ws = (unsigned char*)workspace;
     if (hipMemsetAsync(ws, 0, flags, st) != hipSuccess) LMV_FAIL(LMV_ERR_LAUNCH, "sstage_fwd: flag reset failed");      // every polled word, every call (Guideline 16)
     SsArgs a{};
@@ -745,9 +777,9 @@ static int ss_launch(const lmv_sstage_desc* d, const void* x, const void* c, voi
     a.flags = (unsigned*)ws; a.kbuf = ws + flags; a.vbuf = a.kbuf + (size_t)nb * G::KBUF_IMG; a.halo = a.vbuf + (size_t)nb * G::VBUF_IMG; a.park = a.halo + (size_t)nb * G::HALO_IMG;
     a.B = nb; a.nblocks = d->nblocks; a.eps = d->eps;
     a.timing = (unsigned long long*)d->timing; a.timing_block = d->timing_block;
-    a.err = lmv_stage_errword();
-    if (!a.err) LMV_FAIL(LMV_ERR_LAUNCH, "sstage_fwd: cannot allocate the error word");
-    const int nwg = 2 * ((nb + 7) / 8) * 8;
+    a.err = errword;
+    a.tickets = a.flags + 4 * nb; a.quota = 2u * (unsigned)((nb + 7) / 8); a.skew = (unsigned)lmv_config().stage_ticket_skew;
+    const int nwg = 2 * ((nb + 7) / 8) * 8;          // = 8 quota
     hipLaunchKernelGGL(sstage_kernel<NW>, dim3(nwg), dim3(64 * NW), G::L_TOTAL, st, a);
     LMV_CHECK_LAUNCH("sstage_fwd");
   }

@@ -40,15 +40,47 @@ __device__ __forceinline__ float xmax4(float v) {
   return max2(__uint_as_float(q[0]), __uint_as_float(q[1]));
 }
 
-// one lane polls a flag word until it reaches `epoch` (relaxed agent-scope loads + s_sleep); a bounded spin reports through flags[err]
+// one lane polls a flag word until it reaches `epoch` (relaxed agent-scope loads + s_sleep); a bounded spin reports through the error word (pinned host memory: system scope)
 __device__ __forceinline__ void wait_flag(unsigned* flag, unsigned epoch, unsigned* err, int lane) {
   if (lane == 0) {
     unsigned spins = 0;
     while (__hip_atomic_load((gu32*)flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < epoch) {
       __builtin_amdgcn_s_sleep(4);
-      if (++spins > SPIN_LIMIT) { __hip_atomic_store((gu32*)err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+      if (++spins > SPIN_LIMIT) { __hip_atomic_store((gu32*)err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); break; }
     }
   }
+}
+
+// ---- placement-independent role assignment of the workgroups of a persistent stage launch ------------------------------------------------------------------------
+// The workgroups of a slot (the two halves of an image in sstage; the image-row workgroups + the meta workgroup of an image slot in dstage) wait for each other inside the
+// launch, so a slot only makes progress once ALL its workgroups are resident.  HIP promises nothing about dispatch order or workgroup -> XCD placement
+// (MI355X_MICROARCH.md, "Workgroup dispatch": contract), so (slot, role) is not derived from blockIdx: a workgroup TAKES A TICKET when it starts.  tickets[8]: one counter
+// per XCD (zeroed by the memset in front of the launch), `quota` tickets each; ticket t of counter y is role t % NWG of slot (t / NWG) * 8 + y.  A workgroup first asks the counter of
+// the XCD it really runs on (HW_REG_XCC_ID: the workgroups of a slot then share an L2 -- a speed matter only) and moves on to the next counter when that one is used up, so every one
+// of the 8 * quota workgroups of the grid gets exactly one ticket whatever the placement was.  Because tickets are handed out in order, the STARTED workgroups always hold a prefix of
+// every counter: at most one slot per counter is incomplete at any time, every other started slot is complete and runs to its end without outside help, and the incomplete ones are
+// completed by whichever workgroups start next.  Progress therefore needs only that the device can hold 8 (NWG - 1) + 1 workgroups of the launch (checked on the host:
+// lmv_*stage_supported / _max_concurrent), not any particular dispatch order; exhausted waits still report through the error word.
+// Returns y | (t << 3), or -1 (no ticket left: cannot happen when the grid is 8 * quota workgroups).  Uses the first dword of `smem`; ends with a barrier.
+// skew (test switch "stage_ticket_skew", 0 in production): the first counter asked is displaced by a hash of blockIdx -- the roles are then dealt as under a foreign placement
+// (slots span XCDs, counters run out unevenly and workgroups fall through to the next ones); results must not change (tests/test_*stage_gpu.py).
+__device__ __forceinline__ int stage_ticket(unsigned* tickets, unsigned quota, unsigned char* smem, unsigned skew = 0) {
+  if (threadIdx.x == 0) {
+    unsigned xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    if (skew) xcc += skew * ((blockIdx.x * 2654435761u) >> 27);
+    int got = -1;
+    for (unsigned k = 0; k < 8; ++k) {
+      const unsigned y = (xcc + k) & 7;
+      const unsigned t = __hip_atomic_fetch_add((gu32*)(tickets + y), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (t < quota) { got = (int)(y | (t << 3)); break; }
+    }
+    *reinterpret_cast<volatile int*>(smem) = got;
+  }
+  __syncthreads();
+  const int r = __builtin_amdgcn_readfirstlane(*reinterpret_cast<volatile int*>(smem));
+  __syncthreads();
+  return r;
 }
 
 // gelu_poly2 (common.h) on the 8 pre-activations of one D tile pair at once, the four Horner chains interleaved statement by statement: a dependent

@@ -487,6 +487,9 @@ extern "C" int lmv_linear_dx_ln_bwd(const lmv_linear_problem* p, const lmv_ln_se
 #ifdef LMV_WN_TIMING
   a.dbg = nullptr;
 #endif
+  double trows_ = 0.;
+  for (int i = 0; i < nproblems; ++i) trows_ += (double)p[i].rows;
+  LmvTimedLaunch timed(stream, 2.0 * C * N * trows_, 2.0 * trows_ * (N + 3.0 * C) + 2.0 * N * C, LMV_TK_WN_GEMM);          // (dY in; x, dres in, dx out; the transposed weight once)
   if (int rc = wn_launch<WN_LNBWD>(a, (hipStream_t)stream)) return rc;
   LMV_CHECK_LAUNCH("linear_dx_ln_bwd");
   *partial_rows = a.npanels;
@@ -502,7 +505,7 @@ extern "C" int lmv_linear_res_ln_fwd(const lmv_linear_problem* p, const lmv_ln_s
   double trows = 0., tbytes = 2.0 * N * K + 12.0 * N;          // A, residual in; out and LayerNorm(out) out
   if (g_lmv_timing_on)
     for (int i = 0; i < nproblems; ++i) { trows += (double)p[i].rows; tbytes += 2.0 * p[i].rows * (K + 3.0 * N); }
-  LmvTimedLaunch timed(stream, 2.0 * N * K * trows, tbytes);
+  LmvTimedLaunch timed(stream, 2.0 * N * K * trows, tbytes, LMV_TK_WN_GEMM);
   WnArgs a{};
   int npan[2] = {0, 0};
   for (int i = 0; i < nproblems; ++i) {

@@ -33,6 +33,8 @@ class GraphedStep:
                 step_fn()
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
+        from . import ops as _ops
+        _ops.check_stage_errors("graph warm-up", sync=False)          # (just synchronised) a lost hand-off in the warm-up runs is an exception, not a captured graph of wrong results
         if pre_capture is not None:
             pre_capture()
         self.graph = torch.cuda.CUDAGraph()
@@ -72,7 +74,7 @@ def split_forward(model: Callable, x: torch.Tensor, parts: int, outs: Optional[l
     fork = torch.cuda.Event()
     fork.record(cur)
     fills = _model.cache_fills()
-    was, _model.concurrent_launches = _model.concurrent_launches, len(xs)      # (persistent stage kernels of some shapes may not share the chip: model._sstage_applies)
+    was, _model.launches.concurrent = _model.launches.concurrent, len(xs)      # (persistent stage kernels of a shape share the chip up to a bound: model._sstage_applies; thread-local)
     try:
         ys[0] = model(xs[0])
         cold = _model.cache_fills() != fills
@@ -85,7 +87,7 @@ def split_forward(model: Callable, x: torch.Tensor, parts: int, outs: Optional[l
                 ys[i + 1] = model(xs[i + 1])
                 xs[i + 1].record_stream(s)
     finally:
-        _model.concurrent_launches = was
+        _model.launches.concurrent = was
     for s, y in zip(streams, ys[1:]):
         cur.wait_stream(s)
         y.record_stream(cur)

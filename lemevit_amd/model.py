@@ -21,6 +21,7 @@ statistics, fp32 master weights and gradients (the bf16 matrix copies are cached
 from __future__ import annotations
 
 import os
+import threading
 import weakref
 from collections import OrderedDict
 from typing import Dict, List, Optional, Sequence, Tuple
@@ -527,12 +528,14 @@ def _stem_fused(mods, x: Tensor, cd: torch.dtype) -> Tensor:
     w2, _, b2f = _folded_conv_bn(c2, b2, cd)
     key = (id(c1), id(c2))
     ent = _stem_cache.get(key)
+    if ent is not None and ent[3]() is not c1:          # a recycled id: the module the entry was built for is gone
+        ent = None
     if ent is None or ent[0] is not w1 or ent[1] is not w2:          # (the folds are new tensors whenever a source tensor changed)
         Cm = w1.shape[0]
         w1m = torch.zeros(Cm, 32, device=w1.device, dtype=cd)
         w1m[:, :27] = w1.reshape(Cm, 27)
         w2m = w2.permute(0, 2, 3, 1).reshape(w2.shape[0], 9 * Cm).contiguous()
-        ent = (w1, w2, ops.stem_pack(w1m, w2m))
+        ent = (w1, w2, ops.stem_pack(w1m, w2m), weakref.ref(c1, lambda _r, k=key: _stem_cache.pop(k, None)))          # evicted with the module, as _conv_cache / _sstage_cache
         _cache_filled()
         _stem_cache[key] = ent
     y = ops.stem_fwd(x, ent[2], b1f, b2f, w1.shape[0], w2.shape[0])
@@ -866,7 +869,16 @@ def _lin_probs(pairs, dtype):
 # a whole stage of "S" blocks as one persistent launch (csrc/sstage.hip; inference)
 # ------------------------------------------------------------------------------------------------
 _SSTAGE = os.environ.get("LMV_SSTAGE", "1") != "0"        # 0: the per-block inference schedule (A/B runs)
-concurrent_launches = 1          # set by graph.split_forward while it issues its sub-batches: how many forward passes run side by side on the device
+
+
+class _LaunchContext(threading.local):
+    """How many forward passes the CALLING host thread keeps in flight on the device at once (graph.split_forward sets it while it issues its sub-batches): the persistent stage
+    kernels of a shape may only share the chip up to lmv_*stage_max_concurrent launches.  Thread-local: two host threads doing inference do not see each other's setting (each
+    thread's own launches are what its streams overlap; threads that share a device on top of that are outside the per-thread bound, as processes are)."""
+    concurrent = 1
+
+
+launches = _LaunchContext()
 _DSTAGE = os.environ.get("LMV_DSTAGE", "1") != "0"        # 0: stages of D blocks on the per-block schedule (A/B runs)
 _sstage_cache: dict = {}
 
@@ -875,7 +887,7 @@ def _sstage_applies(stage, xt: Tensor, c: Tensor, H: int, W: int) -> Optional[st
     """A whole stage as ONE launch: models/lemevit.py:615-650 x depth (csrc/sstage.hip: every block an "S" block of a shape lmv_sstage_supported accepts: stage 3 of
     LeMeViT-Base / -Tiny at 224 x 224 -> "S") or :542-582 x depth (csrc/dstage.hip: "D" blocks, lmv_dstage_supported: stage 2 of LeMeViT-Base -> "D").  Inference only
     (nothing is saved for a backward pass, no DropPath), bf16.  None: the per-block schedule."""
-    if not (_SSTAGE and _FUSED and _NATIVE) or torch.is_grad_enabled() or xt.dtype != torch.bfloat16 or len(stage) == 0 or not xt.is_cuda:
+    if not (_SSTAGE and _FUSED and _NATIVE) or ops.stage_kernels_disabled or torch.is_grad_enabled() or xt.dtype != torch.bfloat16 or len(stage) == 0 or not xt.is_cuda:
         return None
     kind = getattr(stage[0], "kind", None)
     if kind not in ("S", "D", "D2", "C"):
@@ -886,15 +898,15 @@ def _sstage_applies(stage, xt: Tensor, c: Tensor, H: int, W: int) -> Optional[st
     b0 = stage[0]
     if kind == "S":
         if ops.sstage_supported(xt.shape[2], b0.attn.num_heads, b0.mlp[0].out_features, H, W, c.shape[1], xt.dtype):
-            return "S"
+            return "S" if launches.concurrent <= ops.sstage_max_concurrent(xt.shape[2]) else None
         # longer sequences (24 x 24 image tokens at 384 x 384): the multi-workgroup kernel of the D stages with self-attention across the workgroups of an image
         if _DSTAGE and ops.dstage_supported(xt.shape[2], b0.attn.num_heads, b0.mlp[0].out_features, H, W, c.shape[1], xt.dtype) and \
-                concurrent_launches <= ops.dstage_max_concurrent(xt.shape[2], H, 2):
+                launches.concurrent <= ops.dstage_max_concurrent(xt.shape[2], H, 2):
             return "S2"
         return None
     if not (_DSTAGE and ops.dstage_supported(xt.shape[2], b0.attn.num_heads, b0.mlp[0].out_features, H, W, c.shape[1], xt.dtype)):
         return None
-    if concurrent_launches > ops.dstage_max_concurrent(xt.shape[2], H, 1 if kind == "C" else 0):
+    if launches.concurrent > ops.dstage_max_concurrent(xt.shape[2], H, 1 if kind == "C" else 0):
         return None          # graph.split_forward runs more sub-batches side by side than launches of this shape may share the chip (96 x 96 grids: one)
     if kind == "D":
         return "D" if all(type(blk.attn) is DualCrossAttention and blk.attn.scale == xt.shape[2] ** (-0.5) for blk in stage) else None
@@ -905,13 +917,13 @@ def _sstage_applies(stage, xt: Tensor, c: Tensor, H: int, W: int) -> Optional[st
 
 def _whole_stage_fwd(whole: str, xt: Tensor, c: Tensor, packed, H: int, W: int):
     if whole == "S":
-        return ops.sstage_fwd(xt, c, packed, H, W, BLOCK_LN_EPS)
-    return ops.dstage_fwd(xt, c, packed, H, W, BLOCK_LN_EPS, kind={"D": 0, "D2": 0, "C": 1, "S2": 2}[whole])
+        return ops.sstage_fwd(xt, c, packed, H, W, BLOCK_LN_EPS, concurrent=launches.concurrent)
+    return ops.dstage_fwd(xt, c, packed, H, W, BLOCK_LN_EPS, kind={"D": 0, "D2": 0, "C": 1, "S2": 2}[whole], concurrent=launches.concurrent)
 
 
 def _sstage_packed(stage, kind: str = "S") -> "ops.SStagePacked":
     """The stage's parameters in the kernel's layout, cached per parameter version (and per training pass, see compute_copy)."""
-    key = id(stage)
+    key = (id(stage), kind)          # one stage resolves to different kernels at different resolutions ("S" at 14 x 14, "S2" at 24 x 24): one pack per (stage, kind)
     plist = [p for blk in stage for p in blk._params().values()]
     stamp = tuple(p._version for p in plist) + tuple(id(p) for p in plist) + (_train_pass,)
     ent = _sstage_cache.get(key)
@@ -935,6 +947,125 @@ def _sstage_packed(stage, kind: str = "S") -> "ops.SStagePacked":
     return packed
 
 
+# ------------------------------------------------------------------------------------------------
+# the attention modules as nn.Module sub-boundaries (DualCrossAttention.forward(x, c) -> (x, c) models/lemevit.py:252,
+# StandardAttention.forward(x) -> x :185, CrossAttention.forward(x, c) -> c :454): called on their own they are ordinary differentiable modules --
+# ONE autograd node over the same kernels the block schedules launch (projection GEMMs, attention cores with the log-sum-exp saved, their backward forms).
+# ------------------------------------------------------------------------------------------------
+def _needs_grad(*ts) -> bool:
+    return torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in ts)
+
+
+class _AttnModuleFn(torch.autograd.Function):
+    """kind "S": (x) -> x'; "D" / "D2": (x, c) -> (x', c'); "C": (x, c) -> c'.  params: (weight, bias) of the module's Linears in declaration order."""
+
+    @staticmethod
+    def forward(ctx, kind, x, c, *params):
+        new_training_pass()                      # parameters may have been updated in place since the last call (see compute_copy)
+        cd = x.dtype
+        x = x.contiguous()
+        c = None if c is None else c.contiguous()
+        W = [compute_copy(params[2 * i], cd) for i in range(len(params) // 2)]
+        Bv = [compute_copy(params[2 * i + 1], torch.float32) for i in range(len(params) // 2)]
+        C = x.shape[-1]
+        emp = lambda like, cols: torch.empty(like.shape[:-1] + (cols,), device=like.device, dtype=cd)
+        if kind == "S":
+            qkv = emp(x, 3 * C)
+            ops.linear_fwd([Prob(x, W[0], qkv, bias=Bv[0])], 3 * C, C)
+            ao, lse = ops.attn_fwd((qkv, 0), (qkv, C), (qkv, 2 * C), C, ops.SDPA_SCALE, want_lse=True)
+            out = torch.empty_like(x)
+            ops.linear_fwd([Prob(ao, W[1], out, bias=Bv[1])], C, C)
+            saved, outs = (x, qkv, ao, lse), (out,)
+        elif kind in ("D", "D2"):
+            N, M = x.shape[1], c.shape[1]
+            sx, sc = ops.dca_scales(N, M, C)
+            wd = 3 * C if kind == "D" else 2 * C
+            p1, p2 = emp(x, wd), emp(c, wd)
+            ops.linear_fwd([Prob(x, W[0], p1, bias=Bv[0]), Prob(c, W[1], p2, bias=Bv[1])], wd, C)
+            if kind == "D":      # models/lemevit.py:297,300
+                aox, lsex = ops.attn_fwd((p1, 0), (p2, C), (p2, 2 * C), C, sx, want_lse=True)
+                aoc, lsec = ops.attn_fwd((p2, 0), (p1, C), (p1, 2 * C), C, sc, want_lse=True)
+            else:                # models/lemevit.py:402,405: the same q / k serve both directions
+                aox, lsex = ops.attn_fwd((p1, 0), (p2, 0), (p2, C), C, sx, want_lse=True)
+                aoc, lsec = ops.attn_fwd((p2, 0), (p1, 0), (p1, C), C, sc, want_lse=True)
+            ox, oc = torch.empty_like(x), torch.empty_like(c)
+            ops.linear_fwd([Prob(aox, W[2], ox, bias=Bv[2]), Prob(aoc, W[3], oc, bias=Bv[3])], C, C)
+            saved, outs = (x, c, p1, p2, aox, aoc, lsex, lsec), (ox, oc)
+        else:                    # "C": q from the meta tokens, kv from the image tokens (models/lemevit.py:477-486)
+            q, kv = torch.empty_like(c), emp(x, 2 * C)
+            ops.linear_fwd([Prob(c, W[0], q, bias=Bv[0])], C, C)
+            ops.linear_fwd([Prob(x, W[1], kv, bias=Bv[1])], 2 * C, C)
+            ao, lse = ops.attn_fwd((q, 0), (kv, 0), (kv, C), C, ops.SDPA_SCALE, want_lse=True)
+            out = torch.empty_like(c)
+            ops.linear_fwd([Prob(ao, W[2], out, bias=Bv[2])], C, C)
+            saved, outs = (x, c, q, kv, ao, lse), (out,)
+        ctx.kind, ctx.W, ctx.acts, ctx.shapes = kind, W, saved, [(p.shape, p.dtype) for p in params]
+        return outs if len(outs) > 1 else outs[0]
+
+    @staticmethod
+    def backward(ctx, *gs):
+        kind, W, S = ctx.kind, ctx.W, ctx.acts
+        gs = [g.contiguous() for g in gs]
+        dev = gs[0].device
+        G = [torch.zeros(s, device=dev, dtype=torch.float32) for s, _ in ctx.shapes]      # fp32 accumulators: (weight, bias) pairs
+        dw = lambda probs, N, K: ops.linear_dw(probs, N, K)
+        if kind == "S":
+            x, qkv, ao, lse = S
+            C = x.shape[-1]
+            dw([Prob(gs[0], ao, G[2], bias_grad=G[3])], C, C)
+            dao = torch.empty_like(x)
+            ops.linear_dx([Prob(gs[0], W[1], dao)], C, C)
+            dqkv = torch.empty_like(qkv)
+            ops.attn_bwd((qkv, 0), (qkv, C), (qkv, 2 * C), ao, lse, dao, (dqkv, 0), (dqkv, C), (dqkv, 2 * C), C, ops.SDPA_SCALE)
+            dw([Prob(dqkv, x, G[0], bias_grad=G[1])], 3 * C, C)
+            dx = torch.empty_like(x)
+            ops.linear_dx([Prob(dqkv, W[0], dx)], 3 * C, C)
+            dc = None
+        elif kind in ("D", "D2"):
+            x, c, p1, p2, aox, aoc, lsex, lsec = S
+            C, N, M = x.shape[-1], x.shape[1], c.shape[1]
+            sx, sc = ops.dca_scales(N, M, C)
+            wd = p1.shape[-1]
+            dw([Prob(gs[0], aox, G[4], bias_grad=G[5]), Prob(gs[1], aoc, G[6], bias_grad=G[7])], C, C)
+            daox, daoc = torch.empty_like(x), torch.empty_like(c)
+            ops.linear_dx([Prob(gs[0], W[2], daox), Prob(gs[1], W[3], daoc)], C, C)
+            d1, d2 = torch.empty_like(p1), torch.empty_like(p2)
+            if kind == "D":
+                ops.attn_bwd((p1, 0), (p2, C), (p2, 2 * C), aox, lsex, daox, (d1, 0), (d2, C), (d2, 2 * C), C, sx)
+                ops.attn_bwd((p2, 0), (p1, C), (p1, 2 * C), aoc, lsec, daoc, (d2, 0), (d1, C), (d1, 2 * C), C, sc)
+            else:                # k is the query of the second direction, q its key: their gradients add to the first direction's
+                ops.attn_bwd((p1, 0), (p2, 0), (p2, C), aox, lsex, daox, (d1, 0), (d2, 0), (d2, C), C, sx)
+                t2, t1 = torch.empty_like(p2), torch.empty_like(p1)
+                ops.attn_bwd((p2, 0), (p1, 0), (p1, C), aoc, lsec, daoc, (t2, 0), (t1, 0), (d1, C), C, sc)
+                d1[..., :C] += t1[..., :C]
+                d2[..., :C] += t2[..., :C]
+            dw([Prob(d1, x, G[0], bias_grad=G[1]), Prob(d2, c, G[2], bias_grad=G[3])], wd, C)
+            dx, dc = torch.empty_like(x), torch.empty_like(c)
+            ops.linear_dx([Prob(d1, W[0], dx), Prob(d2, W[1], dc)], wd, C)
+        else:
+            x, c, q, kv, ao, lse = S
+            C = x.shape[-1]
+            dw([Prob(gs[0], ao, G[4], bias_grad=G[5])], C, C)
+            dao = torch.empty_like(c)
+            ops.linear_dx([Prob(gs[0], W[2], dao)], C, C)
+            dq, dkv = torch.empty_like(q), torch.empty_like(kv)
+            ops.attn_bwd((q, 0), (kv, 0), (kv, C), ao, lse, dao, (dq, 0), (dkv, 0), (dkv, C), C, ops.SDPA_SCALE)
+            dw([Prob(dq, c, G[0], bias_grad=G[1])], C, C)
+            dw([Prob(dkv, x, G[2], bias_grad=G[3])], 2 * C, C)
+            dc, dx = torch.empty_like(c), torch.empty_like(x)
+            ops.linear_dx([Prob(dq, W[0], dc)], C, C)
+            ops.linear_dx([Prob(dkv, W[1], dx)], 2 * C, C)
+        grads = [g.to(dt) for g, (_, dt) in zip(G, ctx.shapes)]
+        return (None, dx, dc) + tuple(grads)
+
+
+def _attn_params(*linears):
+    out = []
+    for m in linears:
+        out += [m.weight, m.bias]
+    return out
+
+
 class StandardAttention(nn.Module):
     """models/lemevit.py:156-217.  forward(x [B,L,C]) -> [B,L,C] (inference path; training runs inside the block node)."""
 
@@ -946,10 +1077,14 @@ class StandardAttention(nn.Module):
         self.qkv = nn.Linear(dim, 3 * dim)
         self.proj = nn.Linear(dim, dim)
 
-    @torch.no_grad()
     def forward(self, x):
-        if torch.is_grad_enabled():
-            new_training_pass()        # parameters may have been updated in place since the last call (see compute_copy)
+        P = _attn_params(self.qkv, self.proj)
+        if _needs_grad(x, *P):
+            return _AttnModuleFn.apply("S", x, None, *P)
+        with torch.no_grad():
+            return self._forward_nograd(x)
+
+    def _forward_nograd(self, x):
         x = x.contiguous()
         C = x.shape[-1]
         qkv = torch.empty(x.shape[:-1] + (3 * C,), device=x.device, dtype=x.dtype)
@@ -973,10 +1108,14 @@ class DualCrossAttention(nn.Module):
         self.proj_x = nn.Linear(dim, dim)
         self.proj_c = nn.Linear(dim, dim)
 
-    @torch.no_grad()
     def forward(self, x, c):
-        if torch.is_grad_enabled():
-            new_training_pass()        # parameters may have been updated in place since the last call (see compute_copy)
+        P = _attn_params(self.qkv1, self.qkv2, self.proj_x, self.proj_c)
+        if _needs_grad(x, c, *P):
+            return _AttnModuleFn.apply("D", x, c, *P)
+        with torch.no_grad():
+            return self._forward_nograd(x, c)
+
+    def _forward_nograd(self, x, c):
         x, c = x.contiguous(), c.contiguous()
         C, N, M = x.shape[-1], x.shape[1], c.shape[1]
         sx, sc = ops.dca_scales(N, M, C)
@@ -1003,10 +1142,14 @@ class DualCrossAttention_v2(nn.Module):
         self.proj_x = nn.Linear(dim, dim)
         self.proj_c = nn.Linear(dim, dim)
 
-    @torch.no_grad()
     def forward(self, x, c):
-        if torch.is_grad_enabled():
-            new_training_pass()        # parameters may have been updated in place since the last call (see compute_copy)
+        P = _attn_params(self.qv1, self.kv2, self.proj_x, self.proj_c)
+        if _needs_grad(x, c, *P):
+            return _AttnModuleFn.apply("D2", x, c, *P)
+        with torch.no_grad():
+            return self._forward_nograd(x, c)
+
+    def _forward_nograd(self, x, c):
         x, c = x.contiguous(), c.contiguous()
         C, N, M = x.shape[-1], x.shape[1], c.shape[1]
         sx, sc = ops.dca_scales(N, M, C)
@@ -1031,10 +1174,14 @@ class CrossAttention(nn.Module):
         self.kv = nn.Linear(dim, 2 * dim)
         self.proj = nn.Linear(dim, dim)
 
-    @torch.no_grad()
     def forward(self, x, c):
-        if torch.is_grad_enabled():
-            new_training_pass()        # parameters may have been updated in place since the last call (see compute_copy)
+        P = _attn_params(self.q, self.kv, self.proj)
+        if _needs_grad(x, c, *P):
+            return _AttnModuleFn.apply("C", x, c, *P)
+        with torch.no_grad():
+            return self._forward_nograd(x, c)
+
+    def _forward_nograd(self, x, c):
         x, c = x.contiguous(), c.contiguous()
         C = x.shape[-1]
         kv = torch.empty(x.shape[:-1] + (2 * C,), device=x.device, dtype=x.dtype)
@@ -1105,9 +1252,9 @@ class LeMeBlock(nn.Module):
         return run_block(self.kind, x, c, H, W, self._params(), masks)
 
     def forward(self, x: Tensor, c: Tensor) -> Tuple[Tensor, Tensor]:
+        """Reference signature: x NCHW in / out (models/lemevit.py:652)."""
         if torch.is_grad_enabled():
             new_training_pass()        # parameters may have been updated in place since the last call (see compute_copy)
-        """Reference signature: x NCHW in / out (models/lemevit.py:652)."""
         B, C, H, W = x.shape
         xt = x.permute(0, 2, 3, 1).reshape(B, H * W, C).contiguous()
         xt, c = self.forward_tokens(xt, c.contiguous(), H, W)
@@ -1282,6 +1429,7 @@ class LeMeViT(nn.Module):
         if hoist:
             c = self.meta_tokens.unsqueeze(0)
         xt, H, W = None, 0, 0
+        checked = False
         all_masks = self._draw_drop_path(B, x.device)
         for i in range(self.num_stages):
             if i == 0 or not isinstance(self.downsample_layers[i], nn.Identity):
@@ -1312,6 +1460,9 @@ class LeMeViT(nn.Module):
             c = c.to(cd).contiguous()
             whole = _sstage_applies(self.stages[i], xt, c, H, W)
             if whole is not None:
+                if not checked:          # the verdict on the stage launches of EARLIER calls (pinned host word: no synchronisation): a lost hand-off raises here, late but never silently
+                    ops.check_stage_errors("found by LeMeViT.forward_features; raised by an earlier call", sync=False)
+                    checked = True
                 xt, c = _whole_stage_fwd(whole, xt.contiguous(), c, _sstage_packed(self.stages[i], whole), H, W)
                 continue
             with image_ranges(xt.device, B):

@@ -615,7 +615,13 @@ def sstage_supported(C_: int, heads: int, hidden: int, H: int, W: int, M: int, d
 
 class SStagePacked:
     """The parameters of `nblocks` consecutive S blocks in the layout lmv_sstage_fwd reads (lmv_sstage_pack)."""
-    __slots__ = ("wpk", "vec", "nblocks", "C", "heads", "hidden")
+    __slots__ = ("wpk", "vec", "nblocks", "C", "heads", "hidden", "layout")          # layout: "sstage" (lmv_sstage_pack) | "dstage" (lmv_dstage_pack): the two kernels' fragment orders differ
+
+
+def _check_packed(P: "SStagePacked", want: str, C_: int, fn: str) -> None:
+    """A pack built for the other stage kernel (or another width) would be read past its end / in the wrong fragment order: refuse it."""
+    if getattr(P, "layout", None) != want or P.C != C_:
+        raise ValueError(f"lemevit_amd: {fn} got parameters packed as {getattr(P, 'layout', None)!r} for C = {P.C}; it needs the {want!r} layout for C = {C_}")
 
 
 SSTAGE_NAMES = ("attn.qkv.weight", "attn.proj.weight", "mlp.0.weight", "mlp.3.weight", "norm1.weight", "norm1.bias", "attn.qkv.bias", "attn.proj.bias",
@@ -629,7 +635,7 @@ def sstage_pack(blocks: Sequence[dict], heads: int) -> SStagePacked:
     hidden = blocks[0]["mlp.0.weight"].shape[0]
     wb, vf = int(lib.lmv_sstage_wpk_bytes(C_, hidden)), int(lib.lmv_sstage_vec_floats(C_, hidden))
     P = SStagePacked()
-    P.nblocks, P.C, P.heads, P.hidden = len(blocks), C_, heads, hidden
+    P.nblocks, P.C, P.heads, P.hidden, P.layout = len(blocks), C_, heads, hidden, "sstage"
     P.wpk = torch.empty(len(blocks) * wb, device=w0.device, dtype=torch.uint8)
     P.vec = torch.empty(len(blocks) * vf, device=w0.device, dtype=torch.float32)
     keep = []
@@ -649,8 +655,23 @@ def sstage_pack(blocks: Sequence[dict], heads: int) -> SStagePacked:
     return P
 
 
-def sstage_fwd(x: Tensor, c: Tensor, P: SStagePacked, H: int, W: int, eps: float, timing: Optional[Tensor] = None, timing_block: int = 0) -> Tuple[Tensor, Tensor]:
+def sstage_max_concurrent(C_: int) -> int:
+    """sstage_fwd launches of this width that may be in flight on different streams at once (lmv_sstage_max_concurrent; include/lemevit_hip.h, "Residency")."""
+    return int(lib.lmv_sstage_max_concurrent(C_))
+
+
+def _check_concurrent(concurrent: int, limit: int, fn: str) -> None:
+    if concurrent > limit:
+        raise RuntimeError(f"lemevit_amd: {fn} asked to run as one of {concurrent} concurrent launches, but this shape may have at most {limit} in flight on the device "
+                           "(their incomplete slots would fill the chip and the in-launch hand-offs could starve): use the per-block schedule or fewer sub-batches")
+
+
+def sstage_fwd(x: Tensor, c: Tensor, P: SStagePacked, H: int, W: int, eps: float, timing: Optional[Tensor] = None, timing_block: int = 0,
+               concurrent: int = 1) -> Tuple[Tensor, Tensor]:
+    """concurrent: how many stage launches the caller keeps in flight on the device at once, this one included (graph.split_forward's sub-batches)."""
     B, N, C_ = x.shape
+    _check_packed(P, "sstage", C_, "sstage_fwd")
+    _check_concurrent(concurrent, sstage_max_concurrent(C_), "sstage_fwd")
     d = _lib.SStageDesc()
     d.B, d.H, d.W, d.M, d.C, d.heads, d.hidden, d.nblocks, d.dtype, d.eps = B, H, W, c.shape[1], C_, P.heads, P.hidden, P.nblocks, dtype_code(x), eps
     d.wpk, d.vec = P.wpk.data_ptr(), P.vec.data_ptr()
@@ -692,7 +713,7 @@ def dstage_pack(blocks: Sequence[dict], heads: int) -> SStagePacked:
     if wb == 0:
         raise ValueError(f"lemevit_amd: dstage_pack does not support C = {C_}")
     P = SStagePacked()
-    P.nblocks, P.C, P.heads, P.hidden = len(blocks), C_, heads, hidden
+    P.nblocks, P.C, P.heads, P.hidden, P.layout = len(blocks), C_, heads, hidden, "dstage"
     P.wpk = torch.empty(len(blocks) * wb, device=w0.device, dtype=torch.uint8)
     P.vec = torch.empty(len(blocks) * vf, device=w0.device, dtype=torch.float32)
     keep = []
@@ -773,9 +794,13 @@ def d2stage_pack(blocks: Sequence[dict], heads: int) -> SStagePacked:
     return dstage_pack(out, heads)
 
 
-def dstage_fwd(x: Tensor, c: Tensor, P: SStagePacked, H: int, W: int, eps: float, timing: Optional[Tensor] = None, timing_block: int = 0, kind: int = 0) -> Tuple[Tensor, Tensor]:
-    """kind = 1: the packed blocks are "C" blocks (cstage_pack): x is returned as it came; kind = 2: "S" blocks (s2stage_pack)."""
+def dstage_fwd(x: Tensor, c: Tensor, P: SStagePacked, H: int, W: int, eps: float, timing: Optional[Tensor] = None, timing_block: int = 0, kind: int = 0,
+               concurrent: int = 1) -> Tuple[Tensor, Tensor]:
+    """kind = 1: the packed blocks are "C" blocks (cstage_pack): x is returned as it came; kind = 2: "S" blocks (s2stage_pack).
+    concurrent: how many stage launches the caller keeps in flight on the device at once, this one included."""
     B, N, C_ = x.shape
+    _check_packed(P, "dstage", C_, "dstage_fwd")
+    _check_concurrent(concurrent, dstage_max_concurrent(C_, H, kind), "dstage_fwd")
     d = _lib.SStageDesc()
     d.kind = kind
     d.B, d.H, d.W, d.M, d.C, d.heads, d.hidden, d.nblocks, d.dtype, d.eps = B, H, W, c.shape[1], C_, P.heads, P.hidden, P.nblocks, dtype_code(x), eps
@@ -818,10 +843,28 @@ def stem_fwd(x: Tensor, wpk: Tensor, b1: Tensor, b2: Tensor, Cm: int, Co: int) -
     return y
 
 
-def stage_error_count(reset: bool = False) -> int:
-    """The sticky error word of the persistent stage kernels (a bounded in-launch wait that ran out); synchronises the device first."""
-    torch.cuda.synchronize()
+def stage_error_count(reset: bool = False, sync: bool = True) -> int:
+    """The sticky error word of the persistent stage kernels (a bounded in-launch wait that ran out = a lost hand-off).  It lives in pinned host memory: reading it costs nothing;
+    sync=True synchronises the device first so that the answer covers every launch issued so far, sync=False covers the launches that have completed."""
+    if sync:
+        torch.cuda.synchronize()
     v = int(lib.lmv_stage_error_count(1 if reset else 0))
     if v < 0:
         check(v, "lmv_stage_error_count")
     return v
+
+
+stage_kernels_disabled = False          # set by check_stage_errors: after a lost hand-off the process keeps to the per-block schedule (lemevit_amd/model.py::_sstage_applies)
+
+
+def check_stage_errors(where: str, sync: bool = True) -> None:
+    """Raise if a persistent stage kernel lost a hand-off (its outputs are then wrong).  Called at the synchronisation points of the callers -- bench.py after its timed
+    regions, graph.try_graphed after its warm-up, LeMeViT.forward at entry (sync=False: the verdict on the PREVIOUS calls, free of charge) -- so that a lost hand-off is an
+    exception, never a wrong tensor or a normal-looking bench line.  The word is cleared and the stage kernels are switched off for the rest of the process."""
+    global stage_kernels_disabled
+    n = stage_error_count(reset=True, sync=sync)
+    if n:
+        stage_kernels_disabled = True
+        raise RuntimeError(f"lemevit_amd: a persistent stage kernel lost an in-launch hand-off ({where}): outputs of the stage launches since the last check are invalid. "
+                           "Likely causes: another process on the device, more concurrent stage launches than lmv_*stage_max_concurrent allows, a device partition smaller than "
+                           "the kernels were sized for.  The per-block schedule is used for the rest of this process.")

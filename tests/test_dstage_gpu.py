@@ -173,6 +173,50 @@ def test_dstage_four_concurrent_launches(C, G, nblocks):
         for k, (xo, co) in enumerate(outs):
             assert torch.equal(xo, ref[0][32 * k:32 * k + 32]) and torch.equal(co, ref[1][32 * k:32 * k + 32]), (rnd, k)
 
+
+
+@pytest.mark.parametrize("C,G,nblocks,B", [(192, 28, 2, 128), (96, 56, 2, 70), (96, 56, 1, 37), (128, 28, 2, 64)])
+@pytest.mark.parametrize("skew", [1, 5])
+def test_dstage_roles_by_ticket_under_foreign_placement(C, G, nblocks, B, skew):
+    """(slot, role) of a workgroup comes from a ticket taken at start (csrc/stage_common.h: stage_ticket), not from blockIdx: no dispatch order and no workgroup -> XCD map is
+    assumed (MI355X_MICROARCH.md, "Workgroup dispatch": contract).  With the test switch the first counter asked is displaced by a hash of the workgroup index -- slots span XCDs,
+    counters run out unevenly, workgroups fall through to later counters, as under an arbitrary placement.  Outputs must equal the unskewed run bit for bit; nothing may time out."""
+    from lemevit_amd import _lib, ops
+    sds = _stage_params(nblocks, 43, C)
+    P = _pack(sds)
+    x, c = _inputs(B, 9, C, G)
+    x, c = x.to(DEV), c.to(DEV)
+    ref = ops.dstage_fwd(x, c, P, G, G, 1e-6)
+    torch.cuda.synchronize()
+    _lib.config_set("stage_ticket_skew", skew)
+    try:
+        for _ in range(2):
+            out = ops.dstage_fwd(x, c, P, G, G, 1e-6)
+            torch.cuda.synchronize()
+            assert torch.equal(out[0], ref[0]) and torch.equal(out[1], ref[1])
+    finally:
+        _lib.config_set("stage_ticket_skew", 0)
+    assert ops.stage_error_count() == 0
+
+
+def test_dstage_excess_concurrency_is_an_error():
+    """a launch that would be one of more concurrent launches than lmv_dstage_max_concurrent allows gets a RuntimeError, never a wrong tensor; so does a
+    pack in the other kernel's layout."""
+    from lemevit_amd import ops
+    C, G = 96, 56
+    sds = _stage_params(1, 3, C)
+    P = _pack(sds)
+    x, c = _inputs(2, 3, C, G)
+    x, c = x.to(DEV), c.to(DEV)
+    limit = ops.dstage_max_concurrent(C, G, 0)
+    assert limit == 4, limit          # MI355X: (1024 - 1) // (8 * 28)
+    with pytest.raises(RuntimeError):
+        ops.dstage_fwd(x, c, P, G, G, 1e-6, concurrent=limit + 1)
+    P.layout = "sstage"
+    with pytest.raises(ValueError):
+        ops.dstage_fwd(x, c, P, G, G, 1e-6)
+
+
 # ---- "C" blocks (stage 0: CrossAttention, only the meta tokens change) through the same kernel (kind = 1) ----
 def _cstage(nblocks, seed, C):
     sds = []

@@ -293,6 +293,131 @@ def test_fused_inference_path(golden, name, monkeypatch):
     assert (a - b).abs().max().item() <= 3e-2 * b.abs().max().item()
 
 
+
+
+# ---- round 5: the attention modules as differentiable sub-boundaries (SURVEY 8(b); VERDICT round 4, missing #5) -----------------------------------------
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-4), (torch.bfloat16, 3e-2)])
+@pytest.mark.parametrize("kind", ["S", "D", "D2", "C"])
+def test_attention_modules_are_differentiable(kind, dtype, tol):
+    """StandardAttention / DualCrossAttention(_v2) / CrossAttention called on their own under autograd (models/lemevit.py:185,252,454 are ordinary nn.Modules): outputs and
+    EVERY gradient -- inputs, weights, biases -- against the CPU oracle's autograd on the operands the kernels read.  (Rounds 1 - 4 decorated these forwards with no_grad: under
+    autograd they silently returned constants.)"""
+    lib = L()
+    C, h, B, N, M = 96, 3, 2, 196, 16
+    cls = {"S": lib.StandardAttention, "D": lib.DualCrossAttention, "D2": lib.DualCrossAttention_v2, "C": lib.CrossAttention}[kind]
+    m = load(cls(dim=C, num_heads=h), "attn.", 77)
+    if dtype == torch.bfloat16:          # the kernels read bf16 copies of the fp32 masters: give the oracle the same operands
+        with torch.no_grad():
+            for n_, p_ in m.named_parameters():
+                if p_.dim() == 2:
+                    p_.copy_(p_.to(torch.bfloat16).float())
+    x0 = det_tensor((B, N, C), "attnmod.x", 5).to(dtype)
+    c0 = det_tensor((B, M, C), "attnmod.c", 5).to(dtype)
+    gx = det_tensor((B, N, C), "attnmod.gx", 6).to(dtype)
+    gc = det_tensor((B, M, C), "attnmod.gc", 6).to(dtype)
+    x = x0.to(DEV).requires_grad_(True)
+    c = c0.to(DEV).requires_grad_(True)
+    if kind == "S":
+        out = m(x); loss = (out.float() * gx.to(DEV).float()).sum()
+    elif kind == "C":
+        out = m(x, c); loss = (out.float() * gc.to(DEV).float()).sum()
+    else:
+        ox, oc = m(x, c); loss = (ox.float() * gx.to(DEV).float()).sum() + (oc.float() * gc.to(DEV).float()).sum()
+    loss.backward()
+    # oracle (float64 autograd)
+    sd = {"attn." + k: v.detach().double().cpu().requires_grad_(True) for k, v in m.state_dict().items()}
+    xr = x0.double().requires_grad_(True); cr = c0.double().requires_grad_(True)
+    if kind == "S":
+        lr = (O.standard_attention(sd, "attn.", xr, h) * gx.double()).sum()
+    elif kind == "C":
+        lr = (O.cross_attention(sd, "attn.", xr, cr, h) * gc.double()).sum()
+    else:
+        fn = O.dual_cross_attention if kind == "D" else O.dual_cross_attention_v2
+        a, b = fn(sd, "attn.", xr, cr, h)
+        lr = (a * gx.double()).sum() + (b * gc.double()).sum()
+    lr.backward()
+    worst = close(x.grad, xr.grad.numpy(), tol, f"{kind} dx")
+    if kind != "S":
+        worst = max(worst, close(c.grad, cr.grad.numpy(), tol, f"{kind} dc"))
+    for n_, p_ in m.named_parameters():
+        assert p_.grad is not None, n_
+        worst = max(worst, close(p_.grad, sd["attn." + n_].grad.numpy(), tol, f"{kind} {n_}"))
+    print(f"attention module {kind} {dtype}: worst gradient error {worst:.2e}")
+    # and without autograd the module still takes the inference launches
+    with torch.no_grad():
+        o2 = m(x0.to(DEV)) if kind == "S" else m(x0.to(DEV), c0.to(DEV))
+    o1 = out if kind in ("S", "C") else ox
+    o2 = o2 if kind in ("S", "C") else o2[0]
+    assert (o1.detach().float() - o2.float()).abs().max().item() <= 2e-2 * o2.float().abs().max().item()
+
+
+def test_one_model_two_resolutions(monkeypatch):
+    """ADVICE round 4 (high): stage 3 of one model instance resolves to the "S" kernel (sstage layout) at 14 x 14 tokens and to the "S2" kind of the D-stage kernel (dstage layout)
+    at 24 x 24; the packed-parameter cache is keyed by (stage, kind) and the ops refuse a foreign pack.  224 -> 384 -> 224 on one instance, each against the per-block schedule."""
+    import lemevit_amd.model as M
+    m = _model("lemevit_tiny", 10, 5).eval()
+    imgs = {r: det_tensor((2, 3, r, r), f"tworez.{r}", 2).to(DEV) for r in (224, 384)}
+    ref = {}
+    monkeypatch.setattr(M, "_SSTAGE", False)
+    with torch.no_grad(), torch.autocast("cuda", torch.bfloat16):
+        for r, im in imgs.items():
+            ref[r] = m(im).float()
+    monkeypatch.setattr(M, "_SSTAGE", True)
+    with torch.no_grad(), torch.autocast("cuda", torch.bfloat16):
+        for r in (224, 384, 224, 384):
+            out = m(imgs[r]).float()
+            torch.cuda.synchronize()
+            d = (out - ref[r]).abs().max().item() / ref[r].abs().max().item()
+            assert d <= 3e-2, (r, d)
+    kinds = sorted(k[1] for k in M._sstage_cache if isinstance(k, tuple))
+    assert "S" in kinds and "S2" in kinds, kinds
+
+
+def test_lost_handoff_is_loud(monkeypatch):
+    """VERDICT round 4, weak #2 / next #2: a persistent stage kernel whose bounded wait ran out sets the sticky error word; the NEXT forward call must raise (it reads the pinned
+    word without a synchronisation), the word is cleared, and the process keeps to the per-block schedule from then on -- a wrong tensor never reaches the caller silently."""
+    import lemevit_amd.model as M
+    from lemevit_amd import _lib, ops
+    m = _model("lemevit_tiny", 10, 5).eval()
+    img = det_tensor((2, 3, 224, 224), "loud.img", 2).to(DEV)
+    with torch.no_grad(), torch.autocast("cuda", torch.bfloat16):
+        good = m(img).float()
+    torch.cuda.synchronize()
+    assert ops.stage_error_count() == 0
+    monkeypatch.setattr(ops, "stage_kernels_disabled", False)
+    _lib.check(_lib.lib.lmv_debug_stage_error_set(1), "lmv_debug_stage_error_set")          # what an exhausted in-launch wait does
+    try:
+        with pytest.raises(RuntimeError, match="hand-off"):
+            with torch.no_grad(), torch.autocast("cuda", torch.bfloat16):
+                m(img)
+        assert ops.stage_kernels_disabled and ops.stage_error_count() == 0          # cleared; stage kernels off
+        with torch.no_grad(), torch.autocast("cuda", torch.bfloat16):
+            again = m(img).float()          # the per-block schedule
+        torch.cuda.synchronize()
+        assert (again - good).abs().max().item() <= 3e-2 * good.abs().max().item()
+        # bench.py / graph.try_graphed call the same check at their synchronisation points
+        _lib.check(_lib.lib.lmv_debug_stage_error_set(1), "lmv_debug_stage_error_set")
+        with pytest.raises(RuntimeError):
+            ops.check_stage_errors("test")
+    finally:
+        _lib.lib.lmv_debug_stage_error_set(0)
+        ops.stage_kernels_disabled = False
+
+
+def test_launch_context_is_thread_local():
+    """VERDICT round 4, weak #8: split_forward's sub-batch count used to be a module global that two inference threads raced on."""
+    import threading
+    import lemevit_amd.model as M
+    seen = {}
+    M.launches.concurrent = 4
+    t = threading.Thread(target=lambda: seen.setdefault("other", M.launches.concurrent))
+    t.start(); t.join()
+    try:
+        assert seen["other"] == 1 and M.launches.concurrent == 4
+    finally:
+        M.launches.concurrent = 1
+
+
 @pytest.mark.parametrize("name", ["train_tiny_96", "train_tiny_96_dp"])
 def test_train_step_fp32(golden, name):
     """Train-mode step (BatchNorm batch statistics, DropPath with the reference's recorded masks): loss, logits, every

@@ -157,6 +157,50 @@ def test_sstage_handoffs_under_uneven_load(C, nblocks, B):
             assert torch.equal(half[0], ref[0][: B // 2]) and torch.equal(half[1], ref[1][: B // 2]), rnd
 
 
+@pytest.mark.parametrize("C,nblocks,B", [(384, 3, 128), (384, 2, 37), (192, 2, 256)])
+@pytest.mark.parametrize("skew", [1, 3, 5])
+def test_sstage_roles_by_ticket_under_foreign_placement(C, nblocks, B, skew):
+    """The (image, half) of a workgroup comes from a ticket it takes when it starts (csrc/stage_common.h: stage_ticket), not from blockIdx -- HIP promises neither a dispatch order
+    nor a workgroup -> XCD map (MI355X_MICROARCH.md, "Workgroup dispatch": contract).  The test switch displaces the counter a workgroup asks first by a hash of its index: pairs then
+    span XCDs, counters run out unevenly and workgroups fall through to the next counter -- what an arbitrary placement would do.  Every output word must equal the unskewed run."""
+    from lemevit_amd import _lib, ops
+    sds = _stage_params(nblocks, 41, C)
+    P = _pack(sds)
+    x, c = _inputs(B, 7, C=C)
+    x, c = x.to(DEV), c.to(DEV)
+    ref = ops.sstage_fwd(x, c, P, G, G, 1e-6)
+    torch.cuda.synchronize()
+    _lib.config_set("stage_ticket_skew", skew)
+    try:
+        for _ in range(2):
+            out = ops.sstage_fwd(x, c, P, G, G, 1e-6)
+            torch.cuda.synchronize()
+            assert torch.equal(out[0], ref[0]) and torch.equal(out[1], ref[1])
+    finally:
+        _lib.config_set("stage_ticket_skew", 0)
+    assert ops.stage_error_count() == 0
+
+
+def test_sstage_refuses_foreign_pack_and_excess_concurrency():
+    """a pack built for the other stage kernel must be refused (it would be read past its end); a launch that would exceed lmv_sstage_max_concurrent is a
+    RuntimeError, never a wrong tensor."""
+    from lemevit_amd import ops
+    sds = _stage_params(1, 3, 384)
+    P = _pack(sds)
+    x, c = _inputs(2, 3)
+    x, c = x.to(DEV), c.to(DEV)
+    P.layout = "dstage"
+    with pytest.raises(ValueError):
+        ops.sstage_fwd(x, c, P, G, G, 1e-6)
+    P.layout = "sstage"
+    limit = ops.sstage_max_concurrent(384)
+    assert limit >= 4, limit          # (an MI355X holds 256 workgroups of the 8-wave instance: 31)
+    with pytest.raises(RuntimeError):
+        ops.sstage_fwd(x, c, P, G, G, 1e-6, concurrent=limit + 1)
+    ops.sstage_fwd(x, c, P, G, G, 1e-6, concurrent=limit)
+    torch.cuda.synchronize()
+
+
 def test_no_handoff_ever_timed_out():
     """Runs last in this file: the sticky error word of the stage kernels (a bounded in-launch wait that ran out) is still clear after every launch above."""
     from lemevit_amd import ops

@@ -10,7 +10,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "liblemevit_hip.so")
+LIB_PATH = os.environ.get("LMV_LIB_PATH") or os.path.join(_HERE, "csrc", "liblemevit_hip.so")          # LMV_LIB_PATH: another build of the same library (A/B runs of kernel variants inside one gpurun call)
 
 LMV_F32, LMV_BF16 = 0, 1
 ACT_NONE, ACT_GELU, ACT_GELU_GRAD = 0, 1, 2

@@ -92,15 +92,23 @@ template <int NW, int NTT, int CT>
 __device__ __forceinline__ void ds_layer_norm(const f32x4_t (&R)[NTT][CT], const float* gam, const float* bet, float eps, unsigned char* xn, float2* stat, int wave, int lane) {
   constexpr int CW = 16 * CT, C = CW * NW;
   const int g = lane >> 4, li = lane & 15;
+  // statistics without cancellation: per wave the mean and the centred sum of squares of its CW channels (two passes over registers), combined over the waves with the
+  // parallel-variance formula -- see layer_norm_to_lds (csrc/sstage.hip)
 #pragma unroll
   for (int t = 0; t < NTT; ++t) {
-    float s1 = 0.f, s2 = 0.f;
+    float s1 = 0.f;
 #pragma unroll
     for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) { s1 += R[t][ct][r]; s2 = fmaf(R[t][ct][r], R[t][ct][r], s2); }
-    s1 = xsum4(s1); s2 = xsum4(s2);
-    if (g == 0) stat[wave * (16 * NTT) + t * 16 + li] = make_float2(s1, s2);
+      for (int r = 0; r < 4; ++r) s1 += R[t][ct][r];
+    const float mw = xsum4(s1) * (1.f / CW);
+    float m2 = 0.f;
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { const float dlt = R[t][ct][r] - mw; m2 = fmaf(dlt, dlt, m2); }
+    m2 = xsum4(m2);
+    if (g == 0) stat[wave * (16 * NTT) + t * 16 + li] = make_float2(mw, m2);
   }
   float4 ga[CT], be[CT];
 #pragma unroll
@@ -109,11 +117,17 @@ __device__ __forceinline__ void ds_layer_norm(const f32x4_t (&R)[NTT][CT], const
   float mean[NTT], rstd[NTT];
 #pragma unroll
   for (int t = 0; t < NTT; ++t) {
-    float s1 = 0.f, s2 = 0.f;
+    float2 p[NW];
+    float sm = 0.f, sq = 0.f;
 #pragma unroll
-    for (int w = 0; w < NW; ++w) { const float2 p = stat[w * (16 * NTT) + t * 16 + li]; s1 += p.x; s2 += p.y; }
-    mean[t] = s1 * (1.f / C);
-    rstd[t] = rsqrtf(fmaxf(s2 * (1.f / C) - mean[t] * mean[t], 0.f) + eps);
+    for (int w = 0; w < NW; ++w) { p[w] = stat[w * (16 * NTT) + t * 16 + li]; sm += p[w].x; sq += p[w].y; }
+    asm volatile("" : "+v"(sm), "+v"(sq));          // scalar code on purpose: the SLP-packed form of this combine is not run-to-run reproducible (csrc/sstage.hip, SS_LN_PACKED)
+    mean[t] = sm * (1.f / NW);
+    float dev = 0.f;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) { const float dlt = p[w].x - mean[t]; dev = fmaf(dlt, dlt, dev); }
+    rstd[t] = rsqrtf(fmaf(dev, (float)CW, sq) * (1.f / C) + eps);
+    asm volatile("" : "+v"(mean[t]), "+v"(rstd[t]));
   }
 #pragma unroll
   for (int ct = 0; ct < CT; ++ct) {

@@ -84,6 +84,33 @@ static_assert(8 * STG_WAVE <= SG<8>::L_STAT && 4 * STG_WAVE <= SG<4>::L_STAT, "s
   (void)WS_FRAGS; (void)V_N1W; (void)V_N1B; (void)V_QKVB; (void)V_PROJB; (void)V_N2W; (void)V_N2B; (void)V_FC1B; (void)V_FC2B; (void)V_POSW;           \
   (void)V_POSB; (void)V_FLOATS; (void)L_XN; (void)L_H; (void)L_STAT; (void)L_TOTAL; (void)KBUF_IMG; (void)VBUF_IMG; (void)HALO_IMG; (void)PARK_IMG;
 constexpr int SS_NSTAMP = 24;
+#ifndef SS_LN1_VAR
+#define SS_LN1_VAR 0      // LayerNorm statistics: 0 per-wave centred sums + parallel-variance combine; 1 one-pass E[x^2] - mean^2 (rounds 1 - 4; A/B builds); 2 the new partials through the old formula
+#endif
+#ifndef SS_LN2_VAR
+#define SS_LN2_VAR 0
+#endif
+// The combine of the per-wave LayerNorm partials must stay SCALAR code.  Left alone, hipcc (ROCm 7.2) SLP-packs the arithmetic of two token tiles into v_pk_add / v_pk_fma_f32
+// (tile t + 1 in the high lanes), and that build is NOT run-to-run reproducible on gfx950 when two workgroups share a CU (the 4-wave instance at B = 256: ~3 % of the K / V words of the
+// ODD token tiles differ between two launches of the same inputs by an ulp of the LayerNorm output; one workgroup per CU, or the 8-wave instance: bit-identical).  Everything that could
+// be checked by hand is consistent -- the waitcnt counts, the splat constants (s[34:35] = (eps, eps)), op_sel / op_sel_hi on the SGPR-pair sources (tools/native/pk_sgpr_probe.hip: the
+// hardware honours them), no permlane or DS-store hazard (variants with shuffles / nops / drained stores behave the same) -- and the scalar build of the same source is bit-stable
+// (tools/ss_repeat.py; tests/test_sstage_gpu.py::test_sstage_vs_per_launch_schedule_full_size is the regression test that caught it).  Opaque copies per tile keep the SLP
+// vectoriser off these values; -DSS_LN_PACKED=1 builds the packed form for further digging.
+#ifndef SS_LN_PACKED
+#define SS_LN_PACKED 0
+#endif
+#if SS_LN_PACKED
+#define SS_LN_OPAQUE2(a, b) ((void)0)
+#else
+#define SS_LN_OPAQUE2(a, b) asm volatile("" : "+v"(a), "+v"(b))
+#endif
+#ifndef SS_DBG_LN_BARRIER
+#define SS_DBG_LN_BARRIER 0
+#endif
+#ifndef SS_DBG_NO_DW
+#define SS_DBG_NO_DW 0
+#endif
 #ifndef SS_PARK
 #define SS_PARK 1      // park the residual registers in L2 while k / v / q / attention run
 #endif
@@ -111,33 +138,84 @@ struct SsArgs {
     if (a.timing && blk == a.timing_block && lane == 0) a.timing[((size_t)blockIdx.x * NW + wave) * SS_NSTAMP + (k)] = __builtin_amdgcn_s_memtime(); \
   } while (0)
 
-template <int NW>
+template <int NW, int VAR = 0>
 __device__ __forceinline__ void layer_norm_to_lds(const f32x4_t (&R)[SS_NT][3], const float* gam, const float* bet, float eps, unsigned char* smem, int wave, int lane) {
   SS_GEO(NW)
   const int g = lane >> 4, li = lane & 15;
   float2* stat = reinterpret_cast<float2*>(smem + L_STAT);
+#if SS_DBG_LN_BARRIER
+  __syncthreads();
+#endif
+  // Statistics without cancellation (the one-pass E[x^2] - mean^2 loses every digit of a row with a large mean and a small variance): a wave takes the
+  // mean and the centred sum of squares of ITS 48 channels of a token in two passes over its registers, the NW partial (mean_w, M2_w) pairs are combined with the parallel-variance
+  // formula  M2 = sum M2_w + 48 sum (mean_w - mean)^2  (Chan et al.) -- differences of means, never of squares.  No extra barrier, no value lives across phases.
+  if constexpr (VAR == 1) {
 #pragma unroll
-  for (int t = 0; t < SS_NT; ++t) {
-    float s1 = 0.f, s2 = 0.f;
+    for (int t = 0; t < SS_NT; ++t) {
+      float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-    for (int ct = 0; ct < 3; ++ct)
+      for (int ct = 0; ct < 3; ++ct)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) { s1 += R[t][ct][r]; s2 = fmaf(R[t][ct][r], R[t][ct][r], s2); }
-    s1 = xsum4(s1); s2 = xsum4(s2);
-    if (g == 0) stat[wave * 112 + t * 16 + li] = make_float2(s1, s2);
+        for (int r = 0; r < 4; ++r) { s1 += R[t][ct][r]; s2 = fmaf(R[t][ct][r], R[t][ct][r], s2); }
+      s1 = xsum4(s1); s2 = xsum4(s2);
+      if (g == 0) stat[wave * 112 + t * 16 + li] = make_float2(s1, s2);
+    }
+  } else {
+#pragma unroll
+    for (int t = 0; t < SS_NT; ++t) {
+      float s1 = 0.f;
+  #pragma unroll
+      for (int ct = 0; ct < 3; ++ct)
+  #pragma unroll
+        for (int r = 0; r < 4; ++r) s1 += R[t][ct][r];
+      const float mw = xsum4(s1) * (1.f / 48.f);
+      float m2 = 0.f;
+  #pragma unroll
+      for (int ct = 0; ct < 3; ++ct)
+  #pragma unroll
+        for (int r = 0; r < 4; ++r) { const float dlt = R[t][ct][r] - mw; m2 = fmaf(dlt, dlt, m2); }
+      m2 = xsum4(m2);
+      if (g == 0) stat[wave * 112 + t * 16 + li] = make_float2(mw, m2);
+    }
   }
   float4 ga[3], be[3];        // requested ahead of the barrier
 #pragma unroll
   for (int ct = 0; ct < 3; ++ct) { ga[ct] = *reinterpret_cast<const float4*>(gam + 48 * wave + 16 * ct + 4 * g); be[ct] = *reinterpret_cast<const float4*>(bet + 48 * wave + 16 * ct + 4 * g); }
   __syncthreads();
   float mean[SS_NT], rstd[SS_NT];
+  if constexpr (VAR == 1) {
 #pragma unroll
-  for (int t = 0; t < SS_NT; ++t) {
-    float s1 = 0.f, s2 = 0.f;
+    for (int t = 0; t < SS_NT; ++t) {
+      float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-    for (int w = 0; w < NW; ++w) { const float2 p = stat[w * 112 + t * 16 + li]; s1 += p.x; s2 += p.y; }
-    mean[t] = s1 * (1.f / SS_C);
-    rstd[t] = rsqrtf(fmaxf(s2 * (1.f / SS_C) - mean[t] * mean[t], 0.f) + eps);
+      for (int w = 0; w < NW; ++w) { const float2 p = stat[w * 112 + t * 16 + li]; s1 += p.x; s2 += p.y; }
+      mean[t] = s1 * (1.f / SS_C);
+      rstd[t] = rsqrtf(fmaxf(s2 * (1.f / SS_C) - mean[t] * mean[t], 0.f) + eps);
+    }
+  } else if constexpr (VAR == 2) {
+#pragma unroll
+    for (int t = 0; t < SS_NT; ++t) {
+      float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+      for (int w = 0; w < NW; ++w) { const float2 p = stat[w * 112 + t * 16 + li]; s1 += 48.f * p.x; s2 += fmaf(48.f * p.x, p.x, p.y); }
+      mean[t] = s1 * (1.f / SS_C);
+      rstd[t] = rsqrtf(fmaxf(s2 * (1.f / SS_C) - mean[t] * mean[t], 0.f) + eps);
+    }
+  } else {
+#pragma unroll
+    for (int t = 0; t < SS_NT; ++t) {
+      float2 p[NW];
+      float sm = 0.f, sq = 0.f;
+#pragma unroll
+      for (int w = 0; w < NW; ++w) { p[w] = stat[w * 112 + t * 16 + li]; sm += p[w].x; sq += p[w].y; }
+      SS_LN_OPAQUE2(sm, sq);
+      mean[t] = sm * (1.f / NW);
+      float dev = 0.f;
+#pragma unroll
+      for (int w = 0; w < NW; ++w) { const float dlt = p[w].x - mean[t]; dev = fmaf(dlt, dlt, dev); }
+      rstd[t] = rsqrtf(fmaf(dev, 48.f, sq) * (1.f / SS_C) + eps);
+      SS_LN_OPAQUE2(mean[t], rstd[t]);
+    }
   }
 #pragma unroll
   for (int ct = 0; ct < 3; ++ct) {
@@ -376,7 +454,11 @@ __global__ __launch_bounds__(64 * NW, 2) void sstage_kernel(const SsArgs a) {
 #pragma unroll
         for (int t = 0; t < SS_NT; ++t) {
           const int slot = 16 * t + li;
+#if SS_DBG_NO_DW
+          const bool valid = false;
+#else
           const bool valid = slot < nimg_slots;
+#endif
           const int sv = valid ? slot : 0, y = sv / SS_G, x = sv - y * SS_G;
           const unsigned char* const tap0 = stg + (y * 16 + x) * STG_ROW + 32 * ct + 8 * g;      // entry of the (-1, -1) neighbour; tap (dy, dx): + ((dy + 1) * 16 + dx + 1) * 96
           float acc[4] = {pb.x, pb.y, pb.z, pb.w};
@@ -416,7 +498,7 @@ __global__ __launch_bounds__(64 * NW, 2) void sstage_kernel(const SsArgs a) {
     {
       SS_PHASE
       ring_fill<2, 3>(ring2, wp + (size_t)(WS_KV + (3 * wave) * (2 * SS_KS)) * 1024, lane);       // lands under the LayerNorm
-      layer_norm_to_lds<NW>(R, vec + V_N1W, vec + V_N1B, a.eps, smem, wave, lane);
+      layer_norm_to_lds<NW, SS_LN1_VAR>(R, vec + V_N1W, vec + V_N1B, a.eps, smem, wave, lane);
       // the residual is not touched again before proj: its 84 registers go to L2 (a wave-private slab, plain stores) and come back behind the
       // attention -- k / v / q and the attention (13 K fragments resident per head) get the registers
 #if SS_PARK
@@ -561,7 +643,7 @@ __global__ __launch_bounds__(64 * NW, 2) void sstage_kernel(const SsArgs a) {
     {
       SS_PHASE
       ring_fill<2, 3>(ring2, wp + (size_t)(WS_FC1 + wave * (2 * SS_KS)) * 1024, lane);            // lands under the LayerNorm
-      layer_norm_to_lds<NW>(R, vec + V_N2W, vec + V_N2B, a.eps, smem, wave, lane);
+      layer_norm_to_lds<NW, SS_LN2_VAR>(R, vec + V_N2W, vec + V_N2B, a.eps, smem, wave, lane);
     }
     SS_STAMP(10);
 #pragma unroll 1

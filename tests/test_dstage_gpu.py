@@ -66,7 +66,7 @@ def _rel(a, ref):
 @pytest.mark.parametrize("C,G", [(192, 28), (96, 56), (128, 28), (64, 56), (192, 48), (96, 96), (128, 48), (64, 96)])          # stages 2 / 1 of LeMeViT-Base (4 / 2 waves x 48 channels), of LeMeViT-Tiny (x 32 channels), of Base at 384 x 384 (96-token workgroups)
 @pytest.mark.parametrize("nblocks,B", [(1, 1), (1, 3), (2, 2), (4, 9), (2, 70)])
 def test_dstage_vs_oracle(nblocks, B, C, G):
-    """Full tensors against the float64 oracle: 1e-2 of max-abs per tensor (bf16 operands at every contraction, fp16 P / V, the GELU polynomial, the
+    """Full tensors against the float64 oracle: 6e-3 of max-abs per tensor (round 5; measured 2.7 - 5.0e-3) (bf16 operands at every contraction, fp16 P / V, the GELU polynomial, the
     meta queries folded through the k projection in bf16); the residual stream stays fp32 between the blocks.  B = 70: more images than the 64 / 32 slots of a launch
     (the second round of a slot reuses its exchange buffers and flags)."""
     from lemevit_amd import ops
@@ -80,7 +80,7 @@ def test_dstage_vs_oracle(nblocks, B, C, G):
     xr, cr = _oracle(sds, x[idx].float(), c[idx].float(), G)
     ex, ec = _rel(xo[idx].float(), xr), _rel(co[idx].float(), cr)
     print(f"dstage C={C} nblocks={nblocks} B={B}: x {ex:.2e} c {ec:.2e}")
-    assert ex <= 1e-2 and ec <= 1e-2, (ex, ec)
+    assert ex <= 6e-3 and ec <= 6e-3, (ex, ec)
 
 
 @pytest.mark.parametrize("C,G", [(192, 28), (96, 56), (128, 28), (64, 56)])
@@ -94,7 +94,7 @@ def test_dstage_large_residual_stream(C, G):
     torch.cuda.synchronize()
     xr, cr = _oracle(sds, x.float(), c.float(), G)
     ex, ec = _rel(xo.float(), xr), _rel(co.float(), cr)
-    assert ex <= 1e-2 and ec <= 1e-2, (ex, ec)
+    assert ex <= 6e-3 and ec <= 6e-3, (ex, ec)
 
 
 @pytest.mark.parametrize("C,G,nblocks,B", [(192, 28, 4, 128), (96, 56, 4, 128), (128, 28, 2, 256), (64, 56, 2, 256), (192, 48, 4, 64), (96, 96, 4, 64)])
@@ -263,7 +263,7 @@ def test_cstage_vs_oracle(nblocks, B, C, G):
         xr, cr = O.leme_block({k: v.double() for k, v in sd.items()}, "blk.", "C", xr, cr, G, G, C // 32)
     ec = _rel(co[idx].float(), cr)
     print(f"cstage C={C} nblocks={nblocks} B={B}: c {ec:.2e}")
-    assert ec <= 1e-2, ec
+    assert ec <= 6e-3, ec
     co2 = ops.dstage_fwd(xd, c.to(DEV), P, G, G, 1e-6, kind=1)[1]
     assert torch.equal(co, co2)
 
@@ -315,7 +315,7 @@ def test_s2stage_vs_oracle(nblocks, B, C):
         xr, cr = O.leme_block({k: v.double() for k, v in sd.items()}, "blk.", "S", xr, cr, G, G, C // 32)
     ex, ec = _rel(xo[idx].float(), xr), _rel(co[idx].float(), cr)
     print(f"s2stage C={C} nblocks={nblocks} B={B}: x {ex:.2e} c {ec:.2e}")
-    assert ex <= 1e-2 and ec <= 1e-2, (ex, ec)
+    assert ex <= 6e-3 and ec <= 6e-3, (ex, ec)
 
 
 def test_s2stage_full_size_and_under_load():
@@ -389,7 +389,7 @@ def test_d2stage_vs_oracle(C, G):
         xr, cr = O.leme_block({k: v.double() for k, v in sd.items()}, "blk.", "D2", xr, cr, G, G, C // 32)
     ex, ec = _rel(xo.float(), xr), _rel(co.float(), cr)
     print(f"d2stage C={C}: x {ex:.2e} c {ec:.2e}")
-    assert ex <= 1e-2 and ec <= 1e-2, (ex, ec)
+    assert ex <= 6e-3 and ec <= 6e-3, (ex, ec)
 
 
 def test_no_handoff_ever_timed_out():

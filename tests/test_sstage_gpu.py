@@ -67,7 +67,7 @@ def _rel(a, ref):
 @pytest.mark.parametrize("C", [384, 192])          # stage 3 of LeMeViT-Base (8 waves per workgroup) / LeMeViT-Tiny (4 waves, two workgroups per CU)
 @pytest.mark.parametrize("nblocks,B", [(1, 1), (1, 3), (2, 2), (3, 9)])
 def test_sstage_vs_oracle(nblocks, B, C):
-    """Full tensors against the float64 oracle.  One block: 1e-2 of max-abs (bf16 operands at five contractions, fp16 P / V, the GELU
+    """Full tensors against the float64 oracle.  One block: 6e-3 of max-abs (round 5; measured 2.5 - 5.0e-3; the shares: tests/test_parity_budget_gpu.py) (bf16 operands at five contractions, fp16 P / V, the GELU
     polynomial; the per-launch bf16 schedule is held to 2e-2 by tests/test_model_gpu.py::test_block_forward); the residual stream stays
     fp32 between blocks here, so the bound does not grow with the depth the way a bf16 stream's does."""
     from lemevit_amd import ops
@@ -79,7 +79,7 @@ def test_sstage_vs_oracle(nblocks, B, C):
     xr, cr = _oracle(sds, x.float(), c.float())
     ex, ec = _rel(xo.float(), xr), _rel(co.float(), cr)
     print(f"sstage C={C} nblocks={nblocks} B={B}: x {ex:.2e} c {ec:.2e}")
-    assert ex <= 1e-2 and ec <= 1e-2, (ex, ec)
+    assert ex <= 6e-3 and ec <= 6e-3, (ex, ec)
 
 
 @pytest.mark.parametrize("C", [384, 192])
@@ -94,7 +94,7 @@ def test_sstage_large_residual_stream(C):
     torch.cuda.synchronize()
     xr, cr = _oracle(sds, x.float(), c.float())
     ex, ec = _rel(xo.float(), xr), _rel(co.float(), cr)
-    assert ex <= 1e-2 and ec <= 1e-2, (ex, ec)
+    assert ex <= 6e-3 and ec <= 6e-3, (ex, ec)
 
 
 @pytest.mark.parametrize("C,nblocks,B", [(384, 18, 128), (192, 8, 256), (192, 8, 300)])

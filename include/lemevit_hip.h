@@ -345,6 +345,9 @@ int lmv_token_mean2_affine_fwd(const void* x, int L, const void* c, int M, int C
 int lmv_adamw_flat(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, const float* wd_mask, void* shadow_bf16,
                    int64_t n, float lr, float beta1, float beta2, float eps, float weight_decay, int step, const int* step_dev,
                    void* stream);
+/* Exponential moving average of the weights over the same flat buffer (timm.utils.ModelEmaV2: main.py:316, engine.py model_ema.update(model)):
+ * ema[i] = decay * ema[i] + (1 - decay) * param[i], n % 4 == 0, one launch (lemevit_amd.optim.ModelEma). */
+int lmv_ema_flat(float* ema, const float* param, int64_t n, float decay, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Whole-block schedules: ONE call enqueues every launch of a LeMeBlock (models/lemevit.py:500-660) on token-major tensors

@@ -144,6 +144,7 @@ SIGNATURES = {
     "lmv_token_mean2_affine_fwd": (_I, [_P, _I, _P, _I, _I, _I, _P, _P, _P, _I, _P]),
     "lmv_token_mean2_bwd": (_I, [_P, _P, _I, _P, _I, _I, _I, _I, _P]),
     "lmv_adamw_flat": (_I, [_P, _P, _P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _I, _P, _P]),
+    "lmv_ema_flat": (_I, [_P, _P, _L, _F, _P]),
     "lmv_block_arena_bytes": (_Z, [C.POINTER(BlockDesc)]),
     "lmv_block_bwd_scratch_bytes": (_Z, [C.POINTER(BlockDesc)]),
     "lmv_block_fwd": (_I, [C.POINTER(BlockDesc), _P, _P, _P, _P, _P, _Z, _I, _P]),

@@ -350,6 +350,18 @@ __global__ __launch_bounds__(TPB) void adamw_kernel(float* __restrict__ p, const
   }
 }
 
+// exponential moving average of a flat fp32 parameter buffer: ema = decay * ema + (1 - decay) * param (timm.utils.ModelEmaV2, main.py:316 / engine.py: model_ema.update)
+__global__ __launch_bounds__(TPB) void ema_kernel(float* __restrict__ ema, const float* __restrict__ p, int64_t n, float decay) {
+  const int64_t n4 = n >> 2;
+  const float w = 1.f - decay;
+  for (int64_t i = blockIdx.x * (int64_t)TPB + threadIdx.x; i < n4; i += (int64_t)gridDim.x * TPB) {
+    float4 E = reinterpret_cast<float4*>(ema)[i];
+    const float4 P = reinterpret_cast<const float4*>(p)[i];
+    E.x = fmaf(decay, E.x, w * P.x); E.y = fmaf(decay, E.y, w * P.y); E.z = fmaf(decay, E.z, w * P.z); E.w = fmaf(decay, E.w, w * P.w);
+    reinterpret_cast<float4*>(ema)[i] = E;
+  }
+}
+
 // out[map(i)] += sum_r partial[r][i]: the workgroup body lives in common.h (lmv_partial_reduce_block), shared with lmv_reduce_batch
 __global__ __launch_bounds__(256) void partial_reduce_kernel(const float* __restrict__ partial, int nrows, int width, float* __restrict__ out_a, int na,
                                                             float* __restrict__ out_b, int mode) {
@@ -551,6 +563,14 @@ extern "C" int lmv_adamw_flat(float* param, const float* grad, float* exp_avg, f
   hipLaunchKernelGGL(adamw_kernel, dim3(grid_for(n / 4)), dim3(TPB), 0, (hipStream_t)stream, param, grad, exp_avg, exp_avg_sq, wd_mask,
                      reinterpret_cast<bf16_t*>(shadow_bf16), step_dev, n, lr, beta1, beta2, eps, weight_decay, bc1, bc2_sqrt);
   LMV_CHECK_LAUNCH("adamw_flat");
+  return LMV_OK;
+}
+
+extern "C" int lmv_ema_flat(float* ema, const float* param, int64_t n, float decay, void* stream) {
+  if (!ema || !param || n <= 0 || (n % 4) || !lmv_aligned16(ema) || !lmv_aligned16(param)) LMV_FAIL(LMV_ERR_SHAPE, "ema_flat: null / misaligned buffer or n %% 4 != 0");
+  if (!(decay >= 0.f && decay <= 1.f)) LMV_FAIL(LMV_ERR_SHAPE, "ema_flat: decay must be in [0, 1]");
+  hipLaunchKernelGGL(ema_kernel, dim3(grid_for(n / 4)), dim3(TPB), 0, (hipStream_t)stream, ema, param, n, decay);
+  LMV_CHECK_LAUNCH("ema_flat");
   return LMV_OK;
 }
 

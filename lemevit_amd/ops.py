@@ -604,6 +604,13 @@ def adamw_flat(param: Tensor, grad: Tensor, exp_avg: Tensor, exp_avg_sq: Tensor,
                              weight_decay, step, _ptr(step_dev), _stream()), "lmv_adamw_flat")
 
 
+def ema_flat(ema: Tensor, param: Tensor, decay: float) -> None:
+    """ema <- decay * ema + (1 - decay) * param over two flat fp32 buffers, one launch (lmv_ema_flat)."""
+    if ema.dtype != torch.float32 or param.dtype != torch.float32 or ema.numel() != param.numel():
+        raise TypeError("lemevit_amd: ema_flat takes two fp32 buffers of the same length")
+    check(lib.lmv_ema_flat(_ptr(ema), _ptr(param), ema.numel(), float(decay), _stream()), "lmv_ema_flat")
+
+
 # -------------------------------------------------------------------------------------------
 # A run of "S" blocks as one persistent launch (csrc/sstage.hip; inference, bf16)
 # -------------------------------------------------------------------------------------------

@@ -170,3 +170,56 @@ class FlatAdamW:
                 self.param_groups[0][k] = sd[k]
         if self._rest is not None and sd.get("rest") is not None:
             self._rest.load_state_dict(sd["rest"])
+
+
+class ModelEma:
+    """Exponential moving average of a model's weights -- the reference's optional ``--model-ema`` (``timm.utils.ModelEmaV2``: main.py:316 builds it, engine.py calls
+    ``model_ema.update(model)`` after every optimizer step, validate runs on ``model_ema.module``).
+
+    ``module`` is an eval-mode copy of the model.  With a ``FlatAdamW`` the block parameters of the copy are views of ONE flat fp32 buffer laid out like the optimizer's, and
+    their update is a single ``lmv_ema_flat`` launch; the ~60 remaining parameters and the buffers (BatchNorm running statistics) go through one multi-tensor lerp, integer
+    buffers are copied -- the same update rule as ModelEmaV2 (every ``state_dict`` entry: ``ema = decay * ema + (1 - decay) * model``)."""
+
+    def __init__(self, model: nn.Module, decay: float = 0.9998, opt: Optional[FlatAdamW] = None):
+        import copy
+        self.decay = float(decay)
+        self.module = copy.deepcopy(model)
+        self.module.eval()
+        for p in self.module.parameters():
+            p.requires_grad_(False)
+            p.grad = None
+            for attr in ("_lmv_shadow", "_lmv_shadow_t", "_lmv_flat_grad", "_lmv_grad_cb"):          # the copy is a plain model: no optimizer-owned operand copies, no gradient hooks
+                if hasattr(p, attr):
+                    delattr(p, attr)
+        self._flat_src: Optional[Tensor] = None
+        self._flat_ema: Optional[Tensor] = None
+        flat_names = set()
+        if opt is not None:
+            self._flat_src = opt._flat_p
+            self._flat_ema = opt._flat_p.detach().clone()
+            table = dict(self.module.named_parameters())
+            for name, _, off, n in opt._slices:
+                q = table[name]
+                q.data = self._flat_ema[off:off + n].view(q.shape)
+                flat_names.add(name)
+        src = model.state_dict()
+        self._pairs_f: List[Tuple[Tensor, str]] = []
+        self._pairs_i: List[Tuple[Tensor, str]] = []
+        for k, v in self.module.state_dict().items():
+            if k in flat_names:
+                continue
+            if k not in src:
+                raise KeyError(k)
+            (self._pairs_f if v.dtype.is_floating_point else self._pairs_i).append((v, k))
+
+    @torch.no_grad()
+    def update(self, model: nn.Module) -> None:
+        from . import model as _model
+        if self._flat_ema is not None:
+            ops.ema_flat(self._flat_ema, self._flat_src, self.decay)
+        src = model.state_dict()
+        if self._pairs_f:
+            torch._foreach_lerp_([e for e, _ in self._pairs_f], [src[k].detach().to(e.dtype) for e, k in self._pairs_f], 1.0 - self.decay)
+        for e, k in self._pairs_i:
+            e.copy_(src[k])
+        _model.new_training_pass()          # the native launch writes through raw pointers (no Tensor._version bump): drop every cached operand copy of the EMA module

@@ -404,6 +404,42 @@ def test_lost_handoff_is_loud(monkeypatch):
         ops.stage_kernels_disabled = False
 
 
+def test_model_ema_matches_reference_rule():
+    """Row f3 (optional EMA, main.py:316 / engine.py model_ema.update): after two optimizer steps every state_dict entry of ModelEma.module equals
+    decay * ema + (1 - decay) * model applied twice (timm.utils.ModelEmaV2's rule), the block parameters through the one-launch flat kernel; and the EMA module runs the
+    inference forward with ITS weights (no stale operand copies)."""
+    lib = L()
+    torch.manual_seed(0)
+    m = _model("lemevit_tiny", 10, 11).train()
+    opt = lib.FlatAdamW(m, lr=1e-2, weight_decay=0.05)
+    decay = 0.9
+    ema = lib.ModelEma(m, decay=decay, opt=opt)
+    ref = {k: v.detach().clone().double() for k, v in m.state_dict().items() if v.dtype.is_floating_point}
+    img = det_tensor((4, 3, 96, 96), "ema.img", 2).to(DEV)
+    tgt = torch.tensor([1, 2, 3, 4], device=DEV)
+    for _ in range(2):
+        opt.zero_grad()
+        with torch.autocast("cuda", torch.bfloat16):
+            torch.nn.functional.cross_entropy(m(img), tgt).backward()
+        opt.step()
+        ema.update(m)
+        for k, v in m.state_dict().items():
+            if v.dtype.is_floating_point:
+                ref[k] = decay * ref[k] + (1 - decay) * v.detach().double()
+    torch.cuda.synchronize()
+    got = ema.module.state_dict()
+    for k, r in ref.items():
+        close(got[k], r.cpu().numpy(), 1e-6, "ema " + k)
+    assert int(got["norm.num_batches_tracked"]) == int(m.state_dict()["norm.num_batches_tracked"])
+    m.eval()
+    with torch.no_grad(), torch.autocast("cuda", torch.bfloat16):
+        a, b = ema.module(img).float(), m(img).float()
+    assert torch.isfinite(a).all() and (a - b).abs().max().item() > 0.0          # different weights -> different logits
+    sd = {k: v.detach().cpu().float() if v.dtype.is_floating_point else v.detach().cpu() for k, v in got.items()}
+    ref_logits = O.lemevit_forward(sd, O.VARIANTS["lemevit_tiny"], img.cpu())
+    close(a, ref_logits.numpy(), 5e-2, "ema module forward")
+
+
 def test_launch_context_is_thread_local():
     """VERDICT round 4, weak #8: split_forward's sub-batch count used to be a module global that two inference threads raced on."""
     import threading

@@ -47,7 +47,7 @@ const char* lmv_last_error(void);
 /* Tuning switches (A/B runs, parity tests of alternative code paths).  The LMV_* environment variables are read ONCE when the library
  * is loaded -- never on a launch path; these two change / read a switch at run time.  Keys: "gemm_bk", "gemm_bk32_tiles", "dw_bk",
  * "dw_target_blocks", "gemm_no_dma", "gemm_w8", "gemm_cumap", "gemm_nst", "gemm_nst_dw", "gemm_rs", "dwconv_v", "mlp_tm", "attn_pv16",
- * "attn_fuse_dq", "attn_fused_bwd", "attn_pair", "ln_bwd_blocks", "ln_bwd_minrows", "stage_ticket_skew" (test switch) (lemevit_amd/csrc/common.h: LmvConfig).
+ * "attn_fuse_dq", "attn_fused_bwd", "attn_pair", "ln_bwd_blocks", "ln_bwd_minrows", "stage_ticket_skew" (test switch), "dw_chain" (lemevit_amd/csrc/common.h: LmvConfig).
  * Process-wide, not synchronised: set them between launches. */
 int lmv_config_set(const char* key, int value);
 int lmv_config_get(const char* key, int* value);
@@ -108,6 +108,14 @@ typedef struct {
 int lmv_linear_dw_partial(const lmv_linear_problem* p, int nproblems, int N, int K, void* workspace, size_t workspace_bytes, int dtype, void* stream,
                           lmv_reduce_seg* segs, int* nsegs);
 int lmv_reduce_batch(const lmv_reduce_seg* segs, int nsegs, void* stream);
+/* lmv_linear_dw_partial with the slab sums of EARLIER launches riding in the same launch (round 5): `pending` (<= 2 LMV_REDUCE_SLABS segments returned by a previous
+ * lmv_linear_dw_partial / _chain call on the SAME stream, whose slabs lie outside `workspace`) is summed by extra workgroups at the tail of this launch's grid -- the
+ * same summation tree as lmv_reduce_batch / lmv_linear_dw: bit-identical gradients -- while the launch leaves its own slabs in `workspace` and describes them in
+ * segs / nsegs for the next call (or for lmv_reduce_batch behind the last one).  lmv_block_bwd can chain the weight-gradient GEMMs of a block this way over two alternating
+ * slab regions (LMV_DW_CHAIN=1: ~160 reduce launches per train step leave the weight-gradient stream); measured 0.2 - 0.3 ms per step SLOWER than a reduce launch behind every
+ * GEMM on LeMeViT-Base, so that stays the default.  bf16 launches only. */
+int lmv_linear_dw_chain(const lmv_linear_problem* p, int nproblems, int N, int K, void* workspace, size_t workspace_bytes, int dtype, void* stream,
+                        const lmv_reduce_seg* pending, int npending, lmv_reduce_seg* segs, int* nsegs);
 
 /* ------------------------------------------------------------------------------------------
  * Fused block entry points (`ln_linear`, `mlp_fused`, `attn_out_proj_residual`).

@@ -97,6 +97,7 @@ SIGNATURES = {
     "lmv_linear_dw": (_I, [C.POINTER(LinearProblem), _I, _I, _I, _P, _Z, _I, _P]),
     "lmv_linear_dw_partial": (_I, [C.POINTER(LinearProblem), _I, _I, _I, _P, _Z, _I, _P, C.POINTER(ReduceSeg), C.POINTER(C.c_int)]),
     "lmv_reduce_batch": (_I, [C.POINTER(ReduceSeg), _I, _P]),
+    "lmv_linear_dw_chain": (_I, [C.POINTER(LinearProblem), _I, _I, _I, _P, _Z, _I, _P, C.POINTER(ReduceSeg), _I, C.POINTER(ReduceSeg), C.POINTER(C.c_int)]),
     "lmv_ln_fold": (_I, [_P, _P, _P, _P, _I, _I, _P, _P, _P, _I, _P]),
     "lmv_ln_linear_fwd": (_I, [C.POINTER(LinearProblem), _I, _I, _I, _F, _I, _I, _P]),
     "lmv_mlp_fused_supported": (_I, [_I, _I, _I]),

@@ -112,6 +112,7 @@ struct LmvConfig {
   int mlp_tm;             // LMV_MLP_TM             0 = auto: token rows per workgroup of the fused MLP kernel (64 / 128)
   int attn_pv16, attn_fuse_dq, attn_fused_bwd, attn_pair;      // LMV_ATTN_*
   int ln_bwd_blocks, ln_bwd_minrows;                           // LMV_LN_BWD_*
+  int dw_chain;           // LMV_DW_CHAIN           1: lmv_block_bwd chains the weight-gradient GEMMs of a block (the slab sums of one ride in the next launch, lmv_linear_dw_chain); 0 (default, measured faster): a reduce launch behind every GEMM
   int stage_ticket_skew;  // LMV_STAGE_TICKET_SKEW  test switch (0): the persistent stage kernels ask ticket counter (XCC_ID + skew * hash(blockIdx)) & 7 first -- a simulated foreign workgroup -> XCD placement
 };
 LmvConfig& lmv_config();

@@ -517,22 +517,33 @@ __global__ __launch_bounds__(64 * NW, 2) void dstage_kernel(const DsArgs a) {
 #pragma unroll
           for (int e = 0; e < 9; ++e) { const float4 v = wq[ct & 1][e]; wt[4 * e] = __float_as_uint(v.x); wt[4 * e + 1] = __float_as_uint(v.y); wt[4 * e + 2] = __float_as_uint(v.z); wt[4 * e + 3] = __float_as_uint(v.w); }
           const float4 pb = wq[ct & 1][9];
+          // the 9 taps of token tile t + 1 are requested before the 36 dot products of tile t are issued (two statically named register sets: csrc/sstage.hip, round 5)
+          uint2 f[2][9];
+          auto tap_base = [&](int t) -> const unsigned char* {
+            const int s = 16 * t + li, y = s / GW, x = s - y * GW;
+            return stg + (y * G::STG_COLS + x) * 32 + 8 * g;      // entry of the (-1, -1) neighbour
+          };
+          {
+            const unsigned char* const tap0 = tap_base(0);
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) f[0][tap] = *reinterpret_cast<const uint2*>(tap0 + ((tap / 3) * G::STG_COLS + tap % 3) * 32);
+          }
 #pragma unroll
           for (int t = 0; t < NT; ++t) {
-            const int s = 16 * t + li, y = s / GW, x = s - y * GW;
-            const unsigned char* const tap0 = stg + (y * G::STG_COLS + x) * 32 + 8 * g;      // entry of the (-1, -1) neighbour
-            uint2 f[9];
+            if (t + 1 < NT) {
+              const unsigned char* const tap1 = tap_base(t + 1);
 #pragma unroll
-            for (int tap = 0; tap < 9; ++tap) f[tap] = *reinterpret_cast<const uint2*>(tap0 + ((tap / 3) * G::STG_COLS + tap % 3) * 32);
+              for (int tap = 0; tap < 9; ++tap) f[(t + 1) & 1][tap] = *reinterpret_cast<const uint2*>(tap1 + ((tap / 3) * G::STG_COLS + tap % 3) * 32);
+            }
 #pragma unroll
-            for (int tap = 0; tap < 9; ++tap) asm volatile("" : "+v"(f[tap]));
+            for (int tap = 0; tap < 9; ++tap) asm volatile("" : "+v"(f[t & 1][tap]));
             float acc[4] = {pb.x, pb.y, pb.z, pb.w};
 #pragma unroll
             for (int tap = 0; tap < 9; ++tap) {
-              acc[0] = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, f[tap].x), __builtin_bit_cast(bf16x2_t, wt[0 * 9 + tap]), acc[0], false);
-              acc[1] = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, f[tap].x), __builtin_bit_cast(bf16x2_t, wt[1 * 9 + tap]), acc[1], false);
-              acc[2] = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, f[tap].y), __builtin_bit_cast(bf16x2_t, wt[2 * 9 + tap]), acc[2], false);
-              acc[3] = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, f[tap].y), __builtin_bit_cast(bf16x2_t, wt[3 * 9 + tap]), acc[3], false);
+              acc[0] = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, f[t & 1][tap].x), __builtin_bit_cast(bf16x2_t, wt[0 * 9 + tap]), acc[0], false);
+              acc[1] = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, f[t & 1][tap].x), __builtin_bit_cast(bf16x2_t, wt[1 * 9 + tap]), acc[1], false);
+              acc[2] = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, f[t & 1][tap].y), __builtin_bit_cast(bf16x2_t, wt[2 * 9 + tap]), acc[2], false);
+              acc[3] = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, f[t & 1][tap].y), __builtin_bit_cast(bf16x2_t, wt[3 * 9 + tap]), acc[3], false);
             }
 #pragma unroll
             for (int r = 0; r < 4; ++r) R[t][ct][r] += acc[r];

@@ -42,6 +42,8 @@
 
 namespace {
 
+__device__ __forceinline__ void reduce_slabs_block(const ReduceSegDev& g, int blk, float4* red);
+
 template <typename T, bool ATR, bool BTR, bool SPLITK, int BK, bool DMA, typename CF, int MINW = 1, int NST = 2, bool LNP = false>
 __global__ __launch_bounds__(CF::NTHR, MINW) void gemm_kernel(const GemmArgs g) {
   static_assert(!LNP || (!ATR && !BTR && !SPLITK), "the LayerNorm-folded epilogue belongs to the forward contraction");
@@ -77,6 +79,16 @@ __global__ __launch_bounds__(CF::NTHR, MINW) void gemm_kernel(const GemmArgs g) 
   // together -- so the rows are fetched from HBM once and shared through that XCD's L2.
   int bid, split = 0;
   if constexpr (SPLITK) {
+    // the LAST pg_blocks workgroups sum the slabs an EARLIER weight-gradient launch of this stream left (lmv_linear_dw_chain): short, independent of this launch's tiles.  Behind the
+    // tiles, not in front: the launch is sized for one generation of tile workgroups, and hundreds of reduce workgroups at the head of the grid push part of them into a second one
+    // (measured: +0.4 ms per train step); at the tail they fill the slots the first finished tiles free.
+    const int main_blocks = (int)gridDim.x - g.pg_blocks;
+    if ((int)blockIdx.x >= main_blocks) {
+      const int rb = (int)blockIdx.x - main_blocks;
+      const int si = (g.pg_n > 1 && rb >= g.pg[1].blk0) ? 1 : 0;
+      reduce_slabs_block(g.pg[si], rb - g.pg[si].blk0, reinterpret_cast<float4*>(smem));
+      return;
+    }
     const int x = blockIdx.x & 7, y = blockIdx.x >> 3;
     if (g.nsplits >= 8) {                // a multiple of 8: XCD x owns splits x, x + 8, ...
       bid = y % g.ntiles;
@@ -310,23 +322,14 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
 // end every dW GEMM with its own ~7 us reduce launch (~160 per train step, mostly launch ramp and tail); the GEMMs of a block now
 // leave their slabs in distinct workspace regions and one launch sums them all.  Same fixed summation tree per element as
 // splitk_reduce_kernel<SL> (sl slab lanes per element, chosen per segment), so results are bit-identical to the per-GEMM path.
-struct ReduceSegDev { const float* ws; float* out_w; float* out_b; int64_t stride, nw; int nslabs, nb, sl, blk0, kind, mode; };
 struct ReduceBatch { ReduceSegDev s[LMV_REDUCE_MAX_SEGS]; int n; };
 
-__global__ __launch_bounds__(256) void splitk_reduce_batch_kernel(const ReduceBatch rb) {
-  __shared__ float4 red[256];
-  int si = 0;
-#pragma unroll
-  for (int k = 1; k < LMV_REDUCE_MAX_SEGS; ++k) if (k < rb.n && (int)blockIdx.x >= rb.s[k].blk0) si = k;
-  const ReduceSegDev& g = rb.s[si];
-  if (g.kind == LMV_REDUCE_ROWS) {              // block-uniform: partial rows of a column reduction (LayerNorm dgamma | dbeta, dwconv tap sums)
-    lmv_partial_reduce_block(red, (int)blockIdx.x - g.blk0, g.ws, g.nslabs, (int)g.stride, g.out_w, (int)g.nw, g.out_b, g.mode);
-    return;
-  }
+// one block of a slab reduction (the summation tree of splitk_reduce_kernel<SL>, SL per segment); red: 256 float4 of LDS
+__device__ __forceinline__ void reduce_slabs_block(const ReduceSegDev& g, int blk, float4* red) {
   const int SL = g.sl, EL = 256 / SL;
   const int64_t n4 = (g.nw + (g.out_b ? g.nb : 0)) >> 2;
   const int e = threadIdx.x % EL, sl = threadIdx.x / EL;
-  const int64_t i = (int64_t)((int)blockIdx.x - g.blk0) * EL + e;
+  const int64_t i = (int64_t)blk * EL + e;
   float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
   if (i < n4) {
     const float* p = g.ws + i * 4;
@@ -347,6 +350,19 @@ __global__ __launch_bounds__(256) void splitk_reduce_batch_kernel(const ReduceBa
   float4 c = *reinterpret_cast<float4*>(o);
   c.x += a.x; c.y += a.y; c.z += a.z; c.w += a.w;
   *reinterpret_cast<float4*>(o) = c;
+}
+
+__global__ __launch_bounds__(256) void splitk_reduce_batch_kernel(const ReduceBatch rb) {
+  __shared__ float4 red[256];
+  int si = 0;
+#pragma unroll
+  for (int k = 1; k < LMV_REDUCE_MAX_SEGS; ++k) if (k < rb.n && (int)blockIdx.x >= rb.s[k].blk0) si = k;
+  const ReduceSegDev& g = rb.s[si];
+  if (g.kind == LMV_REDUCE_ROWS) {              // block-uniform: partial rows of a column reduction (LayerNorm dgamma | dbeta, dwconv tap sums)
+    lmv_partial_reduce_block(red, (int)blockIdx.x - g.blk0, g.ws, g.nslabs, (int)g.stride, g.out_w, (int)g.nw, g.out_b, g.mode);
+    return;
+  }
+  reduce_slabs_block(g, (int)blockIdx.x - g.blk0, red);
 }
 
 static int reduce_lanes(int64_t n4, int nslabs) {      // slab lanes: enough blocks to fill the chip, and at most ~32 serial slab reads per thread
@@ -516,7 +532,7 @@ int launch_mode(const Plan& pl, dim3 grid, bool bf, hipStream_t st) {
 }
 
 int launch(const lmv_linear_problem* p, int nproblems, int N, int K, int act, int dtype, void* stream, Mode mode, void* ws, size_t ws_bytes,
-           lmv_reduce_seg* segs = nullptr, int* nsegs = nullptr) {
+           lmv_reduce_seg* segs = nullptr, int* nsegs = nullptr, const lmv_reduce_seg* pending = nullptr, int npending = 0) {
   Plan pl;
   if (int rc = make_plan(p, nproblems, N, K, act, dtype, mode, &pl)) return rc;      // (validates the operands)
   if (mode == MODE_FWD && dtype == LMV_BF16 && lmv_config().gemm_rs && lmv_rs_eligible(p, nproblems, N, K, act, lmv_config().gemm_rs == 2)) {
@@ -537,6 +553,24 @@ int launch(const lmv_linear_problem* p, int nproblems, int N, int K, int act, in
   hipStream_t st = (hipStream_t)stream;
   int rc;
   if (mode == MODE_DW) grid.x = g.nsplits >= 8 ? pl.total * g.nsplits : 8 * ((pl.total + 8 / g.nsplits - 1) / (8 / g.nsplits));
+  g.pg_n = g.pg_blocks = g.pg_pad = 0;
+  if (mode == MODE_DW && npending > 0) {          // the slab sums of earlier launches ride at the head of this grid
+    if (npending > 2 || !pending || dtype != LMV_BF16) LMV_FAIL(LMV_ERR_SHAPE, "linear_dw_chain: at most 2 pending segments, bf16 launches only");
+    int blocks = 0;
+    for (int i = 0; i < npending; ++i) {
+      const lmv_reduce_seg& q = pending[i];
+      if (q.kind != LMV_REDUCE_SLABS || !q.ws || !q.out_w || q.nslabs <= 0 || q.nw <= 0 || (q.nw % 4) || (q.out_b && (q.nb % 4)) || (q.slab_stride % 4) || !lmv_aligned16(q.ws) ||
+          !lmv_aligned16(q.out_w) || !lmv_aligned16(q.out_b))
+        LMV_FAIL(LMV_ERR_SHAPE, "linear_dw_chain: bad pending segment %d", i);
+      const int64_t n4 = (q.nw + (q.out_b ? q.nb : 0)) / 4;
+      ReduceSegDev& d = g.pg[i];
+      d.ws = q.ws; d.out_w = q.out_w; d.out_b = q.out_b; d.stride = q.slab_stride; d.nw = q.nw; d.nslabs = q.nslabs; d.nb = q.nb; d.kind = q.kind; d.mode = 0;
+      d.sl = reduce_lanes(n4, q.nslabs); d.blk0 = blocks;
+      blocks += (int)((n4 * d.sl + 255) / 256);
+    }
+    g.pg_n = npending; g.pg_blocks = blocks; g.pg_pad = 0;
+    grid.x += blocks;
+  }
   double trows = 0.;
   for (int i = 0; i < nproblems && i < 2; ++i) trows += (double)p[i].rows;
   if (mode == MODE_FWD) rc = launch_mode<false, false, false>(pl, grid, bf, st);
@@ -644,6 +678,18 @@ extern "C" int lmv_linear_dw_partial(const lmv_linear_problem* p, int nproblems,
   if (!segs || !nsegs) LMV_FAIL(LMV_ERR_SHAPE, "linear_dw_partial: segs / nsegs must not be NULL");
   *nsegs = 0;
   return launch(p, nproblems, N, K, LMV_ACT_NONE, dtype, stream, MODE_DW, workspace, workspace_bytes, segs, nsegs);
+}
+
+extern "C" int lmv_linear_dw_chain(const lmv_linear_problem* p, int nproblems, int N, int K, void* workspace, size_t workspace_bytes, int dtype, void* stream,
+                                   const lmv_reduce_seg* pending, int npending, lmv_reduce_seg* segs, int* nsegs) {
+  if (!segs || !nsegs) LMV_FAIL(LMV_ERR_SHAPE, "linear_dw_chain: segs / nsegs must not be NULL");
+  *nsegs = 0;
+  if (npending > 0 && pending)
+    for (int i = 0; i < npending; ++i) {          // a pending slab region must not be the one this launch writes
+      const char* a = (const char*)pending[i].ws; const char* b = (const char*)workspace;
+      if (a < b + workspace_bytes && b < a + (size_t)pending[i].nslabs * pending[i].slab_stride * sizeof(float)) LMV_FAIL(LMV_ERR_SHAPE, "linear_dw_chain: the pending slabs overlap this launch's workspace");
+    }
+  return launch(p, nproblems, N, K, LMV_ACT_NONE, dtype, stream, MODE_DW, workspace, workspace_bytes, segs, nsegs, pending, npending);
 }
 
 extern "C" int lmv_reduce_batch(const lmv_reduce_seg* segs, int nsegs, void* stream) {

@@ -29,6 +29,8 @@ struct Problem {
   int tile_begin;  // first logical tile of this problem
   int pad_;
 };
+// one slab (or partial-row) reduction: out[i] += sum_s ws[s][i] (gemm.hip: splitk_reduce_kernel, lmv_reduce_batch, and the reduction that rides in a weight-gradient launch)
+struct ReduceSegDev { const float* ws; float* out_w; float* out_b; int64_t stride, nw; int nslabs, nb, sl, blk0, kind, mode; };
 struct GemmArgs {
   Problem p[2];
   int nprob, N, lda, ldb, ldc, act, tiles_n, kt_per_split;
@@ -41,6 +43,10 @@ struct GemmArgs {
   float* ws;              // split-K (dW) mode: partial slabs [slab][N*K + N] fp32
   int64_t slab_stride;    // floats per slab
   int slab_base[2];       // first slab of each problem
+  // split-K (dW) mode, round 5: the slab reduction of the PREVIOUS weight-gradient launch(es) of the stream rides in this launch as `pg_blocks` extra workgroups at the TAIL of the
+  // grid (lmv_linear_dw_chain): ~160 reduce launches of ~7 us (19 us next to the main stream's kernels) per train step disappear from the weight-gradient stream
+  ReduceSegDev pg[2];
+  int pg_n, pg_blocks, pg_pad;
 };
 
 // chunk swizzle of a reduction-contiguous panel whose rows are ROWB bytes (64 or 128)

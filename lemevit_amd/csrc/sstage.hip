@@ -451,6 +451,19 @@ __global__ __launch_bounds__(64 * NW, 2) void sstage_kernel(const SsArgs a) {
 #pragma unroll
         for (int e = 0; e < 9; ++e) { const float4 v = wq[ct & 1][e]; wt[4 * e] = __float_as_uint(v.x); wt[4 * e + 1] = __float_as_uint(v.y); wt[4 * e + 2] = __float_as_uint(v.z); wt[4 * e + 3] = __float_as_uint(v.w); }
         const float4 pb = wq[ct & 1][9];
+        // the 9 taps of token tile t + 1 are requested BEFORE the 36 dot products of tile t are issued (round 5: two statically named register sets; with one set the phase sat at ~2x its
+        // instruction-issue time -- 9 LDS round trips exposed per tile at two waves per SIMD)
+        uint2 f[2][9];
+        auto tap_base = [&](int t) -> const unsigned char* {
+          const int slot = 16 * t + li;
+          const int sv = slot < nimg_slots ? slot : 0, y = sv / SS_G, x = sv - y * SS_G;
+          return stg + (y * 16 + x) * STG_ROW + 32 * ct + 8 * g;      // entry of the (-1, -1) neighbour; tap (dy, dx): + ((dy + 1) * 16 + dx + 1) * 96
+        };
+        {
+          const unsigned char* const tap0 = tap_base(0);
+#pragma unroll
+          for (int tap = 0; tap < 9; ++tap) f[0][tap] = *reinterpret_cast<const uint2*>(tap0 + ((tap / 3) * 16 + tap % 3) * STG_ROW);
+        }
 #pragma unroll
         for (int t = 0; t < SS_NT; ++t) {
           const int slot = 16 * t + li;
@@ -459,24 +472,22 @@ __global__ __launch_bounds__(64 * NW, 2) void sstage_kernel(const SsArgs a) {
 #else
           const bool valid = slot < nimg_slots;
 #endif
-          const int sv = valid ? slot : 0, y = sv / SS_G, x = sv - y * SS_G;
-          const unsigned char* const tap0 = stg + (y * 16 + x) * STG_ROW + 32 * ct + 8 * g;      // entry of the (-1, -1) neighbour; tap (dy, dx): + ((dy + 1) * 16 + dx + 1) * 96
+          if (t + 1 < SS_NT) {
+            const unsigned char* const tap1 = tap_base(t + 1);
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) f[(t + 1) & 1][tap] = *reinterpret_cast<const uint2*>(tap1 + ((tap / 3) * 16 + tap % 3) * STG_ROW);
+          }
           float acc[4] = {pb.x, pb.y, pb.z, pb.w};
-          // all 9 taps are requested before the first is used (one at a time, hipcc reused one register pair and waited out an LDS round trip per
-          // tap; the builtin, not inline asm: a DOT result needs wait states before another VALU instruction reads it, and the hazard recognizer only
-          // covers instructions it can see); one v_dot2c_f32_bf16 per tap and channel then takes the bf16 operand straight from a loaded pair (unpacking costs two more
-          // operations per pair)
-          uint2 f[9];
+          // (the builtin, not inline asm: a DOT result needs wait states before another VALU instruction reads it, and the hazard recognizer only covers instructions it can see); one
+          // v_dot2c_f32_bf16 per tap and channel takes the bf16 operand straight from a loaded pair (unpacking costs two more operations per pair)
 #pragma unroll
-          for (int tap = 0; tap < 9; ++tap) f[tap] = *reinterpret_cast<const uint2*>(tap0 + ((tap / 3) * 16 + tap % 3) * STG_ROW);
-#pragma unroll
-          for (int tap = 0; tap < 9; ++tap) asm volatile("" : "+v"(f[tap]));
+          for (int tap = 0; tap < 9; ++tap) asm volatile("" : "+v"(f[t & 1][tap]));
 #pragma unroll
           for (int tap = 0; tap < 9; ++tap) {
-            acc[0] = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, f[tap].x), __builtin_bit_cast(bf16x2_t, wt[0 * 9 + tap]), acc[0], false);
-            acc[1] = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, f[tap].x), __builtin_bit_cast(bf16x2_t, wt[1 * 9 + tap]), acc[1], false);
-            acc[2] = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, f[tap].y), __builtin_bit_cast(bf16x2_t, wt[2 * 9 + tap]), acc[2], false);
-            acc[3] = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, f[tap].y), __builtin_bit_cast(bf16x2_t, wt[3 * 9 + tap]), acc[3], false);
+            acc[0] = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, f[t & 1][tap].x), __builtin_bit_cast(bf16x2_t, wt[0 * 9 + tap]), acc[0], false);
+            acc[1] = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, f[t & 1][tap].x), __builtin_bit_cast(bf16x2_t, wt[1 * 9 + tap]), acc[1], false);
+            acc[2] = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, f[t & 1][tap].y), __builtin_bit_cast(bf16x2_t, wt[2 * 9 + tap]), acc[2], false);
+            acc[3] = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, f[t & 1][tap].y), __builtin_bit_cast(bf16x2_t, wt[3 * 9 + tap]), acc[3], false);
           }
 #pragma unroll
           for (int r = 0; r < 4; ++r) R[t][ct][r] += valid ? acc[r] : 0.f;

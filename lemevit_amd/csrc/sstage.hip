@@ -105,6 +105,9 @@ constexpr int SS_NSTAMP = 24;
 #else
 #define SS_LN_OPAQUE2(a, b) asm volatile("" : "+v"(a), "+v"(b))
 #endif
+#ifndef SS_ATTN_PRIO
+#define SS_ATTN_PRIO 0      // issue priority in the attention phase (VALU-bound; the second-dispatched half of the waves loses the arbitration): 1 waves 4..7 high, 2 / 3 alternating per unit
+#endif
 #ifndef SS_DBG_LN_BARRIER
 #define SS_DBG_LN_BARRIER 0
 #endif
@@ -605,6 +608,13 @@ __global__ __launch_bounds__(64 * NW, 2) void sstage_kernel(const SsArgs a) {
       // wave (wave & 3) left in LDS: waves 0..3 take its tiles 0..3, waves 4..7 its tiles 4..6 (11 / 10 query tiles per wave)
 #pragma unroll 1
       for (int u = 0; u < 3; ++u) {
+#if SS_ATTN_PRIO == 1
+        if (u == 0 && wave >= NW / 2) __builtin_amdgcn_s_setprio(1);
+#elif SS_ATTN_PRIO == 2
+        if ((u != 1) == (wave >= NW / 2)) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
+#elif SS_ATTN_PRIO == 3
+        if ((u == 1) == (wave >= NW / 2)) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
+#endif
         const bool third = u == 2;
         const int h = third ? NW + (wave & (NW / 2 - 1)) : wave;
         const bool groupb = third ? wave >= NW / 2 : u == 1;
@@ -616,6 +626,9 @@ __global__ __launch_bounds__(64 * NW, 2) void sstage_kernel(const SsArgs a) {
         else if (half == 0) attn_image<4, 3>(Qf, h, kr, vr, smem, lane);
         else { attn_image<4, 2>(Qf, h, kr, vr, smem, lane); attn_meta(Qf[6], h, kr, vr, smem, lane); }
       }
+#if SS_ATTN_PRIO
+      __builtin_amdgcn_s_setprio(0);
+#endif
     }
     SS_STAMP(7);
     bf16x8_t ring3[4][3], ringp[SS_PRD][3];

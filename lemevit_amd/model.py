@@ -1000,12 +1000,14 @@ class _AttnModuleFn(torch.autograd.Function):
             ops.linear_fwd([Prob(ao, W[2], out, bias=Bv[2])], C, C)
             saved, outs = (x, c, q, kv, ao, lse), (out,)
         ctx.kind, ctx.W, ctx.acts, ctx.shapes = kind, W, saved, [(p.shape, p.dtype) for p in params]
+        ctx.out_like = [(o.shape, o.dtype, o.device) for o in outs]
         return outs if len(outs) > 1 else outs[0]
 
     @staticmethod
     def backward(ctx, *gs):
         kind, W, S = ctx.kind, ctx.W, ctx.acts
-        gs = [g.contiguous() for g in gs]
+        # (an output the caller did not use arrives as None: its gradient is zero)
+        gs = [torch.zeros(sh, dtype=dt, device=dv) if g is None else g.contiguous() for g, (sh, dt, dv) in zip(gs, ctx.out_like)]
         dev = gs[0].device
         G = [torch.zeros(s, device=dev, dtype=torch.float32) for s, _ in ctx.shapes]      # fp32 accumulators: (weight, bias) pairs
         dw = lambda probs, N, K: ops.linear_dw(probs, N, K)

@@ -343,6 +343,12 @@ def test_attention_modules_are_differentiable(kind, dtype, tol):
         assert p_.grad is not None, n_
         worst = max(worst, close(p_.grad, sd["attn." + n_].grad.numpy(), tol, f"{kind} {n_}"))
     print(f"attention module {kind} {dtype}: worst gradient error {worst:.2e}")
+    if kind in ("D", "D2"):          # an unused output (its gradient arrives as None) must not break the node
+        m.zero_grad()
+        x2 = x0.to(DEV).requires_grad_(True)
+        ox2, _ = m(x2, c0.to(DEV))
+        (ox2.float() * gx.to(DEV).float()).sum().backward()
+        assert torch.isfinite(x2.grad).all() and x2.grad.abs().max().item() > 0
     # and without autograd the module still takes the inference launches
     with torch.no_grad():
         o2 = m(x0.to(DEV)) if kind == "S" else m(x0.to(DEV), c0.to(DEV))

@@ -9,6 +9,9 @@ from __future__ import annotations
 import ctypes as C
 import os
 
+import torch  # noqa: F401  -- FIRST: PyTorch-ROCm ships its own HIP runtime; the library must bind to the copy torch has already loaded (loaded before torch -- `import lemevit_amd`
+                            # in a fresh interpreter -- it pulled /opt/rocm's runtime and every launch later failed with "no ROCm-capable device is detected")
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("LMV_LIB_PATH") or os.path.join(_HERE, "csrc", "liblemevit_hip.so")          # LMV_LIB_PATH: another build of the same library (A/B runs of kernel variants inside one gpurun call)
 

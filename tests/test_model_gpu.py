@@ -446,6 +446,20 @@ def test_model_ema_matches_reference_rule():
     close(a, ref_logits.numpy(), 5e-2, "ema module forward")
 
 
+def test_package_import_before_torch():
+    """`import lemevit_amd` as the FIRST import of a fresh interpreter: the library must bind to the HIP runtime PyTorch-ROCm ships (round 5: loaded before torch it pulled
+    /opt/rocm's copy and every launch failed with "no ROCm-capable device is detected"; lemevit_amd/_lib.py imports torch first now)."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import lemevit_amd, torch\n"
+            "m = lemevit_amd.create_model('lemevit_tiny', num_classes=10).cuda().eval()\n"
+            "with torch.no_grad(), torch.autocast('cuda', torch.bfloat16):\n"
+            "    y = m(torch.randn(2, 3, 224, 224, device='cuda'))\n"
+            "torch.cuda.synchronize(); assert torch.isfinite(y.float()).all(); print('ok', tuple(y.shape))\n")
+    r = subprocess.run([sys.executable, "-c", code], cwd=root, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "ok (2, 10)" in r.stdout, r.stderr[-2000:]
+
+
 def test_launch_context_is_thread_local():
     """VERDICT round 4, weak #8: split_forward's sub-batch count used to be a module global that two inference threads raced on."""
     import threading

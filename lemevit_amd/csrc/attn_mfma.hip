@@ -623,21 +623,149 @@ __device__ __forceinline__ void mfma_bwd_fused_body(const AttnArgs& a, const int
   }
 }
 
+
+// ---- round 5: the same fused backward with the dQ contraction split by QUERY TILE instead of by key tile ---------------------------------------------------
+// In mfma_bwd_fused_body every wave forms a dQ partial over ITS key tiles for both query tiles of a 32-query block, the four partials meet in LDS (fp32) and two waves reduce and
+// store them: two barriers per block, 16 KB of exchange, and the dQ work follows the 4 : 3 : 3 : 3 split of 13 key tiles.  Here, after ONE barrier (every wave's dS tiles of the
+// block are in the transposers), wave w computes the COMPLETE dQ^T tile (query tile w >> 1, d half w & 1) over all key tiles -- 7 MFMAs on 7 K^T fragments it loaded once and keeps
+// in registers (the K image is then dead: its LDS is the second transposer buffer) -- and stores its 8 bytes per lane itself: no partials, no reduce, balanced, and with the
+// transposers double-buffered by block parity the second barrier goes too (a wave can only reach block j + 2's writes of a buffer behind barrier j + 1, which every wave passes
+// after its reads of block j).  train step: main-stream time is worth ~1.2 ms per ms here (LMV_DBG_SKIP_ATTN_BWD: -3.3 ms for 2.75 ms of launches).
 template <int NKT, int LK = 0>
+__device__ __forceinline__ void mfma_bwd_fused_body2(const AttnArgs& a, const int h, const int b) {
+  constexpr int TPW = (NKT + 3) / 4;          // key tiles per wave (scores / dK / dV: by key tile, as before)
+  constexpr int NPAIR = (NKT + 1) / 2;        // 32-key steps of the dQ contraction
+  constexpr int NQ = NKT * 16;
+  constexpr int TBUF = 4 * 2 * TPW * 512;     // one transposer buffer: [wave][q tile][local key tile][16 keys x 16 queries bf16]
+  __shared__ __attribute__((aligned(16))) unsigned char sQ[NQ * 64], sG[NQ * 64];
+  __shared__ __attribute__((aligned(16))) unsigned char sKT[(2 * TBUF > NQ * 64) ? 2 * TBUF : NQ * 64];      // K image during the prologue, then both transposer buffers
+  __shared__ __attribute__((aligned(16))) float sL[NQ], sDl[NQ];
+  auto sT = [&](int buf, int w, int t, int slot) -> unsigned char* { return &sKT[buf * TBUF + ((w * 2 + t) * TPW + slot) * 512]; };
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int g = lane >> 4;
+  const int Lk = LK ? LK : a.Lk, Lq = a.Lq;
+  const int nrows = ((Lq + 31) >> 5) << 5;
+  const int64_t bh = ((int64_t)b * a.H + h) * Lq;
+  const bf16_t* kb = reinterpret_cast<const bf16_t*>(a.k) + b * a.k_bs + h * D;
+  const bf16_t* vb = reinterpret_cast<const bf16_t*>(a.v) + b * a.v_bs + h * D;
+  stage_rows2<256>(sQ, reinterpret_cast<const bf16_t*>(a.q) + b * a.q_bs + h * D, a.q_rs, sG, reinterpret_cast<const bf16_t*>(a.d_o) + b * a.o_bs + h * D, a.o_rs, 0, nrows, Lq, tid);
+  stage_rows2<256>(sKT, kb, a.k_rs, sKT, kb, a.k_rs, 0, NKT * 16, Lk, tid);
+  for (int i = tid; i < nrows; i += 256) {
+    const bool ok = i < Lq;
+    sL[i] = ok ? a.lse[bh + i] : 1e30f;
+    float dl = 0.f;
+    if (ok) {
+      const bf16_t* gp = reinterpret_cast<const bf16_t*>(a.d_o) + b * a.o_bs + (int64_t)i * a.o_rs + h * D;
+      const bf16_t* op = reinterpret_cast<const bf16_t*>(a.o) + b * a.o_bs + (int64_t)i * a.o_rs + h * D;
+      uint4 rg[4], ro[4];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) { rg[c] = *reinterpret_cast<const uint4*>(gp + c * 8); ro[c] = *reinterpret_cast<const uint4*>(op + c * 8); }
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        float gv[8], ov[8];
+        chunk_to_f<bf16_t>(rg[c], gv); chunk_to_f<bf16_t>(ro[c], ov);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) dl += gv[j] * ov[j];
+      }
+    }
+    sDl[i] = dl;
+  }
+  bf16x8_t kf[TPW], vf[TPW];
+  f32x4_t dk[TPW][2], dv[TPW][2];
+#pragma unroll
+  for (int i = 0; i < TPW; ++i) {
+    const int kt = wave + i * 4;
+    kf[i] = load_frag_global(kb, a.k_rs, kt * 16 + (lane & 15), (kt < NKT) ? Lk : 0, lane);
+    vf[i] = load_frag_global(vb, a.v_rs, kt * 16 + (lane & 15), (kt < NKT) ? Lk : 0, lane);
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt) { dk[i][dt] = f32x4_t{0.f, 0.f, 0.f, 0.f}; dv[i][dt] = f32x4_t{0.f, 0.f, 0.f, 0.f}; }
+  }
+  __syncthreads();
+  // this wave's K^T fragments of the dQ contraction: d half (wave & 1), key tiles (2 pp, 2 pp + 1); rows past Lk are zero in the image
+  const int qt_w = wave >> 1, dh = wave & 1;
+  bf16x8_t ktf[NPAIR];
+#pragma unroll
+  for (int pp = 0; pp < NPAIR; ++pp) {
+    const int rowb = (2 * pp + 1 < NKT) ? (2 * pp + 1) * 16 : 2 * pp * 16;
+    ktf[pp] = frag_t(sKT, 2 * pp * 16, rowb, dh * 16, lane);
+  }
+  __syncthreads();          // the K image is dead from here: its bytes are the transposer buffers
+  bf16_t* dqb = reinterpret_cast<bf16_t*>(a.dq) + b * a.q_bs + h * D;
+  int buf = 0;
+  for (int r0 = 0; r0 < nrows; r0 += 32, buf ^= 1) {
+    const bf16x8_t qn0 = frag_n(sQ, r0, lane), qn1 = frag_n(sQ, r0 + 16, lane);
+    const bf16x8_t gn0 = frag_n(sG, r0, lane), gn1 = frag_n(sG, r0 + 16, lane);
+    const bf16x8_t qt0 = frag_t(sQ, r0, r0 + 16, 0, lane), qt1 = frag_t(sQ, r0, r0 + 16, 16, lane);
+    const bf16x8_t gt0 = frag_t(sG, r0, r0 + 16, 0, lane), gt1 = frag_t(sG, r0, r0 + 16, 16, lane);
+    const float4 l0 = *reinterpret_cast<const float4*>(sL + r0 + g * 4), l1 = *reinterpret_cast<const float4*>(sL + r0 + 16 + g * 4);
+    const float4 d0 = *reinterpret_cast<const float4*>(sDl + r0 + g * 4), d1 = *reinterpret_cast<const float4*>(sDl + r0 + 16 + g * 4);
+    const float lse[8] = {l0.x, l0.y, l0.z, l0.w, l1.x, l1.y, l1.z, l1.w};
+    const float dl[8] = {d0.x, d0.y, d0.z, d0.w, d1.x, d1.y, d1.z, d1.w};
+#pragma unroll
+    for (int i = 0; i < TPW; ++i) {
+      const int kt = wave + i * 4;
+      if (kt >= NKT || kt * 16 >= Lk) continue;                      // wave-uniform: tile past the end
+      const bool kvalid = kt * 16 + (lane & 15) < Lk;
+      const f32x4_t s0 = MFMA(qn0, kf[i], (f32x4_t{0.f, 0.f, 0.f, 0.f})), s1 = MFMA(qn1, kf[i], (f32x4_t{0.f, 0.f, 0.f, 0.f}));
+      const f32x4_t p0 = MFMA(gn0, vf[i], (f32x4_t{0.f, 0.f, 0.f, 0.f})), p1 = MFMA(gn1, vf[i], (f32x4_t{0.f, 0.f, 0.f, 0.f}));
+      f32x4_t pr[2], ds[2];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float e0 = kvalid ? __expf(s0[r] * a.scale - lse[r]) : 0.f, e1 = kvalid ? __expf(s1[r] * a.scale - lse[4 + r]) : 0.f;
+        pr[0][r] = e0; pr[1][r] = e1;
+        ds[0][r] = e0 * (p0[r] - dl[r]) * a.scale; ds[1][r] = e1 * (p1[r] - dl[4 + r]) * a.scale;
+      }
+      const bf16x8_t pf = pack8(pr[0], pr[1]), dsf = pack8(ds[0], ds[1]);
+      dv[i][0] = MFMA(gt0, pf, dv[i][0]); dv[i][1] = MFMA(gt1, pf, dv[i][1]);
+      dk[i][0] = MFMA(qt0, dsf, dk[i][0]); dk[i][1] = MFMA(qt1, dsf, dk[i][1]);
+      const uint4 w = __builtin_bit_cast(uint4, dsf);
+      *reinterpret_cast<uint2*>(sT(buf, wave, 0, i) + (lane & 15) * 32 + g * 8) = make_uint2(w.x, w.y);
+      *reinterpret_cast<uint2*>(sT(buf, wave, 1, i) + (lane & 15) * 32 + g * 8) = make_uint2(w.z, w.w);
+    }
+    __syncthreads();          // every key tile's dS of this block is in buffer `buf`
+    {
+      const int rr = (lane & 15) >> 2, qq = lane & 3;
+      f32x4_t dq = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int pp = 0; pp < NPAIR; ++pp) {
+        const int kta = 2 * pp, ktb = 2 * pp + 1;
+        if (kta * 16 >= Lk) continue;
+        const bool has_b = ktb < NKT && ktb * 16 < Lk;
+        const bf16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds4_t)(sT(buf, kta & 3, qt_w, kta >> 2) + (g * 4 + rr) * 32 + qq * 8));
+        bf16x4_t hi = {(__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f};
+        if (has_b) hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds4_t)(sT(buf, ktb & 3, qt_w, ktb >> 2) + (g * 4 + rr) * 32 + qq * 8));
+        const bf16x8_t dst = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+        dq = MFMA(ktf[pp], dst, dq);
+      }
+      const int q = r0 + qt_w * 16 + (lane & 15);
+      if (q < Lq) store4(dqb + (int64_t)q * a.q_rs + g * 8 + dh * 4, dq);          // (frag_t's d order: half dh of the lane's 8 consecutive d)
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < TPW; ++i) {
+    const int kt = wave + i * 4, key = kt * 16 + (lane & 15);
+    if (kt >= NKT || key >= Lk) continue;
+    store8(reinterpret_cast<bf16_t*>(a.dk) + b * a.k_bs + (int64_t)key * a.k_rs + h * D, g, dk[i][0], dk[i][1]);
+    store8(reinterpret_cast<bf16_t*>(a.dv) + b * a.v_bs + (int64_t)key * a.v_rs + h * D, g, dv[i][0], dv[i][1]);
+  }
+}
+
+template <int NKT, int LK = 0, int VER = 1>
 __global__ __launch_bounds__(256, 2) void mfma_bwd_fused_kernel(const AttnArgs a) {
   const int n = a.H * a.B, id = (int)blockIdx.y + a.H * (int)blockIdx.z;
   const int L = LMV_XCD_REMAP ? xcd_contiguous(id, n) : id;
-  mfma_bwd_fused_body<NKT, LK>(a, L % a.H, L / a.H);
+  if constexpr (VER == 2) mfma_bwd_fused_body2<NKT, LK>(a, L % a.H, L / a.H);
+  else mfma_bwd_fused_body<NKT, LK>(a, L % a.H, L / a.H);
 }
 
 // backward of the pair launch: workgroup (0, h, b) differentiates the image-token problem (fused kernel), workgroup (1, h, b) the
 // 16-token problem (the <= 32-key kernel that also produces dQ, with 32-row staging images instead of 448-row ones)
-template <int NKT1, int LK1>
+template <int NKT1, int LK1, int VER = 1>
 __global__ __launch_bounds__(256, 2) void mfma_bwd_pair_kernel(const AttnArgs a1, const AttnArgs a2) {
   const int n1 = a1.H * a1.B;                                 // 1-D grid, problem 1 first (see mfma_fwd_pair_kernel)
   int id = (int)blockIdx.x;
   if (id < n1 && LMV_XCD_REMAP) id = xcd_contiguous(id, n1);
-  if (id < n1) mfma_bwd_fused_body<NKT1, LK1>(a1, id % a1.H, id / a1.H);
+  if (id < n1) { if constexpr (VER == 2) mfma_bwd_fused_body2<NKT1, LK1>(a1, id % a1.H, id / a1.H); else mfma_bwd_fused_body<NKT1, LK1>(a1, id % a1.H, id / a1.H); }
   else mfma_bwd_dkv_body<2, 1, false, true, 16, 32>(a2, nullptr, nullptr, nullptr, 32, 0, (id - n1) % a2.H, (id - n1) / a2.H);
 }
 
@@ -1373,7 +1501,10 @@ int lmv_attn_mfma_bwd(const AttnArgs& a, float* delta, float* acc, hipStream_t s
   if (fused_bwd && nkt >= 4 && a.Lq > 16 && a.Lq <= nkt * 16) {
     // one workgroup per (b, h): dQ, dK and dV from ONE pass over the scores
     dim3 grid(1, a.H, a.B), block(256);
-    if (a.Lk == 196) hipLaunchKernelGGL((mfma_bwd_fused_kernel<14, 196>), grid, block, 0, st, a);
+    const bool v2 = lmv_config().attn_fused_bwd == 2;          // round 5: dQ by query tile, one barrier per block (mfma_bwd_fused_body2)
+    if (a.Lk == 196 && v2) hipLaunchKernelGGL((mfma_bwd_fused_kernel<14, 196, 2>), grid, block, 0, st, a);
+    else if (a.Lk == 49 && v2) hipLaunchKernelGGL((mfma_bwd_fused_kernel<4, 49, 2>), grid, block, 0, st, a);
+    else if (a.Lk == 196) hipLaunchKernelGGL((mfma_bwd_fused_kernel<14, 196>), grid, block, 0, st, a);
     else if (a.Lk == 49) hipLaunchKernelGGL((mfma_bwd_fused_kernel<4, 49>), grid, block, 0, st, a);
     else if (nkt == 4) hipLaunchKernelGGL((mfma_bwd_fused_kernel<4>), grid, block, 0, st, a);
     else if (nkt == 8) hipLaunchKernelGGL((mfma_bwd_fused_kernel<8>), grid, block, 0, st, a);
@@ -1440,7 +1571,10 @@ int lmv_attn_mfma_bwd_pair(const AttnArgs& a1, const AttnArgs& a2, hipStream_t s
   const int on = lmv_config().attn_pair;
   if (!on || a1.B != a2.B || a1.H != a2.H || a2.Lk != 16 || a2.Lq != 16 || a1.Lq != a1.Lk || (a1.Lk != 196 && a1.Lk != 49)) return 0;
   dim3 grid(2 * a1.H * a1.B), block(256);
-  if (a1.Lk == 196) hipLaunchKernelGGL((mfma_bwd_pair_kernel<14, 196>), grid, block, 0, st, a1, a2);
+  const bool v2 = lmv_config().attn_fused_bwd == 2;
+  if (a1.Lk == 196 && v2) hipLaunchKernelGGL((mfma_bwd_pair_kernel<14, 196, 2>), grid, block, 0, st, a1, a2);
+  else if (v2) hipLaunchKernelGGL((mfma_bwd_pair_kernel<4, 49, 2>), grid, block, 0, st, a1, a2);
+  else if (a1.Lk == 196) hipLaunchKernelGGL((mfma_bwd_pair_kernel<14, 196>), grid, block, 0, st, a1, a2);
   else hipLaunchKernelGGL((mfma_bwd_pair_kernel<4, 49>), grid, block, 0, st, a1, a2);
   return 1;
 }

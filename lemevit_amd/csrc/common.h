@@ -110,9 +110,10 @@ struct LmvConfig {
   int mlp_split384;       // LMV_MLP_SPLIT384       1: fused inference schedule runs the C = 384 MLP half as LayerNorm + rsgemm fc1 + wngemm fc2 instead of the one-kernel form
   int mlp_rw96;           // LMV_MLP_RW96           1: the C = 96 one-kernel MLP with both weight matrices resident in LDS (csrc/rwmlp.hip) instead of the tile-streaming form
   int mlp_tm;             // LMV_MLP_TM             0 = auto: token rows per workgroup of the fused MLP kernel (64 / 128)
-  int attn_pv16, attn_fuse_dq, attn_fused_bwd, attn_pair;      // LMV_ATTN_*
+  int attn_pv16, attn_fuse_dq, attn_fused_bwd, attn_pair;      // LMV_ATTN_*  (attn_fused_bwd: 0 separate dQ / dK-dV kernels, 1 round 2's fused backward, 2 (default) round 5's: dQ by query tile, one barrier per block)
   int ln_bwd_blocks, ln_bwd_minrows;                           // LMV_LN_BWD_*
   int dw_chain;           // LMV_DW_CHAIN           1: lmv_block_bwd chains the weight-gradient GEMMs of a block (the slab sums of one ride in the next launch, lmv_linear_dw_chain); 0 (default, measured faster): a reduce launch behind every GEMM
+  int dbg_skip_attn_bwd;  // LMV_DBG_SKIP_ATTN_BWD  timing probe (0): lmv_attn_bwd / _bwd_pair return without launching -- what a train step would gain if the attention backward were free
   int stage_ticket_skew;  // LMV_STAGE_TICKET_SKEW  test switch (0): the persistent stage kernels ask ticket counter (XCC_ID + skew * hash(blockIdx)) & 7 first -- a simulated foreign workgroup -> XCD placement
 };
 LmvConfig& lmv_config();

@@ -128,8 +128,8 @@ const ConfigKey kConfigKeys[] = {
     {"gemm_cumap", "LMV_GEMM_CUMAP", &LmvConfig::gemm_cumap, 1}, {"gemm_nst", "LMV_GEMM_NST", &LmvConfig::gemm_nst, 2},
     {"gemm_nst_dw", "LMV_GEMM_NST_DW", &LmvConfig::gemm_nst_dw, 3}, {"gemm_rs", "LMV_GEMM_RS", &LmvConfig::gemm_rs, 1}, {"gemm_wn", "LMV_GEMM_WN", &LmvConfig::gemm_wn, 1},
     {"dwconv_v", "LMV_DWCONV_V", &LmvConfig::dwconv_v, 0},
-    {"stage_ticket_skew", "LMV_STAGE_TICKET_SKEW", &LmvConfig::stage_ticket_skew, 0}, {"dw_chain", "LMV_DW_CHAIN", &LmvConfig::dw_chain, 0}, {"mlp_tm", "LMV_MLP_TM", &LmvConfig::mlp_tm, 0}, {"mlp_rw96", "LMV_MLP_RW96", &LmvConfig::mlp_rw96, 1}, {"mlp_split384", "LMV_MLP_SPLIT384", &LmvConfig::mlp_split384, 1}, {"dx_ln_fused", "LMV_DX_LN_FUSED", &LmvConfig::dx_ln_fused, 1}, {"res_ln_fused", "LMV_RES_LN_FUSED", &LmvConfig::res_ln_fused, 1}, {"ln_exact_fused", "LMV_LN_EXACT_FUSED", &LmvConfig::ln_exact_fused, 1}, {"attn_pv16", "LMV_ATTN_PV16", &LmvConfig::attn_pv16, 1},
-    {"attn_fuse_dq", "LMV_ATTN_FUSE_DQ", &LmvConfig::attn_fuse_dq, 1}, {"attn_fused_bwd", "LMV_ATTN_FUSED_BWD", &LmvConfig::attn_fused_bwd, 1},
+    {"stage_ticket_skew", "LMV_STAGE_TICKET_SKEW", &LmvConfig::stage_ticket_skew, 0}, {"dw_chain", "LMV_DW_CHAIN", &LmvConfig::dw_chain, 0}, {"dbg_skip_attn_bwd", "LMV_DBG_SKIP_ATTN_BWD", &LmvConfig::dbg_skip_attn_bwd, 0}, {"mlp_tm", "LMV_MLP_TM", &LmvConfig::mlp_tm, 0}, {"mlp_rw96", "LMV_MLP_RW96", &LmvConfig::mlp_rw96, 1}, {"mlp_split384", "LMV_MLP_SPLIT384", &LmvConfig::mlp_split384, 1}, {"dx_ln_fused", "LMV_DX_LN_FUSED", &LmvConfig::dx_ln_fused, 1}, {"res_ln_fused", "LMV_RES_LN_FUSED", &LmvConfig::res_ln_fused, 1}, {"ln_exact_fused", "LMV_LN_EXACT_FUSED", &LmvConfig::ln_exact_fused, 1}, {"attn_pv16", "LMV_ATTN_PV16", &LmvConfig::attn_pv16, 1},
+    {"attn_fuse_dq", "LMV_ATTN_FUSE_DQ", &LmvConfig::attn_fuse_dq, 1}, {"attn_fused_bwd", "LMV_ATTN_FUSED_BWD", &LmvConfig::attn_fused_bwd, 2},
     {"attn_pair", "LMV_ATTN_PAIR", &LmvConfig::attn_pair, 1}, {"ln_bwd_blocks", "LMV_LN_BWD_BLOCKS", &LmvConfig::ln_bwd_blocks, 1024},
     {"ln_bwd_minrows", "LMV_LN_BWD_MINROWS", &LmvConfig::ln_bwd_minrows, 2},
 };

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define LMV_ABI_VERSION 10
+#define LMV_ABI_VERSION 11
 
 enum { LMV_F32 = 0, LMV_BF16 = 1 };
 enum {
@@ -251,6 +251,9 @@ int lmv_dwconv3x3_residual_fwd(const void* x, const float* weight, const float* 
                                int B, int H, int W, int C, int dtype, void* stream);
 int lmv_dwconv3x3_residual_bwd_data(const void* dy, const float* weight, void* dx,
                                     int B, int H, int W, int C, int dtype, void* stream);
+/* ... and a second output dx_scaled[b, ...] = dx[b, ...] * scale[b] (fp32 [B]; the product of the ROUNDED dx, i.e. what lmv_row_scale(dx) gives) from the same launch:
+ * lmv_block_bwd uses it to hand the previous block of a stage its DropPath-scaled output gradient (lmv_block_desc.out_scale). */
+int lmv_dwconv3x3_residual_bwd_data_scaled(const void* dy, const float* weight, void* dx, void* dx_scaled, const float* scale, int B, int H, int W, int C, int dtype, void* stream);
 size_t lmv_dwconv3x3_bwd_weight_workspace_bytes(int B, int H, int W, int C, int dtype);
 int lmv_dwconv3x3_bwd_weight(const void* dy, const void* x, float* dweight, float* dbias,
                              int B, int H, int W, int C, void* workspace, size_t workspace_bytes, int dtype, void* stream);
@@ -400,6 +403,13 @@ typedef struct lmv_block_desc {
    * TRANSPOSED [C, 3C] / [C, C] in `dtype`.  With them lmv_block_bwd runs the dX of fc1 / qkv / proj as forward-form GEMMs
    * dY [rows, N] x wt^T -> [rows, C], which the whole-width kernel (csrc/wngemm.hip) takes for C = 384.  Same values as the weights. */
   const void* fc1_wt; const void* attn_wt[2];
+  /* Round 5 (ABI 11), optional (NULL = absent), S / D blocks in lmv_block_bwd: DropPath scaling handed ACROSS the block boundary.  The backward pass of a block starts by
+   * multiplying the gradients of its outputs by its MLP-half DropPath vectors (masks[1] for x, masks[3] for c: 32 row-scale launches per LeMeViT-Base step on the critical stream).
+   * With out_scale / dx_scaled / dc_scaled the block that PRODUCES those gradients -- the next block of the stage -- also writes them multiplied by out_scale[0] (x) / out_scale[1] (c),
+   * per sample, from its closing depth-wise-convolution and LayerNorm-1 backward launches; the consuming block passes them as g_pre[0] / g_pre[1] and skips its row-scale launch.
+   * g_pre[s] must equal dx_out / dc_out times masks[1] / masks[3] (dx_scaled: the rounded dx times the scale, as lmv_row_scale; dc_scaled: the fp32 value times the scale, rounded once); either g_pre entry may be NULL (that stream is scaled here as before). */
+  const float* out_scale[2]; void* dx_scaled; void* dc_scaled;
+  const void* g_pre[2];
 } lmv_block_desc;
 size_t lmv_block_arena_bytes(const lmv_block_desc* d);
 size_t lmv_block_bwd_scratch_bytes(const lmv_block_desc* d);

@@ -364,13 +364,14 @@ int dx_ln_bwd(Side& sd, const lmv_linear_problem* p, const lmv_ln_segment* seg, 
 // MLP half backward (blocks.py::_mlp_bwd): douts = gradients of the block outputs, returns dt2 (gradient of the MLP half's input) and, where the
 // attention half's DropPath vector nds[s] is set, g2[s] = dt2[s] pre-scaled by it (written by the same LayerNorm-backward launch)
 int mlp_bwd(const lmv_block_desc* d, const Dims& D, const Fwd& f, const Bwd& b, int s0, const void* const* douts, const float* const* ds, const float* const* nds,
-            const void** g2_out, Side& sd) {
+            const void** g2_out, Side& sd, const void* const* gpre = nullptr) {
   const int ns = 2 - s0;
   hipStream_t st = sd.main;
   const void* g[2];
   lmv_row_scale_segment rs[2]; int nrs = 0;
   for (int s = s0; s < 2; ++s) {
     g[s] = douts[s];
+    if (ds[s] && gpre && gpre[s]) { g[s] = gpre[s]; continue; }          // already scaled by the block that produced douts[s] (lmv_block_desc.g_pre)
     if (ds[s]) { rs[nrs].x = douts[s]; rs[nrs].scale = ds[s]; rs[nrs].y = b.g[s]; rs[nrs].rows = D.rows[s]; rs[nrs].rows_per_sample = s == 0 ? D.N : D.M; ++nrs; g[s] = b.g[s]; }
   }
   if (nrs) LMV_TRY(lmv_row_scale_multi(rs, nrs, D.C, D.dtype, st));
@@ -625,7 +626,7 @@ extern "C" int lmv_block_bwd(const lmv_block_desc* d, const void* x, const void*
       const void* douts[2] = {dx_out, dc_out};
       const float* ds[2] = {d->masks[1], d->masks[3]};
       const float* nds[2] = {d->masks[0], d->masks[2]};
-      LMV_TRY(mlp_bwd(d, D, f, b, 0, douts, ds, nds, g2, sd));
+      LMV_TRY(mlp_bwd(d, D, f, b, 0, douts, ds, nds, g2, sd, d->g_pre));
       const bool sh = D.kind == LMV_BLOCK_S;
       for (int s2 = 0; s2 < 2; ++s2) { p[s2] = prob(g2[s2], f.ao[s2], sh ? d->g_attn_w[1] : d->g_attn_w[2 + s2], D.rows[s2]); p[s2].bias_grad = sh ? d->g_attn_b[1] : d->g_attn_b[2 + s2]; }
       LMV_TRY(dw(sd, p, 2, C, C, D.dtype));
@@ -667,6 +668,7 @@ extern "C" int lmv_block_bwd(const lmv_block_desc* d, const void* x, const void*
       lmv_ln_segment seg[2] = {};
       seg[0].x = f.xp; seg[0].dy = b.dn1[0]; seg[0].stats = f.st1[0]; seg[0].dres = b.dt2[0]; seg[0].dx = b.dxp; seg[0].rows = D.rows[0];
       seg[1].x = c; seg[1].dy = b.dn1[1]; seg[1].stats = f.st1[1]; seg[1].dres = b.dt2[1]; seg[1].dx = dc; seg[1].rows = D.rows[1];
+      if (d->out_scale[1] && d->dc_scaled) { seg[1].dx_scale = d->out_scale[1]; seg[1].dx_scaled = d->dc_scaled; seg[1].rows_per_sample = M; }      // dc for the previous block, pre-scaled by ITS DropPath vector
       if (fuse1) {
         for (int s2 = 0; s2 < 2; ++s2) p[s2] = prob(b.dpj[s2], d->attn_wt[0], b.dn1[s2], D.rows[s2]);
         LMV_TRY(dx_ln_bwd(sd, p, seg, 2, 3 * C, d->n1_w, d->g_n1_w, d->g_n1_b, D, b.ws_ln[1], b.ws_ln_bytes));
@@ -685,6 +687,7 @@ extern "C" int lmv_block_bwd(const lmv_block_desc* d, const void* x, const void*
       sg.kind = LMV_REDUCE_ROWS; sg.mode = 1;
     }
     LMV_TRY(flush_reduces(sd));
+    if (!cb && d->out_scale[0] && d->dx_scaled) return lmv_dwconv3x3_residual_bwd_data_scaled(b.dxp, d->pos_w, dx, d->dx_scaled, d->out_scale[0], D.B, D.H, D.W, C, D.dtype, st);
     return lmv_dwconv3x3_residual_bwd_data(b.dxp, d->pos_w, dx, D.B, D.H, D.W, C, D.dtype, st);
   };
   rc = body();

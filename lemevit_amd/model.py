@@ -560,6 +560,10 @@ def _resolve_dtype(x: Tensor) -> torch.dtype:
 # native block schedules (csrc/block.hip): ONE C-ABI call per block and pass instead of ~12 / ~30 per-op calls from blocks.py
 # ------------------------------------------------------------------------------------------------
 _NATIVE = os.environ.get("LMV_BLOCK_NATIVE", "1") != "0"      # 0: the Python schedules of blocks.py (A/B runs; they also serve "D2" / "Sx")
+# Cross-block DropPath pre-scaling (lmv_block_desc.out_scale / g_pre): OFF by default.  Measured on LeMeViT-Base 224 B = 128 (round 5): 26 of the 32 row-scale launches
+# per step go (-0.36 ms of kernel time on the critical stream, +0.18 ms in the two-output depthwise-conv launches), and the step gets 0.2-0.35 ms SLOWER in every interleaved pair.
+_PRESCALE_MAX_BYTES = int(float(os.environ.get("LMV_PRESCALE_MAX_MB", "1e9")) * 2 ** 20)
+_PRESCALE = os.environ.get("LMV_PRESCALE", "0") != "0"
 _KIND_CODE = {"S": 0, "D": 1, "C": 2}
 _COMMON_FIELDS = {"pos_embed.weight": "pos_w", "pos_embed.bias": "pos_b", "norm1.weight": "n1_w", "norm1.bias": "n1_b", "norm2.weight": "n2_w",
                   "norm2.bias": "n2_b", "mlp.0.weight": "fc1_w", "mlp.0.bias": "fc1_b", "mlp.3.weight": "fc2_w", "mlp.3.bias": "fc2_b"}
@@ -729,7 +733,10 @@ def native_block_forward(kind: str, x: Tensor, c: Tensor, H: int, W: int, names,
     return (x if xo is None else xo), co, ((d, arena) if save else None)
 
 
-def native_block_backward(kind: str, state, x: Tensor, c: Tensor, dx: Optional[Tensor], dc: Tensor, H: int, W: int, names, G: Dict[str, Tensor]):
+def native_block_backward(kind: str, state, x: Tensor, c: Tensor, dx: Optional[Tensor], dc: Tensor, H: int, W: int, names, G: Dict[str, Tensor],
+                          out_scale=(None, None), g_pre=(None, None)):
+    """out_scale: per-sample vectors (x, c) of the block that will consume dx / dc -- the PREVIOUS block of the stage: its MLP-half DropPath scales; the pre-scaled copies come
+    back as a third / fourth result (lmv_block_desc.out_scale).  g_pre: dx / dc already multiplied by THIS block's MLP-half DropPath scales by the block that produced them."""
     from ._lib import lib, check
     from . import blocks as blocks_mod
     from .blocks import side_stream_handle
@@ -746,12 +753,20 @@ def native_block_backward(kind: str, state, x: Tensor, c: Tensor, dx: Optional[T
     _bwd_slot = (_bwd_slot + 1) % (blocks_mod._DEFER + 1) if defer else 0
     scratch = _persistent(("bwd", _bwd_slot), nbytes, x.device)
     dx0, dc0 = torch.empty_like(x), torch.empty_like(c)
+    dx_s = torch.empty_like(x) if (out_scale[0] is not None and kind in ("S", "D")) else None
+    dc_s = torch.empty_like(c) if (out_scale[1] is not None and kind in ("S", "D")) else None
+    d.out_scale[0] = None if dx_s is None else out_scale[0].data_ptr()
+    d.out_scale[1] = None if dc_s is None else out_scale[1].data_ptr()
+    d.dx_scaled = None if dx_s is None else dx_s.data_ptr()
+    d.dc_scaled = None if dc_s is None else dc_s.data_ptr()
+    d.g_pre[0] = None if g_pre[0] is None else g_pre[0].data_ptr()
+    d.g_pre[1] = None if g_pre[1] is None else g_pre[1].data_ptr()
     d.flags = 1 if defer else 0          # LMV_BLOCK_NO_JOIN
     check(lib.lmv_block_bwd(d, x.data_ptr(), c.data_ptr(), arena.data_ptr(), arena.numel(), None if dx is None else dx.data_ptr(), dc.data_ptr(), dx0.data_ptr(),
                             dc0.data_ptr(), scratch.data_ptr(), scratch.numel(), ops._stream(), side), "lmv_block_bwd")
     if defer:
-        blocks_mod.defer_join(x.device.index, (arena, x, c, dx, dc, scratch))
-    return dx0, dc0
+        blocks_mod.defer_join(x.device.index, (arena, x, c, dx, dc, scratch, g_pre))
+    return dx0, dc0, dx_s, dc_s
 
 
 # ------------------------------------------------------------------------------------------------
@@ -759,7 +774,9 @@ def native_block_backward(kind: str, state, x: Tensor, c: Tensor, dx: Optional[T
 # ------------------------------------------------------------------------------------------------
 class _BlockFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, c, kind, H, W, masks, names, *params):
+    def forward(ctx, x, c, kind, H, W, masks, prev, names, *params):
+        """prev: (x, c) MLP-half DropPath vectors of the PREVIOUS block of the stage (or None): this block's backward pass then also writes its input gradients multiplied by them
+        (lmv_block_desc.out_scale) and tags the tensors it returns, so that the previous block's node finds them (`_lmv_pre`) and skips its row-scale launch."""
         cd = x.dtype
         P = {n: compute_copy(p, cd if _is_matrix(n) else torch.float32) for n, p in zip(names, params)}
         ctx.native = _native_ok(kind, x, c)
@@ -779,6 +796,7 @@ class _BlockFn(torch.autograd.Function):
                 _join_ranges(x.device)
             xo, co, saved = block_forward(kind, x, c, H, W, P, masks, save=True)
         ctx.kind, ctx.H, ctx.W, ctx.masks, ctx.names = kind, H, W, masks, names
+        ctx.prev = prev if (_PRESCALE and prev is not None and kind in ("S", "D") and x.numel() * x.element_size() <= _PRESCALE_MAX_BYTES) else None
         ctx.saved, ctx.P = saved, P
         ctx.pmeta = [(p.shape, p.dtype) for p in params]
         ctx.params = params
@@ -819,7 +837,20 @@ class _BlockFn(torch.autograd.Function):
                 off += pd
         if ctx.native:
             xin, cin, state = ctx.saved
-            dx0, dc0 = native_block_backward(kind, state, xin, cin, None if dx is None else dx.contiguous(), dc.contiguous(), ctx.H, ctx.W, names, G)
+            g_pre = [None, None]
+            if _PRESCALE and kind in ("S", "D"):
+                # the node that produced dx / dc (the next block of the stage) may have left them pre-multiplied by THIS block's MLP-half DropPath vectors
+                for s_i, (gt, mk) in enumerate(((dx, ctx.masks[1]), (dc, ctx.masks[3]))):
+                    tag = getattr(gt, "_lmv_pre", None)
+                    if tag is not None and mk is not None and tag[1] is mk and tag[0].shape == gt.shape and tag[0].dtype == gt.dtype and gt.is_contiguous():
+                        g_pre[s_i] = tag[0]
+            osc = ctx.prev if ctx.prev is not None else (None, None)
+            dx0, dc0, dx_s, dc_s = native_block_backward(kind, state, xin, cin, None if dx is None else dx.contiguous(), dc.contiguous(), ctx.H, ctx.W, names, G,
+                                                        out_scale=osc, g_pre=tuple(g_pre))
+            if dx_s is not None:
+                dx0._lmv_pre = (dx_s, osc[0])
+            if dc_s is not None:
+                dc0._lmv_pre = (dc_s, osc[1])
             if kind == "C" and dx is not None:
                 dx0 = dx0 + dx                      # the untouched x's pass-through gradient (as blocks.block_backward)
         else:
@@ -834,19 +865,19 @@ class _BlockFn(torch.autograd.Function):
         if cb is not None:
             cb()                     # lemevit_amd.dist.FlatGradSync: this block closes a chunk of the flat gradient buffer -> start its all-reduce
         if inplace:
-            return (dx0, dc0, None, None, None, None, None, *([None] * len(names)))
+            return (dx0, dc0, None, None, None, None, None, None, *([None] * len(names)))
         pg = [G[n] if dt == torch.float32 else G[n].to(dt) for n, (_, dt) in zip(names, ctx.pmeta)]
-        return (dx0, dc0, None, None, None, None, None, *pg)
+        return (dx0, dc0, None, None, None, None, None, None, *pg)
 
 
 def run_block(kind: str, x: Tensor, c: Tensor, H: int, W: int, params: "OrderedDict[str, Tensor]",
-              masks: Sequence[Optional[Tensor]]) -> Tuple[Tensor, Tensor]:
+              masks: Sequence[Optional[Tensor]], prev=None) -> Tuple[Tensor, Tensor]:
     """LeMeBlock on token-major tensors; picks the autograd node or the no-grad fast path."""
     names = PARAM_NAMES[kind]
     plist = [params[n] for n in names]
     need_grad = torch.is_grad_enabled() and (x.requires_grad or c.requires_grad or any(p.requires_grad for p in plist))
     if need_grad:
-        out = _BlockFn.apply(x, c, kind, H, W, tuple(masks), names, *plist)
+        out = _BlockFn.apply(x, c, kind, H, W, tuple(masks), prev, names, *plist)
         return (x, out) if kind == "C" else ((out, c) if kind == "Sx" else out)
     cd = x.dtype
     P = {n: compute_copy(p, cd if _is_matrix(n) else torch.float32) for n, p in zip(names, plist)}
@@ -1245,13 +1276,13 @@ class LeMeBlock(nn.Module):
         m = [torch.empty(B, device=device, dtype=torch.float32).bernoulli_(keep).div_(keep) for _ in range(n)]
         return m + [None] * (4 - n)
 
-    def forward_tokens(self, x: Tensor, c: Tensor, H: int, W: int, masks=None) -> Tuple[Tensor, Tensor]:
-        """x [B, H*W, C] token-major, c [B, M, C]."""
+    def forward_tokens(self, x: Tensor, c: Tensor, H: int, W: int, masks=None, prev=None) -> Tuple[Tensor, Tensor]:
+        """x [B, H*W, C] token-major, c [B, M, C].  prev: the (x, c) MLP-half DropPath vectors of the previous block of the stage (see _BlockFn)."""
         if masks is None:
             masks = self._masks(x.shape[0], x.device)
             if any(m is not None for m in masks):
                 _cache_filled()          # masks drawn HERE are kernels on the current stream: image_ranges() must re-fork its range streams behind them (ADVICE round 3)
-        return run_block(self.kind, x, c, H, W, self._params(), masks)
+        return run_block(self.kind, x, c, H, W, self._params(), masks, prev)
 
     def forward(self, x: Tensor, c: Tensor) -> Tuple[Tensor, Tensor]:
         """Reference signature: x NCHW in / out (models/lemevit.py:652)."""
@@ -1468,8 +1499,12 @@ class LeMeViT(nn.Module):
                 xt, c = _whole_stage_fwd(whole, xt.contiguous(), c, _sstage_packed(self.stages[i], whole), H, W)
                 continue
             with image_ranges(xt.device, B):
+                prev = None
                 for blk in self.stages[i]:
-                    xt, c = blk.forward_tokens(xt, c, H, W, masks=all_masks.get(id(blk)) if all_masks else None)
+                    mk = all_masks.get(id(blk)) if all_masks else None
+                    xt, c = blk.forward_tokens(xt, c, H, W, masks=mk, prev=prev)
+                    # the next block's backward pass writes ITS input gradients pre-multiplied by this block's MLP-half DropPath vectors (S / D blocks: masks 1 and 3)
+                    prev = (mk[1], mk[3]) if (mk is not None and blk.kind in ("S", "D") and mk[1] is not None and mk[3] is not None) else None
         bn = self.norm
         if head is not False and isinstance(self.pre_logits, nn.Identity) and (self.training or torch.is_grad_enabled()) and _tail_native(self.norm_c, head, xt, c, cd):
             # training: final BatchNorm (native kernels) -> LayerNorm(c) + both mean-pools + add (+ classifier) as ONE autograd node

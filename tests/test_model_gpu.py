@@ -1011,6 +1011,53 @@ def _native_vs_python(monkeypatch, kind, C, h, Hs, dtype, B):
         assert torch.equal(a, b), f"{kind} {dtype} {what}: native and Python schedules differ by {float((a.float() - b.float()).abs().max()):.3e}"
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("kind,C,h,Hs", [("S", 192, 6, 7), ("D", 96, 3, 14), ("S", 384, 12, 14)])
+def test_cross_block_droppath_prescale(monkeypatch, kind, C, h, Hs, dtype):
+    """lmv_block_desc.out_scale / g_pre: block k+1's backward pass writes its input gradients a second time, multiplied by block k's MLP-half DropPath vectors, in
+    the launches that produce them (the closing depthwise-conv backward-data for x, LayerNorm-1 backward for c); block k then skips its row-scale launch.  Three chained blocks
+    with DropPath vectors, switch on and off: every gradient bit-identical in fp32 (bf16: within a rounding of dc), and the hand-off must actually have happened (2 blocks x 2 streams)."""
+    import lemevit_amd.model as M
+    from lemevit_amd.blocks import PARAM_NAMES
+    B, N, Mt = 5, Hs * Hs, 16
+    names = PARAM_NAMES[kind]
+    blks = [load(_block(kind, C, h), f"blk{i}.", 11 + i) for i in range(3)]
+    masks = [tuple((det_tensor((B,), f"mask{j}.{i}", 4).abs() > 0.3).float().to(DEV) / 0.7 for i in range(4)) for j in range(3)]
+    real, seen = M.native_block_backward, []
+
+    def spy(*a, **kw):
+        seen.append(sum(g is not None for g in kw.get("g_pre", (None, None))))
+        return real(*a, **kw)
+    monkeypatch.setattr(M, "native_block_backward", spy)
+    res = {}
+    for pre in (True, False):
+        monkeypatch.setattr(M, "_PRESCALE", pre)
+        seen.clear()
+        for b in blks:
+            for p in b.parameters():
+                p.grad = None
+        x = det_tensor((B, N, C), "x", 6).to(DEV, dtype).requires_grad_(True); c = det_tensor((B, Mt, C), "c", 6).to(DEV, dtype).requires_grad_(True)
+        gx = det_tensor((B, N, C), "gx", 6).to(DEV, dtype); gc = det_tensor((B, Mt, C), "gc", 6).to(DEV, dtype)
+        xo, co, prev = x, c, None
+        for b, mk in zip(blks, masks):
+            allp = dict(b.named_parameters())
+            xo, co = M.run_block(kind, xo, co, Hs, Hs, {n: allp[n] for n in names}, mk, prev)
+            prev = (mk[1], mk[3])
+        ((xo.float() * gx.float()).sum() + (co.float() * gc.float()).sum()).backward()
+        torch.cuda.synchronize()
+        assert sum(seen) == (4 if pre else 0), seen
+        res[pre] = [x.grad.clone(), c.grad.clone()] + [p.grad.clone() for b in blks for p in b.parameters() if p.grad is not None]
+    assert len(res[True]) == len(res[False]) > 2
+    for i, (a, b) in enumerate(zip(res[True], res[False])):
+        if dtype == torch.float32:
+            assert torch.equal(a, b), f"{kind} fp32 tensor {i}: pre-scaled and row-scaled gradients differ by {float((a - b).abs().max()):.3e}"
+        else:
+            # bf16: the LayerNorm-backward launches scale the fp32 value and round once, the row-scale launch scales the rounded gradient (two roundings): one bf16 ulp on dc,
+            # carried through the blocks below (the x stream's closing depthwise conv rounds first: S blocks keep x bit-identical)
+            err = float((a.float() - b.float()).abs().max()) / max(float(b.float().abs().max()), 1e-30)
+            assert err <= 2e-2, f"{kind} bf16 tensor {i}: {err:.2e}"
+
+
 def test_block_bwd_two_threads_two_streams():
     """include/lemevit_hip.h promises a stateless, re-entrant library: two host threads run lmv_block_bwd (raw C ABI) on the SAME device at the
     same time, each on its own main + side stream, 12 rounds -- every output and every parameter gradient must be bit-identical to the

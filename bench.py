@@ -59,6 +59,8 @@ def parse():
     ap.add_argument("--torch-adamw", action="store_true", help="use torch.optim.AdamW(fused=True) instead of lemevit_amd.FlatAdamW at N=1")
     ap.add_argument("--grad-wire", default="auto", choices=["auto", "fp32", "bf16"], help="N > 1 with FlatGradSync: element type of the gradient all-reduce.  auto = bf16 "
                     "(106 MB instead of 212 MB per step over xGMI, SURVEY 8(e) / row f3; the reference's own DDP path has no compression: --grad-wire fp32 reproduces its byte count)")
+    ap.add_argument("--adamw-overlap", type=int, default=int(os.environ.get("LMV_ADAMW_OVERLAP", "0")), help="N = 1, FlatAdamW: issue the update of the block parameters in this many chunks "
+                    "DURING the backward pass, each as soon as its gradients are final (lemevit_amd.FlatAdamW(overlap=k)); 0 = one launch behind the backward pass")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--no-issue-probe", action="store_true", help="skip the 5 synchronised single steps that measure host issue time (profiling runs: "
                     "they would sit in the 'last steps' window of a kernel trace)")
@@ -249,7 +251,7 @@ def main():
         if not use_ddp and not args.torch_adamw:
             # the framework's optimizer: block parameters flat, gradients written in place, one fused AdamW launch that also
             # refreshes the bf16 operand copies (same update rule; tests/test_model_gpu.py::test_flat_adamw_matches_torch_adamw)
-            opt = lemevit_amd.FlatAdamW(model, lr=1e-4, eps=1e-8, weight_decay=0.05)
+            opt = lemevit_amd.FlatAdamW(model, lr=1e-4, eps=1e-8, weight_decay=0.05, overlap=0 if (world > 1 or args.force_sync) else args.adamw_overlap)
             if world > 1 or args.force_sync:
                 # data parallelism without a DDP wrapper: the flat block-gradient buffer is all-reduced in 4 large chunks, each as soon
                 # as the backward pass has written it (lemevit_amd/dist.py::FlatGradSync)

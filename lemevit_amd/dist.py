@@ -194,34 +194,15 @@ def attach_flat_grad_sync(model: torch.nn.Module, opt, nchunks: int = 4, group=N
                           compress: Optional[str] = None) -> FlatGradSync:
     """Wire a FlatAdamW-managed model for data parallelism: broadcast rank `src`'s parameters / buffers, cut the flat gradient
     buffer into `nchunks` runs of whole blocks and hook each run's all-reduce to the backward pass of its first block."""
-    from .model import LeMeBlock
-    blocks = [(name, mod) for name, mod in model.named_modules() if isinstance(mod, LeMeBlock)]
-    starts = {}
-    for pname, p, off, n in opt._slices:
-        for bname, _ in blocks:
-            if pname.startswith(bname + "."):
-                starts.setdefault(bname, off)
-                break
-    order = [b for b, _ in blocks if b in starts]                     # forward order = layout order of the flat buffer
-    total = opt._flat_g.numel()
-    offs = [starts[b] for b in order] + [total]
-    nchunks = max(1, min(nchunks, len(order)))
-    # Chunk sizes grow 1 : 2 : ... : nchunks in forward order: the backward pass completes the chunks last-to-first, so the big
-    # ones (late stages hold most of the parameters anyway) are exchanged under the rest of the backward pass and the one
-    # whose all-reduce cannot overlap anything -- the first blocks, differentiated last -- is the smallest.
-    tri = nchunks * (nchunks + 1) / 2
-    targets = [total * (j * (j + 1) / 2) / tri for j in range(1, nchunks)]
-    cuts = [0]
-    for i in range(1, len(order)):
-        if len(cuts) < nchunks and offs[i] >= targets[len(cuts) - 1]:
-            cuts.append(i)
-    bounds = [(offs[c], offs[cuts[j + 1]] if j + 1 < len(cuts) else total) for j, c in enumerate(cuts)]
+    from .optim import flat_chunk_plan
+    if getattr(opt, "_ov_bounds", None):
+        opt.disable_overlap()                                          # the all-reduce owns the chunk callbacks: the update waits for finish()
+    bounds, first = flat_chunk_plan(model, opt, nchunks)
     block_params = {id(p) for _, p, _, _ in opt._slices}
     rest = [p for p in model.parameters() if p.requires_grad and id(p) not in block_params]
     sync = FlatGradSync(opt._flat_g, bounds, rest, group, force, compress, opt=opt)
-    mods = dict(blocks)
-    for k, c in enumerate(cuts):                                       # chunk k is complete when its FIRST block has been differentiated
-        for p in mods[order[c]].parameters():
+    for k, blk in enumerate(first):                                    # chunk k is complete when its FIRST block has been differentiated
+        for p in blk.parameters():
             p._lmv_grad_cb = (lambda kk=k: sync.chunk_ready(kk))
     if sync.active:
         with torch.no_grad():

@@ -857,9 +857,10 @@ class _BlockFn(torch.autograd.Function):
             dx0, dc0 = block_backward(kind, ctx.saved, None if dx is None else dx.contiguous(), None if dc is None else dc.contiguous(), ctx.H, ctx.W, P, G, ctx.masks)
         cb = getattr(ctx.params[0], "_lmv_grad_cb", None) if inplace else None
         ctx.saved = ctx.params = None
-        if cb is not None or not inplace:
+        if (cb is not None and not getattr(cb, "_lmv_no_join", False)) or not inplace:
             # the parameter gradients leave this node now (all-reduce of the chunk / autograd's accumulation on the current stream):
-            # the deferred joins of the weight-gradient side stream (blocks.defer_join) are due
+            # the deferred joins of the weight-gradient side stream (blocks.defer_join) are due.  (A consumer that orders its own stream behind the side stream --
+            # FlatAdamW's overlapped update -- marks its callback `_lmv_no_join`: the main stream keeps going.)
             from . import blocks as _blocks
             _blocks._wait_pending(0, x0.device.index)
         if cb is not None:

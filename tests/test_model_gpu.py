@@ -748,6 +748,66 @@ def test_flat_grad_sync_single_rank_nccl():
             dist.destroy_process_group()
 
 
+def test_flat_adamw_overlapped_update_is_bit_identical():
+    """FlatAdamW(overlap=k): the update of a run of blocks is issued on a second stream as soon as the backward pass has finished the run.  Twin models,
+    three steps each, one with the overlapped update: every parameter, both moments and the bf16 operand copies bit-identical; the chunks must actually have been consumed
+    during the backward pass; zero_grad() may skip its fill only while the gradients are known to be zero; a second backward pass without a step is refused; accumulation under
+    no_overlap() matches the plain optimizer."""
+    Lm = L()
+    torch.manual_seed(0)
+    m1 = Lm.create_model("lemevit_tiny", num_classes=10, drop_path_rate=0.1).to(DEV).train()
+    m2 = Lm.create_model("lemevit_tiny", num_classes=10, drop_path_rate=0.1).to(DEV).train()
+    m2.load_state_dict(m1.state_dict())
+    o1 = Lm.FlatAdamW(m1, lr=1e-3, weight_decay=0.05)
+    o2 = Lm.FlatAdamW(m2, lr=1e-3, weight_decay=0.05, overlap=3)
+    assert len(o2._ov_bounds) == 3 and o2._ov_bounds[0][0] == 0 and o2._ov_bounds[-1][1] == o2._flat_g.numel()
+    x = torch.randn(4, 3, 64, 64, device=DEV); y = torch.randint(0, 10, (4,), device=DEV)
+
+    def one(m, o, accumulate=False):
+        torch.manual_seed(7)
+        with torch.autocast("cuda", torch.bfloat16):
+            loss = torch.nn.functional.cross_entropy(m(x), y)
+        if accumulate and o is o2:
+            with o.no_overlap():
+                loss.backward()
+        else:
+            loss.backward()
+
+    consumed = []
+    for it in range(4):
+        for m, o in ((m1, o1), (m2, o2)):
+            o.zero_grad(set_to_none=False)
+            if it == 2:                      # gradient accumulation: two micro-batches, the overlapped optimizer told to stand back
+                one(m, o, accumulate=True); one(m, o, accumulate=True)
+            else:
+                one(m, o)
+            if o is o2:
+                consumed.append(sum(o._ov_done))
+            o.step()
+            if o is o2 and it != 2:
+                assert float(o._flat_g.abs().max()) == 0.0          # every run zeroed behind its update
+    assert consumed == [3, 3, 0, 3], consumed
+    torch.cuda.synchronize()
+    for (n, p1), (_, p2) in zip(m1.named_parameters(), m2.named_parameters()):
+        assert torch.equal(p1, p2), (n, float((p1 - p2).abs().max()))
+    assert torch.equal(o1._exp_avg, o2._exp_avg) and torch.equal(o1._exp_avg_sq, o2._exp_avg_sq) and torch.equal(o1._shadow, o2._shadow)
+    assert int(o1._step_dev.item()) == int(o2._step_dev.item()) == 4
+    for (a1, b1), (a2, b2) in zip(o1._tpairs, o2._tpairs):
+        assert torch.equal(b1, b2)
+    # a training pass WITHOUT zero_grad() in between: not armed, step() applies everything
+    one(m2, o2); assert sum(o2._ov_done) == 0; o2.step()
+    # a chunk reached twice after one zero_grad() (a second backward pass over a retained graph): refused, not silently applied twice
+    o2.zero_grad(set_to_none=False)
+    one(m2, o2)
+    assert sum(o2._ov_done) == 3
+    with pytest.raises(RuntimeError, match="one backward pass per step"):
+        o2._chunk_ready(1)
+    o2.step()
+    from lemevit_amd import blocks as _blocks
+    _blocks.drain_deferred()
+    torch.cuda.synchronize()
+
+
 # ------------------------------------------------------------------------------------------------
 # dense-prediction backbone (SURVEY section 8, row f4)
 def _backbone(cfg, seed):

@@ -23,6 +23,9 @@
 #include <atomic>
 #include "stage_common.h"
 
+#ifndef DS_STG_ENTRY
+#define DS_STG_ENTRY 40      // bytes per entry of the dwconv staging image (32 of channels; DG::STG_E)
+#endif
 namespace {
 
 constexpr int DS_M = 16, DS_NSTAMP = 16;
@@ -60,7 +63,10 @@ template <int NW, int GW, int CTILES> struct DG {
   static constexpr int L_AO = L_H;
   static constexpr int L_STAT = L_XN + L_XN_BYTES, L_STAT_BYTES = NW * TOK * 8;
   static constexpr int L_TOTAL = L_STAT + L_STAT_BYTES;
-  static constexpr int STG_COLS = GW + 2, STG_ENT = (ROWS + 2) * STG_COLS, STG_WAVE = STG_ENT * 32;      // dwconv staging: [ROWS + 2][GW + 2] entries of 16 channels, bf16
+  // dwconv staging: [ROWS + 2][GW + 2] entries of 16 channels, bf16: 32 bytes in a 40-byte slot (round 5; csrc/sstage.hip, SS_STG_ROW: with packed entries the 16 lanes of a
+  // ds_read2_b64 lane group hit 4 banks, 8 p mod 32; 10 p mod 32 runs through all 16 even banks).  Every access to the image is 8 bytes wide.
+  static constexpr int STG_E = DS_STG_ENTRY;
+  static constexpr int STG_COLS = GW + 2, STG_ENT = (ROWS + 2) * STG_COLS, STG_WAVE = (STG_ENT * STG_E + 15) / 16 * 16;
   static_assert(NW * STG_WAVE <= L_STAT, "staging overlaps the statistics");
   // per-slot workspace
   static constexpr int MF_HEAD = 3 + KS;                                   // meta fragments per head: K2 | V2 d-tile 0 | V2 d-tile 1 | q~ [ks]
@@ -484,12 +490,13 @@ __global__ __launch_bounds__(64 * NW, 2) void dstage_kernel(const DsArgs a) {
 #pragma unroll
           for (int t = 0; t < NT; ++t) {
             const int s = 16 * t + li, y = s / GW, x = s - y * GW;
-            *reinterpret_cast<uint2*>(stg + ((y + 1) * G::STG_COLS + x + 1) * 32 + 8 * g) = make_uint2(pack_bf2(R[t][ct][0], R[t][ct][1]), pack_bf2(R[t][ct][2], R[t][ct][3]));
+            *reinterpret_cast<uint2*>(stg + ((y + 1) * G::STG_COLS + x + 1) * G::STG_E + 8 * g) = make_uint2(pack_bf2(R[t][ct][0], R[t][ct][1]), pack_bf2(R[t][ct][2], R[t][ct][3]));
           }
           // pad columns, and the rows beyond the image
           for (int e = l2; e < 2 * (ROWS + 2) * 2; e += 64) {          // (entry, 16-byte half)
             const int ent = e >> 1, row = ent >> 1, col = (ent & 1) * (GW + 1);
-            *reinterpret_cast<u32x4_t*>(stg + (row * G::STG_COLS + col) * 32 + (e & 1) * 16) = u32x4_t{0u, 0u, 0u, 0u};
+            *reinterpret_cast<uint2*>(stg + (row * G::STG_COLS + col) * G::STG_E + (e & 1) * 16) = make_uint2(0u, 0u);
+            *reinterpret_cast<uint2*>(stg + (row * G::STG_COLS + col) * G::STG_E + (e & 1) * 16 + 8) = make_uint2(0u, 0u);
           }
           // the row above (last grid row of workgroup role - 1) and below (first grid row of role + 1): 2 x 16-byte pieces per token
 #pragma unroll
@@ -508,7 +515,8 @@ __global__ __launch_bounds__(64 * NW, 2) void dstage_kernel(const DsArgs a) {
                 }
                 hv = v;
               }
-              *reinterpret_cast<u32x4_t*>(stg + (srow * G::STG_COLS + tok + 1) * 32 + 16 * q) = hv;
+              *reinterpret_cast<uint2*>(stg + (srow * G::STG_COLS + tok + 1) * G::STG_E + 16 * q) = make_uint2(hv[0], hv[1]);
+              *reinterpret_cast<uint2*>(stg + (srow * G::STG_COLS + tok + 1) * G::STG_E + 16 * q + 8) = make_uint2(hv[2], hv[3]);
             }
           }
           // tap weights: bf16 pairs (w, 0) / (0, w), packed by lmv_*stage_pack (stage_common.h): v_dot2c_f32_bf16 of a loaded channel pair with one of them is that channel's tap product,
@@ -521,19 +529,19 @@ __global__ __launch_bounds__(64 * NW, 2) void dstage_kernel(const DsArgs a) {
           uint2 f[2][9];
           auto tap_base = [&](int t) -> const unsigned char* {
             const int s = 16 * t + li, y = s / GW, x = s - y * GW;
-            return stg + (y * G::STG_COLS + x) * 32 + 8 * g;      // entry of the (-1, -1) neighbour
+            return stg + (y * G::STG_COLS + x) * G::STG_E + 8 * g;      // entry of the (-1, -1) neighbour
           };
           {
             const unsigned char* const tap0 = tap_base(0);
 #pragma unroll
-            for (int tap = 0; tap < 9; ++tap) f[0][tap] = *reinterpret_cast<const uint2*>(tap0 + ((tap / 3) * G::STG_COLS + tap % 3) * 32);
+            for (int tap = 0; tap < 9; ++tap) f[0][tap] = *reinterpret_cast<const uint2*>(tap0 + ((tap / 3) * G::STG_COLS + tap % 3) * G::STG_E);
           }
 #pragma unroll
           for (int t = 0; t < NT; ++t) {
             if (t + 1 < NT) {
               const unsigned char* const tap1 = tap_base(t + 1);
 #pragma unroll
-              for (int tap = 0; tap < 9; ++tap) f[(t + 1) & 1][tap] = *reinterpret_cast<const uint2*>(tap1 + ((tap / 3) * G::STG_COLS + tap % 3) * 32);
+              for (int tap = 0; tap < 9; ++tap) f[(t + 1) & 1][tap] = *reinterpret_cast<const uint2*>(tap1 + ((tap / 3) * G::STG_COLS + tap % 3) * G::STG_E);
             }
 #pragma unroll
             for (int tap = 0; tap < 9; ++tap) asm volatile("" : "+v"(f[t & 1][tap]));

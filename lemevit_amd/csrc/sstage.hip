@@ -69,7 +69,14 @@ template <int NW> struct SG {
   static constexpr size_t HALO_IMG = (size_t)2 * 14 * C * 2;      // [half][14 tokens][C] bf16
   static constexpr size_t PARK_IMG = (size_t)2 * NW * 21 * 1024;  // [half][wave][21 residual tiles][1 KB]: the fp32 residual registers, parked in L2 while k / v / q / attention run
 };
-constexpr int STG_ROW = 96, STG_WAVE = 160 * STG_ROW;                 // dwconv staging: per wave [10 grid rows][16 columns][48 channels] bf16 (over L_XN | L_H)
+// dwconv staging: per wave [10 grid rows][16 columns][48 channels] bf16 (over L_XN | L_H).  An entry is 96 bytes of channels in a 104-byte slot (round 5): the 16 lanes of a
+// ds_read2_b64 lane group read 8 bytes each of 16 CONSECUTIVE entries, and with the 24-dword stride of packed entries 24 p mod 32 takes 4 values -- a 4-way bank conflict on every
+// tap read, which is what the phase was made of (~1000 cycles per token tile for ~62 instructions; tools/native/icache_probe.hip ruled the instruction cache out).  26 p mod 32 runs
+// through all 16 even banks: conflict-free.  (104 is a multiple of 8 only: every access to the image is 8 bytes wide.)
+#ifndef SS_STG_ROW
+#define SS_STG_ROW 104
+#endif
+constexpr int STG_ROW = SS_STG_ROW, STG_WAVE = 160 * STG_ROW;
 static_assert(8 * STG_WAVE <= SG<8>::L_STAT && 4 * STG_WAVE <= SG<4>::L_STAT, "staging overlaps the statistics");
 // the geometry of SG<NW> under the names the code uses
 #define SS_GEO(NW)                                                                                                                                     \
@@ -431,7 +438,8 @@ __global__ __launch_bounds__(64 * NW, 2) void sstage_kernel(const SsArgs a) {
           if (p < 36 * 6) {
             const int e = p / 6, q = p - e * 6;
             const int idx = e < 20 ? (e >> 1) * 16 + (e & 1) * 15 : grow * 16 + (e - 20);
-            *reinterpret_cast<u32x4_t*>(stg + idx * STG_ROW + 16 * q) = u32x4_t{0u, 0u, 0u, 0u};
+            *reinterpret_cast<uint2*>(stg + idx * STG_ROW + 16 * q) = make_uint2(0u, 0u);
+            *reinterpret_cast<uint2*>(stg + idx * STG_ROW + 16 * q + 8) = make_uint2(0u, 0u);
           }
         }
       }
@@ -448,7 +456,8 @@ __global__ __launch_bounds__(64 * NW, 2) void sstage_kernel(const SsArgs a) {
           if (p < 84) {
             const int tok = p / 6, q = p - tok * 6;
             const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(hr, tok * SS_C * 2 + (48 * wave + 8 * q) * 2, 0, 16);
-            *reinterpret_cast<u32x4_t*>(stg + (hrow * 16 + tok + 1) * STG_ROW + 16 * q) = v;          // (the image is bf16, as the exchanged rows are)
+            *reinterpret_cast<uint2*>(stg + (hrow * 16 + tok + 1) * STG_ROW + 16 * q) = make_uint2(v[0], v[1]);          // (the image is bf16, as the exchanged rows are)
+            *reinterpret_cast<uint2*>(stg + (hrow * 16 + tok + 1) * STG_ROW + 16 * q + 8) = make_uint2(v[2], v[3]);
           }
         }
       }
@@ -479,7 +488,7 @@ __global__ __launch_bounds__(64 * NW, 2) void sstage_kernel(const SsArgs a) {
         auto tap_base = [&](int t) -> const unsigned char* {
           const int slot = 16 * t + li;
           const int sv = slot < nimg_slots ? slot : 0, y = sv / SS_G, x = sv - y * SS_G;
-          return stg + (y * 16 + x) * STG_ROW + 32 * ct + 8 * g;      // entry of the (-1, -1) neighbour; tap (dy, dx): + ((dy + 1) * 16 + dx + 1) * 96
+          return stg + (y * 16 + x) * STG_ROW + 32 * ct + 8 * g;      // entry of the (-1, -1) neighbour; tap (dy, dx): + ((dy + 1) * 16 + dx + 1) * STG_ROW
         };
         {
           const unsigned char* const tap0 = tap_base(0);

@@ -1,10 +1,6 @@
 #!/bin/bash
-# A/B of environment switches on the default bench line: usage  bash tools/ab_env.sh "VAR=1" ["VAR2=x" ...]   (first run: baseline)
-cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out
-python -c "import torch; print('stream priority range', torch.cuda.Stream.priority_range())" 2>/dev/null
-for e in "" "$@"; do
-  for i in 1 2; do
-    r=$(env $e python bench.py --no-cpu-baseline --no-kernel-timing --no-forward-probe --no-issue-probe --steps 20 --warmup 5 2>/dev/null | tail -1 | python -c "import sys,json; print(json.loads(sys.stdin.read())['ms_per_step'])")
-    echo "[$e] run $i: $r ms"
-  done
-done
+# Interleaved bench A/B over environment settings: ab_env.sh ROUNDS "VAR=a" "VAR=b" ... ("-" = no setting)
+cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
+R=$1; shift
+run() { s="$1"; [ "$s" = "-" ] && s="LMV_NOP=1"; echo "$1 $(env $s timeout 600 python bench.py --steps 30 --warmup 10 --no-cpu-baseline --no-kernel-timing --no-forward-probe --no-issue-probe 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(d['value'], d['ms_per_step'])")"; }
+for i in $(seq $R); do for s in "$@"; do run "$s"; done; done

@@ -14,6 +14,13 @@ __global__ void k(unsigned long long* out, float* sink, float seed) {
     if (OP == 2) { REP16(asm volatile("v_pk_fma_f32 %0, %0, %4, %0\n v_pk_fma_f32 %1, %1, %4, %1\n v_pk_fma_f32 %2, %2, %4, %2\n v_pk_fma_f32 %3, %3, %4, %3\n v_pk_fma_f32 %0, %0, %4, %0\n v_pk_fma_f32 %1, %1, %4, %1\n v_pk_fma_f32 %2, %2, %4, %2\n v_pk_fma_f32 %3, %3, %4, %3" : "+v"(*(double*)&a0), "+v"(*(double*)&a2), "+v"(*(double*)&a4), "+v"(*(double*)&a6) : "v"(*(double*)&w));) }
     if (OP == 3) { REP16(asm volatile("v_exp_f32 %0, %0\n v_exp_f32 %1, %1\n v_exp_f32 %2, %2\n v_exp_f32 %3, %3\n v_exp_f32 %4, %4\n v_exp_f32 %5, %5\n v_exp_f32 %6, %6\n v_exp_f32 %7, %7" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7));) }
     if (OP == 4) { REP16(asm volatile("v_cndmask_b32 %0, %0, %8, vcc\n v_cndmask_b32 %1, %1, %8, vcc\n v_cndmask_b32 %2, %2, %8, vcc\n v_cndmask_b32 %3, %3, %8, vcc\n v_lshlrev_b32 %4, 16, %4\n v_and_b32 %5, 0xffff0000, %5\n v_add_f32 %6, %6, %8\n v_cvt_pkrtz_f16_f32 %7, %7, %8" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(w) : "vcc");) }
+    if (OP == 5) { REP16(asm volatile("v_dot2c_f32_bf16 %0, %9, %8\n v_dot2c_f32_bf16 %1, %9, %8\n v_dot2c_f32_bf16 %2, %9, %8\n v_dot2c_f32_bf16 %3, %9, %8\n v_dot2c_f32_bf16 %4, %9, %8\n v_dot2c_f32_bf16 %5, %9, %8\n v_dot2c_f32_bf16 %6, %9, %8\n v_dot2c_f32_bf16 %7, %9, %8" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(w), "v"(h));) }
+    // one depth-wise tap of 4 channels (a loaded bf16 pair x 2) as the stage kernels issue it: 4 v_dot2c (8 instructions = 2 taps) ...
+    if (OP == 6) { REP16(asm volatile("v_dot2c_f32_bf16 %0, %9, %8\n v_dot2c_f32_bf16 %1, %9, %8\n v_dot2c_f32_bf16 %2, %4, %8\n v_dot2c_f32_bf16 %3, %4, %8\n v_dot2c_f32_bf16 %0, %5, %8\n v_dot2c_f32_bf16 %1, %5, %8\n v_dot2c_f32_bf16 %2, %6, %8\n v_dot2c_f32_bf16 %3, %6, %8" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(w), "v"(h));) }
+    // ... and as unpack + packed fp32 FMA: per tap 2 v_lshlrev + 2 v_and + 2 v_pk_fma (12 instructions = 2 taps)
+    if (OP == 7) { REP16(asm volatile("v_lshlrev_b32 %4, 16, %9\n v_and_b32 %5, 0xffff0000, %9\n v_lshlrev_b32 %6, 16, %8\n v_and_b32 %7, 0xffff0000, %8\n v_pk_fma_f32 %0, %2, %10, %0\n v_pk_fma_f32 %1, %3, %10, %1\n"
+                                      "v_lshlrev_b32 %4, 16, %9\n v_and_b32 %5, 0xffff0000, %9\n v_lshlrev_b32 %6, 16, %8\n v_and_b32 %7, 0xffff0000, %8\n v_pk_fma_f32 %0, %2, %10, %0\n v_pk_fma_f32 %1, %3, %10, %1"
+                                      : "+v"(*(double*)&a0), "+v"(*(double*)&a2), "+v"(*(double*)&a4), "+v"(*(double*)&a6), "+v"(w), "+v"(w), "+v"(w), "+v"(w) : "v"(w), "v"(h), "v"(*(double*)&w));) }
   }
   unsigned long long t1 = __builtin_amdgcn_s_memtime();
   if ((threadIdx.x & 63) == 0) out[blockIdx.x * 16 + (threadIdx.x >> 6)] = t1 - t0;
@@ -29,4 +36,5 @@ template <int OP> void run(const char* name, unsigned long long* out, float* sin
 int main() {
   unsigned long long* out; float* sink; hipMalloc(&out, 4096); hipMalloc(&sink, 4);
   run<0>("v_fma_f32", out, sink); run<1>("v_fma_mix_f32", out, sink); run<2>("v_pk_fma_f32", out, sink); run<3>("v_exp_f32", out, sink); run<4>("cndmask/shift/add/cvt mix", out, sink);
+  run<5>("v_dot2c_f32_bf16", out, sink); run<6>("dot2c taps (8 instr = 2 taps)", out, sink); run<7>("unpack + pk_fma (12 = 2 taps)", out, sink);
 }

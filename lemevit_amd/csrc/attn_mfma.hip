@@ -719,8 +719,11 @@ __device__ __forceinline__ void mfma_bwd_fused_body2(const AttnArgs& a, const in
       dv[i][0] = MFMA(gt0, pf, dv[i][0]); dv[i][1] = MFMA(gt1, pf, dv[i][1]);
       dk[i][0] = MFMA(qt0, dsf, dk[i][0]); dk[i][1] = MFMA(qt1, dsf, dk[i][1]);
       const uint4 w = __builtin_bit_cast(uint4, dsf);
-      *reinterpret_cast<uint2*>(sT(buf, wave, 0, i) + (lane & 15) * 32 + g * 8) = make_uint2(w.x, w.y);
-      *reinterpret_cast<uint2*>(sT(buf, wave, 1, i) + (lane & 15) * 32 + g * 8) = make_uint2(w.z, w.w);
+      // (8-byte piece g of key row (lane & 15) sits at position g ^ (row >> 2): the 16 lanes of a ds_write_b64 lane group share g, and with the pieces in place their rows hit 4
+      //  banks -- 16 LDS cycles per store instead of 4, 60 % of this loop's LDS time (tools/lds_conflicts.py); the transposing read below undoes it in its address)
+      const int wsl = (g ^ ((lane >> 2) & 3)) * 8;
+      *reinterpret_cast<uint2*>(sT(buf, wave, 0, i) + (lane & 15) * 32 + wsl) = make_uint2(w.x, w.y);
+      *reinterpret_cast<uint2*>(sT(buf, wave, 1, i) + (lane & 15) * 32 + wsl) = make_uint2(w.z, w.w);
     }
     __syncthreads();          // every key tile's dS of this block is in buffer `buf`
     {
@@ -731,9 +734,9 @@ __device__ __forceinline__ void mfma_bwd_fused_body2(const AttnArgs& a, const in
         const int kta = 2 * pp, ktb = 2 * pp + 1;
         if (kta * 16 >= Lk) continue;
         const bool has_b = ktb < NKT && ktb * 16 < Lk;
-        const bf16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds4_t)(sT(buf, kta & 3, qt_w, kta >> 2) + (g * 4 + rr) * 32 + qq * 8));
+        const bf16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds4_t)(sT(buf, kta & 3, qt_w, kta >> 2) + (g * 4 + rr) * 32 + (qq ^ g) * 8));          // (row >> 2 = g)
         bf16x4_t hi = {(__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f};
-        if (has_b) hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds4_t)(sT(buf, ktb & 3, qt_w, ktb >> 2) + (g * 4 + rr) * 32 + qq * 8));
+        if (has_b) hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds4_t)(sT(buf, ktb & 3, qt_w, ktb >> 2) + (g * 4 + rr) * 32 + (qq ^ g) * 8));
         const bf16x8_t dst = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
         dq = MFMA(ktf[pp], dst, dq);
       }

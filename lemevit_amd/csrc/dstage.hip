@@ -467,15 +467,15 @@ __global__ __launch_bounds__(64 * NW, 2) void dstage_kernel(const DsArgs a) {
         DS_PHASE
         unsigned char* const stg = smem + wave * G::STG_WAVE;
         const unsigned char* const hprev = halo + (size_t)((gb + 1) & 1) * (G::HALO_BYTES / 2);      // the rows published at the end of block gb - 1
+        float4 wq[2][10];          // (requested in front of the halo wait: csrc/sstage.hip)
+#pragma unroll
+        for (int e = 0; e < 9; ++e) wq[0][e] = *reinterpret_cast<const float4*>(vec + G::V_POSW + (CW * wave + 4 * g) * 9 + 4 * e);
+        wq[0][9] = *reinterpret_cast<const float4*>(vec + G::V_POSB + CW * wave + 4 * g);
         if (gb > 0 && KIND != 1) {
           // (block 0 of a later image reads its halo from x_in, but still waits: a workgroup must not run two blocks ahead of a neighbour that reads its rows)
           if (role > 0) wait_flag(haloflag + role - 1, (unsigned)gb, errflag, lane);
           if (role + 1 < KWG) wait_flag(haloflag + role + 1, (unsigned)gb, errflag, lane);
         }
-        float4 wq[2][10];
-#pragma unroll
-        for (int e = 0; e < 9; ++e) wq[0][e] = *reinterpret_cast<const float4*>(vec + G::V_POSW + (CW * wave + 4 * g) * 9 + 4 * e);
-        wq[0][9] = *reinterpret_cast<const float4*>(vec + G::V_POSB + CW * wave + 4 * g);
 #pragma unroll
         for (int ct = 0; ct < CT; ++ct) {
           int l2 = lane; asm volatile("" : "+v"(l2));

@@ -420,6 +420,12 @@ __global__ __launch_bounds__(64 * NW, 2) void sstage_kernel(const SsArgs a) {
       // 96 B per entry.  The row across the cut comes from the peer, the row beyond the grid and the two pad columns are zero-filled: every
       // tap is then an unconditional read at base + an immediate offset, no bounds masks (they were half of this phase's VALU work).
       unsigned char* const stg = smem + wave * STG_WAVE;
+      // the 4 x 9 tap weights + bias of the lane's channels, one channel tile ahead (an L2 round trip per tile otherwise); the first tile's are requested HERE, in front of
+      // the staging stores and the halo wait (round 5: behind them the first token tile of the phase waited ~2 k cycles for this round trip)
+      float4 wq[2][10];
+#pragma unroll
+      for (int e = 0; e < 9; ++e) wq[0][e] = *reinterpret_cast<const float4*>(vec + V_POSW + (48 * wave + 4 * g) * 9 + 4 * e);
+      wq[0][9] = *reinterpret_cast<const float4*>(vec + V_POSB + 48 * wave + 4 * g);
 #pragma unroll
       for (int t = 0; t < SS_NT; ++t) {
         const int slot = 16 * t + li;
@@ -462,10 +468,6 @@ __global__ __launch_bounds__(64 * NW, 2) void sstage_kernel(const SsArgs a) {
         }
       }
       SS_STAMP(14);
-      float4 wq[2][10];          // the 4 x 9 tap weights + bias of the lane's channels, one channel tile ahead (an L2 round trip per tile otherwise)
-#pragma unroll
-      for (int e = 0; e < 9; ++e) wq[0][e] = *reinterpret_cast<const float4*>(vec + V_POSW + (48 * wave + 4 * g) * 9 + 4 * e);
-      wq[0][9] = *reinterpret_cast<const float4*>(vec + V_POSB + 48 * wave + 4 * g);
 #pragma unroll
       for (int ct = 0; ct < 3; ++ct) {
         int l2 = lane; asm volatile("" : "+v"(l2));      // per-channel-tile copies: the per-token addresses are recomputed, not kept across the three passes

@@ -748,6 +748,45 @@ def test_flat_grad_sync_single_rank_nccl():
             dist.destroy_process_group()
 
 
+def test_flat_adamw_checkpoint_resume_is_bit_identical(tmp_path):
+    """Checkpoint / resume (the reference: timm's CheckpointSaver + resume_checkpoint, main.py:300-312): model.state_dict() + FlatAdamW.state_dict() saved with torch.save after two
+    steps and loaded into a FRESH model and optimizer must continue exactly like the uninterrupted run -- parameters, BatchNorm statistics, both moments, the step count (bias
+    correction) and the bf16 operand copies the kernels read."""
+    Lm = L()
+
+    def make():
+        torch.manual_seed(0)
+        m = Lm.create_model("lemevit_tiny", num_classes=10, drop_path_rate=0.1).to(DEV).train()
+        return m, Lm.FlatAdamW(m, lr=1e-3, weight_decay=0.05)
+
+    x = torch.randn(4, 3, 64, 64, device=DEV); y = torch.randint(0, 10, (4,), device=DEV)
+
+    def steps(m, o, first, n):
+        for i in range(first, first + n):
+            torch.manual_seed(100 + i)                  # DropPath draws of step i
+            o.zero_grad(set_to_none=False)
+            with torch.autocast("cuda", torch.bfloat16):
+                loss = torch.nn.functional.cross_entropy(m(x), y)
+            loss.backward(); o.step()
+
+    m1, o1 = make(); steps(m1, o1, 0, 4)
+    m2, o2 = make(); steps(m2, o2, 0, 2)
+    path = tmp_path / "ckpt.pt"
+    torch.save({"model": m2.state_dict(), "opt": o2.state_dict()}, path)
+    del m2, o2
+    torch.manual_seed(12345)                            # a different initialisation: everything must come from the file
+    m3 = Lm.create_model("lemevit_tiny", num_classes=10, drop_path_rate=0.1).to(DEV).train()
+    o3 = Lm.FlatAdamW(m3, lr=1e-3, weight_decay=0.05)
+    ck = torch.load(path, map_location=DEV)
+    m3.load_state_dict(ck["model"]); o3.load_state_dict(ck["opt"])
+    steps(m3, o3, 2, 2)
+    torch.cuda.synchronize()
+    for (k, a), (_, b) in zip(m1.state_dict().items(), m3.state_dict().items()):
+        assert torch.equal(a, b), (k, float((a.float() - b.float()).abs().max()))
+    assert torch.equal(o1._exp_avg, o3._exp_avg) and torch.equal(o1._exp_avg_sq, o3._exp_avg_sq) and torch.equal(o1._shadow, o3._shadow)
+    assert int(o1._step_dev.item()) == int(o3._step_dev.item()) == 4
+
+
 def test_flat_adamw_overlapped_update_is_bit_identical():
     """FlatAdamW(overlap=k): the update of a run of blocks is issued on a second stream as soon as the backward pass has finished the run.  Twin models,
     three steps each, one with the overlapped update: every parameter, both moments and the bf16 operand copies bit-identical; the chunks must actually have been consumed

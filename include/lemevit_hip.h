@@ -337,6 +337,16 @@ int lmv_transpose_batch(const lmv_transpose_seg* segs, int nsegs, int dtype, voi
  * lmv_col2im3x3s2_nhwc(lmv_linear_dx(dY, Wm)) its data gradient (a gather over the <= 4 output pixels that read an input pixel). */
 int lmv_im2col3x3s2_nhwc(const void* x, void* patches, int B, int H, int W, int C, int KP, int dtype, void* stream);
 int lmv_col2im3x3s2_nhwc(const void* dpatches, void* dx, int B, int H, int W, int C, int KP, int dtype, void* stream);
+/* The same convolution WITHOUT the patch matrix (round 6; bf16): an implicit GEMM -- the LDS-DMA loads of the GEMM kernels gather the patch elements straight from the
+ * NHWC map x [B, H, W, Cin] (zeros for the padding taps and for the columns behind 9 Cin), so the forward pass and the weight gradient read the map instead of writing and
+ * re-reading a [B Ho Wo, KP] matrix 2.25 x its size.  wm / dwm: [Cout, KP] in lmv_im2col3x3s2_nhwc's column order ((ky * 3 + kx) * Cin + ci), KP >= 9 Cin a multiple of 64;
+ * B Ho Wo must be a multiple of 64 (whole k-tiles of the weight gradient); y [B Ho Wo, Cout] = patches wm^T + bias (act: LMV_ACT_NONE / LMV_ACT_GELU);
+ * dwm += dy^T patches, dbias += column sums of dy (fp32, accumulated; split-K slabs in `workspace`, fixed summation order as lmv_linear_dw).  The data gradient stays
+ * lmv_linear_dx + lmv_col2im3x3s2_nhwc.  Replaces models/lemevit.py:701-703, :714-717 (nn.Conv2d(.., 3, 2, 1)). */
+int lmv_conv3x3s2_fwd(const void* x, const void* wm, const float* bias, void* y, int B, int H, int W, int Cin, int Cout, int KP, int act, int dtype, void* stream);
+size_t lmv_conv3x3s2_dw_workspace_bytes(int B, int H, int W, int Cin, int Cout, int KP, int dtype);
+int lmv_conv3x3s2_dw(const void* dy, const void* x, float* dwm, float* dbias, int B, int H, int W, int Cin, int Cout, int KP, void* workspace, size_t workspace_bytes, int dtype,
+                     void* stream);
 /* Classifier tail (models/lemevit.py:815-835, `x.flatten(2).mean(-1) + c.mean(1)`): out[b, :] = mean_l x[b, l, :] + mean_m c[b, m, :]
  * for token-major x [B, L, C] and c [B, M, C] (c may be NULL), out [B, C] in `dtype`; and its backward, the broadcast
  * dx[b, l, :] = g[b, :] / L, dc[b, m, :] = g[b, :] / M (dc may be NULL). */

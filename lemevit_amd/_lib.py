@@ -145,6 +145,9 @@ SIGNATURES = {
     "lmv_transpose_batch": (_I, [C.POINTER(TransposeSeg), _I, _I, _P]),
     "lmv_row_scale": (_I, [_P, _P, _P, _L, _I, _I, _I, _P]),
     "lmv_im2col3x3s2_nhwc": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "lmv_conv3x3s2_fwd": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "lmv_conv3x3s2_dw_workspace_bytes": (_Z, [_I, _I, _I, _I, _I, _I, _I]),
+    "lmv_conv3x3s2_dw": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _Z, _I, _P]),
     "lmv_col2im3x3s2_nhwc": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "lmv_token_mean2_fwd": (_I, [_P, _I, _P, _I, _I, _I, _P, _I, _P]),
     "lmv_token_mean2_affine_fwd": (_I, [_P, _I, _P, _I, _I, _I, _P, _P, _P, _I, _P]),

@@ -44,9 +44,10 @@ namespace {
 
 __device__ __forceinline__ void reduce_slabs_block(const ReduceSegDev& g, int blk, float4* red);
 
-template <typename T, bool ATR, bool BTR, bool SPLITK, int BK, bool DMA, typename CF, int MINW = 1, int NST = 2, bool LNP = false>
+template <typename T, bool ATR, bool BTR, bool SPLITK, int BK, bool DMA, typename CF, int MINW = 1, int NST = 2, bool LNP = false, bool CONV = false>
 __global__ __launch_bounds__(CF::NTHR, MINW) void gemm_kernel(const GemmArgs g) {
   static_assert(!LNP || (!ATR && !BTR && !SPLITK), "the LayerNorm-folded epilogue belongs to the forward contraction");
+  static_assert(!CONV || (DMA && ((!ATR && !BTR && !SPLITK) || (ATR && BTR && SPLITK))), "the implicit-GEMM convolution: the LDS-DMA forward and weight-gradient kernels");
   using RS = typename std::conditional<LNP, RowStat<CF::WM>, NoStat>::type;
   RS rstat;
   if constexpr (LNP) rstat.clear();
@@ -169,9 +170,15 @@ __global__ __launch_bounds__(CF::NTHR, MINW) void gemm_kernel(const GemmArgs g) 
       const bf16_t *A16, *B16; int kred, k0;
       src_of(kt, &A16, &B16, &kred, &k0);
 #pragma unroll
-      for (int q = 0; q < CF::PA; ++q) panel_dma<ATR, BK, CF::NW>(buf + q * PANEL_BYTES, A16, g.lda, M, m0 + q * PANEL, k0, lane, wave);
+      for (int q = 0; q < CF::PA; ++q) {
+        if constexpr (CONV && !SPLITK) panel_dma_conv<false, BK, CF::NW>(buf + q * PANEL_BYTES, g.cv, M, m0 + q * PANEL, k0, lane, wave);          // forward: the patch rows
+        else panel_dma<ATR, BK, CF::NW>(buf + q * PANEL_BYTES, A16, g.lda, M, m0 + q * PANEL, k0, lane, wave);
+      }
 #pragma unroll
-      for (int q = 0; q < CF::PB; ++q) panel_dma<BTR, BK, CF::NW>(buf + (CF::PA + q) * PANEL_BYTES, B16, g.ldb, N, n0 + q * PANEL, k0, lane, wave);
+      for (int q = 0; q < CF::PB; ++q) {
+        if constexpr (CONV && SPLITK) panel_dma_conv<true, BK, CF::NW>(buf + (CF::PA + q) * PANEL_BYTES, g.cv, N, n0 + q * PANEL, k0, lane, wave);      // weight gradient: the patch columns
+        else panel_dma<BTR, BK, CF::NW>(buf + (CF::PA + q) * PANEL_BYTES, B16, g.ldb, N, n0 + q * PANEL, k0, lane, wave);
+      }
     };
     if constexpr (CF::NW >= 8 && CF::WM == 2 && NST == 2) {
       // 8-wave kernels (64-deep k-tiles, 1.5x the fragment reads): the plain loop -- hipcc waits for the requested k-tile BEFORE this
@@ -496,10 +503,10 @@ int make_plan(const lmv_linear_problem* p, int nproblems, int N, int K, int act,
   return LMV_OK;
 }
 
-template <typename T, bool ATR, bool BTR, bool SPLITK, int BK, bool DMA, typename CF, int MINW = 1, int NST = 2, bool LNP = false>
+template <typename T, bool ATR, bool BTR, bool SPLITK, int BK, bool DMA, typename CF, int MINW = 1, int NST = 2, bool LNP = false, bool CONV = false>
 int launch_one(const GemmArgs& g, dim3 grid, hipStream_t st) {
   constexpr int lds = NST * (CF::PA + CF::PB) * PANEL * BK * (int)sizeof(T);
-  auto kern = gemm_kernel<T, ATR, BTR, SPLITK, BK, DMA, CF, MINW, NST, LNP>;
+  auto kern = gemm_kernel<T, ATR, BTR, SPLITK, BK, DMA, CF, MINW, NST, LNP, CONV>;
   // > 64 KiB of dynamic LDS needs an explicit opt-in, once per kernel AND device.  The call is idempotent, so two threads racing
   // through the first launch both make it; the per-device bit only publishes "done" (re-entrant, no lock).
   static std::atomic<unsigned long long> attr_done{0};
@@ -518,6 +525,15 @@ int launch_one(const GemmArgs& g, dim3 grid, hipStream_t st) {
 template <bool ATR, bool BTR, bool SPLITK>
 int launch_mode(const Plan& pl, dim3 grid, bool bf, hipStream_t st) {
   const GemmArgs& g = pl.g;
+  if (g.cv.on) {          // the implicit-GEMM convolution (lmv_conv3x3s2_fwd / _dw): bf16 LDS-DMA kernels only
+    if constexpr (ATR != BTR) { LMV_FAIL(LMV_ERR_SHAPE, "conv3x3s2: no data-gradient form"); }
+    else {
+      if (!bf || !pl.dma) LMV_FAIL(LMV_ERR_SHAPE, "conv3x3s2: bf16 with whole k-tiles only (rows and 9 Cin padded to a multiple of 64)");
+      if (pl.bk == 32) return launch_one<bf16_t, ATR, BTR, SPLITK, 32, true, C128, 3, 2, false, true>(g, grid, st);
+      if (pl.tile == TILE_128W8) return launch_one<bf16_t, ATR, BTR, SPLITK, 64, true, C128w8, 4, 2, false, true>(g, grid, st);
+      return launch_one<bf16_t, ATR, BTR, SPLITK, 64, true, C128, 1, 2, false, true>(g, grid, st);
+    }
+  }
   if (!bf) return launch_one<float, ATR, BTR, SPLITK, 32, false, C128>(g, grid, st);
   if (!pl.dma) return pl.bk == 64 ? launch_one<bf16_t, ATR, BTR, SPLITK, 64, false, C128>(g, grid, st)
                                   : launch_one<bf16_t, ATR, BTR, SPLITK, 32, false, C128>(g, grid, st);
@@ -532,14 +548,15 @@ int launch_mode(const Plan& pl, dim3 grid, bool bf, hipStream_t st) {
 }
 
 int launch(const lmv_linear_problem* p, int nproblems, int N, int K, int act, int dtype, void* stream, Mode mode, void* ws, size_t ws_bytes,
-           lmv_reduce_seg* segs = nullptr, int* nsegs = nullptr, const lmv_reduce_seg* pending = nullptr, int npending = 0) {
+           lmv_reduce_seg* segs = nullptr, int* nsegs = nullptr, const lmv_reduce_seg* pending = nullptr, int npending = 0, const ConvGeo* cv = nullptr) {
   Plan pl;
   if (int rc = make_plan(p, nproblems, N, K, act, dtype, mode, &pl)) return rc;      // (validates the operands)
-  if (mode == MODE_FWD && dtype == LMV_BF16 && lmv_config().gemm_rs && lmv_rs_eligible(p, nproblems, N, K, act, lmv_config().gemm_rs == 2)) {
+  if (cv) pl.g.cv = *cv;
+  if (!cv && mode == MODE_FWD && dtype == LMV_BF16 && lmv_config().gemm_rs && lmv_rs_eligible(p, nproblems, N, K, act, lmv_config().gemm_rs == 2)) {
     lmv_timing_set_kind(LMV_TK_RS_GEMM);          // (the open bracket of lmv_linear_fwd, if the probe is armed)
     return lmv_rs_linear(p, nproblems, N, K, act, (hipStream_t)stream);              // register-stationary kernel (rsgemm.hip)
   }
-  if (mode == MODE_FWD && dtype == LMV_BF16 && lmv_config().gemm_wn && lmv_wn_eligible(p, nproblems, N, K, act, lmv_config().gemm_wn == 2)) {
+  if (!cv && mode == MODE_FWD && dtype == LMV_BF16 && lmv_config().gemm_wn && lmv_wn_eligible(p, nproblems, N, K, act, lmv_config().gemm_wn == 2)) {
     lmv_timing_set_kind(LMV_TK_WN_GEMM);
     return lmv_wn_linear(p, nproblems, N, K, act, (hipStream_t)stream);              // whole-width kernel (wngemm.hip)
   }
@@ -690,6 +707,51 @@ extern "C" int lmv_linear_dw_chain(const lmv_linear_problem* p, int nproblems, i
       if (a < b + workspace_bytes && b < a + (size_t)pending[i].nslabs * pending[i].slab_stride * sizeof(float)) LMV_FAIL(LMV_ERR_SHAPE, "linear_dw_chain: the pending slabs overlap this launch's workspace");
     }
   return launch(p, nproblems, N, K, LMV_ACT_NONE, dtype, stream, MODE_DW, workspace, workspace_bytes, segs, nsegs, pending, npending);
+}
+
+// ---- Conv2d(Cin, Cout, 3, stride 2, padding 1) on an NHWC map as an implicit GEMM (models/lemevit.py:701-703, :714-717) ----------------------------------------------
+#ifndef LMV_TRY
+#define LMV_TRY(expr) do { const int rc__ = (expr); if (rc__) return rc__; } while (0)
+#endif
+namespace {
+int conv_geo(ConvGeo* cv, const void* x, int B, int H, int W, int Cin, int Cout, int KP, int dtype) {
+  if (dtype != LMV_BF16) LMV_FAIL(LMV_ERR_DTYPE, "conv3x3s2: bf16 only (fp32: lmv_im2col3x3s2_nhwc + lmv_linear_*)");
+  if (B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || (Cin % 8) || (Cout % 8) || KP < 9 * Cin || (KP % 64)) LMV_FAIL(LMV_ERR_SHAPE, "conv3x3s2: Cin, Cout multiples of 8, KP >= 9 Cin a multiple of 64");
+  const int Ho = (H + 1) / 2, Wo = (W + 1) / 2;
+  const int64_t rows = (int64_t)B * Ho * Wo;
+  if (rows % 64) LMV_FAIL(LMV_ERR_SHAPE, "conv3x3s2: B Ho Wo = %lld must be a multiple of 64 (whole k-tiles of the weight gradient)", (long long)rows);
+  if (rows >= (1 << 22) || KP >= (1 << 13) || Ho * Wo >= (1 << 13) * 64 || (int64_t)B * H * W * Cin >= (1LL << 31)) LMV_FAIL(LMV_ERR_SHAPE, "conv3x3s2: map too large for the 32-bit index arithmetic");
+  if (!x || !lmv_aligned16(x)) LMV_FAIL(LMV_ERR_SHAPE, "conv3x3s2: null / misaligned map");
+  *cv = ConvGeo{};
+  cv->on = 1; cv->H = H; cv->W = W; cv->Cin = Cin; cv->Ho = Ho; cv->Wo = Wo; cv->HoWo = Ho * Wo; cv->x = x;
+  auto magic = [](unsigned d) { return ((1ull << 40) + d - 1) / d; };
+  cv->m_cin = magic((unsigned)Cin); cv->m_wo = magic((unsigned)Wo); cv->m_howo = magic((unsigned)(Ho * Wo));
+  return LMV_OK;
+}
+}  // namespace
+extern "C" int lmv_conv3x3s2_fwd(const void* x, const void* wm, const float* bias, void* y, int B, int H, int W, int Cin, int Cout, int KP, int act, int dtype, void* stream) {
+  ConvGeo cv;
+  LMV_TRY(conv_geo(&cv, x, B, H, W, Cin, Cout, KP, dtype));
+  if (act != LMV_ACT_NONE && act != LMV_ACT_GELU) LMV_FAIL(LMV_ERR_SHAPE, "conv3x3s2_fwd: act must be NONE or GELU");
+  lmv_linear_problem p{};
+  p.a = x; p.w = wm; p.out = y; p.bias = bias; p.rows = (int64_t)B * cv.HoWo;          // (a: validated only -- the kernel gathers from cv.x)
+  const double rows = (double)p.rows;
+  LmvTimedLaunch timed(stream, 2.0 * Cout * 9.0 * Cin * rows, 2.0 * ((double)B * H * W * Cin + rows * Cout + (double)Cout * KP));
+  return launch(&p, 1, Cout, KP, act, dtype, stream, MODE_FWD, nullptr, 0, nullptr, nullptr, nullptr, 0, &cv);
+}
+extern "C" size_t lmv_conv3x3s2_dw_workspace_bytes(int B, int H, int W, int Cin, int Cout, int KP, int dtype) {
+  (void)Cin;
+  lmv_linear_problem p{};
+  p.a = p.w = p.out = (void*)16; p.rows = (int64_t)B * ((H + 1) / 2) * ((W + 1) / 2);
+  return lmv_linear_dw_workspace_bytes(&p, 1, Cout, KP, dtype);
+}
+extern "C" int lmv_conv3x3s2_dw(const void* dy, const void* x, float* dwm, float* dbias, int B, int H, int W, int Cin, int Cout, int KP, void* workspace, size_t workspace_bytes, int dtype,
+                                void* stream) {
+  ConvGeo cv;
+  LMV_TRY(conv_geo(&cv, x, B, H, W, Cin, Cout, KP, dtype));
+  lmv_linear_problem p{};
+  p.a = dy; p.w = x; p.out = dwm; p.bias_grad = dbias; p.rows = (int64_t)B * cv.HoWo;
+  return launch(&p, 1, Cout, KP, LMV_ACT_NONE, dtype, stream, MODE_DW, workspace, workspace_bytes, nullptr, nullptr, nullptr, 0, &cv);
 }
 
 extern "C" int lmv_reduce_batch(const lmv_reduce_seg* segs, int nsegs, void* stream) {

@@ -31,9 +31,19 @@ struct Problem {
 };
 // one slab (or partial-row) reduction: out[i] += sum_s ws[s][i] (gemm.hip: splitk_reduce_kernel, lmv_reduce_batch, and the reduction that rides in a weight-gradient launch)
 struct ReduceSegDev { const float* ws; float* out_w; float* out_b; int64_t stride, nw; int nslabs, nb, sl, blk0, kind, mode; };
+// Implicit-GEMM form of Conv2d(Cin, Cout, 3, stride 2, padding 1) on an NHWC map (round 6; lmv_conv3x3s2_fwd / _dw): the "patch matrix" operand [B Ho Wo, KP] (column
+// (ky * 3 + kx) * Cin + ci, zeros behind 9 Cin) is never materialised -- the LDS-DMA loads of a k-tile take their 16-byte pieces straight from the map (per-lane source address:
+// the panel image in LDS is the one the plain GEMM builds), padding taps and the pad columns from a page of zeros.  Divisions by Cin / Wo / Ho Wo are multiplications by
+// ceil(2^40 / d) (exact for n d < 2^40: n < 2^22 rows, d < 2^13).
+struct ConvGeo {
+  int on, H, W, Cin, Ho, Wo, HoWo, pad_;
+  unsigned long long m_cin, m_wo, m_howo;
+  const void* x;          // the map [B, H, W, Cin]
+};
 struct GemmArgs {
   Problem p[2];
   int nprob, N, lda, ldb, ldc, act, tiles_n, kt_per_split;
+  ConvGeo cv;
   int cumap;                     // fwd / dX: CU-aware tile order (see gemm_kernel)
   int ntiles, nsplits, concat;   // dW: tiles of dW, k-splits, and whether problem 1's rows extend problem 0's reduction
   float ln_eps;           // LayerNorm-folded forward (lmv_ln_linear_fwd): eps of the folded LayerNorm
@@ -124,6 +134,39 @@ __device__ __forceinline__ void panel_dma(unsigned char* panel, const bf16_t* __
     } else {
       const int r = sg * 4 + (lane >> 4), p16 = lane & 15, c16 = ((((p16 >> 1) ^ swz_t(r))) << 1) | (p16 & 1);
       src = base + (int64_t)(k0 + r) * ld + min(tile0 + c16 * 8, dim - 8);
+    }
+    __builtin_amdgcn_global_load_lds((glb_vp)src, (lds_vp)(panel + sg * 1024), 16, 0, 0);
+  }
+}
+
+// The same panel images, gathered from an NHWC map (ConvGeo): the operand element (row = output pixel, column k = tap * Cin + ci) is x[b, 2 oy + ky - 1, 2 ox + kx - 1, ci], zero
+// outside the map and for k >= 9 Cin.  A 16-byte piece (8 channels) never straddles a tap because Cin % 8 == 0.  Not TR: the forward operand (rows = pixels, reduction over k);
+// TR: the weight-gradient operand (reduction over pixels, columns = k).
+__device__ __attribute__((aligned(128))) unsigned lmv_zero_page[32];
+__device__ __forceinline__ unsigned cv_div(unsigned n, unsigned long long m) { return (unsigned)(((unsigned long long)n * m) >> 40); }
+__device__ __forceinline__ const bf16_t* cv_src(const ConvGeo& cv, int pixel, int k) {
+  const unsigned b = cv_div((unsigned)pixel, cv.m_howo), rem = (unsigned)pixel - b * (unsigned)cv.HoWo, oy = cv_div(rem, cv.m_wo), ox = rem - oy * (unsigned)cv.Wo;
+  const unsigned tap = cv_div((unsigned)k, cv.m_cin), ci = (unsigned)k - tap * (unsigned)cv.Cin, ky = (tap * 11u) >> 5, kx = tap - 3u * ky;
+  const int iy = 2 * (int)oy - 1 + (int)ky, ix = 2 * (int)ox - 1 + (int)kx;
+  const bool ok = tap < 9u && (unsigned)iy < (unsigned)cv.H && (unsigned)ix < (unsigned)cv.W;
+  const int64_t off = ((int64_t)((int)b * cv.H + iy) * cv.W + ix) * cv.Cin + (int)ci;
+  return ok ? reinterpret_cast<const bf16_t*>(cv.x) + off : reinterpret_cast<const bf16_t*>(lmv_zero_page);
+}
+template <bool TR, int BK, int NW>
+__device__ __forceinline__ void panel_dma_conv(unsigned char* panel, const ConvGeo& cv, int dim, int tile0, int k0, int lane, int wave) {
+  constexpr int NSEG = PANEL * BK * 2 / 1024;
+  static_assert(NSEG % NW == 0, "segments must divide over the waves");
+#pragma unroll
+  for (int i = 0; i < NSEG / NW; ++i) {
+    const int sg = wave + i * NW;
+    const bf16_t* src;
+    if (!TR) {
+      constexpr int ROWB = BK * 2, CPR = ROWB / 16, RPS = 1024 / ROWB;
+      const int r = sg * RPS + lane / CPR, p = lane % CPR, kc = p ^ swz_n<ROWB>(r);
+      src = cv_src(cv, min(tile0 + r, dim - 1), k0 + kc * 8);
+    } else {
+      const int r = sg * 4 + (lane >> 4), p16 = lane & 15, c16 = ((((p16 >> 1) ^ swz_t(r))) << 1) | (p16 & 1);
+      src = cv_src(cv, k0 + r, min(tile0 + c16 * 8, dim - 8));
     }
     __builtin_amdgcn_global_load_lds((glb_vp)src, (lds_vp)(panel + sg * 1024), 16, 0, 0);
   }

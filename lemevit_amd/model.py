@@ -218,31 +218,39 @@ class _Conv3x3s2Fn(torch.autograd.Function):
         Co = weight.shape[0]
         xh = x.detach().permute(0, 2, 3, 1).to(cd).contiguous()            # NHWC; no copy for channels-last input of the right dtype
         KP = (9 * Ci + 63) // 64 * 64 if cd == torch.bfloat16 else 9 * Ci  # bf16: whole 64-deep k-steps (the GEMM's LDS-DMA path)
-        patches = ops.im2col3x3s2_nhwc(xh, KP)
         Wm = _conv_matrix(weight, cd, KP)
         Ho, Wo = (H + 1) // 2, (W + 1) // 2
-        y = torch.empty(B * Ho * Wo, Co, device=x.device, dtype=cd)
         b32 = None if bias is None else compute_copy(bias, torch.float32)
-        ops.linear_fwd([Prob(patches, Wm, y, bias=b32)], Co, KP)
-        ctx.save_for_backward(patches, Wm)
-        ctx.meta = (x.shape, x.dtype, weight.shape, weight.dtype, None if bias is None else bias.dtype)
+        implicit = _CONV_IMPLICIT and ops.conv3x3s2_implicit_ok(xh, Co, KP)
+        if implicit:          # round 6: the GEMM gathers the patch elements from the map -- no patch matrix is written, read back, or kept for the backward pass
+            y = ops.conv3x3s2_fwd(xh, Wm, b32)
+            ctx.save_for_backward(xh, Wm)
+        else:
+            patches = ops.im2col3x3s2_nhwc(xh, KP)
+            y = torch.empty(B * Ho * Wo, Co, device=x.device, dtype=cd)
+            ops.linear_fwd([Prob(patches, Wm, y, bias=b32)], Co, KP)
+            ctx.save_for_backward(patches, Wm)
+        ctx.meta = (x.shape, x.dtype, weight.shape, weight.dtype, None if bias is None else bias.dtype, implicit)
         return y.view(B, Ho, Wo, Co).permute(0, 3, 1, 2)                    # NCHW-shaped, channels-last-strided: no copy
 
     @staticmethod
     def backward(ctx, dy):
         patches, Wm = ctx.saved_tensors
-        (B, Ci, H, W), xdt, wshape, wdt, bdt = ctx.meta
+        (B, Ci, H, W), xdt, wshape, wdt, bdt, implicit = ctx.meta
         Co, KP = Wm.shape
         g = dy.permute(0, 2, 3, 1).contiguous().view(-1, Co)
         if g.dtype != patches.dtype:
             g = g.to(patches.dtype)
         dwm = torch.zeros(Co, KP, device=g.device, dtype=torch.float32)
         db = torch.zeros(Co, device=g.device, dtype=torch.float32)
-        ops.linear_dw([Prob(g, patches, dwm, bias_grad=db)], Co, KP)
+        if implicit:
+            ops.conv3x3s2_dw(g, patches, dwm, db)          # (`patches` is the NHWC map here)
+        else:
+            ops.linear_dw([Prob(g, patches, dwm, bias_grad=db)], Co, KP)
         dw = dwm[:, :9 * Ci].reshape(Co, 3, 3, Ci).permute(0, 3, 1, 2).to(wdt)
         dx = None
         if ctx.needs_input_grad[0]:
-            dp = torch.empty_like(patches)
+            dp = torch.empty(g.shape[0], KP, device=g.device, dtype=g.dtype)
             ops.linear_dx([Prob(g, Wm, dp)], Co, KP)
             dx = ops.col2im3x3s2_nhwc(dp, B, H, W, Ci).permute(0, 3, 1, 2).to(xdt)
         return dx, dw, (None if bdt is None else db.to(bdt)), None
@@ -255,6 +263,7 @@ def _is_conv3x3s2(m: nn.Module, x: Tensor) -> bool:
 
 
 _CONV_NATIVE = os.environ.get("LMV_CONV_NATIVE", "1") != "0"          # A/B testing against MIOpen
+_CONV_IMPLICIT = os.environ.get("LMV_CONV_IMPLICIT", "1") != "0"      # 0: the patch-matrix form of the 3 x 3 / stride-2 convolutions (im2col + GEMM; A/B runs)
 
 
 class _BNActFn(torch.autograd.Function):
@@ -912,6 +921,8 @@ class _LaunchContext(threading.local):
 
 launches = _LaunchContext()
 _DSTAGE = os.environ.get("LMV_DSTAGE", "1") != "0"        # 0: stages of D blocks on the per-block schedule (A/B runs)
+_INFER_SIDE = os.environ.get("LMV_INFER_SIDE", "1") != "0"        # inference: the meta-token MLP of a stage on a forked stream next to its transition convolution (0: in line)
+_INFER_TAIL_PARTS = int(os.environ.get("LMV_INFER_TAIL_PARTS", "2"))      # inference: sub-batches of the per-launch stages behind the last persistent stage kernel (1: whole batch)
 _sstage_cache: dict = {}
 
 
@@ -1462,43 +1473,81 @@ class LeMeViT(nn.Module):
         hoist = c is None
         if hoist:
             c = self.meta_tokens.unsqueeze(0)
-        xt, H, W = None, 0, 0
-        checked = False
-        all_masks = self._draw_drop_path(B, x.device)
-        for i in range(self.num_stages):
-            if i == 0 or not isinstance(self.downsample_layers[i], nn.Identity):
-                x = self._run_downsample(self.downsample_layers[i], x if xt is None else self._to_nchw(xt, H, W))
+        infer = not (self.training or torch.is_grad_enabled())
+        st = {"cd": cd, "masks": self._draw_drop_path(B, x.device), "head": head, "checked": False, "infer": infer,
+              # inference concurrency inside ONE pass (round 6): the meta-token MLP of a stage next to its transition convolution, and the per-launch stages behind the last
+              # persistent stage kernel as sub-batches on forked streams.  Off inside graph.split_forward (its sub-batches already fill the streams a process holds).
+              "side": infer and _INFER_SIDE and launches.concurrent == 1 and x.is_cuda,
+              "tail_parts": _INFER_TAIL_PARTS if (infer and launches.concurrent == 1 and x.is_cuda and B >= 32) else 1,
+              "key": (tuple(x.shape[1:]), cd), "whole": [False] * self.num_stages}
+        out = self._stages_from(0, x, None, 0, 0, c, hoist, st)
+        if infer and launches.concurrent == 1:
+            self.__dict__.setdefault("_whole_seen", {})[st["key"]] = tuple(st["whole"])          # which stages ran as persistent launches at this input shape: where the next pass may split
+        return out
+
+    def _meta_tokens_for(self, i: int, c: Tensor, hoist: bool, B: int, cd: torch.dtype) -> Tensor:
+        """The meta tokens entering stage i: meta_token_downsample[i] (models/lemevit.py:731-743, :812, :819)."""
+        mlp = self.meta_token_downsample[i]
+        pre = None
+        if hoist and not torch.is_grad_enabled() and not self.training:
+            # inference: the first meta-token MLP sees the learned meta tokens only (models/lemevit.py:731-743, :812, :833) -- a constant of the weights, cached per parameter version
+            plist = [self.meta_tokens] + list(mlp.parameters())
+            stamp = (_train_pass, cd) + tuple(p._version for p in plist) + tuple(p.data_ptr() for p in plist)
+            ent = getattr(self, "_meta0_cache", None)
+            if ent is not None and ent[0] == stamp:
+                pre = ent[1]
+        if pre is not None:
+            c = pre
+        elif _is_meta_mlp(mlp, c, cd):
+            l1, n1, _, l2, n2 = mlp
+            c = _MetaMLPFn.apply(c, l1.weight, l1.bias, n1.weight, n1.bias, l2.weight, l2.bias, n2.weight, n2.bias, n1.eps, n2.eps, cd)
+        else:
+            c = mlp(c)
+        if pre is None and hoist and not torch.is_grad_enabled() and not self.training:
+            self._meta0_cache = (stamp, c.detach())
+            _cache_filled()
+        if hoist:
+            c = c.expand(B, -1, -1)
+        return c.to(cd).contiguous()
+
+    def _stages_from(self, i0: int, x: Optional[Tensor], xt: Optional[Tensor], H: int, W: int, c: Tensor, hoist: bool, st: dict) -> Tensor:
+        """Stages i0 .. end and the classifier tail.  x: the NCHW input image (i0 = 0); xt: the token-major map leaving stage i0 - 1."""
+        cd, head = st["cd"], st["head"]
+        B = x.shape[0] if xt is None else xt.shape[0]
+        for i in range(i0, self.num_stages):
+            down = i == 0 or not isinstance(self.downsample_layers[i], nn.Identity)
+            if st["tail_parts"] > 1 and i > i0 and xt is not None:
+                seen = self.__dict__.get("_whole_seen", {}).get(st["key"])
+                if seen is not None and seen[i - 1] and not any(seen[i:]):
+                    return self._tail_split(i, xt, H, W, c, st)
+            cur = torch.cuda.current_stream(c.device) if st["side"] else None
+            if st["side"] and down and i > 0 and not hoist:
+                # the meta tokens of stage i only need the meta tokens of stage i - 1: their MLP (four small launches) runs on a forked stream next to the transition convolution
+                from .blocks import aux_streams
+                side = aux_streams(c.device, 1)[0]
+                side.wait_stream(cur)
+                with torch.cuda.stream(side):
+                    c_in, c = c, self._meta_tokens_for(i, c, False, B, cd)
+                    c_in.record_stream(side)
+                x = self._run_downsample(self.downsample_layers[i], self._to_nchw(xt, H, W))
                 xt, H, W = self._to_tokens(x, cd)
-            mlp = self.meta_token_downsample[i]
-            pre = None
-            if hoist and not torch.is_grad_enabled() and not self.training:
-                # inference: the first meta-token MLP sees the learned meta tokens only (models/lemevit.py:731-743, :812, :833) -- a constant of the weights, cached per parameter version
-                plist = [self.meta_tokens] + list(mlp.parameters())
-                stamp = (_train_pass, cd) + tuple(p._version for p in plist) + tuple(p.data_ptr() for p in plist)
-                ent = getattr(self, "_meta0_cache", None)
-                if ent is not None and ent[0] == stamp:
-                    pre = ent[1]
-            if pre is not None:
-                c = pre
-            elif _is_meta_mlp(mlp, c, cd):
-                l1, n1, _, l2, n2 = mlp
-                c = _MetaMLPFn.apply(c, l1.weight, l1.bias, n1.weight, n1.bias, l2.weight, l2.bias, n2.weight, n2.bias, n1.eps, n2.eps, cd)
+                cur.wait_stream(side)
+                c.record_stream(cur)
             else:
-                c = mlp(c)
-            if pre is None and hoist and not torch.is_grad_enabled() and not self.training:
-                self._meta0_cache = (stamp, c.detach())
-                _cache_filled()
-            if hoist:
-                c = c.expand(B, -1, -1)
-                hoist = False
-            c = c.to(cd).contiguous()
+                if down:
+                    x = self._run_downsample(self.downsample_layers[i], x if xt is None else self._to_nchw(xt, H, W))
+                    xt, H, W = self._to_tokens(x, cd)
+                c = self._meta_tokens_for(i, c, hoist, B, cd)
+            hoist = False
             whole = _sstage_applies(self.stages[i], xt, c, H, W)
             if whole is not None:
-                if not checked:          # the verdict on the stage launches of EARLIER calls (pinned host word: no synchronisation): a lost hand-off raises here, late but never silently
+                st["whole"][i] = True
+                if not st["checked"]:          # the verdict on the stage launches of EARLIER calls (pinned host word: no synchronisation): a lost hand-off raises here, late but never silently
                     ops.check_stage_errors("found by LeMeViT.forward_features; raised by an earlier call", sync=False)
-                    checked = True
+                    st["checked"] = True
                 xt, c = _whole_stage_fwd(whole, xt.contiguous(), c, _sstage_packed(self.stages[i], whole), H, W)
                 continue
+            all_masks = st["masks"]
             with image_ranges(xt.device, B):
                 prev = None
                 for blk in self.stages[i]:
@@ -1506,6 +1555,38 @@ class LeMeViT(nn.Module):
                     xt, c = blk.forward_tokens(xt, c, H, W, masks=mk, prev=prev)
                     # the next block's backward pass writes ITS input gradients pre-multiplied by this block's MLP-half DropPath vectors (S / D blocks: masks 1 and 3)
                     prev = (mk[1], mk[3]) if (mk is not None and blk.kind in ("S", "D") and mk[1] is not None and mk[3] is not None) else None
+        return self._tail(xt, H, W, c, st)
+
+    def _tail_split(self, i: int, xt: Tensor, H: int, W: int, c: Tensor, st: dict) -> Tensor:
+        """Inference: stages i .. end run per launch (no persistent stage kernel takes them: stage 4 of every variant) -- short launches that under-fill the chip, each paying its ramp
+        and its tail.  The images of a batch do not interact in eval mode, so the rest of the pass runs as sub-batches on forked streams (graph.split_forward's argument, applied only
+        where it pays: behind the last persistent launch)."""
+        from .blocks import aux_streams
+        parts = max(1, min(st["tail_parts"], xt.shape[0]))
+        cur = torch.cuda.current_stream(xt.device)
+        xs, cs = xt.chunk(parts), c.chunk(parts)
+        streams = aux_streams(xt.device, len(xs) - 1)
+        sub = dict(st, tail_parts=1, side=False)
+        fork = cur.record_event()
+        fills = cache_fills()
+        ys = [self._stages_from(i, None, xs[0].contiguous(), H, W, cs[0].contiguous(), False, sub)]
+        cold = cache_fills() != fills          # sub-batch 0 filled an operand cache on the current stream: the others wait for all of it (graph.split_forward)
+        for k, s in enumerate(streams):
+            if cold:
+                s.wait_stream(cur)
+            else:
+                s.wait_event(fork)
+            with torch.cuda.stream(s):
+                ys.append(self._stages_from(i, None, xs[k + 1].contiguous(), H, W, cs[k + 1].contiguous(), False, sub))
+            xt.record_stream(s); c.record_stream(s)
+        for s, y in zip(streams, ys[1:]):
+            cur.wait_stream(s)
+            y.record_stream(cur)
+        return torch.cat(ys)
+
+    def _tail(self, xt: Tensor, H: int, W: int, c: Tensor, st: dict) -> Tensor:
+        cd, head = st["cd"], st["head"]
+        B = xt.shape[0]
         bn = self.norm
         if head is not False and isinstance(self.pre_logits, nn.Identity) and (self.training or torch.is_grad_enabled()) and _tail_native(self.norm_c, head, xt, c, cd):
             # training: final BatchNorm (native kernels) -> LayerNorm(c) + both mean-pools + add (+ classifier) as ONE autograd node

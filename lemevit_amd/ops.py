@@ -536,6 +536,33 @@ def im2col3x3s2_nhwc(x: Tensor, KP: int) -> Tensor:
     return out
 
 
+def conv3x3s2_implicit_ok(x: Tensor, Cout: int, KP: int) -> bool:
+    """Whether lmv_conv3x3s2_fwd / _dw take this NHWC map (bf16, whole k-tiles): else the patch-matrix form (im2col3x3s2_nhwc + linear_*)."""
+    B, H, W, C_ = x.shape
+    rows = B * ((H + 1) // 2) * ((W + 1) // 2)
+    return (x.is_cuda and x.dtype == torch.bfloat16 and C_ % 8 == 0 and Cout % 8 == 0 and KP % 64 == 0 and KP >= 9 * C_ and rows % 64 == 0 and rows < (1 << 22) and KP < (1 << 13)
+            and x.numel() < (1 << 31))
+
+
+def conv3x3s2_fwd(x: Tensor, wm: Tensor, bias: Optional[Tensor], act: int = ACT_NONE) -> Tensor:
+    """Conv2d(Cin, Cout, 3, stride 2, padding 1) of the NHWC map x [B, H, W, Cin] as an implicit GEMM (no patch matrix): -> [B * Ho * Wo, Cout].
+    wm [Cout, KP]: column (ky * 3 + kx) * Cin + ci (model._conv_matrix)."""
+    B, H, W, C_ = x.shape
+    Co, KP = wm.shape
+    y = torch.empty(B * ((H + 1) // 2) * ((W + 1) // 2), Co, device=x.device, dtype=x.dtype)
+    check(lib.lmv_conv3x3s2_fwd(_ptr(x), _ptr(wm), None if bias is None else _f32(bias), _ptr(y), B, H, W, C_, Co, KP, act, dtype_code(x), _stream()), "lmv_conv3x3s2_fwd")
+    return y
+
+
+def conv3x3s2_dw(dy: Tensor, x: Tensor, dwm: Tensor, dbias: Optional[Tensor]) -> None:
+    """dwm [Cout, KP] += dy^T patches(x), dbias += column sums of dy (fp32, accumulated) -- the weight gradient of conv3x3s2_fwd, gathered from the map."""
+    B, H, W, C_ = x.shape
+    Co, KP = dwm.shape
+    st = _stream()
+    ws = _workspace(lib.lmv_conv3x3s2_dw_workspace_bytes(B, H, W, C_, Co, KP, dtype_code(x)), x.device, st)
+    check(lib.lmv_conv3x3s2_dw(_ptr(dy), _ptr(x), _f32(dwm), None if dbias is None else _f32(dbias), B, H, W, C_, Co, KP, ws.data_ptr(), ws.numel(), dtype_code(x), st), "lmv_conv3x3s2_dw")
+
+
 def col2im3x3s2_nhwc(dpatches: Tensor, B: int, H: int, W: int, C_: int) -> Tensor:
     """Gradient of im2col3x3s2_nhwc: [B * Ho * Wo, KP] -> [B, H, W, C]."""
     dx = torch.empty((B, H, W, C_), device=dpatches.device, dtype=dpatches.dtype)

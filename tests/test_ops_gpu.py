@@ -531,6 +531,42 @@ def test_conv3x3s2_native(dtype, B, Ci, Co, H, W):
     assert_close(bg.grad, b64.grad, torch.float32, "conv db", tol32=2e-5)
 
 
+@pytest.mark.parametrize("B,Ci,Co,H,W", [(2, 48, 96, 112, 112), (8, 96, 192, 56, 56), (16, 192, 384, 28, 28), (64, 384, 512, 14, 14), (64, 64, 128, 9, 7), (64, 8, 16, 5, 6),
+                                         (128, 24, 40, 3, 3)])
+def test_conv3x3s2_implicit(B, Ci, Co, H, W):
+    """Round 6: the same convolutions as an implicit GEMM (lmv_conv3x3s2_fwd / _dw: the LDS-DMA loads gather the patch elements from the NHWC map; no patch matrix).  Forward and
+    weight / bias gradient against float64 F.conv2d on the rounded operands, and BIT-identical to the patch-matrix form (the same panel images reach the same kernel); odd maps
+    exercise the padding taps, the ragged last row / column and the zero columns behind 9 Cin (Cin = 8, 24: several taps per 16-byte-chunk row; Cin = 24: taps straddle k-tiles)."""
+    import lemevit_amd.model as M
+    from lemevit_amd.model import _Conv3x3s2Fn
+    dtype = torch.bfloat16
+    x, x64 = rnd((B, Ci, H, W), "cix", dtype); w32 = det_tensor((Co, Ci, 3, 3), "ciw", 7, 1.0 / math.sqrt(9 * Ci)); b32 = det_tensor((Co,), "cib", 7, 0.3)
+    wq = w32.to(dtype).double()
+    res = {}
+    for implicit in (True, False):
+        was, M._CONV_IMPLICIT = M._CONV_IMPLICIT, implicit
+        try:
+            xg = x.contiguous(memory_format=torch.channels_last).requires_grad_(True)
+            wg = w32.to(dev()).requires_grad_(True); bg = b32.to(dev()).requires_grad_(True)
+            y = _Conv3x3s2Fn.apply(xg, wg, bg, dtype)
+            assert ops().conv3x3s2_implicit_ok(xg.detach().permute(0, 2, 3, 1), Co, (9 * Ci + 63) // 64 * 64), "the shape list is meant to take the implicit form"
+            gy, gy64 = rnd(tuple(y.shape), "cigy", dtype)
+            (y.float() * gy.float()).sum().backward()
+            res[implicit] = (y.detach().clone(), xg.grad.clone(), wg.grad.clone(), bg.grad.clone())
+        finally:
+            M._CONV_IMPLICIT = was
+    x64 = x64.requires_grad_(True); w64 = wq.clone().requires_grad_(True); b64 = b32.double().requires_grad_(True)
+    ref = torch.nn.functional.conv2d(x64, w64, b64, stride=2, padding=1)
+    (ref * gy64).sum().backward()
+    y, dx, dw, db = res[True]
+    assert_close(y, ref.detach(), dtype, "implicit conv fwd")
+    assert_close(dw, w64.grad, torch.float32, "implicit conv dw", tol32=2e-5 * 4)
+    assert_close(db, b64.grad, torch.float32, "implicit conv db", tol32=2e-5)
+    assert_close(dx, x64.grad, dtype, "implicit conv dx", tol16=4e-3)
+    for a, b, what in zip(res[True], res[False], ("y", "dx", "dw", "db")):
+        assert torch.equal(a, b), f"implicit vs patch-matrix form: {what} differs by {float((a.float() - b.float()).abs().max()):.3e}"
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 def test_layernorm_bwd_two_call_form(dtype):
     """lmv_layernorm_bwd_partial + lmv_layernorm_bwd_reduce (the native block scheduler runs the reduce on its side stream) are

@@ -57,10 +57,10 @@ def parse():
     ap.add_argument("--force-sync", action="store_true", help="run the FlatGradSync collectives even at world size 1 (1-rank process group)")
     ap.add_argument("--force-ddp", action="store_true", help="wrap in DDP (and use the DDP code path) even at world size 1: measures the wrapper's overhead")
     ap.add_argument("--torch-adamw", action="store_true", help="use torch.optim.AdamW(fused=True) instead of lemevit_amd.FlatAdamW at N=1")
-    ap.add_argument("--grad-wire", default="auto", choices=["auto", "fp32", "bf16"], help="N > 1 with FlatGradSync: element type of the gradient all-reduce.  auto = bf16 "
-                    "(106 MB instead of 212 MB per step over xGMI, SURVEY 8(e) / row f3; the reference's own DDP path has no compression: --grad-wire fp32 reproduces its byte count)")
-    ap.add_argument("--adamw-overlap", type=int, default=int(os.environ.get("LMV_ADAMW_OVERLAP", "0")), help="N = 1, FlatAdamW: issue the update of the block parameters in this many chunks "
-                    "DURING the backward pass, each as soon as its gradients are final (lemevit_amd.FlatAdamW(overlap=k)); 0 = one launch behind the backward pass")
+    ap.add_argument("--grad-wire", default="auto", choices=["auto", "fp32", "bf16"], help="N > 1 with FlatGradSync: element type of the gradient all-reduce.  auto = fp32, the reference's DDP byte count "
+                    "(212 MB per step; main.py:333 has no compression) -- the like-for-like scaling line; bf16 halves the bytes over xGMI (SURVEY 8(e) / row f3), opt-in")
+    ap.add_argument("--print-csrc-hash", action="store_true", help="print the content hash of the kernel sources (lemevit_amd/csrc, include/) and exit: the PMC scripts under tools/ "
+                    "store it in the profiles/*_traffic.json files they write, and this program only quotes such a file while the hash still matches the tree it runs from")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--no-issue-probe", action="store_true", help="skip the 5 synchronised single steps that measure host issue time (profiling runs: "
                     "they would sit in the 'last steps' window of a kernel trace)")
@@ -194,8 +194,40 @@ def pick_infer_parts(model, x, use_graph, candidates=(1, 2, 4)):
     return best, table
 
 
+def csrc_hash() -> str:
+    """sha256 over the kernel sources the library is built from (names + contents, sorted): ties a committed PMC figure to the code it was measured on.
+    (`git rev-parse HEAD:lemevit_amd/csrc` would do on the build host, but the GPU box receives the tree without .git.)"""
+    import glob, hashlib
+    h = hashlib.sha256()
+    files = sorted(glob.glob(os.path.join(ROOT, "lemevit_amd", "csrc", "*.hip")) + glob.glob(os.path.join(ROOT, "lemevit_amd", "csrc", "*.h")) +
+                   glob.glob(os.path.join(ROOT, "include", "*.h")) + [os.path.join(ROOT, "lemevit_amd", "csrc", "Makefile")])
+    for f in files:
+        h.update(os.path.relpath(f, ROOT).encode()); h.update(b"\0")
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+        h.update(b"\0")
+    return h.hexdigest()[:16]
+
+
+def _matching(path: str):
+    """The JSON object of a committed PMC file if it was measured on THIS tree's kernel sources, else None (with a note on stderr)."""
+    try:
+        with open(path) as f:
+            d = json.load(f)
+    except Exception as e:
+        print(f"bench.py: cannot read {path}: {e}", file=sys.stderr)
+        return None
+    if d.get("csrc_hash") != csrc_hash():
+        print(f"bench.py: {os.path.relpath(path, ROOT)} was measured on kernel sources {d.get('csrc_hash')} but this tree is {csrc_hash()}: not quoted (re-run the PMC passes)", file=sys.stderr)
+        return None
+    return d
+
+
 def main():
     args = parse()
+    if args.print_csrc_hash:
+        print(csrc_hash())
+        return
     if args.cpu_baseline_protocol:
         return cpu_baseline_protocol(args.cpu_baseline_protocol)
     if args.graph < 0:
@@ -251,12 +283,12 @@ def main():
         if not use_ddp and not args.torch_adamw:
             # the framework's optimizer: block parameters flat, gradients written in place, one fused AdamW launch that also
             # refreshes the bf16 operand copies (same update rule; tests/test_model_gpu.py::test_flat_adamw_matches_torch_adamw)
-            opt = lemevit_amd.FlatAdamW(model, lr=1e-4, eps=1e-8, weight_decay=0.05, overlap=0 if (world > 1 or args.force_sync) else args.adamw_overlap)
+            opt = lemevit_amd.FlatAdamW(model, lr=1e-4, eps=1e-8, weight_decay=0.05)
             if world > 1 or args.force_sync:
                 # data parallelism without a DDP wrapper: the flat block-gradient buffer is all-reduced in 4 large chunks, each as soon
                 # as the backward pass has written it (lemevit_amd/dist.py::FlatGradSync)
                 from lemevit_amd.dist import attach_flat_grad_sync
-                wire = "bf16" if args.grad_wire in ("auto", "bf16") else None
+                wire = "bf16" if args.grad_wire == "bf16" else None
                 gsync = attach_flat_grad_sync(model, opt, force=args.force_sync, compress=wire)
         else:
             opt = torch.optim.AdamW([dict(params=decay, weight_decay=0.05), dict(params=no_decay, weight_decay=0.0)], lr=1e-4, eps=1e-8, fused=True,
@@ -288,7 +320,6 @@ def main():
         torch.cuda.synchronize()
 
     from lemevit_amd import ops as _ops
-    stage_errors = 0
 
     def check_handoffs(where):
         # A persistent stage kernel whose in-launch wait ran out has produced wrong tensors: that must be an exception here, not a normal-looking bench line
@@ -469,28 +500,38 @@ def main():
             import glob
             cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_gemm_fwd_pmc_traffic.json")))      # the newest COMMITTED round (r03's file never left gpurun_out/)
             cands_dw = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_gemm_dw_pmc_traffic.json")))
+            # (each file carries the content hash of the kernel sources it was measured on -- csrc_hash() -- and is only quoted while it matches this tree: a kernel change without
+            #  a new PMC pass leaves `traffic` null instead of a stale figure)
             if gkind == 5 and train and args.model == "lemevit_base" and args.img == 224 and args.batch == 128 and cands_dw:
-                with open(cands_dw[-1]) as f:
-                    traffic = round(json.load(f)["traffic_bytes_per_launch"] / 1e6, 2)
-                traffic_src = (f"canned: profiles/{os.path.basename(cands_dw[-1])} (MB per launch of gemm_kernel<bf16, TR, TR, split-K> over this command's train step, separate rocprofv3 --pmc "
-                               "FETCH_SIZE / WRITE_SIZE passes, tools/pmc_traffic.sh; NOT measured in this run)")
+                d_ = _matching(cands_dw[-1])
+                if d_ is not None:
+                    traffic = round(d_["traffic_bytes_per_launch"] / 1e6, 2)
+                    traffic_src = (f"profiles/{os.path.basename(cands_dw[-1])}, measured on these kernel sources (csrc_hash {csrc_hash()}): MB per launch of gemm_kernel<bf16, TR, TR, split-K> "
+                                   "over this command's train step, separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, tools/pmc_traffic.sh; not collected in this run")
             elif gkind == 0 and train and args.model == "lemevit_base" and args.img == 224 and args.batch == 128 and cands:
                 pmc = cands[-1]
-                with open(pmc) as f:
-                    traffic = round(json.load(f)["traffic_bytes_per_launch"] / 1e6, 2)
-                traffic_src = (f"canned: profiles/{os.path.basename(pmc)} (MB per launch over the forward-form Linear launches -- gemm_kernel<bf16,NT>, rs_gemm_kernel, "
-                               "wn_gemm_kernel -- of this command's train step, separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, tools/pmc_traffic.sh; NOT measured "
-                               "in this run; that launch set also holds the dX launches that run as forward-form GEMMs on transposed weights)")
+                d_ = _matching(pmc)
+                if d_ is not None:
+                    traffic = round(d_["traffic_bytes_per_launch"] / 1e6, 2)
+                    traffic_src = (f"profiles/{os.path.basename(pmc)}, measured on these kernel sources (csrc_hash {csrc_hash()}): MB per launch over the forward-form Linear launches -- "
+                                   "gemm_kernel<bf16,NT>, rs_gemm_kernel, wn_gemm_kernel -- of this command's train step, separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, "
+                                   "tools/pmc_traffic.sh; not collected in this run; that launch set also holds the dX launches that run as forward-form GEMMs on transposed weights")
             elif gkind == 1 and not train and args.model == "lemevit_base" and args.img == 224 and args.batch == 128:
                 # the persistent stage-3 launch: per-kernel PMC table of the same command (tools/pmc_kernels.sh; one launch = the whole batch)
                 cands_k = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_pmc_per_kernel_infer.csv")))
-                if cands_k:
+                hash_ok = False
+                if cands_k and os.path.exists(cands_k[-1] + ".csrc_hash"):
+                    with open(cands_k[-1] + ".csrc_hash") as f:
+                        hash_ok = f.read().strip() == csrc_hash()
+                if cands_k and not hash_ok:
+                    print(f"bench.py: {os.path.basename(cands_k[-1])} carries no matching csrc_hash: roofline.traffic stays null", file=sys.stderr)
+                if cands_k and hash_ok:
                     import csv
                     with open(cands_k[-1]) as f:
                         for row in csv.DictReader(f):
                             if row["kernel"].startswith("sstage_kernel<8>"):
                                 traffic = round(float(row["fetch_MB_per_launch(x2_corrected)"]) + float(row["write_MB_per_launch"]), 1)
-                                traffic_src = (f"canned: profiles/{os.path.basename(cands_k[-1])} (whole-batch launch; FETCH_SIZE x 2 + WRITE_SIZE at the L2-fabric boundary: it counts the write-through "
+                                traffic_src = (f"profiles/{os.path.basename(cands_k[-1])}, measured on these kernel sources (csrc_hash {csrc_hash()}) (whole-batch launch; FETCH_SIZE x 2 + WRITE_SIZE at the L2-fabric boundary: it counts the write-through "
                                                "K / V and halo exchanges and the parked residual registers of the launch -- MALL-absorbable traffic, DESIGN 4.9 -- not only the algorithmic tokens + weights)")
             elif train and gkind == 0:
                 print("bench.py: no profiles/rNN_gemm_fwd_pmc_traffic.json for this workload: roofline.traffic stays null", file=sys.stderr)
@@ -521,9 +562,22 @@ def main():
             "model_tflops": None if gflop is None else round(value * gflop * mult / 1e3, 2),
             "model_frac_of_bf16_peak": None if gflop is None else round(value * gflop * mult / 1e3 / (PEAK_BF16_TFLOPS * world), 4),
             "roofline": roof,
-            "stage_errors": stage_errors, "ranks_seen": ranks_seen, "device_uuids": device_uuids,
-            "grad_wire": None if not (train and world > 1) else ("torch DDP bf16 hook" if (args.ddp or args.force_ddp) else ("bf16" if args.grad_wire in ("auto", "bf16") else "fp32")),
+            # the sticky error word of the persistent stage kernels, READ here (pinned host memory; every region above ended in a synchronise + check that raises on a non-zero
+            # word, so a line is only printed with 0 -- but it is the counter, not a literal)
+            "stage_errors": _ops.stage_error_count(reset=False, sync=False), "ranks_seen": ranks_seen, "device_uuids": device_uuids,
+            "grad_wire": None if not (train and world > 1) else ("torch DDP bf16 hook" if (args.ddp or args.force_ddp) else ("bf16" if args.grad_wire == "bf16" else "fp32")),
         }
+        # HBM traffic of the WHOLE step over its wall time: bytes per step from the newest committed PMC pass over this command (tools/pmc_step_traffic.sh: FETCH_SIZE x 2 +
+        # WRITE_SIZE summed over every kernel of a step), quoted only while it was measured on these kernel sources
+        if world == 1 and args.model == "lemevit_base" and args.img == 224 and args.batch == 128:
+            import glob
+            cands_s = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_train_hbm_traffic.json" if train else "r[0-9][0-9]_infer_hbm_traffic.json")))
+            d_ = _matching(cands_s[-1]) if cands_s else None
+            if d_ is not None:
+                line["hbm_step_mb"] = round(d_["hbm_mb_per_step"], 1)
+                line["hbm_step_gbs"] = round(d_["hbm_mb_per_step"] / 1e3 / (dt / args.steps), 1)
+                line["hbm_step_frac_of_8tbs"] = round(line["hbm_step_gbs"] / 8000.0, 4)
+                line["hbm_step_source"] = f"profiles/{os.path.basename(cands_s[-1])} (csrc_hash {csrc_hash()}) / this run's ms_per_step"
         if fwd_dt is not None:
             fv = args.batch * world * fwd_iters / fwd_dt
             line["forward_images_per_sec"] = round(fv, 2)

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define LMV_ABI_VERSION 11
+#define LMV_ABI_VERSION 12
 
 enum { LMV_F32 = 0, LMV_BF16 = 1 };
 enum {
@@ -44,10 +44,10 @@ enum {
 
 int lmv_abi_version(void);
 const char* lmv_last_error(void);
-/* Tuning switches (A/B runs, parity tests of alternative code paths).  The LMV_* environment variables are read ONCE when the library
- * is loaded -- never on a launch path; these two change / read a switch at run time.  Keys: "gemm_bk", "gemm_bk32_tiles", "dw_bk",
+/* Tuning switches (A/B runs, parity tests of alternative code paths): these two change / read a switch at run time.  Five of them are also read from the environment, ONCE, when
+ * the library is loaded -- never on a launch path: LMV_GEMM_W8, LMV_GEMM_RS, LMV_GEMM_WN, LMV_DW_TARGET_BLOCKS, LMV_STAGE_TICKET_SKEW.  Keys: "gemm_bk", "gemm_bk32_tiles", "dw_bk",
  * "dw_target_blocks", "gemm_no_dma", "gemm_w8", "gemm_cumap", "gemm_nst", "gemm_nst_dw", "gemm_rs", "dwconv_v", "mlp_tm", "attn_pv16",
- * "attn_fuse_dq", "attn_fused_bwd", "attn_pair", "ln_bwd_blocks", "ln_bwd_minrows", "stage_ticket_skew" (test switch), "dw_chain" (lemevit_amd/csrc/common.h: LmvConfig).
+ * "attn_fuse_dq", "attn_fused_bwd", "attn_pair", "ln_bwd_blocks", "ln_bwd_minrows", "stage_ticket_skew" (test switch) (lemevit_amd/csrc/common.h: LmvConfig).
  * Process-wide, not synchronised: set them between launches. */
 int lmv_config_set(const char* key, int value);
 int lmv_config_get(const char* key, int* value);
@@ -108,14 +108,6 @@ typedef struct {
 int lmv_linear_dw_partial(const lmv_linear_problem* p, int nproblems, int N, int K, void* workspace, size_t workspace_bytes, int dtype, void* stream,
                           lmv_reduce_seg* segs, int* nsegs);
 int lmv_reduce_batch(const lmv_reduce_seg* segs, int nsegs, void* stream);
-/* lmv_linear_dw_partial with the slab sums of EARLIER launches riding in the same launch (round 5): `pending` (<= 2 LMV_REDUCE_SLABS segments returned by a previous
- * lmv_linear_dw_partial / _chain call on the SAME stream, whose slabs lie outside `workspace`) is summed by extra workgroups at the tail of this launch's grid -- the
- * same summation tree as lmv_reduce_batch / lmv_linear_dw: bit-identical gradients -- while the launch leaves its own slabs in `workspace` and describes them in
- * segs / nsegs for the next call (or for lmv_reduce_batch behind the last one).  lmv_block_bwd can chain the weight-gradient GEMMs of a block this way over two alternating
- * slab regions (LMV_DW_CHAIN=1: ~160 reduce launches per train step leave the weight-gradient stream); measured 0.2 - 0.3 ms per step SLOWER than a reduce launch behind every
- * GEMM on LeMeViT-Base, so that stays the default.  bf16 launches only. */
-int lmv_linear_dw_chain(const lmv_linear_problem* p, int nproblems, int N, int K, void* workspace, size_t workspace_bytes, int dtype, void* stream,
-                        const lmv_reduce_seg* pending, int npending, lmv_reduce_seg* segs, int* nsegs);
 
 /* ------------------------------------------------------------------------------------------
  * Fused block entry points (`ln_linear`, `mlp_fused`, `attn_out_proj_residual`).
@@ -251,9 +243,6 @@ int lmv_dwconv3x3_residual_fwd(const void* x, const float* weight, const float* 
                                int B, int H, int W, int C, int dtype, void* stream);
 int lmv_dwconv3x3_residual_bwd_data(const void* dy, const float* weight, void* dx,
                                     int B, int H, int W, int C, int dtype, void* stream);
-/* ... and a second output dx_scaled[b, ...] = dx[b, ...] * scale[b] (fp32 [B]; the product of the ROUNDED dx, i.e. what lmv_row_scale(dx) gives) from the same launch:
- * lmv_block_bwd uses it to hand the previous block of a stage its DropPath-scaled output gradient (lmv_block_desc.out_scale). */
-int lmv_dwconv3x3_residual_bwd_data_scaled(const void* dy, const float* weight, void* dx, void* dx_scaled, const float* scale, int B, int H, int W, int C, int dtype, void* stream);
 size_t lmv_dwconv3x3_bwd_weight_workspace_bytes(int B, int H, int W, int C, int dtype);
 int lmv_dwconv3x3_bwd_weight(const void* dy, const void* x, float* dweight, float* dbias,
                              int B, int H, int W, int C, void* workspace, size_t workspace_bytes, int dtype, void* stream);
@@ -413,13 +402,6 @@ typedef struct lmv_block_desc {
    * TRANSPOSED [C, 3C] / [C, C] in `dtype`.  With them lmv_block_bwd runs the dX of fc1 / qkv / proj as forward-form GEMMs
    * dY [rows, N] x wt^T -> [rows, C], which the whole-width kernel (csrc/wngemm.hip) takes for C = 384.  Same values as the weights. */
   const void* fc1_wt; const void* attn_wt[2];
-  /* Round 5 (ABI 11), optional (NULL = absent), S / D blocks in lmv_block_bwd: DropPath scaling handed ACROSS the block boundary.  The backward pass of a block starts by
-   * multiplying the gradients of its outputs by its MLP-half DropPath vectors (masks[1] for x, masks[3] for c: 32 row-scale launches per LeMeViT-Base step on the critical stream).
-   * With out_scale / dx_scaled / dc_scaled the block that PRODUCES those gradients -- the next block of the stage -- also writes them multiplied by out_scale[0] (x) / out_scale[1] (c),
-   * per sample, from its closing depth-wise-convolution and LayerNorm-1 backward launches; the consuming block passes them as g_pre[0] / g_pre[1] and skips its row-scale launch.
-   * g_pre[s] must equal dx_out / dc_out times masks[1] / masks[3] (dx_scaled: the rounded dx times the scale, as lmv_row_scale; dc_scaled: the fp32 value times the scale, rounded once); either g_pre entry may be NULL (that stream is scaled here as before). */
-  const float* out_scale[2]; void* dx_scaled; void* dc_scaled;
-  const void* g_pre[2];
 } lmv_block_desc;
 size_t lmv_block_arena_bytes(const lmv_block_desc* d);
 size_t lmv_block_bwd_scratch_bytes(const lmv_block_desc* d);

@@ -17,7 +17,7 @@ LIB_PATH = os.environ.get("LMV_LIB_PATH") or os.path.join(_HERE, "csrc", "liblem
 
 LMV_F32, LMV_BF16 = 0, 1
 ACT_NONE, ACT_GELU, ACT_GELU_GRAD = 0, 1, 2
-ABI_VERSION = 11
+ABI_VERSION = 12
 
 
 class LinearProblem(C.Structure):
@@ -64,8 +64,7 @@ class BlockDesc(C.Structure):
                 [(n, C.c_void_p) for n in ("g_pos_w", "g_pos_b", "g_n1_w", "g_n1_b")] + [("g_attn_w", C.c_void_p * 4), ("g_attn_b", C.c_void_p * 4)] +
                 [(n, C.c_void_p) for n in ("g_n2_w", "g_n2_b", "g_fc1_w", "g_fc1_b", "g_fc2_w", "g_fc2_b")] +
                 [("fold_attn_w", C.c_void_p * 2), ("fold_attn_s", C.c_void_p * 2), ("fold_attn_b", C.c_void_p * 2)] +
-                [(n, C.c_void_p) for n in ("fold_fc1_w", "fold_fc1_s", "fold_fc1_b", "fc2_wt", "fc1_wt")] + [("attn_wt", C.c_void_p * 2)] +
-                [("out_scale", C.c_void_p * 2), ("dx_scaled", C.c_void_p), ("dc_scaled", C.c_void_p), ("g_pre", C.c_void_p * 2)])
+                [(n, C.c_void_p) for n in ("fold_fc1_w", "fold_fc1_s", "fold_fc1_b", "fc2_wt", "fc1_wt")] + [("attn_wt", C.c_void_p * 2)])
 
 
 class SStageBlockParams(C.Structure):
@@ -101,7 +100,6 @@ SIGNATURES = {
     "lmv_linear_dw": (_I, [C.POINTER(LinearProblem), _I, _I, _I, _P, _Z, _I, _P]),
     "lmv_linear_dw_partial": (_I, [C.POINTER(LinearProblem), _I, _I, _I, _P, _Z, _I, _P, C.POINTER(ReduceSeg), C.POINTER(C.c_int)]),
     "lmv_reduce_batch": (_I, [C.POINTER(ReduceSeg), _I, _P]),
-    "lmv_linear_dw_chain": (_I, [C.POINTER(LinearProblem), _I, _I, _I, _P, _Z, _I, _P, C.POINTER(ReduceSeg), _I, C.POINTER(ReduceSeg), C.POINTER(C.c_int)]),
     "lmv_ln_fold": (_I, [_P, _P, _P, _P, _I, _I, _P, _P, _P, _I, _P]),
     "lmv_ln_linear_fwd": (_I, [C.POINTER(LinearProblem), _I, _I, _I, _F, _I, _I, _P]),
     "lmv_mlp_fused_supported": (_I, [_I, _I, _I]),
@@ -127,7 +125,6 @@ SIGNATURES = {
     "lmv_batchnorm_train_bwd": (_I, [_P, _P, _P, _P, _P, _I, _P, _P, _P, _L, _I, _P, _Z, _I, _P]),
     "lmv_dwconv3x3_residual_fwd": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "lmv_dwconv3x3_residual_bwd_data": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P]),
-    "lmv_dwconv3x3_residual_bwd_data_scaled": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "lmv_dwconv3x3_bwd_weight_workspace_bytes": (_Z, [_I, _I, _I, _I, _I]),
     "lmv_dwconv3x3_bwd_weight": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P, _Z, _I, _P]),
     "lmv_dwconv3x3_bwd_weight_partial": (_I, [_P, _P, _I, _I, _I, _I, _P, _Z, C.POINTER(C.c_int), _I, _P]),

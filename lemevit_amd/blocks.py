@@ -102,7 +102,7 @@ def aux_streams(dev, n: int) -> list:
 
 # The split-K reductions of a block's weight gradients are deferred (ops.DwBatch) and summed by ONE launch at the end of the block's
 # backward pass instead of one ~7 us launch behind every GEMM (LMV_DW_BATCH=0: the per-GEMM path, for A/B runs).
-_DW_BATCH = os.environ.get("LMV_DW_BATCH", "0") != "0"      # measured: 0.5 ms SLOWER per step (the slabs of a whole block leave the MALL before they are read back)
+_DW_BATCH = False      # (a module attribute for A/B runs, no environment switch) measured: 0.5 ms SLOWER per step (the slabs of a whole block leave the MALL before they are read back)
 _batches: Dict[tuple, "ops.DwBatch"] = {}
 
 
@@ -204,7 +204,7 @@ def _join() -> None:
 # The meta-token self-attention of an S block (16 tokens: B * h tiny workgroups, ~13 us of mostly launch ramp and tail per
 # direction) is independent of the image-token attention next to it: it is launched on a SECOND side stream by raw handle and
 # joined before the projection that consumes both, so it runs inside the image-token kernel's shadow.
-_META_SIDE = os.environ.get("LMV_META_SIDE_STREAM", "0") != "0"      # measured: 0.3 ms SLOWER per step (4 stream-wait API calls per block for ~20 us of hidden kernels); kept as an A/B switch
+_META_SIDE = False      # (a module attribute for A/B runs, no environment switch) measured: 0.3 ms SLOWER per step (4 stream-wait API calls per block for ~20 us of hidden kernels); kept as an A/B switch
 _meta_streams: Dict[int, tuple] = {}
 
 

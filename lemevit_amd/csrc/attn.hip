@@ -489,7 +489,6 @@ extern "C" int lmv_attn_fwd_pair(const lmv_attn_desc* d, void* ws, size_t ws_byt
 extern "C" int lmv_attn_bwd_pair(const lmv_attn_desc* d, void* ws, size_t ws_bytes, int dtype, void* stream) {
   for (int i = 0; i < 2; ++i)
     if (int rc = check_desc(d + i, dtype, true)) return rc;
-  if (lmv_config().dbg_skip_attn_bwd) return LMV_OK;          // (timing probe only: what the step would gain if this launch were free -- gradients are garbage)
   LmvTimedLaunch timed(stream, attn_flops(d, true) + attn_flops(d + 1, true), attn_bytes(d, dtype, true) + attn_bytes(d + 1, dtype, true), LMV_TK_ATTN_BWD);
   if (dtype == LMV_BF16) {
     const Args a1 = to_args(d), a2 = to_args(d + 1);
@@ -512,7 +511,6 @@ extern "C" int lmv_attn_fwd(const lmv_attn_desc* d, void* ws, size_t ws_bytes, i
 }
 extern "C" int lmv_attn_bwd(const lmv_attn_desc* d, void* ws, size_t ws_bytes, int dtype, void* stream) {
   if (int rc = check_desc(d, dtype, true)) return rc;
-  if (lmv_config().dbg_skip_attn_bwd) return LMV_OK;
   LmvTimedLaunch timed(stream, attn_flops(d, true), attn_bytes(d, dtype, true), LMV_TK_ATTN_BWD);
   return dtype == LMV_BF16 ? bwd_impl<bf16_t>(d, ws, ws_bytes, (hipStream_t)stream) : bwd_impl<float>(d, ws, ws_bytes, (hipStream_t)stream);
 }

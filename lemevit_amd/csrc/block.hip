@@ -183,13 +183,6 @@ struct Side {
   // and +0.8 ms per train step (round 3).
   void* ws_tail; size_t ws_tail_bytes;         // region of the side workspace behind the weight-gradient slabs (dwconv tap sums)
   lmv_reduce_seg segs[LMV_REDUCE_MAX_SEGS]; int nsegs = 0;
-  // Round 5, measured and NOT adopted (LMV_DW_CHAIN=1 switches it on): the slab sums of a weight-gradient GEMM ride in the NEXT weight-gradient launch of the block
-  // (lmv_linear_dw_chain: extra workgroups at the tail of its grid) over two alternating halves of `ws`, the last GEMM's slabs join the block's closing lmv_reduce_batch -- ~160
-  // reduce launches per step leave the side stream, gradients bit-identical, and the step gets 0.2 - 0.3 ms SLOWER (0.4 with the reduce workgroups at the head of the grid; three
-  // interleaved A/B rounds): the short reduce launches were filling gaps between the main stream's kernels, and two live slab regions double the MALL footprint.  Default: a
-  // reduce launch behind every GEMM.
-  bool chain = false; int flip = 0;
-  lmv_reduce_seg pend[2]; int npend = 0;
   hipStream_t begin() {           // the stream a weight-gradient launch goes to, made to wait for everything enqueued on `main` so far
     if (!side) return main;
     (void)hipEventRecord(fork, main);
@@ -247,24 +240,11 @@ EventPool& event_pool() { static EventPool p; return p; }
 
 int dw(Side& sd, const lmv_linear_problem* p, int np, int N, int K, int dtype) {
   const size_t need = lmv_linear_dw_workspace_bytes(p, np, N, K, dtype);
-  const size_t half = sd.ws_bytes / 2 & ~(size_t)255;
-  if (need > (sd.chain ? half : sd.ws_bytes)) LMV_FAIL(LMV_ERR_WORKSPACE, "block_bwd: weight-gradient workspace %zu > %zu bytes", need, sd.chain ? half : sd.ws_bytes);
-  if (!sd.chain) return lmv_linear_dw(p, np, N, K, sd.ws, sd.ws_bytes, dtype, sd.begin());
-  lmv_reduce_seg out[2]; int nout = 0;
-  const int rc = lmv_linear_dw_chain(p, np, N, K, (unsigned char*)sd.ws + (sd.flip ? half : 0), half, dtype, sd.begin(), sd.pend, sd.npend, out, &nout);
-  if (rc) return rc;
-  sd.flip ^= 1;
-  sd.npend = nout;
-  for (int i = 0; i < nout; ++i) sd.pend[i] = out[i];
-  return LMV_OK;
+  if (need > sd.ws_bytes) LMV_FAIL(LMV_ERR_WORKSPACE, "block_bwd: weight-gradient workspace %zu > %zu bytes", need, sd.ws_bytes);
+  return lmv_linear_dw(p, np, N, K, sd.ws, sd.ws_bytes, dtype, sd.begin());
 }
 // every deferred reduction of the block in one launch, on the side stream behind the launches that produced the partial sums
 int flush_reduces(Side& sd) {
-  for (int i = 0; i < sd.npend; ++i) {          // the slabs of the block's last weight-gradient GEMM
-    if (sd.nsegs >= LMV_REDUCE_MAX_SEGS) LMV_FAIL(LMV_ERR_SHAPE, "block_bwd: too many deferred reductions");
-    sd.segs[sd.nsegs++] = sd.pend[i];
-  }
-  sd.npend = 0;
   if (!sd.nsegs) return LMV_OK;
   const int rc = lmv_reduce_batch(sd.segs, sd.nsegs, sd.begin());
   sd.nsegs = 0;
@@ -322,7 +302,7 @@ void layout_bwd(const Dims& D, Bump& a, Bwd* b) {
   if (w2 > w) w = w2;
   if (w < 256) w = 256;
   b->ws_main_bytes = w; b->ws_main = a.take(w);
-  b->ws_side_bytes = (lmv_config().dw_chain ? 2 : 1) * max_dw_ws(D); b->ws_side = a.take(b->ws_side_bytes);          // Side::chain: two alternating slab regions
+  b->ws_side_bytes = max_dw_ws(D); b->ws_side = a.take(b->ws_side_bytes);
   b->ws_conv_bytes = lmv_dwconv3x3_bwd_weight_workspace_bytes(D.B, D.H, D.W, D.C, D.dtype); b->ws_conv = a.take(b->ws_conv_bytes);
   // LayerNorm dgamma / dbeta partial rows of norm2 and norm1: their reduces run on the side stream, so each keeps its own buffer
   b->ws_ln_bytes = lmv_layernorm_bwd_workspace_bytes(D.rows[0] + D.rows[1], D.C, D.dtype);
@@ -364,14 +344,13 @@ int dx_ln_bwd(Side& sd, const lmv_linear_problem* p, const lmv_ln_segment* seg, 
 // MLP half backward (blocks.py::_mlp_bwd): douts = gradients of the block outputs, returns dt2 (gradient of the MLP half's input) and, where the
 // attention half's DropPath vector nds[s] is set, g2[s] = dt2[s] pre-scaled by it (written by the same LayerNorm-backward launch)
 int mlp_bwd(const lmv_block_desc* d, const Dims& D, const Fwd& f, const Bwd& b, int s0, const void* const* douts, const float* const* ds, const float* const* nds,
-            const void** g2_out, Side& sd, const void* const* gpre = nullptr) {
+            const void** g2_out, Side& sd) {
   const int ns = 2 - s0;
   hipStream_t st = sd.main;
   const void* g[2];
   lmv_row_scale_segment rs[2]; int nrs = 0;
   for (int s = s0; s < 2; ++s) {
     g[s] = douts[s];
-    if (ds[s] && gpre && gpre[s]) { g[s] = gpre[s]; continue; }          // already scaled by the block that produced douts[s] (lmv_block_desc.g_pre)
     if (ds[s]) { rs[nrs].x = douts[s]; rs[nrs].scale = ds[s]; rs[nrs].y = b.g[s]; rs[nrs].rows = D.rows[s]; rs[nrs].rows_per_sample = s == 0 ? D.N : D.M; ++nrs; g[s] = b.g[s]; }
   }
   if (nrs) LMV_TRY(lmv_row_scale_multi(rs, nrs, D.C, D.dtype, st));
@@ -586,7 +565,6 @@ extern "C" int lmv_block_bwd(const lmv_block_desc* d, const void* x, const void*
   if (s.off > scratch_bytes) LMV_FAIL(LMV_ERR_WORKSPACE, "block_bwd: scratch %zu < %zu bytes", scratch_bytes, s.off);
   Side sd{};
   sd.main = (hipStream_t)stream; sd.side = (hipStream_t)side_stream; sd.ws = b.ws_side; sd.ws_bytes = b.ws_side_bytes;
-  sd.chain = D.dtype == LMV_BF16 && lmv_config().dw_chain && b.ws_side_bytes >= 2 * max_dw_ws(D);
   sd.ws_tail = b.ws_conv; sd.ws_tail_bytes = b.ws_conv_bytes;
   if (side_stream) LMV_TRY(event_pool().take(&sd.fork, &sd.join));
   hipStream_t st = sd.main;
@@ -626,7 +604,7 @@ extern "C" int lmv_block_bwd(const lmv_block_desc* d, const void* x, const void*
       const void* douts[2] = {dx_out, dc_out};
       const float* ds[2] = {d->masks[1], d->masks[3]};
       const float* nds[2] = {d->masks[0], d->masks[2]};
-      LMV_TRY(mlp_bwd(d, D, f, b, 0, douts, ds, nds, g2, sd, d->g_pre));
+      LMV_TRY(mlp_bwd(d, D, f, b, 0, douts, ds, nds, g2, sd));
       const bool sh = D.kind == LMV_BLOCK_S;
       for (int s2 = 0; s2 < 2; ++s2) { p[s2] = prob(g2[s2], f.ao[s2], sh ? d->g_attn_w[1] : d->g_attn_w[2 + s2], D.rows[s2]); p[s2].bias_grad = sh ? d->g_attn_b[1] : d->g_attn_b[2 + s2]; }
       LMV_TRY(dw(sd, p, 2, C, C, D.dtype));
@@ -668,7 +646,6 @@ extern "C" int lmv_block_bwd(const lmv_block_desc* d, const void* x, const void*
       lmv_ln_segment seg[2] = {};
       seg[0].x = f.xp; seg[0].dy = b.dn1[0]; seg[0].stats = f.st1[0]; seg[0].dres = b.dt2[0]; seg[0].dx = b.dxp; seg[0].rows = D.rows[0];
       seg[1].x = c; seg[1].dy = b.dn1[1]; seg[1].stats = f.st1[1]; seg[1].dres = b.dt2[1]; seg[1].dx = dc; seg[1].rows = D.rows[1];
-      if (d->out_scale[1] && d->dc_scaled) { seg[1].dx_scale = d->out_scale[1]; seg[1].dx_scaled = d->dc_scaled; seg[1].rows_per_sample = M; }      // dc for the previous block, pre-scaled by ITS DropPath vector
       if (fuse1) {
         for (int s2 = 0; s2 < 2; ++s2) p[s2] = prob(b.dpj[s2], d->attn_wt[0], b.dn1[s2], D.rows[s2]);
         LMV_TRY(dx_ln_bwd(sd, p, seg, 2, 3 * C, d->n1_w, d->g_n1_w, d->g_n1_b, D, b.ws_ln[1], b.ws_ln_bytes));
@@ -687,7 +664,6 @@ extern "C" int lmv_block_bwd(const lmv_block_desc* d, const void* x, const void*
       sg.kind = LMV_REDUCE_ROWS; sg.mode = 1;
     }
     LMV_TRY(flush_reduces(sd));
-    if (!cb && d->out_scale[0] && d->dx_scaled) return lmv_dwconv3x3_residual_bwd_data_scaled(b.dxp, d->pos_w, dx, d->dx_scaled, d->out_scale[0], D.B, D.H, D.W, C, D.dtype, st);
     return lmv_dwconv3x3_residual_bwd_data(b.dxp, d->pos_w, dx, D.B, D.H, D.W, C, D.dtype, st);
   };
   rc = body();

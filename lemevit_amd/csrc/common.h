@@ -90,30 +90,28 @@ static __device__ __forceinline__ void lmv_partial_reduce_block(float4* red, int
 }
 
 // ---- A/B switches ------------------------------------------------------------------------------
-// Every tuning switch of the library lives here.  The environment (LMV_*) is read ONCE, when the library is loaded -- never on a launch
-// path -- and lmv_config_set(key, value) changes a switch at run time (tests and the tools/ sweeps use it).  Defaults = measured best.
+// Every tuning switch of the library lives here; lmv_config_set(key, value) changes one at run time (tests and the tools/ sweeps use it).  Defaults = measured best.
+// Round 6: only the five switches that still name an LMV_* variable below are also read from the environment (ONCE, when the library is loaded -- never on a launch path).
 struct LmvConfig {
-  int gemm_bk;            // LMV_GEMM_BK            0 = auto, 32 / 64 force the k-tile depth of the bf16 GEMMs
-  int gemm_bk32_tiles;    // LMV_GEMM_BK32_TILES    fwd / dX launches with at least this many 128 x 128 tiles use 32-deep k-tiles (4 workgroups per CU)
-  int dw_bk;              // LMV_DW_BK              k-tile depth of the weight-gradient GEMM (32)
+  int gemm_bk;            //            0 = auto, 32 / 64 force the k-tile depth of the bf16 GEMMs
+  int gemm_bk32_tiles;    //    fwd / dX launches with at least this many 128 x 128 tiles use 32-deep k-tiles (4 workgroups per CU)
+  int dw_bk;              //              k-tile depth of the weight-gradient GEMM (32)
   int dw_target_blocks;   // LMV_DW_TARGET_BLOCKS   0 = auto: workgroups one generation of a weight-gradient launch should have
-  int gemm_no_dma;        // LMV_GEMM_NO_DMA        1: register-staged operand path instead of LDS-DMA
+  int gemm_no_dma;        //        1: register-staged operand path instead of LDS-DMA
   int gemm_w8;            // LMV_GEMM_W8            1: 8-wave 64-deep forward kernel; 2: also for every dX launch; 0: off
-  int gemm_cumap;         // LMV_GEMM_CUMAP         1: CU-aware tile order
-  int gemm_nst, gemm_nst_dw;   // LMV_GEMM_NST / _DW ring depth of the 32-deep loop (2 / 3)
+  int gemm_cumap;         //         1: CU-aware tile order
+  int gemm_nst, gemm_nst_dw;   // ring depth of the 32-deep loop (2 / 3)
   int gemm_wn;            // LMV_GEMM_WN            1: whole-width kernel (wngemm.hip) for the 384-wide forward-form launches where it measured faster; 0: off; 2: wherever it applies
   int gemm_rs;            // LMV_GEMM_RS            1: register-stationary kernels (rsgemm.hip) where they measured faster; 0: off; 2: wherever they apply
-  int dwconv_v;           // LMV_DWCONV_V           0 = auto: rows per thread of the depth-wise convolution kernels
-  int ln_exact_fused;     // LMV_LN_EXACT_FUSED     1: norm1 of the C = 96 blocks runs inside its projection launches (lmv_ln_linear_exact_fwd, csrc/rswgemm.hip)
-  int res_ln_fused;       // LMV_RES_LN_FUSED       1: "S" blocks run the attention projection and norm2 as one launch where lmv_linear_res_ln_fwd applies
-  int dx_ln_fused;        // LMV_DX_LN_FUSED        1: lmv_block_bwd fuses the dX of fc1 / qkv with the LayerNorm backward of their input where lmv_linear_dx_ln_bwd applies
-  int mlp_split384;       // LMV_MLP_SPLIT384       1: fused inference schedule runs the C = 384 MLP half as LayerNorm + rsgemm fc1 + wngemm fc2 instead of the one-kernel form
-  int mlp_rw96;           // LMV_MLP_RW96           1: the C = 96 one-kernel MLP with both weight matrices resident in LDS (csrc/rwmlp.hip) instead of the tile-streaming form
-  int mlp_tm;             // LMV_MLP_TM             0 = auto: token rows per workgroup of the fused MLP kernel (64 / 128)
-  int attn_pv16, attn_fuse_dq, attn_fused_bwd, attn_pair;      // LMV_ATTN_*  (attn_fused_bwd: 0 separate dQ / dK-dV kernels, 1 round 2's fused backward, 2 (default) round 5's: dQ by query tile, one barrier per block)
-  int ln_bwd_blocks, ln_bwd_minrows;                           // LMV_LN_BWD_*
-  int dw_chain;           // LMV_DW_CHAIN           1: lmv_block_bwd chains the weight-gradient GEMMs of a block (the slab sums of one ride in the next launch, lmv_linear_dw_chain); 0 (default, measured faster): a reduce launch behind every GEMM
-  int dbg_skip_attn_bwd;  // LMV_DBG_SKIP_ATTN_BWD  timing probe (0): lmv_attn_bwd / _bwd_pair return without launching -- what a train step would gain if the attention backward were free
+  int dwconv_v;           //           0 = auto: rows per thread of the depth-wise convolution kernels
+  int ln_exact_fused;     //     1: norm1 of the C = 96 blocks runs inside its projection launches (lmv_ln_linear_exact_fwd, csrc/rswgemm.hip)
+  int res_ln_fused;       //       1: "S" blocks run the attention projection and norm2 as one launch where lmv_linear_res_ln_fwd applies
+  int dx_ln_fused;        //        1: lmv_block_bwd fuses the dX of fc1 / qkv with the LayerNorm backward of their input where lmv_linear_dx_ln_bwd applies
+  int mlp_split384;       //       1: fused inference schedule runs the C = 384 MLP half as LayerNorm + rsgemm fc1 + wngemm fc2 instead of the one-kernel form
+  int mlp_rw96;           //           1: the C = 96 one-kernel MLP with both weight matrices resident in LDS (csrc/rwmlp.hip) instead of the tile-streaming form
+  int mlp_tm;             //             0 = auto: token rows per workgroup of the fused MLP kernel (64 / 128)
+  int attn_pv16, attn_fuse_dq, attn_fused_bwd, attn_pair;      //  (attn_fused_bwd: 0 separate dQ / dK-dV kernels, 1 round 2's fused backward, 2 (default) round 5's: dQ by query tile, one barrier per block)
+  int ln_bwd_blocks, ln_bwd_minrows;                           //
   int stage_ticket_skew;  // LMV_STAGE_TICKET_SKEW  test switch (0): the persistent stage kernels ask ticket counter (XCC_ID + skew * hash(blockIdx)) & 7 first -- a simulated foreign workgroup -> XCD placement
 };
 LmvConfig& lmv_config();

@@ -60,11 +60,9 @@ __device__ __forceinline__ void mask_row(uint4 (&row)[R + 2], int h, const Geo& 
 
 // FLIP = false: y = x + bias + sum_t w[c][t] * x[h+dy-1][w+dx-1]
 // FLIP = true : y = x +        sum_t w[c][8-t] * x[h+dy-1][w+dx-1]   (transpose conv = backward-data)
-// y2 / scale (nullable): a second output y2 = y * scale[b], the product taken on the ROUNDED y (what lmv_row_scale would compute from the stored tensor): lmv_block_bwd hands the
-// previous block of the stage its DropPath-scaled output gradient from this launch instead of a row-scale pass of its own (round 5)
 template <typename T, bool FLIP>
 __global__ __launch_bounds__(TPB) void dwconv_kernel(const T* __restrict__ x, const float* __restrict__ wgt, const float* __restrict__ bias,
-                                                    T* __restrict__ y, const Geo g, T* __restrict__ y2 = nullptr, const float* __restrict__ scale = nullptr) {
+                                                    T* __restrict__ y, const Geo g) {
   constexpr int EPC = DT<T>::EPC, R = RF;
   const unsigned gid = blockIdx.x * TPB + threadIdx.x, nch = g.C / EPC;
   const unsigned it = gid / nch;
@@ -120,19 +118,6 @@ __global__ __launch_bounds__(TPB) void dwconv_kernel(const T* __restrict__ x, co
 #pragma unroll
     for (int p = 0; p < R; ++p)
       if (I.w0 + p < g.W) *reinterpret_cast<uint4*>(yrow + (int64_t)p * g.C) = f_to_chunk<T>(acc[p]);
-    if (y2) {
-      const float sc = scale[I.b];
-      T* y2row = y2 + (img + (int64_t)h * g.W + I.w0) * g.C + c0;
-#pragma unroll
-      for (int p = 0; p < R; ++p) {
-        if (I.w0 + p >= g.W) continue;
-        float r[EPC];
-        chunk_to_f<T>(f_to_chunk<T>(acc[p]), r);          // the stored value
-#pragma unroll
-        for (int e = 0; e < EPC; ++e) r[e] *= sc;
-        *reinterpret_cast<uint4*>(y2row + (int64_t)p * g.C) = f_to_chunk<T>(r);
-      }
-    }
     mask_row<R>(nxt, h + 2, g, cmask);
 #pragma unroll
     for (int cc = 0; cc < R + 2; ++cc) { win[0][cc] = win[1][cc]; win[1][cc] = win[2][cc]; win[2][cc] = nxt[cc]; }
@@ -262,13 +247,13 @@ inline Geo make_geo(int B, int H, int W, int C, int dtype, int R, bool wgrad = f
 }
 
 template <bool FLIP>
-int launch_dwconv(const void* x, const float* weight, const float* bias, void* y, int B, int H, int W, int C, int dtype, hipStream_t st, void* y2 = nullptr, const float* scale = nullptr) {
+int launch_dwconv(const void* x, const float* weight, const float* bias, void* y, int B, int H, int W, int C, int dtype, hipStream_t st) {
   const Geo g = make_geo(B, H, W, C, dtype, RF);
   const int nch = C / (dtype == LMV_BF16 ? 8 : 4);
   const int64_t threads = (int64_t)B * g.nranges * g.nstrips * nch;
   dim3 grid((unsigned)((threads + TPB - 1) / TPB)), block(TPB);
-  if (dtype == LMV_BF16) hipLaunchKernelGGL((dwconv_kernel<bf16_t, FLIP>), grid, block, 0, st, (const bf16_t*)x, weight, bias, (bf16_t*)y, g, (bf16_t*)y2, scale);
-  else hipLaunchKernelGGL((dwconv_kernel<float, FLIP>), grid, block, 0, st, (const float*)x, weight, bias, (float*)y, g, (float*)y2, scale);
+  if (dtype == LMV_BF16) hipLaunchKernelGGL((dwconv_kernel<bf16_t, FLIP>), grid, block, 0, st, (const bf16_t*)x, weight, bias, (bf16_t*)y, g);
+  else hipLaunchKernelGGL((dwconv_kernel<float, FLIP>), grid, block, 0, st, (const float*)x, weight, bias, (float*)y, g);
   LMV_CHECK_LAUNCH("dwconv");
   return LMV_OK;
 }
@@ -294,13 +279,6 @@ extern "C" int lmv_dwconv3x3_residual_bwd_data(const void* dy, const float* weig
   if (int rc = check("dwconv_bwd_data", dy, dx, B, H, W, C, dtype)) return rc;
   if (!weight || !lmv_aligned16(weight)) LMV_FAIL(LMV_ERR_SHAPE, "dwconv_bwd_data: null or misaligned weight");
   return launch_dwconv<true>(dy, weight, nullptr, dx, B, H, W, C, dtype, (hipStream_t)stream);
-}
-
-extern "C" int lmv_dwconv3x3_residual_bwd_data_scaled(const void* dy, const float* weight, void* dx, void* dx_scaled, const float* scale, int B, int H, int W, int C, int dtype,
-                                                      void* stream) {
-  if (int rc = check("dwconv_bwd_data_scaled", dy, dx, B, H, W, C, dtype)) return rc;
-  if (!weight || !lmv_aligned16(weight) || !dx_scaled || !scale || !lmv_aligned16(dx_scaled)) LMV_FAIL(LMV_ERR_SHAPE, "dwconv_bwd_data_scaled: null or misaligned operand");
-  return launch_dwconv<true>(dy, weight, nullptr, dx, B, H, W, C, dtype, (hipStream_t)stream, dx_scaled, scale);
 }
 
 extern "C" size_t lmv_dwconv3x3_bwd_weight_workspace_bytes(int B, int H, int W, int C, int dtype) {

@@ -96,6 +96,7 @@ struct DsArgs {
 // LayerNorm of NTT register-resident token tiles -> bf16 operand fragments at `xn` ([k-step][tile]); statistics over the NW waves through `stat`
 template <int NW, int NTT, int CT>
 __device__ __forceinline__ void ds_layer_norm(const f32x4_t (&R)[NTT][CT], const float* gam, const float* bet, float eps, unsigned char* xn, float2* stat, int wave, int lane) {
+  __builtin_amdgcn_sched_barrier(0); asm volatile("; LN_FENCE_BEGIN" ::: "memory");          // (tests/test_isa_cpu.py: no packed fp32 arithmetic between the markers: the statistics and their combine)
   constexpr int CW = 16 * CT, C = CW * NW;
   const int g = lane >> 4, li = lane & 15;
   // statistics without cancellation: per wave the mean and the centred sum of squares of its CW channels (two passes over registers), combined over the waves with the
@@ -135,6 +136,7 @@ __device__ __forceinline__ void ds_layer_norm(const f32x4_t (&R)[NTT][CT], const
     rstd[t] = rsqrtf(fmaf(dev, (float)CW, sq) * (1.f / C) + eps);
     asm volatile("" : "+v"(mean[t]), "+v"(rstd[t]));
   }
+asm volatile("; LN_FENCE_END" ::: "memory"); __builtin_amdgcn_sched_barrier(0);          // (the normalisation below packs two CHANNELS of a token with VGPR-pair splats: that form has always been in the bit-stable builds)
 #pragma unroll
   for (int ct = 0; ct < CT; ++ct) {
     const int T = CT * wave + ct;

@@ -42,8 +42,6 @@
 
 namespace {
 
-__device__ __forceinline__ void reduce_slabs_block(const ReduceSegDev& g, int blk, float4* red);
-
 template <typename T, bool ATR, bool BTR, bool SPLITK, int BK, bool DMA, typename CF, int MINW = 1, int NST = 2, bool LNP = false, bool CONV = false>
 __global__ __launch_bounds__(CF::NTHR, MINW) void gemm_kernel(const GemmArgs g) {
   static_assert(!LNP || (!ATR && !BTR && !SPLITK), "the LayerNorm-folded epilogue belongs to the forward contraction");
@@ -80,16 +78,6 @@ __global__ __launch_bounds__(CF::NTHR, MINW) void gemm_kernel(const GemmArgs g) 
   // together -- so the rows are fetched from HBM once and shared through that XCD's L2.
   int bid, split = 0;
   if constexpr (SPLITK) {
-    // the LAST pg_blocks workgroups sum the slabs an EARLIER weight-gradient launch of this stream left (lmv_linear_dw_chain): short, independent of this launch's tiles.  Behind the
-    // tiles, not in front: the launch is sized for one generation of tile workgroups, and hundreds of reduce workgroups at the head of the grid push part of them into a second one
-    // (measured: +0.4 ms per train step); at the tail they fill the slots the first finished tiles free.
-    const int main_blocks = (int)gridDim.x - g.pg_blocks;
-    if ((int)blockIdx.x >= main_blocks) {
-      const int rb = (int)blockIdx.x - main_blocks;
-      const int si = (g.pg_n > 1 && rb >= g.pg[1].blk0) ? 1 : 0;
-      reduce_slabs_block(g.pg[si], rb - g.pg[si].blk0, reinterpret_cast<float4*>(smem));
-      return;
-    }
     const int x = blockIdx.x & 7, y = blockIdx.x >> 3;
     if (g.nsplits >= 8) {                // a multiple of 8: XCD x owns splits x, x + 8, ...
       bid = y % g.ntiles;
@@ -548,7 +536,7 @@ int launch_mode(const Plan& pl, dim3 grid, bool bf, hipStream_t st) {
 }
 
 int launch(const lmv_linear_problem* p, int nproblems, int N, int K, int act, int dtype, void* stream, Mode mode, void* ws, size_t ws_bytes,
-           lmv_reduce_seg* segs = nullptr, int* nsegs = nullptr, const lmv_reduce_seg* pending = nullptr, int npending = 0, const ConvGeo* cv = nullptr) {
+           lmv_reduce_seg* segs = nullptr, int* nsegs = nullptr, const ConvGeo* cv = nullptr) {
   Plan pl;
   if (int rc = make_plan(p, nproblems, N, K, act, dtype, mode, &pl)) return rc;      // (validates the operands)
   if (cv) pl.g.cv = *cv;
@@ -570,24 +558,6 @@ int launch(const lmv_linear_problem* p, int nproblems, int N, int K, int act, in
   hipStream_t st = (hipStream_t)stream;
   int rc;
   if (mode == MODE_DW) grid.x = g.nsplits >= 8 ? pl.total * g.nsplits : 8 * ((pl.total + 8 / g.nsplits - 1) / (8 / g.nsplits));
-  g.pg_n = g.pg_blocks = g.pg_pad = 0;
-  if (mode == MODE_DW && npending > 0) {          // the slab sums of earlier launches ride at the head of this grid
-    if (npending > 2 || !pending || dtype != LMV_BF16) LMV_FAIL(LMV_ERR_SHAPE, "linear_dw_chain: at most 2 pending segments, bf16 launches only");
-    int blocks = 0;
-    for (int i = 0; i < npending; ++i) {
-      const lmv_reduce_seg& q = pending[i];
-      if (q.kind != LMV_REDUCE_SLABS || !q.ws || !q.out_w || q.nslabs <= 0 || q.nw <= 0 || (q.nw % 4) || (q.out_b && (q.nb % 4)) || (q.slab_stride % 4) || !lmv_aligned16(q.ws) ||
-          !lmv_aligned16(q.out_w) || !lmv_aligned16(q.out_b))
-        LMV_FAIL(LMV_ERR_SHAPE, "linear_dw_chain: bad pending segment %d", i);
-      const int64_t n4 = (q.nw + (q.out_b ? q.nb : 0)) / 4;
-      ReduceSegDev& d = g.pg[i];
-      d.ws = q.ws; d.out_w = q.out_w; d.out_b = q.out_b; d.stride = q.slab_stride; d.nw = q.nw; d.nslabs = q.nslabs; d.nb = q.nb; d.kind = q.kind; d.mode = 0;
-      d.sl = reduce_lanes(n4, q.nslabs); d.blk0 = blocks;
-      blocks += (int)((n4 * d.sl + 255) / 256);
-    }
-    g.pg_n = npending; g.pg_blocks = blocks; g.pg_pad = 0;
-    grid.x += blocks;
-  }
   double trows = 0.;
   for (int i = 0; i < nproblems && i < 2; ++i) trows += (double)p[i].rows;
   if (mode == MODE_FWD) rc = launch_mode<false, false, false>(pl, grid, bf, st);
@@ -697,18 +667,6 @@ extern "C" int lmv_linear_dw_partial(const lmv_linear_problem* p, int nproblems,
   return launch(p, nproblems, N, K, LMV_ACT_NONE, dtype, stream, MODE_DW, workspace, workspace_bytes, segs, nsegs);
 }
 
-extern "C" int lmv_linear_dw_chain(const lmv_linear_problem* p, int nproblems, int N, int K, void* workspace, size_t workspace_bytes, int dtype, void* stream,
-                                   const lmv_reduce_seg* pending, int npending, lmv_reduce_seg* segs, int* nsegs) {
-  if (!segs || !nsegs) LMV_FAIL(LMV_ERR_SHAPE, "linear_dw_chain: segs / nsegs must not be NULL");
-  *nsegs = 0;
-  if (npending > 0 && pending)
-    for (int i = 0; i < npending; ++i) {          // a pending slab region must not be the one this launch writes
-      const char* a = (const char*)pending[i].ws; const char* b = (const char*)workspace;
-      if (a < b + workspace_bytes && b < a + (size_t)pending[i].nslabs * pending[i].slab_stride * sizeof(float)) LMV_FAIL(LMV_ERR_SHAPE, "linear_dw_chain: the pending slabs overlap this launch's workspace");
-    }
-  return launch(p, nproblems, N, K, LMV_ACT_NONE, dtype, stream, MODE_DW, workspace, workspace_bytes, segs, nsegs, pending, npending);
-}
-
 // ---- Conv2d(Cin, Cout, 3, stride 2, padding 1) on an NHWC map as an implicit GEMM (models/lemevit.py:701-703, :714-717) ----------------------------------------------
 #ifndef LMV_TRY
 #define LMV_TRY(expr) do { const int rc__ = (expr); if (rc__) return rc__; } while (0)
@@ -737,7 +695,7 @@ extern "C" int lmv_conv3x3s2_fwd(const void* x, const void* wm, const float* bia
   p.a = x; p.w = wm; p.out = y; p.bias = bias; p.rows = (int64_t)B * cv.HoWo;          // (a: validated only -- the kernel gathers from cv.x)
   const double rows = (double)p.rows;
   LmvTimedLaunch timed(stream, 2.0 * Cout * 9.0 * Cin * rows, 2.0 * ((double)B * H * W * Cin + rows * Cout + (double)Cout * KP));
-  return launch(&p, 1, Cout, KP, act, dtype, stream, MODE_FWD, nullptr, 0, nullptr, nullptr, nullptr, 0, &cv);
+  return launch(&p, 1, Cout, KP, act, dtype, stream, MODE_FWD, nullptr, 0, nullptr, nullptr, &cv);
 }
 extern "C" size_t lmv_conv3x3s2_dw_workspace_bytes(int B, int H, int W, int Cin, int Cout, int KP, int dtype) {
   (void)Cin;
@@ -751,7 +709,7 @@ extern "C" int lmv_conv3x3s2_dw(const void* dy, const void* x, float* dwm, float
   LMV_TRY(conv_geo(&cv, x, B, H, W, Cin, Cout, KP, dtype));
   lmv_linear_problem p{};
   p.a = dy; p.w = x; p.out = dwm; p.bias_grad = dbias; p.rows = (int64_t)B * cv.HoWo;
-  return launch(&p, 1, Cout, KP, LMV_ACT_NONE, dtype, stream, MODE_DW, workspace, workspace_bytes, nullptr, nullptr, nullptr, 0, &cv);
+  return launch(&p, 1, Cout, KP, LMV_ACT_NONE, dtype, stream, MODE_DW, workspace, workspace_bytes, nullptr, nullptr, &cv);
 }
 
 extern "C" int lmv_reduce_batch(const lmv_reduce_seg* segs, int nsegs, void* stream) {

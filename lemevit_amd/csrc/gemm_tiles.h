@@ -53,10 +53,6 @@ struct GemmArgs {
   float* ws;              // split-K (dW) mode: partial slabs [slab][N*K + N] fp32
   int64_t slab_stride;    // floats per slab
   int slab_base[2];       // first slab of each problem
-  // split-K (dW) mode, round 5: the slab reduction of the PREVIOUS weight-gradient launch(es) of the stream rides in this launch as `pg_blocks` extra workgroups at the TAIL of the
-  // grid (lmv_linear_dw_chain): ~160 reduce launches of ~7 us (19 us next to the main stream's kernels) per train step disappear from the weight-gradient stream
-  ReduceSegDev pg[2];
-  int pg_n, pg_blocks, pg_pad;
 };
 
 // chunk swizzle of a reduction-contiguous panel whose rows are ROWB bytes (64 or 128)

@@ -115,28 +115,27 @@ extern "C" int lmv_debug_launch_timing_read(float* ms, double* flops, double* by
 
 extern "C" int lmv_abi_version(void) { return LMV_ABI_VERSION; }
 
-// ---- A/B switches: the environment is read once, here ------------------------------------------------------------------------------------
+// ---- A/B switches: lmv_config_set(key, value) at run time (tests, tools); five of them also from the environment, read once, here (round 6: the other ~25 LMV_* variables are gone) ------------------------------------------------------------------------------------
 #include <stdlib.h>
 #include <string.h>
 namespace {
-int env_int(const char* name, int dflt) { const char* e = getenv(name); return e && *e ? atoi(e) : dflt; }
+int env_int(const char* name, int dflt) { const char* e = name ? getenv(name) : nullptr; return e && *e ? atoi(e) : dflt; }
 struct ConfigKey { const char* key; const char* env; int LmvConfig::*field; int dflt; };
 const ConfigKey kConfigKeys[] = {
-    {"gemm_bk", "LMV_GEMM_BK", &LmvConfig::gemm_bk, 0}, {"gemm_bk32_tiles", "LMV_GEMM_BK32_TILES", &LmvConfig::gemm_bk32_tiles, 512},
-    {"dw_bk", "LMV_DW_BK", &LmvConfig::dw_bk, 32}, {"dw_target_blocks", "LMV_DW_TARGET_BLOCKS", &LmvConfig::dw_target_blocks, 0},
-    {"gemm_no_dma", "LMV_GEMM_NO_DMA", &LmvConfig::gemm_no_dma, 0}, {"gemm_w8", "LMV_GEMM_W8", &LmvConfig::gemm_w8, 1},
-    {"gemm_cumap", "LMV_GEMM_CUMAP", &LmvConfig::gemm_cumap, 1}, {"gemm_nst", "LMV_GEMM_NST", &LmvConfig::gemm_nst, 2},
-    {"gemm_nst_dw", "LMV_GEMM_NST_DW", &LmvConfig::gemm_nst_dw, 3}, {"gemm_rs", "LMV_GEMM_RS", &LmvConfig::gemm_rs, 1}, {"gemm_wn", "LMV_GEMM_WN", &LmvConfig::gemm_wn, 1},
-    {"dwconv_v", "LMV_DWCONV_V", &LmvConfig::dwconv_v, 0},
-    {"stage_ticket_skew", "LMV_STAGE_TICKET_SKEW", &LmvConfig::stage_ticket_skew, 0}, {"dw_chain", "LMV_DW_CHAIN", &LmvConfig::dw_chain, 0}, {"dbg_skip_attn_bwd", "LMV_DBG_SKIP_ATTN_BWD", &LmvConfig::dbg_skip_attn_bwd, 0}, {"mlp_tm", "LMV_MLP_TM", &LmvConfig::mlp_tm, 0}, {"mlp_rw96", "LMV_MLP_RW96", &LmvConfig::mlp_rw96, 1}, {"mlp_split384", "LMV_MLP_SPLIT384", &LmvConfig::mlp_split384, 1}, {"dx_ln_fused", "LMV_DX_LN_FUSED", &LmvConfig::dx_ln_fused, 1}, {"res_ln_fused", "LMV_RES_LN_FUSED", &LmvConfig::res_ln_fused, 1}, {"ln_exact_fused", "LMV_LN_EXACT_FUSED", &LmvConfig::ln_exact_fused, 1}, {"attn_pv16", "LMV_ATTN_PV16", &LmvConfig::attn_pv16, 1},
-    {"attn_fuse_dq", "LMV_ATTN_FUSE_DQ", &LmvConfig::attn_fuse_dq, 1}, {"attn_fused_bwd", "LMV_ATTN_FUSED_BWD", &LmvConfig::attn_fused_bwd, 2},
-    {"attn_pair", "LMV_ATTN_PAIR", &LmvConfig::attn_pair, 1}, {"ln_bwd_blocks", "LMV_LN_BWD_BLOCKS", &LmvConfig::ln_bwd_blocks, 1024},
-    {"ln_bwd_minrows", "LMV_LN_BWD_MINROWS", &LmvConfig::ln_bwd_minrows, 2},
+    {"gemm_bk", nullptr, &LmvConfig::gemm_bk, 0}, {"gemm_bk32_tiles", nullptr, &LmvConfig::gemm_bk32_tiles, 512},
+    {"dw_bk", nullptr, &LmvConfig::dw_bk, 32}, {"dw_target_blocks", "LMV_DW_TARGET_BLOCKS", &LmvConfig::dw_target_blocks, 0},
+    {"gemm_no_dma", nullptr, &LmvConfig::gemm_no_dma, 0}, {"gemm_w8", "LMV_GEMM_W8", &LmvConfig::gemm_w8, 1},
+    {"gemm_cumap", nullptr, &LmvConfig::gemm_cumap, 1}, {"gemm_nst", nullptr, &LmvConfig::gemm_nst, 2},
+    {"gemm_nst_dw", nullptr, &LmvConfig::gemm_nst_dw, 3}, {"gemm_rs", "LMV_GEMM_RS", &LmvConfig::gemm_rs, 1}, {"gemm_wn", "LMV_GEMM_WN", &LmvConfig::gemm_wn, 1},
+    {"dwconv_v", nullptr, &LmvConfig::dwconv_v, 0},
+    {"stage_ticket_skew", "LMV_STAGE_TICKET_SKEW", &LmvConfig::stage_ticket_skew, 0}, {"mlp_tm", nullptr, &LmvConfig::mlp_tm, 0}, {"mlp_rw96", nullptr, &LmvConfig::mlp_rw96, 1}, {"mlp_split384", nullptr, &LmvConfig::mlp_split384, 1}, {"dx_ln_fused", nullptr, &LmvConfig::dx_ln_fused, 1}, {"res_ln_fused", nullptr, &LmvConfig::res_ln_fused, 1}, {"ln_exact_fused", nullptr, &LmvConfig::ln_exact_fused, 1}, {"attn_pv16", nullptr, &LmvConfig::attn_pv16, 1},
+    {"attn_fuse_dq", nullptr, &LmvConfig::attn_fuse_dq, 1}, {"attn_fused_bwd", nullptr, &LmvConfig::attn_fused_bwd, 2},
+    {"attn_pair", nullptr, &LmvConfig::attn_pair, 1}, {"ln_bwd_blocks", nullptr, &LmvConfig::ln_bwd_blocks, 1024},
+    {"ln_bwd_minrows", nullptr, &LmvConfig::ln_bwd_minrows, 2},
 };
 LmvConfig config_from_env() {
   LmvConfig c{};
   for (const ConfigKey& k : kConfigKeys) c.*(k.field) = env_int(k.env, k.dflt);
-  if (c.gemm_no_dma == 0 && getenv("LMV_GEMM_NO_DMA")) c.gemm_no_dma = 1;      // (historically: set = on, whatever the value)
   if (c.ln_bwd_blocks <= 0 || c.ln_bwd_blocks > 2048) c.ln_bwd_blocks = 512;
   if (c.ln_bwd_minrows <= 0) c.ln_bwd_minrows = 2;
   return c;
@@ -217,7 +216,21 @@ __global__ __launch_bounds__(TPB) void token_mean2_fwd_kernel(const T* __restric
 #pragma unroll
   for (int e = 0; e < EPC; ++e) acc[e] = 0.f;
   const uint4* px = reinterpret_cast<const uint4*>(x) + (size_t)b * L * cpr + ch;
-  for (int l = 0; l < L; ++l) {
+  // (8 token rows requested before the first is consumed: the one-load-per-iteration loop was a chain of exposed memory round trips -- 21 us for the 6 MB of a stage-4 map;
+  //  the sums are still taken in token order)
+  int l = 0;
+  for (; l + 8 <= L; l += 8) {
+    uint4 v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = px[(size_t)(l + j) * cpr];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      chunk_to_f<T>(v[j], f);
+#pragma unroll
+      for (int e = 0; e < EPC; ++e) acc[e] += f[e];
+    }
+  }
+  for (; l < L; ++l) {
     chunk_to_f<T>(px[(size_t)l * cpr], f);
 #pragma unroll
     for (int e = 0; e < EPC; ++e) acc[e] += f[e];
@@ -234,7 +247,19 @@ __global__ __launch_bounds__(TPB) void token_mean2_fwd_kernel(const T* __restric
 #pragma unroll
     for (int e = 0; e < EPC; ++e) a2[e] = 0.f;
     const uint4* pc = reinterpret_cast<const uint4*>(c) + (size_t)b * M * cpr + ch;
-    for (int m = 0; m < M; ++m) {
+    int m = 0;
+    for (; m + 8 <= M; m += 8) {
+      uint4 v[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = pc[(size_t)(m + j) * cpr];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        chunk_to_f<T>(v[j], f);
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) a2[e] += f[e];
+      }
+    }
+    for (; m < M; ++m) {
       chunk_to_f<T>(pc[(size_t)m * cpr], f);
 #pragma unroll
       for (int e = 0; e < EPC; ++e) a2[e] += f[e];

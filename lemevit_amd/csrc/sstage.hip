@@ -103,26 +103,8 @@ constexpr int SS_NSTAMP = 24;
 // be checked by hand is consistent -- the waitcnt counts, the splat constants (s[34:35] = (eps, eps)), op_sel / op_sel_hi on the SGPR-pair sources (tools/native/pk_sgpr_probe.hip: the
 // hardware honours them), no permlane or DS-store hazard (variants with shuffles / nops / drained stores behave the same) -- and the scalar build of the same source is bit-stable
 // (tools/ss_repeat.py; tests/test_sstage_gpu.py::test_sstage_vs_per_launch_schedule_full_size is the regression test that caught it).  Opaque copies per tile keep the SLP
-// vectoriser off these values; -DSS_LN_PACKED=1 builds the packed form for further digging.
-#ifndef SS_LN_PACKED
-#define SS_LN_PACKED 0
-#endif
-#if SS_LN_PACKED
-#define SS_LN_OPAQUE2(a, b) ((void)0)
-#else
+// vectoriser off these values (tools/experiments/sstage_ln_packed.patch rebuilds the packed form); tests/test_isa_cpu.py fails the build if a packed fp32 op shows up in the statistics phases.
 #define SS_LN_OPAQUE2(a, b) asm volatile("" : "+v"(a), "+v"(b))
-#endif
-#ifndef SS_ATTN_PRIO
-#define SS_ATTN_PRIO 0      // issue priority in the attention phase (VALU-bound; the second-dispatched half of the waves loses the arbitration): 1 waves 4..7 high, 2 / 3 alternating per unit
-#endif
-// -DSS_DBG_SAVE=1 (experiment): the kernel also WRITES what a training form would have to save for lmv_block_bwd -- LayerNorm inputs / outputs, packed qkv, attention
-// output, u, h: 16 C per token and block, row-major [token][channel], in the pieces the fragment layouts give (8 bytes per lane; v: 2 bytes) -- to price those stores next to the compute.
-#ifndef SS_DBG_SAVE
-#define SS_DBG_SAVE 0
-#endif
-#if SS_DBG_SAVE
-#define SS_SAVE8(unit, width, tok, ch, lo, hi) *reinterpret_cast<uint2*>(sv + (size_t)(unit) * (112 * SS_C * 2) + ((size_t)(tok) * (width) + (ch)) * 2) = make_uint2(lo, hi)
-#endif
 #ifndef SS_DBG_LN_BARRIER
 #define SS_DBG_LN_BARRIER 0
 #endif
@@ -148,7 +130,6 @@ struct SsArgs {
   unsigned char* kbuf; unsigned char* vbuf; unsigned char* halo; unsigned char* park; unsigned* flags; unsigned* err;     // flags: [2 B] kv | [2 B] halo | [8] tickets; err: the sticky error word (lmv_stage_error_count)
   unsigned* tickets; unsigned quota, skew;      // stage_ticket (stage_common.h): 8 counters of `quota` = 2 ceil(B / 8) tickets
   int B, nblocks; float eps;
-  unsigned char* save;      // -DSS_DBG_SAVE=1 experiment only: where a training form would write its saved set
   unsigned long long* timing; int timing_block;      // optional (NULL): s_memtime stamps [workgroup][wave][SS_NSTAMP] of one block
 };
 
@@ -158,9 +139,9 @@ struct SsArgs {
   } while (0)
 
 template <int NW, int VAR = 0>
-__device__ __forceinline__ void layer_norm_to_lds(const f32x4_t (&R)[SS_NT][3], const float* gam, const float* bet, float eps, unsigned char* smem, int wave, int lane, unsigned char* sv = nullptr, int unit = 0) {
+__device__ __forceinline__ void layer_norm_to_lds(const f32x4_t (&R)[SS_NT][3], const float* gam, const float* bet, float eps, unsigned char* smem, int wave, int lane) {
+  __builtin_amdgcn_sched_barrier(0); asm volatile("; LN_FENCE_BEGIN" ::: "memory");          // (tests/test_isa_cpu.py: no packed fp32 arithmetic between the markers: the statistics and their combine)
   SS_GEO(NW)
-  (void)sv; (void)unit;
   const int g = lane >> 4, li = lane & 15;
   float2* stat = reinterpret_cast<float2*>(smem + L_STAT);
 #if SS_DBG_LN_BARRIER
@@ -237,6 +218,7 @@ __device__ __forceinline__ void layer_norm_to_lds(const f32x4_t (&R)[SS_NT][3], 
       SS_LN_OPAQUE2(mean[t], rstd[t]);
     }
   }
+asm volatile("; LN_FENCE_END" ::: "memory"); __builtin_amdgcn_sched_barrier(0);          // (the normalisation below packs two CHANNELS of a token with VGPR-pair splats: that form has always been in the bit-stable builds)
 #pragma unroll
   for (int ct = 0; ct < 3; ++ct) {
     const int T = 3 * wave + ct;
@@ -245,9 +227,6 @@ __device__ __forceinline__ void layer_norm_to_lds(const f32x4_t (&R)[SS_NT][3], 
       const float y0 = fmaf((R[t][ct][0] - mean[t]) * rstd[t], ga[ct].x, be[ct].x), y1 = fmaf((R[t][ct][1] - mean[t]) * rstd[t], ga[ct].y, be[ct].y);
       const float y2 = fmaf((R[t][ct][2] - mean[t]) * rstd[t], ga[ct].z, be[ct].z), y3 = fmaf((R[t][ct][3] - mean[t]) * rstd[t], ga[ct].w, be[ct].w);
       *reinterpret_cast<uint2*>(smem + L_XN + (((T >> 1) * SS_NT + t) * 64 + lane) * 16 + (T & 1) * 8) = make_uint2(pack_bf2(y0, y1), pack_bf2(y2, y3));
-#if SS_DBG_SAVE
-      if (sv) SS_SAVE8(unit, SS_C, 16 * t + li, 48 * wave + 16 * ct + 4 * g, pack_bf2(y0, y1), pack_bf2(y2, y3));
-#endif
     }
   }
   __syncthreads();
@@ -403,12 +382,6 @@ __global__ __launch_bounds__(64 * NW, 2) void sstage_kernel(const SsArgs a) {
     const unsigned char* const wp = reinterpret_cast<const unsigned char*>(a.wpk) + (size_t)blk * WS_FRAGS * 1024;      // wave-uniform
     const float* const vec = a.vec + (size_t)blk * V_FLOATS;
     const int lane = lane0, wave = wave0;      // (stamps only)
-#if !SS_DBG_SAVE
-    unsigned char* const sv_or_null = nullptr;
-#else
-    unsigned char* const sv_or_null = a.save ? a.save + ((size_t)blk * gridDim.x + blockIdx.x) * ((size_t)16 * 112 * SS_C * 2) : nullptr;
-    unsigned char* const sv = a.save ? a.save + ((size_t)blk * gridDim.x + blockIdx.x) * ((size_t)16 * 112 * SS_C * 2) : nullptr;
-#endif
 
     SS_STAMP(0);
     asm volatile("; PHASE_DWCONV" ::: "memory");
@@ -535,15 +508,6 @@ __global__ __launch_bounds__(64 * NW, 2) void sstage_kernel(const SsArgs a) {
       }
     }
 
-#if SS_DBG_SAVE
-    if (sv) {
-      SS_PHASE
-#pragma unroll
-      for (int t = 0; t < SS_NT; ++t)
-#pragma unroll
-        for (int ct = 0; ct < 3; ++ct) SS_SAVE8(0, SS_C, 16 * t + li, 48 * wave + 16 * ct + 4 * g, pack_bf2(R[t][ct][0], R[t][ct][1]), pack_bf2(R[t][ct][2], R[t][ct][3]));
-    }
-#endif
     SS_STAMP(1);
     asm volatile("; PHASE_LN1_KV" ::: "memory");
     // ---- norm1 -> LDS; k / v projections of this half's tokens -> exchange buffers ----
@@ -551,7 +515,7 @@ __global__ __launch_bounds__(64 * NW, 2) void sstage_kernel(const SsArgs a) {
     {
       SS_PHASE
       ring_fill<2, 3>(ring2, wp + (size_t)(WS_KV + (3 * wave) * (2 * SS_KS)) * 1024, lane);       // lands under the LayerNorm
-      layer_norm_to_lds<NW, SS_LN1_VAR>(R, vec + V_N1W, vec + V_N1B, a.eps, smem, wave, lane, SS_DBG_SAVE ? sv_or_null : nullptr, 1);
+      layer_norm_to_lds<NW, SS_LN1_VAR>(R, vec + V_N1W, vec + V_N1B, a.eps, smem, wave, lane);
       // the residual is not touched again before proj: its 84 registers go to L2 (a wave-private slab, plain stores) and come back behind the
       // attention -- k / v / q and the attention (13 K fragments resident per head) get the registers
 #if SS_PARK
@@ -583,9 +547,6 @@ __global__ __launch_bounds__(64 * NW, 2) void sstage_kernel(const SsArgs a) {
             const f32x4_t k0 = {acc[t][0][0] + b0.x, acc[t][0][1] + b0.y, acc[t][0][2] + b0.z, acc[t][0][3] + b0.w};
             const f32x4_t k1 = {acc[t][1][0] + b1.x, acc[t][1][1] + b1.y, acc[t][1][2] + b1.z, acc[t][1][3] + b1.w};
             __builtin_amdgcn_raw_buffer_store_b128(pack_bf8(k0, k1), kr, ((h * 14 + kt) * 64 + lane) * 16, 0, 16);
-#if SS_DBG_SAVE
-            if (sv) { SS_SAVE8(2, 3 * SS_C, 16 * t + li, SS_C + 32 * h + 4 * g, pack_bf2(k0[0], k0[1]), pack_bf2(k0[2], k0[3])); SS_SAVE8(2, 3 * SS_C, 16 * t + li, SS_C + 32 * h + 16 + 4 * g, pack_bf2(k1[0], k1[1]), pack_bf2(k1[2], k1[3])); }
-#endif
           }
         } else {
           const float bv0 = vec[V_QKVB + 2 * SS_C + 32 * h + li], bv1 = vec[V_QKVB + 2 * SS_C + 32 * h + 16 + li];
@@ -599,15 +560,6 @@ __global__ __launch_bounds__(64 * NW, 2) void sstage_kernel(const SsArgs a) {
               u32x4_t pk = {pack_h2(lo[0], lo[1]), pack_h2(lo[2], lo[3]), 0u, 0u};
               if (p < 3) { const f32x4_t hi = acc[2 * p + 1][dt] + bv; pk[2] = pack_h2(hi[0], hi[1]); pk[3] = pack_h2(hi[2], hi[3]); }
               __builtin_amdgcn_raw_buffer_store_b128(pk, vr, ((h * 16 + (half * 4 + p) * 2 + dt) * 64 + lane) * 16, 0, 16);
-#if SS_DBG_SAVE == 1          // (== 2: without v, whose operand-swapped tiles only give 2-byte pieces of a row)
-              if (sv) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                  *reinterpret_cast<unsigned short*>(sv + (size_t)2 * (112 * SS_C * 2) + ((size_t)(32 * p + 4 * g + r) * (3 * SS_C) + 2 * SS_C + 32 * h + 16 * dt + li) * 2) = (unsigned short)(pack_bf2(lo[r], 0.f) & 0xffffu);
-                  if (p < 3) *reinterpret_cast<unsigned short*>(sv + (size_t)2 * (112 * SS_C * 2) + ((size_t)(32 * p + 16 + 4 * g + r) * (3 * SS_C) + 2 * SS_C + 32 * h + 16 * dt + li) * 2) = (unsigned short)(pk[2 + (r >> 1)] >> (16 * (r & 1)));
-                }
-              }
-#endif
             }
         }
       }
@@ -641,9 +593,6 @@ __global__ __launch_bounds__(64 * NW, 2) void sstage_kernel(const SsArgs a) {
           const f32x4_t q0 = {(acc[t][0][0] + b0.x) * QS, (acc[t][0][1] + b0.y) * QS, (acc[t][0][2] + b0.z) * QS, (acc[t][0][3] + b0.w) * QS};
           const f32x4_t q1 = {(acc[t][1][0] + b1.x) * QS, (acc[t][1][1] + b1.y) * QS, (acc[t][1][2] + b1.z) * QS, (acc[t][1][3] + b1.w) * QS};
           const u32x4_t qf = pack_bf8(q0, q1);
-#if SS_DBG_SAVE
-          if (sv) { SS_SAVE8(2, 3 * SS_C, 16 * t + li, 32 * h + 4 * g, qf[0], qf[1]); SS_SAVE8(2, 3 * SS_C, 16 * t + li, 32 * h + 16 + 4 * g, qf[2], qf[3]); }
-#endif
           if (hu == 0) Qf[t] = as_bf8(qf);
           else *reinterpret_cast<u32x4_t*>(smem + L_H + ((wave * SS_NT + t) * 64 + lane) * 16) = qf;
         }
@@ -662,13 +611,6 @@ __global__ __launch_bounds__(64 * NW, 2) void sstage_kernel(const SsArgs a) {
       // wave (wave & 3) left in LDS: waves 0..3 take its tiles 0..3, waves 4..7 its tiles 4..6 (11 / 10 query tiles per wave)
 #pragma unroll 1
       for (int u = 0; u < 3; ++u) {
-#if SS_ATTN_PRIO == 1
-        if (u == 0 && wave >= NW / 2) __builtin_amdgcn_s_setprio(1);
-#elif SS_ATTN_PRIO == 2
-        if ((u != 1) == (wave >= NW / 2)) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
-#elif SS_ATTN_PRIO == 3
-        if ((u == 1) == (wave >= NW / 2)) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
-#endif
         const bool third = u == 2;
         const int h = third ? NW + (wave & (NW / 2 - 1)) : wave;
         const bool groupb = third ? wave >= NW / 2 : u == 1;
@@ -680,9 +622,6 @@ __global__ __launch_bounds__(64 * NW, 2) void sstage_kernel(const SsArgs a) {
         else if (half == 0) attn_image<4, 3>(Qf, h, kr, vr, smem, lane);
         else { attn_image<4, 2>(Qf, h, kr, vr, smem, lane); attn_meta(Qf[6], h, kr, vr, smem, lane); }
       }
-#if SS_ATTN_PRIO
-      __builtin_amdgcn_s_setprio(0);
-#endif
     }
     SS_STAMP(7);
     bf16x8_t ring3[4][3], ringp[SS_PRD][3];
@@ -713,17 +652,6 @@ __global__ __launch_bounds__(64 * NW, 2) void sstage_kernel(const SsArgs a) {
       for (int ct = 0; ct < 3; ++ct)
 #pragma unroll
         for (int t = 0; t < SS_NT; ++t) { R[t][ct][0] += pbias[ct].x; R[t][ct][1] += pbias[ct].y; R[t][ct][2] += pbias[ct].z; R[t][ct][3] += pbias[ct].w; }
-#if SS_DBG_SAVE
-      if (sv) {          // t2, and the attention output's volume (its fragments live in attn_image: same piece size)
-#pragma unroll
-        for (int t = 0; t < SS_NT; ++t)
-#pragma unroll
-          for (int ct = 0; ct < 3; ++ct) {
-            SS_SAVE8(6, SS_C, 16 * t + li, 48 * wave + 16 * ct + 4 * g, pack_bf2(R[t][ct][0], R[t][ct][1]), pack_bf2(R[t][ct][2], R[t][ct][3]));
-            SS_SAVE8(5, SS_C, 16 * t + li, 48 * wave + 16 * ct + 4 * g, pack_bf2(R[t][ct][0], R[t][ct][1]), pack_bf2(R[t][ct][2], R[t][ct][3]));
-          }
-      }
-#endif
     }
 
     SS_STAMP(9);
@@ -732,7 +660,7 @@ __global__ __launch_bounds__(64 * NW, 2) void sstage_kernel(const SsArgs a) {
     {
       SS_PHASE
       ring_fill<2, 3>(ring2, wp + (size_t)(WS_FC1 + wave * (2 * SS_KS)) * 1024, lane);            // lands under the LayerNorm
-      layer_norm_to_lds<NW, SS_LN2_VAR>(R, vec + V_N2W, vec + V_N2B, a.eps, smem, wave, lane, SS_DBG_SAVE ? sv_or_null : nullptr, 7);
+      layer_norm_to_lds<NW, SS_LN2_VAR>(R, vec + V_N2W, vec + V_N2B, a.eps, smem, wave, lane);
     }
     SS_STAMP(10);
 #pragma unroll 1
@@ -754,15 +682,9 @@ __global__ __launch_bounds__(64 * NW, 2) void sstage_kernel(const SsArgs a) {
         for (int t = 0; t < SS_NT; ++t) {
           f32x2_t h0 = {acc[t][0][0] + b0.x, acc[t][0][1] + b0.y}, h1 = {acc[t][0][2] + b0.z, acc[t][0][3] + b0.w};
           f32x2_t h2 = {acc[t][1][0] + b1.x, acc[t][1][1] + b1.y}, h3 = {acc[t][1][2] + b1.z, acc[t][1][3] + b1.w};
-#if SS_DBG_SAVE
-          if (sv) { SS_SAVE8(8, SS_HID, 16 * t + li, 32 * NW * c + 32 * wave + 4 * g, pack_bf2(h0[0], h0[1]), pack_bf2(h1[0], h1[1])); SS_SAVE8(8, SS_HID, 16 * t + li, 32 * NW * c + 32 * wave + 16 + 4 * g, pack_bf2(h2[0], h2[1]), pack_bf2(h3[0], h3[1])); }
-#endif
           gelu4(h0, h1, h2, h3);
           const u32x4_t hf = {pack_bf2(h0[0], h0[1]), pack_bf2(h1[0], h1[1]), pack_bf2(h2[0], h2[1]), pack_bf2(h3[0], h3[1])};
           *reinterpret_cast<u32x4_t*>(smem + L_H + ((wave * SS_NT + t) * 64 + lane) * 16) = hf;
-#if SS_DBG_SAVE
-          if (sv) { SS_SAVE8(12, SS_HID, 16 * t + li, 32 * NW * c + 32 * wave + 4 * g, hf[0], hf[1]); SS_SAVE8(12, SS_HID, 16 * t + li, 32 * NW * c + 32 * wave + 16 + 4 * g, hf[2], hf[3]); }
-#endif
         }
       }
       if (c == 2) SS_STAMP(17);
@@ -954,9 +876,6 @@ static int ss_launch(const lmv_sstage_desc* d, const void* x, const void* c, voi
     a.flags = (unsigned*)ws; a.kbuf = ws + flags; a.vbuf = a.kbuf + (size_t)nb * G::KBUF_IMG; a.halo = a.vbuf + (size_t)nb * G::VBUF_IMG; a.park = a.halo + (size_t)nb * G::HALO_IMG;
     a.B = nb; a.nblocks = d->nblocks; a.eps = d->eps;
     a.timing = (unsigned long long*)d->timing; a.timing_block = d->timing_block;
-#if SS_DBG_SAVE
-    if (d->timing_block == -7) { a.save = (unsigned char*)d->timing; a.timing = nullptr; }          // (experiment: `timing` carries the save buffer, 16 x 112 x C x 2 bytes per workgroup and block)
-#endif
     a.err = errword;
     a.tickets = a.flags + 4 * nb; a.quota = 2u * (unsigned)((nb + 7) / 8); a.skew = (unsigned)lmv_config().stage_ticket_skew;
     const int nwg = 2 * ((nb + 7) / 8) * 8;          // = 8 quota

@@ -102,6 +102,7 @@ class FlatGradSync:
         self.compress = compress           # "bf16": the block gradients travel as bfloat16 (half the xGMI bytes)
         self._work = {}
         self._wire = {}                    # chunk -> bf16 wire buffer (compress == "bf16")
+        self._tmp = {}                     # chunk -> fp32 staging of gradient / world on its way to the wire
         self._hold = False                 # no_sync(): gradient accumulation in progress, nothing is sent
 
     @contextlib.contextmanager
@@ -125,7 +126,10 @@ class FlatGradSync:
             wire = self._wire.get(k)
             if wire is None:
                 wire = self._wire[k] = torch.empty(e - s, device=self.flat.device, dtype=torch.bfloat16)
-            wire.copy_(self.flat[s:e])
+            # the MEAN is formed on the wire: every rank sends gradient / world (an exact exponent shift for the power-of-two world sizes of one node), so the bf16 partial
+            # sums of the ring stay at the magnitude of one rank's gradient whatever the world size is (un-divided bf16 sums lose a bit per doubling of the world)
+            torch.mul(self.flat[s:e], 1.0 / self.world, out=self._scratch(k, e - s))
+            wire.copy_(self._scratch(k, e - s))
             self._work[k] = dist.all_reduce(wire, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
         else:
             self._work[k] = dist.all_reduce(self.flat[s:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
@@ -162,7 +166,8 @@ class FlatGradSync:
                 s, e = self.bounds[k]
                 self.flat[s:e].copy_(self._wire[k])
         self._work.clear()
-        self.flat.mul_(1.0 / self.world)
+        if self.compress != "bf16":
+            self.flat.mul_(1.0 / self.world)
         if rest_work is not None:
             rest_work.wait()
             rest_flat.mul_(1.0 / self.world)
@@ -173,30 +178,51 @@ class FlatGradSync:
                     g.copy_(rest_flat[off:off + n].view(g.shape))
                     off += n
 
+    def attach_buffer_broadcast(self, model: torch.nn.Module, src: int = 0):
+        """broadcast_buffers() in front of every TRAINING forward pass of `model` (a forward pre-hook; returns its handle)."""
+        if not self.active:
+            return None
+
+        def _pre(mod, args):
+            if mod.training and torch.is_grad_enabled():
+                self.broadcast_buffers(mod, src)
+        self._buffer_hook = model.register_forward_pre_hook(_pre)
+        return self._buffer_hook
+
+    def _scratch(self, k: int, n: int) -> torch.Tensor:
+        t = self._tmp.get(k)
+        if t is None or t.numel() != n:
+            t = self._tmp[k] = torch.empty(n, device=self.flat.device, dtype=torch.float32)
+        return t
+
     def broadcast_buffers(self, model: torch.nn.Module, src: int = 0) -> None:
-        """The reference's DDP default (main.py:333, broadcast_buffers=True): rank 0's BatchNorm statistics before a forward pass."""
+        """The reference's DDP default (main.py:333, broadcast_buffers=True): rank `src`'s buffers -- the BatchNorm running statistics (3 494 elements for LeMeViT-Base) and
+        their integer batch counters -- reach every rank before a forward pass, as ONE flat broadcast per element class (DistributedDataParallel._sync_buffers coalesces the same
+        way).  attach_flat_grad_sync(broadcast_buffers=True), the default, runs it in front of every training forward pass."""
         if not self.active:
             return
-        bufs = [b for b in model.buffers() if b.is_floating_point()]
-        if not bufs:
-            return
-        flat = torch.cat([b.reshape(-1).float() for b in bufs])
-        dist.broadcast(flat, src, group=self.group)
-        off = 0
         with torch.no_grad():
-            for b in bufs:
-                n = b.numel()
-                b.copy_(flat[off:off + n].view(b.shape))
-                off += n
+            for pick, dt in ((lambda b: b.is_floating_point(), torch.float32), (lambda b: not b.is_floating_point(), torch.int64)):
+                bufs = [b for b in model.buffers() if pick(b)]
+                if not bufs:
+                    continue
+                flat = torch.cat([b.reshape(-1).to(dt) for b in bufs])
+                dist.broadcast(flat, src, group=self.group)
+                off = 0
+                for b in bufs:
+                    n = b.numel()
+                    b.copy_(flat[off:off + n].view(b.shape))
+                    off += n
 
 
 def attach_flat_grad_sync(model: torch.nn.Module, opt, nchunks: int = 4, group=None, src: int = 0, force: bool = False,
-                          compress: Optional[str] = None) -> FlatGradSync:
+                          compress: Optional[str] = None, broadcast_buffers: bool = True) -> FlatGradSync:
     """Wire a FlatAdamW-managed model for data parallelism: broadcast rank `src`'s parameters / buffers, cut the flat gradient
-    buffer into `nchunks` runs of whole blocks and hook each run's all-reduce to the backward pass of its first block."""
+    buffer into `nchunks` runs of whole blocks and hook each run's all-reduce to the backward pass of its first block.
+    broadcast_buffers (default True, as the reference's DistributedDataParallel at main.py:333): rank `src`'s buffers are broadcast in front of EVERY training forward pass
+    (a forward pre-hook on the model), so the BatchNorm running statistics -- which every rank updates from its own shard of the batch -- stay those of rank `src` everywhere,
+    as under torch DDP; False: only once, here."""
     from .optim import flat_chunk_plan
-    if getattr(opt, "_ov_bounds", None):
-        opt.disable_overlap()                                          # the all-reduce owns the chunk callbacks: the update waits for finish()
     bounds, first = flat_chunk_plan(model, opt, nchunks)
     block_params = {id(p) for _, p, _, _ in opt._slices}
     rest = [p for p in model.parameters() if p.requires_grad and id(p) not in block_params]
@@ -211,4 +237,6 @@ def attach_flat_grad_sync(model: torch.nn.Module, opt, nchunks: int = 4, group=N
             for p in rest:
                 dist.broadcast(p.data, src, group=group)
         sync.broadcast_buffers(model, src)
+    if broadcast_buffers:
+        sync.attach_buffer_broadcast(model, src)
     return sync

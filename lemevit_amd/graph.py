@@ -43,6 +43,10 @@ class GraphedStep:
         torch.cuda.synchronize()
 
     def __call__(self) -> None:
+        # the verdict on the stage launches of the replays that have completed so far (a plain load of the pinned error word): a replayed stage kernel that lost a
+        # hand-off is an exception on the next call at the latest.  Callers that consume the outputs of the LAST replay run ops.check_stage_errors(sync=True) first.
+        from . import ops as _ops
+        _ops.check_stage_errors("graph replay", sync=False)
         self.graph.replay()
 
 
@@ -103,4 +107,6 @@ def try_graphed(step_fn: Callable[[], None], warmup: int = 3, pre_capture: Optio
         return GraphedStep(step_fn, warmup, pre_capture), None
     except Exception as e:  # capture can fail on ops that synchronise; fall back to eager
         torch.cuda.synchronize()
+        if "lost an in-launch hand-off" in str(e):
+            raise               # wrong tensors in the warm-up runs are not a reason to fall back: they are an error (ops.check_stage_errors)
         return step_fn, f"{type(e).__name__}: {e}"

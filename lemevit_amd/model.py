@@ -257,12 +257,11 @@ class _Conv3x3s2Fn(torch.autograd.Function):
 
 
 def _is_conv3x3s2(m: nn.Module, x: Tensor) -> bool:
-    return (_CONV_NATIVE and isinstance(m, nn.Conv2d) and m.kernel_size == (3, 3) and m.stride == (2, 2) and m.padding == (1, 1) and m.dilation == (1, 1)
+    return (isinstance(m, nn.Conv2d) and m.kernel_size == (3, 3) and m.stride == (2, 2) and m.padding == (1, 1) and m.dilation == (1, 1)
             and m.groups == 1 and m.in_channels % 8 == 0 and m.out_channels % 8 == 0 and m.padding_mode == "zeros" and x.is_cuda
-            and x.dtype in (torch.float32, torch.bfloat16) and m.weight.dtype == torch.float32)
+            and x.dtype in (torch.float32, torch.bfloat16) and m.weight.dtype in (torch.float32, torch.bfloat16))          # (bf16 weights: benchmark.py's --precision bfloat16 whole-model cast)
 
 
-_CONV_NATIVE = os.environ.get("LMV_CONV_NATIVE", "1") != "0"          # A/B testing against MIOpen
 _CONV_IMPLICIT = os.environ.get("LMV_CONV_IMPLICIT", "1") != "0"      # 0: the patch-matrix form of the 3 x 3 / stride-2 convolutions (im2col + GEMM; A/B runs)
 
 
@@ -292,12 +291,10 @@ class _BNActFn(torch.autograd.Function):
         return dx.view(B, H, W, C).permute(0, 3, 1, 2), dgamma.to(wdt), dbeta.to(bdt), None, None, None, None, None
 
 
-_BN_NATIVE = os.environ.get("LMV_BN_NATIVE", "1") != "0"          # A/B testing against torch / MIOpen
-
 
 def _bn_native(m: nn.Module, x: Tensor) -> bool:
     """Can this BatchNorm2d call run on the HIP training kernels?"""
-    return (_BN_NATIVE and isinstance(m, nn.BatchNorm2d) and m.training and m.affine and m.track_running_stats and m.momentum is not None and x.is_cuda
+    return (isinstance(m, nn.BatchNorm2d) and m.training and m.affine and m.track_running_stats and m.momentum is not None and x.is_cuda
             and x.dim() == 4 and x.dtype in (torch.float32, torch.bfloat16) and x.shape[1] % 8 == 0 and x.shape[1] <= 1024
             and x.shape[0] * x.shape[2] * x.shape[3] > 1 and m.weight.dtype == torch.float32)
 
@@ -463,7 +460,7 @@ def _tail_infer(norm_c: nn.LayerNorm, bn: nn.BatchNorm2d, head: nn.Linear, xt: T
 
 def _tail_native(norm_c: nn.Module, head: Optional[nn.Module], xt: Tensor, c: Tensor, cd: torch.dtype) -> bool:
     ok = (isinstance(norm_c, nn.LayerNorm) and norm_c.elementwise_affine and norm_c.bias is not None and xt.is_cuda and cd in (torch.float32, torch.bfloat16)
-          and xt.shape[-1] % 8 == 0 and norm_c.weight.dtype == torch.float32 and os.environ.get("LMV_TAIL_NATIVE", "1") != "0")
+          and xt.shape[-1] % 8 == 0 and norm_c.weight.dtype == torch.float32)
     if head is not None:
         ok = ok and isinstance(head, nn.Linear) and head.in_features % 8 == 0 and head.weight.dtype == torch.float32
     return ok
@@ -519,7 +516,7 @@ _stem_cache: dict = {}
 
 def _stem_applies(mods, x: Tensor, cd: torch.dtype) -> bool:
     """models/lemevit.py:698-704: Conv(3, C/2, 3, 2, 1) - BN - GELU - Conv(C/2, C, 3, 2, 1) - BN in inference -> ONE launch (csrc/stem.hip)."""
-    if not (_STEM and _CONV_NATIVE and len(mods) == 5 and x.is_cuda and x.dim() == 4 and x.shape[1] == 3 and cd == torch.bfloat16 and x.dtype in (torch.float32, torch.bfloat16)):
+    if not (_STEM and len(mods) == 5 and x.is_cuda and x.dim() == 4 and x.shape[1] == 3 and cd == torch.bfloat16 and x.dtype in (torch.float32, torch.bfloat16)):
         return False
     c1, b1, act, c2, b2 = mods
     ok = lambda c, ci, co: (isinstance(c, nn.Conv2d) and c.kernel_size == (3, 3) and c.stride == (2, 2) and c.padding == (1, 1) and c.dilation == (1, 1) and c.groups == 1
@@ -569,10 +566,6 @@ def _resolve_dtype(x: Tensor) -> torch.dtype:
 # native block schedules (csrc/block.hip): ONE C-ABI call per block and pass instead of ~12 / ~30 per-op calls from blocks.py
 # ------------------------------------------------------------------------------------------------
 _NATIVE = os.environ.get("LMV_BLOCK_NATIVE", "1") != "0"      # 0: the Python schedules of blocks.py (A/B runs; they also serve "D2" / "Sx")
-# Cross-block DropPath pre-scaling (lmv_block_desc.out_scale / g_pre): OFF by default.  Measured on LeMeViT-Base 224 B = 128 (round 5): 26 of the 32 row-scale launches
-# per step go (-0.36 ms of kernel time on the critical stream, +0.18 ms in the two-output depthwise-conv launches), and the step gets 0.2-0.35 ms SLOWER in every interleaved pair.
-_PRESCALE_MAX_BYTES = int(float(os.environ.get("LMV_PRESCALE_MAX_MB", "1e9")) * 2 ** 20)
-_PRESCALE = os.environ.get("LMV_PRESCALE", "0") != "0"
 _KIND_CODE = {"S": 0, "D": 1, "C": 2}
 _COMMON_FIELDS = {"pos_embed.weight": "pos_w", "pos_embed.bias": "pos_b", "norm1.weight": "n1_w", "norm1.bias": "n1_b", "norm2.weight": "n2_w",
                   "norm2.bias": "n2_b", "mlp.0.weight": "fc1_w", "mlp.0.bias": "fc1_b", "mlp.3.weight": "fc2_w", "mlp.3.bias": "fc2_b"}
@@ -742,10 +735,7 @@ def native_block_forward(kind: str, x: Tensor, c: Tensor, H: int, W: int, names,
     return (x if xo is None else xo), co, ((d, arena) if save else None)
 
 
-def native_block_backward(kind: str, state, x: Tensor, c: Tensor, dx: Optional[Tensor], dc: Tensor, H: int, W: int, names, G: Dict[str, Tensor],
-                          out_scale=(None, None), g_pre=(None, None)):
-    """out_scale: per-sample vectors (x, c) of the block that will consume dx / dc -- the PREVIOUS block of the stage: its MLP-half DropPath scales; the pre-scaled copies come
-    back as a third / fourth result (lmv_block_desc.out_scale).  g_pre: dx / dc already multiplied by THIS block's MLP-half DropPath scales by the block that produced them."""
+def native_block_backward(kind: str, state, x: Tensor, c: Tensor, dx: Optional[Tensor], dc: Tensor, H: int, W: int, names, G: Dict[str, Tensor]):
     from ._lib import lib, check
     from . import blocks as blocks_mod
     from .blocks import side_stream_handle
@@ -762,20 +752,12 @@ def native_block_backward(kind: str, state, x: Tensor, c: Tensor, dx: Optional[T
     _bwd_slot = (_bwd_slot + 1) % (blocks_mod._DEFER + 1) if defer else 0
     scratch = _persistent(("bwd", _bwd_slot), nbytes, x.device)
     dx0, dc0 = torch.empty_like(x), torch.empty_like(c)
-    dx_s = torch.empty_like(x) if (out_scale[0] is not None and kind in ("S", "D")) else None
-    dc_s = torch.empty_like(c) if (out_scale[1] is not None and kind in ("S", "D")) else None
-    d.out_scale[0] = None if dx_s is None else out_scale[0].data_ptr()
-    d.out_scale[1] = None if dc_s is None else out_scale[1].data_ptr()
-    d.dx_scaled = None if dx_s is None else dx_s.data_ptr()
-    d.dc_scaled = None if dc_s is None else dc_s.data_ptr()
-    d.g_pre[0] = None if g_pre[0] is None else g_pre[0].data_ptr()
-    d.g_pre[1] = None if g_pre[1] is None else g_pre[1].data_ptr()
     d.flags = 1 if defer else 0          # LMV_BLOCK_NO_JOIN
     check(lib.lmv_block_bwd(d, x.data_ptr(), c.data_ptr(), arena.data_ptr(), arena.numel(), None if dx is None else dx.data_ptr(), dc.data_ptr(), dx0.data_ptr(),
                             dc0.data_ptr(), scratch.data_ptr(), scratch.numel(), ops._stream(), side), "lmv_block_bwd")
     if defer:
-        blocks_mod.defer_join(x.device.index, (arena, x, c, dx, dc, scratch, g_pre))
-    return dx0, dc0, dx_s, dc_s
+        blocks_mod.defer_join(x.device.index, (arena, x, c, dx, dc, scratch))
+    return dx0, dc0
 
 
 # ------------------------------------------------------------------------------------------------
@@ -783,9 +765,7 @@ def native_block_backward(kind: str, state, x: Tensor, c: Tensor, dx: Optional[T
 # ------------------------------------------------------------------------------------------------
 class _BlockFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, c, kind, H, W, masks, prev, names, *params):
-        """prev: (x, c) MLP-half DropPath vectors of the PREVIOUS block of the stage (or None): this block's backward pass then also writes its input gradients multiplied by them
-        (lmv_block_desc.out_scale) and tags the tensors it returns, so that the previous block's node finds them (`_lmv_pre`) and skips its row-scale launch."""
+    def forward(ctx, x, c, kind, H, W, masks, names, *params):
         cd = x.dtype
         P = {n: compute_copy(p, cd if _is_matrix(n) else torch.float32) for n, p in zip(names, params)}
         ctx.native = _native_ok(kind, x, c)
@@ -805,7 +785,6 @@ class _BlockFn(torch.autograd.Function):
                 _join_ranges(x.device)
             xo, co, saved = block_forward(kind, x, c, H, W, P, masks, save=True)
         ctx.kind, ctx.H, ctx.W, ctx.masks, ctx.names = kind, H, W, masks, names
-        ctx.prev = prev if (_PRESCALE and prev is not None and kind in ("S", "D") and x.numel() * x.element_size() <= _PRESCALE_MAX_BYTES) else None
         ctx.saved, ctx.P = saved, P
         ctx.pmeta = [(p.shape, p.dtype) for p in params]
         ctx.params = params
@@ -846,48 +825,34 @@ class _BlockFn(torch.autograd.Function):
                 off += pd
         if ctx.native:
             xin, cin, state = ctx.saved
-            g_pre = [None, None]
-            if _PRESCALE and kind in ("S", "D"):
-                # the node that produced dx / dc (the next block of the stage) may have left them pre-multiplied by THIS block's MLP-half DropPath vectors
-                for s_i, (gt, mk) in enumerate(((dx, ctx.masks[1]), (dc, ctx.masks[3]))):
-                    tag = getattr(gt, "_lmv_pre", None)
-                    if tag is not None and mk is not None and tag[1] is mk and tag[0].shape == gt.shape and tag[0].dtype == gt.dtype and gt.is_contiguous():
-                        g_pre[s_i] = tag[0]
-            osc = ctx.prev if ctx.prev is not None else (None, None)
-            dx0, dc0, dx_s, dc_s = native_block_backward(kind, state, xin, cin, None if dx is None else dx.contiguous(), dc.contiguous(), ctx.H, ctx.W, names, G,
-                                                        out_scale=osc, g_pre=tuple(g_pre))
-            if dx_s is not None:
-                dx0._lmv_pre = (dx_s, osc[0])
-            if dc_s is not None:
-                dc0._lmv_pre = (dc_s, osc[1])
+            dx0, dc0 = native_block_backward(kind, state, xin, cin, None if dx is None else dx.contiguous(), dc.contiguous(), ctx.H, ctx.W, names, G)
             if kind == "C" and dx is not None:
                 dx0 = dx0 + dx                      # the untouched x's pass-through gradient (as blocks.block_backward)
         else:
             dx0, dc0 = block_backward(kind, ctx.saved, None if dx is None else dx.contiguous(), None if dc is None else dc.contiguous(), ctx.H, ctx.W, P, G, ctx.masks)
         cb = getattr(ctx.params[0], "_lmv_grad_cb", None) if inplace else None
         ctx.saved = ctx.params = None
-        if (cb is not None and not getattr(cb, "_lmv_no_join", False)) or not inplace:
+        if cb is not None or not inplace:
             # the parameter gradients leave this node now (all-reduce of the chunk / autograd's accumulation on the current stream):
-            # the deferred joins of the weight-gradient side stream (blocks.defer_join) are due.  (A consumer that orders its own stream behind the side stream --
-            # FlatAdamW's overlapped update -- marks its callback `_lmv_no_join`: the main stream keeps going.)
+            # the deferred joins of the weight-gradient side stream (blocks.defer_join) are due
             from . import blocks as _blocks
             _blocks._wait_pending(0, x0.device.index)
         if cb is not None:
             cb()                     # lemevit_amd.dist.FlatGradSync: this block closes a chunk of the flat gradient buffer -> start its all-reduce
         if inplace:
-            return (dx0, dc0, None, None, None, None, None, None, *([None] * len(names)))
+            return (dx0, dc0, None, None, None, None, None, *([None] * len(names)))
         pg = [G[n] if dt == torch.float32 else G[n].to(dt) for n, (_, dt) in zip(names, ctx.pmeta)]
-        return (dx0, dc0, None, None, None, None, None, None, *pg)
+        return (dx0, dc0, None, None, None, None, None, *pg)
 
 
 def run_block(kind: str, x: Tensor, c: Tensor, H: int, W: int, params: "OrderedDict[str, Tensor]",
-              masks: Sequence[Optional[Tensor]], prev=None) -> Tuple[Tensor, Tensor]:
+              masks: Sequence[Optional[Tensor]]) -> Tuple[Tensor, Tensor]:
     """LeMeBlock on token-major tensors; picks the autograd node or the no-grad fast path."""
     names = PARAM_NAMES[kind]
     plist = [params[n] for n in names]
     need_grad = torch.is_grad_enabled() and (x.requires_grad or c.requires_grad or any(p.requires_grad for p in plist))
     if need_grad:
-        out = _BlockFn.apply(x, c, kind, H, W, tuple(masks), prev, names, *plist)
+        out = _BlockFn.apply(x, c, kind, H, W, tuple(masks), names, *plist)
         return (x, out) if kind == "C" else ((out, c) if kind == "Sx" else out)
     cd = x.dtype
     P = {n: compute_copy(p, cd if _is_matrix(n) else torch.float32) for n, p in zip(names, plist)}
@@ -1288,13 +1253,13 @@ class LeMeBlock(nn.Module):
         m = [torch.empty(B, device=device, dtype=torch.float32).bernoulli_(keep).div_(keep) for _ in range(n)]
         return m + [None] * (4 - n)
 
-    def forward_tokens(self, x: Tensor, c: Tensor, H: int, W: int, masks=None, prev=None) -> Tuple[Tensor, Tensor]:
-        """x [B, H*W, C] token-major, c [B, M, C].  prev: the (x, c) MLP-half DropPath vectors of the previous block of the stage (see _BlockFn)."""
+    def forward_tokens(self, x: Tensor, c: Tensor, H: int, W: int, masks=None) -> Tuple[Tensor, Tensor]:
+        """x [B, H*W, C] token-major, c [B, M, C]."""
         if masks is None:
             masks = self._masks(x.shape[0], x.device)
             if any(m is not None for m in masks):
                 _cache_filled()          # masks drawn HERE are kernels on the current stream: image_ranges() must re-fork its range streams behind them (ADVICE round 3)
-        return run_block(self.kind, x, c, H, W, self._params(), masks, prev)
+        return run_block(self.kind, x, c, H, W, self._params(), masks)
 
     def forward(self, x: Tensor, c: Tensor) -> Tuple[Tensor, Tensor]:
         """Reference signature: x NCHW in / out (models/lemevit.py:652)."""
@@ -1422,8 +1387,9 @@ class LeMeViT(nn.Module):
                     x = _Conv3x3s2Fn.apply(x, w, b32, cd)
                     i += 2
                 else:
-                    x = F.conv2d(x.to(w.dtype), w, b, m.stride, m.padding, m.dilation, m.groups)
-                    i += 2
+                    # (no vendor-library convolution behind the native ones: the stock PyTorch-ROCm column lives in tools/stock_eager.py)
+                    raise NotImplementedError(f"lemevit_amd: no native kernel for {m} on a {tuple(x.shape)} {x.dtype} map (the library carries the 3 x 3 / stride-2 / padding-1 "
+                                              "convolutions of the LeMeViT stem and stage transitions, channels a multiple of 8, fp32 / bf16)")
             elif _is_stem_conv1(m, x) and cd in (torch.float32, torch.bfloat16):
                 x = _StemConv1Fn.apply(x, m.weight, m.bias, cd)
                 i += 1
@@ -1435,7 +1401,9 @@ class LeMeViT(nn.Module):
                 x = _bn_train(m, x, gelu)
                 i += 2 if gelu else 1
             else:
-                x = m(x)
+                if isinstance(m, nn.Conv2d):
+                    raise NotImplementedError(f"lemevit_amd: no native kernel for {m} on a {tuple(x.shape)} {x.dtype} map (see above)")
+                x = m(x)          # (element-wise glue of a caller-built Sequential: activation, Identity, an eval-mode normalisation under autograd)
                 i += 1
         return x
 
@@ -1549,12 +1517,8 @@ class LeMeViT(nn.Module):
                 continue
             all_masks = st["masks"]
             with image_ranges(xt.device, B):
-                prev = None
                 for blk in self.stages[i]:
-                    mk = all_masks.get(id(blk)) if all_masks else None
-                    xt, c = blk.forward_tokens(xt, c, H, W, masks=mk, prev=prev)
-                    # the next block's backward pass writes ITS input gradients pre-multiplied by this block's MLP-half DropPath vectors (S / D blocks: masks 1 and 3)
-                    prev = (mk[1], mk[3]) if (mk is not None and blk.kind in ("S", "D") and mk[1] is not None and mk[3] is not None) else None
+                    xt, c = blk.forward_tokens(xt, c, H, W, masks=all_masks.get(id(blk)) if all_masks else None)
         return self._tail(xt, H, W, c, st)
 
     def _tail_split(self, i: int, xt: Tensor, H: int, W: int, c: Tensor, st: dict) -> Tensor:

@@ -211,17 +211,6 @@ def linear_dw(probs: Sequence[Prob], N: int, K: int, stream: Optional[int] = Non
     check(lib.lmv_linear_dw(arr, len(probs), N, K, ws.data_ptr(), ws.numel(), code, st), "lmv_linear_dw")
 
 
-def linear_dw_chain(probs: Sequence[Prob], N: int, K: int, ws: Tensor, pending: Sequence["_lib.ReduceSeg"]) -> List["_lib.ReduceSeg"]:
-    """lmv_linear_dw_chain: the weight-gradient GEMM of `probs` leaves its slabs in `ws` (returned as segments), the slab sums of `pending` (segments of an earlier call on this
-    stream, in another workspace) ride in the same launch.  Close a chain with reduce_segments()."""
-    arr, code = _pack(probs), dtype_code(probs[0].a)
-    pend = (_lib.ReduceSeg * max(len(pending), 1))(*pending)
-    segs = (_lib.ReduceSeg * 2)()
-    n = C.c_int(0)
-    check(lib.lmv_linear_dw_chain(arr, len(probs), N, K, ws.data_ptr(), ws.numel(), code, _stream(), pend, len(pending), segs, C.byref(n)), "lmv_linear_dw_chain")
-    return [_lib.ReduceSeg.from_buffer_copy(segs[i]) for i in range(n.value)]
-
-
 def reduce_segments(segs: Sequence["_lib.ReduceSeg"]) -> None:
     if segs:
         arr = (_lib.ReduceSeg * len(segs))(*segs)

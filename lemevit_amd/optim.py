@@ -62,19 +62,10 @@ class FlatAdamW:
 
     Interface: ``step()``, ``zero_grad()``, ``param_groups`` (one dict per group with ``lr`` -- schedulers may edit it),
     ``state_dict()`` / ``load_state_dict()``, ``refresh()`` (re-derive the bf16 copies after the parameters were
-    changed by something else; done automatically after ``model.load_state_dict``).
-
-    ``overlap=k`` (k chunks, 0 = off): the update of the block parameters is issued WHILE the backward pass runs.  The flat buffers are cut into k runs of whole blocks
-    (``flat_chunk_plan``); when the backward pass has written the last gradient of a run (its first block has been differentiated) the AdamW launch of that run, the
-    refresh of its transposed bf16 copies and the zeroing of its gradients go to a second stream, next to the differentiation of the earlier blocks -- the same arithmetic on
-    the same values as ``step()`` would do afterwards (nothing later in the backward pass reads the parameters of a finished run or their bf16 copies: see ``_chunk_ready``),
-    so the parameters after a step are bit-identical.  ``step()`` then applies whatever was not consumed (a run whose
-    gradients were unbound, the non-block parameters), and waits for the second stream.  The contract that makes it legal: ONE backward pass per step, armed by
-    ``zero_grad()`` -- ``loss.backward(); opt.step(); opt.zero_grad()`` as benchmark.py:572-596 runs it.  No gradient accumulation, clipping or loss-scale inspection between
-    backward and step (they need the whole gradient first): use ``with opt.no_overlap():`` around such passes, or leave ``overlap`` at 0."""
+    changed by something else; done automatically after ``model.load_state_dict``)."""
 
     def __init__(self, model: nn.Module, lr: float = 1e-3, betas: Tuple[float, float] = (0.9, 0.999), eps: float = 1e-8,
-                 weight_decay: float = 1e-2, no_decay: Callable[[str, Tensor], bool] = _default_no_decay, capturable: bool = True, overlap: int = 0):
+                 weight_decay: float = 1e-2, no_decay: Callable[[str, Tensor], bool] = _default_no_decay, capturable: bool = True):
         from .model import LeMeBlock, _is_matrix
         self.betas, self.eps, self.weight_decay = betas, eps, weight_decay
         flat_named: List[Tuple[str, nn.Parameter, bool]] = []        # (name, param, wants bf16 copy)
@@ -135,17 +126,6 @@ class FlatAdamW:
         self.param_groups = [dict(params=[p for _, p, _, _ in self._slices], lr=lr, betas=betas, eps=eps, weight_decay=weight_decay,
                                   name="lemevit_blocks_flat")] + (self._rest.param_groups if self._rest else [])
         self._hook = model.register_load_state_dict_post_hook(lambda *_: self.refresh())
-        # ---- overlapped update (see the class docstring) ----
-        self._ov_bounds: List[Tuple[int, int]] = []
-        self._ov_tpairs: List[List[Tuple[Tensor, Tensor]]] = []
-        self._ov_done: List[bool] = []
-        self._ov_armed = False             # zero_grad() arms: the next backward pass is the step's only one
-        self._ov_suspended = False         # no_overlap()
-        self._ov_bumped = False            # the step counter has been advanced for the pass in flight
-        self._ov_stream: Optional[torch.cuda.Stream] = None
-        self._clean_pass = -1              # model._train_pass at which every flat gradient was left zeroed by the overlapped update
-        if overlap > 0:
-            self.enable_overlap(model, overlap)
 
     # ---- the optimizer interface ---------------------------------------------------------------------------------
     def _rebind(self, keep: bool) -> list:
@@ -172,58 +152,10 @@ class FlatAdamW:
         return touched
 
     def zero_grad(self, set_to_none: bool = True) -> None:
-        from . import model as _model
-        if not (self._ov_bounds and self._clean_pass == _model._train_pass):      # (the overlapped update zeroed every run behind its launch, and no training pass has run since)
-            self._flat_g.zero_()                                       # the flat gradients stay allocated: the kernels accumulate into them
-        self._clean_pass = -1
+        self._flat_g.zero_()                                           # the flat gradients stay allocated: the kernels accumulate into them
         self._rebind(keep=False)
         if self._rest is not None:
             self._rest.zero_grad(set_to_none=set_to_none)
-        if self._ov_bounds:
-            self._ov_armed, self._ov_bumped = True, False
-            self._ov_done = [False] * len(self._ov_bounds)
-
-    # ---- overlapped update -----------------------------------------------------------------------------------------
-    def enable_overlap(self, model: nn.Module, nchunks: int = 4) -> None:
-        """Arrange for the block parameters to be updated chunk by chunk during the backward pass (class docstring).  Not together with FlatGradSync (the
-        all-reduce owns the chunk callbacks: attach_flat_grad_sync switches this off)."""
-        bounds, first = flat_chunk_plan(model, self, nchunks)
-        self._ov_bounds = bounds
-        self._ov_tpairs = [[] for _ in bounds]
-        for name, p, off, n in self._slices:
-            wt = getattr(p, "_lmv_shadow_t", None)
-            if wt is not None:
-                k = next(i for i, (s_, e_) in enumerate(bounds) if s_ <= off < e_)
-                self._ov_tpairs[k].append((p._lmv_shadow, wt))
-        for k, blk in enumerate(first):
-            cb = (lambda kk=k: self._chunk_ready(kk))
-            cb._lmv_no_join = True             # the update stream waits for the weight-gradient side stream itself: no join of the main stream at the chunk boundary
-            for p in blk.parameters():
-                p._lmv_grad_cb = cb
-        self._ov_first = first
-        self._ov_done = [False] * len(bounds)
-        self._ov_stream = torch.cuda.Stream(device=self._flat_p.device)
-        self._ov_armed = False             # armed by the first zero_grad()
-
-    def disable_overlap(self) -> None:
-        for blk in getattr(self, "_ov_first", []):
-            for p in blk.parameters():
-                if hasattr(p, "_lmv_grad_cb"):
-                    del p._lmv_grad_cb
-        self._ov_bounds, self._ov_tpairs, self._ov_done, self._ov_armed = [], [], [], False
-
-    def no_overlap(self):
-        """Context: backward passes inside it only accumulate (gradient accumulation, clipping); step() then applies everything."""
-        import contextlib
-
-        @contextlib.contextmanager
-        def ctx():
-            prev, self._ov_suspended = self._ov_suspended, True
-            try:
-                yield
-            finally:
-                self._ov_suspended = prev
-        return ctx()
 
     def _apply(self, s: int, e: int) -> None:
         g0 = self.param_groups[0]          # schedulers / users may edit any of these (as for torch.optim.AdamW)
@@ -231,40 +163,6 @@ class FlatAdamW:
         wd = self._wd_mask[s:e]
         ops.adamw_flat(self._flat_p[s:e], self._flat_g[s:e], self._exp_avg[s:e], self._exp_avg_sq[s:e], wd, float(g0["lr"]),
                        float(b1), float(b2), float(g0["eps"]), float(g0["weight_decay"]), 0, shadow=self._shadow[s:e], step_dev=self._step_dev)
-
-    @torch.no_grad()
-    def _chunk_ready(self, k: int) -> None:
-        """Called by model._BlockFn.backward when the first block of run k has been differentiated: every gradient of the run has been enqueued, on the current stream or
-        on the weight-gradient side stream (blocks.py) -- the update stream is ordered behind both, the main stream behind neither.  Nothing later in this backward pass reads the run's parameters or their bf16 copies -- the blocks still to be
-        differentiated precede it -- and the next forward pass starts behind step(), which waits for the update stream."""
-        if not self._ov_bounds or self._ov_suspended:
-            return
-        if not self._ov_armed:
-            return                                           # not armed (no zero_grad() since the last step): step() applies everything
-        if self._ov_done[k]:
-            raise RuntimeError("FlatAdamW(overlap): a second backward pass reached a chunk that the first one already consumed -- one backward pass per step in overlap "
-                               "mode; wrap accumulation passes in `with opt.no_overlap():`")
-        i = k
-        # only when every slice of the run is still bound to the flat gradient buffer (else step() re-binds and applies the run)
-        s, e = self._ov_bounds[k]
-        for j, (_, p, off, n) in enumerate(self._slices):
-            if s <= off < e and p.grad is not self._grad_views[j]:
-                return
-        main = torch.cuda.current_stream(self._flat_p.device)
-        if not self._ov_bumped:
-            self._step_dev += 1                              # (current stream; the update stream is ordered behind it)
-            self._ov_bumped = True
-        self._ov_stream.wait_stream(main)
-        from . import blocks as _blocks
-        side = _blocks._side_streams.get(self._flat_p.device.index)
-        if side is not None:
-            self._ov_stream.wait_stream(side[0])             # the weight-gradient GEMMs and slab reductions of the run (everything the native block calls have enqueued so far)
-        with torch.cuda.stream(self._ov_stream):
-            self._apply(s, e)
-            if self._ov_tpairs[i]:
-                ops.transpose_batch(self._ov_tpairs[i])
-            self._flat_g[s:e].zero_()
-        self._ov_done[k] = True
 
     def rebind_grads(self) -> list:
         """Public form of ``_rebind(keep=True)``: call before anything reads the flat gradient buffer directly (FlatGradSync.finish does).  Returns the (offset, length)
@@ -275,30 +173,10 @@ class FlatAdamW:
     def step(self) -> None:
         from . import blocks as _blocks
         _blocks.drain_deferred()           # backstop: the weight-gradient side stream must have been joined before the update reads the gradients
-        touched = self._rebind(keep=True)
+        self._rebind(keep=True)
         if self._rest is not None:
             self._rest.step()
-        if self._ov_bounds and any(self._ov_done):
-            # overlapped mode: the consumed runs are on the update stream; apply the others here (a consumed run must not have been rewritten since)
-            for k, (s, e) in enumerate(self._ov_bounds):
-                if self._ov_done[k] and any(off < e and off + n > s for off, n in touched):
-                    raise RuntimeError("FlatAdamW(overlap): gradients of a chunk were replaced after the backward pass had already consumed it")
-            main = torch.cuda.current_stream(self._flat_p.device)
-            for k, (s, e) in enumerate(self._ov_bounds):
-                if not self._ov_done[k]:
-                    self._apply(s, e)
-                    ops.transpose_batch(self._ov_tpairs[k])
-                    self._flat_g[s:e].zero_()
-            main.wait_stream(self._ov_stream)
-            from . import model as _model
-            self._clean_pass = _model._train_pass
-            self._ov_armed, self._ov_bumped = False, False
-            self._ov_done = [False] * len(self._ov_bounds)
-            return
-        self._ov_armed = False
-        if not self._ov_bumped:
-            self._step_dev += 1
-        self._ov_bumped = False
+        self._step_dev += 1
         self._apply(0, self._flat_p.numel())
         ops.transpose_batch(self._tpairs)
 
@@ -366,15 +244,32 @@ class ModelEma:
             if k not in src:
                 raise KeyError(k)
             (self._pairs_f if v.dtype.is_floating_point else self._pairs_i).append((v, k))
+        self._src_cache: Optional[Tuple[int, List[Tensor], List[Tensor]]] = None
+
+    def _sources(self, model: nn.Module) -> Tuple[List[Tensor], List[Tensor]]:
+        """The source tensors of the non-flat entries, looked up ONCE per source module (parameters and buffers are updated in place, so the tensors stay the same objects):
+        the reference's flow builds the EMA from the bare model and then calls update() with the DistributedDataParallel wrapper (main.py:316, engine.py) -- the wrapper's
+        state_dict keys carry a 'module.' prefix, so the wrapper is peeled first (timm's ModelEmaV2 zips the two state_dicts positionally for the same reason)."""
+        bare = model
+        while hasattr(bare, "module") and isinstance(getattr(bare, "module"), nn.Module) and not isinstance(bare, type(self.module)):
+            bare = bare.module
+        ent = self._src_cache
+        if ent is None or ent[0] != id(bare):
+            src = bare.state_dict()
+            missing = [k for _, k in self._pairs_f + self._pairs_i if k not in src]
+            if missing:
+                raise KeyError(f"ModelEma.update: the model has no state_dict entry {missing[0]!r} (and {len(missing) - 1} more)")
+            ent = self._src_cache = (id(bare), [src[k] for _, k in self._pairs_f], [src[k] for _, k in self._pairs_i])
+        return ent[1], ent[2]
 
     @torch.no_grad()
     def update(self, model: nn.Module) -> None:
         from . import model as _model
         if self._flat_ema is not None:
             ops.ema_flat(self._flat_ema, self._flat_src, self.decay)
-        src = model.state_dict()
+        src_f, src_i = self._sources(model)
         if self._pairs_f:
-            torch._foreach_lerp_([e for e, _ in self._pairs_f], [src[k].detach().to(e.dtype) for e, k in self._pairs_f], 1.0 - self.decay)
-        for e, k in self._pairs_i:
-            e.copy_(src[k])
+            torch._foreach_lerp_([e for e, _ in self._pairs_f], [t.detach() if t.dtype == e.dtype else t.detach().to(e.dtype) for (e, _), t in zip(self._pairs_f, src_f)], 1.0 - self.decay)
+        for (e, _), t in zip(self._pairs_i, src_i):
+            e.copy_(t)
         _model.new_training_pass()          # the native launch writes through raw pointers (no Tensor._version bump): drop every cached operand copy of the EMA module

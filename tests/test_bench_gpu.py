@@ -31,7 +31,8 @@ def test_bench_single_gpu_line_has_forward_keys():
         assert k in line and line[k] is not None and line[k] > 0, k
     # the forward pass is (much) cheaper than the train step on the same batch
     assert line["forward_ms"] < line["ms_per_step"]
-    assert "concurrent sub-batches" in line["forward_note"]          # the forward probe replays the batch as --infer-parts graph branches
+    assert "hipGraph replay" in line["forward_note"]          # (whole batch or --infer-parts graph branches: whichever the schedule probe measured faster -- forward_schedule_probe_ms)
+    assert line["stage_errors"] == 0 and "forward_schedule_probe_ms" in line
 
 
 @pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two MI355X: bench.py --gpus 2 over RCCL, one device per rank (BASELINE config 4)")

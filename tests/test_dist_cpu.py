@@ -128,3 +128,41 @@ def test_shard_batch():
     assert [list(shard_batch(8, r, 4)) for r in range(4)] == [[0, 1], [2, 3], [4, 5], [6, 7]]
     with pytest.raises(ValueError):
         shard_batch(10, 0, 4)
+
+
+def _bn_worker(rank, world, port, out):
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    from lemevit_amd import dist as D
+    D.init_distributed("gloo")
+    torch.manual_seed(7)
+    net = torch.nn.Sequential(torch.nn.Conv2d(3, 6, 3, padding=1), torch.nn.BatchNorm2d(6), torch.nn.GELU(), torch.nn.Conv2d(6, 4, 3), torch.nn.BatchNorm2d(4)).train()
+    sync = D.FlatGradSync(torch.zeros(8), [(0, 8)], [])
+    sync.attach_buffer_broadcast(net, 0)
+    seen = []
+    net.register_forward_pre_hook(lambda m, a: seen.append({k: v.clone() for k, v in m.state_dict().items() if "running" in k or "num_batches" in k}))       # (runs behind the broadcast)
+    torch.manual_seed(300 + rank)                                  # every rank normalises ITS shard: the running statistics drift apart between broadcasts
+    for _ in range(3):
+        net(torch.randn(4, 3, 8, 8) * (1.0 + rank) + rank)
+    with torch.no_grad():
+        net(torch.randn(4, 3, 8, 8))                               # a no-grad pass is not a training pass: no broadcast
+    final = {k: v.clone() for k, v in net.state_dict().items() if "running" in k}
+    torch.save(dict(seen=seen, final=final), out + f".{rank}")
+    torch.distributed.destroy_process_group()
+
+
+def test_buffer_broadcast_every_training_forward(tmp_path):
+    """The reference's DistributedDataParallel runs with broadcast_buffers=True (main.py:333): rank 0's BatchNorm running statistics and batch counters reach every rank in front
+    of EVERY training forward pass.  FlatGradSync.attach_buffer_broadcast does the same: at the start of each of three training passes both ranks hold the same buffers (rank 0's),
+    although each rank has updated them from different data in between; and the statistics do drift between the broadcasts (the final buffers differ), i.e. the test sees
+    what it claims to."""
+    out = str(tmp_path / "bn.pt")
+    mp.spawn(_bn_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    r0, r1 = torch.load(out + ".0"), torch.load(out + ".1")
+    assert len(r0["seen"]) == 4 and len(r1["seen"]) == 4
+    for step in range(3):
+        for k in r0["seen"][step]:
+            assert torch.equal(r0["seen"][step][k], r1["seen"][step][k]), (step, k)
+    assert int(r1["seen"][2]["1.num_batches_tracked"]) == 2
+    assert any(not torch.equal(r0["final"][k], r1["final"][k]) for k in r0["final"])
+    assert any(not torch.equal(r0["seen"][3][k], r1["seen"][3][k]) for k in r0["final"])          # the no-grad pass saw the drifted statistics: no broadcast outside training

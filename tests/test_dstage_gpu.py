@@ -124,6 +124,14 @@ def test_dstage_vs_per_launch_schedule_full_size(C, G, nblocks, B):
     ex, ec = _rel(xo.float(), xr.float()), _rel(co.float(), cr.float())
     print(f"dstage vs per-launch schedule, C = {C}, {nblocks} blocks, B = {B}: x {ex:.2e} c {ec:.2e}")
     assert ex <= 3e-2 and ec <= 3e-2, (ex, ec)
+    # ... and against the pinned float64 ORACLE on four images of the full-size launch: the first and the last, one that runs in a LATER round of its
+    # slot (image >= the slot count: 64 / 32 slots in flight) and one whose slot takes tickets of another XCD counter.  One block holds 6e-3 (test_dstage_vs_oracle); 2 - 4 blocks deep the measured figures are 3.1 - 6.1e-3 (MI355X, round 6) -- asserted
+    # at 8e-3 (root-sum-square growth of the per-block share over 4 blocks would allow 1.2e-2)
+    idx = sorted({0, 11 % B, (B // 2 + 37) % B, B - 1})
+    xo_, co_ = _oracle(sds, x[idx].float().cpu(), c[idx].float().cpu(), G)
+    es, ecs = _rel(xo[idx].float(), xo_), _rel(co[idx].float(), co_)
+    print(f"dstage vs the float64 oracle, images {idx} of the B = {B} launch, {nblocks} blocks: x {es:.2e} c {ecs:.2e}")
+    assert es <= 8e-3 and ecs <= 8e-3, (es, ecs)
 
 
 @pytest.mark.parametrize("C,G,nblocks,B", [(192, 28, 4, 128), (96, 56, 4, 128), (128, 28, 2, 256), (64, 56, 2, 256), (192, 48, 4, 64), (96, 96, 4, 64)])
@@ -339,13 +347,13 @@ def test_s2stage_full_size_and_under_load():
     ex, ec = _rel(ref[0].float(), xr.float()), _rel(ref[1].float(), cr.float())
     # two bf16 pipelines of the same math 18 blocks deep (the per-launch schedule rounds the residual stream to bf16 after every block, the stage kernel keeps it in fp32): the
     # float64 oracle on two of the images says which one drifts
-    idx = [0, B - 1]
+    idx = [0, 13, B // 2 + 5, B - 1]          # first, last, a later round of a slot (32 images in flight), another XCD counter
     xo_, co_ = x[idx].double().cpu(), c[idx].double().cpu()
     for sd in sds:
         xo_, co_ = O.leme_block({k: v.double() for k, v in sd.items()}, "blk.", "S", xo_, co_, G, G, C // 32)
     es, el = _rel(ref[0][idx].float(), xo_), _rel(xr[idx].float(), xo_)
     print(f"s2stage vs per-launch schedule, 18 blocks, B = 64: x {ex:.2e} c {ec:.2e}; vs the float64 oracle: stage kernel {es:.2e}, per-launch schedule {el:.2e}")
-    assert ex <= 5e-2 and ec <= 5e-2 and es <= 2e-2, (ex, ec, es, el)
+    assert ex <= 5e-2 and ec <= 5e-2 and es <= 1.5e-2, (ex, ec, es, el)          # (18 blocks deep: root-sum-square of the per-block 6e-3; measured 1.1e-2)
     big = torch.empty(3 * 128 * 1024 * 1024, device=DEV, dtype=torch.float32)
     side, side2 = torch.cuda.Stream(), torch.cuda.Stream()
     xh, ch = x[:32].contiguous(), c[:32].contiguous()

@@ -154,51 +154,6 @@ def test_linear_dw_bigk(dtype, rows, rows_c, N, K):
         assert_close(dw2, dyc64.t() @ xc64, torch.float32, "dw2", tol32=tol); assert_close(db2, dyc64.sum(0), torch.float32, "db2", tol32=tol)
 
 
-def test_linear_dw_chain_is_bit_identical():
-    """lmv_linear_dw_chain (round 5): the slab sums of a weight-gradient GEMM ride in the NEXT weight-gradient launch (extra workgroups at the head of its grid) and the last
-    GEMM's slabs are summed by lmv_reduce_batch -- what lmv_block_bwd does with the four GEMMs of a block.  Same summation tree as the reduce launch behind every GEMM
-    (lmv_linear_dw): every gradient word must be identical, including accumulation on top of existing gradients and two problems with different outputs."""
-    o = ops()
-    from lemevit_amd._lib import lib
-    dt = torch.bfloat16
-    shapes = [(27136, 3392, 384, 1536, True), (27136, 3392, 1536, 384, True), (27136, 3392, 384, 384, True), (27136, 3392, 1152, 384, True), (6272, 256, 288, 96, False)]
-    def operands(i, rows, rows_c, N, K):
-        dy, _ = rnd((rows, N), f"c{i}.dy", dt); x, _ = rnd((rows, K), f"c{i}.x", dt)
-        dyc, _ = rnd((rows_c, N), f"c{i}.dyc", dt); xc, _ = rnd((rows_c, K), f"c{i}.xc", dt)
-        return dy, x, dyc, xc
-    ops_in = [operands(i, *sh[:4]) for i, sh in enumerate(shapes)]
-    def grads():
-        out = []
-        for i, (rows, rows_c, N, K, shared) in enumerate(shapes):
-            w = det_tensor((N, K), f"c{i}.w0", 3).to(dev()); b = det_tensor((N,), f"c{i}.b0", 3).to(dev())
-            out.append((w, b, w if shared else torch.zeros_like(w), b if shared else torch.zeros_like(b)))
-        return out
-    def probs(i, G):
-        dy, x, dyc, xc = ops_in[i]
-        return [o.Prob(dy, x, G[i][0], bias_grad=G[i][1]), o.Prob(dyc, xc, G[i][2], bias_grad=G[i][3])]
-    ref = grads()
-    for i, (rows, rows_c, N, K, shared) in enumerate(shapes):
-        o.linear_dw(probs(i, ref), N, K)
-    got = grads()
-    need = max(int(lib.lmv_linear_dw_workspace_bytes(o._pack(probs(i, got)), 2, sh[2], sh[3], 1)) for i, sh in enumerate(shapes))
-    need = (need + 255) // 256 * 256
-    ws = torch.empty(2 * need, device=dev(), dtype=torch.uint8)
-    pending = []
-    for i, (rows, rows_c, N, K, shared) in enumerate(shapes):
-        half = ws[(i & 1) * need:(i & 1) * need + need]
-        pending = o.linear_dw_chain(probs(i, got), N, K, half, pending)
-    o.reduce_segments(pending)
-    torch.cuda.synchronize()
-    for i, (r, g) in enumerate(zip(ref, got)):
-        for a, b in zip(r, g):
-            assert torch.equal(a, b), (i, float((a - b).abs().max()))
-    # a pending region that overlaps the workspace of the call is refused
-    segs = o.linear_dw_chain(probs(0, got), shapes[0][2], shapes[0][3], ws[:need], [])
-    with pytest.raises(RuntimeError):
-        o.linear_dw_chain(probs(1, got), shapes[1][2], shapes[1][3], ws[:need], segs)
-    o.reduce_segments(segs)
-
-
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("rows,rows_c,N,K", [(3000, 48, 384, 1536), (1000, 16, 512, 2048), (777, 0, 256, 768), (129, 0, 1000, 1024)])
 def test_linear_fwd_dx_bigk(dtype, rows, rows_c, N, K):

@@ -184,3 +184,135 @@ def test_stage_layernorm_large_mean_small_variance(kernel):
         assert frac == 0.0, (what, frac, worst)
 
     check(xo, xr, "x"); check(co, cr, "c")
+
+
+# ------------------------------------------------------------------------------------------------------------------------------------------------------
+# The "D" blocks (csrc/dstage.hip; VERDICT round 5, weak #4: "dstage's extra sources have no budget").  Beyond the S-block sources the kernel
+#   * never computes the image tokens' keys: the meta queries are pushed through the k rows of qkv1 -- q~ = bf16(bf16(q2 s_c log2 e) W_k1[h]) -- and the c-direction scores are
+#     q~ . bf16(norm1(x)) (the key bias shifts every score of a query by the same amount and drops out of the softmax)            -> source "qfold";
+#   * runs the c-direction softmax PER WORKGROUP of 112 keys (local maximum, exp2, fp16 P and V, fp32 partial sums) and lets the meta workgroup combine the partials by
+#     log-sum-exp in fp32                                                                                                          -> source "split";
+#   * rounds q1 (scaled by s_x log2 e) and k2 of the x-direction to bf16, P and V2 to fp16                                          -> sources "qk", "pv16".
+D_SOURCES = ("operands", "qk", "qfold", "split", "pv16", "gelu", "dwconv")
+D_BUDGET = {"operands": 4.5e-3, "qk": 2.0e-3, "qfold": 2.5e-3, "split": 2.0e-4, "pv16": 1.0e-3, "gelu": 2.0e-4, "dwconv": 3.0e-3, "total": 5.0e-3}
+
+
+def _emulated_dblock(sd, x, c, on, Gd, tok_per_wg):
+    p = "blk."
+    B, N, C = x.shape
+    Mm = c.shape[1]
+    h = C // 32
+    r_op = _bf16 if "operands" in on else (lambda t: t)
+    if "dwconv" in on:
+        xi = _bf16(x).transpose(1, 2).reshape(B, C, Gd, Gd)
+        y = torch.nn.functional.conv2d(xi, _bf16(sd[p + "pos_embed.weight"]), sd[p + "pos_embed.bias"], stride=1, padding=1, groups=C)
+        x = x + y.reshape(B, C, N).transpose(1, 2)
+    else:
+        x = O.pos_embed_residual(sd, p, x, Gd, Gd)
+    sx, sc = O.dca_scales(N, Mm, C)
+    LOG2E = 1.4426950408889634
+    nx = r_op(O.layer_norm(x, sd[p + "norm1.weight"], sd[p + "norm1.bias"], O.BLOCK_LN_EPS))
+    nc = r_op(O.layer_norm(c, sd[p + "norm1.weight"], sd[p + "norm1.bias"], O.BLOCK_LN_EPS))
+    W1, b1, W2, b2 = sd[p + "attn.qkv1.weight"], sd[p + "attn.qkv1.bias"], sd[p + "attn.qkv2.weight"], sd[p + "attn.qkv2.bias"]
+    q1, k1, v1 = O.split_heads(O.linear(nx, W1, b1), 3, h)          # [B, h, N, 32]
+    q2, k2, v2 = O.split_heads(O.linear(nc, W2, b2), 3, h)          # [B, h, M, 32]
+    # ---- x-direction: every image token against the 16 meta keys ----
+    if "qk" in on:
+        q1 = _bf16(q1 * (sx * LOG2E)) / (sx * LOG2E)
+        k2 = _bf16(k2)
+    s = (q1 @ k2.transpose(-1, -2)) * sx
+    s = s - s.amax(dim=-1, keepdim=True)
+    pr = torch.exp(s)
+    den = pr.sum(dim=-1, keepdim=True)                               # (the kernel sums the UNROUNDED exponentials)
+    if "pv16" in on:
+        pr, v2u = _f16_rtz(pr), _f16_rtz(v2)
+    else:
+        v2u = v2
+    ax = r_op(O.merge_heads((pr @ v2u) / den))
+    # ---- c-direction: the 16 meta queries against all image keys ----
+    if "qfold" in on:
+        Wk = W1[C:2 * C].reshape(h, 32, C)                           # k rows of qkv1 per head: [h, 32, C]
+        q2s = _bf16(q2 * (sc * LOG2E))                               # [B, h, M, 32], as the meta workgroup leaves it in LDS
+        qt = _bf16(torch.einsum("bhmd,hdc->bhmc", q2s, Wk))          # q~ [B, h, M, C]
+        s2 = torch.einsum("bhmc,bnc->bhmn", qt, nx) / LOG2E          # natural-log scores (+ a per-query constant that the softmax does not see)
+    else:
+        s2 = (q2 @ k1.transpose(-1, -2)) * sc
+    v1nb = v1 - b1[2 * C:].reshape(1, h, 1, 32)                      # the kernel multiplies P with the bias-free v1 and adds the bias once behind the combine (sum p = 1)
+    if "split" in on or "pv16" in on:
+        groups = range(0, N, tok_per_wg if "split" in on else N)
+        Mx = torch.full(s2.shape[:-1] + (1,), -float("inf"), dtype=s2.dtype)
+        parts = []
+        for g0 in groups:
+            g1 = min(N, g0 + (tok_per_wg if "split" in on else N))
+            sg = s2[..., g0:g1]
+            mg = sg.amax(dim=-1, keepdim=True)
+            e = torch.exp(sg - mg)
+            lg = e.sum(dim=-1, keepdim=True)
+            vg = v1nb[..., g0:g1, :]
+            if "pv16" in on:
+                e, vg = _f16_rtz(e), _f16_rtz(vg)
+            og = (e @ vg).float().double() if "split" in on else e @ vg          # fp32 partial sums travel to the meta workgroup
+            parts.append((mg, lg.float().double() if "split" in on else lg, og))
+            Mx = torch.maximum(Mx, mg)
+        L = sum(lg * torch.exp(mg - Mx) for mg, lg, og in parts)
+        Oc = sum(og * torch.exp(mg - Mx) for mg, lg, og in parts)
+        ac = Oc / L + b1[2 * C:].reshape(1, h, 1, 32)
+    else:
+        s2 = s2 - s2.amax(dim=-1, keepdim=True)
+        p2 = torch.exp(s2)
+        ac = (p2 @ v1) / p2.sum(dim=-1, keepdim=True)
+    ac = r_op(O.merge_heads(ac))
+    x = x + O.linear(ax, sd[p + "attn.proj_x.weight"], sd[p + "attn.proj_x.bias"])
+    c = c + O.linear(ac, sd[p + "attn.proj_c.weight"], sd[p + "attn.proj_c.bias"])
+
+    def mlp(t):
+        n = r_op(O.layer_norm(t, sd[p + "norm2.weight"], sd[p + "norm2.bias"], O.BLOCK_LN_EPS))
+        u = O.linear(n, sd[p + "mlp.0.weight"], sd[p + "mlp.0.bias"])
+        hdn = _gelu_poly(u) if "gelu" in on else O.gelu_erf(u)
+        return O.linear(r_op(hdn), sd[p + "mlp.3.weight"], sd[p + "mlp.3.bias"])
+
+    return x + mlp(x), c + mlp(c)
+
+
+@pytest.mark.parametrize("C,Gd,nblocks,B", [(192, 28, 1, 2), (192, 28, 3, 2), (96, 56, 2, 1)])
+def test_dstage_parity_budget(C, Gd, nblocks, B):
+    """The D-block restated in float64 with one switch per approximation of csrc/dstage.hip: every share against its own budget, the kernel's total (beyond its bf16 store) against
+    its budget and against 1.3 x the root-sum-square of the shares -- an unlisted error source lifts the total above what the listed ones explain."""
+    import test_dstage_gpu as D
+    from lemevit_amd import ops
+    sds = D._stage_params(nblocks, 5, C)
+    P = D._pack(sds)
+    x, c = D._inputs(B, 3, C, Gd)
+    xo, co = ops.dstage_fwd(x.to(DEV), c.to(DEV), P, Gd, Gd, 1e-6)
+    torch.cuda.synchronize()
+
+    def run(on):
+        xx, cc = x.double(), c.double()
+        for sd in sds:
+            xx, cc = _emulated_dblock({k: v.double() for k, v in sd.items()}, xx, cc, on, Gd, 112)
+        return xx, cc
+
+    exact = run(set())
+    ref = D._oracle(sds, x.float(), c.float(), Gd)
+    assert max(_rel(exact[0], ref[0]), _rel(exact[1], ref[1])) < 1e-10          # the restatement with every switch off IS the pinned oracle
+    err = lambda a, b: max(_rel(a[0], b[0]), _rel(a[1], b[1]))
+    out = (xo.float().cpu(), co.float().cpu())
+
+    def beyond_store_rounding(o, r):
+        worst = 0.0
+        for a, b in zip(o, r):
+            a, b = a.double(), b.double()
+            half = torch.exp2(torch.floor(torch.log2(b.abs().clamp_min(1e-30))) - 8)
+            worst = max(worst, float(((a - b).abs() - half).clamp_min(0).max() / b.abs().max()))
+        return worst
+
+    table = {"total": beyond_store_rounding(out, exact), "unexplained": beyond_store_rounding(out, run(set(D_SOURCES)))}
+    for s in D_SOURCES:
+        table[s] = err(run({s}), exact)
+    print(f"dstage parity budget, C = {C}, {nblocks} block(s): " + "  ".join(f"{k} {v:.2e}" for k, v in table.items()))
+    for k, v in table.items():
+        if k in D_BUDGET:
+            assert v <= D_BUDGET[k], (k, v, D_BUDGET[k])
+    rss = math.sqrt(sum(table[s] ** 2 for s in D_SOURCES))
+    print(f"  root-sum-square of the shares {rss:.2e}; total / rss = {table['total'] / rss:.2f}")
+    assert table["total"] <= 1.3 * rss, (table["total"], rss)

@@ -125,6 +125,17 @@ def test_sstage_vs_per_launch_schedule_full_size(C, nblocks, B):
     ex, ec = _rel(xo.float(), xr.float()), _rel(co.float(), cr.float())
     print(f"sstage vs per-launch schedule, C = {C}, {nblocks} blocks, B = {B}: x {ex:.2e} c {ec:.2e}")
     assert ex <= 3e-2 and ec <= 3e-2, (ex, ec)
+    # ... and against the pinned float64 ORACLE on four images of the full-size launch (the comparison above is a self-comparison): the first and the
+    # last image, and two whose workgroup pair takes tickets of different XCD counters (images i and i + 8 k share a counter; 9 and B / 2 + 3 do not).  The images of a batch are
+    # independent in eval mode, so the oracle runs on the four alone.  Bound: one block holds 6e-3 (test_sstage_vs_oracle); 8 / 18 blocks deep the fp32 residual stream has
+    # taken the bf16 operand roundings of 8 / 18 blocks (root-sum-square growth), measured 0.8 - 1.1e-2 on MI355X -- asserted at 1.5e-2, with the per-launch bf16 schedule of
+    # the same weights printed next to it (2.1e-2: it rounds the stream itself after every block).
+    idx = sorted({0, 9 % B, (B // 2 + 3) % B, B - 1})
+    xo_, co_ = _oracle(sds, x[idx].float().cpu(), c[idx].float().cpu())
+    es, ecs = _rel(xo[idx].float(), xo_), _rel(co[idx].float(), co_)
+    el = _rel(xr[idx].float(), xo_)
+    print(f"sstage vs the float64 oracle, images {idx} of the B = {B} launch, {nblocks} blocks: x {es:.2e} c {ecs:.2e} (per-launch schedule: x {el:.2e})")
+    assert es <= 1.5e-2 and ecs <= 1.5e-2, (es, ecs)
 
 
 @pytest.mark.parametrize("C,nblocks,B", [(384, 6, 128), (192, 8, 256)])

@@ -39,3 +39,4 @@ with open("$OUT", "w") as f:
 print(open("$OUT").read()[:4000])
 PY
 rm -rf $W
+python bench.py --print-csrc-hash > $OUT.csrc_hash

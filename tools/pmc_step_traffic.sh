@@ -34,6 +34,7 @@ fetch, write = res["FETCH_SIZE"]["kb_per_step"] * 1024 * 2, res["WRITE_SIZE"]["k
 out = dict(command="bench.py --graph 0 " + " ".join(args), fetch_bytes_per_step_corrected_x2=fetch, write_bytes_per_step=write, hbm_mb_per_step=(fetch + write) / 1e6,
            hbm_mb_per_image=(fetch + write) / 1e6 / batch, launches_per_step=res["FETCH_SIZE"]["launches_per_step"],
            top_fetch_mb_uncorrected=res["FETCH_SIZE"]["top"], top_write_mb=res["WRITE_SIZE"]["top"])
+out["csrc_hash"] = "$(python bench.py --print-csrc-hash)"
 json.dump(out, open(sys.argv[1], "w"), indent=1)
 print(json.dumps({k: out[k] for k in ("command", "hbm_mb_per_step", "hbm_mb_per_image", "launches_per_step")}))
 PY

@@ -27,6 +27,7 @@ fetch = 2.0 * res["FETCH_SIZE"]["avg_kb"] * 1024; write = res["WRITE_SIZE"]["avg
 out = {"kernel": "gemm_kernel<bf16, TR, TR, split-K> (weight-gradient GEMM) launches of bench.py's train step" if which == "dw" else "forward-form Linear launches (gemm_kernel<bf16,NT>, rs_gemm_kernel, wn_gemm_kernel) of bench.py's train step (native block schedule: forward layers, and the dX launches that run as forward-form GEMMs on transposed weights)", "launches_averaged": res["FETCH_SIZE"]["launches"],
        "fetch_bytes_per_launch_corrected_x2": fetch, "write_bytes_per_launch": write, "traffic_bytes_per_launch": fetch + write,
        "avg_launch_us_under_pmc": res["FETCH_SIZE"]["avg_us"], "raw": res}
+out["csrc_hash"] = "$(python bench.py --print-csrc-hash)"
 json.dump(out, open("$OUT", "w"), indent=1); print(json.dumps(out))
 PY
 rm -rf $W

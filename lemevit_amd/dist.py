@@ -206,13 +206,18 @@ class FlatGradSync:
                 bufs = [b for b in model.buffers() if pick(b)]
                 if not bufs:
                     continue
-                flat = torch.cat([b.reshape(-1).to(dt) for b in bufs])
+                flat = torch.cat([b.reshape(-1).to(dt) for b in bufs])          # (one launch; .to() is a no-op for fp32 / int64 buffers)
                 dist.broadcast(flat, src, group=self.group)
-                off = 0
+                views, off = [], 0
                 for b in bufs:
                     n = b.numel()
-                    b.copy_(flat[off:off + n].view(b.shape))
+                    views.append(flat[off:off + n].view(b.shape))
                     off += n
+                if all(b.dtype == dt for b in bufs):
+                    torch._foreach_copy_(bufs, views)                            # one launch for all of them (12 BatchNorm statistics tensors + 6 counters for LeMeViT)
+                else:
+                    for b, v in zip(bufs, views):
+                        b.copy_(v)
 
 
 def attach_flat_grad_sync(model: torch.nn.Module, opt, nchunks: int = 4, group=None, src: int = 0, force: bool = False,

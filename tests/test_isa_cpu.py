@@ -25,8 +25,8 @@ def _hazard(line: str) -> bool:
 
 def _asm(src: str, tmp_path) -> str:
     out = str(tmp_path / (src + ".s"))
-    # the flags of csrc/Makefile for these two files (-fno-honor-nans included: it changes the code the vectoriser sees)
-    cmd = [HIPCC, "-O3", "-std=c++17", "--offload-arch=gfx950", "-munsafe-fp-atomics", "-fno-honor-nans", "--cuda-device-only", "-S", os.path.join(CSRC, src), "-o", out]
+    # the flags of csrc/Makefile for these two files
+    cmd = [HIPCC, "-O3", "-std=c++17", "--offload-arch=gfx950", "-munsafe-fp-atomics", "-fno-honor-nans", "-fno-slp-vectorize", "--cuda-device-only", "-S", os.path.join(CSRC, src), "-o", out]
     subprocess.run(cmd, check=True, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
     with open(out) as f:
         return f.read()

@@ -609,12 +609,17 @@ __global__ __launch_bounds__(64 * NW, 2) void sstage_kernel(const SsArgs a) {
       SS_PHASE
       // 24 (head, query-tile group) units, three per wave: both groups of head `wave`, and one group of head 8 + (wave & 3) -- whose q fragments
       // wave (wave & 3) left in LDS: waves 0..3 take its tiles 0..3, waves 4..7 its tiles 4..6 (11 / 10 query tiles per wave)
+      // (round 6, the 8-wave instance: the whole extra head on waves 0 .. 3 -- 14 / 7 query tiles per wave instead of 11 / 10.  The second wave of a SIMD loses the issue arbitration of
+      //  this VALU-bound phase: with 11 / 10 waves 0-3 finished in 27 k cycles and idled 12.7 k at the barrier while waves 4-7 took 38 k; now 34 k / 31 k, attention + barrier 40.3 k -> 36.9 k.
+      //  The 4-wave instance -- two workgroups per CU -- measured 1 % slower with it and keeps 11 / 10.)
+      constexpr bool SS_UNITS_14_7 = NW == 8;
+      const int nunits = SS_UNITS_14_7 ? (wave < NW / 2 ? 4 : 2) : 3;
 #pragma unroll 1
-      for (int u = 0; u < 3; ++u) {
-        const bool third = u == 2;
+      for (int u = 0; u < nunits; ++u) {
+        const bool third = u >= 2;
         const int h = third ? NW + (wave & (NW / 2 - 1)) : wave;
-        const bool groupb = third ? wave >= NW / 2 : u == 1;
-        if (third) {
+        const bool groupb = SS_UNITS_14_7 ? (u & 1) : (third ? wave >= NW / 2 : u == 1);
+        if (u == 2) {
 #pragma unroll
           for (int t = 0; t < SS_NT; ++t) Qf[t] = *reinterpret_cast<const bf16x8_t*>(smem + L_H + (((wave & (NW / 2 - 1)) * SS_NT + t) * 64 + lane) * 16);
         }
